@@ -1,0 +1,48 @@
+"""Access to tests/golden/ fixtures (produced by tools/make_golden.py from the compiled reference)."""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+CASES = MANIFEST["cases"]
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def gz(name):
+    return gzip.open(os.path.join(GOLD, name), "rb").read()
+
+
+def case_rows(name):
+    """(n, c+1) uint8 text-layout rows of a fixture's input (QGEN-1 inputs are regenerated)."""
+    e = CASES[name]
+    spec = e["input"]
+    if spec["kind"] == "qgen1":
+        rows = O.qgen1_rows(spec["seed"], spec["n"], spec["c"])
+    else:
+        rows = O.rows_from_text(gz(name + ".in.gz"), spec["c"])
+    assert md5(rows.tobytes()) == e["input_md5"], f"{name}: input md5 mismatch"
+    return rows
+
+
+def case_opts(name):
+    """Reference CLI flags of a fixture -> dict(k, mode, ratio, dist)."""
+    fl = CASES[name]["flags"].split()
+    k = int(fl[fl.index("-c") + 1])
+    if "-f" in fl:
+        mode, ratio = O.MODE_RATIO, float(fl[fl.index("-f") + 1])
+    else:
+        mode, ratio = O.MODE_FIXED, float(fl[fl.index("-r") + 1])
+    return dict(k=k, mode=mode, ratio=ratio, dist=fl[fl.index("-d") + 1])
+
+
+def phase(name):
+    return np.load(os.path.join(GOLD, name + ".phase.npz"))

@@ -1,0 +1,70 @@
+"""Pins the CPU oracle (oracle/qvz_oracle.c) against the reference's own outputs (tests/golden/)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+FAST = [n for n, e in G.CASES.items() if e["input"]["n"] * e["input"]["c"] <= 120000]
+SLOW = [n for n in G.CASES if n not in FAST]
+
+
+@pytest.mark.parametrize("name", FAST + SLOW)
+def test_encode_byte_identical(name):
+    e = G.CASES[name]
+    rows = G.case_rows(name)
+    r = O.encode(rows, **G.case_opts(name))
+    assert len(r["q"]) == e["q_size"]
+    assert G.md5(r["q"]) == e["q_md5"], ".q differs from the reference"
+    assert G.md5(r["u"]) == e["u_md5"], "-u differs from the reference"
+    assert r["size"] == e["size"]
+    assert f"{r['rate']:.4f}" == f"{e['rate']:.4f}"
+    assert f"{r['distortion']:.4f}" == f"{e['distortion']:.4f}"
+    if e["stored"]:
+        assert r["q"] == G.gz(name + ".q.gz")
+        assert r["u"] == G.gz(name + ".u.gz")
+
+
+@pytest.mark.parametrize("name", [n for n, e in G.CASES.items() if e["stored"]])
+def test_decode_matches_u(name):
+    """The invariant the reference's own test.sh checks: decode(encode(x)) == the -u dump."""
+    assert O.decode(G.gz(name + ".q.gz")) == G.gz(name + ".u.gz")
+
+
+@pytest.mark.parametrize("name", [n for n, e in G.CASES.items() if e["phase"]])
+def test_phase_intermediates(name):
+    ph = G.phase(name)
+    rows = G.case_rows(name)
+    k = G.case_opts(name)["k"]
+    labels, means, counts, iters = O.kmeans(rows, k)
+    assert iters > 0
+    np.testing.assert_array_equal(labels, ph["labels"])
+    np.testing.assert_array_equal(means, ph["means"])
+    np.testing.assert_array_equal(counts, ph["counts"])
+    cnt = O.stats(rows, labels, k)
+    np.testing.assert_array_equal(cnt, ph["cnt"])
+    for j in range(k):
+        m = O.marginals(cnt[j])
+        assert m.tobytes() == ph["marg"][j].tobytes(), "marginals not bit-identical"
+
+
+def test_well_known_answer():
+    import ctypes as C
+    kat = G.MANIFEST["well_kat"]
+
+    class W(C.Structure):
+        _fields_ = [("state", C.c_uint32 * 32), ("n", C.c_uint32), ("bit_output", C.c_uint32), ("bits_left", C.c_uint32)]
+
+    lib = O.lib()
+    lib.orc_well_word.restype = C.c_uint32
+    lib.orc_well_bits.restype = C.c_uint32
+    w = W()
+    for i in range(32):
+        w.state[i] = 0x55555555
+    words = [lib.orc_well_word(C.byref(w)) for _ in range(4)]
+    assert words == [int(x, 16) for x in kat["first_words"]]
+    w = W()
+    for i in range(32):
+        w.state[i] = 0x55555555
+    draws = [lib.orc_well_bits(C.byref(w), 7) for _ in range(12)]
+    assert draws == kat["first_draws"]

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ fixtures by RUNNING the unmodified reference (oracle/_ref, built in place from
+/root/reference by oracle/build_ref.sh). Only works in the build container (the reference does not travel);
+the fixtures it writes are data: inputs, expected outputs, md5s and the reference's own `-s` numbers.
+
+    python tools/make_golden.py            # regenerate everything
+
+Layout of tests/golden/:
+    manifest.json                    one entry per case (input recipe, flags, md5s, sizes, -s stats)
+    <case>.q.gz  <case>.u.gz         reference outputs for the cases with store=True
+    <case>.in.gz                     input text, only for inputs that are not QGEN-1
+    <case>.phase.npz                 labels / means / counts / PMF counters / marginals from ref_harness
+"""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402  (QGEN-1 generator only)
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def sm64(x):
+    x = (x + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    return x ^ (x >> 31)
+
+
+def input_rows(spec):
+    kind = spec["kind"]
+    n, c = spec["n"], spec["c"]
+    if kind == "qgen1":
+        return O.qgen1_rows(spec["seed"], n, c)
+    rows = np.zeros((n, c + 1), dtype=np.uint8)
+    rows[:, c] = 10
+    if kind == "const":                      # every symbol the same: zero-entropy contexts
+        rows[:, :c] = spec["q"] + 33
+    elif kind == "uniform":                  # full 72-symbol alphabet, splitmix64 counter stream
+        for i in range(n):
+            for j in range(c):
+                rows[i, j] = 33 + sm64(spec["seed"] * 1000003 + i * c + j) % 72
+    elif kind == "twolevel":                 # two far-apart read populations (k-means separable)
+        for i in range(n):
+            base = 5 if sm64(spec["seed"] + i) % 3 == 0 else 60
+            for j in range(c):
+                rows[i, j] = 33 + base + sm64(spec["seed"] * 7919 + i * c + j) % 6
+    else:
+        raise ValueError(kind)
+    return rows
+
+
+# flags are exactly the reference CLI's (src/main.c:208-303)
+CASES = [
+    # the three survey-verified tiny cases
+    dict(name="t2k_r10_M", inp=dict(kind="qgen1", seed=1, n=2000, c=30), flags="-c 1 -d M -r 1.0", store=True, phase=True),
+    dict(name="t2k_f05_L", inp=dict(kind="qgen1", seed=1, n=2000, c=30), flags="-c 1 -d L -f 0.5", store=True),
+    dict(name="t2k_c3_f05_M", inp=dict(kind="qgen1", seed=1, n=2000, c=30), flags="-c 3 -d M -f 0.5", store=True, phase=True),
+    # BASELINE.json configs[0] and the flag sets of configs[2], configs[3] at its shape
+    dict(name="cfg1_r10_M", inp=dict(kind="qgen1", seed=1, n=10000, c=100), flags="-c 1 -d M -r 1.0", store=True),
+    dict(name="cfg1_f05_L", inp=dict(kind="qgen1", seed=1, n=10000, c=100), flags="-c 1 -d L -f 0.5", store=False),
+    dict(name="cfg1_c3_r10_M", inp=dict(kind="qgen1", seed=1, n=10000, c=100), flags="-c 3 -d M -r 1.0", store=False, phase=True),
+    # edge cases
+    dict(name="const_f05", inp=dict(kind="const", q=40, n=300, c=12), flags="-c 1 -d M -f 0.5", store=True),
+    dict(name="const_r05", inp=dict(kind="const", q=40, n=300, c=12), flags="-c 1 -d M -r 0.5", store=True),
+    dict(name="uniform72_r20_A", inp=dict(kind="uniform", seed=5, n=1500, c=16), flags="-c 1 -d A -r 2.0", store=True),
+    dict(name="uniform72_f09_M", inp=dict(kind="uniform", seed=6, n=1200, c=10), flags="-c 1 -d M -f 0.9", store=True),
+    dict(name="c2_f08", inp=dict(kind="qgen1", seed=9, n=400, c=2), flags="-c 1 -d M -f 0.8", store=True),
+    dict(name="tiny5_r10", inp=dict(kind="qgen1", seed=11, n=5, c=7), flags="-c 1 -d L -r 1.0", store=True),
+    dict(name="twolevel_c2_f05", inp=dict(kind="twolevel", seed=3, n=900, c=20), flags="-c 2 -d M -f 0.5", store=True, phase=True),
+    dict(name="f00_zero_rate", inp=dict(kind="qgen1", seed=2, n=500, c=25), flags="-c 1 -d M -f 0.0", store=True),
+    dict(name="r35_high_rate", inp=dict(kind="qgen1", seed=2, n=800, c=25), flags="-c 1 -d M -r 3.5", store=True),
+    dict(name="wide_c151", inp=dict(kind="qgen1", seed=4, n=700, c=151), flags="-c 1 -d M -f 0.4", store=False),
+]
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def gz_write(path, data):
+    with open(path, "wb") as f:
+        with gzip.GzipFile(fileobj=f, mode="wb", mtime=0, compresslevel=9) as g:
+            g.write(data)
+
+
+def parse_phase(path):
+    raw = open(path, "rb").read()
+    n = int.from_bytes(raw[0:8], "little")
+    c = int.from_bytes(raw[8:12], "little")
+    k = int.from_bytes(raw[12:16], "little")
+    off = 16
+    labels = np.frombuffer(raw, np.uint8, n, off); off += n
+    means = np.frombuffer(raw, np.uint8, k * c, off).reshape(k, c); off += k * c
+    counts = np.frombuffer(raw, np.uint32, k, off); off += 4 * k
+    cnt = np.frombuffer(raw, np.uint32, k * c * 72 * 72, off).reshape(k, c, 72, 72); off += 4 * k * c * 72 * 72
+    marg = np.frombuffer(raw, np.float64, k * c * 72, off).reshape(k, c, 72)
+    return labels, means, counts, cnt, marg
+
+
+def main():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {"generator": "tools/make_golden.py", "reference_binary": "oracle/_ref/qvz_ref_fixedseed "
+                "(reference sources + -DLINUX -DDEBUG -O3: WELL state = 32 x 0x55555555)", "cases": {}}
+    with tempfile.TemporaryDirectory() as td:
+        for case in CASES:
+            name, spec = case["name"], case["inp"]
+            rows = input_rows(spec)
+            text = rows.tobytes()
+            inp = os.path.join(td, name + ".txt")
+            open(inp, "wb").write(text)
+            q, u = os.path.join(td, name + ".q"), os.path.join(td, name + ".u")
+            out = subprocess.run([os.path.join(REF, "qvz_ref_fixedseed")] + case["flags"].split() +
+                                 ["-s", "-u", u, inp, q], check=True, capture_output=True, text=True).stdout
+            dec = os.path.join(td, name + ".dec")
+            subprocess.run([os.path.join(REF, "qvz_ref_fixedseed"), "-x", q, dec], check=True, capture_output=True)
+            qb, ub, db = open(q, "rb").read(), open(u, "rb").read(), open(dec, "rb").read()
+            assert db == ub, f"{name}: reference decode != -u"
+            sline = [ln for ln in out.splitlines() if ln.startswith("rate,")][0].split(",")
+            entry = dict(input=spec, flags=case["flags"], input_md5=md5(text), q_md5=md5(qb), u_md5=md5(ub),
+                         q_size=len(qb), rate=float(sline[1]), distortion=float(sline[3]), size=int(sline[7]),
+                         stored=bool(case.get("store")), phase=bool(case.get("phase")))
+            if spec["kind"] != "qgen1":
+                gz_write(os.path.join(GOLD, name + ".in.gz"), text)
+            if case.get("store"):
+                gz_write(os.path.join(GOLD, name + ".q.gz"), qb)
+                gz_write(os.path.join(GOLD, name + ".u.gz"), ub)
+            if case.get("phase"):
+                fl = case["flags"].split()
+                k = fl[fl.index("-c") + 1]
+                mode, ratio = ("f", fl[fl.index("-f") + 1]) if "-f" in fl else ("r", fl[fl.index("-r") + 1])
+                dist = fl[fl.index("-d") + 1]
+                pb = os.path.join(td, name + ".bin")
+                subprocess.run([os.path.join(REF, "ref_harness"), inp, k, mode, ratio, dist, pb], check=True,
+                               capture_output=True)
+                labels, means, counts, cnt, marg = parse_phase(pb)
+                np.savez_compressed(os.path.join(GOLD, name + ".phase.npz"), labels=labels, means=means,
+                                    counts=counts, cnt=cnt, marg=marg)
+            manifest["cases"][name] = entry
+            print(f"{name:18s} q={len(qb):8d} rate={entry['rate']:.4f} dist={entry['distortion']:.4f} "
+                  f"size={entry['size']}")
+    # WELL known-answer vector from the reference's own well.c (state 32 x 0x55555555)
+    manifest["well_kat"] = dict(state="32 x 0x55555555", first_words=["0x82fd4280", "0x815ebfd5", "0x5303e800", "0x2e7c4815"],
+                                first_draws=[0, 5, 117, 23, 85, 127, 122, 10, 0, 80, 15, 24],
+                                source="SURVEY.md section 8c (checked against compiled reference well.c)")
+    json.dump(manifest, open(os.path.join(GOLD, "manifest.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
