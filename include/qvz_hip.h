@@ -1,0 +1,130 @@
+/* qvz_hip.h - C-ABI of the MI355X (gfx950) implementation of qvz's encode hot path.
+ *
+ * Plain C: pointers, sizes, int return codes. No C++ or torch types cross this boundary.
+ * The reference (mikelhernaez/qvz) has no FFI: its seam is the seven calls encode() makes
+ * (reference src/main.c:42-91). Each entry point below names the reference function(s) it replaces.
+ * The host-side mirror that keeps the reference's own names and struct-based signatures
+ * (do_kmeans_clustering, calculate_statistics, generate_codebooks, start_qv_compression ...) is
+ * declared in qvz_compat.h and is a thin C layer over this file.
+ *
+ * Conventions
+ *  - "d_" pointers are device (HBM) pointers, "h_" pointers are host pointers.
+ *  - stream: a hipStream_t passed as void* (NULL = default stream). Calls are asynchronous on that
+ *    stream unless they return host-visible results.
+ *  - Symbol matrix layout (the one layout every kernel is written for): column-major, offset removed:
+ *        d_sym[s * ld + i] = byte(read i, column s) - 33   in [0,72)
+ *    ld = qvz_hip_ld(n): n rounded up to a multiple of 256, so every column starts 256-byte aligned and
+ *    16-byte vector loads never straddle a column. Entries i >= n inside the padding are ignored.
+ *  - Alphabet is fixed at 72 (reference src/main.c:13, include/pmf.h:11).
+ *  - Return value 0 = success; negative = QVZ_E_*; qvz_hip_last_error() gives the message.
+ */
+#ifndef QVZ_HIP_H
+#define QVZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QVZ_A 72
+#define QVZ_NOT_FOUND 0xFF
+
+#define QVZ_OK 0
+#define QVZ_E_ARG (-1)       /* bad argument (shape, alignment, range)                          */
+#define QVZ_E_HIP (-2)       /* HIP runtime error                                               */
+#define QVZ_E_DATA (-3)      /* input bytes outside [33,105) or missing '\n' (reference: UB)    */
+#define QVZ_E_EMPTY (-4)     /* a k-means cluster went empty (reference: SIGFPE, cluster.c:113) */
+#define QVZ_E_DEAD_CTX (-5)  /* quantizer met a context the codebook does not define            */
+#define QVZ_E_NOMEM (-6)
+
+#define QVZ_MODE_RATIO 0     /* -f, reference include/codebook.h:21 */
+#define QVZ_MODE_FIXED 1     /* -r, reference include/codebook.h:22 */
+#define QVZ_DIST_MANHATTAN 1 /* reference include/distortion.h:7-9 */
+#define QVZ_DIST_MSE 2
+#define QVZ_DIST_LORENTZ 3
+
+const char *qvz_hip_last_error(void);
+uint64_t qvz_hip_ld(uint64_t n);
+int qvz_hip_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Input staging. Replaces the row-major pointer view built by load_file (reference
+ * src/lines.c:27-82: C from the first line, N = size/(C+1), one line_t per read).
+ * ------------------------------------------------------------------------------------------- */
+/* d_text: n rows of c+1 bytes (Q+33 ... '\n') already in HBM. Writes d_sym (c columns x ld).
+ * d_bad (1 x u32, zeroed by the caller): number of bytes outside [33,105) or rows not ending '\n'. */
+int qvz_hip_transpose_text(const uint8_t *d_text, uint64_t n, uint32_t c, uint8_t *d_sym, uint64_t ld,
+                           uint32_t *d_bad, void *stream);
+/* Inverse, for the "-u" dump (reference src/qv_compressor.c:100-125): quantized symbols -> text rows. */
+int qvz_hip_untranspose_text(const uint8_t *d_qv, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text,
+                             void *stream);
+/* QGEN-1 synthetic reads [first, first+n) generated directly in d_sym layout. */
+int qvz_hip_qgen1(uint64_t seed, uint64_t first, uint64_t n, uint32_t c, uint8_t *d_sym, uint64_t ld,
+                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * k-means. Replaces do_kmeans_clustering and helpers (reference src/cluster.c:65-244).
+ * Means are SYMBOLS (byte-33); the reference keeps raw bytes, distances and floor-means are the same.
+ * ------------------------------------------------------------------------------------------- */
+/* cluster_lines/do_cluster_assignment/find_distance/assign_cluster (cluster.c:65,136,176,149):
+ * d_labels[i] = lowest j minimising sum_s (x_s - mean_j,s)^2; d_counts[j] += reads labelled j. */
+int qvz_hip_kmeans_assign(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint32_t k,
+                          const uint8_t *d_means /*[k][c]*/, uint8_t *d_labels /*[ld]*/,
+                          uint32_t *d_counts /*[k], +=*/, void *stream);
+/* first pass of recalculate_means (cluster.c:92-101): d_acc[j][s] += sum of symbols of reads labelled j */
+int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c,
+                              uint64_t ld, uint32_t k, uint64_t *d_acc /*[k][c], +=*/, void *stream);
+/* second pass of recalculate_means (cluster.c:104-128): mean = acc/count (floor), moved_j = sum (dmean)^2.
+ * d_moved[0] = max_j moved_j (double, exact integer). d_status[0] |= 1 if a cluster is empty. */
+int qvz_hip_kmeans_update(const uint64_t *d_acc, const uint32_t *d_counts, uint32_t k, uint32_t c,
+                          uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conditional-PMF counters. Replaces the counting loop of calculate_statistics
+ * (reference src/codebook.c:193-205, pmf_increment src/pmf.c:211-214).
+ * d_cnt[((j*c + s)*72 + prev)*72 + cur] += 1 for every read labelled j (column 0: prev = 0).
+ * d_labels may be NULL when k == 1. Counters are u32 (reference pmf.h:35-36) => n < 2^32.
+ * ------------------------------------------------------------------------------------------- */
+int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
+                     uint32_t k, uint32_t *d_cnt, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * WELL-1024a draws. Replaces well_1024a / well_1024a_bits (reference src/well.c:8-46) for the
+ * quantizer: draw g (global index i*C+s) = (word[g>>2] >> 7*(g&3)) & 127.
+ * Writes words [first_word, first_word+nwords) of the stream seeded with h_state (32 words as stored
+ * in the .q file, n = 0) to d_words. Uses GF(2) jump-ahead so any range can be produced in parallel.
+ * ------------------------------------------------------------------------------------------- */
+int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
+                       void *stream);
+/* State of the generator after `words` outputs, rotated to n = 0 (what a shard's .q header stores). */
+int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32_t *h_state_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Quantizer tables in device form (one per cluster), built from a codebook (see qvz_codebook.h).
+ *   ct[s][72]      u16 : low byte = context index of previous quantized value (QVZ_NOT_FOUND if none),
+ *                        high byte = qratio of that context           (choose_quantizer codebook.c:162-171)
+ *   qs[s][144][72] u16 : low byte = quantized value q[2ctx+b][x], high byte = its state index in that
+ *                        quantizer's output alphabet                  (qv_compressor.c:93-95,109-110)
+ * ------------------------------------------------------------------------------------------- */
+#define QVZ_CT_STRIDE 72
+#define QVZ_QS_STRIDE (144 * 72)
+
+/* Replaces the quantize half of start_qv_compression (reference src/qv_compressor.c:76-135).
+ * d_ct / d_qs: k tables back to back ([k][c][72] and [k][c][144][72] u16).
+ * d_words: WELL words covering draws [first_draw, first_draw + n*c); d_words[0] holds draw
+ *          (first_draw & ~3). first_draw = (global index of read 0 of this call) * c.
+ * h_dist: 72x72 doubles d[x + 72*y] (reference distortion.c:151).
+ * Outputs (each may be NULL): d_qv / d_qi / d_st column-major like d_sym: quantized value, quantizer
+ * index 2*ctx+b and state index per symbol; d_err[i] = per-read sum of d(x,qv) accumulated in column
+ * order exactly as the reference does (bit-identical double); d_status |= QVZ_E_DEAD_CTX flags. */
+int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
+                     uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint32_t *d_words,
+                     uint64_t first_draw, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi,
+                     uint8_t *d_st, double *d_err, int32_t *d_status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+"""Loader for the in-tree native library (qvz_amd/libqvzhip.so, built by `make` / __graft_entry__.build()).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the kernels raises. The
+Python layer is plumbing only (device memory via torch, stream handles, torch.distributed); every computation
+on the encode path runs in the hand-written HIP kernels behind the C-ABI of include/qvz_hip.h.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libqvzhip.so")
+
+u8p, u16p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as integers
+f64p = C.c_void_p
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/qvz_hip.h
+SIGNATURES = {
+    "qvz_hip_last_error": (C.c_char_p, []),
+    "qvz_hip_ld": (C.c_uint64, [C.c_uint64]),
+    "qvz_hip_device_count": (C.c_int, []),
+    "qvz_hip_transpose_text": (C.c_int, [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, u32p, C.c_void_p]),
+    "qvz_hip_untranspose_text": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u8p, C.c_void_p]),
+    "qvz_hip_qgen1": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.c_void_p]),
+    "qvz_hip_kmeans_assign": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u8p, u8p, u32p,
+                                        C.c_void_p]),
+    "qvz_hip_kmeans_accumulate": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u64p,
+                                            C.c_void_p]),
+    "qvz_hip_kmeans_update": (C.c_int, [u64p, u32p, C.c_uint32, C.c_uint32, u8p, f64p, C.c_void_p, C.c_void_p]),
+    "qvz_hip_pmf_hist": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_void_p]),
+    "qvz_hip_well_words": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, u32p, C.c_void_p]),
+    "qvz_hip_well_jump": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]),
+    "qvz_hip_quantize": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u16p, u16p, u32p,
+                                   C.c_uint64, f64p, u8p, u8p, u8p, f64p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class QvzHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C-ABI library. Raises (never falls back) when the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QvzHipError(f"{LIB_PATH} is missing: build it with `make` or __graft_entry__.build(); "
+                              "qvz_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise QvzHipError(f"qvz_hip error {rc}: {lib().qvz_hip_last_error().decode(errors='replace')}")

@@ -1,0 +1,815 @@
+// qvz_kernels.hip - gfx950 (MI355X / CDNA4) kernels for the N-dependent phases of qvz's encode path
+// and their C-ABI (include/qvz_hip.h). Written for wave64, 256 CUs / 8 XCDs, 160 KB LDS per CU.
+// Nothing here is a dense contraction: the budget is HBM bytes, LDS atomics and latency, not MFMA.
+//
+// Data layout: one column-major, offset-removed symbol matrix d_sym[s*ld + i] (see qvz_hip.h). Every
+// kernel streams columns with 4- or 16-byte per-lane accesses, so each wave instruction moves 256 B-1 KiB.
+//
+// Reference behaviour restated by each kernel is cited as file:line of mikelhernaez/qvz.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qvz_hip.h"
+#include "qvz_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+extern "C" const char *qvz_hip_last_error(void) { return g_err; }
+
+int qvz_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" uint64_t qvz_hip_ld(uint64_t n) { return (n + 255) & ~(uint64_t)255; }
+
+extern "C" int qvz_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline int check_matrix(uint64_t n, uint32_t c, uint64_t ld) {
+    if (n == 0 || c == 0) return qvz_set_error(QVZ_E_ARG, "empty matrix (n=%llu c=%u)", (unsigned long long)n, c);
+    if (ld < n || (ld & 255)) return qvz_set_error(QVZ_E_ARG, "ld=%llu must be a multiple of 256 and >= n=%llu",
+                                                    (unsigned long long)ld, (unsigned long long)n);
+    if (c > 1022) return qvz_set_error(QVZ_E_ARG, "c=%u exceeds MAX_READS_PER_LINE (reference lines.h:13)", c);
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// QGEN-1: counter-based synthetic reads straight into the column-major layout.
+// One thread produces 4 consecutive reads so that every column store is a full dword per lane.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t sm64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ int clamp_q(int v) { return v < 2 ? 2 : (v > 41 ? 41 : v); }
+
+__global__ __launch_bounds__(256) void k_qgen1(uint64_t seed, uint64_t first, uint64_t n4, uint32_t C,
+                                               uint8_t *__restrict__ D, uint64_t ld) {
+    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    uint64_t r[4];
+    int base[4], slope[4], q[4], tgt_acc[4], tgt_dec[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r[k] = sm64(seed * 0xD1342543DE82EF95ull + first + 4 * t + k);
+        unsigned cls = (unsigned)(r[k] % 10);
+        base[k] = cls < 6 ? 38 : (cls < 9 ? 30 : 20);
+        slope[k] = (int)((r[k] >> 8) % 13);
+        q[k] = base[k];
+        tgt_acc[k] = 0;   // slope*j mod C, kept incrementally
+        tgt_dec[k] = 0;   // floor(slope*j / C)
+    }
+    for (uint32_t j = 0; j < C; ++j) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint64_t h = sm64(r[k] + j + 1);
+            int target = base[k] - tgt_dec[k];
+            unsigned u = (unsigned)(h & 15);
+            int step = u < 6 ? 0 : (u < 10 ? 1 : (u < 14 ? -1 : (u == 14 ? -2 : 2)));
+            int pull = 0;
+            if (((h >> 4) & 3) == 0) pull = (target > q[k]) - (target < q[k]);
+            q[k] = clamp_q(q[k] + step + pull);
+            int drop = 0;
+            if (((h >> 6) & 63) == 0) drop = -(int)((h >> 12) % 20);
+            packed |= (uint32_t)clamp_q(q[k] + drop) << (8 * k);
+            tgt_acc[k] += slope[k];
+            while (tgt_acc[k] >= (int)C) { tgt_acc[k] -= (int)C; tgt_dec[k] += 1; }
+        }
+        *reinterpret_cast<uint32_t *>(D + (uint64_t)j * ld + 4 * t) = packed;
+    }
+}
+
+extern "C" int qvz_hip_qgen1(uint64_t seed, uint64_t first, uint64_t n, uint32_t c, uint8_t *d_sym, uint64_t ld,
+                             void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    uint64_t n4 = (n + 3) / 4;  // the last thread may write into the ld padding: allowed by contract
+    dim3 grid((unsigned)((n4 + 255) / 256));
+    hipLaunchKernelGGL(k_qgen1, grid, dim3(256), 0, (hipStream_t)stream, seed, first, n4, c, d_sym, ld);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// text rows <-> column-major symbols. Tile = 256 rows x 64 columns staged through LDS so that both the
+// row-major side (64 contiguous bytes per row) and the column-major side (dword per lane) are coalesced.
+// ------------------------------------------------------------------------------------------------
+#define TT_ROWS 256
+#define TT_COLS 64
+#define TT_PITCH (TT_ROWS + 4)  // +4: lanes walking columns hit distinct banks (260/4 = 65 = 1 mod 32)
+
+__global__ __launch_bounds__(256) void k_transpose_text(const uint8_t *__restrict__ text, uint64_t n, uint32_t C,
+                                                        uint8_t *__restrict__ D, uint64_t ld,
+                                                        uint32_t *__restrict__ bad) {
+    __shared__ uint8_t tile[TT_COLS * TT_PITCH];
+    const uint64_t row0 = (uint64_t)blockIdx.x * TT_ROWS;
+    const uint32_t col0 = blockIdx.y * TT_COLS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t stride = (uint64_t)C + 1;
+    uint32_t nbad = 0;
+    const uint32_t col = col0 + lane;
+    for (uint32_t rr = wave; rr < TT_ROWS; rr += 4) {
+        uint64_t row = row0 + rr;
+        uint8_t v = 0;
+        if (row < n && col < C) {
+            uint8_t b = text[row * stride + col];
+            if (b < 33 || b >= 33 + QVZ_A) { nbad++; b = 33; }
+            v = (uint8_t)(b - 33);
+        }
+        tile[lane * TT_PITCH + rr] = v;
+        if (row < n && col0 == 0 && lane == 0 && text[row * stride + C] != '\n') nbad++;
+    }
+    __syncthreads();
+    // 64 columns x 64 dwords of rows: thread -> (column = i / 64, dword = i % 64)
+    for (uint32_t i = threadIdx.x; i < TT_COLS * (TT_ROWS / 4); i += 256) {
+        uint32_t cc = i >> 6, dw = i & 63;
+        if (col0 + cc < C && row0 + 4 * dw < ld)
+            *reinterpret_cast<uint32_t *>(D + (uint64_t)(col0 + cc) * ld + row0 + 4 * dw) =
+                *reinterpret_cast<const uint32_t *>(&tile[cc * TT_PITCH + 4 * dw]);
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+__global__ __launch_bounds__(256) void k_untranspose_text(const uint8_t *__restrict__ Q, uint64_t n, uint32_t C,
+                                                          uint64_t ld, uint8_t *__restrict__ text) {
+    __shared__ uint8_t tile[TT_COLS * TT_PITCH];
+    const uint64_t row0 = (uint64_t)blockIdx.x * TT_ROWS;
+    const uint32_t col0 = blockIdx.y * TT_COLS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t stride = (uint64_t)C + 1;
+    for (uint32_t i = threadIdx.x; i < TT_COLS * (TT_ROWS / 4); i += 256) {
+        uint32_t cc = i >> 6, dw = i & 63;
+        uint32_t v = 0;
+        if (col0 + cc < C && row0 + 4 * dw < ld)
+            v = *reinterpret_cast<const uint32_t *>(Q + (uint64_t)(col0 + cc) * ld + row0 + 4 * dw);
+        *reinterpret_cast<uint32_t *>(&tile[cc * TT_PITCH + 4 * dw]) = v;
+    }
+    __syncthreads();
+    const uint32_t col = col0 + lane;
+    for (uint32_t rr = wave; rr < TT_ROWS; rr += 4) {
+        uint64_t row = row0 + rr;
+        if (row < n) {
+            if (col < C) text[row * stride + col] = (uint8_t)(tile[lane * TT_PITCH + rr] + 33);
+            if (col == C) text[row * stride + C] = '\n';   // lane just past the last column writes the newline
+        }
+    }
+}
+
+extern "C" int qvz_hip_transpose_text(const uint8_t *d_text, uint64_t n, uint32_t c, uint8_t *d_sym, uint64_t ld,
+                                      uint32_t *d_bad, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    dim3 grid((unsigned)((n + TT_ROWS - 1) / TT_ROWS), (c + TT_COLS - 1) / TT_COLS);
+    hipLaunchKernelGGL(k_transpose_text, grid, dim3(256), 0, (hipStream_t)stream, d_text, n, c, d_sym, ld, d_bad);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+extern "C" int qvz_hip_untranspose_text(const uint8_t *d_qv, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text,
+                                        void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    // one extra column slot so that some lane owns column index C (the '\n')
+    dim3 grid((unsigned)((n + TT_ROWS - 1) / TT_ROWS), (c + 1 + TT_COLS - 1) / TT_COLS);
+    hipLaunchKernelGGL(k_untranspose_text, grid, dim3(256), 0, (hipStream_t)stream, d_qv, n, c, ld, d_text);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-means (reference src/cluster.c). Integer-exact: distances fit u32 (c <= 1022, |diff| <= 71).
+// ------------------------------------------------------------------------------------------------
+// Assignment: one thread owns 4 consecutive reads (dword loads down the columns), K clusters per pass
+// with the centroids of the pass in LDS. Passes keep (best distance, best label) so that the lowest
+// cluster id wins ties exactly like the strict '<' scan of assign_cluster (cluster.c:155-163).
+#define KM_KPASS 8
+
+template <int K>
+__global__ __launch_bounds__(256) void k_kmeans_assign(const uint8_t *__restrict__ D, uint64_t n, uint32_t C,
+                                                       uint64_t ld, uint32_t k, const uint8_t *__restrict__ means,
+                                                       uint8_t *__restrict__ labels, uint32_t *__restrict__ counts) {
+    extern __shared__ uint8_t lds_means[];  // [min(k,..)][C] for the current pass
+    __shared__ uint32_t blk_counts[256];
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t i0 = 4 * t;
+    const bool active = i0 < n;
+    uint32_t best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t lab[4] = {0, 0, 0, 0};
+    for (uint32_t kb = 0; kb < k; kb += K) {
+        const uint32_t kk = (k - kb) < (uint32_t)K ? (k - kb) : (uint32_t)K;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < kk * C; i += 256) lds_means[i] = means[(uint64_t)kb * C + i];
+        __syncthreads();
+        if (active) {
+            uint32_t d[4][K];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < K; ++j) d[r][j] = 0;
+            for (uint32_t s = 0; s < C; ++s) {
+                const uint32_t x4 = *reinterpret_cast<const uint32_t *>(D + (uint64_t)s * ld + i0);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if ((uint32_t)j < kk) {
+                        const int m = lds_means[j * C + s];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int diff = (int)((x4 >> (8 * r)) & 0xFF) - m;
+                            d[r][j] += (uint32_t)(diff * diff);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if ((uint32_t)j < kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (d[r][j] < best[r]) { best[r] = d[r][j]; lab[r] = kb + j; }
+        }
+    }
+    // labels + per-cluster counts (cluster->count, cluster.c:168)
+    if (active) {
+        const uint32_t packed = lab[0] | (lab[1] << 8) | (lab[2] << 16) | (lab[3] << 24);
+        *reinterpret_cast<uint32_t *>(labels + i0) = packed;   // labels buffer is ld long: padding is ours
+    }
+    for (uint32_t i = threadIdx.x; i < k; i += 256) blk_counts[i] = 0;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (i0 + r < n) atomicAdd(&blk_counts[lab[r]], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < k; i += 256)
+        if (blk_counts[i]) atomicAdd(&counts[i], blk_counts[i]);
+}
+
+extern "C" int qvz_hip_kmeans_assign(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint32_t k,
+                                     const uint8_t *d_means, uint8_t *d_labels, uint32_t *d_counts, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
+    uint64_t n4 = (n + 3) / 4;
+    dim3 grid((unsigned)((n4 + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 1) {
+        size_t lds = (size_t)c;
+        hipLaunchKernelGGL(k_kmeans_assign<1>, grid, dim3(256), lds, st, d_sym, n, c, ld, k, d_means, d_labels, d_counts);
+    } else if (k <= 4) {
+        size_t lds = (size_t)4 * c;
+        hipLaunchKernelGGL(k_kmeans_assign<4>, grid, dim3(256), lds, st, d_sym, n, c, ld, k, d_means, d_labels, d_counts);
+    } else {
+        size_t lds = (size_t)KM_KPASS * c;
+        hipLaunchKernelGGL(k_kmeans_assign<KM_KPASS>, grid, dim3(256), lds, st, d_sym, n, c, ld, k, d_means, d_labels,
+                           d_counts);
+    }
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// Accumulation: block = (column, row slab). Threads stream 16 rows per load (16 B of symbols + 16 B of
+// labels), keep K partial sums in registers, then wave-reduce and add into the u64 accumulators.
+#define KMA_SLABS 8
+
+template <int K, bool HAVE_LABELS>
+__global__ __launch_bounds__(256) void k_kmeans_accum(const uint8_t *__restrict__ D,
+                                                      const uint8_t *__restrict__ labels, uint64_t n, uint32_t C,
+                                                      uint64_t ld, uint32_t kb, uint32_t k,
+                                                      unsigned long long *__restrict__ acc) {
+    const uint32_t s = blockIdx.x;
+    const uint64_t chunks = (n + 4095) / 4096;          // 4096 rows per block iteration
+    const uint64_t per = (chunks + gridDim.y - 1) / gridDim.y;
+    const uint64_t c0 = (uint64_t)blockIdx.y * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
+    uint32_t sum[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) sum[j] = 0;
+    unsigned long long total[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) total[j] = 0;
+    const uint8_t *col = D + (uint64_t)s * ld;
+    uint32_t iters = 0;
+    for (uint64_t ch = c0; ch < c1; ++ch) {
+        const uint64_t i = ch * 4096 + (uint64_t)threadIdx.x * 16;
+        if (i < n) {
+            const uint4 xv = *reinterpret_cast<const uint4 *>(col + i);
+            uint4 lv = make_uint4(0, 0, 0, 0);
+            if (HAVE_LABELS) lv = *reinterpret_cast<const uint4 *>(labels + i);
+            const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            const uint32_t ls[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (i + 4 * w + b < n) {
+                        const uint32_t x = (xs[w] >> (8 * b)) & 0xFF;
+                        const uint32_t l = (ls[w] >> (8 * b)) & 0xFF;
+#pragma unroll
+                        for (int j = 0; j < K; ++j) sum[j] += (!HAVE_LABELS || l == kb + j) ? x : 0u;
+                    }
+                }
+        }
+        if (++iters == 1u << 16) {   // 2^16 iterations x 16 rows x 71 < 2^32: spill to 64 bit before overflow
+#pragma unroll
+            for (int j = 0; j < K; ++j) { total[j] += sum[j]; sum[j] = 0; }
+            iters = 0;
+        }
+    }
+    __shared__ unsigned long long red[4][K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        unsigned long long v = total[j] + sum[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K && kb + threadIdx.x < k) {
+        unsigned long long v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (v) atomicAdd(&acc[(uint64_t)(kb + threadIdx.x) * C + s], v);
+    }
+}
+
+extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c,
+                                         uint64_t ld, uint32_t k, uint64_t *d_acc, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
+    if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
+    uint64_t chunks = (n + 4095) / 4096;
+    unsigned slabs = (unsigned)(chunks < 2048 / c + 1 ? chunks : 2048 / c + 1);  // ~2048 blocks fill 256 CUs x 8
+    dim3 grid(c, slabs);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(d_acc);
+    if (k == 1) {
+        hipLaunchKernelGGL((k_kmeans_accum<1, false>), grid, dim3(256), 0, st, d_sym, d_labels, n, c, ld, 0u, k, acc);
+    } else {
+        for (uint32_t kb = 0; kb < k; kb += 4)
+            hipLaunchKernelGGL((k_kmeans_accum<4, true>), grid, dim3(256), 0, st, d_sym, d_labels, n, c, ld, kb, k, acc);
+    }
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// New centroids and how far they moved (cluster.c:104-128). One block; exact integers throughout.
+__global__ __launch_bounds__(256) void k_kmeans_update(const unsigned long long *__restrict__ acc,
+                                                       const uint32_t *__restrict__ counts, uint32_t k, uint32_t C,
+                                                       uint8_t *__restrict__ means, double *__restrict__ moved_out,
+                                                       int32_t *__restrict__ status) {
+    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long best;
+    if (threadIdx.x == 0) best = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t cnt = counts[j];
+        unsigned long long part = 0;
+        if (cnt == 0) {
+            if (threadIdx.x == 0) atomicOr(status, 1);
+        } else {
+            for (uint32_t s = threadIdx.x; s < C; s += 256) {
+                const uint32_t nm = (uint32_t)(acc[(uint64_t)j * C + s] / cnt);
+                const int diff = (int)(nm & 0xFF) - (int)means[(uint64_t)j * C + s];   // (uint8_t) cast, cluster.c:113
+                part += (unsigned long long)(diff * diff);
+                means[(uint64_t)j * C + s] = (uint8_t)nm;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long m = red[0] + red[1] + red[2] + red[3];
+            if (m > best) best = m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *moved_out = (double)best;
+}
+
+extern "C" int qvz_hip_kmeans_update(const uint64_t *d_acc, const uint32_t *d_counts, uint32_t k, uint32_t c,
+                                     uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream) {
+    if (k == 0 || c == 0) return qvz_set_error(QVZ_E_ARG, "empty update");
+    hipLaunchKernelGGL(k_kmeans_update, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long *>(d_acc), d_counts, k, c, d_means, d_moved, d_status);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conditional-PMF counters (reference src/codebook.c:193-205).
+//
+// Grid = (column s, row slab). A block owns one column pair (s-1, s) for its slab of reads and keeps the
+// whole 72x72 u32 counter tile of up to PMF_KT clusters in LDS (20 736 B per cluster); threads stream 16
+// reads per 16-byte load of each of the two columns and issue one LDS atomic per read. The tile is flushed
+// once with global atomics (only non-zero bins). Columns s and s+1 of the same slab run side by side, so
+// the second read of each column is served from L2 / Infinity Cache: HBM traffic stays ~1 B per symbol.
+// ------------------------------------------------------------------------------------------------
+#define PMF_TILE (QVZ_A * QVZ_A)
+#define PMF_KT 7   // 7 x 20 736 B = 145 KB of the 160 KB LDS
+
+template <bool HAVE_LABELS>
+__global__ __launch_bounds__(256) void k_pmf_hist(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
+                                                  uint64_t n, uint32_t C, uint64_t ld, uint32_t kb, uint32_t kt,
+                                                  uint32_t *__restrict__ cnt) {
+    extern __shared__ uint32_t tile[];   // [kt][72][72]
+    const uint32_t s = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < kt * PMF_TILE; i += 256) tile[i] = 0;
+    __syncthreads();
+
+    const uint64_t chunks = (n + 4095) / 4096;
+    const uint64_t per = (chunks + gridDim.y - 1) / gridDim.y;
+    const uint64_t c0 = (uint64_t)blockIdx.y * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
+    const uint8_t *cur = D + (uint64_t)s * ld;
+    const uint8_t *prv = D + (uint64_t)(s ? s - 1 : 0) * ld;
+    for (uint64_t ch = c0; ch < c1; ++ch) {
+        const uint64_t i = ch * 4096 + (uint64_t)threadIdx.x * 16;
+        if (i >= n) continue;
+        const uint4 cv = *reinterpret_cast<const uint4 *>(cur + i);
+        uint4 pv = make_uint4(0, 0, 0, 0);
+        if (s) pv = *reinterpret_cast<const uint4 *>(prv + i);
+        uint4 lv = make_uint4(0, 0, 0, 0);
+        if (HAVE_LABELS) lv = *reinterpret_cast<const uint4 *>(labels + i);
+        const uint32_t cs[4] = {cv.x, cv.y, cv.z, cv.w};
+        const uint32_t ps[4] = {pv.x, pv.y, pv.z, pv.w};
+        const uint32_t ls[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t x = (cs[w] >> (8 * b)) & 0xFF;
+                const uint32_t p = (ps[w] >> (8 * b)) & 0xFF;
+                uint32_t l = 0;
+                bool ok = (i + 4 * w + b < n) && x < QVZ_A && p < QVZ_A;
+                if (HAVE_LABELS) {
+                    l = ((ls[w] >> (8 * b)) & 0xFF) - kb;
+                    ok = ok && l < kt;
+                }
+                if (ok) atomicAdd(&tile[l * PMF_TILE + p * QVZ_A + x], 1u);
+            }
+    }
+    __syncthreads();
+    uint32_t *out = cnt + ((uint64_t)kb * C + s) * PMF_TILE;
+    for (uint32_t i = threadIdx.x; i < kt * PMF_TILE; i += 256) {
+        const uint32_t v = tile[i];
+        if (v) atomicAdd(&out[(uint64_t)(i / PMF_TILE) * C * PMF_TILE + (i % PMF_TILE)], v);
+    }
+}
+
+extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
+                                uint32_t k, uint32_t *d_cnt, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
+    if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
+    if (n >= (1ull << 32)) return qvz_set_error(QVZ_E_ARG, "n >= 2^32 overflows the u32 counters (reference pmf.h:35)");
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t chunks = (n + 4095) / 4096;
+    for (uint32_t kb = 0; kb < k; kb += PMF_KT) {
+        const uint32_t kt = (k - kb) < PMF_KT ? (k - kb) : PMF_KT;
+        const size_t lds = (size_t)kt * PMF_TILE * sizeof(uint32_t);
+        // blocks resident per CU by LDS; ~all blocks co-resident so neighbouring columns advance together
+        const unsigned per_cu = (unsigned)(160 * 1024 / lds) > 8 ? 8 : (unsigned)(160 * 1024 / lds);
+        unsigned slabs = (256 * per_cu) / c;
+        if (slabs < 1) slabs = 1;
+        if (slabs > chunks) slabs = (unsigned)chunks;
+        dim3 grid(c, slabs);
+        if (k == 1) {
+            hipLaunchKernelGGL(k_pmf_hist<false>, grid, dim3(256), lds, st, d_sym, d_labels, n, c, ld, kb, kt, d_cnt);
+        } else {
+            if (lds > 64 * 1024)
+                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pmf_hist<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_pmf_hist<true>, grid, dim3(256), lds, st, d_sym, d_labels, n, c, ld, kb, kt, d_cnt);
+        }
+        QVZ_HIP_CHECK(hipGetLastError());
+    }
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// WELL-1024a (reference src/well.c:8-24) with GF(2) jump-ahead.
+//
+// Rotated view v[k] = state[(n+k)&31]: one step is the time-invariant linear map
+//     z0=v[31]; z1=v[0]^v[3]^(v[3]>>8); z2=v[24]^(v[24]<<19)^v[10]^(v[10]<<14);
+//     v' = [ z0^(z0<<11)^z1^(z1<<7)^z2^(z2<<13),  z1^z2,  v[1], ..., v[30] ]        (v'[0] is the output word)
+// so T^(2^j) by repeated squaring of a 1024x1024 bit matrix gives any jump; a jumped state is a valid
+// reference state with n = 0. Chunk start states are produced by log2(#chunks) batched mat-vec levels,
+// then one thread per chunk runs the plain recurrence (32 steps fully unrolled, all state in registers)
+// and writes whole 128-byte lines.
+// ------------------------------------------------------------------------------------------------
+#define WELL_MAXJ 46
+#define WELL_CHUNK_LOG2 13                  // 8192 words (32 768 draws) per generator thread
+#define WELL_CHUNK (1u << WELL_CHUNK_LOG2)
+
+static void well_step_host(uint32_t *v) {
+    uint32_t z0 = v[31], v1 = v[3], v2 = v[24], v3 = v[10];
+    uint32_t z1 = v[0] ^ v1 ^ (v1 >> 8);
+    uint32_t z2 = v2 ^ (v2 << 19) ^ v3 ^ (v3 << 14);
+    uint32_t out = z0 ^ (z0 << 11) ^ z1 ^ (z1 << 7) ^ z2 ^ (z2 << 13);
+    uint32_t y = z1 ^ z2;
+    for (int k = 31; k >= 2; --k) v[k] = v[k - 1];
+    v[1] = y;
+    v[0] = out;
+}
+
+// rows[r*32 + w]: bit c of row r set <=> new bit r depends on old bit c
+static void well_build_T(uint32_t *rows) {
+    memset(rows, 0, 1024 * 32 * sizeof(uint32_t));
+    for (int c = 0; c < 1024; ++c) {
+        uint32_t v[32];
+        memset(v, 0, sizeof(v));
+        v[c >> 5] = 1u << (c & 31);
+        well_step_host(v);
+        for (int r = 0; r < 1024; ++r)
+            if ((v[r >> 5] >> (r & 31)) & 1) rows[r * 32 + (c >> 5)] |= 1u << (c & 31);
+    }
+}
+
+// out = A*A over GF(2): row r of out = XOR of rows c of A for every set bit c of A's row r
+__global__ __launch_bounds__(64) void k_gf2_square(const uint32_t *__restrict__ A, uint32_t *__restrict__ out) {
+    const uint32_t r = blockIdx.x, w = threadIdx.x & 31;
+    uint32_t acc = 0;
+    for (uint32_t cw = 0; cw < 32; ++cw) {
+        uint32_t bits = A[r * 32 + cw];
+        while (bits) {
+            const uint32_t b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            acc ^= A[(cw * 32 + b) * 32 + w];
+        }
+    }
+    if (threadIdx.x < 32) out[r * 32 + w] = acc;
+}
+
+// dst[b] = M * src[b] for `count` states; a block handles up to 8 states so each matrix row is fetched once
+// per 8 products. Thread r owns output bit r; 64-lane ballots assemble two output words per wave.
+#define WELL_SPB 8
+__global__ __launch_bounds__(1024) void k_gf2_apply(const uint32_t *__restrict__ M, const uint32_t *__restrict__ src,
+                                                     uint32_t *__restrict__ dst, uint64_t count) {
+    __shared__ uint32_t sv[WELL_SPB][32];
+    const uint64_t b0 = (uint64_t)blockIdx.x * WELL_SPB;
+    const uint32_t r = threadIdx.x;
+    if (r < WELL_SPB * 32) {
+        const uint64_t st = b0 + (r >> 5);
+        sv[r >> 5][r & 31] = st < count ? src[st * 32 + (r & 31)] : 0;
+    }
+    uint32_t row[32];
+    const uint4 *mrow = reinterpret_cast<const uint4 *>(M + (uint64_t)r * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint4 t = mrow[q];
+        row[4 * q] = t.x; row[4 * q + 1] = t.y; row[4 * q + 2] = t.z; row[4 * q + 3] = t.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sidx = 0; sidx < WELL_SPB; ++sidx) {
+        if (b0 + sidx >= count) break;
+        uint32_t x = 0;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) x ^= row[w] & sv[sidx][w];
+        const unsigned long long bal = __ballot(__popc(x) & 1);
+        if ((r & 63) == 0) {
+            dst[(b0 + sidx) * 32 + (r >> 5)] = (uint32_t)bal;
+            dst[(b0 + sidx) * 32 + (r >> 5) + 1] = (uint32_t)(bal >> 32);
+        }
+    }
+}
+
+// one thread = one chunk of WELL_CHUNK words, reference recurrence with n = 0,31,30,...,1 unrolled
+__global__ __launch_bounds__(64) void k_well_gen(const uint32_t *__restrict__ states, uint64_t nchunks, uint64_t nwords,
+                                                 uint32_t *__restrict__ words) {
+    const uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= nchunks) return;
+    uint32_t s[32];
+    const uint4 *sp = reinterpret_cast<const uint4 *>(states + t * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint4 v = sp[q];
+        s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
+    }
+    const uint64_t w0 = t * WELL_CHUNK;
+    const uint64_t left = nwords - w0;
+    const uint32_t todo = left < WELL_CHUNK ? (uint32_t)left : WELL_CHUNK;
+    for (uint32_t base = 0; base < todo; base += 32) {
+        uint32_t out[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int n = (32 - i) & 31;                        // well.c:10-23 with compile-time n
+            const uint32_t z0 = s[(n + 31) & 31];
+            const uint32_t v1 = s[(n + 3) & 31], v2 = s[(n + 24) & 31], v3 = s[(n + 10) & 31];
+            const uint32_t z1 = s[n] ^ (v1 ^ (v1 >> 8));
+            const uint32_t z2 = (v2 ^ (v2 << 19)) ^ (v3 ^ (v3 << 14));
+            s[n] = z1 ^ z2;
+            const int nn = (n + 31) & 31;
+            s[nn] = (z0 ^ (z0 << 11)) ^ (z1 ^ (z1 << 7)) ^ (z2 ^ (z2 << 13));
+            out[i] = s[nn];
+        }
+        uint32_t *dstw = words + w0 + base;
+        if (base + 32 <= todo) {
+            uint4 *d4 = reinterpret_cast<uint4 *>(dstw);       // w0+base is a multiple of 32 words = 128 B
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d4[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (base + i < todo) dstw[i] = out[i];
+        }
+    }
+}
+
+struct WellTables {
+    int device = -1;
+    uint32_t *d_pow = nullptr;      // [WELL_MAXJ][1024*32] : T^(2^j)
+    uint32_t *d_states = nullptr;   // chunk start states
+    uint64_t states_cap = 0;
+    uint32_t *d_tmp = nullptr;      // 2 x 32 words ping-pong for single-state jumps
+};
+static WellTables g_well;
+
+static int well_init(hipStream_t st) {
+    int dev = 0;
+    QVZ_HIP_CHECK(hipGetDevice(&dev));
+    if (g_well.d_pow && g_well.device == dev) return QVZ_OK;
+    if (g_well.d_pow) {   // device changed: rebuild (single-device-per-process is the supported model)
+        (void)hipFree(g_well.d_pow); (void)hipFree(g_well.d_states); (void)hipFree(g_well.d_tmp);
+        g_well = WellTables();
+    }
+    const size_t msz = 1024 * 32 * sizeof(uint32_t);
+    uint32_t *T = (uint32_t *)malloc(msz);
+    if (!T) return qvz_set_error(QVZ_E_NOMEM, "host alloc");
+    well_build_T(T);
+    QVZ_HIP_CHECK(hipMalloc(&g_well.d_pow, WELL_MAXJ * msz));
+    QVZ_HIP_CHECK(hipMalloc(&g_well.d_tmp, 2 * 32 * sizeof(uint32_t)));
+    QVZ_HIP_CHECK(hipMemcpy(g_well.d_pow, T, msz, hipMemcpyHostToDevice));
+    free(T);
+    for (int j = 1; j < WELL_MAXJ; ++j)
+        hipLaunchKernelGGL(k_gf2_square, dim3(1024), dim3(64), 0, st, g_well.d_pow + (size_t)(j - 1) * 1024 * 32,
+                           g_well.d_pow + (size_t)j * 1024 * 32);
+    QVZ_HIP_CHECK(hipGetLastError());
+    g_well.device = dev;
+    return QVZ_OK;
+}
+
+// d_out (32 words) = T^words * state ; uses d_tmp ping-pong
+static int well_jump_device(const uint32_t *h_state, uint64_t words, uint32_t *d_out, hipStream_t st) {
+    if (words >> WELL_MAXJ) return qvz_set_error(QVZ_E_ARG, "WELL jump too large");
+    uint32_t *a = g_well.d_tmp, *b = g_well.d_tmp + 32;
+    QVZ_HIP_CHECK(hipMemcpyAsync(a, h_state, 128, hipMemcpyHostToDevice, st));
+    for (int j = 0; j < WELL_MAXJ; ++j) {
+        if ((words >> j) & 1) {
+            hipLaunchKernelGGL(k_gf2_apply, dim3(1), dim3(1024), 0, st, g_well.d_pow + (size_t)j * 1024 * 32, a, b,
+                               (uint64_t)1);
+            uint32_t *t = a; a = b; b = t;
+        }
+    }
+    QVZ_HIP_CHECK(hipMemcpyAsync(d_out, a, 128, hipMemcpyDeviceToDevice, st));
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+extern "C" int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32_t *h_state_out) {
+    int rc = well_init(0);
+    if (rc) return rc;
+    uint32_t *d = nullptr;
+    QVZ_HIP_CHECK(hipMalloc(&d, 128));
+    rc = well_jump_device(h_state, words, d, 0);
+    if (!rc && hipMemcpy(h_state_out, d, 128, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = qvz_set_error(QVZ_E_HIP, "copy back failed");
+    (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
+                                  void *stream) {
+    if (nwords == 0) return QVZ_OK;
+    if ((uintptr_t)d_words & 15) return qvz_set_error(QVZ_E_ARG, "d_words must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = well_init(st);
+    if (rc) return rc;
+    const uint64_t nchunks = (nwords + WELL_CHUNK - 1) / WELL_CHUNK;
+    if (nchunks > g_well.states_cap) {
+        if (g_well.d_states) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(g_well.d_states); }
+        g_well.states_cap = nchunks + nchunks / 4 + 64;
+        QVZ_HIP_CHECK(hipMalloc(&g_well.d_states, g_well.states_cap * 128));
+    }
+    rc = well_jump_device(h_state, first_word, g_well.d_states, st);
+    if (rc) return rc;
+    // doubling: states [2^l, 2^(l+1)) = T^(CHUNK*2^l) * states [0, 2^l)
+    for (int l = 0; (1ull << l) < nchunks; ++l) {
+        const uint64_t have = 1ull << l;
+        const uint64_t make = (nchunks - have) < have ? (nchunks - have) : have;
+        const int j = WELL_CHUNK_LOG2 + l;
+        if (j >= WELL_MAXJ) return qvz_set_error(QVZ_E_ARG, "WELL range too large");
+        hipLaunchKernelGGL(k_gf2_apply, dim3((unsigned)((make + WELL_SPB - 1) / WELL_SPB)), dim3(1024), 0, st,
+                           g_well.d_pow + (size_t)j * 1024 * 32, g_well.d_states, g_well.d_states + have * 32, make);
+    }
+    hipLaunchKernelGGL(k_well_gen, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, g_well.d_states, nchunks,
+                       nwords, d_words);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quantizer (reference src/qv_compressor.c:76-135 + choose_quantizer src/codebook.c:162-171).
+//
+// One thread owns 4 consecutive reads and walks the columns once; the 4 reads are independent first-order
+// chains (previous quantized value selects the context), interleaved for latency hiding. Per column a lane
+// loads one dword of symbols and stores one dword each of quantized values / quantizer indices / states.
+// Table look-ups (ct, qs) are 2-byte gathers that hit L1/L2: only the live contexts of a column are ever
+// touched. The 72x72 distortion table sits in LDS; the per-read error is accumulated in column order so it
+// is bit-identical to the reference's `error` (qv_compressor.c:97,118).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
+                                                  uint64_t n, uint32_t C, uint64_t ld, const uint16_t *__restrict__ ct,
+                                                  const uint16_t *__restrict__ qs, const uint32_t *__restrict__ words,
+                                                  uint64_t first_draw, const double *__restrict__ dist,
+                                                  uint8_t *__restrict__ qv_out, uint8_t *__restrict__ qi_out,
+                                                  uint8_t *__restrict__ st_out, double *__restrict__ err_out,
+                                                  int32_t *__restrict__ status) {
+    __shared__ double sdist[QVZ_A * QVZ_A];
+    for (uint32_t i = threadIdx.x; i < QVZ_A * QVZ_A; i += 256) sdist[i] = dist[i];
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t i0 = 4 * t;
+    if (i0 >= n) return;
+    uint32_t lab4 = 0;
+    if (labels) lab4 = *reinterpret_cast<const uint32_t *>(labels + i0);
+    const uint16_t *ctp[4], *qsp[4];
+    uint64_t g[4];
+    uint32_t wcur[4] = {0, 0, 0, 0}, prev[4] = {0, 0, 0, 0};
+    double err[4] = {0.0, 0.0, 0.0, 0.0};
+    const uint64_t wbase = first_draw >> 2;
+    bool dead = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t l = (lab4 >> (8 * r)) & 0xFF;
+        ctp[r] = ct + (uint64_t)l * C * QVZ_CT_STRIDE;
+        qsp[r] = qs + (uint64_t)l * C * QVZ_QS_STRIDE;
+        g[r] = first_draw + (i0 + r) * (uint64_t)C;
+    }
+    for (uint32_t s = 0; s < C; ++s) {
+        const uint32_t x4 = *reinterpret_cast<const uint32_t *>(D + (uint64_t)s * ld + i0);
+        uint32_t qv4 = 0, qi4 = 0, st4 = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t gg = g[r] + s;
+            if (s == 0 || (gg & 3) == 0) wcur[r] = (i0 + r < n) ? words[(gg >> 2) - wbase] : 0;
+            const uint32_t draw = (wcur[r] >> (7 * (uint32_t)(gg & 3))) & 127;          // well.c:33-46
+            uint32_t x = (x4 >> (8 * r)) & 0xFF;
+            if (x >= QVZ_A) x = 0;
+            const uint32_t cv = ctp[r][(uint64_t)s * QVZ_CT_STRIDE + prev[r]];
+            uint32_t ctx = cv & 0xFF;
+            if (ctx == QVZ_NOT_FOUND) { dead = dead || (i0 + r < n); ctx = 0; }      // assert, codebook.c:164
+            const uint32_t qi = 2 * ctx + (draw >= (cv >> 8) ? 1u : 0u);                // codebook.c:165-170
+            const uint32_t qsv = qsp[r][(uint64_t)s * QVZ_QS_STRIDE + qi * QVZ_A + x];
+            const uint32_t qv = qsv & 0xFF;
+            const double dd = sdist[x + QVZ_A * qv];                                     // distortion.c:151
+            err[r] = (s == 0) ? dd : err[r] + dd;
+            prev[r] = qv;
+            qv4 |= qv << (8 * r);
+            qi4 |= qi << (8 * r);
+            st4 |= (qsv >> 8) << (8 * r);
+        }
+        if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ld + i0) = qv4;
+        if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ld + i0) = qi4;
+        if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ld + i0) = st4;
+    }
+    if (err_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (i0 + r < n) err_out[i0 + r] = err[r];
+    }
+    if (dead) atomicOr(status, 1);
+}
+
+extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
+                                uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint32_t *d_words,
+                                uint64_t first_draw, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
+                                double *d_err, int32_t *d_status, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
+    if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
+    if (!d_ct || !d_qs || !d_words || !d_dist || !d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
+    uint64_t n4 = (n + 3) / 4;
+    dim3 grid((unsigned)((n4 + 255) / 256));
+    hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, (hipStream_t)stream, d_sym, k > 1 ? d_labels : nullptr, n, c, ld,
+                       d_ct, d_qs, d_words, first_draw, d_dist, d_qv, d_qi, d_st, d_err, d_status);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}

@@ -1,0 +1,133 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/qvz_hip.h). torch is used for device memory and stream
+handles only; all arithmetic happens in the HIP kernels of qvz_amd/csrc.
+
+Symbol matrices are torch.uint8 tensors of shape (c, ld), column-major in the reference's terms: row s of the
+tensor is column s of the reads, ld = qvz_hip_ld(n) (n padded to 256).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+A = 72
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def ld_for(n):
+    return int(lib().qvz_hip_ld(n))
+
+
+def empty_matrix(n, c, device="cuda"):
+    return torch.empty((c, ld_for(n)), dtype=torch.uint8, device=device)
+
+
+def _dims(sym, n):
+    c, ld = sym.shape
+    assert sym.dtype == torch.uint8 and sym.is_contiguous() and ld == ld_for(n), (sym.shape, n)
+    return c, ld
+
+
+def qgen1(seed, n, c, first=0, out=None):
+    """QGEN-1 reads [first, first+n) generated on device in symbol-matrix layout."""
+    sym = out if out is not None else empty_matrix(n, c)
+    c_, ld = _dims(sym, n)
+    check(lib().qvz_hip_qgen1(seed, first, n, c_, _ptr(sym), ld, _stream()))
+    return sym
+
+
+def transpose_text(text, n, c):
+    """text: uint8 device tensor with n*(c+1) bytes in the reference's file layout -> (sym, bad_count)."""
+    sym = empty_matrix(n, c, text.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=text.device)
+    check(lib().qvz_hip_transpose_text(_ptr(text), n, c, _ptr(sym), sym.shape[1], _ptr(bad), _stream()))
+    return sym, bad
+
+
+def untranspose_text(qv, n):
+    c, ld = _dims(qv, n)
+    text = torch.empty(n * (c + 1), dtype=torch.uint8, device=qv.device)
+    check(lib().qvz_hip_untranspose_text(_ptr(qv), n, c, ld, _ptr(text), _stream()))
+    return text
+
+
+def kmeans_assign(sym, n, means, labels=None, counts=None):
+    c, ld = _dims(sym, n)
+    k = means.shape[0]
+    assert means.dtype == torch.uint8 and means.shape == (k, c) and means.is_contiguous()
+    if labels is None:
+        labels = torch.zeros(ld, dtype=torch.uint8, device=sym.device)
+    if counts is None:
+        counts = torch.zeros(k, dtype=torch.int32, device=sym.device)
+    check(lib().qvz_hip_kmeans_assign(_ptr(sym), n, c, ld, k, _ptr(means), _ptr(labels), _ptr(counts), _stream()))
+    return labels, counts
+
+
+def kmeans_accumulate(sym, n, labels, k, acc=None):
+    c, ld = _dims(sym, n)
+    if acc is None:
+        acc = torch.zeros((k, c), dtype=torch.int64, device=sym.device)
+    check(lib().qvz_hip_kmeans_accumulate(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(acc), _stream()))
+    return acc
+
+
+def kmeans_update(acc, counts, means):
+    k, c = means.shape
+    moved = torch.zeros(1, dtype=torch.float64, device=means.device)
+    status = torch.zeros(1, dtype=torch.int32, device=means.device)
+    check(lib().qvz_hip_kmeans_update(_ptr(acc), _ptr(counts), k, c, _ptr(means), _ptr(moved), _ptr(status),
+                                      _stream()))
+    return moved, status
+
+
+def pmf_hist(sym, n, labels=None, k=1, cnt=None):
+    c, ld = _dims(sym, n)
+    if cnt is None:
+        cnt = torch.zeros((k, c, A, A), dtype=torch.int32, device=sym.device)
+    check(lib().qvz_hip_pmf_hist(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(cnt), _stream()))
+    return cnt
+
+
+def _state_arg(state):
+    st = np.ascontiguousarray(state, dtype=np.uint32)
+    assert st.shape == (32,)
+    return st, st.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def well_words(state, first_word, nwords, device="cuda", out=None):
+    st, sp = _state_arg(state)
+    words = out if out is not None else torch.empty(nwords, dtype=torch.int32, device=device)
+    check(lib().qvz_hip_well_words(sp, first_word, nwords, _ptr(words), _stream()))
+    return words
+
+
+def well_jump(state, words):
+    st, sp = _state_arg(state)
+    out = np.zeros(32, dtype=np.uint32)
+    check(lib().qvz_hip_well_jump(sp, words, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return out
+
+
+def quantize(sym, n, ct, qs, words, first_draw, dist, labels=None, k=1, want=("qv", "qi", "st", "err")):
+    """ct: (k, c, 72) int16/uint16-as-int16, qs: (k, c, 144, 72); words: int32 WELL words covering
+    draws [first_draw & ~3, first_draw + n*c)."""
+    c, ld = _dims(sym, n)
+    dev = sym.device
+    out = {}
+    for name in ("qv", "qi", "st"):
+        out[name] = torch.empty((c, ld), dtype=torch.uint8, device=dev) if name in want else None
+    out["err"] = torch.empty(n, dtype=torch.float64, device=dev) if "err" in want else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().qvz_hip_quantize(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(ct), _ptr(qs), _ptr(words), first_draw,
+                                 _ptr(dist), _ptr(out["qv"]), _ptr(out["qi"]), _ptr(out["st"]), _ptr(out["err"]),
+                                 _ptr(status), _stream()))
+    out["status"] = status
+    return out

@@ -1,0 +1,319 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel behind include/qvz_hip.h against the CPU
+oracle on the same seeded inputs, plus size-independent properties at BASELINE.json's full shapes."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+A = 72
+
+
+@pytest.fixture(scope="module")
+def K():
+    from qvz_amd import kernels
+    return kernels
+
+
+def rows_to_sym(rows):
+    """(n, c+1) text rows -> (c, n) symbols."""
+    return np.ascontiguousarray(rows[:, :-1].T - 33).astype(np.uint8)
+
+
+def upload_sym(K, rows):
+    n, c = rows.shape[0], rows.shape[1] - 1
+    sym = K.empty_matrix(n, c)
+    sym.zero_()
+    sym[:, :n] = torch.from_numpy(rows_to_sym(rows)).cuda()
+    return sym
+
+
+def tables_from_codebooks(cbs):
+    """ct/qs device tables in the layout of include/qvz_hip.h from oracle codebooks (test helper)."""
+    k, c = len(cbs), cbs[0].c
+    ct = np.zeros((k, c, A), dtype=np.uint16)
+    qs = np.zeros((k, c, 2 * A, A), dtype=np.uint16)
+    for j, cb in enumerate(cbs):
+        idx = cb.ctx_idx.astype(np.uint16)
+        qr = np.take_along_axis(cb.qratio.astype(np.uint16), np.minimum(idx, A - 1).astype(np.int64), axis=1)
+        ct[j] = np.where(idx == 0xFF, 0xFF, idx | (qr << 8))
+        q = cb.q.astype(np.int64)
+        st = np.take_along_axis(cb.out_idx.astype(np.uint16), q, axis=2)
+        qs[j] = cb.q.astype(np.uint16) | (st << 8)
+    return torch.from_numpy(ct.view(np.int16)).cuda(), torch.from_numpy(qs.view(np.int16)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,first", [(5000, 37, 0), (1021, 150, 123457), (4, 2, 7), (70000, 100, 3)])
+def test_qgen1_matches_cpu(K, n, c, first):
+    sym = K.qgen1(9, n, c, first=first)
+    ref = rows_to_sym(O.qgen1_rows(9, n, c, first=first))
+    np.testing.assert_array_equal(sym[:, :n].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,c", [(1000, 30), (257, 151), (3, 5), (66000, 64)])
+def test_transpose_roundtrip(K, n, c):
+    rows = O.qgen1_rows(3, n, c)
+    text = torch.from_numpy(rows.reshape(-1)).cuda()
+    sym, bad = K.transpose_text(text, n, c)
+    assert int(bad.item()) == 0
+    np.testing.assert_array_equal(sym[:, :n].cpu().numpy(), rows_to_sym(rows))
+    back = K.untranspose_text(sym, n)
+    np.testing.assert_array_equal(back.cpu().numpy(), rows.reshape(-1))
+
+
+def test_transpose_flags_bad_bytes(K):
+    rows = O.qgen1_rows(3, 500, 20)
+    rows[17, 3] = 20          # below '!' : index -13 in the reference (UB)
+    rows[400, 19] = 33 + 72   # above the 72-symbol alphabet
+    rows[123, 20] = ord("x")  # missing newline
+    _, bad = K.transpose_text(torch.from_numpy(rows.reshape(-1)).cuda(), 500, 20)
+    assert int(bad.item()) == 3
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["t2k_c3_f05_M", "twolevel_c2_f05", "cfg1_c3_r10_M"])
+def test_kmeans_full_loop_matches_reference_phase(K, name):
+    """Host loop of do_kmeans_clustering (cluster.c:212-244) over the three k-means kernels."""
+    rows = G.case_rows(name)
+    k = G.case_opts(name)["k"]
+    ph = G.phase(name)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    sym = upload_sym(K, rows)
+    cent = O.pick_centroids(n, k)
+    means = torch.from_numpy(np.stack([rows[int(i), :c] - 33 for i in cent]).astype(np.uint8)).cuda()
+    iters = 0
+    while True:
+        labels, counts = K.kmeans_assign(sym, n, means)
+        acc = K.kmeans_accumulate(sym, n, labels, k)
+        moved, status = K.kmeans_update(acc, counts, means)
+        iters += 1
+        assert int(status.item()) == 0
+        if not (moved.item() > 4.0) or iters >= 1000:
+            break
+    np.testing.assert_array_equal(labels[:n].cpu().numpy(), ph["labels"])
+    np.testing.assert_array_equal(counts.cpu().numpy().astype(np.uint32), ph["counts"])
+    np.testing.assert_array_equal(means.cpu().numpy() + 33, ph["means"])
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 9, 17])
+def test_kmeans_single_iteration_random_means(K, k):
+    n, c = 12345, 61
+    rows = O.qgen1_rows(21, n, c)
+    rng = np.random.default_rng(k)
+    cent = np.sort(rng.choice(n, size=k, replace=False)).astype(np.uint64)
+    sym = upload_sym(K, rows)
+    means_np = np.stack([rows[int(i), :c] - 33 for i in cent]).astype(np.uint8)
+    means = torch.from_numpy(means_np.copy()).cuda()
+    labels, counts = K.kmeans_assign(sym, n, means)
+    # oracle: one assignment pass == labels after iteration 1 when threshold is huge
+    olab, omeans, ocounts, it = O.kmeans(rows, k, threshold=1e30, centroids=cent)
+    if it < 0:
+        pytest.skip("empty cluster in this draw")
+    np.testing.assert_array_equal(labels[:n].cpu().numpy(), olab)
+    np.testing.assert_array_equal(counts.cpu().numpy().astype(np.uint32), ocounts)
+    acc = K.kmeans_accumulate(sym, n, labels, k)
+    moved, status = K.kmeans_update(acc, counts, means)
+    assert int(status.item()) == 0
+    np.testing.assert_array_equal(means.cpu().numpy() + 33, omeans)
+    ref_acc = np.zeros((k, c), dtype=np.int64)
+    np.add.at(ref_acc, olab, (rows[:, :c] - 33).astype(np.int64))
+    np.testing.assert_array_equal(acc.cpu().numpy(), ref_acc)
+
+
+def test_kmeans_empty_cluster_is_reported(K):
+    rows = O.qgen1_rows(1, 300, 10)
+    sym = upload_sym(K, rows)
+    means = torch.from_numpy(np.stack([rows[0, :10] - 33, np.full(10, 71)]).astype(np.uint8)).cuda()
+    labels, counts = K.kmeans_assign(sym, 300, means)
+    acc = K.kmeans_accumulate(sym, 300, labels, 2)
+    _, status = K.kmeans_update(acc, counts, means)
+    assert int(counts[1].item()) == 0 and int(status.item()) == 1
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,k", [(2000, 30, 1), (10000, 100, 1), (4097, 7, 3), (30000, 40, 9), (5, 7, 1)])
+def test_pmf_counts_match_oracle(K, n, c, k):
+    rows = O.qgen1_rows(5, n, c)
+    rng = np.random.default_rng(n)
+    labels_np = rng.integers(0, k, size=n).astype(np.uint8)
+    sym = upload_sym(K, rows)
+    lab = torch.zeros(sym.shape[1], dtype=torch.uint8, device="cuda")
+    lab[:n] = torch.from_numpy(labels_np).cuda()
+    cnt = K.pmf_hist(sym, n, labels=lab if k > 1 else None, k=k)
+    ref = O.stats(rows, labels_np if k > 1 else np.zeros(n, np.uint8), k)
+    np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ref)
+
+
+def test_pmf_full_alphabet_and_fixture(K):
+    rows = G.case_rows("uniform72_r20_A")
+    n = rows.shape[0]
+    cnt = K.pmf_hist(upload_sym(K, rows), n)
+    np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), O.stats(rows, np.zeros(n, np.uint8), 1))
+    ph = G.phase("t2k_r10_M")
+    rows = G.case_rows("t2k_r10_M")
+    cnt = K.pmf_hist(upload_sym(K, rows), rows.shape[0])
+    np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ph["cnt"])
+
+
+def test_pmf_accumulates_across_calls(K):
+    """Counters are += : two shards of reads give the single-pass counts (the multi-GPU reduction relies on it)."""
+    rows = O.qgen1_rows(8, 9000, 25)
+    full = K.pmf_hist(upload_sym(K, rows), 9000)
+    part = K.pmf_hist(upload_sym(K, rows[:5000]), 5000)
+    part = K.pmf_hist(upload_sym(K, rows[5000:]), 4000, cnt=part)
+    assert torch.equal(full, part)
+
+
+# ------------------------------------------------------------------------------------------------
+def cpu_well_words(state, first, count):
+    import ctypes as C
+
+    class W(C.Structure):
+        _fields_ = [("state", C.c_uint32 * 32), ("n", C.c_uint32), ("bit_output", C.c_uint32), ("bits_left", C.c_uint32)]
+
+    lib = O.lib()
+    lib.orc_well_word.restype = C.c_uint32
+    w = W()
+    for i in range(32):
+        w.state[i] = int(state[i])
+    out = np.zeros(count, dtype=np.uint32)
+    for i in range(first + count):
+        v = lib.orc_well_word(C.byref(w))
+        if i >= first:
+            out[i - first] = v
+    return out
+
+
+@pytest.mark.parametrize("first,count", [(0, 4), (0, 40000), (5, 100), (8191, 3), (8192, 8193), (123457, 20001)])
+def test_well_words_match_reference_recurrence(K, first, count):
+    state = O.WELL_DEBUG_STATE
+    words = K.well_words(state, first, count).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(words, cpu_well_words(state, first, count))
+    if first == 0 and count == 4:
+        assert [hex(int(x)) for x in words] == G.MANIFEST["well_kat"]["first_words"]
+
+
+def test_well_random_state_and_jump(K):
+    rng = np.random.default_rng(77)
+    state = rng.integers(0, 2 ** 31, size=32, dtype=np.uint32)   # rand() values, qv_stream.c:81
+    words = K.well_words(state, 1000, 3000).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(words, cpu_well_words(state, 1000, 3000))
+    # a jumped state, stored with n = 0, continues the same stream (what a shard's .q header holds)
+    jumped = K.well_jump(state, 2500)
+    np.testing.assert_array_equal(cpu_well_words(jumped, 0, 64), cpu_well_words(state, 2500, 64))
+    # far jump: consistency of two routes
+    a = K.well_jump(K.well_jump(state, 10 ** 9), 3 * 10 ** 9 + 17)
+    b = K.well_jump(state, 4 * 10 ** 9 + 17)
+    np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "t2k_c3_f05_M", "uniform72_r20_A", "c2_f08",
+                                  "tiny5_r10", "const_f05", "r35_high_rate", "cfg1_r10_M"])
+def test_quantize_matches_reference_u_file(K, name):
+    """qv output == the reference's -u dump; coder feed and per-read error == oracle."""
+    rows = G.case_rows(name)
+    opts = G.case_opts(name)
+    n, c, k = rows.shape[0], rows.shape[1] - 1, opts["k"]
+    labels_np = O.kmeans(rows, k)[0]
+    cnt = O.stats(rows, labels_np, k)
+    d = O.distortion(opts["dist"])
+    cbs = [O.generate_codebook(cnt[j], d, opts["mode"], opts["ratio"]) for j in range(k)]
+    ref = O.encode_stream(rows, labels_np, cbs, d, want_feed=True)
+    assert G.md5(ref["u"].tobytes()) == G.CASES[name]["u_md5"]
+
+    sym = upload_sym(K, rows)
+    lab = torch.zeros(sym.shape[1], dtype=torch.uint8, device="cuda")
+    lab[:n] = torch.from_numpy(labels_np).cuda()
+    ct, qs = tables_from_codebooks(cbs)
+    nwords = (n * c + 3) // 4
+    words = K.well_words(O.WELL_DEBUG_STATE, 0, nwords)
+    out = K.quantize(sym, n, ct, qs, words, 0, torch.from_numpy(d).cuda(), labels=lab, k=k)
+    assert int(out["status"].item()) == 0
+    text = K.untranspose_text(out["qv"], n).cpu().numpy().tobytes()
+    assert G.md5(text) == G.CASES[name]["u_md5"], "-u differs from the reference"
+    np.testing.assert_array_equal(out["qi"][:, :n].cpu().numpy().T, ref["qi"])
+    np.testing.assert_array_equal(out["st"][:, :n].cpu().numpy().T, ref["st"])
+    # per-read error is accumulated in the reference's order: bit-identical, so is the sequential total
+    err = out["err"].cpu().numpy()
+    total = 0.0
+    for e in err:
+        total += e / float(c)
+    assert total / float(n) == ref["distortion"]
+
+
+def test_quantize_shard_equals_slice_of_full(K):
+    """Reads [a,b) quantized alone with first_draw = a*C reproduce the same rows (multi-GPU sharding)."""
+    rows = O.qgen1_rows(4, 6000, 33)
+    n, c = 6000, 33
+    cnt = O.stats(rows, np.zeros(n, np.uint8), 1)
+    d = O.distortion("M")
+    cb = O.generate_codebook(cnt[0], d, O.MODE_RATIO, 0.6)
+    ct, qs = tables_from_codebooks([cb])
+    dd = torch.from_numpy(d).cuda()
+    state = O.WELL_DEBUG_STATE
+    full = K.quantize(upload_sym(K, rows), n, ct, qs, K.well_words(state, 0, (n * c + 3) // 4), 0, dd)
+    a, b = 2501, 5999      # deliberately not multiples of 4
+    fd = a * c
+    w0 = fd // 4
+    words = K.well_words(state, w0, ((b * c + 3) // 4) - w0)
+    part = K.quantize(upload_sym(K, rows[a:b]), b - a, ct, qs, words, fd, dd)
+    for key in ("qv", "qi", "st"):
+        assert torch.equal(part[key][:, : b - a], full[key][:, a:b]), key
+    assert torch.equal(part["err"], full["err"][a:b])
+
+
+def test_quantize_reports_undefined_context(K):
+    rows = O.qgen1_rows(4, 400, 12)
+    cnt = O.stats(rows, np.zeros(400, np.uint8), 1)
+    d = O.distortion("M")
+    cb = O.generate_codebook(cnt[0], d, O.MODE_RATIO, 0.5)
+    ct, qs = tables_from_codebooks([cb])
+    ct[0, 5, :] = 0xFF   # column 5 defines no context at all
+    out = K.quantize(upload_sym(K, rows), 400, ct, qs, K.well_words(O.WELL_DEBUG_STATE, 0, 1200), 0,
+                     torch.from_numpy(d).cuda())
+    assert int(out["status"].item()) == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json shapes: properties that do not need the oracle to finish at this size
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c", [(10_000_000, 150)])
+def test_full_size_pmf_properties(K, n, c):
+    sym = K.qgen1(2, n, c)
+    cnt = K.pmf_hist(sym, n).to(torch.int64)[0]          # (c, 72, 72)
+    per_col = cnt.sum(dim=(1, 2))
+    assert torch.all(per_col == n), "every column must count every read exactly once"
+    # flow conservation: reads with X_{s-1}=p counted as 'prev' in column s == counted as 'cur' in column s-1
+    cur_marg = cnt.sum(dim=1)                            # (c, 72): occurrences of each symbol in column s
+    prev_marg = cnt.sum(dim=2)                           # (c, 72): occurrences as previous symbol
+    assert torch.equal(prev_marg[1:], cur_marg[:-1])
+    # and against an independent device histogram of the raw column
+    col = 77
+    hist = torch.bincount(sym[col, :n].to(torch.int64), minlength=A)
+    assert torch.equal(hist, cur_marg[col])
+    # shard additivity at scale (what the RCCL all-reduce sums)
+    half = n // 2
+    a = K.pmf_hist(K.qgen1(2, half, c), half)
+    b = K.pmf_hist(K.qgen1(2, n - half, c, first=half), n - half, cnt=a)
+    assert torch.equal(b.to(torch.int64)[0], cnt)
+
+
+def test_full_size_kmeans_properties(K):
+    n, c, k = 10_000_000, 150, 3
+    sym = K.qgen1(2, n, c)
+    means = sym[:, [11, 5000001, 9999999]].T.contiguous()
+    labels, counts = K.kmeans_assign(sym, n, means)
+    assert int(counts.sum().item()) == n
+    assert torch.equal(torch.bincount(labels[:n].to(torch.int64), minlength=k), counts.to(torch.int64))
+    acc = K.kmeans_accumulate(sym, n, labels, k)
+    col = 33
+    for j in range(k):
+        assert int(acc[j, col].item()) == int(sym[col, :n][labels[:n] == j].to(torch.int64).sum().item())
+    # idempotence: re-assigning with the same means gives the same labels
+    labels2, _ = K.kmeans_assign(sym, n, means)
+    assert torch.equal(labels, labels2)
