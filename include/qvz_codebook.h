@@ -1,0 +1,69 @@
+/* qvz_codebook.h - C-ABI for codebook generation on the MI355X and the flat host-side codebook it fills.
+ *
+ * Replaces, for one cluster, the marginal pass of calculate_statistics (reference src/codebook.c:208-219) and
+ * generate_codebooks (src/codebook.c:355-468) with its helpers optimize_for_entropy (:230-269),
+ * compute_qpmf_quan_list (:274-289), compute_qpmf_list (:291-330), compute_xpmf_list (:332-349) and
+ * generate_quantizer / apply_quantizer (src/quantizer.c:34-161).
+ *
+ * Where the arithmetic runs: every probability table, every Lloyd-Max design and every output pmf is computed
+ * by HIP kernels in the reference's summation order (FP64, no FMA contraction). Two things stay on the host by
+ * design, because they are decision-bearing libm values that must be bit-identical to the reference's:
+ * log2() for entropies (src/pmf.c:150) and the few scalar operations that turn two entropies into `ratio`
+ * (src/codebook.c:263-268). The device uses its own log2 only to steer the search, inside a guard band; any
+ * decision that falls inside the band is re-taken by the host from the libm value.
+ */
+#ifndef QVZ_CODEBOOK_H
+#define QVZ_CODEBOOK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "qvz_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Flat form of cond_quantizer_list_t + quantizer_t (reference include/codebook.h:61-69, quantizer.h:16-22).
+ * Index 2*ctx+0 is the "lo" quantizer of a context, 2*ctx+1 the "hi" one. */
+typedef struct qvz_codebook {
+    uint32_t C;
+    uint8_t *nctx;     /* [C]            number of contexts of column s (1 for s = 0)                       */
+    uint8_t *ctx_sym;  /* [C][72]        context symbols in alphabet (merge) order                            */
+    uint8_t *ctx_idx;  /* [C][72]        previous quantized value -> context index, QVZ_NOT_FOUND if none     */
+    uint8_t *qratio;   /* [C][72]        (uint8)(ratio*128)              store_cond_quantizers_indexed :156   */
+    double  *ratio;    /* [C][72]        probability of using the lo quantizer                                */
+    uint8_t *q;        /* [C][144][72]   quantizer tables                                                     */
+    uint8_t *nstates;  /* [C][144]       size of the output alphabet                                          */
+    uint8_t *recon;    /* [C][144][72]   output alphabet (reconstruction points, first nstates valid)         */
+    uint8_t *out_idx;  /* [C][144][72]   value -> state index in the output alphabet (last writer wins)       */
+} qvz_codebook_t;
+
+qvz_codebook_t *qvz_codebook_alloc(uint32_t C);
+void qvz_codebook_free(qvz_codebook_t *cb);
+
+/* distortion matrices d[x + 72*y] (reference src/distortion.c:50-95); host, 41 KB */
+int qvz_distortion_matrix(int type, double *h_dist /*[72*72]*/);
+
+/* d_cnt: this cluster's counters [C][72][72] (device). mode/ratio: -f / -r and its argument.
+ * guard: width of the band (absolute, on entropies in bits) inside which device-side search decisions are
+ * deferred to the host; pass 0 for the default (1e-9). A huge guard makes the host take every decision
+ * (used by the tests to prove the two routes agree). Returns QVZ_OK and fills `out`. */
+int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
+                              double guard, qvz_codebook_t *out, void *stream);
+
+/* Number of host-side decisions the last qvz_hip_generate_codebook call had to take inside the guard band */
+uint64_t qvz_hip_codebook_deferred_decisions(void);
+
+/* Device tables for the quantizer (layout in qvz_hip.h) from a host codebook: h_ct [C][72], h_qs [C][144][72] */
+void qvz_codebook_tables(const qvz_codebook_t *cb, uint16_t *h_ct, uint16_t *h_qs);
+
+/* Serialisation, byte-identical to write_codebooks / write_codebook (reference src/codebook.c:474-555).
+ * buf == NULL returns the size only. */
+size_t qvz_codebook_write_header(uint8_t *buf, uint32_t clusters, uint32_t columns, uint64_t lines);
+size_t qvz_codebook_write(uint8_t *buf, const qvz_codebook_t *cb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -265,12 +265,14 @@ static void lm_design(const double *p, int p_is_zero, const double *d, uint32_t 
         }
         lm_design_t *z = &g_zero_memo[S];
         if (!z->valid) {
+            memset(z->recon, 0, A);
             z->H = orc_lloyd_max(p, d, S, z->q, z->recon, z->out_idx, &z->mse);
             z->valid = 1;
         }
         *out = *z;
         return;
     }
+    memset(out->recon, 0, A);
     out->H = orc_lloyd_max(p, d, S, out->q, out->recon, out->out_idx, &out->mse);
     out->valid = 1;
 }

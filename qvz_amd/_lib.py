@@ -31,6 +31,16 @@ SIGNATURES = {
     "qvz_hip_well_jump": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_hip_quantize": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u16p, u16p, u32p,
                                    C.c_uint64, f64p, u8p, u8p, u8p, f64p, C.c_void_p, C.c_void_p]),
+    # include/qvz_codebook.h
+    "qvz_codebook_alloc": (C.c_void_p, [C.c_uint32]),
+    "qvz_codebook_free": (None, [C.c_void_p]),
+    "qvz_distortion_matrix": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "qvz_hip_generate_codebook": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.c_int, C.c_double,
+                                            C.c_double, C.c_void_p, C.c_void_p]),
+    "qvz_hip_codebook_deferred_decisions": (C.c_uint64, []),
+    "qvz_codebook_tables": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qvz_codebook_write_header": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "qvz_codebook_write": (C.c_size_t, [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,681 @@
+// qvz_codebook.hip - codebook generation for one cluster on gfx950 (C-ABI: include/qvz_codebook.h).
+//
+// Reference path restated: calculate_statistics' marginal pass (src/codebook.c:208-219) and generate_codebooks
+// (src/codebook.c:355-468) with optimize_for_entropy (:230-269), compute_qpmf_quan_list (:274-289),
+// compute_qpmf_list (:291-330), compute_xpmf_list (:332-349), generate_quantizer / apply_quantizer
+// (src/quantizer.c:34-161).
+//
+// The work is N-independent, FP64 and decision-bearing: codebook bytes depend on `<` comparisons of sums, so
+// every sum below is evaluated in the reference's index order with separately rounded multiply and add
+// (this file is compiled with -ffp-contract=off). Parallelism comes from the independent dimensions only:
+//   k_cond_pmf      one wave per (column, previous symbol) row: counts -> P(x | prev) by true division
+//   k_marginals     one block, sequential over columns and over j (pmf.c:200-202 order), lanes over x
+//   k_ctx_propagate one 1024-thread block per column: thread per output element, each a sequential 72-term sum;
+//                   p_temp(k,j) hoisted out of the idx loop (same per-term order => bit-identical)
+//   k_lm_search     one wave per context: Lloyd-Max with a lane per candidate reconstruction point, exact
+//                   (value, index) arg-min by wave shuffles, ballot masks + count-trailing-zeros for the
+//                   boundary walk; the number-of-states search runs on device, steered by device log2 inside
+//                   a guard band; host libm takes every decision that falls inside the band and computes the
+//                   entropies that become `ratio`.
+// Columns are sequentially dependent (column s needs the quantizers of column s-1), so the host drives one
+// column at a time: ~2 small launches and 2 small copies per column.
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qvz_codebook.h"
+#include "qvz_internal.h"
+
+#define A QVZ_A
+
+// ------------------------------------------------------------------------------------------------
+// host-side codebook container, distortion matrices, serialisation
+// ------------------------------------------------------------------------------------------------
+extern "C" qvz_codebook_t *qvz_codebook_alloc(uint32_t C) {
+    qvz_codebook_t *cb = (qvz_codebook_t *)calloc(1, sizeof(*cb));
+    if (!cb) return nullptr;
+    cb->C = C;
+    cb->nctx = (uint8_t *)calloc(C, 1);
+    cb->ctx_sym = (uint8_t *)calloc((size_t)C * A, 1);
+    cb->ctx_idx = (uint8_t *)malloc((size_t)C * A);
+    cb->qratio = (uint8_t *)calloc((size_t)C * A, 1);
+    cb->ratio = (double *)calloc((size_t)C * A, sizeof(double));
+    cb->q = (uint8_t *)calloc((size_t)C * 2 * A * A, 1);
+    cb->nstates = (uint8_t *)calloc((size_t)C * 2 * A, 1);
+    cb->recon = (uint8_t *)calloc((size_t)C * 2 * A * A, 1);
+    cb->out_idx = (uint8_t *)malloc((size_t)C * 2 * A * A);
+    if (!cb->nctx || !cb->ctx_sym || !cb->ctx_idx || !cb->qratio || !cb->ratio || !cb->q || !cb->nstates ||
+        !cb->recon || !cb->out_idx) {
+        qvz_codebook_free(cb);
+        return nullptr;
+    }
+    memset(cb->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
+    memset(cb->out_idx, QVZ_NOT_FOUND, (size_t)C * 2 * A * A);
+    return cb;
+}
+
+extern "C" void qvz_codebook_free(qvz_codebook_t *cb) {
+    if (!cb) return;
+    free(cb->nctx); free(cb->ctx_sym); free(cb->ctx_idx); free(cb->qratio); free(cb->ratio);
+    free(cb->q); free(cb->nstates); free(cb->recon); free(cb->out_idx);
+    free(cb);
+}
+
+extern "C" int qvz_distortion_matrix(int type, double *d) {
+    for (int y = 0; y < A; ++y)
+        for (int x = 0; x < A; ++x) {
+            const int diff = x > y ? x - y : y - x;
+            double v;
+            switch (type) {
+                case QVZ_DIST_MANHATTAN: v = diff; break;                          // distortion.c:50-61
+                case QVZ_DIST_MSE: v = diff * diff; break;                         // distortion.c:66-77
+                case QVZ_DIST_LORENTZ: v = log2(1.0 + (double)diff); break;        // distortion.c:82-95
+                default: return qvz_set_error(QVZ_E_ARG, "unknown distortion type %d", type);
+            }
+            d[x + A * y] = v;
+        }
+    return QVZ_OK;
+}
+
+extern "C" size_t qvz_codebook_write_header(uint8_t *buf, uint32_t clusters, uint32_t columns, uint64_t lines) {
+    if (buf) {                                                   // codebook.c:481-486 (htonl, u32 truncation)
+        const uint32_t l32 = (uint32_t)lines;
+        buf[0] = (uint8_t)clusters;
+        for (int b = 0; b < 4; ++b) {
+            buf[1 + b] = (uint8_t)(columns >> (24 - 8 * b));
+            buf[5 + b] = (uint8_t)(l32 >> (24 - 8 * b));
+        }
+    }
+    return 9;
+}
+
+extern "C" size_t qvz_codebook_write(uint8_t *buf, const qvz_codebook_t *cb) {
+    size_t pos = 0;
+    auto put = [&](uint32_t b) { if (buf) buf[pos] = (uint8_t)b; ++pos; };
+    auto put_table = [&](const uint8_t *q) { for (int i = 0; i < A; ++i) put(q[i] + 33u); };
+    put(cb->qratio[0] + 33u); put('\n');                         // codebook.c:515-517
+    put_table(cb->q); put('\n');                                 // :520-522
+    put_table(cb->q + A); put('\n');                             // :525-528
+    for (uint32_t s = 1; s < cb->C; ++s) {                       // :531-554
+        const uint32_t n = cb->nctx[s];
+        for (uint32_t j = 0; j < n; ++j) put(cb->qratio[(size_t)s * A + j] + 33u);
+        put('\n');
+        for (uint32_t b = 0; b < 2; ++b) {
+            for (uint32_t j = 0; j < n; ++j) put_table(cb->q + ((size_t)s * 2 * A + 2 * j + b) * A);
+            put('\n');
+        }
+    }
+    return pos;
+}
+
+extern "C" void qvz_codebook_tables(const qvz_codebook_t *cb, uint16_t *ct, uint16_t *qs) {
+    for (uint32_t s = 0; s < cb->C; ++s) {
+        for (int p = 0; p < A; ++p) {
+            const uint8_t ctx = cb->ctx_idx[(size_t)s * A + p];
+            ct[(size_t)s * A + p] = ctx == QVZ_NOT_FOUND
+                                        ? (uint16_t)QVZ_NOT_FOUND
+                                        : (uint16_t)(ctx | (cb->qratio[(size_t)s * A + ctx] << 8));
+        }
+        for (uint32_t qi = 0; qi < 2 * A; ++qi) {
+            const size_t t = ((size_t)s * 2 * A + qi) * A;
+            for (int x = 0; x < A; ++x) {
+                const uint8_t qv = cb->q[t + x];
+                qs[t + x] = (uint16_t)(qv | (cb->out_idx[t + qv] << 8));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device kernels
+// ------------------------------------------------------------------------------------------------
+// P[row][x] = cnt[row][x] / total(row)   (recalculate_pmf, pmf.c:219-230; all zero when total == 0)
+__global__ __launch_bounds__(64) void k_cond_pmf(const uint32_t *__restrict__ cnt, double *__restrict__ P) {
+    const uint64_t row = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c1 = cnt[row * A + lane];
+    const uint32_t c2 = lane < A - 64 ? cnt[row * A + 64 + lane] : 0;
+    uint32_t tot = c1 + c2;                                      // u32 like pmf_t.total (pmf.h:36)
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    const double t = (double)tot;
+    P[row * A + lane] = tot ? ((double)c1) / t : 0.0;
+    if (lane < A - 64) P[row * A + 64 + lane] = tot ? ((double)c2) / t : 0.0;
+}
+
+// marg[0] = 1.0*P[0][0] + 0.0*0 ; marg[s][x] = sum_j (1.0*marg[s][x] + marg[s-1][j]*P[s][j][x]) in j order
+// (codebook.c:213-218, combine_pmfs pmf.c:200-202)
+__global__ __launch_bounds__(128) void k_marginals(const double *__restrict__ P, uint32_t C, double *__restrict__ marg) {
+    __shared__ double prev[A];
+    const uint32_t x = threadIdx.x;
+    if (x < A) {
+        const double m0 = 1.0 * P[x] + 0.0 * 0.0;
+        prev[x] = m0;
+        marg[x] = m0;
+    }
+    __syncthreads();
+    for (uint32_t s = 1; s < C; ++s) {
+        double m = 0.0;
+        if (x < A) {
+            const double *Ps = P + (uint64_t)s * A * A;
+            for (int j = 0; j < A; ++j) m = 1.0 * m + prev[j] * Ps[j * A + x];
+        }
+        __syncthreads();
+        if (x < A) {
+            prev[x] = m;
+            marg[(uint64_t)s * A + x] = m;
+        }
+        __syncthreads();
+    }
+}
+
+// One column of the context recursion. Inputs (device): P, marg, previous column's qpmf, quantizer tables and
+// ratios of column s-1, context symbols of column s. Outputs: qpmf[72][72] (row x, entry idx) and
+// xpmf[nu][72] (row idx).
+__global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict__ P, const double *__restrict__ marg,
+                                                        uint32_t s, uint32_t nprev, uint32_t nu,
+                                                        const uint8_t *__restrict__ ctx_sym,   // [nu] symbols of column s
+                                                        const uint8_t *__restrict__ qprev,     // [144][72] tables of column s-1
+                                                        const double *__restrict__ rprev,      // [72] ratios of column s-1
+                                                        const double *__restrict__ prev_qpmf,  // [72][72]
+                                                        double *__restrict__ qpmf, double *__restrict__ xpmf) {
+    extern __shared__ double lds[];
+    double *bufA = lds;             // p_temp[k][j], later the final qpmf[x][idx]
+    double *bufB = lds + A * A;     // raw sums before renormalisation
+    const uint32_t tid = threadIdx.x;
+
+    if (s == 1) {
+        // compute_qpmf_quan_list (codebook.c:274-289): not renormalised
+        const double r0 = rprev[0];
+        for (uint32_t e = tid; e < A * nu; e += 1024) {
+            const uint32_t x = e / nu, idx = e % nu;
+            const uint32_t sym = ctx_sym[idx];
+            double v = 0.0;
+            if (qprev[x] == sym) v += r0;
+            if (qprev[A + x] == sym) v += (1 - r0);
+            bufA[x * A + idx] = v;
+        }
+    } else {
+        // hoisted p_temp(k,j) = sum_x prev_qpmf[x][j] * P_{s-1}(k|x) * marg_{s-2}[x]   (codebook.c:318-321)
+        const double *Pc = P + (uint64_t)(s - 1) * A * A;
+        const double *mm = marg + (uint64_t)(s - 2) * A;
+        for (uint32_t e = tid; e < A * nprev; e += 1024) {
+            const uint32_t k = e / nprev, j = e % nprev;
+            double pt = 0;
+            for (int x = 0; x < A; ++x) pt += prev_qpmf[x * A + j] * Pc[x * A + k] * mm[x];
+            bufA[k * A + j] = pt;
+        }
+        __syncthreads();
+        // qpmf[k][idx] += p_q_xq * p_temp over j                                      (codebook.c:301-322)
+        for (uint32_t e = tid; e < A * nu; e += 1024) {
+            const uint32_t k = e / nu, idx = e % nu;
+            const uint32_t sym = ctx_sym[idx];
+            double acc = 0.0;
+            for (uint32_t j = 0; j < nprev; ++j) {
+                double p_q_xq = 0.0;
+                const double rj = rprev[j];
+                if (qprev[(2 * j) * A + k] == sym) p_q_xq += rj;            // q_lo->ratio
+                if (qprev[(2 * j + 1) * A + k] == sym) p_q_xq += (1 - rj);  // q_hi->ratio
+                acc += p_q_xq * bufA[k * A + j];
+            }
+            bufB[k * A + idx] = acc;
+        }
+        __syncthreads();
+        // renormalize_pmf per row k (pmf.c:235-254): sequential total, true division when total > 0
+        for (uint32_t e = tid; e < A * nu; e += 1024) {
+            const uint32_t k = e / nu, idx = e % nu;
+            double total = 0;
+            for (uint32_t i = 0; i < nu; ++i) total += bufB[k * A + i];
+            const double v = bufB[k * A + idx];
+            bufA[k * A + idx] = total > 0 ? v / total : v;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < A * nu; e += 1024) {
+        const uint32_t x = e / nu, idx = e % nu;
+        qpmf[x * A + idx] = bufA[x * A + idx];
+    }
+    // compute_xpmf_list (codebook.c:332-349)
+    const double *Ps = P + (uint64_t)s * A * A;
+    const double *m1 = marg + (uint64_t)(s - 1) * A;
+    for (uint32_t e = tid; e < nu * A; e += 1024) {
+        const uint32_t idx = e / A, k = e % A;
+        double acc = 0.0;
+        for (int x = 0; x < A; ++x) acc += bufA[x * A + idx] * Ps[x * A + k] * m1[x];
+        bufB[idx * A + k] = acc;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < nu * A; e += 1024) {
+        const uint32_t idx = e / A, k = e % A;
+        double total = 0;
+        for (int i = 0; i < A; ++i) total += bufB[idx * A + i];
+        const double v = bufB[idx * A + k];
+        xpmf[idx * A + k] = total > 0 ? v / total : v;
+    }
+}
+
+// ---- Lloyd-Max search, one wave per context ------------------------------------------------------
+struct LmIn {
+    double target;
+    uint8_t mode;      // 0 skip, 1 search (startS = 0 fresh, > 0 resume from the stored hi design), 2 single design
+    uint8_t startS;
+    uint8_t pad[6];
+};
+
+struct LmOut {
+    double o[2][A];    // output pmfs of lo / hi (apply_quantizer, quantizer.c:139-161)
+    double hdev[2];    // device-side entropies (steering only)
+    uint8_t q[2][A];
+    uint8_t recon[2][A];
+    uint8_t S[2];
+    uint8_t flag;      // 1: stopped at S[1] because |H_dev - target| fell inside the guard band
+    uint8_t pad[5];
+};
+
+struct LmLds {
+    uint8_t bounds[80];
+    uint8_t q[2][A];
+    uint8_t recon[2][A];
+    uint32_t masks[A][4];
+};
+
+// One Lloyd-Max design (quantizer.c:34-132) for S states into slot `b`. All 64 lanes call it together.
+__device__ void lm_design(const double *__restrict__ p, const double *__restrict__ dl, uint32_t S, LmLds *L,
+                          double *__restrict__ o, int b) {
+    const uint32_t lane = threadIdx.x;
+    uint8_t *bounds = L->bounds, *recon = L->recon[b], *q = L->q[b];
+    if (lane == 0) { bounds[0] = 0; bounds[S] = A; }                                  // :45-46
+    for (uint32_t j = lane; j < S; j += 64) if (j >= 1) bounds[j] = (uint8_t)((j * A) / S);   // :47-49
+    __syncthreads();
+    for (uint32_t j = lane; j < S; j += 64) recon[j] = (uint8_t)((bounds[j] + bounds[j + 1] - 1) / 2);   // :50-52
+    __syncthreads();
+
+    uint32_t changed = 1, iter = 0;
+    while (changed && iter < 100) {                                                  // :57, quantizer.h:10
+        changed = 0;
+        iter += 1;
+        for (uint32_t j = 0; j < S; ++j) {                                           // :62-87
+            const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
+            const uint32_t r1 = b0 + lane, r2 = r1 + 64;
+            double best_v = DBL_MAX;
+            uint32_t best_r = b0;                                                    // min_r = bounds[j]
+            if (r1 < b1) {
+                double m = 0.0;
+                for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r1];
+                if (m < best_v) { best_v = m; best_r = r1; }
+            }
+            if (r2 < b1) {
+                double m = 0.0;
+                for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r2];
+                if (m < best_v) { best_v = m; best_r = r2; }
+            }
+            // first minimum wins (strict '<' scan in r order) == lexicographic min of (value, r)
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(best_v, off, 64);
+                const uint32_t orr = __shfl_xor(best_r, off, 64);
+                if (ov < best_v || (ov == best_v && orr < best_r)) { best_v = ov; best_r = orr; }
+            }
+            if (best_r != recon[j]) {
+                changed = 1;
+                if (lane == 0) recon[j] = (uint8_t)best_r;
+            }
+        }
+        __syncthreads();
+        // boundary walk (:93-107). flag(t, j) = d(j, recon[t+1]) < d(j, recon[t]) for j = 1..70 as ballot masks,
+        // then "advance at the first flagged j after the previous boundary" is a count-trailing-zeros per state.
+        for (uint32_t t = 0; t + 1 < S; ++t) {
+            const uint32_t ra = recon[t], rb = recon[t + 1];
+            const uint32_t j1 = lane, j2 = lane + 64;
+            const int f1 = (j1 >= 1) && (dl[j1 * A + rb] < dl[j1 * A + ra]);
+            const int f2 = (j2 <= A - 2) && (dl[j2 * A + rb] < dl[j2 * A + ra]);
+            const unsigned long long m1 = __ballot(f1), m2 = __ballot(f2);
+            if (lane == 0) {
+                L->masks[t][0] = (uint32_t)m1; L->masks[t][1] = (uint32_t)(m1 >> 32);
+                L->masks[t][2] = (uint32_t)m2; L->masks[t][3] = 0;
+            }
+        }
+        __syncthreads();
+        {
+            uint32_t t = 0, jprev = 0;   // stale bounds beyond the last advance are kept, as in the reference
+            while (t + 1 < S) {
+                const unsigned long long m1 = (unsigned long long)L->masks[t][0] | ((unsigned long long)L->masks[t][1] << 32);
+                const unsigned long long m2 = L->masks[t][2];
+                unsigned long long a1 = jprev < 63 ? (m1 & (~0ull << (jprev + 1))) : 0ull;
+                uint32_t jn;
+                if (a1) {
+                    jn = (uint32_t)__builtin_ctzll(a1);
+                } else {
+                    const uint32_t lo = jprev >= 64 ? jprev - 64 + 1 : 0;
+                    const unsigned long long a2 = lo < 64 ? (m2 & (~0ull << lo)) : 0ull;
+                    if (!a2) break;
+                    jn = 64 + (uint32_t)__builtin_ctzll(a2);
+                }
+                t += 1;
+                if (lane == 0) bounds[t] = (uint8_t)jn;
+                jprev = jn;
+            }
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t i = lane; i < A; i += 64) q[i] = 0;                                 // calloc, quantizer.c:14
+    __syncthreads();
+    for (uint32_t j = 0; j < S; ++j) {                                               // :112-116, later regions overwrite
+        const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
+        const uint8_t rj = recon[j];
+        if (b0 + lane < b1) q[b0 + lane] = rj;
+        if (b0 + lane + 64 < b1) q[b0 + lane + 64] = rj;
+        __syncthreads();
+    }
+    for (uint32_t v = lane; v < A; v += 64) {                                        // apply_quantizer :155-157
+        double acc = 0.0;
+        for (int i = 0; i < A; ++i)
+            if (q[i] == v) acc += p[i];
+        o[v] = acc;
+    }
+    __syncthreads();
+}
+
+__device__ double lm_entropy_dev(const double *o) {   // steering value only (device log2, tree order)
+    const uint32_t lane = threadIdx.x;
+    double t = 0.0;
+    for (uint32_t v = lane; v < A; v += 64) {
+        const double x = o[v];
+        if (x > 0.0) t += x * log2(x);
+    }
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    return -t;
+}
+
+__global__ __launch_bounds__(64) void k_lm_search(const double *__restrict__ pm, const double *__restrict__ dist,
+                                                  const LmIn *__restrict__ in, LmOut *__restrict__ out, double guard) {
+    extern __shared__ double sm[];
+    double *dl = sm;                  // dl[i*72 + r] = d(i, r) = dist[i + 72*r]  (lanes walk r: conflict-free)
+    double *p = sm + A * A;
+    double *o = p + A;                // o[2][72]
+    LmLds *L = reinterpret_cast<LmLds *>(o + 2 * A);
+    const uint32_t ctx = blockIdx.x, lane = threadIdx.x;
+    const LmIn I = in[ctx];
+    if (I.mode == 0) return;
+    for (uint32_t e = lane; e < A * A; e += 64) dl[e] = dist[(e / A) + A * (e % A)];
+    for (uint32_t e = lane; e < A; e += 64) p[e] = pm[(uint64_t)ctx * A + e];
+    __syncthreads();
+    LmOut *O = out + ctx;
+
+    int cur = 0;
+    uint32_t S = 1;
+    double H[2] = {0.0, 0.0};
+    uint8_t flag = 0;
+    if (I.mode == 2) {                // single design, stored as both lo and hi
+        S = I.startS;
+        lm_design(p, dl, S, L, o, 0);
+        H[0] = lm_entropy_dev(o);
+        for (uint32_t e = lane; e < A; e += 64) {
+            O->o[0][e] = o[e]; O->o[1][e] = o[e];
+            O->q[0][e] = L->q[0][e]; O->q[1][e] = L->q[0][e];
+            O->recon[0][e] = e < S ? L->recon[0][e] : 0; O->recon[1][e] = e < S ? L->recon[0][e] : 0;
+        }
+        if (lane == 0) { O->S[0] = (uint8_t)S; O->S[1] = (uint8_t)S; O->hdev[0] = H[0]; O->hdev[1] = H[0]; O->flag = 0; }
+        return;
+    }
+    if (I.startS) {                   // resume: the stored hi design becomes the current one
+        S = I.startS;
+        for (uint32_t e = lane; e < A; e += 64) {
+            o[e] = O->o[1][e];
+            L->q[0][e] = O->q[1][e];
+            L->recon[0][e] = O->recon[1][e];
+        }
+        H[0] = O->hdev[1];
+        __syncthreads();
+    } else {
+        lm_design(p, dl, 1, L, o, 0);                                               // codebook.c:244-246
+        H[0] = lm_entropy_dev(o);
+    }
+    for (;;) {                                                                       // codebook.c:249-258
+        cur ^= 1;
+        S += 1;
+        lm_design(p, dl, S, L, o + cur * A, cur);
+        H[cur] = lm_entropy_dev(o + cur * A);
+        if (S >= A) break;
+        const double diff = H[cur] - I.target;
+        if (fabs(diff) <= guard) { flag = 1; break; }      // host decides from libm
+        if (!(diff < 0.0)) break;                          // hi_entropy >= target
+    }
+    const int lo = cur ^ 1;
+    for (uint32_t e = lane; e < A; e += 64) {
+        O->o[0][e] = o[lo * A + e]; O->o[1][e] = o[cur * A + e];
+        O->q[0][e] = L->q[lo][e]; O->q[1][e] = L->q[cur][e];
+        O->recon[0][e] = e < S - 1 ? L->recon[lo][e] : 0; O->recon[1][e] = e < S ? L->recon[cur][e] : 0;
+    }
+    if (lane == 0) {
+        O->S[0] = (uint8_t)(S - 1); O->S[1] = (uint8_t)S;
+        O->hdev[0] = H[lo]; O->hdev[1] = H[cur];
+        O->flag = flag;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------------
+static double entropy_libm(const double *p) {                   // get_entropy, pmf.c:141-155
+    double e = 0.0;
+    for (int i = 0; i < A; ++i)
+        if (p[i] > 0.0) e -= p[i] * log2(p[i]);
+    return e;
+}
+
+// alphabet_union (pmf.c:312-357): a merge of two symbol lists
+static uint32_t merge_lists(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, uint8_t *out) {
+    uint8_t tmp[4 * A];
+    uint32_t i = 0, j = 0, k = 0;
+    while (i < na && j < nb) {
+        if (a[i] < b[j]) tmp[k] = a[i++];
+        else if (a[i] == b[j]) { tmp[k] = a[i]; ++i; ++j; }
+        else tmp[k] = b[j++];
+        ++k;
+    }
+    while (i < na) tmp[k++] = a[i++];
+    while (j < nb) tmp[k++] = b[j++];
+    memcpy(out, tmp, k);
+    return k;
+}
+
+struct ZeroDesign { uint8_t q[A], recon[A]; };
+
+struct CbWork {
+    double *P = nullptr, *marg = nullptr, *qpmf[2] = {nullptr, nullptr}, *xpmf = nullptr, *dist = nullptr, *zero_rows = nullptr;
+    double *rprev = nullptr;
+    uint8_t *qprev = nullptr, *ctx_sym = nullptr;
+    LmIn *lin = nullptr;
+    LmOut *lout = nullptr;
+    void release() {
+        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, qprev, ctx_sym, lin, lout};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+    }
+};
+
+static uint64_t g_deferred = 0;
+extern "C" uint64_t qvz_hip_codebook_deferred_decisions(void) { return g_deferred; }
+
+#define LM_LDS_BYTES ((A * A + A + 2 * A) * sizeof(double) + sizeof(LmLds))
+
+static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint8_t *q, const uint8_t *recon, uint32_t S) {
+    const size_t t = ((size_t)s * 2 * A + qi) * A;
+    memcpy(cb->q + t, q, A);
+    memset(cb->recon + t, 0, A);
+    memcpy(cb->recon + t, recon, S);
+    memset(cb->out_idx + t, QVZ_NOT_FOUND, A);
+    for (uint32_t j = 0; j < S; ++j) cb->out_idx[t + recon[j]] = (uint8_t)j;       // alphabet_compute_index, pmf.c:365-382
+    cb->nstates[(size_t)s * 2 * A + qi] = (uint8_t)S;
+}
+
+static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
+                    qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
+    const size_t tile = (size_t)A * A;
+    QVZ_HIP_CHECK(hipMalloc(&W.P, (size_t)C * tile * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.marg, (size_t)C * A * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.qpmf[0], tile * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.qpmf[1], tile * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.xpmf, tile * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.dist, tile * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.zero_rows, tile * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.rprev, A * sizeof(double)));
+    QVZ_HIP_CHECK(hipMalloc(&W.qprev, 2 * tile));
+    QVZ_HIP_CHECK(hipMalloc(&W.ctx_sym, A));
+    QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
+    QVZ_HIP_CHECK(hipMalloc(&W.lout, A * sizeof(LmOut)));
+    QVZ_HIP_CHECK(hipMemcpyAsync(W.dist, h_dist, tile * sizeof(double), hipMemcpyHostToDevice, st));
+    QVZ_HIP_CHECK(hipMemsetAsync(W.zero_rows, 0, tile * sizeof(double), st));
+    QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ctx_propagate),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile * sizeof(double))));
+
+    hipLaunchKernelGGL(k_cond_pmf, dim3(C * A), dim3(64), 0, st, d_cnt, W.P);
+    hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
+    QVZ_HIP_CHECK(hipGetLastError());
+
+    LmIn hin[A];
+    static LmOut hout[A];
+    double hx[A * A];
+    uint8_t hq[2 * A * A];
+    double hr[A];
+
+    // designs for the all-zero pmf depend only on (distortion, S): one launch, 72 waves
+    ZeroDesign Z[A + 1];
+    memset(hin, 0, sizeof(hin));
+    for (int S = 1; S <= A; ++S) { hin[S - 1].mode = 2; hin[S - 1].startS = (uint8_t)S; }
+    QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(hin), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_lm_search, dim3(A), dim3(64), LM_LDS_BYTES, st, W.zero_rows, W.dist, W.lin, W.lout, guard);
+    QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(hout), hipMemcpyDeviceToHost, st));
+    QVZ_HIP_CHECK(hipStreamSynchronize(st));
+    for (int S = 1; S <= A; ++S) { memcpy(Z[S].q, hout[S - 1].q[1], A); memcpy(Z[S].recon, hout[S - 1].recon[1], A); }
+
+    uint32_t nprev = 0;
+    int pq = 0;   // index of the qpmf buffer holding the previous column
+    for (uint32_t s = 0; s < C; ++s) {
+        uint32_t nu;
+        uint8_t uni[4 * A];
+        const double *d_rows;
+        if (s == 0) {                                                               // codebook.c:392-411
+            nu = 1;
+            uni[0] = 0;
+            d_rows = W.P;                                                           // get_cond_pmf(list, 0, 0)
+            QVZ_HIP_CHECK(hipMemcpyAsync(hx, W.P, A * sizeof(double), hipMemcpyDeviceToHost, st));
+        } else {                                                                    // codebook.c:419-438
+            const size_t b0 = ((size_t)(s - 1) * 2 * A) * A;
+            nu = cb->nstates[(size_t)(s - 1) * 2 * A];
+            memcpy(uni, cb->recon + b0, nu);
+            for (uint32_t j = 1; j < 2 * nprev; ++j)
+                nu = merge_lists(uni, nu, cb->recon + b0 + (size_t)j * A, cb->nstates[(size_t)(s - 1) * 2 * A + j], uni);
+            if (nu > A) return qvz_set_error(QVZ_E_DATA, "column %u: %u contexts exceed the alphabet", s, nu);
+            QVZ_HIP_CHECK(hipMemcpyAsync(W.ctx_sym, uni, nu, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_ctx_propagate, dim3(1), dim3(1024), 2 * tile * sizeof(double), st, W.P, W.marg, s, nprev, nu,
+                               W.ctx_sym, W.qprev, W.rprev, W.qpmf[pq], W.qpmf[pq ^ 1], W.xpmf);
+            QVZ_HIP_CHECK(hipGetLastError());
+            pq ^= 1;
+            d_rows = W.xpmf;
+            QVZ_HIP_CHECK(hipMemcpyAsync(hx, W.xpmf, (size_t)nu * A * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        QVZ_HIP_CHECK(hipStreamSynchronize(st));
+        cb->nctx[s] = (uint8_t)nu;
+        memcpy(cb->ctx_sym + (size_t)s * A, uni, nu);
+        for (uint32_t i = 0; i < nu; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
+
+        // targets (libm) and the per-context plan
+        bool zero[A];
+        double target[A];
+        bool any_gpu = false;
+        memset(hin, 0, sizeof(hin));
+        for (uint32_t j = 0; j < nu; ++j) {
+            const double *pj = hx + (size_t)j * A;
+            zero[j] = true;
+            for (int i = 0; i < A; ++i) if (pj[i] != 0.0) { zero[j] = false; break; }
+            target[j] = mode == QVZ_MODE_RATIO ? entropy_libm(pj) * opt_ratio : opt_ratio;   // codebook.c:444-447
+            if (!zero[j]) {
+                hin[j].target = target[j];
+                hin[j].mode = target[j] == 0.0 ? 2 : 1;                            // :236-242 vs the search
+                hin[j].startS = target[j] == 0.0 ? 1 : 0;
+                any_gpu = true;
+            }
+        }
+        while (any_gpu) {
+            QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(LmIn) * nu, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_lm_search, dim3(nu), dim3(64), LM_LDS_BYTES, st, d_rows, W.dist, W.lin, W.lout, guard);
+            QVZ_HIP_CHECK(hipGetLastError());
+            QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmOut) * nu, hipMemcpyDeviceToHost, st));
+            QVZ_HIP_CHECK(hipStreamSynchronize(st));
+            any_gpu = false;
+            for (uint32_t j = 0; j < nu; ++j) {
+                if (hin[j].mode != 1) { hin[j].mode = 0; continue; }
+                hin[j].mode = 0;
+                if (hout[j].flag) {                                                 // decision inside the guard band
+                    g_deferred += 1;
+                    const double Hhi = entropy_libm(hout[j].o[1]);
+                    if (Hhi < target[j] && hout[j].S[1] < A) {                      // reference keeps searching
+                        hin[j].mode = 1;
+                        hin[j].startS = hout[j].S[1];
+                        any_gpu = true;
+                    }
+                }
+            }
+        }
+
+        // ratios from libm entropies, store (optimize_for_entropy :263-268, store_cond_quantizers_indexed :152-157)
+        for (uint32_t j = 0; j < nu; ++j) {
+            double ratio;
+            if (zero[j]) {
+                // every design of a zero pmf has entropy 0: replay the search loop on the host
+                if (target[j] == 0.0) {
+                    store_design(cb, s, 2 * j, Z[1].q, Z[1].recon, 1);
+                    store_design(cb, s, 2 * j + 1, Z[1].q, Z[1].recon, 1);
+                    ratio = 1.0;
+                } else {
+                    uint32_t states = 1;
+                    do { states += 1; } while (0.0 < target[j] && states < A);
+                    store_design(cb, s, 2 * j, Z[states - 1].q, Z[states - 1].recon, states - 1);
+                    store_design(cb, s, 2 * j + 1, Z[states].q, Z[states].recon, states);
+                    if (0.0 < target[j]) ratio = 0.0;
+                    else ratio = 1.0;                                               // lo_entropy (0) >= target
+                }
+            } else {
+                const LmOut &o = hout[j];
+                store_design(cb, s, 2 * j, o.q[0], o.recon[0], o.S[0]);
+                store_design(cb, s, 2 * j + 1, o.q[1], o.recon[1], o.S[1]);
+                if (target[j] == 0.0) {
+                    ratio = 1.0;
+                } else {
+                    const double lo_entropy = entropy_libm(o.o[0]), hi_entropy = entropy_libm(o.o[1]);
+                    if (hi_entropy < target[j]) ratio = 0.0;
+                    else if (lo_entropy >= target[j] || hi_entropy == lo_entropy) ratio = 1.0;
+                    else ratio = (target[j] - hi_entropy) / (lo_entropy - hi_entropy);
+                }
+            }
+            cb->ratio[(size_t)s * A + j] = ratio;
+            cb->qratio[(size_t)s * A + j] = (uint8_t)(ratio * 128.);
+        }
+        // hand this column's tables and ratios to the next column's propagation
+        memcpy(hq, cb->q + (size_t)s * 2 * tile, 2 * tile);
+        for (uint32_t j = 0; j < A; ++j) hr[j] = j < nu ? cb->ratio[(size_t)s * A + j] : 0.0;
+        QVZ_HIP_CHECK(hipMemcpyAsync(W.qprev, hq, 2 * tile, hipMemcpyHostToDevice, st));
+        QVZ_HIP_CHECK(hipMemcpyAsync(W.rprev, hr, sizeof(hr), hipMemcpyHostToDevice, st));
+        QVZ_HIP_CHECK(hipStreamSynchronize(st));   // hq / hr are stack buffers reused next column
+        nprev = nu;
+    }
+    return QVZ_OK;
+}
+
+extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
+                                         double guard, qvz_codebook_t *out, void *stream) {
+    if (!d_cnt || !h_dist || !out || out->C != C || C == 0) return qvz_set_error(QVZ_E_ARG, "bad codebook arguments");
+    if (mode != QVZ_MODE_RATIO && mode != QVZ_MODE_FIXED) return qvz_set_error(QVZ_E_ARG, "unknown mode %d", mode);
+    if (guard <= 0.0) guard = 1e-9;
+    g_deferred = 0;
+    memset(out->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
+    CbWork W;
+    const int rc = generate(d_cnt, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, W);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    W.release();
+    return rc;
+}

@@ -131,3 +131,85 @@ def quantize(sym, n, ct, qs, words, first_draw, dist, labels=None, k=1, want=("q
                                  _ptr(status), _stream()))
     out["status"] = status
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# codebooks (include/qvz_codebook.h)
+# ------------------------------------------------------------------------------------------------
+class _CodebookStruct(C.Structure):
+    _fields_ = [("C", C.c_uint32), ("nctx", C.POINTER(C.c_uint8)), ("ctx_sym", C.POINTER(C.c_uint8)),
+                ("ctx_idx", C.POINTER(C.c_uint8)), ("qratio", C.POINTER(C.c_uint8)), ("ratio", C.POINTER(C.c_double)),
+                ("q", C.POINTER(C.c_uint8)), ("nstates", C.POINTER(C.c_uint8)), ("recon", C.POINTER(C.c_uint8)),
+                ("out_idx", C.POINTER(C.c_uint8))]
+
+
+class Codebook:
+    """Owns one qvz_codebook_t (host, flat) and exposes its arrays as numpy views."""
+
+    def __init__(self, c):
+        self.c = c
+        self.handle = lib().qvz_codebook_alloc(c)
+        if not self.handle:
+            raise MemoryError("qvz_codebook_alloc")
+        s = C.cast(self.handle, C.POINTER(_CodebookStruct)).contents
+        as_np = np.ctypeslib.as_array
+        self.nctx = as_np(s.nctx, (c,))
+        self.ctx_sym = as_np(s.ctx_sym, (c, A))
+        self.ctx_idx = as_np(s.ctx_idx, (c, A))
+        self.qratio = as_np(s.qratio, (c, A))
+        self.ratio = as_np(s.ratio, (c, A))
+        self.q = as_np(s.q, (c, 2 * A, A))
+        self.nstates = as_np(s.nstates, (c, 2 * A))
+        self.recon = as_np(s.recon, (c, 2 * A, A))
+        self.out_idx = as_np(s.out_idx, (c, 2 * A, A))
+
+    def __del__(self):
+        try:
+            lib().qvz_codebook_free(self.handle)
+        except Exception:
+            pass
+
+    def serialize(self):
+        n = lib().qvz_codebook_write(None, self.handle)
+        buf = np.zeros(n, dtype=np.uint8)
+        lib().qvz_codebook_write(buf.ctypes.data_as(C.c_void_p), self.handle)
+        return buf.tobytes()
+
+    def tables(self):
+        """(ct, qs) host arrays in the quantizer's device-table layout (include/qvz_hip.h)."""
+        ct = np.zeros((self.c, A), dtype=np.uint16)
+        qs = np.zeros((self.c, 2 * A, A), dtype=np.uint16)
+        lib().qvz_codebook_tables(self.handle, ct.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p))
+        return ct, qs
+
+
+def distortion_matrix(kind):
+    code = {"A": 1, "M": 2, "L": 3}.get(kind, kind)
+    d = np.zeros(A * A, dtype=np.float64)
+    check(lib().qvz_distortion_matrix(code, d.ctypes.data_as(C.POINTER(C.c_double))))
+    return d
+
+
+def write_header(clusters, columns, lines):
+    buf = np.zeros(9, dtype=np.uint8)
+    lib().qvz_codebook_write_header(buf.ctypes.data_as(C.c_void_p), clusters, columns, lines)
+    return buf.tobytes()
+
+
+def generate_codebook(cnt_cluster, dist, mode, ratio, guard=0.0):
+    """cnt_cluster: (c, 72, 72) int32 device tensor of one cluster. Returns (Codebook, deferred_decisions)."""
+    c = cnt_cluster.shape[0]
+    assert cnt_cluster.is_contiguous() and cnt_cluster.dtype == torch.int32
+    cb = Codebook(c)
+    d = np.ascontiguousarray(dist, dtype=np.float64)
+    check(lib().qvz_hip_generate_codebook(_ptr(cnt_cluster), c, d.ctypes.data_as(C.POINTER(C.c_double)), mode,
+                                          float(ratio), float(guard), cb.handle, _stream()))
+    return cb, int(lib().qvz_hip_codebook_deferred_decisions())
+
+
+def upload_tables(cbs, device="cuda"):
+    """Stack the quantizer tables of k codebooks on the device: ct (k, c, 72), qs (k, c, 144, 72) as int16."""
+    cts, qss = zip(*[cb.tables() for cb in cbs])
+    ct = torch.from_numpy(np.stack(cts).view(np.int16)).to(device)
+    qs = torch.from_numpy(np.stack(qss).view(np.int16)).to(device)
+    return ct, qs

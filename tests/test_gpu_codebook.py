@@ -1,0 +1,108 @@
+"""GPU parity of codebook generation (Lloyd-Max, rate search, context recursion) against the CPU oracle and the
+reference's own codebook bytes. Bit-exact: the codebook decides the bitstream."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def K():
+    from qvz_amd import kernels
+    return kernels
+
+
+def oracle_codebooks(name):
+    rows = G.case_rows(name)
+    opts = G.case_opts(name)
+    labels = O.kmeans(rows, opts["k"])[0]
+    cnt = O.stats(rows, labels, opts["k"])
+    d = O.distortion(opts["dist"])
+    return rows, opts, cnt, d, [O.generate_codebook(cnt[j], d, opts["mode"], opts["ratio"]) for j in range(opts["k"])]
+
+
+def assert_same_codebook(cb, ref):
+    assert cb.serialize() == ref.serialize(), "serialised codebook differs"
+    np.testing.assert_array_equal(cb.nctx, ref.nctx)
+    for s in range(cb.c):
+        n = int(ref.nctx[s])
+        assert cb.ratio[s, :n].tobytes() == ref.ratio[s, :n].tobytes(), f"ratio bits differ in column {s}"
+        np.testing.assert_array_equal(cb.ctx_sym[s, :n], ref.ctx_sym[s, :n])
+        np.testing.assert_array_equal(cb.ctx_idx[s], ref.ctx_idx[s])
+        np.testing.assert_array_equal(cb.nstates[s, : 2 * n], ref.nstates[s, : 2 * n])
+        np.testing.assert_array_equal(cb.recon[s, : 2 * n], ref.recon[s, : 2 * n])
+        np.testing.assert_array_equal(cb.out_idx[s, : 2 * n], ref.out_idx[s, : 2 * n])
+
+
+def test_distortion_matrices_bit_identical(K):
+    for kind in "MLA":
+        assert K.distortion_matrix(kind).tobytes() == O.distortion(kind).tobytes()
+
+
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_codebook_matches_oracle_and_reference_bytes(K, name):
+    rows, opts, cnt, d, refs = oracle_codebooks(name)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    blob = K.write_header(opts["k"], c, n)
+    for j in range(opts["k"]):
+        cb, deferred = K.generate_codebook(torch.from_numpy(cnt[j].view(np.int32)).cuda(), K.distortion_matrix(opts["dist"]),
+                                           opts["mode"], opts["ratio"])
+        assert_same_codebook(cb, refs[j])
+        blob += cb.serialize()
+    if G.CASES[name]["stored"]:
+        q = G.gz(name + ".q.gz")
+        assert q[: len(blob)] == blob, "codebook section differs from the reference's .q file"
+
+
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "uniform72_f09_M", "r35_high_rate"])
+def test_host_decides_everything_with_infinite_guard(K, name):
+    """Rare-branch test: with a huge guard band every search decision is deferred to host libm and the search is
+    resumed state by state; the codebook must not change."""
+    rows, opts, cnt, d, refs = oracle_codebooks(name)
+    cb, deferred = K.generate_codebook(torch.from_numpy(cnt[0].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"],
+                                       guard=1e30)
+    assert deferred > 0
+    assert_same_codebook(cb, refs[0])
+    cb2, deferred2 = K.generate_codebook(torch.from_numpy(cnt[0].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"])
+    assert deferred2 <= deferred
+    assert_same_codebook(cb2, refs[0])
+
+
+def test_device_tables_match_python_builder(K):
+    from test_gpu_kernels import tables_from_codebooks
+    rows, opts, cnt, d, refs = oracle_codebooks("t2k_c3_f05_M")
+    cbs = [K.generate_codebook(torch.from_numpy(cnt[j].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"])[0]
+           for j in range(opts["k"])]
+    ct, qs = K.upload_tables(cbs)
+    rct, rqs = tables_from_codebooks(refs)
+    # only defined entries are compared: contexts beyond nctx are never addressed
+    assert torch.equal(ct, rct)
+    for j, ref in enumerate(refs):
+        for s in range(ref.c):
+            n = 2 * int(ref.nctx[s])
+            assert torch.equal(qs[j, s, :n], rqs[j, s, :n])
+
+
+def test_end_to_end_device_pipeline_reproduces_u_file(K):
+    """PMF counters -> codebook -> tables -> WELL -> quantize, all on the device, against the reference -u dump."""
+    name = "cfg1_r10_M"
+    rows = G.case_rows(name)
+    opts = G.case_opts(name)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    sym = K.qgen1(1, n, c)
+    cnt = K.pmf_hist(sym, n)
+    dist = K.distortion_matrix(opts["dist"])
+    cb, _ = K.generate_codebook(cnt[0], dist, opts["mode"], opts["ratio"])
+    ct, qs = K.upload_tables([cb])
+    words = K.well_words(O.WELL_DEBUG_STATE, 0, (n * c + 3) // 4)
+    out = K.quantize(sym, n, ct, qs, words, 0, torch.from_numpy(dist).cuda())
+    assert int(out["status"].item()) == 0
+    text = K.untranspose_text(out["qv"], n).cpu().numpy().tobytes()
+    assert G.md5(text) == G.CASES[name]["u_md5"]
+    q = G.gz(name + ".q.gz")
+    blob = K.write_header(1, c, n) + cb.serialize()
+    assert q[: len(blob)] == blob
