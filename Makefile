@@ -1,22 +1,39 @@
-# Builds the MI355X (gfx950) product: libqvzhip.so (HIP kernels + C-ABI, include/qvz_hip.h).
+# Builds the MI355X (gfx950) product:
+#   qvz_amd/libqvzhip.so  HIP kernels (hipcc) + host C layer (gcc): everything declared in include/*.h
+#   qvz_amd/bin/qvz       the drop-in command line front end (C), linked against the library
 # hipcc cross-compiles without a GPU. -ffp-contract=off: the codebook path is decision-bearing FP64 and the
 # reference is built without FMA (hard part 2).
 HIPCC    ?= hipcc
+CC       ?= gcc
 ARCH     ?= gfx950
 HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -std=c++17 -Iinclude -Iqvz_amd/csrc
+CFLAGS   ?= -O2 -ffp-contract=off -fPIC -std=gnu11 -Wall -Wextra -Iinclude
 CSRC     := qvz_amd/csrc
 HIP_SRCS := $(wildcard $(CSRC)/*.hip)
+HOST_SRCS:= $(CSRC)/host/qvz_coder.c $(CSRC)/host/qvz_encode.c
+HOST_OBJS:= $(HOST_SRCS:.c=.o)
+HIP_OBJS := $(HIP_SRCS:.hip=.hip.o)
 HDRS     := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h)
 
-all: qvz_amd/libqvzhip.so
+all: qvz_amd/libqvzhip.so qvz_amd/bin/qvz
 
-qvz_amd/libqvzhip.so: $(HIP_SRCS) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+$(CSRC)/host/%.o: $(CSRC)/host/%.c $(HDRS)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(CSRC)/%.hip.o: $(CSRC)/%.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+qvz_amd/libqvzhip.so: $(HIP_OBJS) $(HOST_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) $(HOST_OBJS) -lm -lpthread
+
+qvz_amd/bin/qvz: $(CSRC)/host/qvz_main.c qvz_amd/libqvzhip.so $(HDRS)
+	mkdir -p qvz_amd/bin
+	$(CC) $(CFLAGS) -fPIE -o $@ $(CSRC)/host/qvz_main.c -Lqvz_amd -lqvzhip -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath-link,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f qvz_amd/libqvzhip.so
+	rm -f qvz_amd/libqvzhip.so qvz_amd/bin/qvz $(HOST_OBJS) $(HIP_OBJS)
 
 .PHONY: all oracle clean

@@ -1,0 +1,51 @@
+/* qvz_coder.h - host-side adaptive arithmetic coder of the qvz bitstream (plain C).
+ *
+ * Replaces compress_qv / qv_write_cluster (reference src/qv_compressor.c:8-22), arithmetic_encoder_step and
+ * encoder_last_step (src/arith.c:24-116), update_stats and the stats initialisation (src/qv_stream.c:9-61,96-108)
+ * and the MSB-first bit writer (src/os_stream.c:72-120). The reference's stream is one serial chain of
+ * interval updates, so this part stays on a host core; the GPU hands it the (quantizer index, state) feed.
+ *
+ * Exactness: output bytes are identical to the reference's. Two restructurings are used, both exact:
+ *   - the E1/E2 and E3 renormalisation loops run as one count-leading-zeros batch each per symbol (after the
+ *     E1/E2 batch msb(l)=0, msb(u)=1 and E3 shifts preserve that, so one batch of each suffices);
+ *   - floor(range*cum/n) is taken as (uint64)((double)(range*cum) / (double)n): with range*cum < 2^42 and
+ *     n < 2^21 the true quotient is either an integer or at least 2^-21 away from one, far more than the
+ *     2^-53 relative rounding of one IEEE division, so the truncation is exact.
+ */
+#ifndef QVZ_CODER_H
+#define QVZ_CODER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "qvz_codebook.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qvz_coder qvz_coder_t;
+
+/* cbs: `clusters` codebooks (their nctx / nstates define the model, qv_stream.c:46-53). The coder appends to
+ * an internal growable byte buffer. */
+qvz_coder_t *qvz_coder_create(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs);
+void qvz_coder_destroy(qvz_coder_t *cd);
+
+/* Encodes `reads` reads in file order. labels[i] (NULL when clusters == 1), feed[i*columns + s] = quantizer
+ * index (low byte) | state index (high byte) as produced by qvz_hip_pack_feed. Returns 0, or -1 when a feed
+ * entry addresses a quantizer the codebook does not define or a state outside its alphabet. */
+int qvz_coder_encode(qvz_coder_t *cd, const uint8_t *labels, const uint16_t *feed, uint64_t reads);
+
+/* encoder_last_step (arith.c:99-116): flush the tag and pad. After this the buffer is complete. */
+void qvz_coder_finish(qvz_coder_t *cd);
+
+/* Bytes produced so far (complete bytes only until qvz_coder_finish) and access to them. take() hands out the
+ * first `*size` bytes and drops them from the coder, so a long stream can be written to disk incrementally. */
+uint64_t qvz_coder_bytes(const qvz_coder_t *cd);
+const uint8_t *qvz_coder_data(const qvz_coder_t *cd, uint64_t *size);
+void qvz_coder_drop(qvz_coder_t *cd, uint64_t size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+/* qvz_encode.h - host C driver of the MI355X encode path: the counterpart of encode() in the reference's
+ * src/main.c:18-127, calling the HIP kernels through include/qvz_hip.h / qvz_codebook.h and running the serial
+ * arithmetic coder (include/qvz_coder.h) on the host, overlapped with the GPU.
+ *
+ * Output files are byte-identical to the reference's for the same 128-byte WELL state:
+ *   .q  = 9-byte header + codebooks (src/codebook.c:474-555) + WELL state (src/qv_stream.c:89) + stream
+ *   -u  = quantized symbols as text (src/qv_compressor.c:100-125)
+ */
+#ifndef QVZ_ENCODE_H
+#define QVZ_ENCODE_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#include "qvz_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QVZ_SEED_TIME 0      /* srand(time(0)); 32 x rand()          (reference default, qv_stream.c:77-81) */
+#define QVZ_SEED_DEBUG 1     /* 32 x 0x55555555                      (reference -DDEBUG, qv_stream.c:83)   */
+#define QVZ_SEED_EXPLICIT 2  /* options.well_state                                                          */
+
+typedef struct qvz_options {
+    /* the fields of qv_options_t the encoder reads (reference include/codebook.h:28-40) */
+    int verbose;
+    int stats;
+    int mode;                 /* QVZ_MODE_RATIO (-f) or QVZ_MODE_FIXED (-r) */
+    int clusters;             /* -c */
+    int distortion;           /* QVZ_DIST_* (-d) */
+    double ratio;             /* argument of -f / -r */
+    double cluster_threshold; /* -T */
+    const char *uncompressed_name; /* -u, or NULL */
+    /* additions of this implementation */
+    int device;               /* HIP device ordinal */
+    int seed_mode;            /* QVZ_SEED_* */
+    uint32_t well_state[32];  /* used when seed_mode == QVZ_SEED_EXPLICIT */
+    uint64_t chunk_reads;     /* reads per quantize/encode chunk (0 = default) */
+} qvz_options_t;
+
+typedef struct qvz_result {
+    uint64_t lines;
+    uint32_t columns;
+    uint64_t stream_bytes;    /* os->written: arithmetic stream only, what "-s" calls size (main.c:125) */
+    uint64_t file_bytes;      /* whole .q file */
+    double distortion;        /* bit-identical to the reference's value (sequential sum in read order) */
+    uint32_t kmeans_iterations;
+    uint64_t deferred_decisions; /* codebook search decisions taken by host libm inside the guard band */
+    double t_upload, t_cluster, t_stats, t_codebook, t_encode, t_total;   /* seconds */
+} qvz_result_t;
+
+void qvz_options_default(qvz_options_t *o);   /* reference defaults, main.c:198-204 (+ mode = RATIO) */
+
+/* text: the whole input file image (rows of c+1 bytes). fout receives the .q file, fu (may be NULL) the -u text. */
+int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
+                      qvz_result_t *res);
+/* mmaps `in_path` like load_file (lines.c:27-82) and encodes it to `out_path`. */
+int qvz_encode_file(const char *in_path, const char *out_path, const qvz_options_t *opts, qvz_result_t *res);
+
+const char *qvz_encode_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -49,6 +49,20 @@ const char *qvz_hip_last_error(void);
 uint64_t qvz_hip_ld(uint64_t n);
 int qvz_hip_device_count(void);
 
+/* Device memory / stream plumbing so that host C code (qvz_amd/csrc/host) needs no HIP headers.
+ * The reference has no counterpart: it mmaps the input and callocs everything (src/lines.c:64,116). */
+int qvz_hip_set_device(int device);
+int qvz_hip_malloc(void **d_ptr, size_t bytes);
+int qvz_hip_free(void *d_ptr);
+int qvz_hip_malloc_host(void **h_ptr, size_t bytes);   /* pinned host memory for async copies */
+int qvz_hip_free_host(void *h_ptr);
+int qvz_hip_memset(void *d_ptr, int value, size_t bytes, void *stream);
+int qvz_hip_copy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int qvz_hip_copy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int qvz_hip_stream_create(void **stream);
+int qvz_hip_stream_destroy(void *stream);
+int qvz_hip_stream_sync(void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Input staging. Replaces the row-major pointer view built by load_file (reference
  * src/lines.c:27-82: C from the first line, N = size/(C+1), one line_t per read).
@@ -77,7 +91,8 @@ int qvz_hip_kmeans_assign(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t
 int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c,
                               uint64_t ld, uint32_t k, uint64_t *d_acc /*[k][c], +=*/, void *stream);
 /* second pass of recalculate_means (cluster.c:104-128): mean = acc/count (floor), moved_j = sum (dmean)^2.
- * d_moved[0] = max_j moved_j (double, exact integer). d_status[0] |= 1 if a cluster is empty. */
+ * d_moved: k+1 doubles (exact integers): [0] = max_j moved_j, [1+j] = moved_j.
+ * d_status[0] |= 1 if a cluster is empty. */
 int qvz_hip_kmeans_update(const uint64_t *d_acc, const uint32_t *d_counts, uint32_t k, uint32_t c,
                           uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream);
 
@@ -116,13 +131,19 @@ int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32_t *h_state
  * d_words: WELL words covering draws [first_draw, first_draw + n*c); d_words[0] holds draw
  *          (first_draw & ~3). first_draw = (global index of read 0 of this call) * c.
  * h_dist: 72x72 doubles d[x + 72*y] (reference distortion.c:151).
- * Outputs (each may be NULL): d_qv / d_qi / d_st column-major like d_sym: quantized value, quantizer
+ * Outputs (each may be NULL): d_qv / d_qi / d_st column-major with pitch ld_out (a multiple of 256, >= n; lets a
+ * chunk of a large matrix be quantized into chunk-sized buffers): quantized value, quantizer
  * index 2*ctx+b and state index per symbol; d_err[i] = per-read sum of d(x,qv) accumulated in column
  * order exactly as the reference does (bit-identical double); d_status |= QVZ_E_DEAD_CTX flags. */
 int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
                      uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint32_t *d_words,
                      uint64_t first_draw, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi,
-                     uint8_t *d_st, double *d_err, int32_t *d_status, void *stream);
+                     uint8_t *d_st, uint64_t ld_out, double *d_err, int32_t *d_status, void *stream);
+
+/* Coder feed: column-major quantizer indices / state indices (pitch ld) -> read-major pairs
+ * d_feed[i*c + s] = qi | st << 8, the order compress_qv consumes them in (qv_compressor.c:89-119). */
+int qvz_hip_pack_feed(const uint8_t *d_qi, const uint8_t *d_st, uint64_t n, uint32_t c, uint64_t ld,
+                      uint16_t *d_feed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,19 @@ SIGNATURES = {
     "qvz_hip_well_words": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, u32p, C.c_void_p]),
     "qvz_hip_well_jump": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_hip_quantize": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u16p, u16p, u32p,
-                                   C.c_uint64, f64p, u8p, u8p, u8p, f64p, C.c_void_p, C.c_void_p]),
+                                   C.c_uint64, f64p, u8p, u8p, u8p, C.c_uint64, f64p, C.c_void_p, C.c_void_p]),
+    "qvz_hip_pack_feed": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, u16p, C.c_void_p]),
+    "qvz_hip_set_device": (C.c_int, [C.c_int]),
+    "qvz_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "qvz_hip_free": (C.c_int, [C.c_void_p]),
+    "qvz_hip_malloc_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "qvz_hip_free_host": (C.c_int, [C.c_void_p]),
+    "qvz_hip_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "qvz_hip_copy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "qvz_hip_copy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "qvz_hip_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "qvz_hip_stream_destroy": (C.c_int, [C.c_void_p]),
+    "qvz_hip_stream_sync": (C.c_int, [C.c_void_p]),
     # include/qvz_codebook.h
     "qvz_codebook_alloc": (C.c_void_p, [C.c_uint32]),
     "qvz_codebook_free": (None, [C.c_void_p]),
@@ -41,6 +53,19 @@ SIGNATURES = {
     "qvz_codebook_tables": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "qvz_codebook_write_header": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "qvz_codebook_write": (C.c_size_t, [C.c_void_p, C.c_void_p]),
+    # include/qvz_coder.h (host C)
+    "qvz_coder_create": (C.c_void_p, [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "qvz_coder_destroy": (None, [C.c_void_p]),
+    "qvz_coder_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "qvz_coder_finish": (None, [C.c_void_p]),
+    "qvz_coder_bytes": (C.c_uint64, [C.c_void_p]),
+    "qvz_coder_data": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "qvz_coder_drop": (None, [C.c_void_p, C.c_uint64]),
+    # include/qvz_encode.h (host C)
+    "qvz_options_default": (None, [C.c_void_p]),
+    "qvz_encode_buffer": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qvz_encode_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "qvz_encode_last_error": (C.c_char_p, []),
 }
 
 _lib = None

@@ -1,0 +1,194 @@
+/* qvz_coder.c - see include/qvz_coder.h. Plain C, one stream per coder object, no global state. */
+#include "qvz_coder.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define A QVZ_A
+#define M_BITS 22u                           /* m_arith, reference include/qvz_compressor.h:19 */
+#define MSB (1u << (M_BITS - 1))
+#define MASK_M ((1u << M_BITS) - 1)
+#define MASK_M1 ((1u << (M_BITS - 1)) - 1)
+#define RESCALE (1u << (M_BITS - 3))         /* a->r, arith.c:11 */
+#define STEP 8u                              /* qv_stream.c:56 */
+#define NO_TABLE 0xFFFFFFFFu
+
+struct qvz_coder {
+    uint32_t clusters, columns;
+    uint32_t *arena;          /* tables back to back: [n][card][counts...] */
+    uint32_t *offset;         /* [clusters][columns][144] -> arena index or NO_TABLE */
+    uint32_t cluster_table;   /* arena index of the cluster-id model */
+    uint32_t l, u;
+    uint64_t scale3;
+    uint64_t acc;             /* bit accumulator, MSB-first */
+    uint32_t nbits;
+    uint8_t *buf;
+    uint64_t len, cap, dropped;
+};
+
+static int buf_reserve(qvz_coder_t *cd, uint64_t extra) {
+    if (cd->len + extra <= cd->cap) return 0;
+    uint64_t ncap = cd->cap ? cd->cap * 2 : (1u << 20);
+    while (ncap < cd->len + extra) ncap *= 2;
+    uint8_t *nb = (uint8_t *)realloc(cd->buf, ncap);
+    if (!nb) return -1;
+    cd->buf = nb;
+    cd->cap = ncap;
+    return 0;
+}
+
+/* append `count` (<= 32) bits, most significant first (stream_write_bit order, os_stream.c:72-92) */
+static inline void put_bits(qvz_coder_t *cd, uint32_t value, uint32_t count) {
+    cd->acc = (cd->acc << count) | (value & (count == 32 ? 0xFFFFFFFFu : ((1u << count) - 1)));
+    cd->nbits += count;
+    while (cd->nbits >= 8) {
+        cd->nbits -= 8;
+        cd->buf[cd->len++] = (uint8_t)(cd->acc >> cd->nbits);
+    }
+}
+
+static inline void put_run(qvz_coder_t *cd, uint32_t bit, uint64_t count) {
+    const uint32_t pattern = bit ? 0xFFFFFFFFu : 0u;
+    while (count) {
+        uint32_t c = count > 32 ? 32 : (uint32_t)count;
+        if (cd->len + 8 > cd->cap) buf_reserve(cd, 4096);
+        put_bits(cd, pattern, c);
+        count -= c;
+    }
+}
+
+qvz_coder_t *qvz_coder_create(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs) {
+    qvz_coder_t *cd = (qvz_coder_t *)calloc(1, sizeof(*cd));
+    if (!cd) return NULL;
+    cd->clusters = clusters;
+    cd->columns = columns;
+    size_t words = 2 + clusters;
+    for (uint32_t c = 0; c < clusters; ++c)
+        for (uint32_t s = 0; s < columns; ++s)
+            for (uint32_t j = 0; j < 2u * cbs[c]->nctx[s]; ++j) words += 2 + cbs[c]->nstates[(size_t)s * 2 * A + j];
+    cd->arena = (uint32_t *)malloc(words * sizeof(uint32_t));
+    cd->offset = (uint32_t *)malloc((size_t)clusters * columns * 2 * A * sizeof(uint32_t));
+    if (!cd->arena || !cd->offset || buf_reserve(cd, 1u << 20)) { qvz_coder_destroy(cd); return NULL; }
+    uint32_t pos = 0;
+    cd->cluster_table = pos;                                    /* qv_stream.c:96-104 */
+    cd->arena[pos++] = clusters;
+    cd->arena[pos++] = clusters;
+    for (uint32_t c = 0; c < clusters; ++c) cd->arena[pos++] = 1;
+    for (uint32_t c = 0; c < clusters; ++c)
+        for (uint32_t s = 0; s < columns; ++s)
+            for (uint32_t j = 0; j < 2 * A; ++j) {
+                uint32_t *off = &cd->offset[((size_t)c * columns + s) * 2 * A + j];
+                if (j >= 2u * cbs[c]->nctx[s]) { *off = NO_TABLE; continue; }
+                const uint32_t card = cbs[c]->nstates[(size_t)s * 2 * A + j];   /* qv_stream.c:46-53 */
+                *off = pos;
+                cd->arena[pos++] = card;       /* n */
+                cd->arena[pos++] = card;       /* alphabetCard */
+                for (uint32_t i = 0; i < card; ++i) cd->arena[pos++] = 1;
+            }
+    cd->l = 0;                                                  /* arith.c:12-13 */
+    cd->u = MASK_M;
+    return cd;
+}
+
+void qvz_coder_destroy(qvz_coder_t *cd) {
+    if (!cd) return;
+    free(cd->arena); free(cd->offset); free(cd->buf);
+    free(cd);
+}
+
+static inline uint32_t clz_field(uint32_t v, uint32_t width) {   /* leading zeros inside a `width`-bit field */
+    return v ? (uint32_t)__builtin_clz(v) - (32 - width) : width;
+}
+
+/* arithmetic_encoder_step (arith.c:24-97) + update_stats (qv_stream.c:9-25) on table t, symbol x */
+static inline void encode_symbol(qvz_coder_t *cd, uint32_t *t, uint32_t x) {
+    const uint32_t n = t[0], card = t[1];
+    uint32_t *counts = t + 2;
+    uint32_t cum_lo = 0;
+    for (uint32_t i = 0; i < x; ++i) cum_lo += counts[i];
+    const uint32_t cum_hi = cum_lo + counts[x];
+    const uint64_t range = (uint64_t)cd->u - cd->l + 1;
+    const double dn = (double)n;
+    uint32_t u = cd->l + (uint32_t)(uint64_t)((double)(range * cum_hi) / dn) - 1;   /* arith.c:47 */
+    uint32_t l = cd->l + (uint32_t)(uint64_t)((double)(range * cum_lo) / dn);       /* arith.c:48 */
+
+    const uint32_t diff = l ^ u;
+    if (!(diff & MSB)) {                                        /* E1/E2 batch, arith.c:66-79 */
+        const uint32_t k = clz_field(diff, M_BITS);
+        const uint32_t top = l >> (M_BITS - k);                 /* the k leading bits shared by l and u */
+        const uint32_t b = top >> (k - 1);
+        put_bits(cd, b, 1);
+        if (cd->scale3) { put_run(cd, !b, cd->scale3); cd->scale3 = 0; }
+        if (k > 1) put_bits(cd, top & ((1u << (k - 1)) - 1), k - 1);
+        l = (l << k) & MASK_M;
+        u = ((u << k) & MASK_M) | ((1u << k) - 1);
+    }
+    {                                                           /* E3 batch, arith.c:80-84 */
+        const uint32_t ones_l = clz_field((~l) & MASK_M1, M_BITS - 1);
+        const uint32_t zeros_u = clz_field(u & MASK_M1, M_BITS - 1);
+        const uint32_t j = ones_l < zeros_u ? ones_l : zeros_u;
+        if (j) {
+            cd->scale3 += j;
+            l = (l << j) & MASK_M1;
+            u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
+        }
+    }
+    cd->l = l;
+    cd->u = u;
+
+    counts[x] += STEP;                                          /* qv_stream.c:12-13 */
+    uint32_t nn = n + STEP;
+    if (nn > RESCALE) {                                         /* qv_stream.c:15-24 */
+        nn = 0;
+        for (uint32_t i = 0; i < card; ++i)
+            if (counts[i]) { counts[i] = (counts[i] >> 1) + 1; nn += counts[i]; }
+    }
+    t[0] = nn;
+}
+
+int qvz_coder_encode(qvz_coder_t *cd, const uint8_t *labels, const uint16_t *feed, uint64_t reads) {
+    const uint32_t C = cd->columns;
+    for (uint64_t i = 0; i < reads; ++i) {
+        /* worst case per symbol is M_BITS bits plus a pending run that put_run grows for on its own */
+        if (buf_reserve(cd, (uint64_t)(C + 1) * 4 + 64)) return -1;
+        const uint32_t cl = labels ? labels[i] : 0;
+        if (cl >= cd->clusters) return -1;
+        encode_symbol(cd, cd->arena + cd->cluster_table, cl);   /* qv_write_cluster, qv_compressor.c:19-22 */
+        const uint32_t *off = cd->offset + (size_t)cl * C * 2 * A;
+        const uint16_t *f = feed + i * C;
+        for (uint32_t s = 0; s < C; ++s) {
+            const uint32_t qi = f[s] & 0xFF, st = f[s] >> 8;
+            if (qi >= 2 * A) return -1;
+            const uint32_t o = off[(size_t)s * 2 * A + qi];
+            if (o == NO_TABLE || st >= cd->arena[o + 1]) return -1;
+            encode_symbol(cd, cd->arena + o, st);               /* compress_qv, qv_compressor.c:8-11 */
+        }
+    }
+    return 0;
+}
+
+void qvz_coder_finish(qvz_coder_t *cd) {                        /* encoder_last_step, arith.c:99-116 */
+    buf_reserve(cd, 64);
+    const uint32_t b = cd->l >> (M_BITS - 1);
+    put_bits(cd, b, 1);
+    if (cd->scale3) { put_run(cd, !b, cd->scale3); cd->scale3 = 0; }
+    buf_reserve(cd, 64);
+    put_bits(cd, cd->l & MASK_M1, M_BITS - 1);                  /* stream_write_bits(os, l, m-1) */
+    /* stream_finish_byte (os_stream.c:105-110): pad with zeros; an aligned stream still gets one 0x00 byte */
+    if (cd->nbits) put_bits(cd, 0, 8 - cd->nbits);
+    else cd->buf[cd->len++] = 0;
+}
+
+uint64_t qvz_coder_bytes(const qvz_coder_t *cd) { return cd->dropped + cd->len; }
+
+const uint8_t *qvz_coder_data(const qvz_coder_t *cd, uint64_t *size) {
+    *size = cd->len;
+    return cd->buf;
+}
+
+void qvz_coder_drop(qvz_coder_t *cd, uint64_t size) {
+    if (size > cd->len) size = cd->len;
+    memmove(cd->buf, cd->buf + size, cd->len - size);
+    cd->len -= size;
+    cd->dropped += size;
+}

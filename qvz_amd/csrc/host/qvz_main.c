@@ -1,0 +1,116 @@
+/* qvz - command line front end with the reference's grammar (mikelhernaez/qvz src/main.c:189-356):
+ *     qvz (options) [input file] [output file]
+ * one token per option, an option's value is the next argv, no combined short options. Encoding runs on the
+ * MI355X through libqvzhip; `-x` (decoding) is outside this build's scope and is reported as such.
+ * Environment (additions): QVZ_WELL_SEED=debug|time (default time), QVZ_DEVICE=<ordinal>, QVZ_CHUNK_READS=<n>. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qvz_encode.h"
+
+static void usage(const char *name) {   /* main.c:166-184 */
+    printf("Usage: %s (options) [input file] [output file]\n", name);
+    printf("Options are:\n");
+    printf("   -q           : Store quality values in compressed file (default)\n");
+    printf("   -x           : Extract quality values from compressed file\n");
+    printf("   -f [ratio]   : Compress using [ratio] bits per bit of input entropy per symbol\n");
+    printf("   -r [rate]    : Compress using fixed [rate] bits per symbol\n");
+    printf("   -d [M|L|A]   : Optimize for MSE, Log(1+L1), L1 distortions, respectively (default: MSE)\n");
+    printf("   -D [FILE]    : Optimize using the custom distortion matrix specified in FILE\n");
+    printf("   -c [#]       : Compress using [#] clusters (default: 1)\n");
+    printf("   -T [#]       : Use [#] as a threshold for cluster center movement (L2 norm) to declare a stable solution (default: 4).\n");
+    printf("   -u [FILE]    : Write the uncompressed lossy values to FILE (default: off)\n");
+    printf("   -h           : Print this help\n");
+    printf("   -s           : Print summary stats\n");
+    printf("   -v           : Enable verbose output\n");
+    printf("\nFor custom distortion matrices, a 72x72 matrix of values must be provided as the cost of reconstructing\n");
+    printf("the x-th row as the y-th column, where x and y range from 0 to 71 (inclusive) corresponding to the possible\n");
+    printf("Phred scores.\n");
+}
+
+int main(int argc, char **argv) {
+    const char *input_name = 0, *output_name = 0;
+    qvz_options_t opts;
+    int extract = 0, file_idx = 0, i = 1;
+    qvz_options_default(&opts);
+
+    while (i < argc) {
+        if (argv[i][0] != '-') {                                  /* main.c:210-229 */
+            if (file_idx == 0) { input_name = argv[i]; file_idx = 1; }
+            else if (file_idx == 1) { output_name = argv[i]; file_idx = 2; }
+            else {
+                printf("Garbage argument \"%s\" detected.\n", argv[i]);
+                usage(argv[0]);
+                exit(1);
+            }
+            i += 1;
+            continue;
+        }
+        const int has_value = i + 1 < argc;
+        switch (argv[i][1]) {                                     /* main.c:232-302 */
+            case 'x': extract = 1; i += 1; break;
+            case 'q': extract = 0; i += 1; break;
+            case 'f': extract = 0; opts.ratio = has_value ? atof(argv[i + 1]) : 0; opts.mode = QVZ_MODE_RATIO; i += 2; break;
+            case 'r': extract = 0; opts.ratio = has_value ? atof(argv[i + 1]) : 0; opts.mode = QVZ_MODE_FIXED; i += 2; break;
+            case 'c': opts.clusters = has_value ? atoi(argv[i + 1]) : 1; i += 2; break;
+            case 'v': opts.verbose = 1; i += 1; break;
+            case 'h': usage(argv[0]); exit(0);
+            case 's': opts.stats = 1; i += 1; break;
+            case 'u': opts.uncompressed_name = has_value ? argv[i + 1] : NULL; i += 2; break;
+            case 'T': opts.cluster_threshold = has_value ? atoi(argv[i + 1]) : 4; i += 2; break;
+            case 'd':
+                switch (has_value ? argv[i + 1][0] : 0) {
+                    case 'M': opts.distortion = QVZ_DIST_MSE; break;
+                    case 'L': opts.distortion = QVZ_DIST_LORENTZ; break;
+                    case 'A': opts.distortion = QVZ_DIST_MANHATTAN; break;
+                    default: printf("Distortion measure not supported, using MSE.\n"); break;
+                }
+                i += 2;
+                break;
+            case 'D':
+                printf("Custom distortion matrices (-D) are not part of this build (SURVEY.md section 8f).\n");
+                exit(1);
+            default:
+                printf("Unrecognized option -%c.\n", argv[i][1]);
+                usage(argv[0]);
+                exit(1);
+        }
+    }
+    if (file_idx != 2) {                                          /* main.c:305-309 */
+        printf("Missing required filenames.\n");
+        usage(argv[0]);
+        exit(1);
+    }
+    if (opts.verbose) {                                           /* main.c:311-344 */
+        if (extract) {
+            printf("%s will be decoded to %s.\n", input_name, output_name);
+        } else {
+            printf("%s will be encoded as %s.\n", input_name, output_name);
+            if (opts.mode == QVZ_MODE_RATIO) printf("Ratio mode selected, targeting %f compression ratio.\n", opts.ratio);
+            else if (opts.mode == QVZ_MODE_FIXED) printf("Fixed-rate mode selected, targeting %f bits per symbol.\n", opts.ratio);
+            switch (opts.distortion) {
+                case QVZ_DIST_MSE: printf("MSE will be used as a distortion metric.\n"); break;
+                case QVZ_DIST_LORENTZ: printf("log(1+L1) will be used as a distortion metric.\n"); break;
+                case QVZ_DIST_MANHATTAN: printf("L1 will be used as a distortion metric.\n"); break;
+            }
+            printf("Compression will use %d clusters, with a movement threshold of %.0f.\n", opts.clusters, opts.cluster_threshold);
+        }
+    }
+    if (extract) {
+        printf("Decoding (-x) is not part of this build: use the reference decoder on the .q file (SURVEY.md section 8f).\n");
+        return 1;
+    }
+    const char *seed = getenv("QVZ_WELL_SEED");
+    if (seed && strcmp(seed, "debug") == 0) opts.seed_mode = QVZ_SEED_DEBUG;
+    if (getenv("QVZ_DEVICE")) opts.device = atoi(getenv("QVZ_DEVICE"));
+    if (getenv("QVZ_CHUNK_READS")) opts.chunk_reads = strtoull(getenv("QVZ_CHUNK_READS"), 0, 10);
+
+    qvz_result_t res;
+    const int rc = qvz_encode_file(input_name, output_name, &opts, &res);
+    if (rc) {
+        printf("%s\n", qvz_encode_last_error());                  /* reference: printf + exit(1), main.c:43-46 */
+        exit(1);
+    }
+    return 0;
+}

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void k_kmeans_update(const unsigned long long 
         if (threadIdx.x == 0) {
             unsigned long long m = red[0] + red[1] + red[2] + red[3];
             if (m > best) best = m;
+            moved_out[1 + j] = (double)m;   // per-cluster value, printed by -v (cluster.c:126-127)
         }
     }
     __syncthreads();
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
                                                   const uint16_t *__restrict__ qs, const uint32_t *__restrict__ words,
                                                   uint64_t first_draw, const double *__restrict__ dist,
                                                   uint8_t *__restrict__ qv_out, uint8_t *__restrict__ qi_out,
-                                                  uint8_t *__restrict__ st_out, double *__restrict__ err_out,
+                                                  uint8_t *__restrict__ st_out, uint64_t ldo, double *__restrict__ err_out,
                                                   int32_t *__restrict__ status) {
     __shared__ double sdist[QVZ_A * QVZ_A];
     for (uint32_t i = threadIdx.x; i < QVZ_A * QVZ_A; i += 256) sdist[i] = dist[i];
@@ -785,9 +786,9 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
             qi4 |= qi << (8 * r);
             st4 |= (qsv >> 8) << (8 * r);
         }
-        if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ld + i0) = qv4;
-        if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ld + i0) = qi4;
-        if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ld + i0) = st4;
+        if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0) = qv4;
+        if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0) = qi4;
+        if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0) = st4;
     }
     if (err_out) {
 #pragma unroll
@@ -800,16 +801,86 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
 extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
                                 uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint32_t *d_words,
                                 uint64_t first_draw, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
-                                double *d_err, int32_t *d_status, void *stream) {
+                                uint64_t ld_out, double *d_err, int32_t *d_status, void *stream) {
     int rc = check_matrix(n, c, ld);
     if (rc) return rc;
+    if ((d_qv || d_qi || d_st) && (rc = check_matrix(n, c, ld_out))) return rc;
     if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
     if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
     if (!d_ct || !d_qs || !d_words || !d_dist || !d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
     uint64_t n4 = (n + 3) / 4;
     dim3 grid((unsigned)((n4 + 255) / 256));
     hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, (hipStream_t)stream, d_sym, k > 1 ? d_labels : nullptr, n, c, ld,
-                       d_ct, d_qs, d_words, first_draw, d_dist, d_qv, d_qi, d_st, d_err, d_status);
+                       d_ct, d_qs, d_words, first_draw, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Coder feed: (qi, st) column-major -> read-major u16 pairs, through the same 256 x 64 LDS tile as the text
+// transposer (two byte planes).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_feed(const uint8_t *__restrict__ QI, const uint8_t *__restrict__ ST,
+                                                   uint64_t n, uint32_t C, uint64_t ld, uint16_t *__restrict__ feed) {
+    __shared__ uint8_t tq[TT_COLS * TT_PITCH];
+    __shared__ uint8_t ts[TT_COLS * TT_PITCH];
+    const uint64_t row0 = (uint64_t)blockIdx.x * TT_ROWS;
+    const uint32_t col0 = blockIdx.y * TT_COLS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < TT_COLS * (TT_ROWS / 4); i += 256) {
+        const uint32_t cc = i >> 6, dw = i & 63;
+        uint32_t a = 0, b = 0;
+        if (col0 + cc < C && row0 + 4 * dw < ld) {
+            a = *reinterpret_cast<const uint32_t *>(QI + (uint64_t)(col0 + cc) * ld + row0 + 4 * dw);
+            b = *reinterpret_cast<const uint32_t *>(ST + (uint64_t)(col0 + cc) * ld + row0 + 4 * dw);
+        }
+        *reinterpret_cast<uint32_t *>(&tq[cc * TT_PITCH + 4 * dw]) = a;
+        *reinterpret_cast<uint32_t *>(&ts[cc * TT_PITCH + 4 * dw]) = b;
+    }
+    __syncthreads();
+    const uint32_t col = col0 + lane;
+    for (uint32_t rr = wave; rr < TT_ROWS; rr += 4) {
+        const uint64_t row = row0 + rr;
+        if (row < n && col < C)
+            feed[row * C + col] = (uint16_t)(tq[lane * TT_PITCH + rr] | (ts[lane * TT_PITCH + rr] << 8));
+    }
+}
+
+extern "C" int qvz_hip_pack_feed(const uint8_t *d_qi, const uint8_t *d_st, uint64_t n, uint32_t c, uint64_t ld,
+                                 uint16_t *d_feed, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    dim3 grid((unsigned)((n + TT_ROWS - 1) / TT_ROWS), (c + TT_COLS - 1) / TT_COLS);
+    hipLaunchKernelGGL(k_pack_feed, grid, dim3(256), 0, (hipStream_t)stream, d_qi, d_st, n, c, ld, d_feed);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// memory / stream plumbing for host C callers
+// ------------------------------------------------------------------------------------------------
+extern "C" int qvz_hip_set_device(int device) { QVZ_HIP_CHECK(hipSetDevice(device)); return QVZ_OK; }
+extern "C" int qvz_hip_malloc(void **d_ptr, size_t bytes) { QVZ_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1)); return QVZ_OK; }
+extern "C" int qvz_hip_free(void *d_ptr) { if (d_ptr) QVZ_HIP_CHECK(hipFree(d_ptr)); return QVZ_OK; }
+extern "C" int qvz_hip_malloc_host(void **h_ptr, size_t bytes) { QVZ_HIP_CHECK(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault)); return QVZ_OK; }
+extern "C" int qvz_hip_free_host(void *h_ptr) { if (h_ptr) QVZ_HIP_CHECK(hipHostFree(h_ptr)); return QVZ_OK; }
+extern "C" int qvz_hip_memset(void *d_ptr, int value, size_t bytes, void *stream) {
+    QVZ_HIP_CHECK(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)stream));
+    return QVZ_OK;
+}
+extern "C" int qvz_hip_copy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    QVZ_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return QVZ_OK;
+}
+extern "C" int qvz_hip_copy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    QVZ_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return QVZ_OK;
+}
+extern "C" int qvz_hip_stream_create(void **stream) {
+    hipStream_t s;
+    QVZ_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return QVZ_OK;
+}
+extern "C" int qvz_hip_stream_destroy(void *stream) { QVZ_HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); return QVZ_OK; }
+extern "C" int qvz_hip_stream_sync(void *stream) { QVZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); return QVZ_OK; }

@@ -1,0 +1,95 @@
+"""Bindings of the host C layer (include/qvz_coder.h, include/qvz_encode.h). No torch needed here: the arithmetic
+coder and the file-level driver are plain C inside libqvzhip.so."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import QvzHipError, lib
+
+MODE_RATIO, MODE_FIXED = 0, 1
+DIST = {"A": 1, "M": 2, "L": 3}
+SEED_TIME, SEED_DEBUG, SEED_EXPLICIT = 0, 1, 2
+
+
+class Options(C.Structure):
+    """qvz_options_t (include/qvz_encode.h)."""
+    _fields_ = [("verbose", C.c_int), ("stats", C.c_int), ("mode", C.c_int), ("clusters", C.c_int),
+                ("distortion", C.c_int), ("ratio", C.c_double), ("cluster_threshold", C.c_double),
+                ("uncompressed_name", C.c_char_p), ("device", C.c_int), ("seed_mode", C.c_int),
+                ("well_state", C.c_uint32 * 32), ("chunk_reads", C.c_uint64)]
+
+
+class Result(C.Structure):
+    """qvz_result_t (include/qvz_encode.h)."""
+    _fields_ = [("lines", C.c_uint64), ("columns", C.c_uint32), ("stream_bytes", C.c_uint64),
+                ("file_bytes", C.c_uint64), ("distortion", C.c_double), ("kmeans_iterations", C.c_uint32),
+                ("deferred_decisions", C.c_uint64), ("t_upload", C.c_double), ("t_cluster", C.c_double),
+                ("t_stats", C.c_double), ("t_codebook", C.c_double), ("t_encode", C.c_double), ("t_total", C.c_double)]
+
+
+def default_options():
+    o = Options()
+    lib().qvz_options_default(C.byref(o))
+    return o
+
+
+def encode_file(in_path, out_path, clusters=1, mode=MODE_RATIO, ratio=0.5, dist="M", threshold=4.0, u_path=None,
+                well_state=None, seed_mode=None, chunk_reads=0, device=0):
+    """Whole-file encode on the GPU (the reference's encode(), src/main.c:18-127). Returns a Result."""
+    o = default_options()
+    o.clusters, o.mode, o.ratio, o.distortion, o.cluster_threshold = clusters, mode, ratio, DIST.get(dist, dist), threshold
+    o.device, o.chunk_reads = device, chunk_reads
+    if u_path:
+        o.uncompressed_name = u_path.encode()
+    if well_state is not None:
+        o.seed_mode = SEED_EXPLICIT
+        for i, v in enumerate(np.asarray(well_state, dtype=np.uint32)):
+            o.well_state[i] = int(v)
+    elif seed_mode is not None:
+        o.seed_mode = seed_mode
+    r = Result()
+    rc = lib().qvz_encode_file(in_path.encode(), out_path.encode(), C.byref(o), C.byref(r))
+    if rc:
+        raise QvzHipError(f"qvz_encode_file failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return r
+
+
+class Coder:
+    """One arithmetic-coded stream (include/qvz_coder.h). handles: qvz_codebook_t* of each cluster."""
+
+    def __init__(self, columns, codebook_handles):
+        k = len(codebook_handles)
+        arr = (C.c_void_p * k)(*codebook_handles)
+        self.h = lib().qvz_coder_create(k, columns, arr)
+        if not self.h:
+            raise MemoryError("qvz_coder_create")
+        self.columns = columns
+
+    def encode(self, feed, labels=None):
+        feed = np.ascontiguousarray(feed, dtype=np.uint16)
+        n = feed.shape[0]
+        lp = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, dtype=np.uint8)
+            lp = labels.ctypes.data_as(C.c_void_p)
+        if lib().qvz_coder_encode(self.h, lp, feed.ctypes.data_as(C.c_void_p), n):
+            raise QvzHipError("coder feed addresses an undefined quantizer or state")
+
+    def finish(self):
+        lib().qvz_coder_finish(self.h)
+
+    def take(self):
+        sz = C.c_uint64(0)
+        p = lib().qvz_coder_data(self.h, C.byref(sz))
+        data = C.string_at(p, sz.value) if sz.value else b""
+        lib().qvz_coder_drop(self.h, sz.value)
+        return data
+
+    def total_bytes(self):
+        return int(lib().qvz_coder_bytes(self.h))
+
+    def __del__(self):
+        try:
+            lib().qvz_coder_destroy(self.h)
+        except Exception:
+            pass

@@ -81,7 +81,7 @@ def kmeans_accumulate(sym, n, labels, k, acc=None):
 
 def kmeans_update(acc, counts, means):
     k, c = means.shape
-    moved = torch.zeros(1, dtype=torch.float64, device=means.device)
+    moved = torch.zeros(k + 1, dtype=torch.float64, device=means.device)   # [0] = max, [1+j] per cluster
     status = torch.zeros(1, dtype=torch.int32, device=means.device)
     check(lib().qvz_hip_kmeans_update(_ptr(acc), _ptr(counts), k, c, _ptr(means), _ptr(moved), _ptr(status),
                                       _stream()))
@@ -127,10 +127,18 @@ def quantize(sym, n, ct, qs, words, first_draw, dist, labels=None, k=1, want=("q
     out["err"] = torch.empty(n, dtype=torch.float64, device=dev) if "err" in want else None
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib().qvz_hip_quantize(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(ct), _ptr(qs), _ptr(words), first_draw,
-                                 _ptr(dist), _ptr(out["qv"]), _ptr(out["qi"]), _ptr(out["st"]), _ptr(out["err"]),
+                                 _ptr(dist), _ptr(out["qv"]), _ptr(out["qi"]), _ptr(out["st"]), ld, _ptr(out["err"]),
                                  _ptr(status), _stream()))
     out["status"] = status
     return out
+
+
+def pack_feed(qi, st, n):
+    """Column-major (qi, st) -> read-major int16 feed of shape (n, c): qi | st << 8."""
+    c, ld = _dims(qi, n)
+    feed = torch.empty((n, c), dtype=torch.int16, device=qi.device)
+    check(lib().qvz_hip_pack_feed(_ptr(qi), _ptr(st), n, c, ld, _ptr(feed), _stream()))
+    return feed
 
 
 # ------------------------------------------------------------------------------------------------

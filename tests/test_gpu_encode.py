@@ -1,0 +1,122 @@
+"""End-to-end GPU tests of the drop-in surface: the host C driver (qvz_encode_file) and the `qvz` binary must
+produce byte-identical .q and -u files to the reference for the same WELL state, and print the reference's -s line."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QVZ_BIN = os.path.join(ROOT, "qvz_amd", "bin", "qvz")
+
+
+def fresh_process_rand():
+    """Centroids come from libc rand() with whatever state the process is in (reference cluster.c:199-200): a new
+    process starts as if srand(1) had been called, so in-process tests reset it the same way."""
+    import ctypes
+    ctypes.CDLL(None).srand(1)
+
+
+def write_input(tmp_path, name):
+    rows = G.case_rows(name)
+    p = tmp_path / (name + ".txt")
+    p.write_bytes(rows.tobytes())
+    return str(p), rows
+
+
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_encode_file_byte_identical(tmp_path, name):
+    from qvz_amd import host
+    e = G.CASES[name]
+    inp, rows = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    q, u = str(tmp_path / "out.q"), str(tmp_path / "out.u")
+    fresh_process_rand()
+    r = host.encode_file(inp, q, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"],
+                         u_path=u, seed_mode=host.SEED_DEBUG)
+    qb, ub = open(q, "rb").read(), open(u, "rb").read()
+    assert len(qb) == e["q_size"] == r.file_bytes
+    assert G.md5(ub) == e["u_md5"], "-u differs from the reference"
+    assert G.md5(qb) == e["q_md5"], ".q differs from the reference"
+    assert r.stream_bytes == e["size"] and r.lines == rows.shape[0] and r.columns == rows.shape[1] - 1
+    assert f"{r.distortion:.4f}" == f"{e['distortion']:.4f}"
+    # the reference decoder's invariant (test.sh): decode(.q) == -u ; the oracle's decoder stands in for qvz -x
+    assert O.decode(qb) == ub
+
+
+@pytest.mark.parametrize("chunk", [256, 768, 4096])
+def test_chunking_does_not_change_the_bytes(tmp_path, chunk):
+    from qvz_amd import host
+    name = "t2k_c3_f05_M"
+    inp, _ = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    q, u = str(tmp_path / "o.q"), str(tmp_path / "o.u")
+    fresh_process_rand()
+    host.encode_file(inp, q, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], u_path=u,
+                     seed_mode=host.SEED_DEBUG, chunk_reads=chunk)
+    assert open(q, "rb").read() == G.gz(name + ".q.gz")
+    assert open(u, "rb").read() == G.gz(name + ".u.gz")
+
+
+def test_explicit_well_state_roundtrip(tmp_path):
+    """A random 128-byte state (what the reference draws from rand()): stored in the file, and the output decodes
+    to the -u dump with the oracle's decoder."""
+    from qvz_amd import host
+    inp, rows = write_input(tmp_path, "t2k_f05_L")
+    state = np.random.default_rng(5).integers(0, 2 ** 31, size=32, dtype=np.uint32)
+    q, u = str(tmp_path / "o.q"), str(tmp_path / "o.u")
+    host.encode_file(inp, q, mode=host.MODE_RATIO, ratio=0.5, dist="L", u_path=u, well_state=state)
+    qb, ub = open(q, "rb").read(), open(u, "rb").read()
+    ref = O.encode(rows, k=1, mode=O.MODE_RATIO, ratio=0.5, dist="L", well_state=state)
+    assert qb == ref["q"] and ub == ref["u"]
+    assert O.decode(qb) == ub
+
+
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_c3_f05_M", "cfg1_f05_L"])
+def test_cli_binary_matches_reference_output_and_stats_line(tmp_path, name):
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    q, u = str(tmp_path / "cli.q"), str(tmp_path / "cli.u")
+    env = dict(os.environ, QVZ_WELL_SEED="debug")
+    out = subprocess.run([QVZ_BIN] + e["flags"].split() + ["-s", "-u", u, inp, q], env=env, capture_output=True,
+                         text=True, check=True).stdout
+    assert G.md5(open(q, "rb").read()) == e["q_md5"]
+    assert G.md5(open(u, "rb").read()) == e["u_md5"]
+    m = re.search(r"rate, ([\d.]+), distortion, ([\d.]+), time, ([\d.]+), size, (\d+) ", out)
+    assert m, out
+    assert m.group(1) == f"{e['rate']:.4f}" and m.group(2) == f"{e['distortion']:.4f}" and int(m.group(4)) == e["size"]
+
+
+def test_cli_verbose_lines_and_errors(tmp_path):
+    inp, _ = write_input(tmp_path, "t2k_c3_f05_M")
+    env = dict(os.environ, QVZ_WELL_SEED="debug")
+    out = subprocess.run([QVZ_BIN, "-c", "3", "-f", "0.5", "-v", inp, str(tmp_path / "v.q")], env=env,
+                         capture_output=True, text=True, check=True).stdout
+    for needle in ["will be encoded as", "Ratio mode selected, targeting 0.500000 compression ratio.",
+                   "MSE will be used as a distortion metric.", "Compression will use 3 clusters, with a movement threshold of 4.",
+                   "Chose block 0, line 886.", "Chose block 0, line 915.", "Chose block 0, line 335.",
+                   "Total number of iterations: 4.", "Clustering took", "Stats and codebook generation took", "Line: 0M",
+                   "MSE distortion: 0.597", "Lines: 2000", "Columns: 30", "Total bytes used: 11488", "Encoding took",
+                   "Total time elapsed:"]:
+        assert needle in out, (needle, out)
+    # reference behaviour for bad command lines: message + usage + exit status 1 (main.c:298-309)
+    r = subprocess.run([QVZ_BIN, "-z", inp, "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unrecognized option -z." in r.stdout and "Usage:" in r.stdout
+    r = subprocess.run([QVZ_BIN, inp], capture_output=True, text=True)
+    assert r.returncode == 1 and "Missing required filenames." in r.stdout
+    r = subprocess.run([QVZ_BIN, str(tmp_path / "missing.txt"), str(tmp_path / "o.q")], capture_output=True, text=True)
+    assert r.returncode == 1 and "load_file returned error: 1" in r.stdout
+    # out-of-alphabet bytes are undefined behaviour in the reference; here they are refused
+    bad = tmp_path / "bad.txt"
+    rows = G.case_rows("tiny5_r10").copy()
+    rows[2, 3] = 10
+    bad.write_bytes(rows.tobytes())
+    r = subprocess.run([QVZ_BIN, str(bad), str(tmp_path / "o.q")], capture_output=True, text=True)
+    assert r.returncode == 1 and "outside" in r.stdout

@@ -92,7 +92,7 @@ def test_kmeans_full_loop_matches_reference_phase(K, name):
         moved, status = K.kmeans_update(acc, counts, means)
         iters += 1
         assert int(status.item()) == 0
-        if not (moved.item() > 4.0) or iters >= 1000:
+        if not (moved[0].item() > 4.0) or iters >= 1000:
             break
     np.testing.assert_array_equal(labels[:n].cpu().numpy(), ph["labels"])
     np.testing.assert_array_equal(counts.cpu().numpy().astype(np.uint32), ph["counts"])

@@ -1,0 +1,134 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the headers declare, and the host C
+logic (arithmetic coder, codebook serialisation, quantizer-table builder) matches the reference fixtures."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(qvz_\w+)\s*\(", text))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    from qvz_amd import _lib
+    lib = _lib.lib()
+    names = declared_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/ but not exported by libqvzhip.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in qvz_amd/_lib.py"
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} is bound in _lib.py but not declared in include/"
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from qvz_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libqvzhip.so")
+    with pytest.raises(_lib.QvzHipError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def product_codebook_from_oracle(ref):
+    """Fill a product qvz_codebook_t (host struct) with an oracle codebook's contents."""
+    from qvz_amd import kernels as K
+    cb = K.Codebook(ref.c)
+    for name in ("nctx", "ctx_sym", "ctx_idx", "qratio", "ratio", "q", "nstates", "recon", "out_idx"):
+        getattr(cb, name)[...] = getattr(ref, name)
+    return cb
+
+
+def oracle_side(name):
+    rows = G.case_rows(name)
+    opts = G.case_opts(name)
+    labels = O.kmeans(rows, opts["k"])[0]
+    cnt = O.stats(rows, labels, opts["k"])
+    d = O.distortion(opts["dist"])
+    cbs = [O.generate_codebook(cnt[j], d, opts["mode"], opts["ratio"]) for j in range(opts["k"])]
+    ref = O.encode_stream(rows, labels, cbs, d, want_feed=True)
+    return rows, opts, labels, cbs, ref
+
+
+STORED = sorted(n for n, e in G.CASES.items() if e["stored"] and e["input"]["n"] * e["input"]["c"] <= 200000)
+
+
+@pytest.mark.parametrize("name", STORED + ["cfg1_r10_M"])
+def test_coder_reproduces_reference_stream(name):
+    from qvz_amd import host
+    rows, opts, labels, ocbs, ref = oracle_side(name)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    cbs = [product_codebook_from_oracle(o) for o in ocbs]
+    feed = (ref["qi"].astype(np.uint16) | (ref["st"].astype(np.uint16) << 8))
+    coder = host.Coder(c, [cb.handle for cb in cbs])
+    # feed it in uneven pieces, draining the buffer in between: the stream must not depend on the chunking
+    cuts = sorted(set([0, 1, n // 3, n // 2 + 1, n]))
+    out = b""
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            coder.encode(feed[a:b], labels[a:b] if opts["k"] > 1 else None)
+            out += coder.take()
+    coder.finish()
+    out += coder.take()
+    q = G.gz(name + ".q.gz")
+    size = G.CASES[name]["size"]
+    assert len(out) == size == coder.total_bytes()
+    assert out == q[-size:], "arithmetic stream differs from the reference's"
+    # and the part in front of it: header + codebooks + 128-byte WELL state
+    from qvz_amd import kernels as K
+    blob = K.write_header(opts["k"], c, n) + b"".join(cb.serialize() for cb in cbs) + O.WELL_DEBUG_STATE.tobytes()
+    assert blob + out == q
+
+
+def test_coder_rejects_undefined_feed():
+    from qvz_amd import host
+    rows, opts, labels, ocbs, ref = oracle_side("t2k_f05_L")
+    cbs = [product_codebook_from_oracle(o) for o in ocbs]
+    feed = (ref["qi"].astype(np.uint16) | (ref["st"].astype(np.uint16) << 8))[:10].copy()
+    feed[3, 5] = 143            # quantizer index beyond 2*nctx
+    with pytest.raises(Exception):
+        host.Coder(rows.shape[1] - 1, [cb.handle for cb in cbs]).encode(feed)
+    feed[3, 5] = 0 | (71 << 8)  # state beyond the output alphabet
+    with pytest.raises(Exception):
+        host.Coder(rows.shape[1] - 1, [cb.handle for cb in cbs]).encode(feed)
+
+
+def test_coder_long_pending_run_and_alignment():
+    """const input: every symbol has probability ~1, so E3 underflow runs and the final padding byte are exercised."""
+    for name in ("const_f05", "const_r05", "f00_zero_rate"):
+        test_coder_reproduces_reference_stream(name)
+
+
+def test_quantizer_tables_from_host_builder():
+    rows, opts, labels, ocbs, ref = oracle_side("t2k_c3_f05_M")
+    for o in ocbs:
+        cb = product_codebook_from_oracle(o)
+        ct, qs = cb.tables()
+        for s in range(o.c):
+            for p in range(72):
+                ctx = int(o.ctx_idx[s, p])
+                want = 0xFF if ctx == 0xFF else ctx | (int(o.qratio[s, ctx]) << 8)
+                assert int(ct[s, p]) == want
+            for qi in range(2 * int(o.nctx[s])):
+                qv = o.q[s, qi].astype(np.int64)
+                want = o.q[s, qi].astype(np.uint16) | (o.out_idx[s, qi][qv].astype(np.uint16) << 8)
+                np.testing.assert_array_equal(qs[s, qi], want)
+
+
+def test_distortion_matrix_host():
+    from qvz_amd import kernels as K
+    for kind in "MLA":
+        assert K.distortion_matrix(kind).tobytes() == O.distortion(kind).tobytes()
