@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the qvz encode hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full pass of the hot path over a synthetic QGEN-1 quality matrix that is already resident in HBM:
+k-means (to convergence) -> conditional-PMF counters (-> RCCL all-reduce when sharded) -> Lloyd-Max codebooks ->
+WELL draws -> quantize (the -u product + coder feed) -> arithmetic coding into `shards` independent
+reference-format streams by host threads. Nothing is cached between steps.
+
+Workload (BASELINE.json): 100M reads x 150 columns per GPU, flags of configs[2] (-c 1 -d L -f 0.5) by default;
+--config 3 selects configs[3] (-c 3 -d M -r 1.0), --config 1 the 10M x 150 case. Reads shard across ranks (weak
+scaling: every rank holds --reads reads); the only exchanges are the small all-reduces above.
+
+Prints ONE JSON line on rank 0: metric/value/unit, ms_per_step, bits_per_symbol, per-phase seconds, a `roofline`
+object for the dominant GPU kernel (HIP events around each launch on the launch stream) and a `cpu_baseline`
+object (reference qvz, or the CPU oracle when the reference binary is absent, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CONFIGS = {
+    1: dict(reads=10_000_000, cols=150, clusters=1, dist="M", mode="r", ratio=1.0, seed=2,
+            name="10M reads x 150 cols, -c 1 -d M -r 1.0"),
+    2: dict(reads=100_000_000, cols=150, clusters=1, dist="L", mode="f", ratio=0.5, seed=3,
+            name="100M reads x 150 cols, -c 1 -d L -f 0.5"),
+    3: dict(reads=100_000_000, cols=150, clusters=3, dist="M", mode="r", ratio=1.0, seed=3,
+            name="100M reads x 150 cols, -c 3 -d M -r 1.0"),
+}
+
+# algorithmic bytes per symbol of each kernel (DESIGN.md "Kernels")
+ALG_BYTES_PER_SYMBOL = {
+    "pmf_hist": 1.0,             # each symbol read once (+1 B/read of labels when k > 1, added below)
+    "kmeans_assign": 1.0,
+    "kmeans_accumulate": 1.0,    # + labels re-read per column when k > 1 (2 B/sym)
+    "quantize": 5.0,             # symbol in, qv out, (qi, st) out, 1 B of WELL draws in
+    "well_words": 1.0,
+    "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out
+}
+
+
+def cpu_baseline(cfg, cores_note):
+    """Reference qvz (oracle/_ref/qvz_ref, single thread - it has no threaded mode) on two bounded QGEN-1 samples of
+    the same workload; falls back to the CPU oracle ("port") when the reference binary did not travel."""
+    import oracle_lib as O
+    c = cfg["cols"]
+    flags = ["-c", str(cfg["clusters"]), "-d", cfg["dist"], "-" + cfg["mode"], str(cfg["ratio"])]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "qvz_ref")
+    samples = [60_000, 240_000]
+    times = []
+    kind = "reference" if os.path.exists(ref_bin) else "port"
+    with tempfile.TemporaryDirectory() as td:
+        for n in samples:
+            rows = O.qgen1_rows(cfg["seed"], n, c)
+            if kind == "reference":
+                inp = os.path.join(td, f"s{n}.txt")
+                open(inp, "wb").write(rows.tobytes())
+                t = time.perf_counter()
+                subprocess.run([ref_bin] + flags + [inp, os.path.join(td, "s.q")], check=True, capture_output=True)
+                times.append(time.perf_counter() - t)
+            else:
+                t = time.perf_counter()
+                O.encode(rows, k=cfg["clusters"], mode=O.MODE_RATIO if cfg["mode"] == "f" else O.MODE_FIXED,
+                         ratio=cfg["ratio"], dist=cfg["dist"], want_u=False)
+                times.append(time.perf_counter() - t)
+    (n1, n2), (t1, t2) = samples, times
+    slope = (t2 - t1) / ((n2 - n1) * c)                 # seconds per symbol, N-dependent phases
+    fixed = max(t1 - slope * n1 * c, 0.0)               # N-independent (codebook generation)
+    full = cfg["reads"] * c
+    return dict(value=round(n2 * c / t2, 1), unit="quality-symbols/s", cores=1, kind=kind,
+                sample=f"QGEN-1 seed {cfg['seed']}, {n2} reads x {c} cols, flags {' '.join(flags)}, whole encode() "
+                       f"incl. codebook generation, {t2:.2f} s; second sample {n1} reads {t1:.2f} s",
+                seconds_per_symbol=slope, fixed_seconds=round(fixed, 3),
+                extrapolated_full_workload_value=round(full / (fixed + slope * full), 1), host=cores_note)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (testing)")
+    ap.add_argument("--shards", type=int, default=0, help="arithmetic-coded streams per GPU (default: host threads)")
+    ap.add_argument("--threads", type=int, default=0, help="host coder threads per rank (default: cores / ranks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from qvz_amd import host
+    from qvz_amd import kernels as K
+    from qvz_amd import pipeline as P
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    group = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = dist.group.WORLD
+
+    cfg = dict(CONFIGS[args.config])
+    if args.reads:
+        cfg["reads"] = args.reads
+    n = cfg["reads"] - cfg["reads"] % 4            # per-rank reads; shard starts stay on WELL word boundaries
+    c, k = cfg["cols"], cfg["clusters"]
+    n_total = n * world
+    first = rank * n
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    # a GPU box's CPU share is 16 cores per GPU even where more logical CPUs are visible
+    threads = args.threads or max(1, min(16, cores // max(1, world)))
+    shards = args.shards or threads
+    mode = host.MODE_RATIO if cfg["mode"] == "f" else host.MODE_FIXED
+
+    sym = K.qgen1(cfg["seed"], n, c, first=first)          # synthetic input, resident in HBM before timing
+    lines = P.reference_centroid_lines(n_total, k)        # the reads the reference's rand() would pick
+    means0 = torch.stack([K.qgen1(cfg["seed"], 4, c, first=ln - ln % 4)[:, ln % 4] for ln in lines]).contiguous()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(timer=None):
+        return P.encode_pass(sym, n, first, n_total, means0, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"],
+                             shards=shards, threads=threads, group=group, timer=timer, device_index=local)
+
+    for _ in range(args.warmup):
+        step()
+    timer = P.Timer(True)
+    barrier()
+    t0 = time.perf_counter()
+    results = [step(timer) for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        sb = torch.tensor([results[-1]["total_stream_bytes"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(sb)
+        stream_bytes = int(sb.item())
+    else:
+        stream_bytes = results[-1]["total_stream_bytes"]
+
+    if rank == 0:
+        spans = timer.totals_ms()
+        per_launch = {name: float(np.mean(v)) for name, v in spans.items()}
+        per_step = {name: float(np.sum(v)) / args.steps for name, v in spans.items()}
+        dom = max(per_step, key=per_step.get)
+        bps = ALG_BYTES_PER_SYMBOL[dom]
+        extra = 0.0
+        if k > 1 and dom == "pmf_hist":
+            extra = float(n)
+        if k > 1 and dom == "kmeans_accumulate":
+            bps = 2.0
+        alg_bytes = bps * n * c + extra
+        achieved = alg_bytes / (per_launch[dom] * 1e-3) / 1e9
+        roof = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None,
+                    ms_per_launch=round(per_launch[dom], 4), algorithmic_bytes_per_launch=int(alg_bytes),
+                    bytes_per_symbol=bps)
+        pmf_ach = (n * c + (n if k > 1 else 0)) / (per_launch["pmf_hist"] * 1e-3) / 1e9
+        wall = {ph: round(float(np.mean([r["wall"][ph] for r in results])), 4) for ph in results[-1]["wall"]}
+        line = {
+            "metric": "quality-symbols/s (encode)", "value": round(n_total * c * args.steps / elapsed, 1),
+            "unit": "quality-symbols/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic QGEN-1 (SURVEY.md Appendix D), generated on device",
+            "config": {"workload": cfg["name"] + f" per GPU, reads sharded over {world} GPU(s)", "reads_per_gpu": n,
+                       "columns": c, "clusters": k, "coder": f"{shards} independent reference-format streams per GPU "
+                       f"on {threads} host threads", "parallelism": f"read-sharded x{world}"},
+            "bits_per_symbol": round(stream_bytes * 8.0 / (n_total * c), 5),
+            "distortion": results[-1]["distortion"], "kmeans_iterations": results[-1]["kmeans_iterations"],
+            "phase_seconds": wall,
+            "gpu_kernel_ms_per_step": {kname: round(v, 4) for kname, v in sorted(per_step.items())},
+            "roofline": roof,
+            "roofline_pmf_hist": dict(kernel="pmf_hist", bound="hbm", achieved=round(pmf_ach, 1), peak=HBM_PEAK_GBPS,
+                                      unit="GB/s", frac=round(pmf_ach / HBM_PEAK_GBPS, 4),
+                                      ms_per_launch=round(per_launch["pmf_hist"], 4)),
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

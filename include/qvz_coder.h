@@ -45,6 +45,32 @@ uint64_t qvz_coder_bytes(const qvz_coder_t *cd);
 const uint8_t *qvz_coder_data(const qvz_coder_t *cd, uint64_t *size);
 void qvz_coder_drop(qvz_coder_t *cd, uint64_t size);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Sharded coding (option B). The reference format has exactly one serial stream per
+ * file, so one stream caps the whole encoder at one host core. Here reads [0,n) are cut into `shards`
+ * contiguous ranges, every range starting at a multiple of 4 reads (= a WELL word boundary, 4*C draws = C
+ * words); each range is coded as an independent stream with a fresh adaptive model - byte-for-byte what the
+ * reference writes for a file holding only those reads, given the codebooks of the whole file and the WELL
+ * state advanced to the range's first draw (stored rotated to n = 0). Wrapped with qvz_shard_file_image every
+ * shard is a file the unmodified reference decoder accepts; the decodes concatenate to the single-stream -u
+ * output. Cost: each shard re-learns its model (slightly more bits per symbol) and repeats the codebooks.
+ * ------------------------------------------------------------------------------------------------------- */
+/* first[g] for g = 0..shards (first[shards] = n): equal-sized ranges rounded to multiples of 4 reads */
+void qvz_shard_bounds(uint64_t n, uint32_t shards, uint64_t *first);
+
+/* Codes all shards with `threads` host threads pulling the feed straight from HBM (d_feed[i*columns+s] u16,
+ * d_labels[i] or NULL) in slices over their own streams. streams[g] is malloc'd (free with free()),
+ * sizes[g] its length. device: HIP ordinal the buffers live on. */
+int qvz_encode_shards_device(const uint16_t *d_feed, const uint8_t *d_labels, uint64_t n, uint32_t columns,
+                             uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                             uint32_t threads, int device, uint8_t **streams, uint64_t *sizes);
+
+/* Reference-format file image of one shard: header(clusters, columns, shard_reads) + codebooks + 128-byte WELL
+ * state + stream. buf == NULL returns the size. */
+size_t qvz_shard_file_image(uint8_t *buf, uint32_t clusters, uint32_t columns, uint64_t shard_reads,
+                            const qvz_codebook_t *const *cbs, const uint32_t *well_state_at_shard,
+                            const uint8_t *stream, uint64_t stream_bytes);
+
 #ifdef __cplusplus
 }
 #endif

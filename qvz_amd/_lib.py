@@ -61,6 +61,12 @@ SIGNATURES = {
     "qvz_coder_bytes": (C.c_uint64, [C.c_void_p]),
     "qvz_coder_data": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "qvz_coder_drop": (None, [C.c_void_p, C.c_uint64]),
+    "qvz_shard_bounds": (None, [C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "qvz_encode_shards_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                           C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "qvz_shard_file_image": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]),
     # include/qvz_encode.h (host C)
     "qvz_options_default": (None, [C.c_void_p]),
     "qvz_encode_buffer": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -54,6 +54,47 @@ def encode_file(in_path, out_path, clusters=1, mode=MODE_RATIO, ratio=0.5, dist=
     return r
 
 
+def shard_bounds(n, shards):
+    """first[g] for g = 0..shards; every shard starts at a multiple of 4 reads (a WELL word boundary)."""
+    first = (C.c_uint64 * (shards + 1))()
+    lib().qvz_shard_bounds(n, shards, first)
+    return [int(x) for x in first]
+
+
+def encode_shards_device(feed, labels, n, columns, codebook_handles, shards, threads, device=0):
+    """feed: device tensor (n, columns) int16; labels: device uint8 tensor or None. Returns list of bytes streams.
+    The C side runs `threads` host threads, each pulling its shards' feed from HBM and coding them."""
+    k = len(codebook_handles)
+    arr = (C.c_void_p * k)(*codebook_handles)
+    streams = (C.c_void_p * shards)()
+    sizes = (C.c_uint64 * shards)()
+    rc = lib().qvz_encode_shards_device(C.c_void_p(feed.data_ptr()), C.c_void_p(labels.data_ptr()) if labels is not None else None,
+                                        n, columns, k, arr, shards, threads, device, streams, sizes)
+    if rc:
+        raise QvzHipError(f"qvz_encode_shards_device failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    out = []
+    for g in range(shards):
+        out.append(C.string_at(streams[g], sizes[g]) if sizes[g] else b"")
+        libc.free(streams[g])
+    return out
+
+
+def shard_file_image(columns, shard_reads, codebook_handles, well_state_at_shard, stream):
+    """Reference-format .q image of one shard (decodable by the unmodified reference decoder)."""
+    k = len(codebook_handles)
+    arr = (C.c_void_p * k)(*codebook_handles)
+    ws = np.ascontiguousarray(well_state_at_shard, dtype=np.uint32)
+    wp = ws.ctypes.data_as(C.POINTER(C.c_uint32))
+    n = lib().qvz_shard_file_image(None, k, columns, shard_reads, arr, wp, None, len(stream))
+    buf = np.zeros(n, dtype=np.uint8)
+    sbuf = np.frombuffer(stream, dtype=np.uint8) if len(stream) else np.zeros(1, dtype=np.uint8)
+    lib().qvz_shard_file_image(buf.ctypes.data_as(C.c_void_p), k, columns, shard_reads, arr, wp,
+                               sbuf.ctypes.data_as(C.c_void_p), len(stream))
+    return buf.tobytes()
+
+
 class Coder:
     """One arithmetic-coded stream (include/qvz_coder.h). handles: qvz_codebook_t* of each cluster."""
 

@@ -1,0 +1,175 @@
+"""One pass of the encode hot path over a resident symbol matrix, optionally sharded over ranks.
+
+Plumbing only: every phase is a call into the C-ABI (HIP kernels / host C). torch supplies device tensors, the
+stream and - when a process group is given - the RCCL all-reduces that make read-sharded ranks see the statistics
+of the whole file:
+
+    k-means iteration : all_reduce(SUM) of acc[k][C] (i64) and count[k] (i32)          ~3.6 KB
+    PMF counters      : all_reduce(SUM) of cnt[k][C][72][72] (i32), once                 3.1 MB per cluster
+    distortion        : all_reduce(SUM) of one double
+
+Codebook generation is N-independent and deterministic, so every rank generates the same codebooks from the
+reduced counters; quantisation and coding are embarrassingly parallel per shard.
+"""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import host
+from . import kernels as K
+
+LINES_PER_BLOCK = 1_000_000   # reference include/lines.h:12
+
+
+def reference_centroid_lines(n_total, k, reseed=True):
+    """Read indices the reference picks as initial centroids (cluster.c:198-201): libc rand(), fresh-process state."""
+    libc = ctypes.CDLL(None)
+    if reseed:
+        libc.srand(1)
+    blocks = (n_total + LINES_PER_BLOCK - 1) // LINES_PER_BLOCK
+    lines = []
+    for _ in range(k):
+        b = libc.rand() % blocks
+        count = min(LINES_PER_BLOCK, n_total - b * LINES_PER_BLOCK)
+        lines.append(b * LINES_PER_BLOCK + libc.rand() % count)
+    return lines
+
+
+class Timer:
+    """Per-phase device timing with events recorded on the stream the kernels are launched on."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+        self.spans = []
+
+    def span(self, name):
+        return _Span(self, name)
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.spans:
+            out.setdefault(name, []).append(a.elapsed_time(b))
+        return out
+
+
+class _Span:
+    def __init__(self, timer, name):
+        self.t, self.name = timer, name
+
+    def __enter__(self):
+        if self.t.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t.enabled:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.t.spans.append((self.name, self.a, b))
+
+
+def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MODE_RATIO, ratio=0.5, dist="M",
+                threshold=4.0, well_state=None, shards=1, threads=1, group=None, timer=None, keep=False, device_index=0):
+    """Runs k-means -> PMF -> codebooks -> WELL -> quantize -> feed -> sharded arithmetic coding for the reads
+    [first_read, first_read+n) held in `sym` (this rank's shard of a file with n_total reads).
+
+    means0: (clusters, c) uint8 device tensor of the initial centroids (symbols). first_read must be a multiple of 4.
+    Returns a dict with stream sizes, distortion, codebooks, phase wall times; with keep=True also the device outputs.
+    """
+    import torch.distributed as dist_mod
+    c, ld = sym.shape
+    k = clusters
+    assert first_read % 4 == 0, "shards must start on a WELL word boundary"
+    timer = timer or Timer(False)
+    dev = sym.device
+    wall = {}
+    t0 = time.perf_counter()
+
+    # ---- k-means (cluster.c:212-244) ----
+    means = means0.clone()
+    labels = torch.zeros(ld, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(k, dtype=torch.int32, device=dev)
+    acc = torch.zeros((k, c), dtype=torch.int64, device=dev)
+    iters = 0
+    while True:
+        counts.zero_()
+        acc.zero_()
+        with timer.span("kmeans_assign"):
+            K.kmeans_assign(sym, n, means, labels=labels, counts=counts)
+        with timer.span("kmeans_accumulate"):
+            K.kmeans_accumulate(sym, n, labels, k, acc=acc)
+        if group is not None:
+            dist_mod.all_reduce(acc, group=group)
+            dist_mod.all_reduce(counts, group=group)
+        moved, status = K.kmeans_update(acc, counts, means)
+        iters += 1
+        mv = moved[0].item()
+        if int(status.item()):
+            raise RuntimeError("a cluster went empty during k-means (reference: division by zero, cluster.c:113)")
+        if not (mv > threshold) or iters >= 1000:
+            break
+    torch.cuda.synchronize()
+    wall["kmeans"] = time.perf_counter() - t0
+
+    # ---- conditional-PMF counters (codebook.c:193-205) ----
+    t1 = time.perf_counter()
+    cnt = torch.zeros((k, c, 72, 72), dtype=torch.int32, device=dev)
+    with timer.span("pmf_hist"):
+        K.pmf_hist(sym, n, labels=labels if k > 1 else None, k=k, cnt=cnt)
+    if group is not None:
+        dist_mod.all_reduce(cnt, group=group)
+    torch.cuda.synchronize()
+    wall["pmf"] = time.perf_counter() - t1
+
+    # ---- codebooks (codebook.c:208-468), identical on every rank ----
+    t2 = time.perf_counter()
+    dmat = K.distortion_matrix(dist)
+    cbs, deferred = [], 0
+    for j in range(k):
+        cb, d = K.generate_codebook(cnt[j], dmat, mode, ratio)
+        cbs.append(cb)
+        deferred += d
+    ct, qs = K.upload_tables(cbs, dev)
+    torch.cuda.synchronize()
+    wall["codebook"] = time.perf_counter() - t2
+
+    # ---- WELL draws + quantize (qv_compressor.c:76-135) ----
+    t3 = time.perf_counter()
+    if well_state is None:
+        well_state = np.full(32, 0x55555555, dtype=np.uint32)
+    first_draw = first_read * c
+    w0 = first_draw // 4
+    nwords = (first_draw + n * c + 3) // 4 - w0
+    with timer.span("well_words"):
+        words = K.well_words(well_state, w0, nwords, device=dev)
+    ddist = torch.from_numpy(dmat).to(dev)
+    with timer.span("quantize"):
+        out = K.quantize(sym, n, ct, qs, words, first_draw, ddist, labels=labels if k > 1 else None, k=k)
+    del words
+    with timer.span("pack_feed"):
+        feed = K.pack_feed(out["qi"], out["st"], n)
+    if int(out["status"].item()):
+        raise RuntimeError("quantizer met a context the codebook does not define")
+    torch.cuda.synchronize()
+    wall["quantize"] = time.perf_counter() - t3
+
+    # ---- arithmetic coding: `shards` independent reference-format streams on `threads` host threads ----
+    t4 = time.perf_counter()
+    streams = host.encode_shards_device(feed, labels if k > 1 else None, n, c, [cb.handle for cb in cbs], shards, threads,
+                                        device=device_index)
+    wall["coder"] = time.perf_counter() - t4
+
+    err_sum = (out["err"] / float(c)).sum()
+    if group is not None:
+        dist_mod.all_reduce(err_sum, group=group)
+    distortion = float(err_sum.item()) / float(n_total)
+    wall["total"] = time.perf_counter() - t0
+    res = dict(stream_bytes=[len(s) for s in streams], total_stream_bytes=sum(len(s) for s in streams), distortion=distortion,
+               kmeans_iterations=iters, deferred=deferred, wall=wall, codebooks=cbs)
+    if keep:
+        res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, err=out["err"], feed=feed)
+    return res

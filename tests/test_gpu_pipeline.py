@@ -1,0 +1,87 @@
+"""GPU tests of the whole device pipeline (qvz_amd/pipeline.py) incl. the sharded coder: every shard must be a file
+the reference decoder accepts, and the decodes must concatenate to the single-stream -u output."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def setup_case(name):
+    from qvz_amd import kernels as K, pipeline as P
+    from test_gpu_kernels import upload_sym
+    rows = G.case_rows(name)
+    opts = G.case_opts(name)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    sym = upload_sym(K, rows)
+    lines = P.reference_centroid_lines(n, opts["k"])
+    means0 = torch.from_numpy(np.stack([rows[i, :c] - 33 for i in lines]).astype(np.uint8)).cuda()
+    return rows, opts, n, c, sym, means0
+
+
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_c3_f05_M", "twolevel_c2_f05", "cfg1_f05_L"])
+def test_single_shard_equals_reference_stream(name):
+    from qvz_amd import kernels as K, pipeline as P
+    rows, opts, n, c, sym, means0 = setup_case(name)
+    r = P.encode_pass(sym, n, 0, n, means0, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"],
+                      shards=1, threads=1, keep=True)
+    e = G.CASES[name]
+    assert r["total_stream_bytes"] == e["size"]
+    text = K.untranspose_text(r["qv"], n).cpu().numpy().tobytes()
+    assert G.md5(text) == e["u_md5"]
+    blob = K.write_header(opts["k"], c, n) + b"".join(cb.serialize() for cb in r["codebooks"]) + O.WELL_DEBUG_STATE.tobytes()
+    assert G.md5(blob + r["streams"][0]) == e["q_md5"]
+    assert abs(r["distortion"] - e["distortion"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,shards,threads", [("t2k_r10_M", 2, 2), ("t2k_c3_f05_M", 5, 3), ("cfg1_f05_L", 16, 8),
+                                                  ("tiny5_r10", 3, 2)])
+def test_every_shard_is_reference_decodable(name, shards, threads):
+    from qvz_amd import host, kernels as K, pipeline as P
+    rows, opts, n, c, sym, means0 = setup_case(name)
+    r = P.encode_pass(sym, n, 0, n, means0, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"],
+                      shards=shards, threads=threads, keep=True)
+    u = K.untranspose_text(r["qv"], n).cpu().numpy().tobytes()
+    assert G.md5(u) == G.CASES[name]["u_md5"], "quantized symbols must not depend on the sharding of the coder"
+    first = host.shard_bounds(n, shards)
+    handles = [cb.handle for cb in r["codebooks"]]
+    decoded = b""
+    for g in range(shards):
+        reads = first[g + 1] - first[g]
+        if reads == 0:
+            continue
+        state = K.well_jump(O.WELL_DEBUG_STATE, first[g] * c // 4)      # generator at the shard's first draw, n = 0
+        image = host.shard_file_image(c, reads, handles, state, r["streams"][g])
+        decoded += O.decode(image)                                      # stands in for the reference's `qvz -x`
+    assert decoded == u
+    single = G.CASES[name]["size"]
+    assert r["total_stream_bytes"] >= single * 0.98   # re-learning the model per shard costs bits, it never saves many
+
+
+def test_read_sharded_ranks_equal_single_pass():
+    """Two 'ranks' in one process: each quantizes its half with the global counters (summed by hand here, by RCCL in
+    bench.py) and its WELL offset; the halves must reproduce the single-pass outputs bit for bit."""
+    from qvz_amd import kernels as K
+    rows = O.qgen1_rows(6, 9000, 40)
+    n, c = 9000, 40
+    from test_gpu_kernels import upload_sym
+    full_sym = upload_sym(K, rows)
+    cnt_full = K.pmf_hist(full_sym, n)
+    halves = [(0, 4500), (4500, 9000)]      # 4500 is a multiple of 4
+    cnt = None
+    for a, b in halves:
+        cnt = K.pmf_hist(upload_sym(K, rows[a:b]), b - a, cnt=cnt)
+    assert torch.equal(cnt, cnt_full)
+    d = K.distortion_matrix("M")
+    cb, _ = K.generate_codebook(cnt[0], d, 0, 0.5)
+    ct, qs = K.upload_tables([cb])
+    dd = torch.from_numpy(d).cuda()
+    full = K.quantize(full_sym, n, ct, qs, K.well_words(O.WELL_DEBUG_STATE, 0, n * c // 4), 0, dd)
+    for a, b in halves:
+        w = K.well_words(O.WELL_DEBUG_STATE, a * c // 4, (b - a) * c // 4)
+        part = K.quantize(upload_sym(K, rows[a:b]), b - a, ct, qs, w, a * c, dd)
+        assert torch.equal(part["qv"][:, : b - a], full["qv"][:, a:b])
+        assert torch.equal(part["err"], full["err"][a:b])
