@@ -37,6 +37,9 @@ typedef struct qvz_codebook {
     uint8_t *nstates;  /* [C][144]       size of the output alphabet                                          */
     uint8_t *recon;    /* [C][144][72]   output alphabet (reconstruction points, first nstates valid)         */
     uint8_t *out_idx;  /* [C][144][72]   value -> state index in the output alphabet (last writer wins)       */
+    uint8_t *live;     /* [C][72]        1 if the context's pmf P(X_s | Q_{s-1}) has mass, 0 for a "dead" context:
+                          a previous value no read can produce (the reference still stores quantizers for it,
+                          SURVEY.md Appendix E.5). Not in the file format; lets per-shard coder models skip them. */
 } qvz_codebook_t;
 
 qvz_codebook_t *qvz_codebook_alloc(uint32_t C);

@@ -57,34 +57,52 @@ static inline void put_run(qvz_coder_t *cd, uint32_t bit, uint64_t count) {
     }
 }
 
+/* Initial adaptive model (initialize_stream_stats qv_stream.c:32-61 and :96-104) as one flat arena of tables
+ * [n][card][counts...]: the cluster-id table first (index 0), then one table per (cluster, column, quantizer).
+ * live_only: leave out the quantizers of dead contexts (qvz_codebook_t.live == 0); they map to QVZ_NO_TABLE. */
+int qvz_model_build(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs, int live_only,
+                    uint32_t **arena_out, uint32_t **offset_out, uint32_t *words_out) {
+    size_t words = 2 + clusters;
+    for (uint32_t c = 0; c < clusters; ++c)
+        for (uint32_t s = 0; s < columns; ++s)
+            for (uint32_t j = 0; j < 2u * cbs[c]->nctx[s]; ++j)
+                if (!live_only || cbs[c]->live[(size_t)s * A + j / 2]) words += 2 + cbs[c]->nstates[(size_t)s * 2 * A + j];
+    if (words >= NO_TABLE) return -1;
+    uint32_t *arena = (uint32_t *)malloc(words * sizeof(uint32_t));
+    uint32_t *offset = (uint32_t *)malloc((size_t)clusters * columns * 2 * A * sizeof(uint32_t));
+    if (!arena || !offset) { free(arena); free(offset); return -1; }
+    uint32_t pos = 0;
+    arena[pos++] = clusters;                                    /* cluster_stats: n = card = k, counts 1 */
+    arena[pos++] = clusters;
+    for (uint32_t c = 0; c < clusters; ++c) arena[pos++] = 1;
+    for (uint32_t c = 0; c < clusters; ++c)
+        for (uint32_t s = 0; s < columns; ++s)
+            for (uint32_t j = 0; j < 2 * A; ++j) {
+                uint32_t *off = &offset[((size_t)c * columns + s) * 2 * A + j];
+                if (j >= 2u * cbs[c]->nctx[s] || (live_only && !cbs[c]->live[(size_t)s * A + j / 2])) { *off = NO_TABLE; continue; }
+                const uint32_t card = cbs[c]->nstates[(size_t)s * 2 * A + j];   /* qv_stream.c:46-53 */
+                *off = pos;
+                arena[pos++] = card;       /* n */
+                arena[pos++] = card;       /* alphabetCard */
+                for (uint32_t i = 0; i < card; ++i) arena[pos++] = 1;
+            }
+    *arena_out = arena;
+    *offset_out = offset;
+    *words_out = pos;
+    return 0;
+}
+
 qvz_coder_t *qvz_coder_create(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs) {
     qvz_coder_t *cd = (qvz_coder_t *)calloc(1, sizeof(*cd));
     if (!cd) return NULL;
     cd->clusters = clusters;
     cd->columns = columns;
-    size_t words = 2 + clusters;
-    for (uint32_t c = 0; c < clusters; ++c)
-        for (uint32_t s = 0; s < columns; ++s)
-            for (uint32_t j = 0; j < 2u * cbs[c]->nctx[s]; ++j) words += 2 + cbs[c]->nstates[(size_t)s * 2 * A + j];
-    cd->arena = (uint32_t *)malloc(words * sizeof(uint32_t));
-    cd->offset = (uint32_t *)malloc((size_t)clusters * columns * 2 * A * sizeof(uint32_t));
-    if (!cd->arena || !cd->offset || buf_reserve(cd, 1u << 20)) { qvz_coder_destroy(cd); return NULL; }
-    uint32_t pos = 0;
-    cd->cluster_table = pos;                                    /* qv_stream.c:96-104 */
-    cd->arena[pos++] = clusters;
-    cd->arena[pos++] = clusters;
-    for (uint32_t c = 0; c < clusters; ++c) cd->arena[pos++] = 1;
-    for (uint32_t c = 0; c < clusters; ++c)
-        for (uint32_t s = 0; s < columns; ++s)
-            for (uint32_t j = 0; j < 2 * A; ++j) {
-                uint32_t *off = &cd->offset[((size_t)c * columns + s) * 2 * A + j];
-                if (j >= 2u * cbs[c]->nctx[s]) { *off = NO_TABLE; continue; }
-                const uint32_t card = cbs[c]->nstates[(size_t)s * 2 * A + j];   /* qv_stream.c:46-53 */
-                *off = pos;
-                cd->arena[pos++] = card;       /* n */
-                cd->arena[pos++] = card;       /* alphabetCard */
-                for (uint32_t i = 0; i < card; ++i) cd->arena[pos++] = 1;
-            }
+    uint32_t words;
+    if (qvz_model_build(clusters, columns, cbs, 0, &cd->arena, &cd->offset, &words) || buf_reserve(cd, 1u << 20)) {
+        qvz_coder_destroy(cd);
+        return NULL;
+    }
+    cd->cluster_table = 0;
     cd->l = 0;                                                  /* arith.c:12-13 */
     cd->u = MASK_M;
     return cd;

@@ -48,11 +48,13 @@ extern "C" qvz_codebook_t *qvz_codebook_alloc(uint32_t C) {
     cb->nstates = (uint8_t *)calloc((size_t)C * 2 * A, 1);
     cb->recon = (uint8_t *)calloc((size_t)C * 2 * A * A, 1);
     cb->out_idx = (uint8_t *)malloc((size_t)C * 2 * A * A);
+    cb->live = (uint8_t *)malloc((size_t)C * A);
     if (!cb->nctx || !cb->ctx_sym || !cb->ctx_idx || !cb->qratio || !cb->ratio || !cb->q || !cb->nstates ||
-        !cb->recon || !cb->out_idx) {
+        !cb->recon || !cb->out_idx || !cb->live) {
         qvz_codebook_free(cb);
         return nullptr;
     }
+    memset(cb->live, 1, (size_t)C * A);      /* conservative default: every context may be visited */
     memset(cb->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
     memset(cb->out_idx, QVZ_NOT_FOUND, (size_t)C * 2 * A * A);
     return cb;
@@ -61,7 +63,7 @@ extern "C" qvz_codebook_t *qvz_codebook_alloc(uint32_t C) {
 extern "C" void qvz_codebook_free(qvz_codebook_t *cb) {
     if (!cb) return;
     free(cb->nctx); free(cb->ctx_sym); free(cb->ctx_idx); free(cb->qratio); free(cb->ratio);
-    free(cb->q); free(cb->nstates); free(cb->recon); free(cb->out_idx);
+    free(cb->q); free(cb->nstates); free(cb->recon); free(cb->out_idx); free(cb->live);
     free(cb);
 }
 
@@ -654,6 +656,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             }
             cb->ratio[(size_t)s * A + j] = ratio;
             cb->qratio[(size_t)s * A + j] = (uint8_t)(ratio * 128.);
+            cb->live[(size_t)s * A + j] = zero[j] ? 0 : 1;
         }
         // hand this column's tables and ratios to the next column's propagation
         memcpy(hq, cb->q + (size_t)s * 2 * tile, 2 * tile);
