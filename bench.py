@@ -49,6 +49,7 @@ ALG_BYTES_PER_SYMBOL = {
     "quantize": 5.0,             # symbol in, qv out, (qi, st) out, 1 B of WELL draws in
     "well_words": 1.0,
     "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out
+    "arith_shards": 2.0,         # 2-byte feed entry in (+ ~0.16 B/symbol of stream out); latency-bound integer chain
 }
 
 
@@ -96,6 +97,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (testing)")
     ap.add_argument("--shards", type=int, default=0, help="arithmetic-coded streams per GPU (default: host threads)")
     ap.add_argument("--threads", type=int, default=0, help="host coder threads per rank (default: cores / ranks)")
+    ap.add_argument("--coder", choices=["host", "gpu"], default="host",
+                    help="arithmetic coder: host threads, or one GPU lane per shard (byte-identical streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,7 +132,7 @@ def main():
         cores = os.cpu_count() or 1
     # a GPU box's CPU share is 16 cores per GPU even where more logical CPUs are visible
     threads = args.threads or max(1, min(16, cores // max(1, world)))
-    shards = args.shards or threads
+    shards = args.shards or (threads if args.coder == "host" else 16384)
     mode = host.MODE_RATIO if cfg["mode"] == "f" else host.MODE_FIXED
 
     sym = K.qgen1(cfg["seed"], n, c, first=first)          # synthetic input, resident in HBM before timing
@@ -144,7 +147,8 @@ def main():
 
     def step(timer=None):
         return P.encode_pass(sym, n, first, n_total, means0, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"],
-                             shards=shards, threads=threads, group=group, timer=timer, device_index=local)
+                             shards=shards, threads=threads, group=group, timer=timer, device_index=local,
+                             coder=args.coder)
 
     for _ in range(args.warmup):
         step()
@@ -190,7 +194,8 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic QGEN-1 (SURVEY.md Appendix D), generated on device",
             "config": {"workload": cfg["name"] + f" per GPU, reads sharded over {world} GPU(s)", "reads_per_gpu": n,
                        "columns": c, "clusters": k, "coder": f"{shards} independent reference-format streams per GPU "
-                       f"on {threads} host threads", "parallelism": f"read-sharded x{world}"},
+                       + (f"on {threads} host threads" if args.coder == "host" else "coded on the GPU, one lane per stream"),
+                       "parallelism": f"read-sharded x{world}"},
             "bits_per_symbol": round(stream_bytes * 8.0 / (n_total * c), 5),
             "distortion": results[-1]["distortion"], "kmeans_iterations": results[-1]["kmeans_iterations"],
             "phase_seconds": wall,

@@ -65,6 +65,22 @@ int qvz_encode_shards_device(const uint16_t *d_feed, const uint8_t *d_labels, ui
                              uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                              uint32_t threads, int device, uint8_t **streams, uint64_t *sizes);
 
+/* The same sharded coding on the GPU ("wavefront-serial" coder): one lane per shard runs the identical integer
+ * interval arithmetic and adaptive model, so stream g is byte-identical to what qvz_encode_shards_device (and the
+ * reference, for a file holding only that shard's reads) produces. d_out: shards * cap_per_shard bytes in HBM,
+ * stream g at d_out + g*cap_per_shard; h_sizes[g] receives its length. Fails with QVZ_E_NOMEM if a stream outgrows
+ * cap_per_shard (worst case 22 bits/symbol; 1 byte/symbol is ample for real data) and with QVZ_E_DEAD_CTX if the feed
+ * reaches a dead context (per-shard models hold live contexts only, qvz_codebook_t.live). */
+int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint64_t n, uint32_t columns,
+                          uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, uint8_t *d_out,
+                          uint64_t cap_per_shard, uint64_t *h_sizes, void *stream);
+
+/* Initial adaptive model as a flat arena of tables [n][card][counts...] (cluster-id table at index 0) plus the
+ * (cluster, column, quantizer) -> arena index map (0xFFFFFFFF = none). Shared by the host and GPU coders.
+ * Caller frees *arena_out and *offset_out with free(). Returns 0 on success. */
+int qvz_model_build(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs, int live_only,
+                    uint32_t **arena_out, uint32_t **offset_out, uint32_t *words_out);
+
 /* Reference-format file image of one shard: header(clusters, columns, shard_reads) + codebooks + 128-byte WELL
  * state + stream. buf == NULL returns the size. */
 size_t qvz_shard_file_image(uint8_t *buf, uint32_t clusters, uint32_t columns, uint64_t shard_reads,

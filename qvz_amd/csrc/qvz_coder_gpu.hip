@@ -1,0 +1,235 @@
+// qvz_coder_gpu.hip - "wavefront-serial" arithmetic coder on gfx950: one LANE per shard.
+//
+// The reference's stream (src/arith.c:24-116, src/qv_stream.c:9-25) is one serial chain of interval updates, so a
+// single stream cannot be parallelised bit-exactly. Sharded output (include/qvz_coder.h, SURVEY.md section 8e option B)
+// gives S independent chains: each lane below codes one contiguous range of reads exactly as the reference would
+// code a file holding only those reads - same integer interval arithmetic, same E1/E2/E3 renormalisation, same
+// adaptive counts (init 1, step 8, halve-and-+1 when n > 2^19) - with its own model arena in HBM. Lanes of a wave
+// run the same (read, column) step at the same time; what differs per lane is data: table addresses, symbol
+// values, shift counts. The kernel is latency-bound integer work, not a bandwidth kernel: its roofline is the
+// dependent-instruction chain per symbol, and throughput scales with the number of shards in flight.
+//
+// Exactness notes (same restructurings as the host coder, qvz_amd/csrc/host/qvz_coder.c):
+//   floor(range*cum/n): q = (u64)(prod * (1.0/n)) corrected by one step against prod - q*n; prod < 2^42, n < 2^21.
+//   E1/E2 and E3 loops: one count-leading-zeros batch each.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qvz_coder.h"
+#include "qvz_internal.h"
+
+#define A QVZ_A
+#define M_BITS 22u
+#define MSB (1u << (M_BITS - 1))
+#define MASK_M ((1u << M_BITS) - 1)
+#define MASK_M1 ((1u << (M_BITS - 1)) - 1)
+#define RESCALE (1u << (M_BITS - 3))
+#define STEP 8u
+#define NO_TABLE 0xFFFFFFFFu
+
+struct LaneCoder {
+    uint32_t l, u, scale3;
+    uint32_t nbits;          // valid bits in acc (< 32 between symbols)
+    uint64_t acc;            // MSB-first accumulator
+    uint8_t *out;
+    uint64_t pos, cap;
+    bool overflow;
+};
+
+__device__ __forceinline__ void lc_flush32(LaneCoder &c) {
+    // emit the top 32 pending bits as 4 big-endian bytes (pos stays 4-byte aligned)
+    const uint32_t w = (uint32_t)(c.acc >> (c.nbits - 32));
+    if (c.pos + 4 <= c.cap) *reinterpret_cast<uint32_t *>(c.out + c.pos) = __builtin_bswap32(w);
+    else c.overflow = true;
+    c.pos += 4;
+    c.nbits -= 32;
+}
+
+__device__ __forceinline__ void lc_put(LaneCoder &c, uint32_t value, uint32_t count) {   // count <= 32
+    c.acc = (c.acc << count) | (uint64_t)(count == 32 ? value : (value & ((1u << count) - 1)));
+    c.nbits += count;
+    if (c.nbits >= 32) lc_flush32(c);
+}
+
+__device__ __forceinline__ void lc_run(LaneCoder &c, uint32_t bit, uint32_t count) {
+    const uint32_t pat = bit ? 0xFFFFFFFFu : 0u;
+    while (count) {
+        const uint32_t k = count > 32 ? 32 : count;
+        lc_put(c, pat, k);
+        count -= k;
+    }
+}
+
+__device__ __forceinline__ uint32_t clz_field(uint32_t v, uint32_t width) {
+    return v ? (uint32_t)__clz((int)v) - (32 - width) : width;
+}
+
+__device__ __forceinline__ uint32_t exact_div(uint64_t prod, uint32_t n, double rn) {
+    int64_t q = (int64_t)((double)prod * rn);
+    const int64_t r = (int64_t)prod - q * (int64_t)n;
+    if (r < 0) q -= 1;
+    else if (r >= (int64_t)n) q += 1;
+    return (uint32_t)q;
+}
+
+// arithmetic_encoder_step (arith.c:24-97) + update_stats (qv_stream.c:9-25) on table t ([n][card][counts...])
+__device__ __forceinline__ void lc_encode(LaneCoder &c, uint32_t *__restrict__ t, uint32_t x) {
+    const uint32_t n = t[0], card = t[1];
+    uint32_t cum_lo = 0;
+    for (uint32_t i = 0; i < x; ++i) cum_lo += t[2 + i];
+    const uint32_t fx = t[2 + x];
+    const uint32_t cum_hi = cum_lo + fx;
+    const uint32_t range = c.u - c.l + 1;
+    const double rn = 1.0 / (double)n;
+    uint32_t u = c.l + exact_div((uint64_t)range * cum_hi, n, rn) - 1;
+    uint32_t l = c.l + exact_div((uint64_t)range * cum_lo, n, rn);
+
+    const uint32_t diff = l ^ u;
+    if (!(diff & MSB)) {                                        // E1/E2 batch
+        const uint32_t k = clz_field(diff, M_BITS);
+        const uint32_t top = l >> (M_BITS - k);
+        const uint32_t b = top >> (k - 1);
+        lc_put(c, b, 1);
+        if (c.scale3) { lc_run(c, !b, c.scale3); c.scale3 = 0; }
+        if (k > 1) lc_put(c, top & ((1u << (k - 1)) - 1), k - 1);
+        l = (l << k) & MASK_M;
+        u = ((u << k) & MASK_M) | ((1u << k) - 1);
+    }
+    {                                                           // E3 batch
+        const uint32_t ones_l = clz_field((~l) & MASK_M1, M_BITS - 1);
+        const uint32_t zeros_u = clz_field(u & MASK_M1, M_BITS - 1);
+        const uint32_t j = ones_l < zeros_u ? ones_l : zeros_u;
+        if (j) {
+            c.scale3 += j;
+            l = (l << j) & MASK_M1;
+            u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
+        }
+    }
+    c.l = l;
+    c.u = u;
+
+    t[2 + x] = fx + STEP;                                       // qv_stream.c:12-13
+    uint32_t nn = n + STEP;
+    if (nn > RESCALE) {                                         // qv_stream.c:15-24
+        nn = 0;
+        for (uint32_t i = 0; i < card; ++i) {
+            const uint32_t v = t[2 + i];
+            if (v) { const uint32_t h = (v >> 1) + 1; t[2 + i] = h; nn += h; }
+        }
+    }
+    t[0] = nn;
+}
+
+__global__ __launch_bounds__(64) void k_arith_shards(const uint16_t *__restrict__ feed, const uint8_t *__restrict__ labels,
+                                                     uint32_t C, uint32_t K, const uint64_t *__restrict__ first,
+                                                     uint32_t shards, const uint32_t *__restrict__ off,
+                                                     uint32_t *__restrict__ arena, uint32_t arena_words,
+                                                     uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ sizes,
+                                                     int32_t *__restrict__ status) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= shards) return;
+    const uint64_t r0 = first[g], r1 = first[g + 1];
+    uint32_t *ar = arena + (uint64_t)g * arena_words;
+    LaneCoder c;
+    c.l = 0; c.u = MASK_M; c.scale3 = 0; c.nbits = 0; c.acc = 0;
+    c.out = out + (uint64_t)g * cap; c.pos = 0; c.cap = cap; c.overflow = false;
+    bool bad = false;
+
+    for (uint64_t i = r0; i < r1; ++i) {
+        uint32_t cl = 0;
+        if (K > 1) {
+            cl = labels[i];
+            if (cl >= K) { bad = true; cl = 0; }
+            lc_encode(c, ar, cl);                               // qv_write_cluster (table 0 of the arena)
+        }
+        const uint32_t *offc = off + (uint64_t)cl * C * 2 * A;
+        const uint16_t *f = feed + i * C;
+        for (uint32_t s = 0; s < C; ++s) {
+            const uint32_t v = f[s];
+            const uint32_t qi = v & 0xFF, st = v >> 8;
+            const uint32_t o = qi < 2 * A ? offc[s * 2 * A + qi] : NO_TABLE;
+            if (o == NO_TABLE || st >= ar[o + 1]) { bad = true; continue; }
+            lc_encode(c, ar + o, st);                           // compress_qv
+        }
+    }
+    // encoder_last_step (arith.c:99-116) + stream_finish_byte (os_stream.c:105-110)
+    const uint32_t b = c.l >> (M_BITS - 1);
+    lc_put(c, b, 1);
+    if (c.scale3) { lc_run(c, !b, c.scale3); c.scale3 = 0; }
+    lc_put(c, c.l & MASK_M1, M_BITS - 1);
+    uint64_t total_bits = c.pos * 8 + c.nbits;
+    if (total_bits % 8) { const uint32_t pad = 8 - (uint32_t)(total_bits % 8); lc_put(c, 0, pad); total_bits += pad; }
+    else { lc_put(c, 0, 8); total_bits += 8; }                  // aligned streams still get one 0x00 byte
+    const uint64_t bytes = total_bits / 8;
+    while (c.nbits) {                                           // spill the remaining whole bytes
+        const uint32_t take = c.nbits >= 8 ? 8 : c.nbits;
+        const uint8_t byte = (uint8_t)((c.acc >> (c.nbits - take)) << (8 - take));
+        if (c.pos < c.cap) c.out[c.pos] = byte; else c.overflow = true;
+        c.pos += 1;
+        c.nbits -= take;
+    }
+    sizes[g] = bytes;
+    if (bad) atomicOr(status, 1);
+    if (c.overflow) atomicOr(status, 2);
+}
+
+// every shard starts from the same initial model
+__global__ __launch_bounds__(256) void k_arena_fill(const uint32_t *__restrict__ tmpl, uint32_t words, uint32_t shards,
+                                                    uint32_t *__restrict__ arena) {
+    const uint64_t total = (uint64_t)words * shards;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256)
+        arena[i] = tmpl[i % words];
+}
+
+extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint64_t n, uint32_t columns,
+                                     uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, uint8_t *d_out,
+                                     uint64_t cap_per_shard, uint64_t *h_sizes, void *stream) {
+    if (!d_feed || !n || !columns || !clusters || !shards || !d_out || !h_sizes) return qvz_set_error(QVZ_E_ARG, "bad shard-coder arguments");
+    if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
+    if (cap_per_shard & 3) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
+    if (qvz_model_build(clusters, columns, cbs, 1, &h_arena, &h_off, &words)) return qvz_set_error(QVZ_E_NOMEM, "model build failed");
+    uint64_t *h_first = (uint64_t *)malloc((shards + 1) * sizeof(uint64_t));
+    if (!h_first) { free(h_arena); free(h_off); return qvz_set_error(QVZ_E_NOMEM, "host alloc"); }
+    qvz_shard_bounds(n, shards, h_first);
+
+    uint32_t *d_tmpl = nullptr, *d_off = nullptr, *d_arena = nullptr;
+    uint64_t *d_first = nullptr, *d_sizes = nullptr;
+    int32_t *d_status = nullptr;
+    int rc = QVZ_OK;
+    int32_t status = 0;
+    const size_t offn = (size_t)clusters * columns * 2 * A;
+#define TRY(expr)                                                                                                    \
+    do {                                                                                                             \
+        hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+    TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
+    TRY(hipMalloc(&d_off, offn * 4));
+    TRY(hipMalloc(&d_arena, (size_t)words * shards * 4));
+    TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
+    TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
+    TRY(hipMalloc(&d_status, sizeof(int32_t)));
+    TRY(hipMemcpyAsync(d_tmpl, h_arena, (size_t)words * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
+    hipLaunchKernelGGL(k_arith_shards, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns, clusters, d_first,
+                       shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
+    TRY(hipGetLastError());
+    TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+    if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder feed addresses a quantizer without a model table (dead context or bad state)");
+    else if (status & 2) rc = qvz_set_error(QVZ_E_NOMEM, "a shard's stream exceeded cap_per_shard=%llu bytes", (unsigned long long)cap_per_shard);
+done:
+#undef TRY
+    (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
+    free(h_arena); free(h_off); free(h_first);
+    return rc;
+}

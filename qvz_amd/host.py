@@ -81,6 +81,30 @@ def encode_shards_device(feed, labels, n, columns, codebook_handles, shards, thr
     return out
 
 
+def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True):
+    """GPU sharded coder (one lane per shard). Returns (sizes, streams|None, out_tensor)."""
+    import torch
+    k = len(codebook_handles)
+    arr = (C.c_void_p * k)(*codebook_handles)
+    if cap_per_shard is None:
+        per = (n + shards - 1) // shards + 4
+        cap_per_shard = max(256, (per * columns) // 2 + 64)     # 4 bits/symbol: > 3x what real codebooks need
+    cap_per_shard = (cap_per_shard + 3) & ~3
+    out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=feed.device)
+    sizes = (C.c_uint64 * shards)()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib().qvz_hip_encode_shards(C.c_void_p(feed.data_ptr()), C.c_void_p(labels.data_ptr()) if labels is not None else None,
+                                     n, columns, k, arr, shards, C.c_void_p(out.data_ptr()), cap_per_shard, sizes, stream)
+    if rc:
+        raise QvzHipError(f"qvz_hip_encode_shards failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
+    sizes = [int(x) for x in sizes]
+    streams = None
+    if want_streams:
+        host_out = out.view(shards, cap_per_shard).cpu().numpy()
+        streams = [host_out[g, : sizes[g]].tobytes() for g in range(shards)]
+    return sizes, streams, out
+
+
 def shard_file_image(columns, shard_reads, codebook_handles, well_state_at_shard, stream):
     """Reference-format .q image of one shard (decodable by the unmodified reference decoder)."""
     k = len(codebook_handles)

@@ -73,9 +73,12 @@ class _Span:
 
 
 def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MODE_RATIO, ratio=0.5, dist="M",
-                threshold=4.0, well_state=None, shards=1, threads=1, group=None, timer=None, keep=False, device_index=0):
+                threshold=4.0, well_state=None, shards=1, threads=1, group=None, timer=None, keep=False, device_index=0,
+                coder="host"):
     """Runs k-means -> PMF -> codebooks -> WELL -> quantize -> feed -> sharded arithmetic coding for the reads
     [first_read, first_read+n) held in `sym` (this rank's shard of a file with n_total reads).
+    coder: "host" = `threads` host threads (qvz_encode_shards_device), "gpu" = one GPU lane per shard
+    (qvz_hip_encode_shards); both produce byte-identical streams.
 
     means0: (clusters, c) uint8 device tensor of the initial centroids (symbols). first_read must be a multiple of 4.
     Returns a dict with stream sizes, distortion, codebooks, phase wall times; with keep=True also the device outputs.
@@ -159,8 +162,15 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
 
     # ---- arithmetic coding: `shards` independent reference-format streams on `threads` host threads ----
     t4 = time.perf_counter()
-    streams = host.encode_shards_device(feed, labels if k > 1 else None, n, c, [cb.handle for cb in cbs], shards, threads,
-                                        device=device_index)
+    if coder == "gpu":
+        with timer.span("arith_shards"):
+            sizes, streams, coded = host.encode_shards_gpu(feed, labels if k > 1 else None, n, c, [cb.handle for cb in cbs],
+                                                           shards, want_streams=keep)
+        stream_sizes = sizes
+    else:
+        streams = host.encode_shards_device(feed, labels if k > 1 else None, n, c, [cb.handle for cb in cbs], shards, threads,
+                                            device=device_index)
+        stream_sizes = [len(s) for s in streams]
     wall["coder"] = time.perf_counter() - t4
 
     err_sum = (out["err"] / float(c)).sum()
@@ -168,7 +178,7 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
         dist_mod.all_reduce(err_sum, group=group)
     distortion = float(err_sum.item()) / float(n_total)
     wall["total"] = time.perf_counter() - t0
-    res = dict(stream_bytes=[len(s) for s in streams], total_stream_bytes=sum(len(s) for s in streams), distortion=distortion,
+    res = dict(stream_bytes=stream_sizes, total_stream_bytes=sum(stream_sizes), distortion=distortion,
                kmeans_iterations=iters, deferred=deferred, wall=wall, codebooks=cbs)
     if keep:
         res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, err=out["err"], feed=feed)

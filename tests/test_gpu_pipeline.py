@@ -61,6 +61,38 @@ def test_every_shard_is_reference_decodable(name, shards, threads):
     assert r["total_stream_bytes"] >= single * 0.98   # re-learning the model per shard costs bits, it never saves many
 
 
+@pytest.mark.parametrize("name,shards", [("t2k_r10_M", 1), ("t2k_r10_M", 7), ("t2k_c3_f05_M", 4), ("cfg1_f05_L", 64),
+                                         ("cfg1_r10_M", 300), ("const_f05", 2), ("uniform72_r20_A", 5), ("tiny5_r10", 2)])
+def test_gpu_coder_streams_equal_host_coder_streams(name, shards):
+    """The lane-per-shard GPU coder and the host C coder must emit the same bytes for every shard; with one shard
+    that is the reference's own stream."""
+    from qvz_amd import host, pipeline as P
+    rows, opts, n, c, sym, means0 = setup_case(name)
+    kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=shards, keep=True)
+    a = P.encode_pass(sym, n, 0, n, means0, threads=4, coder="host", **kw)
+    b = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
+    assert a["stream_bytes"] == b["stream_bytes"]
+    for g in range(shards):
+        assert a["streams"][g] == b["streams"][g], f"shard {g} differs between host and GPU coder"
+    if shards == 1:
+        assert b["total_stream_bytes"] == G.CASES[name]["size"]
+        assert b["streams"][0] == G.gz(name + ".q.gz")[-G.CASES[name]["size"]:]
+
+
+def test_gpu_coder_reports_overflow_and_bad_feed():
+    from qvz_amd import host, kernels as K, pipeline as P
+    rows, opts, n, c, sym, means0 = setup_case("t2k_r10_M")
+    r = P.encode_pass(sym, n, 0, n, means0, mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=2, coder="gpu",
+                      keep=True)
+    handles = [cb.handle for cb in r["codebooks"]]
+    with pytest.raises(Exception, match="cap_per_shard"):
+        host.encode_shards_gpu(r["feed"], None, n, c, handles, 2, cap_per_shard=64)
+    feed = r["feed"].clone()
+    feed[10, 3] = 143          # quantizer index with no model table
+    with pytest.raises(Exception, match="model table"):
+        host.encode_shards_gpu(feed, None, n, c, handles, 2)
+
+
 def test_read_sharded_ranks_equal_single_pass():
     """Two 'ranks' in one process: each quantizes its half with the global counters (summed by hand here, by RCCL in
     bench.py) and its WELL offset; the halves must reproduce the single-pass outputs bit for bit."""
