@@ -78,7 +78,9 @@ int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint6
 /* Initial adaptive model as a flat arena of tables [n][card][counts...] (cluster-id table at index 0) plus the
  * (cluster, column, quantizer) -> arena index map (0xFFFFFFFF = none). Shared by the host and GPU coders.
  * Caller frees *arena_out and *offset_out with free(). Returns 0 on success. */
-int qvz_model_build(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs, int live_only,
+#define QVZ_MODEL_LIVE_ONLY 1   /* leave out tables of dead contexts (qvz_codebook_t.live == 0) */
+#define QVZ_MODEL_ALIGN16 2     /* start every table on a 16-byte boundary */
+int qvz_model_build(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs, int flags,
                     uint32_t **arena_out, uint32_t **offset_out, uint32_t *words_out);
 
 /* Reference-format file image of one shard: header(clusters, columns, shard_reads) + codebooks + 128-byte WELL

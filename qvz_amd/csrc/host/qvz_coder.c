@@ -59,22 +59,28 @@ static inline void put_run(qvz_coder_t *cd, uint32_t bit, uint64_t count) {
 
 /* Initial adaptive model (initialize_stream_stats qv_stream.c:32-61 and :96-104) as one flat arena of tables
  * [n][card][counts...]: the cluster-id table first (index 0), then one table per (cluster, column, quantizer).
- * live_only: leave out the quantizers of dead contexts (qvz_codebook_t.live == 0); they map to QVZ_NO_TABLE. */
-int qvz_model_build(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs, int live_only,
+ * flags: QVZ_MODEL_LIVE_ONLY leaves out the quantizers of dead contexts (qvz_codebook_t.live == 0; they map to
+ * 0xFFFFFFFF), QVZ_MODEL_ALIGN16 starts every table on a 16-byte boundary (vector loads on the GPU). */
+int qvz_model_build(uint32_t clusters, uint32_t columns, const qvz_codebook_t *const *cbs, int flags,
                     uint32_t **arena_out, uint32_t **offset_out, uint32_t *words_out) {
-    size_t words = 2 + clusters;
+    size_t words;
+    const int aligned = flags & QVZ_MODEL_ALIGN16;
+    const int live_only = flags & QVZ_MODEL_LIVE_ONLY;
+#define PAD4(w) (aligned ? (((w) + 3u) & ~3u) : (w))
+    words = PAD4(2 + clusters);
     for (uint32_t c = 0; c < clusters; ++c)
         for (uint32_t s = 0; s < columns; ++s)
             for (uint32_t j = 0; j < 2u * cbs[c]->nctx[s]; ++j)
-                if (!live_only || cbs[c]->live[(size_t)s * A + j / 2]) words += 2 + cbs[c]->nstates[(size_t)s * 2 * A + j];
+                if (!live_only || cbs[c]->live[(size_t)s * A + j / 2]) words += PAD4(2u + cbs[c]->nstates[(size_t)s * 2 * A + j]);
     if (words >= NO_TABLE) return -1;
-    uint32_t *arena = (uint32_t *)malloc(words * sizeof(uint32_t));
+    uint32_t *arena = (uint32_t *)calloc(words, sizeof(uint32_t));
     uint32_t *offset = (uint32_t *)malloc((size_t)clusters * columns * 2 * A * sizeof(uint32_t));
     if (!arena || !offset) { free(arena); free(offset); return -1; }
     uint32_t pos = 0;
     arena[pos++] = clusters;                                    /* cluster_stats: n = card = k, counts 1 */
     arena[pos++] = clusters;
     for (uint32_t c = 0; c < clusters; ++c) arena[pos++] = 1;
+    pos = PAD4(pos);
     for (uint32_t c = 0; c < clusters; ++c)
         for (uint32_t s = 0; s < columns; ++s)
             for (uint32_t j = 0; j < 2 * A; ++j) {
@@ -85,7 +91,9 @@ int qvz_model_build(uint32_t clusters, uint32_t columns, const qvz_codebook_t *c
                 arena[pos++] = card;       /* n */
                 arena[pos++] = card;       /* alphabetCard */
                 for (uint32_t i = 0; i < card; ++i) arena[pos++] = 1;
+                pos = PAD4(pos);
             }
+#undef PAD4
     *arena_out = arena;
     *offset_out = offset;
     *words_out = pos;

@@ -67,13 +67,18 @@ __device__ __forceinline__ uint32_t clz_field(uint32_t v, uint32_t width) {
     return v ? (uint32_t)__clz((int)v) - (32 - width) : width;
 }
 
+// floor(prod / n) for prod < 2^42, n < 2^21 (so the quotient fits 32 bits). rn ~ 1/n from v_rcp_f64: the estimate
+// is within one of the true quotient, and one correction step against the exact remainder settles it.
 __device__ __forceinline__ uint32_t exact_div(uint64_t prod, uint32_t n, double rn) {
-    int64_t q = (int64_t)((double)prod * rn);
-    const int64_t r = (int64_t)prod - q * (int64_t)n;
+    const double pd = (double)(uint32_t)(prod >> 32) * 4294967296.0 + (double)(uint32_t)prod;   // exact: prod < 2^53
+    uint32_t q = (uint32_t)(pd * rn);
+    const int64_t r = (int64_t)prod - (int64_t)((uint64_t)q * n);
     if (r < 0) q -= 1;
     else if (r >= (int64_t)n) q += 1;
-    return (uint32_t)q;
+    return q;
 }
+
+__device__ __forceinline__ double fast_rcp(uint32_t n) { return __builtin_amdgcn_rcp((double)n); }
 
 // arithmetic_encoder_step (arith.c:24-97) + update_stats (qv_stream.c:9-25) on table t ([n][card][counts...])
 __device__ __forceinline__ void lc_encode(LaneCoder &c, uint32_t *__restrict__ t, uint32_t x) {
@@ -83,7 +88,7 @@ __device__ __forceinline__ void lc_encode(LaneCoder &c, uint32_t *__restrict__ t
     const uint32_t fx = t[2 + x];
     const uint32_t cum_hi = cum_lo + fx;
     const uint32_t range = c.u - c.l + 1;
-    const double rn = 1.0 / (double)n;
+    const double rn = fast_rcp(n);
     uint32_t u = c.l + exact_div((uint64_t)range * cum_hi, n, rn) - 1;
     uint32_t l = c.l + exact_div((uint64_t)range * cum_lo, n, rn);
 
@@ -176,6 +181,186 @@ __global__ __launch_bounds__(64) void k_arith_shards(const uint16_t *__restrict_
     if (c.overflow) atomicOr(status, 2);
 }
 
+// ---- software-pipelined variant -------------------------------------------------------------------------------
+// The simple kernel above is a chain of four dependent memory round trips per symbol (feed -> table offset ->
+// table -> interval). Here the data-independent part runs ahead of the interval chain in blocks of 4 symbols:
+//   iteration b:  issue table-header loads for block b+1 (offsets loaded one iteration ago)
+//                 issue offset look-ups      for block b+2 (feed loaded one iteration ago)
+//                 issue the 8-byte feed load for block b+3
+//                 then code block b from registers: {n, card, c0..c5} of each table were loaded one block ago.
+// Tables start on 16-byte boundaries (QVZ_MODEL_ALIGN16) so a header is two dwordx4 loads. A header prefetched up
+// to 7 symbols early is still current because two symbols less than C apart never share a table (a table belongs
+// to one column); hence the kernel is used for C >= 8 only.
+struct Hdr { uint4 a, b; };   // a = {n, card, c0, c1}, b = {c2, c3, c4, c5}
+
+__device__ __forceinline__ void lc_interval(LaneCoder &c, uint32_t n, uint32_t cum_lo, uint32_t fx) {
+    const uint32_t range = c.u - c.l + 1;
+    const double rn = fast_rcp(n);
+    uint32_t u = c.l + exact_div((uint64_t)range * (cum_lo + fx), n, rn) - 1;
+    uint32_t l = c.l + exact_div((uint64_t)range * cum_lo, n, rn);
+    const uint32_t diff = l ^ u;
+    if (!(diff & MSB)) {
+        const uint32_t k = clz_field(diff, M_BITS);
+        const uint32_t top = l >> (M_BITS - k);
+        const uint32_t b = top >> (k - 1);
+        lc_put(c, b, 1);
+        if (c.scale3) { lc_run(c, !b, c.scale3); c.scale3 = 0; }
+        if (k > 1) lc_put(c, top & ((1u << (k - 1)) - 1), k - 1);
+        l = (l << k) & MASK_M;
+        u = ((u << k) & MASK_M) | ((1u << k) - 1);
+    }
+    const uint32_t ones_l = clz_field((~l) & MASK_M1, M_BITS - 1);
+    const uint32_t zeros_u = clz_field(u & MASK_M1, M_BITS - 1);
+    const uint32_t j = ones_l < zeros_u ? ones_l : zeros_u;
+    if (j) {
+        c.scale3 += j;
+        l = (l << j) & MASK_M1;
+        u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
+    }
+    c.l = l;
+    c.u = u;
+}
+
+__device__ __forceinline__ void lc_encode_hdr(LaneCoder &c, uint32_t *__restrict__ t, const Hdr &h, uint32_t x) {
+    const uint32_t n = h.a.x, card = h.a.y;
+    uint32_t cum_lo, fx;
+    if (x < 6) {
+        const uint32_t c0 = h.a.z, c1 = h.a.w, c2 = h.b.x, c3 = h.b.y, c4 = h.b.z, c5 = h.b.w;
+        cum_lo = (x > 0 ? c0 : 0u) + (x > 1 ? c1 : 0u) + (x > 2 ? c2 : 0u) + (x > 3 ? c3 : 0u) + (x > 4 ? c4 : 0u);
+        fx = x == 0 ? c0 : x == 1 ? c1 : x == 2 ? c2 : x == 3 ? c3 : x == 4 ? c4 : c5;
+    } else {
+        cum_lo = h.a.z + h.a.w + h.b.x + h.b.y + h.b.z + h.b.w;
+        for (uint32_t i = 6; i < x; ++i) cum_lo += t[2 + i];
+        fx = t[2 + x];
+    }
+    lc_interval(c, n, cum_lo, fx);
+    t[2 + x] = fx + STEP;
+    uint32_t nn = n + STEP;
+    if (nn > RESCALE) {
+        nn = 0;
+        for (uint32_t i = 0; i < card; ++i) {
+            const uint32_t v = t[2 + i];
+            if (v) { const uint32_t hv = (v >> 1) + 1; t[2 + i] = hv; nn += hv; }
+        }
+    }
+    t[0] = nn;
+}
+
+template <bool HAVE_LABELS>
+__global__ __launch_bounds__(64) void k_arith_shards_pf(const uint16_t *__restrict__ feed, const uint8_t *__restrict__ labels,
+                                                        uint32_t C, uint32_t K, const uint64_t *__restrict__ first,
+                                                        uint32_t shards, const uint32_t *__restrict__ off,
+                                                        uint32_t *__restrict__ arena, uint32_t arena_words,
+                                                        uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ sizes,
+                                                        int32_t *__restrict__ status) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= shards) return;
+    const uint64_t r0 = first[g], r1 = first[g + 1];
+    const uint64_t T = (r1 - r0) * C;                            // symbols of this shard
+    const uint16_t *fbase = feed + r0 * C;                       // 8-byte aligned: r0 is a multiple of 4
+    uint32_t *ar = arena + (uint64_t)g * arena_words;
+    LaneCoder c;
+    c.l = 0; c.u = MASK_M; c.scale3 = 0; c.nbits = 0; c.acc = 0;
+    c.out = out + (uint64_t)g * cap; c.pos = 0; c.cap = cap; c.overflow = false;
+    bool bad = false;
+
+    auto load_feed = [&](uint64_t blk) -> uint2 {                // 4 feed entries of block blk
+        const uint64_t t0 = blk * 4;
+        if (t0 + 4 <= T) return *reinterpret_cast<const uint2 *>(fbase + t0);
+        uint32_t v[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 4; ++j) if (t0 + j < T) v[j] = fbase[t0 + j];
+        return make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    };
+    auto entry = [](const uint2 &w, int j) -> uint32_t { return ((j < 2 ? w.x : w.y) >> (16 * (j & 1))) & 0xFFFF; };
+    auto label_of = [&](uint64_t i) -> uint32_t {
+        if (!HAVE_LABELS) return 0u;
+        const uint32_t cl = labels[i];
+        return cl < K ? cl : 0u;
+    };
+
+    // prefetch cursor: (read, column) of the next symbol whose table offset has not been looked up yet
+    uint64_t pi = r0;
+    uint32_t ps = 0;
+    const uint32_t *poffc = off + (uint64_t)(r0 < r1 ? label_of(r0) : 0u) * C * 2 * A;
+    auto lookup_block = [&](const uint2 &w, uint64_t blk, uint32_t *o) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (blk * 4 + j < T) {
+                const uint32_t qi = entry(w, j) & 0xFF;
+                o[j] = qi < 2 * A ? poffc[ps * 2 * A + qi] : NO_TABLE;
+                if (++ps == C) {
+                    ps = 0;
+                    ++pi;
+                    if (pi < r1) poffc = off + (uint64_t)label_of(pi) * C * 2 * A;
+                }
+            } else {
+                o[j] = NO_TABLE;
+            }
+        }
+    };
+    auto load_hdrs = [&](const uint32_t *o, Hdr *h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(ar + (o[j] == NO_TABLE ? 0u : o[j]));
+            h[j].a = p[0];
+            h[j].b = p[1];                                       // may over-read into the next table: never used then
+        }
+    };
+
+    uint2 f0 = load_feed(0), f1 = load_feed(1), f2 = load_feed(2);
+    uint32_t o_cur[4], o_next[4], o_nn[4];
+    Hdr h_cur[4], h_next[4];
+    lookup_block(f0, 0, o_cur);
+    lookup_block(f1, 1, o_next);
+    load_hdrs(o_cur, h_cur);
+
+    uint64_t ci = r0;        // compute cursor
+    uint32_t cs = 0;
+    const uint64_t nblk = (T + 3) / 4;
+    for (uint64_t b = 0; b < nblk; ++b) {
+        load_hdrs(o_next, h_next);                               // block b+1
+        lookup_block(f2, b + 2, o_nn);                           // block b+2
+        const uint2 f3 = load_feed(b + 3);                       // block b+3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (b * 4 + j < T) {
+                if (HAVE_LABELS && cs == 0) {
+                    const uint32_t raw = labels[ci];
+                    if (raw >= K) bad = true;
+                    lc_encode(c, ar, raw < K ? raw : 0u);        // qv_write_cluster: table 0, straight from memory
+                }
+                const uint32_t st = entry(f0, j) >> 8;
+                const uint32_t o = o_cur[j];
+                if (o == NO_TABLE || st >= h_cur[j].a.y) bad = true;
+                else lc_encode_hdr(c, ar + o, h_cur[j], st);
+                if (++cs == C) { cs = 0; ++ci; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h_cur[j] = h_next[j]; o_cur[j] = o_next[j]; o_next[j] = o_nn[j]; }
+        f0 = f1; f1 = f2; f2 = f3;
+    }
+
+    const uint32_t bb = c.l >> (M_BITS - 1);                     // encoder_last_step + stream_finish_byte
+    lc_put(c, bb, 1);
+    if (c.scale3) { lc_run(c, !bb, c.scale3); c.scale3 = 0; }
+    lc_put(c, c.l & MASK_M1, M_BITS - 1);
+    uint64_t total_bits = c.pos * 8 + c.nbits;
+    if (total_bits % 8) { const uint32_t pad = 8 - (uint32_t)(total_bits % 8); lc_put(c, 0, pad); total_bits += pad; }
+    else { lc_put(c, 0, 8); total_bits += 8; }
+    const uint64_t bytes = total_bits / 8;
+    while (c.nbits) {
+        const uint32_t take = c.nbits >= 8 ? 8 : c.nbits;
+        const uint8_t byte = (uint8_t)((c.acc >> (c.nbits - take)) << (8 - take));
+        if (c.pos < c.cap) c.out[c.pos] = byte; else c.overflow = true;
+        c.pos += 1;
+        c.nbits -= take;
+    }
+    sizes[g] = bytes;
+    if (bad) atomicOr(status, 1);
+    if (c.overflow) atomicOr(status, 2);
+}
+
 // every shard starts from the same initial model
 __global__ __launch_bounds__(256) void k_arena_fill(const uint32_t *__restrict__ tmpl, uint32_t words, uint32_t shards,
                                                     uint32_t *__restrict__ arena) {
@@ -192,7 +377,8 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
     if (cap_per_shard & 3) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4");
     hipStream_t st = (hipStream_t)stream;
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
-    if (qvz_model_build(clusters, columns, cbs, 1, &h_arena, &h_off, &words)) return qvz_set_error(QVZ_E_NOMEM, "model build failed");
+    if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
+        return qvz_set_error(QVZ_E_NOMEM, "model build failed");
     uint64_t *h_first = (uint64_t *)malloc((shards + 1) * sizeof(uint64_t));
     if (!h_first) { free(h_arena); free(h_off); return qvz_set_error(QVZ_E_NOMEM, "host alloc"); }
     qvz_shard_bounds(n, shards, h_first);
@@ -210,7 +396,7 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
     } while (0)
     TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
     TRY(hipMalloc(&d_off, offn * 4));
-    TRY(hipMalloc(&d_arena, (size_t)words * shards * 4));
+    TRY(hipMalloc(&d_arena, ((size_t)words * shards + 8) * 4));   // + slack: a header prefetch reads 32 bytes
     TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
     TRY(hipMalloc(&d_status, sizeof(int32_t)));
@@ -219,8 +405,17 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
-    hipLaunchKernelGGL(k_arith_shards, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns, clusters, d_first,
-                       shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
+    if (columns >= 8 && !getenv("QVZ_CODER_SIMPLE")) {
+        if (clusters > 1)
+            hipLaunchKernelGGL(k_arith_shards_pf<true>, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns,
+                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
+        else
+            hipLaunchKernelGGL(k_arith_shards_pf<false>, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns,
+                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
+    } else {
+        hipLaunchKernelGGL(k_arith_shards, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns, clusters,
+                           d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
+    }
     TRY(hipGetLastError());
     TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));

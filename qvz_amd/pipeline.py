@@ -37,6 +37,17 @@ def reference_centroid_lines(n_total, k, reseed=True):
     return lines
 
 
+def rank_read_range(n_total, world, rank):
+    """Contiguous reads [first, last) of `rank` when a file of n_total reads is sharded over `world` ranks: equal
+    shares rounded up to a multiple of 4 reads, so every shard's first draw (first*C) sits on a WELL word boundary
+    (4 reads x C draws = C whole 4-draw words) for any C."""
+    per = -(-n_total // world)
+    per4 = (per + 3) & ~3
+    first = min(rank * per4, n_total)
+    last = n_total if rank == world - 1 else min((rank + 1) * per4, n_total)
+    return first, last
+
+
 class Timer:
     """Per-phase device timing with events recorded on the stream the kernels are launched on."""
 
