@@ -15,7 +15,11 @@ HOST_OBJS:= $(HOST_SRCS:.c=.o)
 HIP_OBJS := $(HIP_SRCS:.hip=.hip.o)
 HDRS     := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h)
 
-all: qvz_amd/libqvzhip.so qvz_amd/bin/qvz
+all: qvz_amd/libqvzhip.so qvz_amd/libqvzcompat.so qvz_amd/bin/qvz
+
+# the reference's own entry-point names (include/qvz_compat.h) in a library of their own
+qvz_amd/libqvzcompat.so: $(CSRC)/host/qvz_compat.c qvz_amd/libqvzhip.so $(HDRS)
+	$(CC) $(CFLAGS) -I$(CSRC)/host -shared -o $@ $(CSRC)/host/qvz_compat.c -Lqvz_amd -lqvzhip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
 
 $(CSRC)/host/%.o: $(CSRC)/host/%.c $(HDRS)
 	$(CC) $(CFLAGS) -c $< -o $@
@@ -34,6 +38,6 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f qvz_amd/libqvzhip.so qvz_amd/bin/qvz $(HOST_OBJS) $(HIP_OBJS)
+	rm -f qvz_amd/libqvzhip.so qvz_amd/libqvzcompat.so qvz_amd/bin/qvz $(HOST_OBJS) $(HIP_OBJS)
 
 .PHONY: all oracle clean

@@ -55,6 +55,10 @@ int qvz_distortion_matrix(int type, double *h_dist /*[72*72]*/);
 int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
                               double guard, qvz_codebook_t *out, void *stream);
 
+/* Marginal pmfs of one cluster, h_marg[s*72 + x]: the second half of calculate_statistics
+ * (reference src/codebook.c:208-219, combine_pmfs src/pmf.c:189-205), bit-identical to the reference's values. */
+int qvz_hip_marginals(const uint32_t *d_cnt, uint32_t C, double *h_marg, void *stream);
+
 /* Number of host-side decisions the last qvz_hip_generate_codebook call had to take inside the guard band */
 uint64_t qvz_hip_codebook_deferred_decisions(void);
 

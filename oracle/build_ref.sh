@@ -32,3 +32,11 @@ gcc -shared "$OUT"/objpic/*.o -o "$OUT/libqvzref.so" -lm -lrt
 echo "build_ref: built $OUT/qvz_ref $OUT/qvz_ref_fixedseed $OUT/libqvzref.so"
 gcc -O2 -w -I"$REF/include" -DLINUX "$HERE/ref_harness.c" -o "$OUT/ref_harness" -L"$OUT" -lqvzref -Wl,-rpath,'$ORIGIN' -lm -lrt
 echo "build_ref: built $OUT/ref_harness"
+# qvz_dropin: the reference's UNMODIFIED main.c + util.c linked against this repo's libqvzcompat.so (the reference's
+# entry-point names implemented on the MI355X, include/qvz_compat.h) instead of the reference's own objects.
+# It is the drop-in proof used by tests/test_gpu_dropin.py; rpath is relative so the binary works on the GPU box.
+if [ -f "$HERE/../qvz_amd/libqvzcompat.so" ]; then
+  gcc -O3 -w -I"$REF/include" -DLINUX "$REF/src/main.c" "$REF/src/util.c" -o "$OUT/qvz_dropin" \
+      -L"$HERE/../qvz_amd" -lqvzcompat -lqvzhip -Wl,-rpath,'$ORIGIN/../../qvz_amd' -Wl,-rpath-link,/opt/rocm/lib -lm -lrt
+  echo "build_ref: built $OUT/qvz_dropin (reference main.c on libqvzcompat.so)"
+fi

@@ -50,6 +50,7 @@ SIGNATURES = {
     "qvz_hip_generate_codebook": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.c_int, C.c_double,
                                             C.c_double, C.c_void_p, C.c_void_p]),
     "qvz_hip_codebook_deferred_decisions": (C.c_uint64, []),
+    "qvz_hip_marginals": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.c_void_p]),
     "qvz_codebook_tables": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "qvz_codebook_write_header": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "qvz_codebook_write": (C.c_size_t, [C.c_void_p, C.c_void_p]),

@@ -1,6 +1,7 @@
-/* qvz_encode.c - host C driver of the encode path (see include/qvz_encode.h). Counterpart of encode() in the
- * reference's src/main.c:18-127; prints the same -v / -s lines. All heavy phases are HIP kernel calls through
- * the C-ABI; this file owns file I/O, the k-means loop condition, libc rand() semantics and the serial coder. */
+/* qvz_encode.c - host C driver of the encode path (see include/qvz_encode.h, qvz_job.h). Counterpart of encode()
+ * in the reference's src/main.c:18-127; prints the same -v / -s lines. All heavy phases are HIP kernel calls
+ * through the C-ABI; this file owns file I/O, the k-means loop condition, libc rand() semantics and the serial
+ * coder. */
 #define _GNU_SOURCE
 #include "qvz_encode.h"
 
@@ -15,15 +16,15 @@
 
 #include "qvz_codebook.h"
 #include "qvz_coder.h"
+#include "qvz_job.h"
 
 #define A QVZ_A
-#define LINES_PER_BLOCK 1000000ull   /* MAX_LINES_PER_BLOCK, reference include/lines.h:12 */
 #define MAX_COLUMNS 1022u            /* MAX_READS_PER_LINE, reference include/lines.h:13 */
 
 static __thread char g_err[512] = "";
 const char *qvz_encode_last_error(void) { return g_err; }
 
-static int fail(int code, const char *fmt, ...) {
+int qvz_job_fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -34,7 +35,7 @@ static int fail(int code, const char *fmt, ...) {
 #define HIP(call)                                                                                   \
     do {                                                                                            \
         int rc_ = (call);                                                                           \
-        if (rc_) { rc = fail(rc_, "%s: %s", #call, qvz_hip_last_error()); goto done; }              \
+        if (rc_) { rc = qvz_job_fail(rc_, "%s: %s", #call, qvz_hip_last_error()); goto done; }      \
     } while (0)
 
 static double now(void) {
@@ -51,6 +52,193 @@ void qvz_options_default(qvz_options_t *o) {
     o->cluster_threshold = 4;     /* main.c:204 */
     o->mode = QVZ_MODE_RATIO;     /* uninitialised in the reference (main.c:198-204); README documents -f 0.5 */
     o->seed_mode = QVZ_SEED_TIME;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+int qvz_job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_t lines, uint32_t columns,
+                 const qvz_options_t *opts) {
+    memset(job, 0, sizeof(*job));
+    job->opts = *opts;
+    job->text = text;
+    if (bytes) {   /* load_file (lines.c:44-54): columns from the first line, lines = size / (columns+1) */
+        const uint8_t *nl = (const uint8_t *)memchr(text, '\n', bytes < MAX_COLUMNS + 2 ? bytes : MAX_COLUMNS + 2);
+        if (!nl) return qvz_job_fail(QVZ_E_DATA, "first line longer than %u symbols or missing newline (LF_ERROR_TOO_LONG)", MAX_COLUMNS);
+        columns = (uint32_t)(nl - text);
+        lines = columns ? bytes / ((uint64_t)columns + 1) : 0;
+    }
+    if (columns == 0 || columns > MAX_COLUMNS) return qvz_job_fail(QVZ_E_DATA, "bad column count %u", columns);
+    if (lines == 0) return qvz_job_fail(QVZ_E_DATA, "no complete line in the input");
+    if (lines >= (1ull << 32)) return qvz_job_fail(QVZ_E_ARG, "more than 2^32-1 lines: the .q header and the u32 counters cannot hold it (codebook.c:482)");
+    if (opts->clusters < 1 || opts->clusters > 255) return qvz_job_fail(QVZ_E_ARG, "clusters must be 1..255");
+    job->N = lines;
+    job->C = columns;
+    job->K = (uint32_t)opts->clusters;
+    job->ld = qvz_hip_ld(lines);
+    if (qvz_distortion_matrix(opts->distortion, job->h_dist)) return qvz_job_fail(QVZ_E_ARG, "%s", qvz_hip_last_error());
+
+    /* Centroid picks (cluster.c:198-204) use libc rand() in whatever state the process is in. They are drawn here,
+     * BEFORE the first HIP call: initialising the HIP runtime consumes rand() values of its own, which would shift
+     * the sequence away from what the reference binary sees in a fresh process. */
+    uint32_t block_count = (uint32_t)(lines / QVZ_LINES_PER_BLOCK);            /* lines.c:93-96 */
+    if ((uint64_t)block_count * QVZ_LINES_PER_BLOCK != lines) block_count += 1;
+    for (uint32_t j = 0; j < job->K; ++j) {
+        const uint32_t block_id = (uint32_t)rand() % block_count;
+        const uint64_t left = lines - (uint64_t)block_id * QVZ_LINES_PER_BLOCK;
+        const uint32_t count = left > QVZ_LINES_PER_BLOCK ? (uint32_t)QVZ_LINES_PER_BLOCK : (uint32_t)left;
+        const uint32_t line_id = (uint32_t)rand() % count;
+        job->centroid_lines[j] = (uint64_t)block_id * QVZ_LINES_PER_BLOCK + line_id;
+        if (opts->verbose) printf("Chose block %d, line %d.\n", block_id, line_id);
+    }
+    return 0;
+}
+
+int qvz_job_upload(qvz_job_t *job) {
+    int rc = 0;
+    const double t0 = now();
+    const uint64_t N = job->N, stride = (uint64_t)job->C + 1, ld = job->ld;
+    const uint32_t C = job->C;
+    uint8_t *d_up = NULL;
+    uint32_t *d_bad = NULL;
+    if (job->uploaded) return 0;
+    HIP(qvz_hip_set_device(job->opts.device));
+    const uint64_t up_reads = 1u << 21;   /* ~2M reads per staging copy; a multiple of 256 */
+    HIP(qvz_hip_malloc((void **)&job->d_sym, (size_t)C * ld));
+    HIP(qvz_hip_malloc((void **)&job->d_labels, ld));
+    HIP(qvz_hip_malloc((void **)&d_up, (size_t)(N < up_reads ? N : up_reads) * stride));
+    HIP(qvz_hip_malloc((void **)&d_bad, sizeof(uint32_t)));
+    HIP(qvz_hip_memset(d_bad, 0, sizeof(uint32_t), NULL));
+    HIP(qvz_hip_memset(job->d_labels, 0, ld, NULL));               /* calloc'd line_t.cluster, lines.c:116 */
+    for (uint64_t r0 = 0; r0 < N; r0 += up_reads) {
+        const uint64_t n = N - r0 < up_reads ? N - r0 : up_reads;
+        HIP(qvz_hip_copy_h2d(d_up, job->text + r0 * stride, n * stride, NULL));
+        HIP(qvz_hip_transpose_text(d_up, n, C, job->d_sym + r0, ld, d_bad, NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+    }
+    {
+        uint32_t bad = 0;
+        HIP(qvz_hip_copy_d2h(&bad, d_bad, sizeof(bad), NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+        if (bad) { rc = qvz_job_fail(QVZ_E_DATA, "%u input bytes outside '!'..'h' or lines without '\\n' (undefined behaviour in the reference, pmf.c:372-381)", bad); goto done; }
+    }
+    job->uploaded = 1;
+    job->t_upload = now() - t0;
+done:
+    qvz_hip_free(d_up);
+    qvz_hip_free(d_bad);
+    return rc;
+}
+
+int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
+    int rc = 0;
+    const double t0 = now();
+    const uint32_t K = job->K, C = job->C;
+    const uint64_t N = job->N, ld = job->ld, stride = (uint64_t)C + 1;
+    double *h_moved = NULL;
+    if ((rc = qvz_job_upload(job))) return rc;
+    job->h_means = (uint8_t *)malloc((size_t)K * C);
+    job->h_counts = (uint32_t *)calloc(K, sizeof(uint32_t));
+    job->h_acc = (uint64_t *)calloc((size_t)K * C, sizeof(uint64_t));
+    h_moved = (double *)malloc((K + 1) * sizeof(double));
+    if (!job->h_means || !job->h_counts || !job->h_acc || !h_moved) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+    for (uint32_t j = 0; j < K; ++j) {                                          /* memcpy of the read, cluster.c:201 */
+        const uint8_t *row = job->text + job->centroid_lines[j] * stride;
+        for (uint32_t s = 0; s < C; ++s) job->h_means[(size_t)j * C + s] = (uint8_t)(row[s] - 33);
+    }
+    HIP(qvz_hip_malloc((void **)&job->d_means, (size_t)K * C));
+    HIP(qvz_hip_malloc((void **)&job->d_counts, K * sizeof(uint32_t)));
+    HIP(qvz_hip_malloc((void **)&job->d_acc, (size_t)K * C * sizeof(uint64_t)));
+    HIP(qvz_hip_malloc((void **)&job->d_moved, (K + 1) * sizeof(double)));
+    HIP(qvz_hip_malloc((void **)&job->d_kstat, sizeof(int32_t)));
+    HIP(qvz_hip_copy_h2d(job->d_means, job->h_means, (size_t)K * C, NULL));
+    HIP(qvz_hip_memset(job->d_kstat, 0, sizeof(int32_t), NULL));
+    uint32_t iter = 0;
+    int loop = 1;
+    while (iter < 1000 && loop) {                                               /* cluster.c:221, cluster.h:9 */
+        int32_t kstat = 0;
+        HIP(qvz_hip_memset(job->d_counts, 0, K * sizeof(uint32_t), NULL));
+        HIP(qvz_hip_memset(job->d_acc, 0, (size_t)K * C * sizeof(uint64_t), NULL));
+        HIP(qvz_hip_kmeans_assign(job->d_sym, N, C, ld, K, job->d_means, job->d_labels, job->d_counts, NULL));
+        HIP(qvz_hip_kmeans_accumulate(job->d_sym, job->d_labels, N, C, ld, K, job->d_acc, NULL));
+        HIP(qvz_hip_kmeans_update(job->d_acc, job->d_counts, K, C, job->d_means, job->d_moved, job->d_kstat, NULL));
+        HIP(qvz_hip_copy_d2h(h_moved, job->d_moved, (K + 1) * sizeof(double), NULL));
+        HIP(qvz_hip_copy_d2h(&kstat, job->d_kstat, sizeof(kstat), NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+        if (kstat) { rc = qvz_job_fail(QVZ_E_EMPTY, "a cluster went empty during k-means (the reference divides by zero here, cluster.c:113)"); goto done; }
+        if (job->opts.verbose) {
+            for (uint32_t j = 0; j < K; ++j) printf("Cluster %d moved %f.\n", j, h_moved[1 + j]);   /* cluster.c:126-127 */
+            printf("\n");                                                       /* cluster.c:236-238 */
+        }
+        loop = h_moved[0] > job->opts.cluster_threshold;                        /* cluster.c:230-233 */
+        iter += 1;
+    }
+    if (job->opts.verbose) printf("\nTotal number of iterations: %d.\n", iter); /* cluster.c:241-243 */
+    job->kmeans_iterations = iter;
+    HIP(qvz_hip_copy_d2h(job->h_means, job->d_means, (size_t)K * C, NULL));
+    HIP(qvz_hip_copy_d2h(job->h_counts, job->d_counts, K * sizeof(uint32_t), NULL));
+    HIP(qvz_hip_copy_d2h(job->h_acc, job->d_acc, (size_t)K * C * sizeof(uint64_t), NULL));
+    if (want_host_labels) {
+        job->h_labels = (uint8_t *)malloc(N);
+        if (!job->h_labels) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        HIP(qvz_hip_copy_d2h(job->h_labels, job->d_labels, N, NULL));
+    }
+    HIP(qvz_hip_stream_sync(NULL));
+    job->clustered = 1;
+    job->t_cluster = now() - t0;
+done:
+    free(h_moved);
+    return rc;
+}
+
+int qvz_job_stats(qvz_job_t *job) {
+    int rc = 0;
+    const double t0 = now();
+    const size_t words = (size_t)job->K * job->C * A * A;
+    if ((rc = qvz_job_upload(job))) return rc;
+    HIP(qvz_hip_malloc((void **)&job->d_cnt, words * sizeof(uint32_t)));
+    HIP(qvz_hip_memset(job->d_cnt, 0, words * sizeof(uint32_t), NULL));
+    HIP(qvz_hip_pmf_hist(job->d_sym, job->K > 1 ? job->d_labels : NULL, job->N, job->C, job->ld, job->K, job->d_cnt, NULL));
+    HIP(qvz_hip_stream_sync(NULL));
+    job->counted = 1;
+    job->t_stats = now() - t0;
+done:
+    return rc;
+}
+
+int qvz_job_codebooks(qvz_job_t *job) {
+    int rc = 0;
+    const double t0 = now();
+    if (!job->counted && (rc = qvz_job_stats(job))) return rc;
+    job->cbs = (qvz_codebook_t **)calloc(job->K, sizeof(*job->cbs));
+    if (!job->cbs) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
+    for (uint32_t j = 0; j < job->K; ++j) {
+        job->cbs[j] = qvz_codebook_alloc(job->C);
+        if (!job->cbs[j]) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        HIP(qvz_hip_generate_codebook(job->d_cnt + (size_t)j * job->C * A * A, job->C, job->h_dist, job->opts.mode,
+                                      job->opts.ratio, 0.0, job->cbs[j], NULL));
+        job->deferred_decisions += qvz_hip_codebook_deferred_decisions();
+    }
+    job->t_codebook = now() - t0;
+done:
+    return rc;
+}
+
+int qvz_job_write_codebooks(qvz_job_t *job, FILE *fout, uint64_t *bytes) {   /* codebook.c:474-498 */
+    uint8_t hdr[9];
+    uint64_t total = 9;
+    qvz_codebook_write_header(hdr, job->K, job->C, job->N);
+    if (fwrite(hdr, 1, 9, fout) != 9) return qvz_job_fail(QVZ_E_ARG, "write failed");
+    for (uint32_t j = 0; j < job->K; ++j) {
+        const size_t sz = qvz_codebook_write(NULL, job->cbs[j]);
+        uint8_t *buf = (uint8_t *)malloc(sz);
+        if (!buf) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
+        qvz_codebook_write(buf, job->cbs[j]);
+        const size_t w = fwrite(buf, 1, sz, fout);
+        free(buf);
+        if (w != sz) return qvz_job_fail(QVZ_E_ARG, "write failed");
+        total += sz;
+    }
+    if (bytes) *bytes = total;
+    return 0;
 }
 
 /* One set of per-chunk buffers; two sets alternate so the GPU prepares chunk i+1 while the host codes chunk i */
@@ -77,198 +265,71 @@ static void chunk_free(chunk_t *ck) {
     memset(ck, 0, sizeof(*ck));
 }
 
-int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
-                      qvz_result_t *res) {
+static int issue_chunk(qvz_job_t *job, chunk_t *q, uint64_t r0, uint64_t chunk, const uint16_t *d_ct, const uint16_t *d_qs,
+                       const double *d_dist, int want_text) {
     int rc = 0;
-    qvz_result_t R;
-    memset(&R, 0, sizeof(R));
-    const double t_start = now();
-
-    /* load_file (lines.c:44-54): columns from the first line, lines = size / (columns+1) */
-    const uint8_t *nl = (const uint8_t *)memchr(text, '\n', bytes < MAX_COLUMNS + 2 ? bytes : MAX_COLUMNS + 2);
-    if (!nl) return fail(QVZ_E_DATA, "first line longer than %u symbols or missing newline (LF_ERROR_TOO_LONG)", MAX_COLUMNS);
-    const uint32_t C = (uint32_t)(nl - text);
-    if (C == 0) return fail(QVZ_E_DATA, "empty first line");
-    const uint64_t N = bytes / ((uint64_t)C + 1);
-    if (N == 0) return fail(QVZ_E_DATA, "no complete line in the input");
-    if (N >= (1ull << 32)) return fail(QVZ_E_ARG, "more than 2^32-1 lines: the .q header and the u32 counters cannot hold it (codebook.c:482)");
-    const uint32_t K = (uint32_t)opts->clusters;
-    if (K < 1 || K > 255) return fail(QVZ_E_ARG, "clusters must be 1..255");
+    const uint32_t C = job->C, K = job->K;
     const uint64_t stride = (uint64_t)C + 1;
-    const uint64_t ld = qvz_hip_ld(N);
+    q->r0 = r0;
+    q->n = job->N - r0 < chunk ? job->N - r0 : chunk;
+    const uint64_t fd = q->r0 * C, w0 = fd >> 2, w1 = ((q->r0 + q->n) * C + 3) >> 2, ldn = qvz_hip_ld(q->n);
+    HIP(qvz_hip_memset(q->d_status, 0, sizeof(int32_t), q->stream));
+    HIP(qvz_hip_well_words(job->well_state, w0, w1 - w0, q->d_words, q->stream));
+    HIP(qvz_hip_quantize(job->d_sym + q->r0, K > 1 ? job->d_labels + q->r0 : NULL, q->n, C, job->ld, K, d_ct, d_qs, q->d_words,
+                         fd, d_dist, q->d_qv, q->d_qi, q->d_st, ldn, q->d_err, q->d_status, q->stream));
+    HIP(qvz_hip_pack_feed(q->d_qi, q->d_st, q->n, C, ldn, q->d_feed, q->stream));
+    HIP(qvz_hip_copy_d2h(q->h_feed, q->d_feed, q->n * C * sizeof(uint16_t), q->stream));
+    HIP(qvz_hip_copy_d2h(q->h_err, q->d_err, q->n * sizeof(double), q->stream));
+    HIP(qvz_hip_copy_d2h(q->h_status, q->d_status, sizeof(int32_t), q->stream));
+    if (K > 1) HIP(qvz_hip_copy_d2h(q->h_labels, job->d_labels + q->r0, q->n, q->stream));
+    if (want_text) {
+        HIP(qvz_hip_untranspose_text(q->d_qv, q->n, C, ldn, q->d_text, q->stream));
+        HIP(qvz_hip_copy_d2h(q->h_text, q->d_text, q->n * stride, q->stream));
+    }
+done:
+    return rc;
+}
 
-    uint8_t *d_sym = NULL, *d_labels = NULL, *d_means = NULL, *d_up = NULL;
-    uint32_t *d_cnt = NULL, *d_counts = NULL, *d_bad = NULL;
-    uint64_t *d_acc = NULL;
-    double *d_moved = NULL, *d_dist = NULL;
-    int32_t *d_kstat = NULL;
+int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_bytes, double *distortion_out) {
+    int rc = 0;
+    const double t0 = now();
+    const uint32_t C = job->C, K = job->K;
+    const uint64_t N = job->N, stride = (uint64_t)C + 1;
     uint16_t *d_ct = NULL, *d_qs = NULL, *h_ct = NULL, *h_qs = NULL;
-    qvz_codebook_t **cbs = NULL;
+    double *d_dist = NULL;
     qvz_coder_t *coder = NULL;
     chunk_t ck[2];
     memset(ck, 0, sizeof(ck));
-    double h_dist[A * A];
 
-    /* Centroid picks (cluster.c:198-204) use libc rand() in whatever state the process is in. They are drawn
-     * BEFORE the first HIP call: initialising the HIP runtime consumes rand() values of its own, which would
-     * shift the sequence away from what the reference binary sees in a fresh process. */
-    uint64_t cent_lines[256];
-    {
-        uint32_t block_count = (uint32_t)(N / LINES_PER_BLOCK);               /* lines.c:93-96 */
-        if ((uint64_t)block_count * LINES_PER_BLOCK != N) block_count += 1;
-        for (uint32_t j = 0; j < K; ++j) {
-            const uint32_t block_id = (uint32_t)rand() % block_count;
-            const uint64_t left = N - (uint64_t)block_id * LINES_PER_BLOCK;
-            const uint32_t count = left > LINES_PER_BLOCK ? (uint32_t)LINES_PER_BLOCK : (uint32_t)left;
-            const uint32_t line_id = (uint32_t)rand() % count;
-            cent_lines[j] = (uint64_t)block_id * LINES_PER_BLOCK + line_id;
-            if (opts->verbose) printf("Chose block %d, line %d.\n", block_id, line_id);
-        }
-    }
-
-    HIP(qvz_hip_set_device(opts->device));
-    HIP(qvz_distortion_matrix(opts->distortion, h_dist));
-
-    /* ---- upload + transpose: replaces the row-major pointer view of load_file ---------------------------- */
-    const uint64_t up_reads = 1u << 21;   /* ~2M reads per staging copy */
-    HIP(qvz_hip_malloc((void **)&d_sym, (size_t)C * ld));
-    HIP(qvz_hip_malloc((void **)&d_labels, ld));
-    HIP(qvz_hip_malloc((void **)&d_up, (size_t)(N < up_reads ? N : up_reads) * stride));
-    HIP(qvz_hip_malloc((void **)&d_bad, sizeof(uint32_t)));
-    HIP(qvz_hip_memset(d_bad, 0, sizeof(uint32_t), NULL));
-    HIP(qvz_hip_memset(d_labels, 0, ld, NULL));                  /* calloc'd line_t.cluster, lines.c:116 */
-    for (uint64_t r0 = 0; r0 < N; r0 += up_reads) {
-        const uint64_t n = N - r0 < up_reads ? N - r0 : up_reads;
-        HIP(qvz_hip_copy_h2d(d_up, text + r0 * stride, n * stride, NULL));
-        HIP(qvz_hip_transpose_text(d_up, n, C, d_sym + r0, ld, d_bad, NULL));   /* r0 is a multiple of 256 */
-        HIP(qvz_hip_stream_sync(NULL));
-    }
-    {
-        uint32_t bad = 0;
-        HIP(qvz_hip_copy_d2h(&bad, d_bad, sizeof(bad), NULL));
-        HIP(qvz_hip_stream_sync(NULL));
-        if (bad) { rc = fail(QVZ_E_DATA, "%u input bytes outside '!'..'h' or lines without '\\n' (undefined behaviour in the reference, pmf.c:372-381)", bad); goto done; }
-    }
-    qvz_hip_free(d_up); d_up = NULL;
-    R.t_upload = now() - t_start;
-
-    /* ---- k-means (cluster.c:192-244) ------------------------------------------------------------------ */
-    const double t_cluster0 = now();
-    {
-        uint8_t *h_means = (uint8_t *)malloc((size_t)K * C);
-        double *h_moved = (double *)malloc((K + 1) * sizeof(double));
-        if (!h_means || !h_moved) { free(h_means); free(h_moved); rc = fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        for (uint32_t j = 0; j < K; ++j) {
-            const uint8_t *row = text + cent_lines[j] * stride;
-            for (uint32_t s = 0; s < C; ++s) h_means[(size_t)j * C + s] = (uint8_t)(row[s] - 33);
-        }
-        int krc = 0;
-        if ((krc = qvz_hip_malloc((void **)&d_means, (size_t)K * C)) || (krc = qvz_hip_malloc((void **)&d_counts, K * sizeof(uint32_t))) ||
-            (krc = qvz_hip_malloc((void **)&d_acc, (size_t)K * C * sizeof(uint64_t))) ||
-            (krc = qvz_hip_malloc((void **)&d_moved, (K + 1) * sizeof(double))) ||
-            (krc = qvz_hip_malloc((void **)&d_kstat, sizeof(int32_t))) ||
-            (krc = qvz_hip_copy_h2d(d_means, h_means, (size_t)K * C, NULL)) || (krc = qvz_hip_memset(d_kstat, 0, sizeof(int32_t), NULL))) {
-            free(h_means); free(h_moved);
-            rc = fail(krc, "k-means setup: %s", qvz_hip_last_error());
-            goto done;
-        }
-        uint32_t iter = 0;
-        int loop = 1;
-        while (iter < 1000 && loop) {                                          /* cluster.c:221, cluster.h:9 */
-            int32_t kstat = 0;
-            if ((krc = qvz_hip_memset(d_counts, 0, K * sizeof(uint32_t), NULL)) ||
-                (krc = qvz_hip_memset(d_acc, 0, (size_t)K * C * sizeof(uint64_t), NULL)) ||
-                (krc = qvz_hip_kmeans_assign(d_sym, N, C, ld, K, d_means, d_labels, d_counts, NULL)) ||
-                (krc = qvz_hip_kmeans_accumulate(d_sym, d_labels, N, C, ld, K, d_acc, NULL)) ||
-                (krc = qvz_hip_kmeans_update(d_acc, d_counts, K, C, d_means, d_moved, d_kstat, NULL)) ||
-                (krc = qvz_hip_copy_d2h(h_moved, d_moved, (K + 1) * sizeof(double), NULL)) ||
-                (krc = qvz_hip_copy_d2h(&kstat, d_kstat, sizeof(kstat), NULL)) || (krc = qvz_hip_stream_sync(NULL)))
-                break;
-            if (kstat) { krc = QVZ_E_EMPTY; break; }
-            if (opts->verbose) {
-                for (uint32_t j = 0; j < K; ++j) printf("Cluster %d moved %f.\n", j, h_moved[1 + j]);   /* cluster.c:126-127 */
-                printf("\n");                                                  /* cluster.c:236-238 */
-            }
-            loop = h_moved[0] > opts->cluster_threshold;                       /* cluster.c:230-233 */
-            iter += 1;
-        }
-        free(h_means); free(h_moved);
-        if (krc == QVZ_E_EMPTY) { rc = fail(krc, "a cluster went empty during k-means (the reference divides by zero here, cluster.c:113)"); goto done; }
-        if (krc) { rc = fail(krc, "k-means: %s", qvz_hip_last_error()); goto done; }
-        if (opts->verbose) printf("\nTotal number of iterations: %d.\n", iter);   /* cluster.c:241-243 */
-        R.kmeans_iterations = iter;
-    }
-    R.t_cluster = now() - t_cluster0;
-    if (opts->verbose) printf("Clustering took %.4f seconds\n", R.t_cluster);     /* main.c:56-58 */
-
-    /* ---- statistics + codebooks (main.c:61-67) -------------------------------------------------------- */
-    const double t_stats0 = now();
-    HIP(qvz_hip_malloc((void **)&d_cnt, (size_t)K * C * A * A * sizeof(uint32_t)));
-    HIP(qvz_hip_memset(d_cnt, 0, (size_t)K * C * A * A * sizeof(uint32_t), NULL));
-    HIP(qvz_hip_pmf_hist(d_sym, K > 1 ? d_labels : NULL, N, C, ld, K, d_cnt, NULL));
-    HIP(qvz_hip_stream_sync(NULL));
-    R.t_stats = now() - t_stats0;
-    cbs = (qvz_codebook_t **)calloc(K, sizeof(*cbs));
-    if (!cbs) { rc = fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-    for (uint32_t j = 0; j < K; ++j) {
-        cbs[j] = qvz_codebook_alloc(C);
-        if (!cbs[j]) { rc = fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        HIP(qvz_hip_generate_codebook(d_cnt + (size_t)j * C * A * A, C, h_dist, opts->mode, opts->ratio, 0.0, cbs[j], NULL));
-        R.deferred_decisions += qvz_hip_codebook_deferred_decisions();
-    }
-    R.t_codebook = now() - t_stats0 - R.t_stats;
-    if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", now() - t_stats0);   /* main.c:66-67 */
-
-    /* ---- write_codebooks (codebook.c:474-498) + WELL state (qv_stream.c:70-89) ------------------------ */
-    const double t_encode0 = now();
-    uint64_t file_bytes = 0;
-    {
-        uint8_t hdr[9];
-        qvz_codebook_write_header(hdr, K, C, N);
-        if (fwrite(hdr, 1, 9, fout) != 9) { rc = fail(QVZ_E_ARG, "write failed"); goto done; }
-        file_bytes += 9;
-        for (uint32_t j = 0; j < K; ++j) {
-            const size_t sz = qvz_codebook_write(NULL, cbs[j]);
-            uint8_t *buf = (uint8_t *)malloc(sz);
-            if (!buf) { rc = fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-            qvz_codebook_write(buf, cbs[j]);
-            const size_t w = fwrite(buf, 1, sz, fout);
-            free(buf);
-            if (w != sz) { rc = fail(QVZ_E_ARG, "write failed"); goto done; }
-            file_bytes += sz;
-        }
-    }
-    uint32_t well_state[32];
-    if (opts->seed_mode == QVZ_SEED_EXPLICIT) {
-        memcpy(well_state, opts->well_state, sizeof(well_state));
+    /* WELL state (qv_stream.c:70-89): written right after the codebooks */
+    if (job->opts.seed_mode == QVZ_SEED_EXPLICIT) {
+        memcpy(job->well_state, job->opts.well_state, sizeof(job->well_state));
     } else {
         srand((uint32_t)time(0));                                              /* qv_stream.c:77 (also in -DDEBUG builds) */
-        for (int i = 0; i < 32; ++i) well_state[i] = opts->seed_mode == QVZ_SEED_DEBUG ? 0x55555555u : (uint32_t)rand();
+        for (int i = 0; i < 32; ++i) job->well_state[i] = job->opts.seed_mode == QVZ_SEED_DEBUG ? 0x55555555u : (uint32_t)rand();
     }
-    if (fwrite(well_state, sizeof(uint32_t), 32, fout) != 32) { rc = fail(QVZ_E_ARG, "write failed"); goto done; }
-    file_bytes += 128;
+    if (fwrite(job->well_state, sizeof(uint32_t), 32, fout) != 32) return qvz_job_fail(QVZ_E_ARG, "write failed");
 
-    /* ---- quantizer tables ----------------------------------------------------------------------------- */
-    {
+    {   /* quantizer tables */
         const size_t ctn = (size_t)K * C * QVZ_CT_STRIDE, qsn = (size_t)K * C * QVZ_QS_STRIDE;
         h_ct = (uint16_t *)malloc(ctn * sizeof(uint16_t));
         h_qs = (uint16_t *)malloc(qsn * sizeof(uint16_t));
-        if (!h_ct || !h_qs) { rc = fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        if (!h_ct || !h_qs) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
         for (uint32_t j = 0; j < K; ++j)
-            qvz_codebook_tables(cbs[j], h_ct + (size_t)j * C * QVZ_CT_STRIDE, h_qs + (size_t)j * C * QVZ_QS_STRIDE);
+            qvz_codebook_tables(job->cbs[j], h_ct + (size_t)j * C * QVZ_CT_STRIDE, h_qs + (size_t)j * C * QVZ_QS_STRIDE);
         HIP(qvz_hip_malloc((void **)&d_ct, ctn * sizeof(uint16_t)));
         HIP(qvz_hip_malloc((void **)&d_qs, qsn * sizeof(uint16_t)));
-        HIP(qvz_hip_malloc((void **)&d_dist, sizeof(h_dist)));
+        HIP(qvz_hip_malloc((void **)&d_dist, sizeof(job->h_dist)));
         HIP(qvz_hip_copy_h2d(d_ct, h_ct, ctn * sizeof(uint16_t), NULL));
         HIP(qvz_hip_copy_h2d(d_qs, h_qs, qsn * sizeof(uint16_t), NULL));
-        HIP(qvz_hip_copy_h2d(d_dist, h_dist, sizeof(h_dist), NULL));
+        HIP(qvz_hip_copy_h2d(d_dist, job->h_dist, sizeof(job->h_dist), NULL));
         HIP(qvz_hip_stream_sync(NULL));
     }
 
-    /* ---- quantize (GPU) + arithmetic coding (host), chunked and overlapped (qv_compressor.c:48-143) ---- */
-    coder = qvz_coder_create(K, C, (const qvz_codebook_t *const *)cbs);
-    if (!coder) { rc = fail(QVZ_E_NOMEM, "coder alloc"); goto done; }
-    uint64_t chunk = opts->chunk_reads ? opts->chunk_reads : (1u << 20);
+    /* quantize (GPU) + arithmetic coding (host), chunked and overlapped (qv_compressor.c:48-143) */
+    coder = qvz_coder_create(K, C, (const qvz_codebook_t *const *)job->cbs);
+    if (!coder) { rc = qvz_job_fail(QVZ_E_NOMEM, "coder alloc"); goto done; }
+    uint64_t chunk = job->opts.chunk_reads ? job->opts.chunk_reads : (1u << 20);
     chunk = (chunk + 255) & ~255ull;
     if (chunk > ((N + 255) & ~255ull)) chunk = (N + 255) & ~255ull;
     const uint64_t ldc = qvz_hip_ld(chunk);
@@ -295,71 +356,87 @@ int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu,
         double distortion = 0.0;
         uint64_t next = 0;       /* first read not yet issued to the GPU */
         int cur = 0;
-        /* issue(): GPU side of one chunk on its own stream */
-#define ISSUE(set)                                                                                               \
-    do {                                                                                                         \
-        chunk_t *q_ = &ck[set];                                                                                  \
-        q_->r0 = next;                                                                                           \
-        q_->n = N - next < chunk ? N - next : chunk;                                                             \
-        const uint64_t fd_ = q_->r0 * C, w0_ = fd_ >> 2, w1_ = ((q_->r0 + q_->n) * C + 3) >> 2;                  \
-        HIP(qvz_hip_memset(q_->d_status, 0, sizeof(int32_t), q_->stream));                                       \
-        HIP(qvz_hip_well_words(well_state, w0_, w1_ - w0_, q_->d_words, q_->stream));                            \
-        HIP(qvz_hip_quantize(d_sym + q_->r0, K > 1 ? d_labels + q_->r0 : NULL, q_->n, C, ld, K, d_ct, d_qs,      \
-                             q_->d_words, fd_, d_dist, q_->d_qv, q_->d_qi, q_->d_st, qvz_hip_ld(q_->n), q_->d_err, \
-                             q_->d_status, q_->stream));                                                         \
-        HIP(qvz_hip_pack_feed(q_->d_qi, q_->d_st, q_->n, C, qvz_hip_ld(q_->n), q_->d_feed, q_->stream));          \
-        HIP(qvz_hip_copy_d2h(q_->h_feed, q_->d_feed, q_->n * C * sizeof(uint16_t), q_->stream));                 \
-        HIP(qvz_hip_copy_d2h(q_->h_err, q_->d_err, q_->n * sizeof(double), q_->stream));                         \
-        HIP(qvz_hip_copy_d2h(q_->h_status, q_->d_status, sizeof(int32_t), q_->stream));                          \
-        if (K > 1) HIP(qvz_hip_copy_d2h(q_->h_labels, d_labels + q_->r0, q_->n, q_->stream));                    \
-        if (fu) {                                                                                                \
-            HIP(qvz_hip_untranspose_text(q_->d_qv, q_->n, C, qvz_hip_ld(q_->n), q_->d_text, q_->stream));         \
-            HIP(qvz_hip_copy_d2h(q_->h_text, q_->d_text, q_->n * stride, q_->stream));                           \
-        }                                                                                                        \
-        next += q_->n;                                                                                           \
-    } while (0)
-
         HIP(qvz_hip_stream_sync(NULL));
-        ISSUE(cur);
+        if ((rc = issue_chunk(job, &ck[cur], next, chunk, d_ct, d_qs, d_dist, fu != NULL))) goto done;
+        next += ck[cur].n;
         while (ck[cur].n) {
             chunk_t *q = &ck[cur];
             HIP(qvz_hip_stream_sync(q->stream));
             ck[cur ^ 1].n = 0;
-            if (next < N) ISSUE(cur ^ 1);      /* the GPU prepares the next chunk while this one is coded */
-            if (*q->h_status) { rc = fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
-            if (opts->verbose) {
+            if (next < N) {      /* the GPU prepares the next chunk while this one is coded */
+                if ((rc = issue_chunk(job, &ck[cur ^ 1], next, chunk, d_ct, d_qs, d_dist, fu != NULL))) goto done;
+                next += ck[cur ^ 1].n;
+            }
+            if (*q->h_status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
+            if (job->opts.verbose) {
                 /* "Line: %dM" at the first line of every 1M-line block (qv_compressor.c:79-81) */
-                for (uint64_t blk = (q->r0 + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK; blk * LINES_PER_BLOCK < q->r0 + q->n; ++blk)
+                for (uint64_t blk = (q->r0 + QVZ_LINES_PER_BLOCK - 1) / QVZ_LINES_PER_BLOCK; blk * QVZ_LINES_PER_BLOCK < q->r0 + q->n; ++blk)
                     printf("Line: %dM\n", (int)blk);
             }
-            if (qvz_coder_encode(coder, K > 1 ? q->h_labels : NULL, q->h_feed, q->n)) { rc = fail(QVZ_E_DATA, "coder feed out of range"); goto done; }
+            if (qvz_coder_encode(coder, K > 1 ? q->h_labels : NULL, q->h_feed, q->n)) { rc = qvz_job_fail(QVZ_E_DATA, "coder feed out of range"); goto done; }
             for (uint64_t i = 0; i < q->n; ++i) distortion += q->h_err[i] / ((double)C);   /* qv_compressor.c:127 */
-            if (fu && fwrite(q->h_text, 1, q->n * stride, fu) != q->n * stride) { rc = fail(QVZ_E_ARG, "write failed"); goto done; }
+            if (fu && fwrite(q->h_text, 1, q->n * stride, fu) != q->n * stride) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
             {
                 uint64_t sz;
                 const uint8_t *data = qvz_coder_data(coder, &sz);
-                if (sz && fwrite(data, 1, sz, fout) != sz) { rc = fail(QVZ_E_ARG, "write failed"); goto done; }
+                if (sz && fwrite(data, 1, sz, fout) != sz) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
                 qvz_coder_drop(coder, sz);
             }
             cur ^= 1;
         }
-#undef ISSUE
         qvz_coder_finish(coder);                                               /* encoder_last_step, arith.c:99-116 */
         {
             uint64_t sz;
             const uint8_t *data = qvz_coder_data(coder, &sz);
-            if (sz && fwrite(data, 1, sz, fout) != sz) { rc = fail(QVZ_E_ARG, "write failed"); goto done; }
+            if (sz && fwrite(data, 1, sz, fout) != sz) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
             qvz_coder_drop(coder, sz);
         }
-        R.distortion = distortion / ((double)N);                               /* qv_compressor.c:139-140 */
+        if (distortion_out) *distortion_out = distortion / ((double)N);       /* qv_compressor.c:139-140 */
     }
-    R.stream_bytes = qvz_coder_bytes(coder);
-    R.file_bytes = file_bytes + R.stream_bytes;
-    R.lines = N;
-    R.columns = C;
-    R.t_encode = now() - t_encode0;
-    R.t_total = now() - t_start;
+    if (stream_bytes) *stream_bytes = qvz_coder_bytes(coder);
+    job->t_encode = now() - t0;
+done:
+    for (int b = 0; b < 2; ++b) chunk_free(&ck[b]);
+    qvz_coder_destroy(coder);
+    free(h_ct); free(h_qs);
+    qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist);
+    return rc;
+}
 
+void qvz_job_release(qvz_job_t *job) {
+    if (job->cbs) { for (uint32_t j = 0; j < job->K; ++j) qvz_codebook_free(job->cbs[j]); free(job->cbs); }
+    free(job->h_labels); free(job->h_means); free(job->h_counts); free(job->h_acc);
+    qvz_hip_free(job->d_sym); qvz_hip_free(job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
+    qvz_hip_free(job->d_counts); qvz_hip_free(job->d_acc); qvz_hip_free(job->d_moved); qvz_hip_free(job->d_kstat);
+    memset(job, 0, sizeof(*job));
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
+                      qvz_result_t *res) {
+    qvz_job_t job;
+    qvz_result_t R;
+    memset(&R, 0, sizeof(R));
+    const double t_start = now();
+    int rc = qvz_job_init(&job, text, bytes, 0, 0, opts);
+    if (rc) return rc;
+    uint64_t head_bytes = 0;
+    if ((rc = qvz_job_upload(&job))) goto done;
+    if ((rc = qvz_job_kmeans(&job, 0))) goto done;
+    if (opts->verbose) printf("Clustering took %.4f seconds\n", job.t_cluster);                      /* main.c:56-58 */
+    if ((rc = qvz_job_stats(&job))) goto done;
+    if ((rc = qvz_job_codebooks(&job))) goto done;
+    if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", job.t_stats + job.t_codebook);   /* main.c:66-67 */
+    if ((rc = qvz_job_write_codebooks(&job, fout, &head_bytes))) goto done;
+    if ((rc = qvz_job_compress(&job, fout, fu, &R.stream_bytes, &R.distortion))) goto done;
+    R.lines = job.N;
+    R.columns = job.C;
+    R.file_bytes = head_bytes + 128 + R.stream_bytes;
+    R.kmeans_iterations = job.kmeans_iterations;
+    R.deferred_decisions = job.deferred_decisions;
+    R.t_upload = job.t_upload; R.t_cluster = job.t_cluster; R.t_stats = job.t_stats; R.t_codebook = job.t_codebook;
+    R.t_encode = job.t_encode;
+    R.t_total = now() - t_start;
     if (opts->verbose) {                                                       /* main.c:96-121 */
         switch (opts->distortion) {
             case QVZ_DIST_MANHATTAN: printf("L1 distortion: %f\n", R.distortion); break;
@@ -376,32 +453,25 @@ int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu,
     if (opts->stats)                                                           /* main.c:124-126 */
         printf("rate, %.4f, distortion, %.4f, time, %.4f, size, %llu \n", (R.stream_bytes * 8.) / ((double)R.lines * R.columns),
                R.distortion, R.t_total, (unsigned long long)R.stream_bytes);
-
 done:
-    for (int b = 0; b < 2; ++b) chunk_free(&ck[b]);
-    qvz_coder_destroy(coder);
-    if (cbs) { for (uint32_t j = 0; j < K; ++j) qvz_codebook_free(cbs[j]); free(cbs); }
-    free(h_ct); free(h_qs);
-    qvz_hip_free(d_sym); qvz_hip_free(d_labels); qvz_hip_free(d_means); qvz_hip_free(d_up); qvz_hip_free(d_cnt);
-    qvz_hip_free(d_counts); qvz_hip_free(d_bad); qvz_hip_free(d_acc); qvz_hip_free(d_moved); qvz_hip_free(d_dist);
-    qvz_hip_free(d_kstat); qvz_hip_free(d_ct); qvz_hip_free(d_qs);
+    qvz_job_release(&job);
     if (res) *res = R;
     return rc;
 }
 
 int qvz_encode_file(const char *in_path, const char *out_path, const qvz_options_t *opts, qvz_result_t *res) {
     const int fd = open(in_path, O_RDONLY);
-    if (fd < 0) return fail(QVZ_E_ARG, "load_file returned error: 1");       /* LF_ERROR_NOT_FOUND, lines.h:18 */
+    if (fd < 0) return qvz_job_fail(QVZ_E_ARG, "load_file returned error: 1");       /* LF_ERROR_NOT_FOUND, lines.h:18 */
     struct stat st;
-    if (fstat(fd, &st) || st.st_size == 0) { close(fd); return fail(QVZ_E_DATA, "empty or unreadable input"); }
+    if (fstat(fd, &st) || st.st_size == 0) { close(fd); return qvz_job_fail(QVZ_E_DATA, "empty or unreadable input"); }
     void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);   /* lines.c:64 */
-    if (map == MAP_FAILED) { close(fd); return fail(QVZ_E_NOMEM, "mmap failed"); }
+    if (map == MAP_FAILED) { close(fd); return qvz_job_fail(QVZ_E_NOMEM, "mmap failed"); }
     FILE *fout = fopen(out_path, "wb");                                         /* main.c:74 */
-    if (!fout) { munmap(map, (size_t)st.st_size); close(fd); return fail(QVZ_E_ARG, "Unable to open output file"); }
+    if (!fout) { munmap(map, (size_t)st.st_size); close(fd); return qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); }
     FILE *fu = NULL;
     if (opts->uncompressed_name) {
         fu = fopen(opts->uncompressed_name, "w");                               /* main.c:81 */
-        if (!fu) { fclose(fout); munmap(map, (size_t)st.st_size); close(fd); return fail(QVZ_E_ARG, "Unable to open uncompressed file"); }
+        if (!fu) { fclose(fout); munmap(map, (size_t)st.st_size); close(fd); return qvz_job_fail(QVZ_E_ARG, "Unable to open uncompressed file"); }
     }
     const int rc = qvz_encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, fout, fu, opts, res);
     if (fu) fclose(fu);

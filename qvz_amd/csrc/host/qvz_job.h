@@ -1,0 +1,58 @@
+/* qvz_job.h - the encode path as resumable stages (internal to the host C layer).
+ * qvz_encode_buffer (include/qvz_encode.h) runs them back to back; the compat layer (include/qvz_compat.h)
+ * calls one stage per reference entry point (do_kmeans_clustering, calculate_statistics, ...). */
+#ifndef QVZ_JOB_H
+#define QVZ_JOB_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#include "qvz_codebook.h"
+#include "qvz_encode.h"
+
+#define QVZ_LINES_PER_BLOCK 1000000ull   /* MAX_LINES_PER_BLOCK, reference include/lines.h:12 */
+
+typedef struct qvz_job {
+    /* input view: rows of C+1 bytes (Q+33 ... '\n') in file order */
+    const uint8_t *text;
+    uint64_t N;
+    uint32_t C, K;
+    qvz_options_t opts;
+    /* host-visible results of the stages */
+    uint64_t centroid_lines[256];
+    uint32_t kmeans_iterations;
+    uint8_t *h_labels;          /* [N]      after qvz_job_kmeans (when requested)          */
+    uint8_t *h_means;           /* [K][C]   symbols (byte-33)                              */
+    uint32_t *h_counts;         /* [K]                                                       */
+    uint64_t *h_acc;            /* [K][C]   symbol sums of the last iteration                */
+    qvz_codebook_t **cbs;       /* [K]      after qvz_job_codebooks                          */
+    uint64_t deferred_decisions;
+    uint32_t well_state[32];
+    double h_dist[QVZ_A * QVZ_A];
+    /* device state */
+    uint64_t ld;
+    uint8_t *d_sym, *d_labels, *d_means;
+    uint32_t *d_cnt, *d_counts;
+    uint64_t *d_acc;
+    double *d_moved;
+    int32_t *d_kstat;
+    int uploaded, clustered, counted;
+    double t_upload, t_cluster, t_stats, t_codebook, t_encode;
+} qvz_job_t;
+
+/* Draws the centroid reads with libc rand() (cluster.c:198-204). Must run before the first HIP call of the process:
+ * HIP runtime start-up consumes rand() values. No device work. */
+int qvz_job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes_or_zero, uint64_t lines, uint32_t columns,
+                 const qvz_options_t *opts);
+int qvz_job_upload(qvz_job_t *job);                       /* text -> column-major symbols in HBM            */
+int qvz_job_kmeans(qvz_job_t *job, int want_host_labels); /* do_kmeans_clustering, cluster.c:212-244        */
+int qvz_job_stats(qvz_job_t *job);                        /* counting loop of calculate_statistics           */
+int qvz_job_codebooks(qvz_job_t *job);                    /* generate_codebooks                              */
+int qvz_job_write_codebooks(qvz_job_t *job, FILE *fout, uint64_t *bytes);   /* write_codebooks             */
+/* start_qv_compression: writes the WELL state and the stream to fout, the -u text to fu (may be NULL) */
+int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_bytes, double *distortion);
+void qvz_job_release(qvz_job_t *job);
+
+int qvz_job_fail(int code, const char *fmt, ...);
+
+#endif

@@ -682,3 +682,25 @@ extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, cons
     W.release();
     return rc;
 }
+
+// Marginal pmfs of one cluster (second half of calculate_statistics, codebook.c:208-219) copied to the host:
+// h_marg[s*72 + x]. Used by the compat layer to fill cond_pmf_list_t.marginal_pmfs; generate_codebook computes
+// the same values internally.
+extern "C" int qvz_hip_marginals(const uint32_t *d_cnt, uint32_t C, double *h_marg, void *stream) {
+    if (!d_cnt || !h_marg || C == 0) return qvz_set_error(QVZ_E_ARG, "bad marginals arguments");
+    hipStream_t st = (hipStream_t)stream;
+    double *P = nullptr, *marg = nullptr;
+    int rc = QVZ_OK;
+    if (hipMalloc(&P, (size_t)C * A * A * sizeof(double)) != hipSuccess || hipMalloc(&marg, (size_t)C * A * sizeof(double)) != hipSuccess) {
+        rc = qvz_set_error(QVZ_E_NOMEM, "device alloc");
+    } else {
+        hipLaunchKernelGGL(k_cond_pmf, dim3(C * A), dim3(64), 0, st, d_cnt, P);
+        hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, P, C, marg);
+        if (hipMemcpyAsync(h_marg, marg, (size_t)C * A * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            rc = qvz_set_error(QVZ_E_HIP, "marginals copy failed");
+    }
+    (void)hipFree(P);
+    (void)hipFree(marg);
+    return rc;
+}
