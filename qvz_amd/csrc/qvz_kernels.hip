@@ -415,31 +415,43 @@ extern "C" int qvz_hip_kmeans_update(const uint64_t *d_acc, const uint32_t *d_co
 // ------------------------------------------------------------------------------------------------
 // Conditional-PMF counters (reference src/codebook.c:193-205).
 //
-// Grid = (column s, row slab). A block owns one column pair (s-1, s) for its slab of reads and keeps the
-// whole 72x72 u32 counter tile of up to PMF_KT clusters in LDS (20 736 B per cluster); threads stream 16
-// reads per 16-byte load of each of the two columns and issue one LDS atomic per read. The tile is flushed
-// once with global atomics (only non-zero bins). Columns s and s+1 of the same slab run side by side, so
-// the second read of each column is served from L2 / Infinity Cache: HBM traffic stays ~1 B per symbol.
+// Grid = (column s, row slab). A block owns one column pair (s-1, s) for its slab of reads and keeps the whole
+// 72x72 u32 counter tile of up to PMF_KT clusters in LDS (20 736 B per cluster); threads stream 16 reads per
+// 16-byte load of each of the two columns and issue one LDS atomic per read. Quality scores are heavily skewed
+// (a handful of (prev, cur) pairs carry most of the mass), so lanes of one wave instruction pile up on the same
+// counter and the LDS serialises them: the tile is therefore kept in R replicas, lane l using replica l % R;
+// consecutive replicas are offset by one dword so the same bin of different replicas sits in different banks.
+// The replicas are summed and flushed once with global atomics (non-zero bins only). Columns s and s+1 of the
+// same slab run side by side, so the second read of each column is served from L2 / Infinity Cache: HBM traffic
+// stays ~1 B per symbol.
 // ------------------------------------------------------------------------------------------------
 #define PMF_TILE (QVZ_A * QVZ_A)
 #define PMF_KT 7   // 7 x 20 736 B = 145 KB of the 160 KB LDS
 
+// AA = side of the LDS tile: symbols < AA are counted in LDS, larger ones (none for a correct hint) go straight to
+// the global counters, so the hint only affects speed. Real Illumina data and QGEN-1 stay below 42: a 42x42 tile
+// is 7 KB instead of 20.7 KB, which buys three times the replicas at the same occupancy.
 template <bool HAVE_LABELS>
-__global__ __launch_bounds__(256) void k_pmf_hist(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
-                                                  uint64_t n, uint32_t C, uint64_t ld, uint32_t kb, uint32_t kt,
-                                                  uint32_t *__restrict__ cnt) {
-    extern __shared__ uint32_t tile[];   // [kt][72][72]
-    const uint32_t s = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < kt * PMF_TILE; i += 256) tile[i] = 0;
+__global__ void k_pmf_hist(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels, uint64_t n, uint32_t C,
+                           uint64_t ld, uint32_t kb, uint32_t kt, uint32_t R, uint32_t AA, uint32_t *__restrict__ cnt) {
+    extern __shared__ uint32_t tile[];   // [R][kt][AA][AA] (+1 dword skew per replica)
+    const uint32_t s = blockIdx.x, T = blockDim.x;
+    const uint32_t ts = AA * AA;                                 // one cluster's tile
+    const uint32_t rs = kt * ts + 1;                             // replica stride in dwords
+    for (uint32_t i = threadIdx.x; i < R * rs; i += T) tile[i] = 0;
     __syncthreads();
+    uint32_t *mine = tile + (threadIdx.x % R) * rs;
+    uint32_t *out = cnt + ((uint64_t)kb * C + s) * PMF_TILE;
+    int miss = 0;
 
-    const uint64_t chunks = (n + 4095) / 4096;
+    const uint64_t rows = (uint64_t)T * 16;                      // rows per block iteration
+    const uint64_t chunks = (n + rows - 1) / rows;
     const uint64_t per = (chunks + gridDim.y - 1) / gridDim.y;
     const uint64_t c0 = (uint64_t)blockIdx.y * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
     const uint8_t *cur = D + (uint64_t)s * ld;
     const uint8_t *prv = D + (uint64_t)(s ? s - 1 : 0) * ld;
     for (uint64_t ch = c0; ch < c1; ++ch) {
-        const uint64_t i = ch * 4096 + (uint64_t)threadIdx.x * 16;
+        const uint64_t i = ch * rows + (uint64_t)threadIdx.x * 16;
         if (i >= n) continue;
         const uint4 cv = *reinterpret_cast<const uint4 *>(cur + i);
         uint4 pv = make_uint4(0, 0, 0, 0);
@@ -461,15 +473,178 @@ __global__ __launch_bounds__(256) void k_pmf_hist(const uint8_t *__restrict__ D,
                     l = ((ls[w] >> (8 * b)) & 0xFF) - kb;
                     ok = ok && l < kt;
                 }
-                if (ok) atomicAdd(&tile[l * PMF_TILE + p * QVZ_A + x], 1u);
+                if (ok) {
+                    if (x < AA && p < AA) atomicAdd(&mine[l * ts + p * AA + x], 1u);
+                    else miss = 1;                               // outside the hinted range: second pass below
+                }
             }
     }
-    __syncthreads();
-    uint32_t *out = cnt + ((uint64_t)kb * C + s) * PMF_TILE;
-    for (uint32_t i = threadIdx.x; i < kt * PMF_TILE; i += 256) {
-        const uint32_t v = tile[i];
-        if (v) atomicAdd(&out[(uint64_t)(i / PMF_TILE) * C * PMF_TILE + (i % PMF_TILE)], v);
+    if (__syncthreads_or(miss)) {
+        // Rare: the sampled hint was too small. Re-scan the slab and send only the out-of-range pairs straight to
+        // the global counters; kept out of the hot loop so that it costs nothing when it does not happen.
+        for (uint64_t ch = c0; ch < c1; ++ch) {
+            const uint64_t i0 = ch * rows + (uint64_t)threadIdx.x * 16;
+            for (uint32_t r = 0; r < 16; ++r) {
+                const uint64_t i = i0 + r;
+                if (i >= n) break;
+                const uint32_t x = cur[i], p = s ? prv[i] : 0u;
+                if (x >= QVZ_A || p >= QVZ_A || (x < AA && p < AA)) continue;
+                uint32_t l = 0;
+                if (HAVE_LABELS) { l = labels[i] - kb; if (l >= kt) continue; }
+                atomicAdd(&out[(uint64_t)l * C * PMF_TILE + p * QVZ_A + x], 1u);
+            }
+        }
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kt * ts; i += T) {
+        uint32_t v = 0;
+        for (uint32_t r = 0; r < R; ++r) v += tile[r * rs + i];
+        if (v) {
+            const uint32_t l = i / ts, e = i % ts;
+            atomicAdd(&out[(uint64_t)l * C * PMF_TILE + (e / AA) * QVZ_A + (e % AA)], v);
+        }
+    }
+}
+
+// ---- column-walking variant: every symbol is loaded exactly once ------------------------------------------------
+// k_pmf_hist above reads each column twice (as `cur` of column s and as `prev` of column s+1) and measurement shows
+// the second read costs as much as the first: with the LDS work removed it still runs at the HBM ceiling for 2 B per
+// symbol. Here a block owns a slab of rows and walks the columns left to right: a thread keeps the previous column's
+// 16-byte groups (and the labels) in registers, prefetches the next column while it counts the current one, and G
+// consecutive column tiles live in LDS at a time (flushed with global atomics every G columns).
+#define PMF_WALK_T 1024
+typedef unsigned short pmf_u16x2 __attribute__((ext_vector_type(2)));
+
+// One (prev, cur) pair that did not pass the packed fast check: full per-symbol logic (cold path).
+template <bool HAVE_LABELS>
+__device__ __noinline__ void pmf_count_slow(uint32_t x, uint32_t p, uint32_t lraw, uint32_t kb, uint32_t kt, uint32_t AA,
+                                            uint32_t *col_tile, uint32_t *gcol, uint32_t C) {
+    if (x >= QVZ_A || p >= QVZ_A) return;
+    uint32_t l = 0;
+    if (HAVE_LABELS) { l = lraw - kb; if (l >= kt) return; }
+    if (x < AA && p < AA) atomicAdd(&col_tile[l * AA * AA + p * AA + x], 1u);
+    else atomicAdd(&gcol[(uint64_t)l * C * PMF_TILE + p * QVZ_A + x], 1u);        // outside the hinted range
+}
+
+// Inner loop budget (k = 1): per 4-symbol word one packed range check (7 VALU) and per symbol v_perm_b32 +
+// v_dot2_u32_u16 + ds_add_u32. The kernel is issue-bound, not bandwidth-bound, so instruction count is what matters.
+template <bool HAVE_LABELS, int Q>
+__global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
+                                                          uint64_t n, uint32_t C, uint64_t ld, uint32_t kb, uint32_t kt,
+                                                          uint32_t R, uint32_t AA, uint32_t G, uint32_t *__restrict__ cnt) {
+    extern __shared__ uint32_t tile[];   // [R][G][kt][AA][AA] (+1 dword skew per replica)
+    const uint32_t T = PMF_WALK_T;
+    const uint32_t ts = AA * AA, cs = kt * ts;                   // one cluster's tile, one column's tiles
+    const uint32_t rs = G * cs + 1;                              // replica stride
+    uint32_t *mine = tile + (threadIdx.x % R) * rs;
+    const uint64_t slab0 = (uint64_t)blockIdx.x * T * 16 * Q;
+    uint64_t row[Q];
+    uint4 prv[Q], cur[Q], lab[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        row[q] = slab0 + ((uint64_t)q * T + threadIdx.x) * 16;
+        prv[q] = make_uint4(0, 0, 0, 0);                         // column 0 counts under prev = 0 (codebook.c:200)
+        lab[q] = make_uint4(0, 0, 0, 0);
+        if (HAVE_LABELS && row[q] < n) lab[q] = *reinterpret_cast<const uint4 *>(labels + row[q]);
+        cur[q] = row[q] < n ? *reinterpret_cast<const uint4 *>(D + row[q]) : make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t k80 = 0x01010101u * (0x80u - AA);             // byte + (128 - AA) sets bit 7 iff byte >= AA
+    pmf_u16x2 coef;
+    coef.x = 4;                                                  // byte address = 4*x + 4*AA*p + tile base
+    coef.y = (unsigned short)(4 * AA);
+    for (uint32_t g0 = 0; g0 < C; g0 += G) {
+        const uint32_t g1 = g0 + G < C ? g0 + G : C;
+        for (uint32_t i = threadIdx.x; i < R * rs; i += T) tile[i] = 0;
+        __syncthreads();
+        for (uint32_t s = g0; s < g1; ++s) {
+            uint4 nxt[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q)                          // prefetch column s+1 while column s is counted
+                nxt[q] = (s + 1 < C && row[q] < n) ? *reinterpret_cast<const uint4 *>(D + (uint64_t)(s + 1) * ld + row[q])
+                                                   : make_uint4(0, 0, 0, 0);
+            uint32_t *col_tile = mine + (s - g0) * cs;
+            uint32_t *gcol = cnt + ((uint64_t)kb * C + s) * PMF_TILE;
+            const uint32_t base = (uint32_t)((col_tile - tile) * 4);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t cw[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+                const uint32_t pw[4] = {prv[q].x, prv[q].y, prv[q].z, prv[q].w};
+                const uint32_t lw[4] = {lab[q].x, lab[q].y, lab[q].z, lab[q].w};
+                if (row[q] + 16 <= n) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t bad = ((cw[w] + k80) | (pw[w] + k80) | cw[w] | pw[w]) & 0x80808080u;
+                        if (bad == 0) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                // [x, 0, p, 0] as two u16 lanes, then 4*x + 4*AA*p + base in one dot product
+                                const uint32_t sel = 0x0C000C00u | ((4u + b) << 16) | (uint32_t)b;
+                                const uint32_t xp = __builtin_amdgcn_perm(pw[w], cw[w], sel);
+                                pmf_u16x2 v;
+                                v.x = (unsigned short)(xp & 0xFFFF);
+                                v.y = (unsigned short)(xp >> 16);
+                                uint32_t addr = __builtin_amdgcn_udot2(v, coef, base, false);
+                                if (HAVE_LABELS) {
+                                    const uint32_t l = ((lw[w] >> (8 * b)) & 0xFF) - kb;
+                                    if (l >= kt) continue;
+                                    addr += l * ts * 4;
+                                }
+                                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tile) + addr), 1u);
+                            }
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                                pmf_count_slow<HAVE_LABELS>((cw[w] >> (8 * b)) & 0xFF, (pw[w] >> (8 * b)) & 0xFF,
+                                                            (lw[w] >> (8 * b)) & 0xFF, kb, kt, AA, col_tile, gcol, C);
+                        }
+                    }
+                } else if (row[q] < n) {                         // the last, partial group of the matrix
+                    for (uint32_t r = 0; r < 16 && row[q] + r < n; ++r)
+                        pmf_count_slow<HAVE_LABELS>((cw[r >> 2] >> (8 * (r & 3))) & 0xFF, (pw[r >> 2] >> (8 * (r & 3))) & 0xFF,
+                                                    (lw[r >> 2] >> (8 * (r & 3))) & 0xFF, kb, kt, AA, col_tile, gcol, C);
+                }
+                prv[q] = cur[q];
+                cur[q] = nxt[q];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (g1 - g0) * cs; i += T) {
+            uint32_t v = 0;
+            for (uint32_t r = 0; r < R; ++r) v += tile[r * rs + i];
+            if (v) {
+                const uint32_t s = g0 + i / cs, l = (i % cs) / ts, e = i % ts;
+                atomicAdd(&cnt[(((uint64_t)(kb + l) * C + s) * QVZ_A + e / AA) * QVZ_A + e % AA], v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// largest symbol in an evenly spread sample of every column (64 x 1024 rows per column)
+__global__ __launch_bounds__(256) void k_sym_max(const uint8_t *__restrict__ D, uint64_t n, uint64_t ld,
+                                                 uint32_t *__restrict__ result) {
+    const uint8_t *col = D + (uint64_t)blockIdx.x * ld;
+    const uint64_t groups = (n + 1023) / 1024;                   // 1024-row groups in the column
+    const uint64_t step = groups > 64 ? groups / 64 : 1;
+    uint32_t m = 0;
+    for (uint64_t g = 0; g < groups; g += step) {
+        const uint64_t i = g * 1024 + (uint64_t)(threadIdx.x & 63) * 16;
+        if ((threadIdx.x >> 6) != (g / step) % 4 || i >= n) continue;     // the 4 waves take groups in turn
+        const uint4 v = *reinterpret_cast<const uint4 *>(col + i);
+        const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (i + 4 * w + b < n) { const uint32_t x = (ws[w] >> (8 * b)) & 0xFF; m = x > m ? x : m; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(result, m);
+}
+
+static unsigned env_uint(const char *name, unsigned dflt) {
+    const char *v = getenv(name);
+    return v && *v ? (unsigned)strtoul(v, nullptr, 10) : dflt;
 }
 
 extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
@@ -480,23 +655,99 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
     if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
     if (n >= (1ull << 32)) return qvz_set_error(QVZ_E_ARG, "n >= 2^32 overflows the u32 counters (reference pmf.h:35)");
     hipStream_t st = (hipStream_t)stream;
-    const uint64_t chunks = (n + 4095) / 4096;
+
+    // tile side from a device-side sample of the data (one tiny launch + a 4-byte read back)
+    unsigned AA = env_uint("QVZ_PMF_AA", 0);
+    if (AA == 0) {
+        static uint32_t *d_max = nullptr;
+        if (!d_max) QVZ_HIP_CHECK(hipMalloc(&d_max, sizeof(uint32_t)));
+        uint32_t h_max = 0;
+        QVZ_HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_sym_max, dim3(c), dim3(256), 0, st, d_sym, n, ld, d_max);
+        QVZ_HIP_CHECK(hipMemcpyAsync(&h_max, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        QVZ_HIP_CHECK(hipStreamSynchronize(st));
+        AA = h_max + 1;
+    }
+    AA = (AA + 1) & ~1u;
+    if (AA > QVZ_A) AA = QVZ_A;
+    if (AA < 2) AA = 2;
+
+    const unsigned lds_budget = 160 * 1024;
+    // The walking kernel needs >= ~1000 slabs of 16384 rows to fill the chip; smaller inputs use the two-read kernel.
+    const unsigned algo = env_uint("QVZ_PMF_ALGO", n >= 1000ull * 16384 ? 1 : 0);
+    if (algo >= 1) {
+        // column-walking kernel: slabs of 16384*Q rows, G column tiles x R replicas in <= 80 KB (two blocks per CU)
+        for (uint32_t kb = 0; kb < k; kb += PMF_KT) {
+            const uint32_t kt = (k - kb) < PMF_KT ? (k - kb) : PMF_KT;
+            const size_t tile_bytes = (size_t)kt * AA * AA * sizeof(uint32_t);
+            const size_t budget = tile_bytes * 2 + 4 <= lds_budget / 2 ? lds_budget / 2 : lds_budget;
+            unsigned R = env_uint("QVZ_PMF_R", 0), G = env_uint("QVZ_PMF_G", 0);
+            // measured (tools/tune_pmf2.py, 100M x 150): replicas stop paying beyond ~5, G = 2..3 column tiles are enough
+            if (G == 0) G = 2 * tile_bytes + 4 <= budget ? 2 : 1;
+            if (R == 0) {
+                R = (unsigned)(budget / (G * tile_bytes + 4));
+                if (R > 5) R = 5;
+            }
+            if (G < 1) G = 1;
+            if (G > c) G = c;
+            while (R > 1 && (size_t)R * (G * tile_bytes + 4) > lds_budget) R -= 1;
+            while (G > 1 && (size_t)R * (G * tile_bytes + 4) > lds_budget) G -= 1;
+            const size_t lds = (size_t)R * (G * tile_bytes + 4);
+            unsigned Q = env_uint("QVZ_PMF_Q", 0);
+            if (Q == 0) Q = n >= 768ull * 65536 ? 4 : (n >= 768ull * 32768 ? 2 : 1);
+            const uint64_t slab = 16384ull * Q;
+            dim3 grid((unsigned)((n + slab - 1) / slab));
+#define LAUNCH_WALK(LBL, QQ)                                                                                           \
+    do {                                                                                                               \
+        if (lds > 64 * 1024)                                                                                           \
+            QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pmf_walk<LBL, QQ>),                    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        hipLaunchKernelGGL((k_pmf_walk<LBL, QQ>), grid, dim3(PMF_WALK_T), lds, st, d_sym, d_labels, n, c, ld, kb, kt,  \
+                           R, AA, G, d_cnt);                                                                           \
+    } while (0)
+            if (k == 1) {
+                if (Q == 4) LAUNCH_WALK(false, 4); else if (Q == 2) LAUNCH_WALK(false, 2); else LAUNCH_WALK(false, 1);
+            } else {
+                if (Q == 4) LAUNCH_WALK(true, 4); else if (Q == 2) LAUNCH_WALK(true, 2); else LAUNCH_WALK(true, 1);
+            }
+#undef LAUNCH_WALK
+            QVZ_HIP_CHECK(hipGetLastError());
+        }
+        return QVZ_OK;
+    }
     for (uint32_t kb = 0; kb < k; kb += PMF_KT) {
         const uint32_t kt = (k - kb) < PMF_KT ? (k - kb) : PMF_KT;
-        const size_t lds = (size_t)kt * PMF_TILE * sizeof(uint32_t);
-        // blocks resident per CU by LDS; ~all blocks co-resident so neighbouring columns advance together
-        const unsigned per_cu = (unsigned)(160 * 1024 / lds) > 8 ? 8 : (unsigned)(160 * 1024 / lds);
-        unsigned slabs = (256 * per_cu) / c;
+        const size_t tile_bytes = ((size_t)kt * AA * AA + 1) * sizeof(uint32_t);
+        // replicas: as many as fit in half the LDS (two 1024-thread blocks per CU = full occupancy), at most 16
+        unsigned R = env_uint("QVZ_PMF_R", 0);
+        if (R == 0) {
+            R = (unsigned)((lds_budget / 2) / tile_bytes);
+            if (R > 16) R = 16;
+        }
+        if (R < 1) R = 1;
+        while (R > 1 && R * tile_bytes > lds_budget) R -= 1;
+        const size_t lds = R * tile_bytes;
+        unsigned T = env_uint("QVZ_PMF_T", 1024);
+        if (T != 256 && T != 512 && T != 1024) T = 1024;
+        unsigned per_cu = (unsigned)(lds_budget / lds);
+        if (per_cu * T > 2048) per_cu = 2048 / T;
+        if (per_cu < 1) per_cu = 1;
+        const uint64_t chunks = (n + (uint64_t)T * 16 - 1) / ((uint64_t)T * 16);
+        // enough blocks for several rounds per CU so the tail is short, few enough that the flush stays negligible
+        unsigned slabs = env_uint("QVZ_PMF_SLABS", (256 * per_cu * 4 + c - 1) / c);
         if (slabs < 1) slabs = 1;
         if (slabs > chunks) slabs = (unsigned)chunks;
         dim3 grid(c, slabs);
         if (k == 1) {
-            hipLaunchKernelGGL(k_pmf_hist<false>, grid, dim3(256), lds, st, d_sym, d_labels, n, c, ld, kb, kt, d_cnt);
+            if (lds > 64 * 1024)
+                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pmf_hist<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_pmf_hist<false>, grid, dim3(T), lds, st, d_sym, d_labels, n, c, ld, kb, kt, R, AA, d_cnt);
         } else {
             if (lds > 64 * 1024)
                 QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pmf_hist<true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_pmf_hist<true>, grid, dim3(256), lds, st, d_sym, d_labels, n, c, ld, kb, kt, d_cnt);
+            hipLaunchKernelGGL(k_pmf_hist<true>, grid, dim3(T), lds, st, d_sym, d_labels, n, c, ld, kb, kt, R, AA, d_cnt);
         }
         QVZ_HIP_CHECK(hipGetLastError());
     }
