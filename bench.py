@@ -6,7 +6,8 @@
 A "step" is one full pass of the hot path over a synthetic QGEN-1 quality matrix that is already resident in HBM:
 k-means (to convergence) -> conditional-PMF counters (-> RCCL all-reduce when sharded) -> Lloyd-Max codebooks ->
 WELL draws -> quantize (the -u product + coder feed) -> arithmetic coding into `shards` independent
-reference-format streams by host threads. Nothing is cached between steps.
+reference-format streams (default: 8192 streams per GPU coded on the GPU, one lane per stream; --coder host uses
+host threads instead; both produce byte-identical streams). Nothing is cached between steps.
 
 Workload (BASELINE.json): 100M reads x 150 columns per GPU, flags of configs[2] (-c 1 -d L -f 0.5) by default;
 --config 3 selects configs[3] (-c 3 -d M -r 1.0), --config 1 the 10M x 150 case. Reads shard across ranks (weak
@@ -97,7 +98,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (testing)")
     ap.add_argument("--shards", type=int, default=0, help="arithmetic-coded streams per GPU (default: host threads)")
     ap.add_argument("--threads", type=int, default=0, help="host coder threads per rank (default: cores / ranks)")
-    ap.add_argument("--coder", choices=["host", "gpu"], default="host",
+    ap.add_argument("--coder", choices=["host", "gpu"], default="gpu",
                     help="arithmetic coder: host threads, or one GPU lane per shard (byte-identical streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -132,7 +133,7 @@ def main():
         cores = os.cpu_count() or 1
     # a GPU box's CPU share is 16 cores per GPU even where more logical CPUs are visible
     threads = args.threads or max(1, min(16, cores // max(1, world)))
-    shards = args.shards or (threads if args.coder == "host" else 16384)
+    shards = args.shards or (threads if args.coder == "host" else 8192)
     mode = host.MODE_RATIO if cfg["mode"] == "f" else host.MODE_FIXED
 
     sym = K.qgen1(cfg["seed"], n, c, first=first)          # synthetic input, resident in HBM before timing

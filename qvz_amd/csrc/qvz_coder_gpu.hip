@@ -42,8 +42,9 @@ struct LaneCoder {
 __device__ __forceinline__ void lc_flush32(LaneCoder &c) {
     // emit the top 32 pending bits as 4 big-endian bytes (pos stays 4-byte aligned)
     const uint32_t w = (uint32_t)(c.acc >> (c.nbits - 32));
-    if (c.pos + 4 <= c.cap) *reinterpret_cast<uint32_t *>(c.out + c.pos) = __builtin_bswap32(w);
-    else c.overflow = true;
+    const bool fits = c.pos + 4 <= c.cap;                        // on overflow the word lands (harmlessly) in the last slot
+    *reinterpret_cast<uint32_t *>(c.out + (fits ? c.pos : c.cap - 4)) = __builtin_bswap32(w);
+    c.overflow = c.overflow || !fits;
     c.pos += 4;
     c.nbits -= 32;
 }
@@ -191,34 +192,57 @@ __global__ __launch_bounds__(64) void k_arith_shards(const uint16_t *__restrict_
 // Tables start on 16-byte boundaries (QVZ_MODEL_ALIGN16) so a header is two dwordx4 loads. A header prefetched up
 // to 7 symbols early is still current because two symbols less than C apart never share a table (a table belongs
 // to one column); hence the kernel is used for C >= 8 only.
+//
+// Measured limits (MI355X, 100M x 150): the compiler still drains vmcnt(0) around the
+// data-dependent stores, but giving the loads a wave of their own (loader wave -> LDS ring -> coder wave, tried and
+// removed) did not make a stream faster: a lone wave issues one VALU instruction per ~4 cycles and the per-symbol
+// chain is ~450 instructions (~0.9 us). Stream speed is instruction-count bound; throughput scales with streams.
 struct Hdr { uint4 a, b; };   // a = {n, card, c0, c1}, b = {c2, c3, c4, c5}
 
+// Branch-light interval step. Lanes of a wave are different streams, so every data-dependent `if` costs the whole
+// wave both sides plus exec-mask bookkeeping; the first version spent most of its instructions there. Here the
+// renormalisation is written with shift counts that may be zero, and the common case of the pending-bit run
+// (scale3 <= 9, so that the first bit, the run and the remaining k-1 bits fit one 31-bit pattern) is folded into a
+// single emit. Same integers as arithmetic_encoder_step (arith.c:24-97); only the control flow differs.
 __device__ __forceinline__ void lc_interval(LaneCoder &c, uint32_t n, uint32_t cum_lo, uint32_t fx) {
     const uint32_t range = c.u - c.l + 1;
     const double rn = fast_rcp(n);
     uint32_t u = c.l + exact_div((uint64_t)range * (cum_lo + fx), n, rn) - 1;
     uint32_t l = c.l + exact_div((uint64_t)range * cum_lo, n, rn);
     const uint32_t diff = l ^ u;
-    if (!(diff & MSB)) {
-        const uint32_t k = clz_field(diff, M_BITS);
-        const uint32_t top = l >> (M_BITS - k);
-        const uint32_t b = top >> (k - 1);
+    // E1/E2: k leading bits shared by l and u (k = 0 when the MSBs differ)
+    const uint32_t lz = diff ? (uint32_t)__clz((int)diff) - (32 - M_BITS) : M_BITS;
+    const uint32_t k = (diff & MSB) ? 0u : lz;
+    const uint32_t top = l >> (M_BITS - k);                      // k = 0: l >> 22 = 0
+    const uint32_t km1 = k ? k - 1 : 0u;
+    const uint32_t s3 = k ? c.scale3 : 0u;                        // the pending run is flushed only when a bit is decided
+    if (s3 > 9) {                                                // rare: long run, emit piecewise
+        const uint32_t b = top >> km1;
         lc_put(c, b, 1);
-        if (c.scale3) { lc_run(c, !b, c.scale3); c.scale3 = 0; }
-        if (k > 1) lc_put(c, top & ((1u << (k - 1)) - 1), k - 1);
-        l = (l << k) & MASK_M;
-        u = ((u << k) & MASK_M) | ((1u << k) - 1);
+        lc_run(c, !b, s3);
+        if (km1) lc_put(c, top & ((1u << km1) - 1), km1);
+    } else {
+        // pattern = b, then s3 copies of !b, then the remaining k-1 bits of top
+        const uint32_t b = top >> km1;
+        const uint32_t rest = top & ((1u << km1) - 1);
+        const uint32_t run = b ? 0u : ((1u << s3) - 1);
+        const uint32_t bits = (((b << s3) | run) << km1) | rest;
+        const uint32_t nb = k + s3;                              // 0 when k = 0
+        c.acc = (c.acc << nb) | bits;
+        c.nbits += nb;
+        if (c.nbits >= 32) lc_flush32(c);
     }
-    const uint32_t ones_l = clz_field((~l) & MASK_M1, M_BITS - 1);
-    const uint32_t zeros_u = clz_field(u & MASK_M1, M_BITS - 1);
+    c.scale3 = k ? 0u : c.scale3;
+    l = (l << k) & MASK_M;
+    u = ((u << k) & MASK_M) | ((1u << k) - 1);
+    // E3: j positions below the MSB where l has ones and u has zeros (j = 0 is a no-op)
+    const uint32_t nl = (~l) & MASK_M1, nu = u & MASK_M1;
+    const uint32_t ones_l = nl ? (uint32_t)__clz((int)nl) - (32 - (M_BITS - 1)) : M_BITS - 1;
+    const uint32_t zeros_u = nu ? (uint32_t)__clz((int)nu) - (32 - (M_BITS - 1)) : M_BITS - 1;
     const uint32_t j = ones_l < zeros_u ? ones_l : zeros_u;
-    if (j) {
-        c.scale3 += j;
-        l = (l << j) & MASK_M1;
-        u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
-    }
-    c.l = l;
-    c.u = u;
+    c.scale3 += j;
+    c.l = (l << j) & MASK_M1;
+    c.u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
 }
 
 __device__ __forceinline__ void lc_encode_hdr(LaneCoder &c, uint32_t *__restrict__ t, const Hdr &h, uint32_t x) {
@@ -324,16 +348,18 @@ __global__ __launch_bounds__(64) void k_arith_shards_pf(const uint16_t *__restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (b * 4 + j < T) {
-                if (HAVE_LABELS && cs == 0) {
-                    const uint32_t raw = labels[ci];
-                    if (raw >= K) bad = true;
-                    lc_encode(c, ar, raw < K ? raw : 0u);        // qv_write_cluster: table 0, straight from memory
+                if (HAVE_LABELS) {
+                    if (cs == 0) {
+                        const uint32_t raw = labels[ci];
+                        if (raw >= K) bad = true;
+                        lc_encode(c, ar, raw < K ? raw : 0u);    // qv_write_cluster: table 0, straight from memory
+                    }
+                    if (++cs == C) { cs = 0; ++ci; }
                 }
                 const uint32_t st = entry(f0, j) >> 8;
                 const uint32_t o = o_cur[j];
                 if (o == NO_TABLE || st >= h_cur[j].a.y) bad = true;
                 else lc_encode_hdr(c, ar + o, h_cur[j], st);
-                if (++cs == C) { cs = 0; ++ci; }
             }
         }
 #pragma unroll
@@ -374,7 +400,7 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
                                      uint64_t cap_per_shard, uint64_t *h_sizes, void *stream) {
     if (!d_feed || !n || !columns || !clusters || !shards || !d_out || !h_sizes) return qvz_set_error(QVZ_E_ARG, "bad shard-coder arguments");
     if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
-    if (cap_per_shard & 3) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4");
+    if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
     hipStream_t st = (hipStream_t)stream;
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
     if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
@@ -389,6 +415,7 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
     int rc = QVZ_OK;
     int32_t status = 0;
     const size_t offn = (size_t)clusters * columns * 2 * A;
+    const char *variant = getenv("QVZ_CODER_KERNEL");            // development knob: "simple" selects the unpipelined kernel
 #define TRY(expr)                                                                                                    \
     do {                                                                                                             \
         hipError_t e_ = (expr);                                                                                      \
@@ -405,7 +432,7 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
-    if (columns >= 8 && !getenv("QVZ_CODER_SIMPLE")) {
+    if (columns >= 8 && !(variant && strcmp(variant, "simple") == 0)) {
         if (clusters > 1)
             hipLaunchKernelGGL(k_arith_shards_pf<true>, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns,
                                clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
