@@ -113,6 +113,11 @@ int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, 
  * ------------------------------------------------------------------------------------------- */
 int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
                        void *stream);
+/* The same draws as a matrix in the symbols' layout: d_draws[s*ld + i] = draw of (read first_read+i, column s), one
+ * byte each (0..127). This is what the quantizer consumes; internally the word stream is generated in chunks into a
+ * reusable workspace and transposed through LDS. */
+int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, uint64_t n, uint32_t c, uint8_t *d_draws,
+                       uint64_t ld, void *stream);
 /* State of the generator after `words` outputs, rotated to n = 0 (what a shard's .q header stores). */
 int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32_t *h_state_out);
 
@@ -128,16 +133,15 @@ int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32_t *h_state
 
 /* Replaces the quantize half of start_qv_compression (reference src/qv_compressor.c:76-135).
  * d_ct / d_qs: k tables back to back ([k][c][72] and [k][c][144][72] u16).
- * d_words: WELL words covering draws [first_draw, first_draw + n*c); d_words[0] holds draw
- *          (first_draw & ~3). first_draw = (global index of read 0 of this call) * c.
+ * d_draws: draw matrix of these n reads (qvz_hip_well_draws), pitch ld_draws.
  * h_dist: 72x72 doubles d[x + 72*y] (reference distortion.c:151).
  * Outputs (each may be NULL): d_qv / d_qi / d_st column-major with pitch ld_out (a multiple of 256, >= n; lets a
  * chunk of a large matrix be quantized into chunk-sized buffers): quantized value, quantizer
  * index 2*ctx+b and state index per symbol; d_err[i] = per-read sum of d(x,qv) accumulated in column
  * order exactly as the reference does (bit-identical double); d_status |= QVZ_E_DEAD_CTX flags. */
 int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
-                     uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint32_t *d_words,
-                     uint64_t first_draw, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi,
+                     uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
+                     uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi,
                      uint8_t *d_st, uint64_t ld_out, double *d_err, int32_t *d_status, void *stream);
 
 /* Coder feed: column-major quantizer indices / state indices (pitch ld) -> read-major pairs

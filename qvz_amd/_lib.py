@@ -28,8 +28,10 @@ SIGNATURES = {
     "qvz_hip_kmeans_update": (C.c_int, [u64p, u32p, C.c_uint32, C.c_uint32, u8p, f64p, C.c_void_p, C.c_void_p]),
     "qvz_hip_pmf_hist": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_void_p]),
     "qvz_hip_well_words": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, u32p, C.c_void_p]),
+    "qvz_hip_well_draws": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint64,
+                                     C.c_void_p]),
     "qvz_hip_well_jump": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]),
-    "qvz_hip_quantize": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u16p, u16p, u32p,
+    "qvz_hip_quantize": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u16p, u16p, u8p,
                                    C.c_uint64, f64p, u8p, u8p, u8p, C.c_uint64, f64p, C.c_void_p, C.c_void_p]),
     "qvz_hip_pack_feed": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, u16p, C.c_void_p]),
     "qvz_hip_set_device": (C.c_int, [C.c_int]),

@@ -246,7 +246,7 @@ typedef struct {
     void *stream;
     uint8_t *d_qv, *d_qi, *d_st, *d_text;
     uint16_t *d_feed;
-    uint32_t *d_words;
+    uint8_t *d_draws;
     double *d_err;
     int32_t *d_status;
     uint16_t *h_feed;
@@ -258,7 +258,7 @@ typedef struct {
 
 static void chunk_free(chunk_t *ck) {
     qvz_hip_free(ck->d_qv); qvz_hip_free(ck->d_qi); qvz_hip_free(ck->d_st); qvz_hip_free(ck->d_text);
-    qvz_hip_free(ck->d_feed); qvz_hip_free(ck->d_words); qvz_hip_free(ck->d_err); qvz_hip_free(ck->d_status);
+    qvz_hip_free(ck->d_feed); qvz_hip_free(ck->d_draws); qvz_hip_free(ck->d_err); qvz_hip_free(ck->d_status);
     qvz_hip_free_host(ck->h_feed); qvz_hip_free_host(ck->h_labels); qvz_hip_free_host(ck->h_text);
     qvz_hip_free_host(ck->h_err); qvz_hip_free_host(ck->h_status);
     if (ck->stream) qvz_hip_stream_destroy(ck->stream);
@@ -272,11 +272,11 @@ static int issue_chunk(qvz_job_t *job, chunk_t *q, uint64_t r0, uint64_t chunk, 
     const uint64_t stride = (uint64_t)C + 1;
     q->r0 = r0;
     q->n = job->N - r0 < chunk ? job->N - r0 : chunk;
-    const uint64_t fd = q->r0 * C, w0 = fd >> 2, w1 = ((q->r0 + q->n) * C + 3) >> 2, ldn = qvz_hip_ld(q->n);
+    const uint64_t ldn = qvz_hip_ld(q->n);
     HIP(qvz_hip_memset(q->d_status, 0, sizeof(int32_t), q->stream));
-    HIP(qvz_hip_well_words(job->well_state, w0, w1 - w0, q->d_words, q->stream));
-    HIP(qvz_hip_quantize(job->d_sym + q->r0, K > 1 ? job->d_labels + q->r0 : NULL, q->n, C, job->ld, K, d_ct, d_qs, q->d_words,
-                         fd, d_dist, q->d_qv, q->d_qi, q->d_st, ldn, q->d_err, q->d_status, q->stream));
+    HIP(qvz_hip_well_draws(job->well_state, q->r0, q->n, C, q->d_draws, ldn, q->stream));
+    HIP(qvz_hip_quantize(job->d_sym + q->r0, K > 1 ? job->d_labels + q->r0 : NULL, q->n, C, job->ld, K, d_ct, d_qs, q->d_draws,
+                         ldn, d_dist, q->d_qv, q->d_qi, q->d_st, ldn, q->d_err, q->d_status, q->stream));
     HIP(qvz_hip_pack_feed(q->d_qi, q->d_st, q->n, C, ldn, q->d_feed, q->stream));
     HIP(qvz_hip_copy_d2h(q->h_feed, q->d_feed, q->n * C * sizeof(uint16_t), q->stream));
     HIP(qvz_hip_copy_d2h(q->h_err, q->d_err, q->n * sizeof(double), q->stream));
@@ -340,7 +340,7 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
         HIP(qvz_hip_malloc((void **)&k_->d_qi, (size_t)C * ldc));
         HIP(qvz_hip_malloc((void **)&k_->d_st, (size_t)C * ldc));
         HIP(qvz_hip_malloc((void **)&k_->d_feed, chunk * C * sizeof(uint16_t)));
-        HIP(qvz_hip_malloc((void **)&k_->d_words, (chunk * C / 4 + 8) * sizeof(uint32_t)));
+        HIP(qvz_hip_malloc((void **)&k_->d_draws, (size_t)C * ldc));
         HIP(qvz_hip_malloc((void **)&k_->d_err, chunk * sizeof(double)));
         HIP(qvz_hip_malloc((void **)&k_->d_status, sizeof(int32_t)));
         HIP(qvz_hip_malloc_host((void **)&k_->h_feed, chunk * C * sizeof(uint16_t)));

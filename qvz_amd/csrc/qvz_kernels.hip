@@ -977,19 +977,91 @@ extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Draw matrix: draws[s*ld + i] = 7-bit WELL draw of (read first_read + i, column s), the layout of the symbols.
+// The generator emits the stream linearly (draw g = read*C + column lives in word g>>2); the quantizer wants, for a
+// fixed column, the draws of consecutive reads next to each other. Gathering them per lane from the linear stream
+// fetched 8.5x the algorithmic bytes (rocprofv3 FETCH_SIZE, profiles/): each 128-byte line was re-fetched many
+// times. This LDS-tiled transpose reads every word once (coalesced) and writes every draw once (dword per lane).
+// ------------------------------------------------------------------------------------------------
+#define DT_MAX_WORDS 15360   // 60 KB of LDS per block
+
+__global__ __launch_bounds__(256) void k_draws_transpose(const uint32_t *__restrict__ words, uint64_t word0, uint64_t draw0,
+                                                         uint64_t n, uint32_t C, uint32_t TR, uint8_t *__restrict__ draws,
+                                                         uint64_t ld) {
+    __shared__ uint32_t w[DT_MAX_WORDS + 4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * TR;               // first read of this tile (multiple of 4)
+    const uint32_t reads = (uint32_t)(n - i0 < TR ? n - i0 : TR);
+    const uint64_t g0 = draw0 + i0 * C, g1 = g0 + (uint64_t)reads * C;     // draws [g0, g1) of the stream
+    const uint64_t wa = g0 >> 2, wb = (g1 + 3) >> 2;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(wb - wa); i += 256) w[i] = words[wa - word0 + i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t quads = (reads + 3) / 4;
+    const uint32_t base = (uint32_t)(g0 - (wa << 2));             // offset of the tile's first draw inside w[]
+    for (uint32_t s = wave; s < C; s += 4)                       // waves take columns in turn, lanes take read quads
+        for (uint32_t q = lane; q < quads; q += 64) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint32_t rd = 4 * q + r;
+                if (rd < reads) {
+                    const uint32_t d = base + rd * C + s;
+                    packed |= ((w[d >> 2] >> (7 * (d & 3))) & 127u) << (8 * r);   // well_1024a_bits, well.c:33-46
+                }
+            }
+            *reinterpret_cast<uint32_t *>(draws + (uint64_t)s * ld + i0 + 4 * q) = packed;
+        }
+}
+
+// Generates the draws of reads [first_read, first_read + n) in chunks: words into a reusable workspace
+// (qvz_hip_well_words), then the transpose above.
+extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, uint64_t n, uint32_t c, uint8_t *d_draws,
+                                  uint64_t ld, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    static uint32_t *d_ws = nullptr;
+    static uint64_t ws_words = 0;
+    uint32_t TR = (DT_MAX_WORDS * 4 - 8) / c;                    // reads per tile: TR*c draws fit the LDS buffer
+    TR &= ~3u;
+    if (TR > 256) TR = 256;
+    if (TR < 4) return qvz_set_error(QVZ_E_ARG, "c=%u too wide for the draw transposer", c);
+    const uint64_t chunk = 1ull << 22;                           // reads per generator pass (multiple of TR? not needed)
+    const uint64_t chunk_reads = (chunk / TR) * TR;
+    const uint64_t need = chunk_reads * c / 4 + 8;
+    if (need > ws_words) {
+        if (d_ws) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(d_ws); d_ws = nullptr; }
+        QVZ_HIP_CHECK(hipMalloc(&d_ws, need * sizeof(uint32_t)));
+        ws_words = need;
+    }
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk_reads) {
+        const uint64_t m = n - r0 < chunk_reads ? n - r0 : chunk_reads;
+        const uint64_t g0 = (first_read + r0) * c, g1 = g0 + m * c;
+        const uint64_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
+        rc = qvz_hip_well_words(h_state, w0, w1 - w0, d_ws, stream);
+        if (rc) return rc;
+        dim3 grid((unsigned)((m + TR - 1) / TR));
+        hipLaunchKernelGGL(k_draws_transpose, grid, dim3(256), 0, st, d_ws, w0, g0, m, c, TR, d_draws + r0, ld);
+        QVZ_HIP_CHECK(hipGetLastError());
+    }
+    return QVZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Quantizer (reference src/qv_compressor.c:76-135 + choose_quantizer src/codebook.c:162-171).
 //
 // One thread owns 4 consecutive reads and walks the columns once; the 4 reads are independent first-order
 // chains (previous quantized value selects the context), interleaved for latency hiding. Per column a lane
 // loads one dword of symbols and stores one dword each of quantized values / quantizer indices / states.
-// Table look-ups (ct, qs) are 2-byte gathers that hit L1/L2: only the live contexts of a column are ever
-// touched. The 72x72 distortion table sits in LDS; the per-read error is accumulated in column order so it
+// The WELL draws arrive in the same column-major layout as the symbols (qvz_hip_well_draws), so they are one more
+// coalesced dword per lane and column. Table look-ups (ct, qs) are 2-byte gathers that hit L1/L2: only the live
+// contexts of a column are ever touched. The 72x72 distortion table sits in LDS; the per-read error is accumulated in column order so it
 // is bit-identical to the reference's `error` (qv_compressor.c:97,118).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                   uint64_t n, uint32_t C, uint64_t ld, const uint16_t *__restrict__ ct,
-                                                  const uint16_t *__restrict__ qs, const uint32_t *__restrict__ words,
-                                                  uint64_t first_draw, const double *__restrict__ dist,
+                                                  const uint16_t *__restrict__ qs, const uint8_t *__restrict__ draws,
+                                                  uint64_t ldd, const double *__restrict__ dist,
                                                   uint8_t *__restrict__ qv_out, uint8_t *__restrict__ qi_out,
                                                   uint8_t *__restrict__ st_out, uint64_t ldo, double *__restrict__ err_out,
                                                   int32_t *__restrict__ status) {
@@ -1002,26 +1074,22 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
     uint32_t lab4 = 0;
     if (labels) lab4 = *reinterpret_cast<const uint32_t *>(labels + i0);
     const uint16_t *ctp[4], *qsp[4];
-    uint64_t g[4];
-    uint32_t wcur[4] = {0, 0, 0, 0}, prev[4] = {0, 0, 0, 0};
+    uint32_t prev[4] = {0, 0, 0, 0};
     double err[4] = {0.0, 0.0, 0.0, 0.0};
-    const uint64_t wbase = first_draw >> 2;
     bool dead = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t l = (lab4 >> (8 * r)) & 0xFF;
         ctp[r] = ct + (uint64_t)l * C * QVZ_CT_STRIDE;
         qsp[r] = qs + (uint64_t)l * C * QVZ_QS_STRIDE;
-        g[r] = first_draw + (i0 + r) * (uint64_t)C;
     }
     for (uint32_t s = 0; s < C; ++s) {
         const uint32_t x4 = *reinterpret_cast<const uint32_t *>(D + (uint64_t)s * ld + i0);
+        const uint32_t d4 = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)s * ldd + i0);   // 7-bit draws, same layout
         uint32_t qv4 = 0, qi4 = 0, st4 = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint64_t gg = g[r] + s;
-            if (s == 0 || (gg & 3) == 0) wcur[r] = (i0 + r < n) ? words[(gg >> 2) - wbase] : 0;
-            const uint32_t draw = (wcur[r] >> (7 * (uint32_t)(gg & 3))) & 127;          // well.c:33-46
+            const uint32_t draw = (d4 >> (8 * r)) & 127;                                 // well.c:33-46
             uint32_t x = (x4 >> (8 * r)) & 0xFF;
             if (x >= QVZ_A) x = 0;
             const uint32_t cv = ctp[r][(uint64_t)s * QVZ_CT_STRIDE + prev[r]];
@@ -1050,19 +1118,20 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
 }
 
 extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
-                                uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint32_t *d_words,
-                                uint64_t first_draw, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
+                                uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
+                                uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
                                 uint64_t ld_out, double *d_err, int32_t *d_status, void *stream) {
     int rc = check_matrix(n, c, ld);
     if (rc) return rc;
+    if ((rc = check_matrix(n, c, ld_draws))) return rc;
     if ((d_qv || d_qi || d_st) && (rc = check_matrix(n, c, ld_out))) return rc;
     if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
     if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
-    if (!d_ct || !d_qs || !d_words || !d_dist || !d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
+    if (!d_ct || !d_qs || !d_draws || !d_dist || !d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
     uint64_t n4 = (n + 3) / 4;
     dim3 grid((unsigned)((n4 + 255) / 256));
     hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, (hipStream_t)stream, d_sym, k > 1 ? d_labels : nullptr, n, c, ld,
-                       d_ct, d_qs, d_words, first_draw, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status);
+                       d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
 }

@@ -109,6 +109,15 @@ def well_words(state, first_word, nwords, device="cuda", out=None):
     return words
 
 
+def well_draws(state, first_read, n, c, out=None):
+    """Draw matrix (c, ld) uint8 of reads [first_read, first_read+n): the layout of the symbol matrix."""
+    st, sp = _state_arg(state)
+    draws = out if out is not None else empty_matrix(n, c)
+    c_, ld = _dims(draws, n)
+    check(lib().qvz_hip_well_draws(sp, first_read, n, c_, _ptr(draws), ld, _stream()))
+    return draws
+
+
 def well_jump(state, words):
     st, sp = _state_arg(state)
     out = np.zeros(32, dtype=np.uint32)
@@ -116,17 +125,18 @@ def well_jump(state, words):
     return out
 
 
-def quantize(sym, n, ct, qs, words, first_draw, dist, labels=None, k=1, want=("qv", "qi", "st", "err")):
-    """ct: (k, c, 72) int16/uint16-as-int16, qs: (k, c, 144, 72); words: int32 WELL words covering
-    draws [first_draw & ~3, first_draw + n*c)."""
+def quantize(sym, n, ct, qs, draws, dist, labels=None, k=1, want=("qv", "qi", "st", "err")):
+    """ct: (k, c, 72) int16/uint16-as-int16, qs: (k, c, 144, 72); draws: (c, ld) uint8 draw matrix of the same reads
+    (well_draws)."""
     c, ld = _dims(sym, n)
+    assert draws.shape == sym.shape and draws.dtype == torch.uint8
     dev = sym.device
     out = {}
     for name in ("qv", "qi", "st"):
         out[name] = torch.empty((c, ld), dtype=torch.uint8, device=dev) if name in want else None
     out["err"] = torch.empty(n, dtype=torch.float64, device=dev) if "err" in want else None
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(lib().qvz_hip_quantize(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(ct), _ptr(qs), _ptr(words), first_draw,
+    check(lib().qvz_hip_quantize(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(ct), _ptr(qs), _ptr(draws), ld,
                                  _ptr(dist), _ptr(out["qv"]), _ptr(out["qi"]), _ptr(out["st"]), ld, _ptr(out["err"]),
                                  _ptr(status), _stream()))
     out["status"] = status

@@ -155,15 +155,12 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     t3 = time.perf_counter()
     if well_state is None:
         well_state = np.full(32, 0x55555555, dtype=np.uint32)
-    first_draw = first_read * c
-    w0 = first_draw // 4
-    nwords = (first_draw + n * c + 3) // 4 - w0
-    with timer.span("well_words"):
-        words = K.well_words(well_state, w0, nwords, device=dev)
+    with timer.span("well_draws"):
+        draws = K.well_draws(well_state, first_read, n, c)
     ddist = torch.from_numpy(dmat).to(dev)
     with timer.span("quantize"):
-        out = K.quantize(sym, n, ct, qs, words, first_draw, ddist, labels=labels if k > 1 else None, k=k)
-    del words
+        out = K.quantize(sym, n, ct, qs, draws, ddist, labels=labels if k > 1 else None, k=k)
+    del draws
     with timer.span("pack_feed"):
         feed = K.pack_feed(out["qi"], out["st"], n)
     if int(out["status"].item()):

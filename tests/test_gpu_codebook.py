@@ -98,8 +98,8 @@ def test_end_to_end_device_pipeline_reproduces_u_file(K):
     dist = K.distortion_matrix(opts["dist"])
     cb, _ = K.generate_codebook(cnt[0], dist, opts["mode"], opts["ratio"])
     ct, qs = K.upload_tables([cb])
-    words = K.well_words(O.WELL_DEBUG_STATE, 0, (n * c + 3) // 4)
-    out = K.quantize(sym, n, ct, qs, words, 0, torch.from_numpy(dist).cuda())
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    out = K.quantize(sym, n, ct, qs, draws, torch.from_numpy(dist).cuda())
     assert int(out["status"].item()) == 0
     text = K.untranspose_text(out["qv"], n).cpu().numpy().tobytes()
     assert G.md5(text) == G.CASES[name]["u_md5"]

@@ -211,6 +211,24 @@ def test_well_random_state_and_jump(K):
     np.testing.assert_array_equal(a, b)
 
 
+def cpu_draws(state, first_read, n, c):
+    """(c, n) matrix of 7-bit draws as the reference consumes them: draw g = read*c + column (well.c:33-46)."""
+    g0 = first_read * c
+    words = cpu_well_words(state, g0 // 4, (g0 + n * c + 3) // 4 - g0 // 4)
+    g = g0 + np.arange(n * c, dtype=np.int64)
+    d = (words[g // 4 - g0 // 4] >> (7 * (g % 4)).astype(np.uint32)) & 127
+    return d.reshape(n, c).T.astype(np.uint8)
+
+
+@pytest.mark.parametrize("first,n,c", [(0, 1000, 30), (0, 5, 7), (2501, 3498, 33), (123456, 70001, 150), (7, 300, 1022),
+                                       (4_194_301, 10, 2)])
+def test_well_draw_matrix_matches_reference_draw_order(K, first, n, c):
+    draws = K.well_draws(O.WELL_DEBUG_STATE, first, n, c)
+    np.testing.assert_array_equal(draws[:, :n].cpu().numpy(), cpu_draws(O.WELL_DEBUG_STATE, first, n, c))
+    if first == 0 and n >= 1000:
+        assert draws[:12, 0].cpu().tolist() == G.MANIFEST["well_kat"]["first_draws"]      # read 0, columns 0..11
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "t2k_c3_f05_M", "uniform72_r20_A", "c2_f08",
                                   "tiny5_r10", "const_f05", "r35_high_rate", "cfg1_r10_M"])
@@ -230,9 +248,8 @@ def test_quantize_matches_reference_u_file(K, name):
     lab = torch.zeros(sym.shape[1], dtype=torch.uint8, device="cuda")
     lab[:n] = torch.from_numpy(labels_np).cuda()
     ct, qs = tables_from_codebooks(cbs)
-    nwords = (n * c + 3) // 4
-    words = K.well_words(O.WELL_DEBUG_STATE, 0, nwords)
-    out = K.quantize(sym, n, ct, qs, words, 0, torch.from_numpy(d).cuda(), labels=lab, k=k)
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    out = K.quantize(sym, n, ct, qs, draws, torch.from_numpy(d).cuda(), labels=lab, k=k)
     assert int(out["status"].item()) == 0
     text = K.untranspose_text(out["qv"], n).cpu().numpy().tobytes()
     assert G.md5(text) == G.CASES[name]["u_md5"], "-u differs from the reference"
@@ -247,7 +264,7 @@ def test_quantize_matches_reference_u_file(K, name):
 
 
 def test_quantize_shard_equals_slice_of_full(K):
-    """Reads [a,b) quantized alone with first_draw = a*C reproduce the same rows (multi-GPU sharding)."""
+    """Reads [a,b) quantized alone with the draws of reads [a,b) reproduce the same rows (multi-GPU sharding)."""
     rows = O.qgen1_rows(4, 6000, 33)
     n, c = 6000, 33
     cnt = O.stats(rows, np.zeros(n, np.uint8), 1)
@@ -256,12 +273,9 @@ def test_quantize_shard_equals_slice_of_full(K):
     ct, qs = tables_from_codebooks([cb])
     dd = torch.from_numpy(d).cuda()
     state = O.WELL_DEBUG_STATE
-    full = K.quantize(upload_sym(K, rows), n, ct, qs, K.well_words(state, 0, (n * c + 3) // 4), 0, dd)
+    full = K.quantize(upload_sym(K, rows), n, ct, qs, K.well_draws(state, 0, n, c), dd)
     a, b = 2501, 5999      # deliberately not multiples of 4
-    fd = a * c
-    w0 = fd // 4
-    words = K.well_words(state, w0, ((b * c + 3) // 4) - w0)
-    part = K.quantize(upload_sym(K, rows[a:b]), b - a, ct, qs, words, fd, dd)
+    part = K.quantize(upload_sym(K, rows[a:b]), b - a, ct, qs, K.well_draws(state, a, b - a, c), dd)
     for key in ("qv", "qi", "st"):
         assert torch.equal(part[key][:, : b - a], full[key][:, a:b]), key
     assert torch.equal(part["err"], full["err"][a:b])
@@ -274,7 +288,7 @@ def test_quantize_reports_undefined_context(K):
     cb = O.generate_codebook(cnt[0], d, O.MODE_RATIO, 0.5)
     ct, qs = tables_from_codebooks([cb])
     ct[0, 5, :] = 0xFF   # column 5 defines no context at all
-    out = K.quantize(upload_sym(K, rows), 400, ct, qs, K.well_words(O.WELL_DEBUG_STATE, 0, 1200), 0,
+    out = K.quantize(upload_sym(K, rows), 400, ct, qs, K.well_draws(O.WELL_DEBUG_STATE, 0, 400, 12),
                      torch.from_numpy(d).cuda())
     assert int(out["status"].item()) == 1
 

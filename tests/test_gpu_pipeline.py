@@ -111,9 +111,8 @@ def test_read_sharded_ranks_equal_single_pass():
     cb, _ = K.generate_codebook(cnt[0], d, 0, 0.5)
     ct, qs = K.upload_tables([cb])
     dd = torch.from_numpy(d).cuda()
-    full = K.quantize(full_sym, n, ct, qs, K.well_words(O.WELL_DEBUG_STATE, 0, n * c // 4), 0, dd)
+    full = K.quantize(full_sym, n, ct, qs, K.well_draws(O.WELL_DEBUG_STATE, 0, n, c), dd)
     for a, b in halves:
-        w = K.well_words(O.WELL_DEBUG_STATE, a * c // 4, (b - a) * c // 4)
-        part = K.quantize(upload_sym(K, rows[a:b]), b - a, ct, qs, w, a * c, dd)
+        part = K.quantize(upload_sym(K, rows[a:b]), b - a, ct, qs, K.well_draws(O.WELL_DEBUG_STATE, a, b - a, c), dd)
         assert torch.equal(part["qv"][:, : b - a], full["qv"][:, a:b])
         assert torch.equal(part["err"], full["err"][a:b])

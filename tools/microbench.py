@@ -73,6 +73,10 @@ def main():
     state = np.full(32, 0x55555555, dtype=np.uint32)
     ms, mn = timeit(lambda: K.well_words(state, 0, nwords, out=words), args.reps)
     report("well_words", ms, mn, 4 * nwords)
+    del words
+    draws = K.empty_matrix(n, c)
+    ms, mn = timeit(lambda: K.well_draws(state, 0, n, c, out=draws), args.reps)
+    report("well_draws(words+transpose)", ms, mn, 3 * n * c)
 
     # identity-ish tables: one context per previous value, 2-state quantizers (shape of the work, not of a real codebook)
     ct = torch.zeros((k, c, 72), dtype=torch.int16, device="cuda")
@@ -83,7 +87,7 @@ def main():
     qv = ((x // 8) * 8).to(torch.int16)
     qs[:] = (qv | ((x // 8).to(torch.int16) << 8))[None, None, None, :]
     dist = torch.from_numpy(np.array([[(a - b) ** 2 for a in range(72)] for b in range(72)], dtype=np.float64).reshape(-1)).cuda()
-    ms, mn = timeit(lambda: K.quantize(sym, n, ct, qs, words, 0, dist, labels=labels if k > 1 else None, k=k), args.reps)
+    ms, mn = timeit(lambda: K.quantize(sym, n, ct, qs, draws, dist, labels=labels if k > 1 else None, k=k), args.reps)
     report("quantize(qv+qi+st+err)", ms, mn, n * c * 5)
 
     text = torch.empty(n * (c + 1), dtype=torch.uint8, device="cuda")
