@@ -387,6 +387,210 @@ __global__ __launch_bounds__(64) void k_arith_shards_pf(const uint16_t *__restri
     if (c.overflow) atomicOr(status, 2);
 }
 
+// ---- model wave + coder wave ---------------------------------------------------------------------------------------
+// A stream's speed is its instruction count (see above), so the per-symbol chain is cut in two and run on two SIMDs.
+// Workgroup = 2 waves serving the same 64 streams:
+//   wave 1 (model): owns the adaptive tables. Prefetches feed -> table offset -> table header a block ahead, picks
+//                   cum_lo / freq / n for every symbol, applies update_stats (count += 8, halve-and-+1 rescale,
+//                   qv_stream.c:9-25) and parks the (n, cum_lo, freq) triples of an 8-symbol block in an LDS ring;
+//   wave 0 (coder): reads triples (LDS only), runs the interval arithmetic + renormalisation + bit output
+//                   (arith.c:24-97). It issues no global loads at all.
+// The model never needs the coder's state and the coder never needs the tables, so the two chains are independent
+// given the triples; one raw s_barrier per block (no fence: __syncthreads() would drain vmcnt) and two ring slots
+// keep the model at most one block ahead. The tables are private to the model wave, so its header prefetch is safe
+// for the same reason as in k_arith_shards_pf (a table is touched again only C symbols later; C >= 32 here).
+#define MC_BS 8
+template <bool HAVE_LABELS>
+__global__ __launch_bounds__(128) void k_arith_shards_mc(const uint16_t *__restrict__ feed, const uint8_t *__restrict__ labels,
+                                                         uint32_t C, uint32_t K, const uint64_t *__restrict__ first,
+                                                         uint32_t shards, const uint32_t *__restrict__ off,
+                                                         uint32_t *__restrict__ arena, uint32_t arena_words,
+                                                         uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ sizes,
+                                                         int32_t *__restrict__ status) {
+    // [slot][symbol][0..2 = symbol triple, 3..5 = cluster-id triple (n = 0: none)][lane]
+    __shared__ uint32_t ring[2][MC_BS][6][64];
+    __shared__ unsigned long long s_nblk;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 64 + lane;
+    const bool live = g < shards;
+    const uint64_t r0 = live ? first[g] : 0, r1 = live ? first[g + 1] : 0;
+    const uint64_t T = (r1 - r0) * C;
+    const uint64_t nblk = (T + MC_BS - 1) / MC_BS;
+    if (threadIdx.x == 0) s_nblk = 0;
+    __syncthreads();
+    if (wave == 0) atomicMax(&s_nblk, (unsigned long long)nblk);
+    __syncthreads();
+    const uint64_t nmax = s_nblk;
+
+    if (wave == 1) {
+        // ------------------------------------ model wave ------------------------------------
+        uint32_t *ar = arena + (uint64_t)(live ? g : 0) * arena_words;
+        const uint16_t *fbase = feed + r0 * C;
+        bool bad = false;
+        auto label_of = [&](uint64_t i) -> uint32_t {
+            if (!HAVE_LABELS) return 0u;
+            const uint32_t cl = labels[i];
+            return cl < K ? cl : 0u;
+        };
+        auto load_feed = [&](uint64_t blk) -> uint4 {
+            const uint64_t t0 = blk * MC_BS;
+            if (t0 + MC_BS <= T) {
+                const uint2 a = *reinterpret_cast<const uint2 *>(fbase + t0);      // 8-byte aligned (r0 % 4 == 0)
+                const uint2 b = *reinterpret_cast<const uint2 *>(fbase + t0 + 4);
+                return make_uint4(a.x, a.y, b.x, b.y);
+            }
+            uint32_t v[MC_BS];
+            for (int j = 0; j < MC_BS; ++j) v[j] = (t0 + j < T) ? fbase[t0 + j] : 0u;
+            return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+        };
+        auto entry = [](const uint4 &w, int j) -> uint32_t {
+            const uint32_t word = j < 2 ? w.x : (j < 4 ? w.y : (j < 6 ? w.z : w.w));
+            return (word >> (16 * (j & 1))) & 0xFFFF;
+        };
+        uint64_t pi = r0;                                        // look-up cursor (runs ahead of the update cursor)
+        uint32_t ps = 0;
+        const uint32_t *poffc = off + (uint64_t)(r0 < r1 ? label_of(r0) : 0u) * C * 2 * A;
+        auto lookup_block = [&](const uint4 &w, uint64_t blk, uint32_t *o) {
+#pragma unroll
+            for (int j = 0; j < MC_BS; ++j) {
+                o[j] = NO_TABLE;
+                if (blk * MC_BS + j < T) {
+                    const uint32_t qi = entry(w, j) & 0xFF;
+                    if (qi < 2 * A) o[j] = poffc[ps * 2 * A + qi];
+                    if (++ps == C) {
+                        ps = 0;
+                        ++pi;
+                        if (pi < r1) poffc = off + (uint64_t)label_of(pi) * C * 2 * A;
+                    }
+                }
+            }
+        };
+        auto load_hdrs = [&](const uint32_t *o, Hdr *h) {
+#pragma unroll
+            for (int j = 0; j < MC_BS; ++j) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(ar + (o[j] == NO_TABLE ? 0u : o[j]));
+                h[j].a = p[0];
+                h[j].b = p[1];
+            }
+        };
+        // update_stats on a table whose first counts are in registers; returns the triple
+        auto model_step = [&](uint32_t *t, const Hdr &h, uint32_t x, uint32_t &n_out, uint32_t &cum_out, uint32_t &fx_out) {
+            const uint32_t n = h.a.x, card = h.a.y;
+            uint32_t cum_lo, fx;
+            if (x < 6) {
+                const uint32_t c0 = h.a.z, c1 = h.a.w, c2 = h.b.x, c3 = h.b.y, c4 = h.b.z, c5 = h.b.w;
+                cum_lo = (x > 0 ? c0 : 0u) + (x > 1 ? c1 : 0u) + (x > 2 ? c2 : 0u) + (x > 3 ? c3 : 0u) + (x > 4 ? c4 : 0u);
+                fx = x == 0 ? c0 : x == 1 ? c1 : x == 2 ? c2 : x == 3 ? c3 : x == 4 ? c4 : c5;
+            } else {
+                cum_lo = h.a.z + h.a.w + h.b.x + h.b.y + h.b.z + h.b.w;
+                for (uint32_t i = 6; i < x; ++i) cum_lo += t[2 + i];
+                fx = t[2 + x];
+            }
+            t[2 + x] = fx + STEP;
+            uint32_t nn = n + STEP;
+            if (nn > RESCALE) {
+                nn = 0;
+                for (uint32_t i = 0; i < card; ++i) {
+                    const uint32_t v = t[2 + i];
+                    if (v) { const uint32_t hv = (v >> 1) + 1; t[2 + i] = hv; nn += hv; }
+                }
+            }
+            t[0] = nn;
+            n_out = n; cum_out = cum_lo; fx_out = fx;
+        };
+
+        uint4 f0 = load_feed(0), f1 = load_feed(1), f2 = load_feed(2);
+        uint32_t o_cur[MC_BS], o_next[MC_BS], o_nn[MC_BS];
+        Hdr h_cur[MC_BS], h_next[MC_BS];
+        lookup_block(f0, 0, o_cur);
+        lookup_block(f1, 1, o_next);
+        load_hdrs(o_cur, h_cur);
+        uint64_t ci = r0;                                        // update cursor
+        uint32_t cs = 0;
+        for (uint64_t b = 0; b <= nmax; ++b) {
+            if (b < nmax) {
+                load_hdrs(o_next, h_next);                       // block b+1
+                lookup_block(f2, b + 2, o_nn);                   // block b+2
+                const uint4 f3 = load_feed(b + 3);               // block b+3
+                const uint32_t slot = (uint32_t)(b & 1);
+#pragma unroll
+                for (int j = 0; j < MC_BS; ++j) {
+                    uint32_t n1 = 0, cum1 = 0, fx1 = 0, n0 = 0, cum0 = 0, fx0 = 0;
+                    if (b * MC_BS + j < T) {
+                        if (HAVE_LABELS) {
+                            if (cs == 0) {                       // qv_write_cluster: table 0, straight from memory
+                                const uint32_t raw = labels[ci];
+                                if (raw >= K) bad = true;
+                                const uint32_t cl = raw < K ? raw : 0u;
+                                n0 = ar[0];
+                                for (uint32_t i = 0; i < cl; ++i) cum0 += ar[2 + i];
+                                fx0 = ar[2 + cl];
+                                ar[2 + cl] = fx0 + STEP;
+                                uint32_t nn = n0 + STEP;
+                                if (nn > RESCALE) {
+                                    nn = 0;
+                                    for (uint32_t i = 0; i < K; ++i) { const uint32_t v = (ar[2 + i] >> 1) + 1; ar[2 + i] = v; nn += v; }
+                                }
+                                ar[0] = nn;
+                            }
+                            if (++cs == C) { cs = 0; ++ci; }
+                        }
+                        const uint32_t st = entry(f0, j) >> 8;
+                        const uint32_t o = o_cur[j];
+                        if (o == NO_TABLE || st >= h_cur[j].a.y) bad = true;
+                        else model_step(ar + o, h_cur[j], st, n1, cum1, fx1);
+                    }
+                    ring[slot][j][0][lane] = n1; ring[slot][j][1][lane] = cum1; ring[slot][j][2][lane] = fx1;
+                    if (HAVE_LABELS) { ring[slot][j][3][lane] = n0; ring[slot][j][4][lane] = cum0; ring[slot][j][5][lane] = fx0; }
+                }
+#pragma unroll
+                for (int j = 0; j < MC_BS; ++j) { h_cur[j] = h_next[j]; o_cur[j] = o_next[j]; o_next[j] = o_nn[j]; }
+                f0 = f1; f1 = f2; f2 = f3;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (bad) atomicOr(status, 1);
+        return;
+    }
+
+    // ------------------------------------ coder wave ------------------------------------
+    LaneCoder c;
+    c.l = 0; c.u = MASK_M; c.scale3 = 0; c.nbits = 0; c.acc = 0;
+    c.out = out + (uint64_t)(live ? g : 0) * cap; c.pos = 0; c.cap = cap; c.overflow = false;
+    for (uint64_t b = 0; b <= nmax; ++b) {
+        asm volatile("s_barrier" ::: "memory");                  // the model wave parked block b in slot b&1 before barrier b
+        if (b == nmax) break;                                    // (while we code it, the model fills the other slot)
+        const uint32_t slot = (uint32_t)(b & 1);
+#pragma unroll
+        for (int j = 0; j < MC_BS; ++j) {
+            if (HAVE_LABELS) {
+                const uint32_t n0 = ring[slot][j][3][lane];
+                if (n0) lc_interval(c, n0, ring[slot][j][4][lane], ring[slot][j][5][lane]);
+            }
+            const uint32_t n1 = ring[slot][j][0][lane];
+            if (n1) lc_interval(c, n1, ring[slot][j][1][lane], ring[slot][j][2][lane]);
+        }
+    }
+    if (!live) return;
+    const uint32_t bb = c.l >> (M_BITS - 1);                     // encoder_last_step + stream_finish_byte
+    lc_put(c, bb, 1);
+    if (c.scale3) { lc_run(c, !bb, c.scale3); c.scale3 = 0; }
+    lc_put(c, c.l & MASK_M1, M_BITS - 1);
+    uint64_t total_bits = c.pos * 8 + c.nbits;
+    if (total_bits % 8) { const uint32_t pad = 8 - (uint32_t)(total_bits % 8); lc_put(c, 0, pad); total_bits += pad; }
+    else { lc_put(c, 0, 8); total_bits += 8; }
+    const uint64_t bytes = total_bits / 8;
+    while (c.nbits) {
+        const uint32_t take = c.nbits >= 8 ? 8 : c.nbits;
+        const uint8_t byte = (uint8_t)((c.acc >> (c.nbits - take)) << (8 - take));
+        if (c.pos < c.cap) c.out[c.pos] = byte; else c.overflow = true;
+        c.pos += 1;
+        c.nbits -= take;
+    }
+    sizes[g] = bytes;
+    if (c.overflow) atomicOr(status, 2);
+}
+
 // every shard starts from the same initial model
 __global__ __launch_bounds__(256) void k_arena_fill(const uint32_t *__restrict__ tmpl, uint32_t words, uint32_t shards,
                                                     uint32_t *__restrict__ arena) {
@@ -432,7 +636,14 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
-    if (columns >= 8 && !(variant && strcmp(variant, "simple") == 0)) {
+    if (columns >= 32 && !(variant && strcmp(variant, "mc") != 0)) {
+        if (clusters > 1)
+            hipLaunchKernelGGL(k_arith_shards_mc<true>, dim3((shards + 63) / 64), dim3(128), 0, st, d_feed, d_labels, columns,
+                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
+        else
+            hipLaunchKernelGGL(k_arith_shards_mc<false>, dim3((shards + 63) / 64), dim3(128), 0, st, d_feed, d_labels, columns,
+                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
+    } else if (columns >= 8 && !(variant && strcmp(variant, "simple") == 0)) {
         if (clusters > 1)
             hipLaunchKernelGGL(k_arith_shards_pf<true>, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns,
                                clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
