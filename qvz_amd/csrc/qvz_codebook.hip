@@ -12,7 +12,7 @@
 //   k_marginals     one block, sequential over columns and over j (pmf.c:200-202 order), lanes over x
 //   k_ctx_propagate one 1024-thread block per column: thread per output element, each a sequential 72-term sum;
 //                   p_temp(k,j) hoisted out of the idx loop (same per-term order => bit-identical)
-//   k_lm_search     one wave per context: Lloyd-Max with a lane per candidate reconstruction point, exact
+//   k_lm_window     one wave per (context, state count): Lloyd-Max with a lane per candidate reconstruction point, exact
 //                   (value, index) arg-min by wave shuffles, ballot masks + count-trailing-zeros for the
 //                   boundary walk; the number-of-states search runs on device, steered by device log2 inside
 //                   a guard band; host libm takes every decision that falls inside the band and computes the
@@ -259,22 +259,25 @@ __global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict
     }
 }
 
-// ---- Lloyd-Max search, one wave per context ------------------------------------------------------
+// ---- Lloyd-Max search: a window of state counts per context, one wave per design ----------------------
+// The reference walks S = 1, 2, 3 ... until the design's entropy reaches the target (codebook.c:244-258). The
+// designs for different S do not depend on each other, only the stopping decision is sequential, so a launch
+// computes a window of consecutive S per context on separate CUs and the host replays the walk over the results.
 struct LmIn {
     double target;
-    uint8_t mode;      // 0 skip, 1 search (startS = 0 fresh, > 0 resume from the stored hi design), 2 single design
+    uint8_t mode;      // 0 skip, 1 window [startS, startS + W), 2 the single design startS
     uint8_t startS;
     uint8_t pad[6];
 };
 
-struct LmOut {
-    double o[2][A];    // output pmfs of lo / hi (apply_quantizer, quantizer.c:139-161)
-    double hdev[2];    // device-side entropies (steering only)
-    uint8_t q[2][A];
-    uint8_t recon[2][A];
-    uint8_t S[2];
-    uint8_t flag;      // 1: stopped at S[1] because |H_dev - target| fell inside the guard band
-    uint8_t pad[5];
+struct LmDesign {
+    double o[A];       // output pmf (apply_quantizer, quantizer.c:139-161)
+    double hdev;       // device-side entropy (steering only; decisions inside the guard band are the host's)
+    uint8_t q[A];
+    uint8_t recon[A];
+    uint8_t S;
+    uint8_t valid;     // 0: not computed (S > 72, or a smaller S of this context already reached the target)
+    uint8_t pad[6];
 };
 
 struct LmLds {
@@ -285,8 +288,10 @@ struct LmLds {
 };
 
 // One Lloyd-Max design (quantizer.c:34-132) for S states into slot `b`. All 64 lanes call it together.
-__device__ void lm_design(const double *__restrict__ p, const double *__restrict__ dl, uint32_t S, LmLds *L,
-                          double *__restrict__ o, int b) {
+// `stop` (may be null) holds the smallest S of this context known to reach the target: a design with a larger S
+// is not needed by the walk and gives up (returns false).
+__device__ bool lm_design(const double *__restrict__ p, const double *__restrict__ dl, uint32_t S, LmLds *L,
+                          double *__restrict__ o, int b, const uint32_t *stop) {
     const uint32_t lane = threadIdx.x;
     uint8_t *bounds = L->bounds, *recon = L->recon[b], *q = L->q[b];
     if (lane == 0) { bounds[0] = 0; bounds[S] = A; }                                  // :45-46
@@ -299,6 +304,7 @@ __device__ void lm_design(const double *__restrict__ p, const double *__restrict
     while (changed && iter < 100) {                                                  // :57, quantizer.h:10
         changed = 0;
         iter += 1;
+        if (stop && __atomic_load_n(stop, __ATOMIC_RELAXED) < S) return false;       // wave-uniform
         for (uint32_t j = 0; j < S; ++j) {                                           // :62-87
             const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
             const uint32_t r1 = b0 + lane, r2 = r1 + 64;
@@ -379,6 +385,7 @@ __device__ void lm_design(const double *__restrict__ p, const double *__restrict
         o[v] = acc;
     }
     __syncthreads();
+    return true;
 }
 
 __device__ double lm_entropy_dev(const double *o) {   // steering value only (device log2, tree order)
@@ -392,70 +399,41 @@ __device__ double lm_entropy_dev(const double *o) {   // steering value only (de
     return -t;
 }
 
-__global__ __launch_bounds__(64) void k_lm_search(const double *__restrict__ pm, const double *__restrict__ dist,
-                                                  const LmIn *__restrict__ in, LmOut *__restrict__ out, double guard) {
+// grid (contexts, window); block (ctx, w) designs S = startS + w. distT[i*72 + r] = d(i, r) (lanes walk r: no LDS
+// bank conflicts). blockIdx.x runs fastest, so the small S of every context are dispatched first.
+__global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm, const double *__restrict__ distT,
+                                                  const LmIn *__restrict__ in, LmDesign *__restrict__ out,
+                                                  uint32_t *__restrict__ stop, double guard) {
     extern __shared__ double sm[];
-    double *dl = sm;                  // dl[i*72 + r] = d(i, r) = dist[i + 72*r]  (lanes walk r: conflict-free)
+    double *dl = sm;
     double *p = sm + A * A;
-    double *o = p + A;                // o[2][72]
-    LmLds *L = reinterpret_cast<LmLds *>(o + 2 * A);
-    const uint32_t ctx = blockIdx.x, lane = threadIdx.x;
+    double *o = p + A;
+    LmLds *L = reinterpret_cast<LmLds *>(o + A);
+    const uint32_t ctx = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
     const LmIn I = in[ctx];
-    if (I.mode == 0) return;
-    for (uint32_t e = lane; e < A * A; e += 64) dl[e] = dist[(e / A) + A * (e % A)];
-    for (uint32_t e = lane; e < A; e += 64) p[e] = pm[(uint64_t)ctx * A + e];
-    __syncthreads();
-    LmOut *O = out + ctx;
-
-    int cur = 0;
-    uint32_t S = 1;
-    double H[2] = {0.0, 0.0};
-    uint8_t flag = 0;
-    if (I.mode == 2) {                // single design, stored as both lo and hi
-        S = I.startS;
-        lm_design(p, dl, S, L, o, 0);
-        H[0] = lm_entropy_dev(o);
-        for (uint32_t e = lane; e < A; e += 64) {
-            O->o[0][e] = o[e]; O->o[1][e] = o[e];
-            O->q[0][e] = L->q[0][e]; O->q[1][e] = L->q[0][e];
-            O->recon[0][e] = e < S ? L->recon[0][e] : 0; O->recon[1][e] = e < S ? L->recon[0][e] : 0;
-        }
-        if (lane == 0) { O->S[0] = (uint8_t)S; O->S[1] = (uint8_t)S; O->hdev[0] = H[0]; O->hdev[1] = H[0]; O->flag = 0; }
+    LmDesign *O = out + (size_t)ctx * gridDim.y + w;
+    const uint32_t S = (uint32_t)I.startS + w;
+    const bool wanted = I.mode == 1 ? S <= A : (I.mode == 2 && w == 0);
+    if (!wanted || (I.mode == 1 && __atomic_load_n(stop + ctx, __ATOMIC_RELAXED) < S)) {
+        if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
         return;
     }
-    if (I.startS) {                   // resume: the stored hi design becomes the current one
-        S = I.startS;
-        for (uint32_t e = lane; e < A; e += 64) {
-            o[e] = O->o[1][e];
-            L->q[0][e] = O->q[1][e];
-            L->recon[0][e] = O->recon[1][e];
-        }
-        H[0] = O->hdev[1];
-        __syncthreads();
-    } else {
-        lm_design(p, dl, 1, L, o, 0);                                               // codebook.c:244-246
-        H[0] = lm_entropy_dev(o);
+    for (uint32_t e = lane; e < A * A; e += 64) dl[e] = distT[e];
+    for (uint32_t e = lane; e < A; e += 64) p[e] = pm[(uint64_t)ctx * A + e];
+    __syncthreads();
+    if (!lm_design(p, dl, S, L, o, 0, I.mode == 1 ? stop + ctx : nullptr)) {
+        if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
+        return;
     }
-    for (;;) {                                                                       // codebook.c:249-258
-        cur ^= 1;
-        S += 1;
-        lm_design(p, dl, S, L, o + cur * A, cur);
-        H[cur] = lm_entropy_dev(o + cur * A);
-        if (S >= A) break;
-        const double diff = H[cur] - I.target;
-        if (fabs(diff) <= guard) { flag = 1; break; }      // host decides from libm
-        if (!(diff < 0.0)) break;                          // hi_entropy >= target
-    }
-    const int lo = cur ^ 1;
+    const double H = lm_entropy_dev(o);
     for (uint32_t e = lane; e < A; e += 64) {
-        O->o[0][e] = o[lo * A + e]; O->o[1][e] = o[cur * A + e];
-        O->q[0][e] = L->q[lo][e]; O->q[1][e] = L->q[cur][e];
-        O->recon[0][e] = e < S - 1 ? L->recon[lo][e] : 0; O->recon[1][e] = e < S ? L->recon[cur][e] : 0;
+        O->o[e] = o[e];
+        O->q[e] = L->q[0][e];
+        O->recon[e] = e < S ? L->recon[0][e] : 0;
     }
     if (lane == 0) {
-        O->S[0] = (uint8_t)(S - 1); O->S[1] = (uint8_t)S;
-        O->hdev[0] = H[lo]; O->hdev[1] = H[cur];
-        O->flag = flag;
+        O->S = (uint8_t)S; O->valid = 1; O->hdev = H;
+        if (I.mode == 1 && S > 1 && H - I.target > guard) atomicMin(stop + ctx, S);   // surely >= target: the walk ends here or earlier
     }
 }
 
@@ -492,17 +470,19 @@ struct CbWork {
     double *rprev = nullptr;
     uint8_t *qprev = nullptr, *ctx_sym = nullptr;
     LmIn *lin = nullptr;
-    LmOut *lout = nullptr;
+    LmDesign *lout = nullptr, *hout = nullptr;     // device window results and their pinned host mirror
+    uint32_t *stop = nullptr;
     void release() {
-        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, qprev, ctx_sym, lin, lout};
+        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, qprev, ctx_sym, lin, lout, stop};
         for (void *p : ptrs) if (p) (void)hipFree(p);
+        if (hout) (void)hipHostFree(hout);
     }
 };
 
 static uint64_t g_deferred = 0;
 extern "C" uint64_t qvz_hip_codebook_deferred_decisions(void) { return g_deferred; }
 
-#define LM_LDS_BYTES ((A * A + A + 2 * A) * sizeof(double) + sizeof(LmLds))
+#define LM_LDS_BYTES ((A * A + A + A) * sizeof(double) + sizeof(LmLds))
 
 static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint8_t *q, const uint8_t *recon, uint32_t S) {
     const size_t t = ((size_t)s * 2 * A + qi) * A;
@@ -528,8 +508,16 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     QVZ_HIP_CHECK(hipMalloc(&W.qprev, 2 * tile));
     QVZ_HIP_CHECK(hipMalloc(&W.ctx_sym, A));
     QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
-    QVZ_HIP_CHECK(hipMalloc(&W.lout, A * sizeof(LmOut)));
-    QVZ_HIP_CHECK(hipMemcpyAsync(W.dist, h_dist, tile * sizeof(double), hipMemcpyHostToDevice, st));
+    QVZ_HIP_CHECK(hipMalloc(&W.lout, tile * sizeof(LmDesign)));
+    QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocDefault));
+    QVZ_HIP_CHECK(hipMalloc(&W.stop, A * sizeof(uint32_t)));
+    {
+        double hT[A * A];                          // d(i, r) = dist[i + 72 r] laid out with r fastest
+        for (int i = 0; i < A; ++i)
+            for (int r = 0; r < A; ++r) hT[i * A + r] = h_dist[i + A * r];
+        QVZ_HIP_CHECK(hipMemcpyAsync(W.dist, hT, tile * sizeof(double), hipMemcpyHostToDevice, st));
+        QVZ_HIP_CHECK(hipStreamSynchronize(st));
+    }
     QVZ_HIP_CHECK(hipMemsetAsync(W.zero_rows, 0, tile * sizeof(double), st));
     QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ctx_propagate),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile * sizeof(double))));
@@ -539,7 +527,8 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     QVZ_HIP_CHECK(hipGetLastError());
 
     LmIn hin[A];
-    static LmOut hout[A];
+    LmDesign *hout = W.hout;
+    LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
     double hx[A * A];
     uint8_t hq[2 * A * A];
     double hr[A];
@@ -549,10 +538,12 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     memset(hin, 0, sizeof(hin));
     for (int S = 1; S <= A; ++S) { hin[S - 1].mode = 2; hin[S - 1].startS = (uint8_t)S; }
     QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(hin), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_lm_search, dim3(A), dim3(64), LM_LDS_BYTES, st, W.zero_rows, W.dist, W.lin, W.lout, guard);
-    QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(hout), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_lm_window, dim3(A, 1), dim3(64), LM_LDS_BYTES, st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
+    QVZ_HIP_CHECK(hipGetLastError());
+    QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, A * sizeof(LmDesign), hipMemcpyDeviceToHost, st));
     QVZ_HIP_CHECK(hipStreamSynchronize(st));
-    for (int S = 1; S <= A; ++S) { memcpy(Z[S].q, hout[S - 1].q[1], A); memcpy(Z[S].recon, hout[S - 1].recon[1], A); }
+    for (int S = 1; S <= A; ++S) { memcpy(Z[S].q, hout[S - 1].q, A); memcpy(Z[S].recon, hout[S - 1].recon, A); }
+    uint32_t window0 = 16;                         // first window of a column: the previous column's largest S + 3
 
     uint32_t nprev = 0;
     int pq = 0;   // index of the qpmf buffer holding the previous column
@@ -598,31 +589,54 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             if (!zero[j]) {
                 hin[j].target = target[j];
                 hin[j].mode = target[j] == 0.0 ? 2 : 1;                            // :236-242 vs the search
-                hin[j].startS = target[j] == 0.0 ? 1 : 0;
+                hin[j].startS = 1;
                 any_gpu = true;
             }
         }
+        uint32_t win = window0, smax = 1;
         while (any_gpu) {
             QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(LmIn) * nu, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_lm_search, dim3(nu), dim3(64), LM_LDS_BYTES, st, d_rows, W.dist, W.lin, W.lout, guard);
+            QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_lm_window, dim3(nu, win), dim3(64), LM_LDS_BYTES, st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
             QVZ_HIP_CHECK(hipGetLastError());
-            QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmOut) * nu, hipMemcpyDeviceToHost, st));
+            QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win, hipMemcpyDeviceToHost, st));
             QVZ_HIP_CHECK(hipStreamSynchronize(st));
             any_gpu = false;
             for (uint32_t j = 0; j < nu; ++j) {
-                if (hin[j].mode != 1) { hin[j].mode = 0; continue; }
+                const LmDesign *d = hout + (size_t)j * win;
+                if (hin[j].mode == 2) {                                             // target 0: one state, lo == hi
+                    if (!d[0].valid) return qvz_set_error(QVZ_E_HIP, "column %u context %u: design missing", s, j);
+                    lo_d[j] = d[0]; hi_d[j] = d[0];
+                    hin[j].mode = 0;
+                    continue;
+                }
+                if (hin[j].mode != 1) continue;
+                // replay of the walk (codebook.c:249-258) over the window; d[0] is the last design already rejected
+                // (or S = 1 at the start), so the walk resumes at d[1]
                 hin[j].mode = 0;
-                if (hout[j].flag) {                                                 // decision inside the guard band
-                    g_deferred += 1;
-                    const double Hhi = entropy_libm(hout[j].o[1]);
-                    if (Hhi < target[j] && hout[j].S[1] < A) {                      // reference keeps searching
-                        hin[j].mode = 1;
-                        hin[j].startS = hout[j].S[1];
-                        any_gpu = true;
-                    }
+                bool done = false;
+                uint32_t w = 1;
+                for (; w < win && (uint32_t)hin[j].startS + w <= A; ++w) {
+                    if (!d[w].valid || !d[w - 1].valid)
+                        return qvz_set_error(QVZ_E_HIP, "column %u context %u: design %u missing", s, j, hin[j].startS + w);
+                    const double diff = d[w].hdev - target[j];
+                    bool below;
+                    if (fabs(diff) <= guard) { g_deferred += 1; below = entropy_libm(d[w].o) < target[j]; }
+                    else below = diff < 0.0;
+                    if (!below || d[w].S >= A) { done = true; break; }
+                }
+                if (done) {
+                    lo_d[j] = d[w - 1]; hi_d[j] = d[w];
+                    if (d[w].S > smax) smax = d[w].S;
+                } else {                                                            // keep walking from the last design
+                    hin[j].mode = 1;
+                    hin[j].startS = (uint8_t)(hin[j].startS + w - 1);
+                    any_gpu = true;
                 }
             }
+            if (any_gpu) win = win * 2 > A ? A : win * 2;
         }
+        window0 = smax + 3 < 8 ? 8 : (smax + 3 > A ? A : smax + 3);
 
         // ratios from libm entropies, store (optimize_for_entropy :263-268, store_cond_quantizers_indexed :152-157)
         for (uint32_t j = 0; j < nu; ++j) {
@@ -642,13 +656,12 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
                     else ratio = 1.0;                                               // lo_entropy (0) >= target
                 }
             } else {
-                const LmOut &o = hout[j];
-                store_design(cb, s, 2 * j, o.q[0], o.recon[0], o.S[0]);
-                store_design(cb, s, 2 * j + 1, o.q[1], o.recon[1], o.S[1]);
+                store_design(cb, s, 2 * j, lo_d[j].q, lo_d[j].recon, lo_d[j].S);
+                store_design(cb, s, 2 * j + 1, hi_d[j].q, hi_d[j].recon, hi_d[j].S);
                 if (target[j] == 0.0) {
                     ratio = 1.0;
                 } else {
-                    const double lo_entropy = entropy_libm(o.o[0]), hi_entropy = entropy_libm(o.o[1]);
+                    const double lo_entropy = entropy_libm(lo_d[j].o), hi_entropy = entropy_libm(hi_d[j].o);
                     if (hi_entropy < target[j]) ratio = 0.0;
                     else if (lo_entropy >= target[j] || hi_entropy == lo_entropy) ratio = 1.0;
                     else ratio = (target[j] - hi_entropy) / (lo_entropy - hi_entropy);
