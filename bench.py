@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (testing)")
     ap.add_argument("--shards", type=int, default=0, help="arithmetic-coded streams per GPU (default: host threads)")
     ap.add_argument("--threads", type=int, default=0, help="host coder threads per rank (default: cores / ranks)")
-    ap.add_argument("--coder", choices=["host", "gpu"], default="gpu",
+    ap.add_argument("--coder", choices=["host", "gpu", "gpu-feed"], default="gpu",
                     help="arithmetic coder: host threads, or one GPU lane per shard (byte-identical streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

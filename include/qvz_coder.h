@@ -75,6 +75,19 @@ int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint6
                           uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, uint8_t *d_out,
                           uint64_t cap_per_shard, uint64_t *h_sizes, void *stream);
 
+/* The GPU sharded coder fed straight from the quantizer's output planes (d_qi[s*ld+i], d_st[s*ld+i], as written by
+ * qvz_hip_quantize; no packed feed). Same streams, byte for byte, as qvz_hip_encode_shards / qvz_encode_shards_device.
+ * The adaptive model of a column depends on that column's symbols only (qv_stream.c:9-25 updates one table, and a
+ * table belongs to one column), so the model runs with one lane per (stream, column) and leaves a 16-byte record
+ * (cum_lo / n, cum_hi / n as doubles) per symbol; one lane per stream then runs the serial interval arithmetic
+ * (arith.c:24-97) over its records. Records pass through d_work (work_bytes, 16-byte aligned) in segments of as many
+ * reads per stream as fit: 16 * shards * (columns + (clusters > 1)) bytes per read. d_work = NULL: a workspace of up to 4 GiB is
+ * allocated for the call. */
+int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
+                          uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                          uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,
+                          void *stream);
+
 /* Initial adaptive model as a flat arena of tables [n][card][counts...] (cluster-id table at index 0) plus the
  * (cluster, column, quantizer) -> arena index map (0xFFFFFFFF = none). Shared by the host and GPU coders.
  * Caller frees *arena_out and *offset_out with free(). Returns 0 on success. */

@@ -591,6 +591,330 @@ __global__ __launch_bounds__(128) void k_arith_shards_mc(const uint16_t *__restr
     if (c.overflow) atomicOr(status, 2);
 }
 
+// ---- column-parallel model + streaming coder ------------------------------------------------------------------------
+// PMC on the kernels above (profiles/, 100M x 150, 8192 streams): 52 % of the wave cycles parked on s_waitcnt, 49 % L2
+// misses, ~1.1 TB fetched + 0.6 TB written for 15 G symbols. A lane that walks its reads column by column touches a
+// different table (a different 64-128 B line of its 0.5 MB arena) every symbol, so the "latency-bound" chain was in fact
+// random HBM traffic. But the adaptive model of column s is a function of the column-s symbols only (a table belongs
+// to one column, update_stats touches nothing else, qv_stream.c:9-25): only the interval arithmetic is a serial
+// chain over the whole read. Hence two kernels:
+//   k_model_columns  one lane per (stream, column) - 1.2 M lanes at 8192 x 150 instead of 8192. The lane walks its
+//                    stream's reads for that column, so its working set is the handful of tables of one column
+//                    (L1/L2 resident) and qi/st are read along the read axis. It emits the 8-byte record
+//                    (n, cum_lo, freq) of every symbol in the stream's read-major coding order.
+//   k_code_records   one lane per stream: streams its records (plain sequential loads, prefetched two blocks ahead)
+//                    through the interval arithmetic + renormalisation + bit output (arith.c:24-97). No tables.
+// Records go through a caller-sized workspace in segments of `seg_reads` reads per stream; the coder state of a
+// stream survives between segments in CoderState.
+struct CoderState {
+    uint32_t l, u, scale3, nbits;
+    uint64_t acc, pos;
+    uint32_t overflow, pad;
+};
+
+// Record of one symbol: x = cum_lo / n / 1024 and y = (n - cum_hi) / n / 1024 as correctly rounded doubles; (0, 0) codes
+// nothing. The coder keeps l and ~u left-aligned in 32 bits (l32 = l << 10, nu32 = (~u & MASK) << 10), so that
+// R * 1024 = 2^32 - (l32 + nu32) and
+//     l  += floor(R * cum_lo / n)       = trunc(fma(R * 1024, x, 2^-24))
+//     ~u += R - floor(R * cum_hi / n)   = ceil(R * (n - cum_hi) / n) = trunc(fma(R * 1024, y, 1 - 2^-24))     (arith.c:47-48)
+// exactly: R <= 2^22 and n <= 2^19, so |R*x*1024 - R*cum/n| <= 2^22 * 2^-54, the fma rounds by at most 2^-31, and the
+// computed value is within 2^-30 of the true quotient plus the constant; a quotient that is an integer Q lands in
+// [Q + c - 2^-30, Q + c + 2^-30] and truncates to Q for either constant c, one that is not has a fractional part in
+// [2^-19, 1 - 2^-19] and truncates to floor (+1 with the second constant, i.e. the ceiling). The division by n thus
+// leaves the serial chain - the model lanes do it - and the all-zero record is a natural no-op (both steps add 0, the
+// interval is already renormalised), so padding needs no branch.
+#define QUOT_LO 5.9604644775390625e-08    /* 2^-24 */
+#define QUOT_HI 0.99999994039535522461    /* 1 - 2^-24 */
+typedef double2 Record;
+__device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint32_t fx) {
+    const double nd = (double)n;
+    return make_double2((double)cum_lo / nd * 0x1p-10, (double)(n - cum_lo - fx) / nd * 0x1p-10);
+}
+
+template <bool HAVE_LABELS>
+__global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
+                                                       const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
+                                                       const uint64_t *__restrict__ first, uint32_t shards,
+                                                       const uint32_t *__restrict__ off, uint32_t *__restrict__ arena,
+                                                       uint32_t arena_words, uint64_t seg_lo, uint32_t seg_reads,
+                                                       Record *__restrict__ rec, int32_t *__restrict__ status) {
+    const uint32_t Cx = C + (HAVE_LABELS ? 1u : 0u);             // records per read: [cluster id,] column 0 .. C-1
+    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (uint64_t)shards * Cx) return;
+    const uint32_t g = (uint32_t)(id / Cx), sx = (uint32_t)(id % Cx);
+    const uint64_t r0 = first[g] + seg_lo, rend = first[g + 1];  // r0 is a multiple of 4
+    if (r0 >= rend) return;
+    const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
+    uint32_t *ar = arena + (uint64_t)g * arena_words;
+    Record *rp = rec + (uint64_t)g * seg_reads * Cx + sx;
+    const bool cluster_lane = HAVE_LABELS && sx == 0;
+    const uint32_t s = HAVE_LABELS ? sx - 1 : sx;
+    bool bad = false;
+    for (uint64_t r = r0; r < r1; r += 4) {
+        uint32_t qw = 0, sw = 0;
+        if (!cluster_lane) {
+            qw = *reinterpret_cast<const uint32_t *>(qi + (uint64_t)s * ld + r);   // 4 reads of this column
+            sw = *reinterpret_cast<const uint32_t *>(st + (uint64_t)s * ld + r);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (r + j >= r1) break;
+            uint32_t cl = 0;
+            if (HAVE_LABELS) {
+                const uint32_t raw = labels[r + j];
+                if (raw >= K) bad = true; else cl = raw;
+            }
+            uint32_t o, x;
+            if (cluster_lane) {                                  // qv_write_cluster: table 0 of the arena
+                o = 0; x = cl;
+            } else {
+                const uint32_t q = (qw >> (8 * j)) & 0xFF;
+                x = (sw >> (8 * j)) & 0xFF;
+                o = q < 2 * A ? off[((uint64_t)cl * C + s) * 2 * A + q] : NO_TABLE;
+            }
+            Record w = make_double2(0.0, 0.0);                   // nothing to code (bad feed, reported below)
+            if (o == NO_TABLE) {
+                bad = true;
+            } else {
+                uint32_t *t = ar + o;
+                const uint4 ha = reinterpret_cast<const uint4 *>(t)[0];            // n, card, c0, c1
+                const uint32_t n = ha.x, card = ha.y;
+                if (x >= card) {
+                    bad = true;
+                } else {
+                    uint32_t cum_lo, fx;
+                    if (x < 2) {
+                        cum_lo = x ? ha.z : 0u;
+                        fx = x ? ha.w : ha.z;
+                    } else {
+                        const uint4 hb = reinterpret_cast<const uint4 *>(t)[1];    // c2 .. c5 (may run past a short table: unused then)
+                        if (x < 6) {
+                            cum_lo = ha.z + ha.w + (x > 2 ? hb.x : 0u) + (x > 3 ? hb.y : 0u) + (x > 4 ? hb.z : 0u);
+                            fx = x == 2 ? hb.x : x == 3 ? hb.y : x == 4 ? hb.z : hb.w;
+                        } else {
+                            cum_lo = ha.z + ha.w + hb.x + hb.y + hb.z + hb.w;
+                            for (uint32_t i = 6; i < x; ++i) cum_lo += t[2 + i];
+                            fx = t[2 + x];
+                        }
+                    }
+                    t[2 + x] = fx + STEP;                        // update_stats, qv_stream.c:12-24
+                    uint32_t nn = n + STEP;
+                    if (nn > RESCALE) {
+                        nn = 0;
+                        for (uint32_t i = 0; i < card; ++i) {
+                            const uint32_t v = t[2 + i];
+                            if (v) { const uint32_t hv = (v >> 1) + 1; t[2 + i] = hv; nn += hv; }
+                        }
+                    }
+                    t[0] = nn;
+                    w = make_record(n, cum_lo, fx);
+                }
+            }
+            rp[(r + j - r0) * Cx] = w;
+        }
+    }
+    if (bad) atomicOr(status, 1);
+}
+
+// encoder_last_step (arith.c:99-116) + stream_finish_byte (os_stream.c:105-110); returns the stream length
+__device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
+    const uint32_t bb = c.l >> (M_BITS - 1);
+    lc_put(c, bb, 1);
+    if (c.scale3) { lc_run(c, !bb, c.scale3); c.scale3 = 0; }
+    lc_put(c, c.l & MASK_M1, M_BITS - 1);
+    uint64_t total_bits = c.pos * 8 + c.nbits;
+    if (total_bits % 8) { const uint32_t pad = 8 - (uint32_t)(total_bits % 8); lc_put(c, 0, pad); total_bits += pad; }
+    else { lc_put(c, 0, 8); total_bits += 8; }                   // aligned streams still get one 0x00 byte
+    while (c.nbits) {                                            // spill the remaining whole bytes
+        const uint32_t take = c.nbits >= 8 ? 8 : c.nbits;
+        const uint8_t byte = (uint8_t)((c.acc >> (c.nbits - take)) << (8 - take));
+        if (c.pos < c.cap) c.out[c.pos] = byte; else c.overflow = true;
+        c.pos += 1;
+        c.nbits -= take;
+    }
+    return total_bits / 8;
+}
+
+// Workgroup = three waves serving the same 64 streams, one lane per stream in each:
+//   wave 2 (loader)    streams every lane's records (one 256-byte run per lane and block, two blocks in flight in
+//                      registers) into an LDS ring; it is the only wave that loads from global memory;
+//   wave 0 (interval)  the serial chain proper (arith.c:24-97): l/u from the record, E1/E2 shift count k, E3 count j,
+//                      renormalised l/u - 24 dependent instructions, no branch. What the symbol contributes to the
+//                      output depends only on (top k bits of the new l, k, j), parked as one 32-bit word in a second ring;
+//   wave 1 (emitter)   pending-bit bookkeeping (scale3), bit accumulator and the byte stream (stores).
+// A lone wave issues a dependent VALU instruction every 8 cycles (tools/lat_bench.hip), so a stream's speed is the
+// length of its longest per-wave chain; that is why the work is cut by wave and kept branch-free.
+// One raw s_barrier per block of CR_B symbols (no fence, nobody waits on vmcnt): before barrier b the loader has
+// parked records b and the interval wave the words of block b-1; after it the interval wave codes block b and the
+// emitter writes out block b-1. Two slots per ring suffice.
+#define CR_B 16      // symbols per block and lane
+__global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
+                                                      uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
+                                                      CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
+                                                      uint64_t *__restrict__ sizes, int32_t *__restrict__ status) {
+    __shared__ Record ring[2][CR_B][64];
+    __shared__ uint32_t words[2][CR_B][64];
+    __shared__ uint32_t final_l[64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 64 + lane;
+    const bool live = g < shards;
+    uint64_t T = 0;
+    if (live) {
+        const uint64_t rend = first[g + 1], a = first[g] + seg_lo, b = a + seg_reads;
+        if (a < rend) T = ((b < rend ? b : rend) - a) * Cx;
+    }
+    uint64_t Tmax = T;
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t v = __shfl_xor(Tmax, o, 64); Tmax = v > Tmax ? v : Tmax; }
+    const uint64_t nblk = (Tmax + CR_B - 1) / CR_B;              // the same in all three waves
+    const bool fresh = is_first || !live;
+
+    if (wave == 2) {
+        // ------------------------------------ loader ------------------------------------
+        const uint64_t total = (uint64_t)seg_reads * Cx;         // records in a stream's area
+        const Record *p = rec + (uint64_t)(live ? g : 0) * total;
+        auto load_block = [&](uint64_t blk, Record *d) {
+#pragma unroll
+            for (int i = 0; i < CR_B; ++i) {
+                const uint64_t idx = blk * CR_B + i;
+                d[i] = p[idx < total ? idx : total - 1];         // unconditional (clamped) so that vmcnt stays countable
+            }
+        };
+        auto park = [&](uint64_t b, const Record *d) {           // block b -> slot b & 1, then barrier b
+            const uint32_t slot = (uint32_t)(b & 1);
+#pragma unroll
+            for (int i = 0; i < CR_B; ++i) {
+                const bool pad = b * CR_B + i >= T;              // beyond this lane's symbols: the no-op record
+                ring[slot][i][lane] = make_double2(pad ? 0.0 : d[i].x, pad ? 0.0 : d[i].y);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        // three register stages used in rotation (no copies: a copy would wait for the load it copies)
+        Record s0[CR_B], s1[CR_B], s2[CR_B];
+        load_block(0, s0);
+        load_block(1, s1);
+        for (uint64_t b = 0; b < nblk; b += 3) {
+            load_block(b + 2, s2);
+            park(b, s0);
+            if (b + 1 >= nblk) break;
+            load_block(b + 3, s0);
+            park(b + 1, s1);
+            if (b + 2 >= nblk) break;
+            load_block(b + 4, s1);
+            park(b + 2, s2);
+        }
+        asm volatile("s_barrier" ::: "memory");                  // barrier nblk (the emitter's last block)
+        if (is_last) asm volatile("s_barrier" ::: "memory");     // hand-over of the final l
+        return;
+    }
+
+    if (wave == 0) {
+        // ------------------------------------ interval chain ------------------------------------
+        uint32_t l32 = 0, nu32 = 0;                              // l = 0, u = 2^22 - 1
+        if (!fresh) { l32 = cs[g].l << 10; nu32 = (~cs[g].u & MASK_M) << 10; }
+        for (uint64_t b = 0; b < nblk; ++b) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // words of block b-1 are parked
+            const uint32_t slot = (uint32_t)(b & 1);
+            Record r[CR_B];                                      // all 16 LDS reads up front: their latency overlaps the chain
+#pragma unroll
+            for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane];
+#pragma unroll
+            for (int jx = 0; jx < CR_B; ++jx) {
+                const double rd = 4294967296.0 - (double)(l32 + nu32);       // (u - l + 1) * 1024
+                const uint32_t ql = (uint32_t)__builtin_fma(rd, r[jx].x, QUOT_LO);
+                const uint32_t qc = (uint32_t)__builtin_fma(rd, r[jx].y, QUOT_HI);
+                l32 += ql << 10;
+                nu32 += qc << 10;
+                const uint32_t k = (uint32_t)__builtin_clz(~(l32 ^ nu32));   // E1/E2: leading bits shared by l and u (low 10 bits stop it at 22)
+                const uint32_t lk = l32;                                      // its top k bits go out
+                l32 <<= k;
+                nu32 <<= k;
+                const uint32_t j = (uint32_t)__builtin_clz(~(l32 & nu32) << 1);   // E3: positions below the MSB with l = 1, u = 0
+                l32 = (l32 << j) & 0x7FFFFFFFu;
+                nu32 = (nu32 << j) & 0x7FFFFFFFu;
+                words[slot][jx][lane] = lk | (k << 5) | j;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // barrier nblk
+        if (is_last) {
+            final_l[lane] = l32 >> 10;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if (live) {
+            cs[g].l = l32 >> 10; cs[g].u = ~(nu32 >> 10) & MASK_M;
+        }
+        return;
+    }
+
+    // ------------------------------------ emitter ------------------------------------
+    // A symbol puts out k + s3 bits: the first of the k shared bits, the s3 pending E3 bits (its complement), then the
+    // other k-1. As a number that is top + ((2^s3 - 1) << (k-1)) whatever the first bit is (top = the k bits), one
+    // v_bfm + one add. Symbols with at most 16 bits (all but ~2^-16 of them) take the straight path: two of them fit
+    // the 64-bit accumulator on top of < 32 pending bits, so the flush test runs once per pair. Stores go through a
+    // running 64-bit pointer; room is checked once per block (64 bytes at most on the straight path), which makes a
+    // stream that comes within 128 bytes of cap_per_shard count as overflowed.
+    uint8_t *const base = out + (uint64_t)(live ? g : 0) * cap;
+    uint8_t *const end = base + cap;
+    uint8_t *p = base;
+    uint32_t scale3 = 0, nbits = 0;
+    uint64_t acc = 0;
+    bool ovf = false;
+    if (!fresh) {
+        const CoderState s = cs[g];
+        scale3 = s.scale3; nbits = s.nbits; acc = s.acc; p = base + s.pos; ovf = s.overflow != 0;
+    }
+    auto flush = [&]() {                                         // top 32 pending bits -> 4 big-endian bytes
+        *reinterpret_cast<uint32_t *>(p) = __builtin_bswap32((uint32_t)(acc >> (nbits - 32)));
+        p += 4;
+        nbits -= 32;
+    };
+    for (uint64_t b = 0; b <= nblk; ++b) {
+        asm volatile("s_barrier" ::: "memory");
+        if (b == 0) continue;
+        const uint32_t slot = (uint32_t)((b - 1) & 1);
+        uint32_t w[CR_B];
+#pragma unroll
+        for (int jx = 0; jx < CR_B; ++jx) w[jx] = words[slot][jx][lane];
+        if (p + 128 > end) { ovf = true; p = base; }             // out of room: keep the stores inside the stream's area
+#pragma unroll
+        for (int jx = 0; jx < CR_B; ++jx) {
+            const uint32_t k = (w[jx] >> 5) & 31, j = w[jx] & 31;
+            const uint32_t top = (w[jx] >> 1) >> (31 - k);       // the k leading bits of l (0 when k = 0)
+            const uint32_t km1 = k ? k - 1 : 0u;
+            const uint32_t s3 = k ? scale3 : 0u;                 // the pending run goes out only when a bit is decided
+            const uint32_t nb = k + s3;
+            if (nb > 16) {                                       // rare: piecewise, with exact bounds
+                if (nbits >= 32) flush();
+                LaneCoder c;
+                c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
+                c.l = 0; c.u = 0; c.scale3 = 0;
+                const uint32_t bit = top >> km1;
+                lc_put(c, bit, 1);
+                lc_run(c, !bit, s3);
+                if (km1) lc_put(c, top & ((1u << km1) - 1), km1);
+                acc = c.acc; nbits = c.nbits; ovf = c.overflow;
+                p = base + c.pos;
+                if (p + 128 > end) { ovf = true; p = base; }
+            } else {
+                acc = (acc << nb) | (uint64_t)(top + (((1u << s3) - 1) << km1));
+                nbits += nb;
+            }
+            scale3 = scale3 - s3 + j;
+            if ((jx & 1) && nbits >= 32) flush();
+        }
+    }
+    if (is_last) {
+        asm volatile("s_barrier" ::: "memory");
+        if (!live) return;
+        LaneCoder c;
+        c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
+        c.scale3 = scale3; c.u = 0;
+        c.l = final_l[lane];
+        sizes[g] = lc_finish(c);
+        if (c.overflow) atomicOr(status, 2);
+    } else if (live) {
+        cs[g].scale3 = scale3; cs[g].nbits = nbits; cs[g].acc = acc; cs[g].pos = (uint64_t)(p - base); cs[g].overflow = ovf ? 1u : 0u;
+    }
+}
+
 // every shard starts from the same initial model
 __global__ __launch_bounds__(256) void k_arena_fill(const uint32_t *__restrict__ tmpl, uint32_t words, uint32_t shards,
                                                     uint32_t *__restrict__ arena) {
@@ -663,6 +987,89 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
 done:
 #undef TRY
     (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
+    free(h_arena); free(h_off); free(h_first);
+    return rc;
+}
+
+extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
+                                     uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                                     uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,
+                                     void *stream) {
+    if (!d_qi || !d_st || !n || !columns || !clusters || !shards || !d_out || !h_sizes || ld < n || (ld & 3))
+        return qvz_set_error(QVZ_E_ARG, "bad plane-coder arguments");
+    if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
+    if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t Cx = columns + (clusters > 1 ? 1u : 0u);
+    uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
+    if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
+        return qvz_set_error(QVZ_E_NOMEM, "model build failed");
+    uint64_t *h_first = (uint64_t *)malloc((shards + 1) * sizeof(uint64_t));
+    if (!h_first) { free(h_arena); free(h_off); return qvz_set_error(QVZ_E_NOMEM, "host alloc"); }
+    qvz_shard_bounds(n, shards, h_first);
+    uint64_t longest = 0;
+    for (uint32_t g = 0; g < shards; ++g) if (h_first[g + 1] - h_first[g] > longest) longest = h_first[g + 1] - h_first[g];
+    longest = (longest + 3) & ~(uint64_t)3;
+
+    uint32_t *d_tmpl = nullptr, *d_off = nullptr, *d_arena = nullptr;
+    uint64_t *d_first = nullptr, *d_sizes = nullptr;
+    int32_t *d_status = nullptr;
+    CoderState *d_cs = nullptr;
+    void *own_work = nullptr;
+    int rc = QVZ_OK;
+    int32_t status = 0;
+    const size_t offn = (size_t)clusters * columns * 2 * A;
+    const uint64_t per_read = (uint64_t)shards * Cx * sizeof(Record);  // record bytes for one read of every stream
+    uint64_t seg_reads = 0, seg_lo = 0;
+#define TRY(expr)                                                                                                    \
+    do {                                                                                                             \
+        hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+    if (!d_work) {                                               // no workspace given: up to 4 GiB of our own
+        work_bytes = per_read * longest;
+        if (work_bytes > (4ull << 30)) work_bytes = 4ull << 30;
+        if (work_bytes < per_read * 4) work_bytes = per_read * 4;
+        TRY(hipMalloc(&own_work, work_bytes));
+        d_work = own_work;
+    }
+    seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
+    if (seg_reads > longest) seg_reads = longest;
+    if (seg_reads < 4 || seg_reads > 0xFFFFFFFCull) { rc = qvz_set_error(QVZ_E_ARG, "workspace of %llu bytes holds fewer than 4 reads of %u streams", (unsigned long long)work_bytes, shards); goto done; }
+    TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
+    TRY(hipMalloc(&d_off, offn * 4));
+    TRY(hipMalloc(&d_arena, ((size_t)words * shards + 8) * 4));   // + slack: a header read covers 32 bytes
+    TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
+    TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
+    TRY(hipMalloc(&d_status, sizeof(int32_t)));
+    TRY(hipMalloc(&d_cs, shards * sizeof(CoderState)));
+    TRY(hipMemcpyAsync(d_tmpl, h_arena, (size_t)words * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
+    for (seg_lo = 0; seg_lo < longest; seg_lo += seg_reads) {
+        const uint32_t mblocks = (uint32_t)(((uint64_t)shards * Cx + 255) / 256);
+        const int is_first = seg_lo == 0, is_last = seg_lo + seg_reads >= longest;
+        if (clusters > 1)
+            hipLaunchKernelGGL(k_model_columns<true>, dim3(mblocks), dim3(256), 0, st, d_qi, d_st, ld, d_labels, columns, clusters,
+                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, (Record *)d_work, d_status);
+        else
+            hipLaunchKernelGGL(k_model_columns<false>, dim3(mblocks), dim3(256), 0, st, d_qi, d_st, ld, d_labels, columns, clusters,
+                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, (Record *)d_work, d_status);
+        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(192), 0, st, (const Record *)d_work, Cx, d_first, shards,
+                           seg_lo, (uint32_t)seg_reads, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
+    }
+    TRY(hipGetLastError());
+    TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+    if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder input addresses a quantizer without a model table (dead context or bad state)");
+    else if (status & 2) rc = qvz_set_error(QVZ_E_NOMEM, "a shard's stream exceeded cap_per_shard=%llu bytes", (unsigned long long)cap_per_shard);
+done:
+#undef TRY
+    (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
+    (void)hipFree(d_cs); (void)hipFree(own_work);
     free(h_arena); free(h_off); free(h_first);
     return rc;
 }

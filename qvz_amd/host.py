@@ -105,6 +105,43 @@ def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_pe
     return sizes, streams, out
 
 
+def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True,
+                      work_bytes=None):
+    """GPU sharded coder fed from the quantizer's planes (qvz_hip_encode_planes): the model runs with a lane per
+    (stream, column), the interval arithmetic with a lane per stream. qi/st: (columns, ld) uint8 device tensors.
+    work_bytes: size of the record workspace (default: everything at once, capped at 16 GiB).
+    Returns (sizes, streams|None, out_tensor)."""
+    import torch
+    k = len(codebook_handles)
+    arr = (C.c_void_p * k)(*codebook_handles)
+    ld = qi.shape[1]
+    if cap_per_shard is None:
+        per = (n + shards - 1) // shards + 4
+        cap_per_shard = max(256, (per * columns) // 2 + 64)     # 4 bits/symbol: > 3x what real codebooks need
+    cap_per_shard = (cap_per_shard + 3) & ~3
+    per_read = 16 * shards * (columns + (1 if k > 1 else 0))
+    longest = ((n + shards - 1) // shards + 7) & ~3
+    if work_bytes is None:
+        work_bytes = min(per_read * longest, 16 << 30)
+    work_bytes = max(work_bytes, per_read * 4)
+    work = torch.empty(work_bytes, dtype=torch.uint8, device=qi.device)
+    out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=qi.device)
+    sizes = (C.c_uint64 * shards)()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib().qvz_hip_encode_planes(C.c_void_p(qi.data_ptr()), C.c_void_p(st.data_ptr()), ld,
+                                     C.c_void_p(labels.data_ptr()) if labels is not None else None, n, columns, k, arr, shards,
+                                     C.c_void_p(out.data_ptr()), cap_per_shard, sizes, C.c_void_p(work.data_ptr()), work_bytes,
+                                     stream)
+    if rc:
+        raise QvzHipError(f"qvz_hip_encode_planes failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
+    sizes = [int(x) for x in sizes]
+    streams = None
+    if want_streams:
+        host_out = out.view(shards, cap_per_shard).cpu().numpy()
+        streams = [host_out[g, : sizes[g]].tobytes() for g in range(shards)]
+    return sizes, streams, out
+
+
 def shard_file_image(columns, shard_reads, codebook_handles, well_state_at_shard, stream):
     """Reference-format .q image of one shard (decodable by the unmodified reference decoder)."""
     k = len(codebook_handles)

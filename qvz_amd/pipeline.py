@@ -85,11 +85,12 @@ class _Span:
 
 def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MODE_RATIO, ratio=0.5, dist="M",
                 threshold=4.0, well_state=None, shards=1, threads=1, group=None, timer=None, keep=False, device_index=0,
-                coder="host"):
+                coder="host", work_bytes=None):
     """Runs k-means -> PMF -> codebooks -> WELL -> quantize -> feed -> sharded arithmetic coding for the reads
     [first_read, first_read+n) held in `sym` (this rank's shard of a file with n_total reads).
-    coder: "host" = `threads` host threads (qvz_encode_shards_device), "gpu" = one GPU lane per shard
-    (qvz_hip_encode_shards); both produce byte-identical streams.
+    coder: "host" = `threads` host threads over the packed feed (qvz_encode_shards_device); "gpu" = the column-parallel
+    model + lane-per-stream coder fed from the quantizer's planes (qvz_hip_encode_planes); "gpu-feed" = the older
+    lane-per-stream kernel over the packed feed (qvz_hip_encode_shards). All produce byte-identical streams.
 
     means0: (clusters, c) uint8 device tensor of the initial centroids (symbols). first_read must be a multiple of 4.
     Returns a dict with stream sizes, distortion, codebooks, phase wall times; with keep=True also the device outputs.
@@ -161,8 +162,10 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     with timer.span("quantize"):
         out = K.quantize(sym, n, ct, qs, draws, ddist, labels=labels if k > 1 else None, k=k)
     del draws
-    with timer.span("pack_feed"):
-        feed = K.pack_feed(out["qi"], out["st"], n)
+    feed = None
+    if coder != "gpu" or keep:
+        with timer.span("pack_feed"):
+            feed = K.pack_feed(out["qi"], out["st"], n)
     if int(out["status"].item()):
         raise RuntimeError("quantizer met a context the codebook does not define")
     torch.cuda.synchronize()
@@ -171,6 +174,12 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     # ---- arithmetic coding: `shards` independent reference-format streams on `threads` host threads ----
     t4 = time.perf_counter()
     if coder == "gpu":
+        with timer.span("arith_shards"):
+            sizes, streams, coded = host.encode_planes_gpu(out["qi"], out["st"], labels if k > 1 else None, n, c,
+                                                           [cb.handle for cb in cbs], shards, want_streams=keep,
+                                                           work_bytes=work_bytes)
+        stream_sizes = sizes
+    elif coder == "gpu-feed":
         with timer.span("arith_shards"):
             sizes, streams, coded = host.encode_shards_gpu(feed, labels if k > 1 else None, n, c, [cb.handle for cb in cbs],
                                                            shards, want_streams=keep)
@@ -189,5 +198,5 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     res = dict(stream_bytes=stream_sizes, total_stream_bytes=sum(stream_sizes), distortion=distortion,
                kmeans_iterations=iters, deferred=deferred, wall=wall, codebooks=cbs)
     if keep:
-        res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, err=out["err"], feed=feed)
+        res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, err=out["err"], feed=feed, qi=out["qi"], st=out["st"])
     return res

@@ -74,6 +74,12 @@ def test_gpu_coder_streams_equal_host_coder_streams(name, shards):
     assert a["stream_bytes"] == b["stream_bytes"]
     for g in range(shards):
         assert a["streams"][g] == b["streams"][g], f"shard {g} differs between host and GPU coder"
+    # the record workspace squeezed to 8 reads per stream: many segments, coder state carried between launches
+    small = 16 * shards * (c + (1 if opts["k"] > 1 else 0)) * 8
+    d = P.encode_pass(sym, n, 0, n, means0, coder="gpu", work_bytes=small, **kw)
+    assert d["streams"] == a["streams"], "segmented record workspace changed a stream"
+    e = P.encode_pass(sym, n, 0, n, means0, coder="gpu-feed", **kw)
+    assert e["streams"] == a["streams"], "feed-based GPU coder differs from the host coder"
     if shards == 1:
         assert b["total_stream_bytes"] == G.CASES[name]["size"]
         assert b["streams"][0] == G.gz(name + ".q.gz")[-G.CASES[name]["size"]:]
@@ -87,10 +93,27 @@ def test_gpu_coder_reports_overflow_and_bad_feed():
     handles = [cb.handle for cb in r["codebooks"]]
     with pytest.raises(Exception, match="cap_per_shard"):
         host.encode_shards_gpu(r["feed"], None, n, c, handles, 2, cap_per_shard=64)
+    with pytest.raises(Exception, match="cap_per_shard"):
+        host.encode_planes_gpu(r["qi"], r["st"], None, n, c, handles, 2, cap_per_shard=64)
     feed = r["feed"].clone()
     feed[10, 3] = 143          # quantizer index with no model table
     with pytest.raises(Exception, match="model table"):
         host.encode_shards_gpu(feed, None, n, c, handles, 2)
+    qi = r["qi"].clone()
+    qi[3, 10] = 143
+    with pytest.raises(Exception, match="model table"):
+        host.encode_planes_gpu(qi, r["st"], None, n, c, handles, 2)
+    with pytest.raises(Exception, match="fewer than 4 reads"):
+        lib_small = torch.empty(64, dtype=torch.uint8, device="cuda")
+        from qvz_amd._lib import lib
+        import ctypes as C
+        arr = (C.c_void_p * 1)(*handles)
+        sizes = (C.c_uint64 * 2)()
+        out = torch.empty(2 * 4096, dtype=torch.uint8, device="cuda")
+        rc = lib().qvz_hip_encode_planes(C.c_void_p(r["qi"].data_ptr()), C.c_void_p(r["st"].data_ptr()), r["qi"].shape[1], None, n, c,
+                                         1, arr, 2, C.c_void_p(out.data_ptr()), 4096, sizes, C.c_void_p(lib_small.data_ptr()), 64, None)
+        if rc:
+            raise RuntimeError(lib().qvz_hip_last_error().decode())
 
 
 def test_read_sharded_ranks_equal_single_pass():
