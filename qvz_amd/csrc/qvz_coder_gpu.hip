@@ -14,6 +14,8 @@
 //   E1/E2 and E3 loops: one count-leading-zeros batch each.
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -626,9 +628,16 @@ struct CoderState {
 #define QUOT_LO 5.9604644775390625e-08    /* 2^-24 */
 #define QUOT_HI 0.99999994039535522461    /* 1 - 2^-24 */
 typedef double2 Record;
+// The two quotients need not be correctly rounded, only within 2^-47 of cum / n (see above: the budget is 2^-24 over
+// R <= 2^22): 1/n from v_rcp_f64 plus two Newton steps (relative error ~2^-52) times the numerator is far inside that,
+// and costs a dozen instructions instead of two IEEE divisions.
 __device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint32_t fx) {
     const double nd = (double)n;
-    return make_double2((double)cum_lo / nd * 0x1p-10, (double)(n - cum_lo - fx) / nd * 0x1p-10);
+    double rn = __builtin_amdgcn_rcp(nd);
+    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
+    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
+    rn *= 0x1p-10;
+    return make_double2((double)cum_lo * rn, (double)(n - cum_lo - fx) * rn);
 }
 
 template <bool HAVE_LABELS>
@@ -733,6 +742,166 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
         c.nbits -= take;
     }
     return total_bits / 8;
+}
+
+// ---- the model as prefix counts: one WAVE per (stream, column), one lane per read ---------------------------------
+// k_model_columns above still walks reads serially in every lane and keeps its tables in HBM/L2; measured, it is
+// bound by that traffic. But between two rescales a table is nothing but counts: after e earlier hits of which E
+// had the same state and L a smaller one,  n = n0 + 8e,  freq = c0_x + 8E,  cum_lo = cum0_x + 8L  (qv_stream.c:9-14).
+// So a wave takes 64 consecutive reads of its column at once: the counts before the chunk come from the column's
+// tables in LDS, the in-chunk ranks (e, E, L) from one ballot + mbcnt per distinct (table, state) pair present in
+// the chunk, and the tables are brought up to date with LDS atomics. A chunk in which some table would pass the
+// rescale threshold (n > 2^19, once per 65536 hits of a table) is replayed serially, symbol by symbol, with the
+// reference's halve-and-+1 rescale. Records leave through an LDS transposition so that the workgroup (W waves = W
+// adjacent columns of the same stream) writes W * 16 contiguous bytes per read of the stream's read-major record area.
+// Table state crosses segment boundaries through `save` (one slice per (stream, column)).
+#define RK_NONE 0xFFFFu
+template <bool HAVE_LABELS>
+__global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
+                                                      const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
+                                                      const uint64_t *__restrict__ first, const uint16_t *__restrict__ coff,
+                                                      const uint32_t *__restrict__ colbase, const uint32_t *__restrict__ tmpl,
+                                                      uint32_t *__restrict__ save, uint32_t total_words, uint32_t slice_cap,
+                                                      uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
+                                                      uint32_t log2w, Record *__restrict__ rec, int32_t *__restrict__ status) {
+    extern __shared__ uint4 rk_smem[];
+    const uint32_t W = 1u << log2w, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t Cx = C + (HAVE_LABELS ? 1u : 0u);
+    const uint32_t g = blockIdx.x, cg = blockIdx.y;
+    const uint32_t sx = cg * W + wave;                           // position in the read's record group: [cluster id,] column 0 ..
+    const uint64_t r0 = first[g] + seg_lo, rend = first[g + 1];
+    if (r0 >= rend) return;                                      // whole workgroup
+    const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
+    const uint32_t rb_stride = W + 1;                            // +1: conflict-free transposition
+    Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [2][64][W + 1]
+    const uint32_t cof_words = (K * 2 * A + 1) / 2;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(recbuf + 2 * 64 * rb_stride) + (size_t)wave * (slice_cap + cof_words);
+    uint16_t *cof = reinterpret_cast<uint16_t *>(tab + slice_cap);
+    const bool active = sx < Cx;
+    const bool cluster_wave = HAVE_LABELS && sx == 0;
+    const uint32_t s = HAVE_LABELS ? sx - 1 : sx;
+    uint32_t b0 = 0, sw = 0;
+    if (active) {
+        b0 = colbase[sx];
+        sw = colbase[sx + 1] - b0;
+        const uint32_t *src = is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0;
+        for (uint32_t i = lane; i < sw; i += 64) tab[i] = src[i];
+        if (!cluster_wave)
+            for (uint32_t i = lane; i < K * 2 * A; i += 64) cof[i] = coff[(uint64_t)sx * K * 2 * A + i];
+    }
+    __syncthreads();
+
+    bool bad = false;
+    uint32_t chunk = 0;
+    // the next chunk's bytes are requested before the current chunk is worked on
+    uint32_t q_nx = 0, x_nx = 0, lab_nx = 0;
+    auto fetch = [&](uint64_t rbn) {
+        const uint64_t r = rbn + lane;
+        q_nx = 0; x_nx = 0; lab_nx = 0;
+        if (active && r < r1) {
+            if (!cluster_wave) { q_nx = qi[(uint64_t)s * ld + r]; x_nx = st[(uint64_t)s * ld + r]; }
+            if (HAVE_LABELS) lab_nx = labels[r];
+        }
+    };
+    fetch(r0);
+    for (uint64_t rb = r0; rb < r1; rb += 64, ++chunk) {
+        Record outr = make_double2(0.0, 0.0);
+        const uint32_t q = q_nx, raw = lab_nx;
+        uint32_t x = x_nx;
+        fetch(rb + 64);
+        if (active) {
+            const uint64_t r = rb + lane;
+            const bool valid = r < r1;
+            uint32_t cl = 0;
+            if (HAVE_LABELS && valid) {
+                if (raw >= K) bad = true; else cl = raw;
+            }
+            uint32_t tb = RK_NONE;
+            if (valid) {
+                if (cluster_wave) { tb = 0; x = cl; }
+                else if (q < 2 * A) tb = cof[cl * 2 * A + q];
+            }
+            bool ok = valid && tb != RK_NONE;
+            uint32_t card = 0;
+            if (ok) { card = tab[tb + 1]; if (x >= card) ok = false; }
+            if (valid && !ok) bad = true;
+            const uint32_t key = ok ? ((tb << 8) | x) : 0xFFFFFFFFu;
+            // counts before this chunk; cum_lo from whichever end of the table is nearer (cum_lo = n - sum of c_y, y >= x)
+            uint32_t n_b = 0, c_x = 0, cum_b = 0;
+            if (ok) { n_b = tab[tb]; c_x = tab[tb + 2 + x]; }
+            {
+                const bool up = 2 * x < card;
+                uint32_t y = up ? 0u : x + 1, yend = up ? x : card, acc = 0;
+                if (!ok) yend = y;
+                while (__ballot(y < yend)) {
+                    if (y < yend) acc += tab[tb + 2 + y];
+                    ++y;
+                }
+                cum_b = up ? acc : n_b - c_x - acc;
+            }
+            // ranks inside the chunk: earlier lanes with the same table (e), same table and state (E), smaller state (L)
+            uint32_t e = 0, E = 0, L = 0, hits = 0;
+            unsigned long long todo = __ballot(ok);
+            while (todo) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+                const unsigned long long m = __ballot(key == kk);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+                if ((key >> 8) == (kk >> 8)) {
+                    e += below;
+                    hits += cnt;
+                    if (key == kk) E = below;
+                    else if ((key & 0xFF) > (kk & 0xFF)) L += below;
+                }
+                todo &= ~m;
+            }
+            uint32_t n = n_b + STEP * e, fx = c_x + STEP * E, cum_lo = cum_b + STEP * L;
+            if (!__ballot(ok && n_b + STEP * hits > RESCALE)) {
+                if (ok) {                                        // update_stats for the whole chunk (order-free sums)
+                    atomicAdd(&tab[tb + 2 + x], STEP);
+                    atomicAdd(&tab[tb], STEP);
+                }
+            } else {
+                // a table rescales inside this chunk: replay the chunk serially (qv_stream.c:9-25), every lane doing the
+                // same uniform work on the LDS tables, lane i keeping symbol i's values
+                unsigned long long rest = __ballot(ok);
+                while (rest) {
+                    const int i = __builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, i);
+                    const uint32_t t = kk >> 8, xx = kk & 0xFF;
+                    const uint32_t nn0 = tab[t], card = tab[t + 1];
+                    uint32_t cum = 0;
+                    for (uint32_t y = 0; y < xx; ++y) cum += tab[t + 2 + y];
+                    const uint32_t f = tab[t + 2 + xx];
+                    if (lane == (uint32_t)i) { n = nn0; cum_lo = cum; fx = f; }
+                    uint32_t nn = nn0 + STEP;
+                    if (lane == 0) tab[t + 2 + xx] = f + STEP;
+                    if (nn > RESCALE) {
+                        nn = 0;
+                        for (uint32_t y = 0; y < card; ++y) {
+                            const uint32_t v = tab[t + 2 + y];
+                            if (v) { const uint32_t hv = (v >> 1) + 1; if (lane == 0) tab[t + 2 + y] = hv; nn += hv; }
+                        }
+                    }
+                    if (lane == 0) tab[t] = nn;
+                }
+            }
+            if (ok) outr = make_record(n, cum_lo, fx);
+        }
+        Record *buf = recbuf + (size_t)(chunk & 1) * 64 * rb_stride;
+        buf[lane * rb_stride + wave] = outr;
+        __syncthreads();
+        {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
+            const uint32_t rd = threadIdx.x >> log2w, cw = threadIdx.x & (W - 1);
+            if (rb + rd < r1 && cg * W + cw < Cx)
+                rec[((uint64_t)g * seg_reads + (rb - r0) + rd) * Cx + cg * W + cw] = buf[rd * rb_stride + cw];
+        }
+    }
+    if (active && !is_last)
+        for (uint32_t i = lane; i < sw; i += 64) save[(uint64_t)g * total_words + b0 + i] = tab[i];
+    if (bad) atomicOr(status, 1);
 }
 
 // Workgroup = three waves serving the same 64 streams, one lane per stream in each:
@@ -1021,6 +1190,51 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     const size_t offn = (size_t)clusters * columns * 2 * A;
     const uint64_t per_read = (uint64_t)shards * Cx * sizeof(Record);  // record bytes for one read of every stream
     uint64_t seg_reads = 0, seg_lo = 0;
+
+    // Column slices for k_model_ranks: the tables of record position sx (all clusters) packed back to back, with
+    // coff[sx][cluster][quantizer] = word offset inside the slice. W = columns per workgroup, as many as LDS holds.
+    std::vector<uint32_t> h_slices, h_colbase(Cx + 1, 0);
+    std::vector<uint16_t> h_coff((size_t)Cx * clusters * 2 * A, (uint16_t)RK_NONE);
+    uint32_t slice_cap = 0, rk_waves = 0;
+    size_t rk_lds = 0;
+    uint32_t *d_slices = nullptr, *d_colbase = nullptr, *d_save = nullptr;
+    uint16_t *d_coff = nullptr;
+    {
+        bool fits = true;
+        for (uint32_t sx = 0; sx < Cx; ++sx) {
+            h_colbase[sx] = (uint32_t)h_slices.size();
+            if (clusters > 1 && sx == 0) {                       // cluster_stats: n = card = k, counts 1
+                h_slices.push_back(clusters); h_slices.push_back(clusters);
+                for (uint32_t c = 0; c < clusters; ++c) h_slices.push_back(1);
+            } else {
+                const uint32_t s = clusters > 1 ? sx - 1 : sx;
+                for (uint32_t c = 0; c < clusters; ++c)
+                    for (uint32_t j = 0; j < 2 * A; ++j) {
+                        const uint32_t o = h_off[((size_t)c * columns + s) * 2 * A + j];
+                        if (o == NO_TABLE) continue;
+                        const size_t rel = h_slices.size() - h_colbase[sx];
+                        if (rel >= RK_NONE) { fits = false; continue; }
+                        h_coff[((size_t)sx * clusters + c) * 2 * A + j] = (uint16_t)rel;
+                        for (uint32_t i = 0; i < 2 + h_arena[o + 1]; ++i) h_slices.push_back(h_arena[o + i]);
+                    }
+            }
+            const uint32_t len = (uint32_t)h_slices.size() - h_colbase[sx];
+            if (len > slice_cap) slice_cap = len;
+        }
+        h_colbase[Cx] = (uint32_t)h_slices.size();
+        slice_cap = (slice_cap + 3) & ~3u;
+        const char *mk = getenv("QVZ_MODEL_KERNEL");             // development knob: "columns" forces the lane-per-column kernel
+        if (fits && !(mk && strcmp(mk, "columns") == 0)) {
+            const uint32_t cof_words = (clusters * 2 * A + 1) / 2;
+            const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: columns (waves) per workgroup, a power of two
+            uint32_t wmax = we ? (uint32_t)atoi(we) : 16;
+            if (wmax < 1 || wmax > 16 || (wmax & (wmax - 1))) wmax = 16;
+            for (uint32_t w = wmax; w >= 1; w >>= 1) {
+                const size_t need = (size_t)2 * 64 * (w + 1) * sizeof(Record) + (size_t)w * (slice_cap + cof_words) * 4;
+                if (need <= 160 * 1024) { rk_waves = w; rk_lds = need; break; }
+            }
+        }
+    }
 #define TRY(expr)                                                                                                    \
     do {                                                                                                             \
         hipError_t e_ = (expr);                                                                                      \
@@ -1036,22 +1250,44 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
     if (seg_reads > longest) seg_reads = longest;
     if (seg_reads < 4 || seg_reads > 0xFFFFFFFCull) { rc = qvz_set_error(QVZ_E_ARG, "workspace of %llu bytes holds fewer than 4 reads of %u streams", (unsigned long long)work_bytes, shards); goto done; }
-    TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
-    TRY(hipMalloc(&d_off, offn * 4));
-    TRY(hipMalloc(&d_arena, ((size_t)words * shards + 8) * 4));   // + slack: a header read covers 32 bytes
     TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
     TRY(hipMalloc(&d_status, sizeof(int32_t)));
     TRY(hipMalloc(&d_cs, shards * sizeof(CoderState)));
-    TRY(hipMemcpyAsync(d_tmpl, h_arena, (size_t)words * 4, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
+    if (rk_waves) {
+        TRY(hipMalloc(&d_slices, h_slices.size() * 4));
+        TRY(hipMalloc(&d_colbase, h_colbase.size() * 4));
+        TRY(hipMalloc(&d_coff, h_coff.size() * 2));
+        if (seg_reads < longest) TRY(hipMalloc(&d_save, h_slices.size() * 4 * (size_t)shards));   // table state between segments
+        TRY(hipMemcpyAsync(d_slices, h_slices.data(), h_slices.size() * 4, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(d_colbase, h_colbase.data(), h_colbase.size() * 4, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(d_coff, h_coff.data(), h_coff.size() * 2, hipMemcpyHostToDevice, st));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+    } else {                                                     // lane-per-column kernel with per-stream arenas in HBM
+        TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
+        TRY(hipMalloc(&d_off, offn * 4));
+        TRY(hipMalloc(&d_arena, ((size_t)words * shards + 8) * 4));   // + slack: a header read covers 32 bytes
+        TRY(hipMemcpyAsync(d_tmpl, h_arena, (size_t)words * 4, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
+    }
     for (seg_lo = 0; seg_lo < longest; seg_lo += seg_reads) {
         const uint32_t mblocks = (uint32_t)(((uint64_t)shards * Cx + 255) / 256);
         const int is_first = seg_lo == 0, is_last = seg_lo + seg_reads >= longest;
-        if (clusters > 1)
+        if (rk_waves) {
+            const dim3 grid(shards, (Cx + rk_waves - 1) / rk_waves), block(64 * rk_waves);
+            if (clusters > 1)
+                hipLaunchKernelGGL(k_model_ranks<true>, grid, block, rk_lds, st, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
+                                   d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
+                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), (Record *)d_work, d_status);
+            else
+                hipLaunchKernelGGL(k_model_ranks<false>, grid, block, rk_lds, st, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
+                                   d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
+                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), (Record *)d_work, d_status);
+        } else if (clusters > 1)
             hipLaunchKernelGGL(k_model_columns<true>, dim3(mblocks), dim3(256), 0, st, d_qi, d_st, ld, d_labels, columns, clusters,
                                d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, (Record *)d_work, d_status);
         else
@@ -1069,7 +1305,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
 done:
 #undef TRY
     (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
-    (void)hipFree(d_cs); (void)hipFree(own_work);
+    (void)hipFree(d_cs); (void)hipFree(own_work); (void)hipFree(d_slices); (void)hipFree(d_colbase); (void)hipFree(d_coff); (void)hipFree(d_save);
     free(h_arena); free(h_off); free(h_first);
     return rc;
 }

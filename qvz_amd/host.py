@@ -88,7 +88,7 @@ def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_pe
     arr = (C.c_void_p * k)(*codebook_handles)
     if cap_per_shard is None:
         per = (n + shards - 1) // shards + 4
-        cap_per_shard = max(256, (per * columns) // 2 + 64)     # 4 bits/symbol: > 3x what real codebooks need
+        cap_per_shard = (per * columns * 3) // 4 + 512          # 6 bits/symbol
     cap_per_shard = (cap_per_shard + 3) & ~3
     out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=feed.device)
     sizes = (C.c_uint64 * shards)()
@@ -117,7 +117,7 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     ld = qi.shape[1]
     if cap_per_shard is None:
         per = (n + shards - 1) // shards + 4
-        cap_per_shard = max(256, (per * columns) // 2 + 64)     # 4 bits/symbol: > 3x what real codebooks need
+        cap_per_shard = (per * columns * 3) // 4 + 512          # 6 bits/symbol + the 128-byte margin the emitter wants
     cap_per_shard = (cap_per_shard + 3) & ~3
     per_read = 16 * shards * (columns + (1 if k > 1 else 0))
     longest = ((n + shards - 1) // shards + 7) & ~3

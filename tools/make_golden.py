@@ -80,6 +80,9 @@ CASES = [
     dict(name="f00_zero_rate", inp=dict(kind="qgen1", seed=2, n=500, c=25), flags="-c 1 -d M -f 0.0", store=True),
     dict(name="r35_high_rate", inp=dict(kind="qgen1", seed=2, n=800, c=25), flags="-c 1 -d M -r 3.5", store=True),
     dict(name="wide_c151", inp=dict(kind="qgen1", seed=4, n=700, c=151), flags="-c 1 -d M -f 0.4", store=False),
+    # long enough for update_stats to rescale (a table passes n > 2^19 after 65536 hits, qv_stream.c:15-24)
+    dict(name="rescale_140k_c4", inp=dict(kind="qgen1", seed=12, n=140000, c=4), flags="-c 1 -d M -f 0.5", store=False),
+    dict(name="rescale_c2_100k_c3", inp=dict(kind="qgen1", seed=13, n=100000, c=3), flags="-c 2 -d M -r 0.8", store=False),
 ]
 
 
