@@ -749,8 +749,11 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 // bound by that traffic. But between two rescales a table is nothing but counts: after e earlier hits of which E
 // had the same state and L a smaller one,  n = n0 + 8e,  freq = c0_x + 8E,  cum_lo = cum0_x + 8L  (qv_stream.c:9-14).
 // So a wave takes 64 consecutive reads of its column at once: the counts before the chunk come from the column's
-// tables in LDS, the in-chunk ranks (e, E, L) from one ballot + mbcnt per distinct (table, state) pair present in
-// the chunk, and the tables are brought up to date with LDS atomics. A chunk in which some table would pass the
+// tables in LDS, the in-chunk ranks (e, E, L) from lane bit-masks: every lane ORs its bit into a 64-bit mask beside
+// its table head and beside its count (ds_or_b64: commutative, so no ordering is assumed), and "earlier lanes with
+// ..." is v_mbcnt of such a mask. (A first version looped over the distinct (table, state) pairs of the chunk with
+// ballots: ~35 pairs per chunk on the 100M x 150 workload, 675 VALU instructions per chunk; this one needs ~100.)
+// The tables are then brought up to date with LDS atomic adds. A chunk in which some table would pass the
 // rescale threshold (n > 2^19, once per 65536 hits of a table) is replayed serially, symbol by symbol, with the
 // reference's halve-and-+1 rescale. Records leave through an LDS transposition so that the workgroup (W waves = W
 // adjacent columns of the same stream) writes W * 16 contiguous bytes per read of the stream's read-major record area.
@@ -775,7 +778,10 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     const uint32_t rb_stride = W + 1;                            // +1: conflict-free transposition
     Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [2][64][W + 1]
     const uint32_t cof_words = (K * 2 * A + 1) / 2;
-    uint32_t *tab = reinterpret_cast<uint32_t *>(recbuf + 2 * 64 * rb_stride) + (size_t)wave * (slice_cap + cof_words);
+    // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, table offsets of the column [K][144] u16
+    unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 2 * 64 * rb_stride) +
+                              (size_t)wave * ((3 * slice_cap + cof_words) / 2);
+    uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
     uint16_t *cof = reinterpret_cast<uint16_t *>(tab + slice_cap);
     const bool active = sx < Cx;
     const bool cluster_wave = HAVE_LABELS && sx == 0;
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         b0 = colbase[sx];
         sw = colbase[sx + 1] - b0;
         const uint32_t *src = is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0;
-        for (uint32_t i = lane; i < sw; i += 64) tab[i] = src[i];
+        for (uint32_t i = lane; i < sw; i += 64) { tab[i] = src[i]; msk[i] = 0ull; }
         if (!cluster_wave)
             for (uint32_t i = lane; i < K * 2 * A; i += 64) cof[i] = coff[(uint64_t)sx * K * 2 * A + i];
     }
@@ -825,37 +831,40 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             uint32_t card = 0;
             if (ok) { card = tab[tb + 1]; if (x >= card) ok = false; }
             if (valid && !ok) bad = true;
-            const uint32_t key = ok ? ((tb << 8) | x) : 0xFFFFFFFFu;
-            // counts before this chunk; cum_lo from whichever end of the table is nearer (cum_lo = n - sum of c_y, y >= x)
-            uint32_t n_b = 0, c_x = 0, cum_b = 0;
-            if (ok) { n_b = tab[tb]; c_x = tab[tb + 2 + x]; }
+            // every lane marks its table and its (table, state) entry
+            const unsigned long long bit = 1ull << lane;
+            if (ok) {
+                __hip_atomic_fetch_or(&msk[tb], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&msk[tb + 2 + x], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // counts before this chunk, and ranks inside it: earlier lanes with the same table (e), the same table and
+            // state (E), a smaller state (L). cum_lo and L come from whichever end of the table is nearer
+            // (sum over y < x directly, or n - c_x - sum over y > x).
+            uint32_t n_b = 0, c_x = 0, cum_b = 0, e = 0, E = 0, L = 0, hits = 0;
+            auto earlier = [](unsigned long long m, uint32_t add) -> uint32_t {     // add + popcount(m & lanes below me)
+                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, add));
+            };
+            if (ok) {
+                n_b = tab[tb];
+                c_x = tab[tb + 2 + x];
+                const unsigned long long mt = msk[tb];
+                e = earlier(mt, 0u);
+                hits = (uint32_t)__builtin_popcountll(mt);
+                E = earlier(msk[tb + 2 + x], 0u);
+            }
             {
                 const bool up = 2 * x < card;
-                uint32_t y = up ? 0u : x + 1, yend = up ? x : card, acc = 0;
+                uint32_t y = up ? 0u : x + 1, yend = up ? x : card, acc = 0, accm = 0;
                 if (!ok) yend = y;
                 while (__ballot(y < yend)) {
-                    if (y < yend) acc += tab[tb + 2 + y];
+                    if (y < yend) { acc += tab[tb + 2 + y]; accm = earlier(msk[tb + 2 + y], accm); }
                     ++y;
                 }
                 cum_b = up ? acc : n_b - c_x - acc;
+                L = up ? accm : e - E - accm;
             }
-            // ranks inside the chunk: earlier lanes with the same table (e), same table and state (E), smaller state (L)
-            uint32_t e = 0, E = 0, L = 0, hits = 0;
-            unsigned long long todo = __ballot(ok);
-            while (todo) {
-                const int leader = __builtin_ctzll(todo);
-                const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-                const unsigned long long m = __ballot(key == kk);
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
-                if ((key >> 8) == (kk >> 8)) {
-                    e += below;
-                    hits += cnt;
-                    if (key == kk) E = below;
-                    else if ((key & 0xFF) > (kk & 0xFF)) L += below;
-                }
-                todo &= ~m;
-            }
+            if (ok) { msk[tb] = 0ull; msk[tb + 2 + x] = 0ull; }  // leave the masks clean for the next chunk
+            const uint32_t key = ok ? ((tb << 8) | x) : 0xFFFFFFFFu;
             uint32_t n = n_b + STEP * e, fx = c_x + STEP * E, cum_lo = cum_b + STEP * L;
             if (!__ballot(ok && n_b + STEP * hits > RESCALE)) {
                 if (ok) {                                        // update_stats for the whole chunk (order-free sums)
@@ -1227,10 +1236,10 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         if (fits && !(mk && strcmp(mk, "columns") == 0)) {
             const uint32_t cof_words = (clusters * 2 * A + 1) / 2;
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: columns (waves) per workgroup, a power of two
-            uint32_t wmax = we ? (uint32_t)atoi(we) : 16;
-            if (wmax < 1 || wmax > 16 || (wmax & (wmax - 1))) wmax = 16;
+            uint32_t wmax = we ? (uint32_t)atoi(we) : 8;
+            if (wmax < 1 || wmax > 16 || (wmax & (wmax - 1))) wmax = 8;
             for (uint32_t w = wmax; w >= 1; w >>= 1) {
-                const size_t need = (size_t)2 * 64 * (w + 1) * sizeof(Record) + (size_t)w * (slice_cap + cof_words) * 4;
+                const size_t need = (size_t)2 * 64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words) * 4;
                 if (need <= 160 * 1024) { rk_waves = w; rk_lds = need; break; }
             }
         }
