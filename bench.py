@@ -49,9 +49,13 @@ ALG_BYTES_PER_SYMBOL = {
     "kmeans_accumulate": 1.0,    # + labels re-read per column when k > 1 (2 B/sym)
     "quantize": 5.0,             # symbol in, draw in, qv out, (qi, st) out
     "well_draws": 3.0,           # word stream written once and read once, draw matrix written once
-    "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out
-    "arith_shards": 2.0,         # 2-byte feed entry in (+ ~0.16 B/symbol of stream out); latency-bound integer chain
+    "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out (host / gpu-feed coders only)
+    "model_records": 18.0,       # qi + st in, one 16-byte record out
+    "code_records": 16.0,        # record in (+ ~0.17 B/symbol of stream out); bound by the serial interval chain per stream
+    "arith_shards": 2.0,         # gpu-feed coder: 2-byte feed entry in; latency-bound
 }
+# kernels whose time is a dependent-instruction chain per stream, not a bandwidth figure
+CHAIN_KERNELS = ("code_records", "arith_shards")
 
 
 def cpu_baseline(cfg, cores_note):
@@ -171,13 +175,17 @@ def main():
 
     if rank == 0:
         spans = timer.totals_ms()
+        if args.coder == "gpu":      # the planes coder times its two kernel families itself (HIP events inside the C call)
+            spans.pop("arith_shards", None)
+            spans["model_records"] = [r["wall"]["coder_model_kernels"] * 1e3 for r in results]
+            spans["code_records"] = [r["wall"]["coder_interval_kernels"] * 1e3 for r in results]
         per_launch = {name: float(np.mean(v)) for name, v in spans.items()}
         per_step = {name: float(np.sum(v)) / args.steps for name, v in spans.items()}
         # `roofline` is reported for the dominant HBM-bound kernel. The lane-per-stream coder usually takes the most
         # time of all, but it is a serial integer chain per stream (latency / instruction-issue bound, DESIGN.md
         # section 6): an HBM fraction says nothing about it, so it is listed separately as `longest_kernel`.
         longest = max(per_step, key=per_step.get)
-        streaming = {kname: v for kname, v in per_step.items() if kname != "arith_shards"}
+        streaming = {kname: v for kname, v in per_step.items() if kname not in CHAIN_KERNELS}
         dom = max(streaming, key=streaming.get)
         bps = ALG_BYTES_PER_SYMBOL[dom]
         extra = 0.0
@@ -200,7 +208,8 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic QGEN-1 (SURVEY.md Appendix D), generated on device",
             "config": {"workload": cfg["name"] + f" per GPU, reads sharded over {world} GPU(s)", "reads_per_gpu": n,
                        "columns": c, "clusters": k, "coder": f"{shards} independent reference-format streams per GPU "
-                       + (f"on {threads} host threads" if args.coder == "host" else "coded on the GPU, one lane per stream"),
+                       + (f"on {threads} host threads" if args.coder == "host" else
+                          "coded on the GPU (model: a wave per stream and column; interval chain: a lane per stream)"),
                        "parallelism": f"read-sharded x{world}"},
             "bits_per_symbol": round(stream_bytes * 8.0 / (n_total * c), 5),
             "distortion": results[-1]["distortion"], "kmeans_iterations": results[-1]["kmeans_iterations"],
@@ -211,10 +220,13 @@ def main():
                                       unit="GB/s", frac=round(pmf_ach / HBM_PEAK_GBPS, 4),
                                       ms_per_launch=round(per_launch["pmf_hist"], 4)),
             "longest_kernel": dict(kernel=longest, ms_per_step=round(per_step[longest], 3),
-                                   bound="hbm" if longest != "arith_shards" else
+                                   bound="hbm" if longest not in CHAIN_KERNELS else
                                    "latency: one serial integer interval chain per stream (not an HBM or MFMA kernel)",
                                    symbols_per_second=round(n * c / (per_step[longest] * 1e-3), 1),
-                                   streams=shards if longest == "arith_shards" else None),
+                                   streams=shards if longest in CHAIN_KERNELS else None),
+            "coder_chain": dict(kernel="code_records" if args.coder == "gpu" else "arith_shards", streams=shards,
+                                ns_per_symbol_per_stream=round(per_step.get("code_records", per_step.get("arith_shards", 0.0))
+                                                               * 1e6 * shards / (n * c), 2)) if args.coder != "host" else None,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")

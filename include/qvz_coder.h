@@ -77,16 +77,29 @@ int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint6
 
 /* The GPU sharded coder fed straight from the quantizer's output planes (d_qi[s*ld+i], d_st[s*ld+i], as written by
  * qvz_hip_quantize; no packed feed). Same streams, byte for byte, as qvz_hip_encode_shards / qvz_encode_shards_device.
- * The adaptive model of a column depends on that column's symbols only (qv_stream.c:9-25 updates one table, and a
- * table belongs to one column), so the model runs with one lane per (stream, column) and leaves a 16-byte record
- * (cum_lo / n, cum_hi / n as doubles) per symbol; one lane per stream then runs the serial interval arithmetic
- * (arith.c:24-97) over its records. Records pass through d_work (work_bytes, 16-byte aligned) in segments of as many
- * reads per stream as fit: 16 * shards * (columns + (clusters > 1)) bytes per read. d_work = NULL: a workspace of up to 4 GiB is
- * allocated for the call. */
+ *
+ * The adaptive model of a column depends on that column's symbols only (update_stats touches one table and a table
+ * belongs to one column, qv_stream.c:9-25), so the model does not have to run inside the serial chain:
+ *   model  one wave per (stream, column), one lane per read: the counts a symbol sees are the table's counts plus
+ *          8 x (earlier reads of the chunk with the same table / the same state / a smaller state), taken from lane
+ *          bit-masks in LDS; chunks in which a table passes the rescale threshold (n > 2^19) are replayed serially.
+ *          It leaves a 16-byte record per symbol: cum_lo / n and (n - cum_hi) / n as doubles (pre-scaled by 2^-10).
+ *   coder  one lane per stream walks its records: two fused multiply-adds give the new bounds exactly
+ *          (arith.c:47-48), then E1/E2/E3 renormalisation (arith.c:50-97) and the bit output, split over three
+ *          waves (record loader / interval chain / bit emitter) that hand blocks over through LDS.
+ * Records pass through d_work (work_bytes, 16-byte aligned) in segments of as many reads per stream as fit:
+ * 16 * shards * (columns + (clusters > 1)) bytes per read; d_work = NULL: a workspace of up to 4 GiB is allocated
+ * for the call. Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel
+ * with one lane per (stream, column) and the tables in HBM.
+ * d_labels must be readable up to n rounded up to a multiple of 4. The emitter checks its room once per 16 symbols:
+ * a stream that comes within 128 bytes of cap_per_shard is reported as overflowed (QVZ_E_NOMEM). */
 int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                           uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                           uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,
                           void *stream);
+/* GPU time of the last qvz_hip_encode_planes call, split into its model kernels and its coder kernels (HIP events on
+ * the call's stream, summed over the segments). Either pointer may be NULL. */
+void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);
 
 /* Initial adaptive model as a flat arena of tables [n][card][counts...] (cluster-id table at index 0) plus the
  * (cluster, column, quantizer) -> arena index map (0xFFFFFFFF = none). Shared by the host and GPU coders.

@@ -780,7 +780,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     const uint32_t cof_words = (K * 2 * A + 1) / 2;
     // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, table offsets of the column [K][144] u16
     unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 2 * 64 * rb_stride) +
-                              (size_t)wave * ((3 * slice_cap + cof_words) / 2);
+                              (size_t)wave * ((3 * slice_cap + cof_words + 192) / 2);
     uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
     uint16_t *cof = reinterpret_cast<uint16_t *>(tab + slice_cap);
     const bool active = sx < Cx;
@@ -799,38 +799,62 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
 
     bool bad = false;
     uint32_t chunk = 0;
-    // the next chunk's bytes are requested before the current chunk is worked on
+    // Input staging: a wave takes its column 256 reads at a time (one dword per lane and plane = 256 contiguous bytes)
+    // and requests the next 256 while it works through the current four chunks out of LDS, so the HBM latency of the
+    // planes (several chunk times) stays off the chunk loop.
+    uint8_t *stage = reinterpret_cast<uint8_t *>(cof + ((K * 2 * A + 1) & ~1u)) ;   // [3][256]: qi, st, labels of the current block
     uint32_t q_nx = 0, x_nx = 0, lab_nx = 0;
-    auto fetch = [&](uint64_t rbn) {
-        const uint64_t r = rbn + lane;
+    auto fetch = [&](uint64_t rbn) {                             // rbn is a multiple of 4, and so are r1 rounded up and ld
+        const uint64_t r = rbn + 4 * lane;
         q_nx = 0; x_nx = 0; lab_nx = 0;
         if (active && r < r1) {
-            if (!cluster_wave) { q_nx = qi[(uint64_t)s * ld + r]; x_nx = st[(uint64_t)s * ld + r]; }
-            if (HAVE_LABELS) lab_nx = labels[r];
+            if (!cluster_wave) {
+                q_nx = *reinterpret_cast<const uint32_t *>(qi + (uint64_t)s * ld + r);
+                x_nx = *reinterpret_cast<const uint32_t *>(st + (uint64_t)s * ld + r);
+            }
+            if (HAVE_LABELS) lab_nx = *reinterpret_cast<const uint32_t *>(labels + r);
         }
     };
+    // Table look-up of a chunk (stage -> table offset -> alphabet size): three dependent LDS round trips that do not
+    // depend on the counts, so they are issued one chunk ahead and overlap the barrier and the record drain.
+    uint32_t tb_nx = RK_NONE, x_lk = 0, card_nx = 0;
+    bool ok_nx = false;
+    auto lookup = [&](uint64_t rbn, uint32_t ch) {
+        tb_nx = RK_NONE; x_lk = 0; card_nx = 0; ok_nx = false;
+        const uint64_t r = rbn + lane;
+        if (!active || r >= r1) return;
+        const uint32_t in_blk = (ch & 3) * 64 + lane;
+        const uint32_t q = stage[in_blk];
+        uint32_t x = stage[256 + in_blk], cl = 0;
+        if (HAVE_LABELS) {
+            const uint32_t raw = stage[512 + in_blk];
+            if (raw >= K) bad = true; else cl = raw;
+        }
+        if (cluster_wave) { tb_nx = 0; x = cl; }
+        else if (q < 2 * A) tb_nx = cof[cl * 2 * A + q];
+        ok_nx = tb_nx != RK_NONE;
+        if (ok_nx) { card_nx = tab[tb_nx + 1]; if (x >= card_nx) ok_nx = false; }
+        if (!ok_nx) bad = true;
+        x_lk = x;
+    };
+    auto park = [&](uint64_t rbn) {                              // the requested dwords become the current block; request the next
+        reinterpret_cast<uint32_t *>(stage)[lane] = q_nx;
+        reinterpret_cast<uint32_t *>(stage)[64 + lane] = x_nx;
+        if (HAVE_LABELS) reinterpret_cast<uint32_t *>(stage)[128 + lane] = lab_nx;
+        fetch(rbn + 256);
+    };
     fetch(r0);
+    park(r0);
+    lookup(r0, 0);
     for (uint64_t rb = r0; rb < r1; rb += 64, ++chunk) {
         Record outr = make_double2(0.0, 0.0);
-        const uint32_t q = q_nx, raw = lab_nx;
-        uint32_t x = x_nx;
-        fetch(rb + 64);
+        const uint32_t tb = tb_nx, x = x_lk, card = card_nx;
+        const bool ok = ok_nx;
+        if (rb + 64 < r1) {
+            if (((chunk + 1) & 3) == 0) park(rb + 64);
+            lookup(rb + 64, chunk + 1);
+        }
         if (active) {
-            const uint64_t r = rb + lane;
-            const bool valid = r < r1;
-            uint32_t cl = 0;
-            if (HAVE_LABELS && valid) {
-                if (raw >= K) bad = true; else cl = raw;
-            }
-            uint32_t tb = RK_NONE;
-            if (valid) {
-                if (cluster_wave) { tb = 0; x = cl; }
-                else if (q < 2 * A) tb = cof[cl * 2 * A + q];
-            }
-            bool ok = valid && tb != RK_NONE;
-            uint32_t card = 0;
-            if (ok) { card = tab[tb + 1]; if (x >= card) ok = false; }
-            if (valid && !ok) bad = true;
             // every lane marks its table and its (table, state) entry
             const unsigned long long bit = 1ull << lane;
             if (ok) {
@@ -856,9 +880,16 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 const bool up = 2 * x < card;
                 uint32_t y = up ? 0u : x + 1, yend = up ? x : card, acc = 0, accm = 0;
                 if (!ok) yend = y;
-                while (__ballot(y < yend)) {
-                    if (y < yend) { acc += tab[tb + 2 + y]; accm = earlier(msk[tb + 2 + y], accm); }
-                    ++y;
+                while (__ballot(y < yend)) {                     // four entries per LDS round trip
+                    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+                    if (y < yend) { c0 = tab[tb + 2 + y]; m0 = msk[tb + 2 + y]; }
+                    if (y + 1 < yend) { c1 = tab[tb + 3 + y]; m1 = msk[tb + 3 + y]; }
+                    if (y + 2 < yend) { c2 = tab[tb + 4 + y]; m2 = msk[tb + 4 + y]; }
+                    if (y + 3 < yend) { c3 = tab[tb + 5 + y]; m3 = msk[tb + 5 + y]; }
+                    acc += c0 + c1 + c2 + c3;
+                    accm = earlier(m3, earlier(m2, earlier(m1, earlier(m0, accm))));
+                    y += 4;
                 }
                 cum_b = up ? acc : n_b - c_x - acc;
                 L = up ? accm : e - E - accm;
@@ -1169,6 +1200,12 @@ done:
     return rc;
 }
 
+static double g_planes_ms[2] = {0.0, 0.0};   // model kernels, coder kernels of the last qvz_hip_encode_planes call
+extern "C" void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms) {
+    if (model_ms) *model_ms = g_planes_ms[0];
+    if (coder_ms) *coder_ms = g_planes_ms[1];
+}
+
 extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                      uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                      uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,
@@ -1208,6 +1245,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     size_t rk_lds = 0;
     uint32_t *d_slices = nullptr, *d_colbase = nullptr, *d_save = nullptr;
     uint16_t *d_coff = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     {
         bool fits = true;
         for (uint32_t sx = 0; sx < Cx; ++sx) {
@@ -1239,7 +1277,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
             uint32_t wmax = we ? (uint32_t)atoi(we) : 8;
             if (wmax < 1 || wmax > 16 || (wmax & (wmax - 1))) wmax = 8;
             for (uint32_t w = wmax; w >= 1; w >>= 1) {
-                const size_t need = (size_t)2 * 64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words) * 4;
+                const size_t need = (size_t)2 * 64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words + 192) * 4;
                 if (need <= 160 * 1024) { rk_waves = w; rk_lds = need; break; }
             }
         }
@@ -1283,9 +1321,19 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
     }
+    for (int i = 0; i < 3; ++i) TRY(hipEventCreate(&ev[i]));
+    g_planes_ms[0] = g_planes_ms[1] = 0.0;
     for (seg_lo = 0; seg_lo < longest; seg_lo += seg_reads) {
         const uint32_t mblocks = (uint32_t)(((uint64_t)shards * Cx + 255) / 256);
         const int is_first = seg_lo == 0, is_last = seg_lo + seg_reads >= longest;
+        if (seg_lo) {                                            // the previous segment's kernel times (events are reused)
+            float a = 0.f, b = 0.f;
+            TRY(hipEventSynchronize(ev[2]));
+            TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+            TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+            g_planes_ms[0] += a; g_planes_ms[1] += b;
+        }
+        TRY(hipEventRecord(ev[0], st));
         if (rk_waves) {
             const dim3 grid(shards, (Cx + rk_waves - 1) / rk_waves), block(64 * rk_waves);
             if (clusters > 1)
@@ -1302,18 +1350,27 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         else
             hipLaunchKernelGGL(k_model_columns<false>, dim3(mblocks), dim3(256), 0, st, d_qi, d_st, ld, d_labels, columns, clusters,
                                d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, (Record *)d_work, d_status);
+        TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(192), 0, st, (const Record *)d_work, Cx, d_first, shards,
                            seg_lo, (uint32_t)seg_reads, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
+        TRY(hipEventRecord(ev[2], st));
     }
     TRY(hipGetLastError());
     TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
+    {
+        float a = 0.f, b = 0.f;
+        TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+        g_planes_ms[0] += a; g_planes_ms[1] += b;
+    }
     if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder input addresses a quantizer without a model table (dead context or bad state)");
     else if (status & 2) rc = qvz_set_error(QVZ_E_NOMEM, "a shard's stream exceeded cap_per_shard=%llu bytes", (unsigned long long)cap_per_shard);
 done:
 #undef TRY
     (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
+    for (int i = 0; i < 3; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
     (void)hipFree(d_cs); (void)hipFree(own_work); (void)hipFree(d_slices); (void)hipFree(d_colbase); (void)hipFree(d_coff); (void)hipFree(d_save);
     free(h_arena); free(h_off); free(h_first);
     return rc;

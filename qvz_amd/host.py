@@ -134,6 +134,9 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
                                      stream)
     if rc:
         raise QvzHipError(f"qvz_hip_encode_planes failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
+    a, b = C.c_double(), C.c_double()
+    lib().qvz_hip_encode_planes_last_ms(C.byref(a), C.byref(b))
+    encode_planes_gpu.last_ms = (a.value, b.value)      # (model kernels, coder kernels) of this call
     sizes = [int(x) for x in sizes]
     streams = None
     if want_streams:

@@ -178,6 +178,7 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
             sizes, streams, coded = host.encode_planes_gpu(out["qi"], out["st"], labels if k > 1 else None, n, c,
                                                            [cb.handle for cb in cbs], shards, want_streams=keep,
                                                            work_bytes=work_bytes)
+        wall["coder_model_kernels"], wall["coder_interval_kernels"] = (x * 1e-3 for x in host.encode_planes_gpu.last_ms)
         stream_sizes = sizes
     elif coder == "gpu-feed":
         with timer.span("arith_shards"):
