@@ -17,6 +17,7 @@
 #include <vector>
 
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -776,10 +777,10 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     if (r0 >= rend) return;                                      // whole workgroup
     const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
     const uint32_t rb_stride = W + 1;                            // +1: conflict-free transposition
-    Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [2][64][W + 1]
+    Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [64][W + 1]
     const uint32_t cof_words = (K * 2 * A + 1) / 2;
     // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, table offsets of the column [K][144] u16
-    unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 2 * 64 * rb_stride) +
+    unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride) +
                               (size_t)wave * ((3 * slice_cap + cof_words + 192) / 2);
     uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
     uint16_t *cof = reinterpret_cast<uint16_t *>(tab + slice_cap);
@@ -930,7 +931,8 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             }
             if (ok) outr = make_record(n, cum_lo, fx);
         }
-        Record *buf = recbuf + (size_t)(chunk & 1) * 64 * rb_stride;
+        Record *buf = recbuf;
+        __syncthreads();                                         // the previous chunk has been drained
         buf[lane * rb_stride + wave] = outr;
         __syncthreads();
         {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
 // One raw s_barrier per block of CR_B symbols (no fence, nobody waits on vmcnt): before barrier b the loader has
 // parked records b and the interval wave the words of block b-1; after it the interval wave codes block b and the
 // emitter writes out block b-1. Two slots per ring suffice.
-#define CR_B 16      // symbols per block and lane
+#define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring: small enough to sit beside three of the model kernel's workgroups)
 __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
@@ -967,6 +969,7 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
+    asm volatile("s_setprio 3");                                 // a latency chain: issue ahead of the throughput kernels sharing the CU
     uint64_t T = 0;
     if (live) {
         const uint64_t rend = first[g + 1], a = first[g] + seg_lo, b = a + seg_reads;
@@ -981,10 +984,13 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
         // ------------------------------------ loader ------------------------------------
         const uint64_t total = (uint64_t)seg_reads * Cx;         // records in a stream's area
         const Record *p = rec + (uint64_t)(live ? g : 0) * total;
-        auto load_block = [&](uint64_t blk, Record *d) {
+        // A register stage holds LD_B ring blocks (a 256-byte run of the lane's records); three stages in rotation
+        // keep two of them (512 bytes per lane) in flight. No copies between stages: a copy would wait for its load.
+        constexpr int LD_B = 2;
+        auto load_stage = [&](uint64_t stg, Record *d) {
 #pragma unroll
-            for (int i = 0; i < CR_B; ++i) {
-                const uint64_t idx = blk * CR_B + i;
+            for (int i = 0; i < LD_B * CR_B; ++i) {
+                const uint64_t idx = stg * (LD_B * CR_B) + i;
                 d[i] = p[idx < total ? idx : total - 1];         // unconditional (clamped) so that vmcnt stays countable
             }
         };
@@ -997,19 +1003,25 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
-        // three register stages used in rotation (no copies: a copy would wait for the load it copies)
-        Record s0[CR_B], s1[CR_B], s2[CR_B];
-        load_block(0, s0);
-        load_block(1, s1);
-        for (uint64_t b = 0; b < nblk; b += 3) {
-            load_block(b + 2, s2);
-            park(b, s0);
-            if (b + 1 >= nblk) break;
-            load_block(b + 3, s0);
-            park(b + 1, s1);
-            if (b + 2 >= nblk) break;
-            load_block(b + 4, s1);
-            park(b + 2, s2);
+        auto park_stage = [&](uint64_t stg, const Record *d) -> bool {   // false: that was the last block
+#pragma unroll
+            for (int k = 0; k < LD_B; ++k) {
+                const uint64_t b = stg * LD_B + k;
+                if (b >= nblk) return false;
+                park(b, d + k * CR_B);
+            }
+            return (stg + 1) * LD_B < nblk;
+        };
+        Record s0[LD_B * CR_B], s1[LD_B * CR_B], s2[LD_B * CR_B];
+        load_stage(0, s0);
+        load_stage(1, s1);
+        for (uint64_t t = 0; t * LD_B < nblk; t += 3) {
+            load_stage(t + 2, s2);
+            if (!park_stage(t, s0)) break;
+            load_stage(t + 3, s0);
+            if (!park_stage(t + 1, s1)) break;
+            load_stage(t + 4, s1);
+            if (!park_stage(t + 2, s2)) break;
         }
         asm volatile("s_barrier" ::: "memory");                  // barrier nblk (the emitter's last block)
         if (is_last) asm volatile("s_barrier" ::: "memory");     // hand-over of the final l
@@ -1245,7 +1257,11 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     size_t rk_lds = 0;
     uint32_t *d_slices = nullptr, *d_colbase = nullptr, *d_save = nullptr;
     uint16_t *d_coff = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool overlap = false;
+    hipStream_t s_model = nullptr, s_coder = nullptr;
+    hipEvent_t ev_start = nullptr;
+    std::vector<hipEvent_t> evs;                                // per segment: model start, model end, coder start, coder end
+    uint32_t nseg = 0;
     {
         bool fits = true;
         for (uint32_t sx = 0; sx < Cx; ++sx) {
@@ -1274,10 +1290,10 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         if (fits && !(mk && strcmp(mk, "columns") == 0)) {
             const uint32_t cof_words = (clusters * 2 * A + 1) / 2;
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: columns (waves) per workgroup, a power of two
-            uint32_t wmax = we ? (uint32_t)atoi(we) : 8;
-            if (wmax < 1 || wmax > 16 || (wmax & (wmax - 1))) wmax = 8;
+            uint32_t wmax = we ? (uint32_t)atoi(we) : 4;
+            if (wmax < 1 || wmax > 16 || (wmax & (wmax - 1))) wmax = 4;
             for (uint32_t w = wmax; w >= 1; w >>= 1) {
-                const size_t need = (size_t)2 * 64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words + 192) * 4;
+                const size_t need = (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words + 192) * 4;
                 if (need <= 160 * 1024) { rk_waves = w; rk_lds = need; break; }
             }
         }
@@ -1294,9 +1310,25 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipMalloc(&own_work, work_bytes));
         d_work = own_work;
     }
+    // Segments. With room for two record buffers the model kernel of segment i+1 runs beside the coder kernel of
+    // segment i on a second HIP stream (the coder keeps three waves on half of the CUs busy with a latency chain; the
+    // model kernel is throughput work that fills the rest); segments are then cut to about an eighth of a stream so
+    // that the un-overlapped head and tail stay small.
     seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
     if (seg_reads > longest) seg_reads = longest;
+    {
+        const char *ov = getenv("QVZ_CODER_OVERLAP");            // development knob: "0" keeps everything on the caller's stream
+        const uint64_t half = (work_bytes / 2 / per_read) & ~(uint64_t)63;
+        if (!(ov && atoi(ov) == 0) && longest >= 1024 && half >= 64) {
+            uint64_t target = ((longest + 7) / 8 + 63) & ~(uint64_t)63;
+            seg_reads = half < target ? half : target;
+            overlap = true;
+        }
+    }
     if (seg_reads < 4 || seg_reads > 0xFFFFFFFCull) { rc = qvz_set_error(QVZ_E_ARG, "workspace of %llu bytes holds fewer than 4 reads of %u streams", (unsigned long long)work_bytes, shards); goto done; }
+    if (getenv("QVZ_CODER_DEBUG"))
+        fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu\n",
+                shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size());
     TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
     TRY(hipMalloc(&d_status, sizeof(int32_t)));
@@ -1321,56 +1353,70 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
     }
-    for (int i = 0; i < 3; ++i) TRY(hipEventCreate(&ev[i]));
+    nseg = (uint32_t)((longest + seg_reads - 1) / seg_reads);
+    evs.assign((size_t)nseg * 4, nullptr);
+    for (size_t i = 0; i < evs.size(); ++i) TRY(hipEventCreate(&evs[i]));
     g_planes_ms[0] = g_planes_ms[1] = 0.0;
-    for (seg_lo = 0; seg_lo < longest; seg_lo += seg_reads) {
+    s_model = s_coder = st;
+    if (overlap) {
+        TRY(hipStreamCreateWithFlags(&s_model, hipStreamNonBlocking));
+        TRY(hipStreamCreateWithFlags(&s_coder, hipStreamNonBlocking));
+        TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        TRY(hipEventRecord(ev_start, st));                       // uploads and whatever the caller queued before us
+        TRY(hipStreamWaitEvent(s_model, ev_start, 0));
+        TRY(hipStreamWaitEvent(s_coder, ev_start, 0));
+    }
+    for (uint32_t i = 0; i < nseg; ++i) {
+        seg_lo = (uint64_t)i * seg_reads;
         const uint32_t mblocks = (uint32_t)(((uint64_t)shards * Cx + 255) / 256);
-        const int is_first = seg_lo == 0, is_last = seg_lo + seg_reads >= longest;
-        if (seg_lo) {                                            // the previous segment's kernel times (events are reused)
-            float a = 0.f, b = 0.f;
-            TRY(hipEventSynchronize(ev[2]));
-            TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
-            TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
-            g_planes_ms[0] += a; g_planes_ms[1] += b;
-        }
-        TRY(hipEventRecord(ev[0], st));
+        const int is_first = i == 0, is_last = i + 1 == nseg;
+        Record *buf = (Record *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * shards * Cx : 0);
+        hipEvent_t *e = &evs[(size_t)i * 4];
+        if (overlap && i >= 2) TRY(hipStreamWaitEvent(s_model, evs[(size_t)(i - 2) * 4 + 3], 0));   // the coder has drained this buffer
+        TRY(hipEventRecord(e[0], s_model));
         if (rk_waves) {
             const dim3 grid(shards, (Cx + rk_waves - 1) / rk_waves), block(64 * rk_waves);
             if (clusters > 1)
-                hipLaunchKernelGGL(k_model_ranks<true>, grid, block, rk_lds, st, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
+                hipLaunchKernelGGL(k_model_ranks<true>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), (Record *)d_work, d_status);
+                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
             else
-                hipLaunchKernelGGL(k_model_ranks<false>, grid, block, rk_lds, st, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
+                hipLaunchKernelGGL(k_model_ranks<false>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), (Record *)d_work, d_status);
+                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
         } else if (clusters > 1)
-            hipLaunchKernelGGL(k_model_columns<true>, dim3(mblocks), dim3(256), 0, st, d_qi, d_st, ld, d_labels, columns, clusters,
-                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, (Record *)d_work, d_status);
+            hipLaunchKernelGGL(k_model_columns<true>, dim3(mblocks), dim3(256), 0, s_model, d_qi, d_st, ld, d_labels, columns, clusters,
+                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, buf, d_status);
         else
-            hipLaunchKernelGGL(k_model_columns<false>, dim3(mblocks), dim3(256), 0, st, d_qi, d_st, ld, d_labels, columns, clusters,
-                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, (Record *)d_work, d_status);
-        TRY(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(192), 0, st, (const Record *)d_work, Cx, d_first, shards,
+            hipLaunchKernelGGL(k_model_columns<false>, dim3(mblocks), dim3(256), 0, s_model, d_qi, d_st, ld, d_labels, columns, clusters,
+                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, buf, d_status);
+        TRY(hipEventRecord(e[1], s_model));
+        if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
+        TRY(hipEventRecord(e[2], s_coder));
+        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(192), 0, s_coder, (const Record *)buf, Cx, d_first, shards,
                            seg_lo, (uint32_t)seg_reads, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
-        TRY(hipEventRecord(ev[2], st));
+        TRY(hipEventRecord(e[3], s_coder));
     }
     TRY(hipGetLastError());
+    if (overlap) TRY(hipStreamWaitEvent(st, evs[(size_t)(nseg - 1) * 4 + 3], 0));   // the last coder kernel ends after everything else
     TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
-    {
-        float a = 0.f, b = 0.f;
-        TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
-        TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
-        g_planes_ms[0] += a; g_planes_ms[1] += b;
+    for (uint32_t i = 0; i < nseg; ++i) {                        // busy time of either kernel family (they overlap in time)
+        float ta = 0.f, tb = 0.f;
+        TRY(hipEventElapsedTime(&ta, evs[(size_t)i * 4], evs[(size_t)i * 4 + 1]));
+        TRY(hipEventElapsedTime(&tb, evs[(size_t)i * 4 + 2], evs[(size_t)i * 4 + 3]));
+        g_planes_ms[0] += ta; g_planes_ms[1] += tb;
     }
     if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder input addresses a quantizer without a model table (dead context or bad state)");
     else if (status & 2) rc = qvz_set_error(QVZ_E_NOMEM, "a shard's stream exceeded cap_per_shard=%llu bytes", (unsigned long long)cap_per_shard);
 done:
 #undef TRY
     (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
-    for (int i = 0; i < 3; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
+    for (size_t i = 0; i < evs.size(); ++i) if (evs[i]) (void)hipEventDestroy(evs[i]);
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (s_model && s_model != st) { (void)hipStreamSynchronize(s_model); (void)hipStreamDestroy(s_model); }
+    if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); (void)hipStreamDestroy(s_coder); }
     (void)hipFree(d_cs); (void)hipFree(own_work); (void)hipFree(d_slices); (void)hipFree(d_colbase); (void)hipFree(d_coff); (void)hipFree(d_save);
     free(h_arena); free(h_off); free(h_first);
     return rc;
