@@ -1289,12 +1289,24 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         const char *mk = getenv("QVZ_MODEL_KERNEL");             // development knob: "columns" forces the lane-per-column kernel
         if (fits && !(mk && strcmp(mk, "columns") == 0)) {
             const uint32_t cof_words = (clusters * 2 * A + 1) / 2;
-            const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: columns (waves) per workgroup, a power of two
-            uint32_t wmax = we ? (uint32_t)atoi(we) : 4;
-            if (wmax < 1 || wmax > 16 || (wmax & (wmax - 1))) wmax = 4;
-            for (uint32_t w = wmax; w >= 1; w >>= 1) {
-                const size_t need = (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words + 192) * 4;
-                if (need <= 160 * 1024) { rk_waves = w; rk_lds = need; break; }
+            // W = columns (waves) per workgroup: records leave as W * 16-byte runs, so wider is better for the stores,
+            // but LDS decides how many waves a CU holds (k_code_records wants ~21 KB beside them). Take W = 4 if it
+            // keeps 8 waves on a CU, else whichever of 4, 2, 8, 1 keeps the most.
+            const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
+            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words + 192) * 4; };
+            const size_t budget = 160 * 1024 - 21 * 1024;
+            const uint32_t order[4] = {4, 2, 8, 1};
+            uint32_t best_waves = 0;
+            for (uint32_t w : order) {
+                const size_t need = need_of(w);
+                if (need > 160 * 1024) continue;
+                const uint32_t resident = (uint32_t)(need <= budget ? budget / need : 1) * w;
+                if (resident > best_waves) { best_waves = resident; rk_waves = w; rk_lds = need; }
+                if (best_waves >= 8) break;
+            }
+            if (we) {
+                const uint32_t w = (uint32_t)atoi(we);
+                if (w >= 1 && w <= 16 && !(w & (w - 1)) && need_of(w) <= 160 * 1024) { rk_waves = w; rk_lds = need_of(w); }
             }
         }
     }

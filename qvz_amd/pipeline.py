@@ -140,6 +140,18 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     torch.cuda.synchronize()
     wall["pmf"] = time.perf_counter() - t1
 
+    # ---- WELL draws (well.c:8-46): they depend on the seed only, so they are generated on a side stream while the
+    # codebooks (small latency-bound kernels + host work) are being made ----
+    if well_state is None:
+        well_state = np.full(32, 0x55555555, dtype=np.uint32)
+    main_stream = torch.cuda.current_stream()
+    draws = K.empty_matrix(n, c)             # allocated on the main stream (the caching allocator pools per stream)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(main_stream)
+    with torch.cuda.stream(side):
+        with timer.span("well_draws"):
+            K.well_draws(well_state, first_read, n, c, out=draws)
+
     # ---- codebooks (codebook.c:208-468), identical on every rank ----
     t2 = time.perf_counter()
     dmat = K.distortion_matrix(dist)
@@ -152,12 +164,9 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     torch.cuda.synchronize()
     wall["codebook"] = time.perf_counter() - t2
 
-    # ---- WELL draws + quantize (qv_compressor.c:76-135) ----
+    # ---- quantize (qv_compressor.c:76-135) ----
     t3 = time.perf_counter()
-    if well_state is None:
-        well_state = np.full(32, 0x55555555, dtype=np.uint32)
-    with timer.span("well_draws"):
-        draws = K.well_draws(well_state, first_read, n, c)
+    main_stream.wait_stream(side)
     ddist = torch.from_numpy(dmat).to(dev)
     with timer.span("quantize"):
         out = K.quantize(sym, n, ct, qs, draws, ddist, labels=labels if k > 1 else None, k=k)
