@@ -284,7 +284,7 @@ struct LmLds {
     uint8_t bounds[80];
     uint8_t q[2][A];
     uint8_t recon[2][A];
-    uint32_t masks[A][4];
+    double mv[A];            // expected distortion of every candidate reconstruction point within its own region
 };
 
 // One Lloyd-Max design (quantizer.c:34-132) for S states into slot `b`. All 64 lanes call it together.
@@ -305,53 +305,75 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
         changed = 0;
         iter += 1;
         if (stop && __atomic_load_n(stop, __ATOMIC_RELAXED) < S) return false;       // wave-uniform
-        for (uint32_t j = 0; j < S; ++j) {                                           // :62-87
-            const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
-            const uint32_t r1 = b0 + lane, r2 = r1 + 64;
-            double best_v = DBL_MAX;
-            uint32_t best_r = b0;                                                    // min_r = bounds[j]
-            if (r1 < b1) {
+        // New reconstruction points (:62-87). The regions of one iteration depend on the bounds only, which do not
+        // move in this phase, so when the bounds form a partition (they always do unless an earlier walk left stale
+        // ones behind) every candidate r is evaluated in its own region at once: the loop is as long as the widest
+        // region instead of the whole alphabet. Same sums in the same order, first minimum wins.
+        bool mono = true;
+        for (uint32_t t = lane; t < S; t += 64) mono = mono && bounds[t] <= bounds[t + 1];
+        if (!__ballot(!mono)) {
+            for (uint32_t rr = lane; rr < A; rr += 64) {
+                uint32_t j = 0;
+                for (uint32_t t = 1; t < S; ++t) j += bounds[t] <= rr ? 1u : 0u;
+                const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
                 double m = 0.0;
-                for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r1];
-                if (m < best_v) { best_v = m; best_r = r1; }
+                for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + rr];
+                L->mv[rr] = m;
             }
-            if (r2 < b1) {
-                double m = 0.0;
-                for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r2];
-                if (m < best_v) { best_v = m; best_r = r2; }
+            __syncthreads();
+            uint32_t chg = 0;
+            for (uint32_t j = lane; j < S; j += 64) {
+                const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
+                double best_v = DBL_MAX;
+                uint32_t best_r = b0;                                                // min_r = bounds[j]
+                for (uint32_t r = b0; r < b1; ++r) {
+                    const double v = L->mv[r];
+                    if (v < best_v) { best_v = v; best_r = r; }
+                }
+                if (best_r != recon[j]) { chg = 1; recon[j] = (uint8_t)best_r; }
             }
-            // first minimum wins (strict '<' scan in r order) == lexicographic min of (value, r)
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_xor(best_v, off, 64);
-                const uint32_t orr = __shfl_xor(best_r, off, 64);
-                if (ov < best_v || (ov == best_v && orr < best_r)) { best_v = ov; best_r = orr; }
-            }
-            if (best_r != recon[j]) {
-                changed = 1;
-                if (lane == 0) recon[j] = (uint8_t)best_r;
+            changed = __ballot(chg) ? 1u : 0u;
+        } else {
+            for (uint32_t j = 0; j < S; ++j) {
+                const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
+                const uint32_t r1 = b0 + lane, r2 = r1 + 64;
+                double best_v = DBL_MAX;
+                uint32_t best_r = b0;
+                if (r1 < b1) {
+                    double m = 0.0;
+                    for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r1];
+                    if (m < best_v) { best_v = m; best_r = r1; }
+                }
+                if (r2 < b1) {
+                    double m = 0.0;
+                    for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r2];
+                    if (m < best_v) { best_v = m; best_r = r2; }
+                }
+                // first minimum wins (strict '<' scan in r order) == lexicographic min of (value, r)
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ov = __shfl_xor(best_v, off, 64);
+                    const uint32_t orr = __shfl_xor(best_r, off, 64);
+                    if (ov < best_v || (ov == best_v && orr < best_r)) { best_v = ov; best_r = orr; }
+                }
+                if (best_r != recon[j]) {
+                    changed = 1;
+                    if (lane == 0) recon[j] = (uint8_t)best_r;
+                }
             }
         }
         __syncthreads();
-        // boundary walk (:93-107). flag(t, j) = d(j, recon[t+1]) < d(j, recon[t]) for j = 1..70 as ballot masks,
-        // then "advance at the first flagged j after the previous boundary" is a count-trailing-zeros per state.
-        for (uint32_t t = 0; t + 1 < S; ++t) {
-            const uint32_t ra = recon[t], rb = recon[t + 1];
-            const uint32_t j1 = lane, j2 = lane + 64;
-            const int f1 = (j1 >= 1) && (dl[j1 * A + rb] < dl[j1 * A + ra]);
-            const int f2 = (j2 <= A - 2) && (dl[j2 * A + rb] < dl[j2 * A + ra]);
-            const unsigned long long m1 = __ballot(f1), m2 = __ballot(f2);
-            if (lane == 0) {
-                L->masks[t][0] = (uint32_t)m1; L->masks[t][1] = (uint32_t)(m1 >> 32);
-                L->masks[t][2] = (uint32_t)m2; L->masks[t][3] = 0;
-            }
-        }
-        __syncthreads();
+        // Boundary walk (:93-107). flag(t, j) = d(j, recon[t+1]) < d(j, recon[t]) for j = 1..70 as two ballot masks;
+        // "advance at the first flagged j after the previous boundary" is a count-trailing-zeros. The walk stops at
+        // the first state without such a j; the bounds beyond it keep their old values, as in the reference.
         {
-            uint32_t t = 0, jprev = 0;   // stale bounds beyond the last advance are kept, as in the reference
-            while (t + 1 < S) {
-                const unsigned long long m1 = (unsigned long long)L->masks[t][0] | ((unsigned long long)L->masks[t][1] << 32);
-                const unsigned long long m2 = L->masks[t][2];
-                unsigned long long a1 = jprev < 63 ? (m1 & (~0ull << (jprev + 1))) : 0ull;
+            uint32_t jprev = 0;
+            for (uint32_t t = 0; t + 1 < S; ++t) {
+                const uint32_t ra = recon[t], rb = recon[t + 1];
+                const uint32_t j1 = lane, j2 = lane + 64;
+                const int f1 = (j1 >= 1) && (dl[j1 * A + rb] < dl[j1 * A + ra]);
+                const int f2 = (j2 <= A - 2) && (dl[j2 * A + rb] < dl[j2 * A + ra]);
+                const unsigned long long m1 = __ballot(f1), m2 = __ballot(f2);
+                const unsigned long long a1 = jprev < 63 ? (m1 & (~0ull << (jprev + 1))) : 0ull;
                 uint32_t jn;
                 if (a1) {
                     jn = (uint32_t)__builtin_ctzll(a1);
@@ -361,8 +383,7 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                     if (!a2) break;
                     jn = 64 + (uint32_t)__builtin_ctzll(a2);
                 }
-                t += 1;
-                if (lane == 0) bounds[t] = (uint8_t)jn;
+                if (lane == 0) bounds[t + 1] = (uint8_t)jn;
                 jprev = jn;
             }
         }
