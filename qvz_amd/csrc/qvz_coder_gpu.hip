@@ -1067,13 +1067,20 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
 
     // ------------------------------------ emitter ------------------------------------
     // A symbol puts out k + s3 bits: the first of the k shared bits, the s3 pending E3 bits (its complement), then the
-    // other k-1. As a number that is top + ((2^s3 - 1) << (k-1)) whatever the first bit is (top = the k bits), one
-    // v_bfm + one add. Symbols with at most 16 bits (all but ~2^-16 of them) take the straight path: two of them fit
-    // the 64-bit accumulator on top of < 32 pending bits, so the flush test runs once per pair. Stores go through a
-    // running 64-bit pointer; room is checked once per block (64 bytes at most on the straight path), which makes a
-    // stream that comes within 128 bytes of cap_per_shard count as overflowed.
-    uint8_t *const base = out + (uint64_t)(live ? g : 0) * cap;
-    uint8_t *const end = base + cap;
+    // other k-1. As a number that is top + ((2^s3 - 1) << (k-1)) whatever the first bit is (top = the k bits): one
+    // v_bfm + one add. A lone wave pays dearly for every exec-mask change (v_cmp -> s_and_saveexec -> ... measured 226
+    // cycles per symbol for 25 instructions with a divergent flush test), so the straight path has none:
+    //   * symbols are taken in pairs; a pair in which some lane has more than 16 bits to put out (about one symbol in
+    //     2^16) goes through a wave-uniform branch to the piecewise code with exact bounds;
+    //   * after a pair the accumulator holds fewer than 64 bits; the word at its top is STORED UNCONDITIONALLY at the
+    //     write pointer, and the pointer advances by 4 only if the word was complete (nbits >= 32): an incomplete
+    //     word is simply overwritten later. No test, one store per pair.
+    // Room is checked once per block, which makes a stream that comes within 128 bytes of cap_per_shard count as
+    // overflowed.
+    // lanes past the last stream store too (zeros, never advancing): park them on the last 4 bytes of the output area,
+    // inside the 128-byte margin no stream may reach
+    uint8_t *const base = live ? out + (uint64_t)g * cap : out + (uint64_t)shards * cap - 4;
+    uint8_t *const end = live ? base + cap : base + 4 + 128;
     uint8_t *p = base;
     uint32_t scale3 = 0, nbits = 0;
     uint64_t acc = 0;
@@ -1082,10 +1089,23 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
         const CoderState s = cs[g];
         scale3 = s.scale3; nbits = s.nbits; acc = s.acc; p = base + s.pos; ovf = s.overflow != 0;
     }
-    auto flush = [&]() {                                         // top 32 pending bits -> 4 big-endian bytes
-        *reinterpret_cast<uint32_t *>(p) = __builtin_bswap32((uint32_t)(acc >> (nbits - 32)));
-        p += 4;
-        nbits -= 32;
+    auto piecewise = [&](uint32_t w) {                           // one symbol, any number of bits, exact bounds
+        const uint32_t k = (w >> 5) & 31, j = w & 31;
+        if (k) {
+            const uint32_t top = w >> (32 - k), km1 = k - 1;
+            LaneCoder c;
+            c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
+            c.l = 0; c.u = 0; c.scale3 = 0;
+            if (c.nbits >= 32) lc_flush32(c);
+            const uint32_t bit = top >> km1;
+            lc_put(c, bit, 1);
+            lc_run(c, !bit, scale3);
+            if (km1) lc_put(c, top & ((1u << km1) - 1), km1);
+            acc = c.acc; nbits = c.nbits; ovf = c.overflow;
+            p = base + c.pos;
+            scale3 = 0;
+        }
+        scale3 += j;
     };
     for (uint64_t b = 0; b <= nblk; ++b) {
         asm volatile("s_barrier" ::: "memory");
@@ -1094,32 +1114,35 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
         uint32_t w[CR_B];
 #pragma unroll
         for (int jx = 0; jx < CR_B; ++jx) w[jx] = words[slot][jx][lane];
-        if (p + 128 > end) { ovf = true; p = base; }             // out of room: keep the stores inside the stream's area
+        {                                                        // out of room: keep the stores inside the stream's area
+            const bool tight = p + 128 > end;
+            ovf = ovf || tight;
+            p = tight ? base : p;
+        }
 #pragma unroll
-        for (int jx = 0; jx < CR_B; ++jx) {
-            const uint32_t k = (w[jx] >> 5) & 31, j = w[jx] & 31;
-            const uint32_t top = (w[jx] >> 1) >> (31 - k);       // the k leading bits of l (0 when k = 0)
-            const uint32_t km1 = k ? k - 1 : 0u;
-            const uint32_t s3 = k ? scale3 : 0u;                 // the pending run goes out only when a bit is decided
-            const uint32_t nb = k + s3;
-            if (nb > 16) {                                       // rare: piecewise, with exact bounds
-                if (nbits >= 32) flush();
-                LaneCoder c;
-                c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
-                c.l = 0; c.u = 0; c.scale3 = 0;
-                const uint32_t bit = top >> km1;
-                lc_put(c, bit, 1);
-                lc_run(c, !bit, s3);
-                if (km1) lc_put(c, top & ((1u << km1) - 1), km1);
-                acc = c.acc; nbits = c.nbits; ovf = c.overflow;
-                p = base + c.pos;
-                if (p + 128 > end) { ovf = true; p = base; }
-            } else {
-                acc = (acc << nb) | (uint64_t)(top + (((1u << s3) - 1) << km1));
-                nbits += nb;
+        for (int jx = 0; jx < CR_B; jx += 2) {
+            const uint32_t k0 = (w[jx] >> 5) & 31, j0 = w[jx] & 31, k1 = (w[jx + 1] >> 5) & 31, j1 = w[jx + 1] & 31;
+            const uint32_t s30 = k0 ? scale3 : 0u;               // the pending run goes out only when a bit is decided
+            const uint32_t sc1 = scale3 - s30 + j0;
+            const uint32_t s31 = k1 ? sc1 : 0u;
+            const uint32_t nb0 = k0 + s30, nb1 = k1 + s31;
+            if (__ballot((nb0 | nb1) > 16)) {                    // wave-uniform, rare
+                piecewise(w[jx]);
+                piecewise(w[jx + 1]);
+                const bool tight = p + 128 > end;
+                ovf = ovf || tight;
+                p = tight ? base : p;
+                continue;
             }
-            scale3 = scale3 - s3 + j;
-            if ((jx & 1) && nbits >= 32) flush();
+            const uint32_t top0 = (w[jx] >> 1) >> (31 - k0), top1 = (w[jx + 1] >> 1) >> (31 - k1);   // the k leading bits of l
+            const uint32_t km0 = k0 ? k0 - 1 : 0u, km1 = k1 ? k1 - 1 : 0u;
+            acc = (acc << nb0) | (uint64_t)(top0 + (((1u << s30) - 1) << km0));
+            acc = (acc << nb1) | (uint64_t)(top1 + (((1u << s31) - 1) << km1));
+            nbits += nb0 + nb1;                                  // < 32 + 32
+            scale3 = sc1 - s31 + j1;
+            *reinterpret_cast<uint32_t *>(p) = __builtin_bswap32((uint32_t)(acc >> ((nbits - 32) & 63)));
+            p += (nbits >> 5) << 2;                              // keep the word only if it was complete
+            nbits &= 31;
         }
     }
     if (is_last) {
