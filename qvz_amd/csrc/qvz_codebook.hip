@@ -207,7 +207,8 @@ __global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict
         for (uint32_t e = tid; e < A * nprev; e += 1024) {
             const uint32_t k = e / nprev, j = e % nprev;
             double pt = 0;
-            for (int x = 0; x < A; ++x) pt += prev_qpmf[x * A + j] * Pc[x * A + k] * mm[x];
+#pragma unroll 8
+            for (int x = 0; x < A; ++x) pt += prev_qpmf[x * A + j] * Pc[x * A + k] * mm[x];   // loads run ahead, the sum stays in order
             bufA[k * A + j] = pt;
         }
         __syncthreads();
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict
     for (uint32_t e = tid; e < nu * A; e += 1024) {
         const uint32_t idx = e / A, k = e % A;
         double acc = 0.0;
+#pragma unroll 8
         for (int x = 0; x < A; ++x) acc += bufA[x * A + idx] * Ps[x * A + k] * m1[x];
         bufB[idx * A + k] = acc;
     }

@@ -110,7 +110,21 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     counts = torch.zeros(k, dtype=torch.int32, device=dev)
     acc = torch.zeros((k, c), dtype=torch.int64, device=dev)
     iters = 0
-    while True:
+    while k == 1:
+        # One cluster: every read is in it whatever the centroid is (cluster.c:75-98 finds the nearest of one), so the
+        # assignment pass is skipped, and a second iteration would recompute the same sums - the means cannot move
+        # again. What remains of the reference's loop is one accumulation and its iteration count (2 if the first
+        # update moved the centroid by more than the threshold, cluster.c:230-233, else 1).
+        counts.fill_(n)
+        with timer.span("kmeans_accumulate"):
+            K.kmeans_accumulate(sym, n, labels, k, acc=acc)
+        if group is not None:
+            dist_mod.all_reduce(acc, group=group)
+            dist_mod.all_reduce(counts, group=group)
+        moved, status = K.kmeans_update(acc, counts, means)
+        iters = 2 if moved[0].item() > threshold else 1
+        break
+    while k > 1:
         counts.zero_()
         acc.zero_()
         with timer.span("kmeans_assign"):
