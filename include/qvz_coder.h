@@ -97,6 +97,18 @@ int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld,
                           uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                           uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,
                           void *stream);
+/* Decoder of sharded streams on the GPU, one lane per stream: the reference's
+ * start_qv_decompression (src/qv_compressor.c:145-231) with arithmetic_decoder_step / decoder_last_step
+ * (src/arith.c:118-205) and update_stats (src/qv_stream.c:9-25), per shard. d_in holds stream g at
+ * d_in + g * cap_per_shard (h_sizes[g] bytes, the layout the GPU coders write); d_draws is the draw matrix of the
+ * same reads (qvz_hip_well_draws with the file's WELL state). Writes the quality values qv[s*ld + i] (the layout of
+ * the quantizer's `qv` plane: qvz_hip_untranspose_text turns it into the reference's decoded text) and, for
+ * clusters > 1, the decoded cluster id of every read. With one shard this decodes the reference's own stream.
+ * QVZ_E_DATA if a stream does not fit the codebooks. */
+int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n,
+                          uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                          const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels, void *stream);
+
 /* GPU time of the last qvz_hip_encode_planes call, split into its model kernels and its coder kernels (HIP events on
  * the call's stream, summed over the segments). Either pointer may be NULL. */
 void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);

@@ -145,6 +145,25 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     return sizes, streams, out
 
 
+def decode_shards_gpu(coded, cap_per_shard, sizes, n, columns, codebook_handles, shards, draws, want_labels=False):
+    """GPU decoder of sharded streams (qvz_hip_decode_shards). coded: uint8 device tensor with stream g at
+    g * cap_per_shard; draws: (columns, ld) draw matrix of the same reads. Returns (qv plane (columns, ld), labels|None)."""
+    import torch
+    k = len(codebook_handles)
+    arr = (C.c_void_p * k)(*codebook_handles)
+    ld = draws.shape[1]
+    qv = torch.zeros((columns, ld), dtype=torch.uint8, device=draws.device)
+    labels = torch.zeros(ld, dtype=torch.uint8, device=draws.device) if (k > 1 or want_labels) else None
+    sz = (C.c_uint64 * shards)(*[int(x) for x in sizes])
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib().qvz_hip_decode_shards(C.c_void_p(coded.data_ptr()), cap_per_shard, sz, n, columns, k, arr, shards,
+                                     C.c_void_p(draws.data_ptr()), ld, C.c_void_p(qv.data_ptr()),
+                                     C.c_void_p(labels.data_ptr()) if labels is not None else None, stream)
+    if rc:
+        raise QvzHipError(f"qvz_hip_decode_shards failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
+    return qv, labels
+
+
 def shard_file_image(columns, shard_reads, codebook_handles, well_state_at_shard, stream):
     """Reference-format .q image of one shard (decodable by the unmodified reference decoder)."""
     k = len(codebook_handles)

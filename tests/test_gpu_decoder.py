@@ -1,0 +1,87 @@
+"""GPU tests of the shard decoder (qvz_hip_decode_shards): it must decode the reference
+encoder's own streams to the reference's `-u` text, and invert the GPU coders shard by shard."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from test_gpu_pipeline import setup_case  # noqa: E402
+
+
+def encode(name, shards, coder="gpu"):
+    from qvz_amd import pipeline as P
+    rows, opts, n, c, sym, means0 = setup_case(name)
+    r = P.encode_pass(sym, n, 0, n, means0, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"],
+                      shards=shards, threads=2, keep=True, coder=coder)
+    return rows, opts, n, c, r
+
+
+def upload_streams(streams):
+    cap = (max(len(s) for s in streams) + 7) & ~3
+    buf = np.zeros((len(streams), cap), dtype=np.uint8)
+    for g, s in enumerate(streams):
+        buf[g, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    return torch.from_numpy(buf).cuda().view(-1), cap
+
+
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "t2k_c3_f05_M", "cfg1_r10_M", "const_f05", "const_r05",
+                                  "uniform72_r20_A", "uniform72_f09_M", "c2_f08", "tiny5_r10", "twolevel_c2_f05",
+                                  "f00_zero_rate", "r35_high_rate"])
+def test_decodes_the_reference_encoders_stream(name):
+    """Stream bytes straight out of the reference's .q file -> GPU decoder -> the reference's -u text."""
+    from qvz_amd import host, kernels as K
+    rows, opts, n, c, r = encode(name, 1, coder="host")          # codebooks only (bit-identical to the file's, tested elsewhere)
+    e = G.CASES[name]
+    stream = G.gz(name + ".q.gz")[-e["size"]:]
+    coded, cap = upload_streams([stream])
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    qv, labels = host.decode_shards_gpu(coded, cap, [len(stream)], n, c, [cb.handle for cb in r["codebooks"]], 1, draws)
+    text = K.untranspose_text(qv, n).cpu().numpy().tobytes()
+    assert text == G.gz(name + ".u.gz")
+    if opts["k"] > 1:
+        assert torch.equal(labels[:n], r["labels"][:n])
+
+
+@pytest.mark.parametrize("name,shards", [("t2k_r10_M", 3), ("t2k_c3_f05_M", 5), ("cfg1_f05_L", 64), ("cfg1_c3_r10_M", 17),
+                                         ("wide_c151", 2), ("tiny5_r10", 2), ("rescale_140k_c4", 1), ("rescale_c2_100k_c3", 2),
+                                         ("r35_high_rate", 4)])
+def test_round_trip_of_gpu_coded_shards(name, shards):
+    from qvz_amd import host, kernels as K
+    rows, opts, n, c, r = encode(name, shards)
+    coded, cap = upload_streams(r["streams"])
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    qv, labels = host.decode_shards_gpu(coded, cap, r["stream_bytes"], n, c, [cb.handle for cb in r["codebooks"]], shards, draws)
+    assert torch.equal(qv[:, :n], r["qv"][:, :n])
+    if opts["k"] > 1:
+        assert torch.equal(labels[:n], r["labels"][:n])
+    assert G.md5(K.untranspose_text(qv, n).cpu().numpy().tobytes()) == G.CASES[name]["u_md5"]
+
+
+def test_decoder_rejects_a_foreign_stream():
+    from qvz_amd import host, kernels as K
+    rows, opts, n, c, r = encode("t2k_r10_M", 2)
+    junk = [bytes([0xFF]) * len(s) for s in r["streams"]]
+    coded, cap = upload_streams(junk)
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    with pytest.raises(Exception, match="does not decode"):
+        host.decode_shards_gpu(coded, cap, [len(s) for s in junk], n, c, [cb.handle for cb in r["codebooks"]], 2, draws)
+
+
+def test_round_trip_at_bench_stream_length():
+    """12 208 reads per stream x 150 columns (the per-stream shape of BASELINE configs[1] at 8192 streams), 256 streams."""
+    from qvz_amd import host, kernels as K, pipeline as P
+    n, c, shards = 3_125_248, 150, 256
+    sym = K.qgen1(3, n, c)
+    means0 = K.qgen1(3, 4, c)[:, 0].contiguous().view(1, c)
+    r = P.encode_pass(sym, n, 0, n, means0, mode=host.MODE_RATIO, ratio=0.5, dist="L", shards=shards, coder="gpu", keep=True)
+    cap = (max(r["stream_bytes"]) + 7) & ~3
+    coded = torch.zeros(shards * cap, dtype=torch.uint8, device="cuda").view(shards, cap)
+    for g, s in enumerate(r["streams"]):
+        coded[g, : len(s)] = torch.from_numpy(np.frombuffer(s, dtype=np.uint8).copy()).cuda()
+    draws = K.well_draws(np.full(32, 0x55555555, dtype=np.uint32), 0, n, c)
+    qv, _ = host.decode_shards_gpu(coded.view(-1), cap, r["stream_bytes"], n, c, [cb.handle for cb in r["codebooks"]], shards, draws)
+    assert torch.equal(qv[:, :n], r["qv"][:, :n])
