@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--coder", choices=["host", "gpu", "gpu-feed"], default="gpu",
                     help="arithmetic coder: host threads, or one GPU lane per shard (byte-identical streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roundtrip", action="store_true",
+                    help="after the timed steps, decode every stream on the GPU and compare with the quantizer's output")
     args = ap.parse_args()
 
     import torch
@@ -173,6 +175,22 @@ def main():
     else:
         stream_bytes = results[-1]["total_stream_bytes"]
 
+    roundtrip = None
+    if args.roundtrip and args.coder != "host":
+        # full-size parity property: encode -> decode of every stream reproduces the quantized values bit for bit
+        r = P.encode_pass(sym, n, first, n_total, means0, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"],
+                          shards=shards, threads=threads, group=group, device_index=local, coder=args.coder, keep_device=True)
+        draws = K.well_draws(np.full(32, 0x55555555, dtype=np.uint32), first, n, c)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        qv, lab = host.decode_shards_gpu(r["coded"], r["cap_per_shard"], r["stream_bytes"], n, c,
+                                         [cb.handle for cb in r["codebooks"]], shards, draws)
+        torch.cuda.synchronize()
+        td = time.perf_counter() - td
+        same = bool(torch.equal(qv[:, :n], r["qv"][:, :n])) and (k == 1 or bool(torch.equal(lab[:n], r["labels"][:n])))
+        roundtrip = dict(decoded_equals_quantized=same, decode_seconds=round(td, 4),
+                         decode_symbols_per_second=round(n * c / td, 1), streams=shards)
+        del qv, lab, draws, r
     if rank == 0:
         spans = timer.totals_ms()
         if args.coder == "gpu":      # the planes coder times its two kernel families itself (HIP events inside the C call)
@@ -228,6 +246,8 @@ def main():
                                 ns_per_symbol_per_stream=round(per_step.get("code_records", per_step.get("arith_shards", 0.0))
                                                                * 1e6 * shards / (n * c), 2)) if args.coder != "host" else None,
         }
+        if args.roundtrip and args.coder != "host":
+            line["roundtrip"] = roundtrip
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")
         print(json.dumps(line), flush=True)

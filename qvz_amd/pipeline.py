@@ -85,7 +85,7 @@ class _Span:
 
 def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MODE_RATIO, ratio=0.5, dist="M",
                 threshold=4.0, well_state=None, shards=1, threads=1, group=None, timer=None, keep=False, device_index=0,
-                coder="host", work_bytes=None):
+                coder="host", work_bytes=None, keep_device=False):
     """Runs k-means -> PMF -> codebooks -> WELL -> quantize -> feed -> sharded arithmetic coding for the reads
     [first_read, first_read+n) held in `sym` (this rank's shard of a file with n_total reads).
     coder: "host" = `threads` host threads over the packed feed (qvz_encode_shards_device); "gpu" = the column-parallel
@@ -93,7 +93,9 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     lane-per-stream kernel over the packed feed (qvz_hip_encode_shards). All produce byte-identical streams.
 
     means0: (clusters, c) uint8 device tensor of the initial centroids (symbols). first_read must be a multiple of 4.
-    Returns a dict with stream sizes, distortion, codebooks, phase wall times; with keep=True also the device outputs.
+    Returns a dict with stream sizes, distortion, codebooks, phase wall times; with keep=True also the device outputs
+    and the streams as host bytes; with keep_device=True (GPU coders) the coded streams stay on the device
+    (`coded`, stream g at g * `cap_per_shard`) next to `qv` and `labels`.
     """
     import torch.distributed as dist_mod
     c, ld = sym.shape
@@ -221,6 +223,8 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     wall["total"] = time.perf_counter() - t0
     res = dict(stream_bytes=stream_sizes, total_stream_bytes=sum(stream_sizes), distortion=distortion,
                kmeans_iterations=iters, deferred=deferred, wall=wall, codebooks=cbs)
+    if keep_device and coder != "host":
+        res.update(coded=coded, cap_per_shard=coded.numel() // shards, qv=out["qv"], labels=labels)
     if keep:
         res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, err=out["err"], feed=feed, qi=out["qi"], st=out["st"])
     return res
