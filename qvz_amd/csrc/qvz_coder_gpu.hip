@@ -946,44 +946,55 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     if (bad) atomicOr(status, 1);
 }
 
-// Workgroup = three waves serving the same 64 streams, one lane per stream in each:
-//   wave 2 (loader)    streams every lane's records (one 256-byte run per lane and block, two blocks in flight in
-//                      registers) into an LDS ring; it is the only wave that loads from global memory;
+// Workgroup = four waves serving the same 64 streams, one lane per stream in each. A lone wave issues a dependent
+// VALU instruction every 8 cycles and an independent one every 5 (tools/lat_bench.hip), pays tens of cycles for every
+// exec-mask change, and a load whose 64 lanes touch 64 different lines holds the wave for about as many cycles; so a
+// stream's speed is the work of its busiest wave, and the work is cut by wave and kept branch-free:
+//   wave 3 (loader)    streams every lane's records (128-byte runs, four blocks in flight in registers) into an LDS
+//                      ring; it is the only wave that loads from global memory;
 //   wave 0 (interval)  the serial chain proper (arith.c:24-97): l/u from the record, E1/E2 shift count k, E3 count j,
-//                      renormalised l/u - 24 dependent instructions, no branch. What the symbol contributes to the
-//                      output depends only on (top k bits of the new l, k, j), parked as one 32-bit word in a second ring;
-//   wave 1 (emitter)   pending-bit bookkeeping (scale3), bit accumulator and the byte stream (stores).
-// A lone wave issues a dependent VALU instruction every 8 cycles (tools/lat_bench.hip), so a stream's speed is the
-// length of its longest per-wave chain; that is why the work is cut by wave and kept branch-free.
-// One raw s_barrier per block of CR_B symbols (no fence, nobody waits on vmcnt): before barrier b the loader has
-// parked records b and the interval wave the words of block b-1; after it the interval wave codes block b and the
-// emitter writes out block b-1. Two slots per ring suffice.
-#define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring: small enough to sit beside three of the model kernel's workgroups)
-__global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
+//                      renormalised l/u - 24 dependent instructions. What the symbol contributes to the output
+//                      depends only on (top k bits of the new l, k, j), parked as one word in a second ring;
+//   wave 1 (bits)      pending-bit bookkeeping (scale3): turns a word into (value, bit count) in a third ring;
+//   wave 2 (bytes)     bit accumulator and the byte stream (the only wave that stores).
+// One raw s_barrier per block of CR_B symbols (no fence, nobody but the loader waits on vmcnt): before barrier b the
+// loader has parked records b; after it the interval wave codes block b, the bits wave block b-1, the bytes wave
+// block b-2. (Measured with a single emitter wave: emitter busy 1440 cycles per 8 symbols, loader 1190, chain 1070.)
+#define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps ~27 KB of LDS so that it fits beside the model kernel's workgroups)
+#define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
+__global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
                                                       uint64_t *__restrict__ sizes, int32_t *__restrict__ status) {
     __shared__ Record ring[2][CR_B][64];
-    __shared__ uint32_t words[2][CR_B][64];
-    __shared__ uint32_t final_l[64];
+    __shared__ uint32_t words[3][CR_B][64];                      // three slots: the bytes wave re-reads a rare symbol's word two blocks later
+    __shared__ uint32_t ebits[2][CR_B][64];                      // value (16 bits) | bit count << 16, or CR_RARE | pending run
+    __shared__ uint32_t final_l[64], final_s3[64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
-    asm volatile("s_setprio 3");                                 // a latency chain: issue ahead of the throughput kernels sharing the CU
+    if (wave == 0) asm volatile("s_setprio 3");                  // the latency chain issues ahead of the throughput kernels sharing the CU
     uint64_t T = 0;
     if (live) {
         const uint64_t rend = first[g + 1], a = first[g] + seg_lo, b = a + seg_reads;
         if (a < rend) T = ((b < rend ? b : rend) - a) * Cx;
     }
-    uint64_t Tmax = T;
-    for (int o = 32; o > 0; o >>= 1) { const uint64_t v = __shfl_xor(Tmax, o, 64); Tmax = v > Tmax ? v : Tmax; }
-    const uint64_t nblk = (Tmax + CR_B - 1) / CR_B;              // the same in all three waves
+    uint64_t Tmax = T, Tmin = T;                                 // lanes past the last stream have T = 0 and are padded
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t v = __shfl_xor(Tmax, o, 64), m = __shfl_xor(Tmin, o, 64);
+        Tmax = v > Tmax ? v : Tmax;
+        Tmin = m < Tmin ? m : Tmin;
+    }
+    const uint64_t nblk = (Tmax + CR_B - 1) / CR_B;              // the same in all four waves
     const bool fresh = is_first || !live;
+#define CR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // barriers 0 .. nblk + 1 in every wave (+ one more on the last segment for the hand-over of l and scale3)
 
-    if (wave == 2) {
+    if (wave == 3) {
         // ------------------------------------ loader ------------------------------------
         const uint64_t total = (uint64_t)seg_reads * Cx;         // records in a stream's area
         const Record *p = rec + (uint64_t)(live ? g : 0) * total;
+        const uint64_t nfull = Tmin / CR_B;                      // blocks that are whole in every lane: no padding test
         // A register stage holds LD_B ring blocks (a 256-byte run of the lane's records); three stages in rotation
         // keep two of them (512 bytes per lane) in flight. No copies between stages: a copy would wait for its load.
         constexpr int LD_B = 2;
@@ -996,12 +1007,17 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
         };
         auto park = [&](uint64_t b, const Record *d) {           // block b -> slot b & 1, then barrier b
             const uint32_t slot = (uint32_t)(b & 1);
+            if (b < nfull) {
 #pragma unroll
-            for (int i = 0; i < CR_B; ++i) {
-                const bool pad = b * CR_B + i >= T;              // beyond this lane's symbols: the no-op record
-                ring[slot][i][lane] = make_double2(pad ? 0.0 : d[i].x, pad ? 0.0 : d[i].y);
+                for (int i = 0; i < CR_B; ++i) ring[slot][i][lane] = d[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < CR_B; ++i) {
+                    const bool pad = b * CR_B + i >= T;          // beyond this lane's symbols: the no-op record
+                    ring[slot][i][lane] = make_double2(pad ? 0.0 : d[i].x, pad ? 0.0 : d[i].y);
+                }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            CR_BARRIER();
         };
         auto park_stage = [&](uint64_t stg, const Record *d) -> bool {   // false: that was the last block
 #pragma unroll
@@ -1023,8 +1039,9 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
             load_stage(t + 4, s1);
             if (!park_stage(t + 2, s2)) break;
         }
-        asm volatile("s_barrier" ::: "memory");                  // barrier nblk (the emitter's last block)
-        if (is_last) asm volatile("s_barrier" ::: "memory");     // hand-over of the final l
+        CR_BARRIER();                                            // barriers nblk and nblk + 1: the other waves run behind
+        CR_BARRIER();
+        if (is_last) CR_BARRIER();
         return;
     }
 
@@ -1032,10 +1049,11 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
         // ------------------------------------ interval chain ------------------------------------
         uint32_t l32 = 0, nu32 = 0;                              // l = 0, u = 2^22 - 1
         if (!fresh) { l32 = cs[g].l << 10; nu32 = (~cs[g].u & MASK_M) << 10; }
+        uint32_t wslot = 0;                                      // b % 3
         for (uint64_t b = 0; b < nblk; ++b) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // words of block b-1 are parked
+            CR_BARRIER();
             const uint32_t slot = (uint32_t)(b & 1);
-            Record r[CR_B];                                      // all 16 LDS reads up front: their latency overlaps the chain
+            Record r[CR_B];                                      // all LDS reads up front: their latency overlaps the chain
 #pragma unroll
             for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane];
 #pragma unroll
@@ -1052,68 +1070,101 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
                 const uint32_t j = (uint32_t)__builtin_clz(~(l32 & nu32) << 1);   // E3: positions below the MSB with l = 1, u = 0
                 l32 = (l32 << j) & 0x7FFFFFFFu;
                 nu32 = (nu32 << j) & 0x7FFFFFFFu;
-                words[slot][jx][lane] = lk | (k << 5) | j;
+                words[wslot][jx][lane] = lk | (k << 5) | j;
             }
+            wslot = wslot == 2 ? 0u : wslot + 1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // barrier nblk
+        CR_BARRIER();
+        CR_BARRIER();
         if (is_last) {
             final_l[lane] = l32 >> 10;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            CR_BARRIER();
         } else if (live) {
             cs[g].l = l32 >> 10; cs[g].u = ~(nu32 >> 10) & MASK_M;
         }
         return;
     }
 
-    // ------------------------------------ emitter ------------------------------------
-    // A symbol puts out k + s3 bits: the first of the k shared bits, the s3 pending E3 bits (its complement), then the
-    // other k-1. As a number that is top + ((2^s3 - 1) << (k-1)) whatever the first bit is (top = the k bits): one
-    // v_bfm + one add. A lone wave pays dearly for every exec-mask change (v_cmp -> s_and_saveexec -> ... measured 226
-    // cycles per symbol for 25 instructions with a divergent flush test), so the straight path has none:
-    //   * symbols are taken in pairs; a pair in which some lane has more than 16 bits to put out (about one symbol in
-    //     2^16) goes through a wave-uniform branch to the piecewise code with exact bounds;
-    //   * after a pair the accumulator holds fewer than 64 bits; the word at its top is STORED UNCONDITIONALLY at the
-    //     write pointer, and the pointer advances by 4 only if the word was complete (nbits >= 32): an incomplete
-    //     word is simply overwritten later. No test, one store per pair.
-    // Room is checked once per block, which makes a stream that comes within 128 bytes of cap_per_shard count as
-    // overflowed.
-    // lanes past the last stream store too (zeros, never advancing): park them on the last 4 bytes of the output area,
-    // inside the 128-byte margin no stream may reach
+    if (wave == 1) {
+        // ------------------------------------ bits ------------------------------------
+        // A symbol puts out k + s3 bits: the first of the k shared bits, the s3 pending E3 bits (its complement), then
+        // the other k-1. As a number that is top + ((2^s3 - 1) << (k-1)) whatever the first bit is (top = the k bits):
+        // one v_bfm + one add. More than 16 bits (about one symbol in 2^16): left to the bytes wave, piecewise.
+        uint32_t scale3 = fresh ? 0u : cs[g].scale3;
+        uint32_t wslot = 0;                                      // (b - 1) % 3
+        for (uint64_t b = 0; b <= nblk; ++b) {
+            CR_BARRIER();
+            if (b == 0) continue;
+            const uint32_t slot = (uint32_t)((b - 1) & 1);
+            uint32_t w[CR_B];
+#pragma unroll
+            for (int jx = 0; jx < CR_B; ++jx) w[jx] = words[wslot][jx][lane];
+#pragma unroll
+            for (int jx = 0; jx < CR_B; ++jx) {
+                const uint32_t k = (w[jx] >> 5) & 31, j = w[jx] & 31;
+                const uint32_t top = (w[jx] >> 1) >> (31 - k);   // the k leading bits of l (0 when k = 0)
+                const uint32_t km1 = k ? k - 1 : 0u;
+                const uint32_t s3 = k ? scale3 : 0u;             // the pending run goes out only when a bit is decided
+                const uint32_t nb = k + s3;
+                const uint32_t value = top + (((1u << (s3 & 31)) - 1) << km1);
+                ebits[slot][jx][lane] = nb > 16 ? (CR_RARE | s3) : (value | (nb << 16));
+                scale3 = scale3 - s3 + j;
+            }
+            wslot = wslot == 2 ? 0u : wslot + 1;
+        }
+        CR_BARRIER();                                            // barrier nblk + 1
+        if (is_last) {
+            final_s3[lane] = scale3;
+            CR_BARRIER();
+        } else if (live) {
+            cs[g].scale3 = scale3;
+        }
+        return;
+    }
+
+    // ------------------------------------ bytes ------------------------------------
+    // Symbols are taken in pairs (at most 16 bits each on top of fewer than 32 pending ones: the 64-bit accumulator
+    // holds them). After a pair the word at the top of the accumulator is STORED UNCONDITIONALLY at the write pointer
+    // and the pointer advances by 4 only if the word was complete (nbits >= 32): an incomplete word is overwritten
+    // later. No test, no exec-mask change, one store per pair. A pair with a long symbol in some lane goes through a
+    // wave-uniform branch to the code with exact bounds. Room is checked once per block, which makes a stream that
+    // comes within 128 bytes of cap_per_shard count as overflowed.
+    // Lanes past the last stream store too (zeros, never advancing): they are parked on the last 4 bytes of the output
+    // area, inside the 128-byte margin no stream may reach.
     uint8_t *const base = live ? out + (uint64_t)g * cap : out + (uint64_t)shards * cap - 4;
     uint8_t *const end = live ? base + cap : base + 4 + 128;
     uint8_t *p = base;
-    uint32_t scale3 = 0, nbits = 0;
+    uint32_t nbits = 0;
     uint64_t acc = 0;
     bool ovf = false;
     if (!fresh) {
         const CoderState s = cs[g];
-        scale3 = s.scale3; nbits = s.nbits; acc = s.acc; p = base + s.pos; ovf = s.overflow != 0;
+        nbits = s.nbits; acc = s.acc; p = base + s.pos; ovf = s.overflow != 0;
     }
-    auto piecewise = [&](uint32_t w) {                           // one symbol, any number of bits, exact bounds
-        const uint32_t k = (w >> 5) & 31, j = w & 31;
-        if (k) {
-            const uint32_t top = w >> (32 - k), km1 = k - 1;
-            LaneCoder c;
-            c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
-            c.l = 0; c.u = 0; c.scale3 = 0;
-            if (c.nbits >= 32) lc_flush32(c);
+    auto piecewise = [&](uint32_t e, uint32_t w) {               // one symbol, any number of bits, exact bounds
+        LaneCoder c;
+        c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
+        c.l = 0; c.u = 0; c.scale3 = 0;
+        if (e & CR_RARE) {
+            const uint32_t k = (w >> 5) & 31, km1 = k - 1, top = w >> (32 - k);   // k >= 1 here
             const uint32_t bit = top >> km1;
             lc_put(c, bit, 1);
-            lc_run(c, !bit, scale3);
+            lc_run(c, !bit, e & ~CR_RARE);
             if (km1) lc_put(c, top & ((1u << km1) - 1), km1);
-            acc = c.acc; nbits = c.nbits; ovf = c.overflow;
-            p = base + c.pos;
-            scale3 = 0;
+        } else if (e >> 16) {
+            lc_put(c, e & 0xFFFF, e >> 16);
         }
-        scale3 += j;
+        acc = c.acc; nbits = c.nbits; ovf = c.overflow;
+        p = base + c.pos;
     };
-    for (uint64_t b = 0; b <= nblk; ++b) {
-        asm volatile("s_barrier" ::: "memory");
-        if (b == 0) continue;
-        const uint32_t slot = (uint32_t)((b - 1) & 1);
-        uint32_t w[CR_B];
+    uint32_t wslot = 0;                                          // (b - 2) % 3
+    for (uint64_t b = 0; b <= nblk + 1; ++b) {
+        CR_BARRIER();
+        if (b < 2) continue;
+        const uint32_t slot = (uint32_t)((b - 2) & 1);
+        uint32_t e[CR_B];
 #pragma unroll
-        for (int jx = 0; jx < CR_B; ++jx) w[jx] = words[slot][jx][lane];
+        for (int jx = 0; jx < CR_B; ++jx) e[jx] = ebits[slot][jx][lane];
         {                                                        // out of room: keep the stores inside the stream's area
             const bool tight = p + 128 > end;
             ovf = ovf || tight;
@@ -1121,42 +1172,36 @@ __global__ __launch_bounds__(192) void k_code_records(const Record *__restrict__
         }
 #pragma unroll
         for (int jx = 0; jx < CR_B; jx += 2) {
-            const uint32_t k0 = (w[jx] >> 5) & 31, j0 = w[jx] & 31, k1 = (w[jx + 1] >> 5) & 31, j1 = w[jx + 1] & 31;
-            const uint32_t s30 = k0 ? scale3 : 0u;               // the pending run goes out only when a bit is decided
-            const uint32_t sc1 = scale3 - s30 + j0;
-            const uint32_t s31 = k1 ? sc1 : 0u;
-            const uint32_t nb0 = k0 + s30, nb1 = k1 + s31;
-            if (__ballot((nb0 | nb1) > 16)) {                    // wave-uniform, rare
-                piecewise(w[jx]);
-                piecewise(w[jx + 1]);
+            if (__ballot((e[jx] | e[jx + 1]) & CR_RARE)) {       // wave-uniform, rare
+                piecewise(e[jx], words[wslot][jx][lane]);
+                piecewise(e[jx + 1], words[wslot][jx + 1][lane]);
                 const bool tight = p + 128 > end;
                 ovf = ovf || tight;
                 p = tight ? base : p;
                 continue;
             }
-            const uint32_t top0 = (w[jx] >> 1) >> (31 - k0), top1 = (w[jx + 1] >> 1) >> (31 - k1);   // the k leading bits of l
-            const uint32_t km0 = k0 ? k0 - 1 : 0u, km1 = k1 ? k1 - 1 : 0u;
-            acc = (acc << nb0) | (uint64_t)(top0 + (((1u << s30) - 1) << km0));
-            acc = (acc << nb1) | (uint64_t)(top1 + (((1u << s31) - 1) << km1));
-            nbits += nb0 + nb1;                                  // < 32 + 32
-            scale3 = sc1 - s31 + j1;
+            acc = (acc << (e[jx] >> 16)) | (uint64_t)(e[jx] & 0xFFFF);
+            acc = (acc << (e[jx + 1] >> 16)) | (uint64_t)(e[jx + 1] & 0xFFFF);
+            nbits += (e[jx] >> 16) + (e[jx + 1] >> 16);          // < 32 + 32
             *reinterpret_cast<uint32_t *>(p) = __builtin_bswap32((uint32_t)(acc >> ((nbits - 32) & 63)));
             p += (nbits >> 5) << 2;                              // keep the word only if it was complete
             nbits &= 31;
         }
+        wslot = wslot == 2 ? 0u : wslot + 1;
     }
     if (is_last) {
-        asm volatile("s_barrier" ::: "memory");
+        CR_BARRIER();
         if (!live) return;
         LaneCoder c;
         c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
-        c.scale3 = scale3; c.u = 0;
+        c.scale3 = final_s3[lane]; c.u = 0;
         c.l = final_l[lane];
         sizes[g] = lc_finish(c);
         if (c.overflow) atomicOr(status, 2);
     } else if (live) {
-        cs[g].scale3 = scale3; cs[g].nbits = nbits; cs[g].acc = acc; cs[g].pos = (uint64_t)(p - base); cs[g].overflow = ovf ? 1u : 0u;
+        cs[g].nbits = nbits; cs[g].acc = acc; cs[g].pos = (uint64_t)(p - base); cs[g].overflow = ovf ? 1u : 0u;
     }
+#undef CR_BARRIER
 }
 
 // every shard starts from the same initial model
@@ -1428,7 +1473,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipEventRecord(e[1], s_model));
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
-        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(192), 0, s_coder, (const Record *)buf, Cx, d_first, shards,
+        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(256), 0, s_coder, (const Record *)buf, Cx, d_first, shards,
                            seg_lo, (uint32_t)seg_reads, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
         TRY(hipEventRecord(e[3], s_coder));
     }
