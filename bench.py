@@ -58,6 +58,20 @@ ALG_BYTES_PER_SYMBOL = {
 CHAIN_KERNELS = ("code_records", "arith_shards")
 
 
+def measured_traffic(kernel, args, cfg, shards, world):
+    """HBM bytes per step of `kernel` from the committed PMC passes (profiles/r01_h_pmc_traffic.json), if they were taken
+    on this very workload; None otherwise. (The counters need rocprofv3 around the process, bench.py cannot read them.)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        same = (w["config"] == args.config and w["reads"] == cfg["reads"] and w["columns"] == cfg["cols"] and
+                w["coder"] == args.coder and w["shards"] == shards and world == 1)
+        return t["kernels"][kernel]["hbm_bytes"] if same and kernel in t["kernels"] else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, cores_note):
     """Reference qvz (oracle/_ref/qvz_ref, single thread - it has no threaded mode) on two bounded QGEN-1 samples of
     the same workload; falls back to the CPU oracle ("port") when the reference binary did not travel."""
@@ -214,9 +228,10 @@ def main():
         alg_bytes = bps * n * c + extra
         achieved = alg_bytes / (per_launch[dom] * 1e-3) / 1e9
         roof = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(dom, args, cfg, shards, world),
                     ms_per_launch=round(per_launch[dom], 4), algorithmic_bytes_per_launch=int(alg_bytes),
-                    bytes_per_symbol=bps)
+                    bytes_per_symbol=bps, traffic_source="profiles/r01_h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                    "WRITE_SIZE passes of this workload, FETCH_SIZE x2 per the gfx950 correction); null if the workload differs")
         pmf_ach = (n * c + (n if k > 1 else 0)) / (per_launch["pmf_hist"] * 1e-3) / 1e9
         wall = {ph: round(float(np.mean([r["wall"][ph] for r in results])), 4) for ph in results[-1]["wall"]}
         line = {
