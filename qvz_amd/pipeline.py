@@ -85,7 +85,7 @@ class _Span:
 
 def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MODE_RATIO, ratio=0.5, dist="M",
                 threshold=4.0, well_state=None, shards=1, threads=1, group=None, timer=None, keep=False, device_index=0,
-                coder="host", work_bytes=None, keep_device=False):
+                coder="host", work_bytes=None, keep_device=False, reuse=None, want_reuse=False):
     """Runs k-means -> PMF -> codebooks -> WELL -> quantize -> feed -> sharded arithmetic coding for the reads
     [first_read, first_read+n) held in `sym` (this rank's shard of a file with n_total reads).
     coder: "host" = `threads` host threads over the packed feed (qvz_encode_shards_device); "gpu" = the column-parallel
@@ -96,6 +96,9 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     Returns a dict with stream sizes, distortion, codebooks, phase wall times; with keep=True also the device outputs
     and the streams as host bytes; with keep_device=True (GPU coders) the coded streams stay on the device
     (`coded`, stream g at g * `cap_per_shard`) next to `qv` and `labels`.
+    reuse / want_reuse: the cluster labels, the PMF counters and the WELL draws do not depend on -f / -r / -d, so a
+    rate-distortion sweep (the reference's generate_rd.sh: 20 encodes of one file) computes them once: pass
+    want_reuse=True on the first operating point and hand its result["reuse"] to the others (rd_sweep below).
     """
     import torch.distributed as dist_mod
     c, ld = sym.shape
@@ -112,7 +115,9 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     counts = torch.zeros(k, dtype=torch.int32, device=dev)
     acc = torch.zeros((k, c), dtype=torch.int64, device=dev)
     iters = 0
-    while k == 1:
+    if reuse is not None:
+        labels, means, iters = reuse["labels"], reuse["means"], reuse["kmeans_iterations"]
+    while k == 1 and reuse is None:
         # One cluster: every read is in it whatever the centroid is (cluster.c:75-98 finds the nearest of one), so the
         # assignment pass is skipped, and a second iteration would recompute the same sums - the means cannot move
         # again. What remains of the reference's loop is one accumulation and its iteration count (2 if the first
@@ -126,7 +131,7 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
         moved, status = K.kmeans_update(acc, counts, means)
         iters = 2 if moved[0].item() > threshold else 1
         break
-    while k > 1:
+    while k > 1 and reuse is None:
         counts.zero_()
         acc.zero_()
         with timer.span("kmeans_assign"):
@@ -148,11 +153,14 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
 
     # ---- conditional-PMF counters (codebook.c:193-205) ----
     t1 = time.perf_counter()
-    cnt = torch.zeros((k, c, 72, 72), dtype=torch.int32, device=dev)
-    with timer.span("pmf_hist"):
-        K.pmf_hist(sym, n, labels=labels if k > 1 else None, k=k, cnt=cnt)
-    if group is not None:
-        dist_mod.all_reduce(cnt, group=group)
+    if reuse is not None:
+        cnt = reuse["cnt"]
+    else:
+        cnt = torch.zeros((k, c, 72, 72), dtype=torch.int32, device=dev)
+        with timer.span("pmf_hist"):
+            K.pmf_hist(sym, n, labels=labels if k > 1 else None, k=k, cnt=cnt)
+        if group is not None:
+            dist_mod.all_reduce(cnt, group=group)
     torch.cuda.synchronize()
     wall["pmf"] = time.perf_counter() - t1
 
@@ -161,12 +169,15 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     if well_state is None:
         well_state = np.full(32, 0x55555555, dtype=np.uint32)
     main_stream = torch.cuda.current_stream()
-    draws = K.empty_matrix(n, c)             # allocated on the main stream (the caching allocator pools per stream)
     side = torch.cuda.Stream(device=dev)
-    side.wait_stream(main_stream)
-    with torch.cuda.stream(side):
-        with timer.span("well_draws"):
-            K.well_draws(well_state, first_read, n, c, out=draws)
+    if reuse is not None and reuse.get("draws") is not None:
+        draws = reuse["draws"]
+    else:
+        draws = K.empty_matrix(n, c)         # allocated on the main stream (the caching allocator pools per stream)
+        side.wait_stream(main_stream)
+        with torch.cuda.stream(side):
+            with timer.span("well_draws"):
+                K.well_draws(well_state, first_read, n, c, out=draws)
 
     # ---- codebooks (codebook.c:208-468), identical on every rank ----
     t2 = time.perf_counter()
@@ -186,7 +197,8 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     ddist = torch.from_numpy(dmat).to(dev)
     with timer.span("quantize"):
         out = K.quantize(sym, n, ct, qs, draws, ddist, labels=labels if k > 1 else None, k=k)
-    del draws
+    if not want_reuse and reuse is None:
+        del draws
     feed = None
     if coder != "gpu" or keep:
         with timer.span("pack_feed"):
@@ -223,8 +235,24 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     wall["total"] = time.perf_counter() - t0
     res = dict(stream_bytes=stream_sizes, total_stream_bytes=sum(stream_sizes), distortion=distortion,
                kmeans_iterations=iters, deferred=deferred, wall=wall, codebooks=cbs)
+    if want_reuse:
+        res["reuse"] = dict(labels=labels, means=means, kmeans_iterations=iters, cnt=cnt, draws=draws)
     if keep_device and coder != "host":
         res.update(coded=coded, cap_per_shard=coded.numel() // shards, qv=out["qv"], labels=labels)
     if keep:
         res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, err=out["err"], feed=feed, qi=out["qi"], st=out["st"])
     return res
+
+
+def rd_sweep(sym, n, first_read, n_total, means0, points, **kw):
+    """Rate-distortion sweep (reference generate_rd.sh:1-17): `points` is a list of
+    (mode, ratio, dist) operating points of the same input; cluster labels, PMF counters and WELL draws are computed for
+    the first point only. Every point's outputs equal those of a separate encode_pass. Returns the list of results."""
+    out, reuse = [], None
+    for mode, ratio, dist in points:
+        r = encode_pass(sym, n, first_read, n_total, means0, mode=mode, ratio=ratio, dist=dist, reuse=reuse,
+                        want_reuse=reuse is None, **kw)
+        if reuse is None:
+            reuse = r.pop("reuse")
+        out.append(r)
+    return out

@@ -161,3 +161,22 @@ def test_read_sharded_ranks_equal_single_pass():
         part = K.quantize(upload_sym(K, rows[a:b]), b - a, ct, qs, K.well_draws(O.WELL_DEBUG_STATE, a, b - a, c), dd)
         assert torch.equal(part["qv"][:, : b - a], full["qv"][:, a:b])
         assert torch.equal(part["err"], full["err"][a:b])
+
+
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_c3_f05_M"])
+def test_rd_sweep_equals_separate_encodes(name):
+    """Rate-distortion sweep (generate_rd.sh): labels, counters and draws computed once, every operating point must come
+    out exactly as a separate encode of the same input."""
+    from qvz_amd import host, pipeline as P
+    rows, opts, n, c, sym, means0 = setup_case(name)
+    points = [(host.MODE_RATIO, 0.3, "M"), (host.MODE_FIXED, 1.5, "L"), (host.MODE_RATIO, 0.8, "A"), (opts["mode"], opts["ratio"], opts["dist"])]
+    kw = dict(clusters=opts["k"], shards=3, coder="gpu", keep=True)
+    swept = P.rd_sweep(sym, n, 0, n, means0, points, **kw)
+    for (mode, ratio, dist), got in zip(points, swept):
+        alone = P.encode_pass(sym, n, 0, n, means0, mode=mode, ratio=ratio, dist=dist, **kw)
+        assert got["streams"] == alone["streams"]
+        assert got["distortion"] == alone["distortion"]
+        assert torch.equal(got["qv"][:, :n], alone["qv"][:, :n])
+    assert swept[-1]["total_stream_bytes"] >= G.CASES[name]["size"] * 0.98
+    rates = [8.0 * r["total_stream_bytes"] / (n * c) for r in swept[:3]]
+    assert rates[0] < rates[2]                       # -f 0.3 codes fewer bits than -f 0.8
