@@ -818,25 +818,25 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     };
     // Table look-up of a chunk (stage -> table offset -> alphabet size): three dependent LDS round trips that do not
     // depend on the counts, so they are issued one chunk ahead and overlap the barrier and the record drain.
-    uint32_t tb_nx = RK_NONE, x_lk = 0, card_nx = 0;
+    // Written without per-lane branches (selects and safe indices instead): every exec-mask change costs a wave
+    // several scalar instructions and their latencies.
+    uint32_t tb_nx = 0, x_lk = 0, card_nx = 1;
     bool ok_nx = false;
     auto lookup = [&](uint64_t rbn, uint32_t ch) {
-        tb_nx = RK_NONE; x_lk = 0; card_nx = 0; ok_nx = false;
-        const uint64_t r = rbn + lane;
-        if (!active || r >= r1) return;
+        const bool on = active && rbn + lane < r1;
         const uint32_t in_blk = (ch & 3) * 64 + lane;
-        const uint32_t q = stage[in_blk];
-        uint32_t x = stage[256 + in_blk], cl = 0;
-        if (HAVE_LABELS) {
-            const uint32_t raw = stage[512 + in_blk];
-            if (raw >= K) bad = true; else cl = raw;
-        }
-        if (cluster_wave) { tb_nx = 0; x = cl; }
-        else if (q < 2 * A) tb_nx = cof[cl * 2 * A + q];
-        ok_nx = tb_nx != RK_NONE;
-        if (ok_nx) { card_nx = tab[tb_nx + 1]; if (x >= card_nx) ok_nx = false; }
-        if (!ok_nx) bad = true;
-        x_lk = x;
+        const uint32_t q = stage[in_blk], xs = stage[256 + in_blk];
+        const uint32_t raw = HAVE_LABELS ? stage[512 + in_blk] : 0u;
+        const uint32_t cl = raw < K ? raw : 0u;
+        const uint32_t tbr = cof[cl * 2 * A + (q < 2 * A ? q : 0u)];
+        const uint32_t tb = cluster_wave ? 0u : (q < 2 * A ? tbr : (uint32_t)RK_NONE);
+        const uint32_t x = cluster_wave ? cl : xs;
+        bool ok = on && tb != RK_NONE && raw < K;
+        const uint32_t tbs = ok ? tb : 0u;                       // lanes without a symbol work on table 0 and contribute nothing
+        const uint32_t card = tab[tbs + 1];
+        ok = ok && x < card;
+        bad = bad || (on && !ok);
+        tb_nx = tbs; x_lk = ok ? x : 0u; card_nx = card; ok_nx = ok;
     };
     auto park = [&](uint64_t rbn) {                              // the requested dwords become the current block; request the next
         reinterpret_cast<uint32_t *>(stage)[lane] = q_nx;
@@ -856,27 +856,21 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             lookup(rb + 64, chunk + 1);
         }
         if (active) {
-            // every lane marks its table and its (table, state) entry
-            const unsigned long long bit = 1ull << lane;
-            if (ok) {
-                __hip_atomic_fetch_or(&msk[tb], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_or(&msk[tb + 2 + x], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            // every lane marks its table and its (table, state) entry (lanes without a symbol OR in nothing)
+            const unsigned long long bit = ok ? 1ull << lane : 0ull;
+            __hip_atomic_fetch_or(&msk[tb], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&msk[tb + 2 + x], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // counts before this chunk, and ranks inside it: earlier lanes with the same table (e), the same table and
             // state (E), a smaller state (L). cum_lo and L come from whichever end of the table is nearer
             // (sum over y < x directly, or n - c_x - sum over y > x).
-            uint32_t n_b = 0, c_x = 0, cum_b = 0, e = 0, E = 0, L = 0, hits = 0;
+            uint32_t cum_b = 0, L = 0;
             auto earlier = [](unsigned long long m, uint32_t add) -> uint32_t {     // add + popcount(m & lanes below me)
                 return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, add));
             };
-            if (ok) {
-                n_b = tab[tb];
-                c_x = tab[tb + 2 + x];
-                const unsigned long long mt = msk[tb];
-                e = earlier(mt, 0u);
-                hits = (uint32_t)__builtin_popcountll(mt);
-                E = earlier(msk[tb + 2 + x], 0u);
-            }
+            const uint32_t n_b = tab[tb], c_x = tab[tb + 2 + x];
+            const unsigned long long mt = msk[tb];
+            const uint32_t e = earlier(mt, 0u), hits = (uint32_t)__builtin_popcountll(mt);
+            const uint32_t E = earlier(msk[tb + 2 + x], 0u);
             {
                 const bool up = 2 * x < card;
                 uint32_t y = up ? 0u : x + 1, yend = up ? x : card, acc = 0, accm = 0;
@@ -895,14 +889,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 cum_b = up ? acc : n_b - c_x - acc;
                 L = up ? accm : e - E - accm;
             }
-            if (ok) { msk[tb] = 0ull; msk[tb + 2 + x] = 0ull; }  // leave the masks clean for the next chunk
+            msk[tb] = 0ull;                                      // leave the masks clean for the next chunk
+            msk[tb + 2 + x] = 0ull;
             const uint32_t key = ok ? ((tb << 8) | x) : 0xFFFFFFFFu;
             uint32_t n = n_b + STEP * e, fx = c_x + STEP * E, cum_lo = cum_b + STEP * L;
             if (!__ballot(ok && n_b + STEP * hits > RESCALE)) {
-                if (ok) {                                        // update_stats for the whole chunk (order-free sums)
-                    atomicAdd(&tab[tb + 2 + x], STEP);
-                    atomicAdd(&tab[tb], STEP);
-                }
+                const uint32_t step = ok ? STEP : 0u;            // update_stats for the whole chunk (order-free sums)
+                atomicAdd(&tab[tb + 2 + x], step);
+                atomicAdd(&tab[tb], step);
             } else {
                 // a table rescales inside this chunk: replay the chunk serially (qv_stream.c:9-25), every lane doing the
                 // same uniform work on the LDS tables, lane i keeping symbol i's values
@@ -929,7 +923,10 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                     if (lane == 0) tab[t] = nn;
                 }
             }
-            if (ok) outr = make_record(n, cum_lo, fx);
+            {
+                const Record rr = make_record(n ? n : 1u, cum_lo, fx);
+                outr = make_double2(ok ? rr.x : 0.0, ok ? rr.y : 0.0);
+            }
         }
         Record *buf = recbuf;
         __syncthreads();                                         // the previous chunk has been drained
