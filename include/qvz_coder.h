@@ -88,7 +88,7 @@ int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint6
  *          (arith.c:47-48), then E1/E2/E3 renormalisation (arith.c:50-97) and the bit output, split over three
  *          waves (record loader / interval chain / bit emitter) that hand blocks over through LDS.
  * Records pass through d_work (work_bytes, 16-byte aligned) in segments of as many reads per stream as fit:
- * 16 * shards * (columns + (clusters > 1)) bytes per read; d_work = NULL: a workspace of up to 4 GiB is allocated
+ * 16 bytes x (shards rounded up to 64) x (columns + (clusters > 1), rounded up to 8) per read; d_work = NULL: a workspace of up to 4 GiB is allocated
  * for the call. Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel
  * with one lane per (stream, column) and the tables in HBM.
  * d_labels must be readable up to n rounded up to a multiple of 4. The emitter checks its room once per 16 symbols:

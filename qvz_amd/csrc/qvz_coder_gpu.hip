@@ -641,6 +641,15 @@ __device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint3
     return make_double2((double)cum_lo * rn, (double)(n - cum_lo - fx) * rn);
 }
 
+// Record area of one segment. A read has Cp = Cx rounded up to 8 records (the pad records are zero = no-ops), streams
+// go in groups of 64 (one coder workgroup), and inside a group the lanes' blocks of 8 records lie side by side:
+// record t of stream g is at ((g / 64 * nblk8 + t / 8) * 64 + g % 64) * 8 + t % 8 with nblk8 = seg_reads * Cp / 8.
+// So the coder reads one contiguous 8 KiB per block of 8 symbols (sequential for HBM) instead of 64 runs of 128
+// bytes 2-30 MB apart, while the model kernel still writes W * 16-byte runs.
+__device__ __forceinline__ uint64_t rec_index(uint32_t g, uint64_t t, uint64_t nblk8) {
+    return (((uint64_t)(g >> 6) * nblk8 + (t >> 3)) * 64 + (g & 63)) * 8 + (t & 7);
+}
+
 template <bool HAVE_LABELS>
 __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                        const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
@@ -656,7 +665,8 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
     if (r0 >= rend) return;
     const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
     uint32_t *ar = arena + (uint64_t)g * arena_words;
-    Record *rp = rec + (uint64_t)g * seg_reads * Cx + sx;
+    const uint32_t Cp = (Cx + 7) & ~7u;
+    const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;
     const bool cluster_lane = HAVE_LABELS && sx == 0;
     const uint32_t s = HAVE_LABELS ? sx - 1 : sx;
     bool bad = false;
@@ -720,7 +730,9 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                     w = make_record(n, cum_lo, fx);
                 }
             }
-            rp[(r + j - r0) * Cx] = w;
+            rec[rec_index(g, (r + j - r0) * Cp + sx, nblk8)] = w;
+            if (sx + 1 == Cx)                                    // the read's pad records
+                for (uint32_t pc = Cx; pc < Cp; ++pc) rec[rec_index(g, (r + j - r0) * Cp + pc, nblk8)] = make_double2(0.0, 0.0);
         }
     }
     if (bad) atomicOr(status, 1);
@@ -773,6 +785,8 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     const uint32_t Cx = C + (HAVE_LABELS ? 1u : 0u);
     const uint32_t g = blockIdx.x, cg = blockIdx.y;
     const uint32_t sx = cg * W + wave;                           // position in the read's record group: [cluster id,] column 0 ..
+    const uint32_t Cp = (Cx + 7) & ~7u;
+    const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;
     const uint64_t r0 = first[g] + seg_lo, rend = first[g + 1];
     if (r0 >= rend) return;                                      // whole workgroup
     const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
@@ -934,8 +948,8 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         __syncthreads();
         {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
             const uint32_t rd = threadIdx.x >> log2w, cw = threadIdx.x & (W - 1);
-            if (rb + rd < r1 && cg * W + cw < Cx)
-                rec[((uint64_t)g * seg_reads + (rb - r0) + rd) * Cx + cg * W + cw] = buf[rd * rb_stride + cw];
+            if (rb + rd < r1 && cg * W + cw < Cp)                // columns Cx .. Cp-1 belong to idle waves: zero records
+                rec[rec_index(g, ((rb - r0) + rd) * Cp + cg * W + cw, nblk8)] = buf[rd * rb_stride + cw];
         }
     }
     if (active && !is_last)
@@ -958,6 +972,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
 // loader has parked records b; after it the interval wave codes block b, the bits wave block b-1, the bytes wave
 // block b-2. (Measured with a single emitter wave: emitter busy 1440 cycles per 8 symbols, loader 1190, chain 1070.)
 #define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps ~27 KB of LDS so that it fits beside the model kernel's workgroups)
+static_assert(CR_B == 8, "the record layout (rec_index) has 8 records per lane and block");
 #define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
 __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
@@ -970,11 +985,12 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
+    const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read (rec_index)
     if (wave == 0) asm volatile("s_setprio 3");                  // the latency chain issues ahead of the throughput kernels sharing the CU
     uint64_t T = 0;
     if (live) {
         const uint64_t rend = first[g + 1], a = first[g] + seg_lo, b = a + seg_reads;
-        if (a < rend) T = ((b < rend ? b : rend) - a) * Cx;
+        if (a < rend) T = ((b < rend ? b : rend) - a) * Cp;
     }
     uint64_t Tmax = T, Tmin = T;                                 // lanes past the last stream have T = 0 and are padded
     for (int o = 32; o > 0; o >>= 1) {
@@ -989,8 +1005,8 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
 
     if (wave == 3) {
         // ------------------------------------ loader ------------------------------------
-        const uint64_t total = (uint64_t)seg_reads * Cx;         // records in a stream's area
-        const Record *p = rec + (uint64_t)(live ? g : 0) * total;
+        const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // blocks of 8 records in a stream's area
+        const Record *p = rec + ((uint64_t)blockIdx.x * nblk8 * 64 + lane) * 8;   // + blk * 512 + i (rec_index)
         const uint64_t nfull = Tmin / CR_B;                      // blocks that are whole in every lane: no padding test
         // A register stage holds LD_B ring blocks (a 256-byte run of the lane's records); three stages in rotation
         // keep two of them (512 bytes per lane) in flight. No copies between stages: a copy would wait for its load.
@@ -998,8 +1014,8 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         auto load_stage = [&](uint64_t stg, Record *d) {
 #pragma unroll
             for (int i = 0; i < LD_B * CR_B; ++i) {
-                const uint64_t idx = stg * (LD_B * CR_B) + i;
-                d[i] = p[idx < total ? idx : total - 1];         // unconditional (clamped) so that vmcnt stays countable
+                const uint64_t blk = stg * LD_B + i / CR_B;      // unconditional (clamped) so that vmcnt stays countable
+                d[i] = p[(blk < nblk8 ? blk : nblk8 - 1) * 512 + (i % CR_B)];
             }
         };
         auto park = [&](uint64_t b, const Record *d) {           // block b -> slot b & 1, then barrier b
@@ -1311,7 +1327,8 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     int rc = QVZ_OK;
     int32_t status = 0;
     const size_t offn = (size_t)clusters * columns * 2 * A;
-    const uint64_t per_read = (uint64_t)shards * Cx * sizeof(Record);  // record bytes for one read of every stream
+    const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read incl. pad, streams padded to 64 (rec_index)
+    const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(Record);  // record bytes for one read of every stream
     uint64_t seg_reads = 0, seg_lo = 0;
 
     // Column slices for k_model_ranks: the tables of record position sx (all clusters) packed back to back, with
@@ -1447,12 +1464,12 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         seg_lo = (uint64_t)i * seg_reads;
         const uint32_t mblocks = (uint32_t)(((uint64_t)shards * Cx + 255) / 256);
         const int is_first = i == 0, is_last = i + 1 == nseg;
-        Record *buf = (Record *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * shards * Cx : 0);
+        Record *buf = (Record *)((char *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * per_read : 0));
         hipEvent_t *e = &evs[(size_t)i * 4];
         if (overlap && i >= 2) TRY(hipStreamWaitEvent(s_model, evs[(size_t)(i - 2) * 4 + 3], 0));   // the coder has drained this buffer
         TRY(hipEventRecord(e[0], s_model));
         if (rk_waves) {
-            const dim3 grid(shards, (Cx + rk_waves - 1) / rk_waves), block(64 * rk_waves);
+            const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves), block(64 * rk_waves);
             if (clusters > 1)
                 hipLaunchKernelGGL(k_model_ranks<true>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,

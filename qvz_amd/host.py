@@ -105,6 +105,12 @@ def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_pe
     return sizes, streams, out
 
 
+def planes_bytes_per_read(shards, columns, k):
+    """Record-workspace bytes that one read of every stream takes in qvz_hip_encode_planes: 16 bytes per record, streams
+    padded to a multiple of 64, records per read (columns + a cluster id when k > 1) padded to a multiple of 8."""
+    return 16 * ((shards + 63) // 64 * 64) * ((columns + (1 if k > 1 else 0) + 7) // 8 * 8)
+
+
 def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True,
                       work_bytes=None):
     """GPU sharded coder fed from the quantizer's planes (qvz_hip_encode_planes): the model runs with a lane per
@@ -119,7 +125,7 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
         per = (n + shards - 1) // shards + 4
         cap_per_shard = (per * columns * 3) // 4 + 512          # 6 bits/symbol + the 128-byte margin the emitter wants
     cap_per_shard = (cap_per_shard + 3) & ~3
-    per_read = 16 * shards * (columns + (1 if k > 1 else 0))
+    per_read = planes_bytes_per_read(shards, columns, k)
     longest = ((n + shards - 1) // shards + 7) & ~3
     if work_bytes is None:
         # default: everything at once, capped (QVZ_WORK_GIB, 48 GiB unless set); fewer, longer segments mean fewer

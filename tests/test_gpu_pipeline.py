@@ -78,7 +78,7 @@ def test_gpu_coder_streams_equal_host_coder_streams(name, shards):
     for g in range(shards):
         assert a["streams"][g] == b["streams"][g], f"shard {g} differs between host and GPU coder"
     # the record workspace squeezed to 8 reads per stream: many segments, coder state carried between launches
-    small = 16 * shards * (c + (1 if opts["k"] > 1 else 0)) * 8
+    small = host.planes_bytes_per_read(shards, c, opts["k"]) * 8
     d = P.encode_pass(sym, n, 0, n, means0, coder="gpu", work_bytes=small, **kw)
     assert d["streams"] == a["streams"], "segmented record workspace changed a stream"
     e = P.encode_pass(sym, n, 0, n, means0, coder="gpu-feed", **kw)
@@ -102,7 +102,7 @@ def test_gpu_model_kernels_agree(name, shards, monkeypatch):
     monkeypatch.setenv("QVZ_MODEL_KERNEL", "columns")
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards)
     assert streams == a["streams"]
-    small = 16 * shards * (c + (1 if opts["k"] > 1 else 0)) * 64       # 64 reads per segment
+    small = host.planes_bytes_per_read(shards, c, opts["k"]) * 64       # 64 reads per segment
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
     assert streams == a["streams"]
 
