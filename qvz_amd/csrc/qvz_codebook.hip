@@ -183,8 +183,10 @@ __global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict
                                                         const uint8_t *__restrict__ qprev,     // [144][72] tables of column s-1
                                                         const double *__restrict__ rprev,      // [72] ratios of column s-1
                                                         const double *__restrict__ prev_qpmf,  // [72][72]
-                                                        double *__restrict__ qpmf, double *__restrict__ xpmf) {
+                                                        double *__restrict__ qpmf, double *__restrict__ xpmf,
+                                                        uint32_t *__restrict__ stop) {
     extern __shared__ double lds[];
+    if (threadIdx.x < A) stop[threadIdx.x] = 0xFFFFFFFFu;        // the design window that follows starts with no stop marks
     double *bufA = lds;             // p_temp[k][j], later the final qpmf[x][idx]
     double *bufB = lds + A * A;     // raw sums before renormalisation
     const uint32_t tid = threadIdx.x;
@@ -495,10 +497,12 @@ struct CbWork {
     LmIn *lin = nullptr;
     LmDesign *lout = nullptr, *hout = nullptr;     // device window results and their pinned host mirror
     uint32_t *stop = nullptr;
+    uint8_t *pin = nullptr;                        // pinned staging for everything else that crosses PCIe per column
     void release() {
         void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, qprev, ctx_sym, lin, lout, stop};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (hout) (void)hipHostFree(hout);
+        if (pin) (void)hipHostFree(pin);
     }
 };
 
@@ -549,18 +553,23 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
     QVZ_HIP_CHECK(hipGetLastError());
 
-    LmIn hin[A];
+    // Per column two stream syncs (after the context propagation, after the design window). Everything copied per
+    // column sits in pinned memory (pageable hipMemcpyAsync calls block and go through a bounce buffer), and what the
+    // next column's propagation needs from this one is double-buffered so that no third sync is needed.
+    QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A), hipHostMallocDefault));
+    double *hx = reinterpret_cast<double *>(W.pin);
+    LmIn *hin = reinterpret_cast<LmIn *>(hx + tile);
+    double *hr2 = reinterpret_cast<double *>(hin + A);                  // [2][A]
+    uint8_t *hq2 = reinterpret_cast<uint8_t *>(hr2 + 2 * A);            // [2][2 * tile]
+    uint8_t *hu2 = hq2 + 2 * 2 * tile;                                  // [2][4 * A]
     LmDesign *hout = W.hout;
     LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
-    double hx[A * A];
-    uint8_t hq[2 * A * A];
-    double hr[A];
 
     // designs for the all-zero pmf depend only on (distortion, S): one launch, 72 waves
     ZeroDesign Z[A + 1];
-    memset(hin, 0, sizeof(hin));
+    memset(hin, 0, A * sizeof(LmIn));
     for (int S = 1; S <= A; ++S) { hin[S - 1].mode = 2; hin[S - 1].startS = (uint8_t)S; }
-    QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(hin), hipMemcpyHostToDevice, st));
+    QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, A * sizeof(LmIn), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_lm_window, dim3(A, 1), dim3(64), LM_LDS_BYTES, st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
     QVZ_HIP_CHECK(hipGetLastError());
     QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, A * sizeof(LmDesign), hipMemcpyDeviceToHost, st));
@@ -572,7 +581,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     int pq = 0;   // index of the qpmf buffer holding the previous column
     for (uint32_t s = 0; s < C; ++s) {
         uint32_t nu;
-        uint8_t uni[4 * A];
+        uint8_t *uni = hu2 + (size_t)(s & 1) * 4 * A;
         const double *d_rows;
         if (s == 0) {                                                               // codebook.c:392-411
             nu = 1;
@@ -588,7 +597,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             if (nu > A) return qvz_set_error(QVZ_E_DATA, "column %u: %u contexts exceed the alphabet", s, nu);
             QVZ_HIP_CHECK(hipMemcpyAsync(W.ctx_sym, uni, nu, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_ctx_propagate, dim3(1), dim3(1024), 2 * tile * sizeof(double), st, W.P, W.marg, s, nprev, nu,
-                               W.ctx_sym, W.qprev, W.rprev, W.qpmf[pq], W.qpmf[pq ^ 1], W.xpmf);
+                               W.ctx_sym, W.qprev, W.rprev, W.qpmf[pq], W.qpmf[pq ^ 1], W.xpmf, W.stop);
             QVZ_HIP_CHECK(hipGetLastError());
             pq ^= 1;
             d_rows = W.xpmf;
@@ -603,7 +612,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
         bool zero[A];
         double target[A];
         bool any_gpu = false;
-        memset(hin, 0, sizeof(hin));
+        memset(hin, 0, A * sizeof(LmIn));
         for (uint32_t j = 0; j < nu; ++j) {
             const double *pj = hx + (size_t)j * A;
             zero[j] = true;
@@ -616,10 +625,11 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
                 any_gpu = true;
             }
         }
-        uint32_t win = window0, smax = 1;
+        uint32_t win = window0, smax = 1, round = 0;
         while (any_gpu) {
             QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(LmIn) * nu, hipMemcpyHostToDevice, st));
-            QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));
+            if (s == 0 || round) QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));   // (k_ctx_propagate resets it otherwise)
+            ++round;
             hipLaunchKernelGGL(k_lm_window, dim3(nu, win), dim3(64), LM_LDS_BYTES, st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
             QVZ_HIP_CHECK(hipGetLastError());
             QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win, hipMemcpyDeviceToHost, st));
@@ -695,11 +705,12 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             cb->live[(size_t)s * A + j] = zero[j] ? 0 : 1;
         }
         // hand this column's tables and ratios to the next column's propagation
+        uint8_t *hq = hq2 + (size_t)(s & 1) * 2 * tile;   // slot s & 1: its last use (column s - 2) finished before column s - 1's syncs
+        double *hr = hr2 + (size_t)(s & 1) * A;
         memcpy(hq, cb->q + (size_t)s * 2 * tile, 2 * tile);
         for (uint32_t j = 0; j < A; ++j) hr[j] = j < nu ? cb->ratio[(size_t)s * A + j] : 0.0;
         QVZ_HIP_CHECK(hipMemcpyAsync(W.qprev, hq, 2 * tile, hipMemcpyHostToDevice, st));
-        QVZ_HIP_CHECK(hipMemcpyAsync(W.rprev, hr, sizeof(hr), hipMemcpyHostToDevice, st));
-        QVZ_HIP_CHECK(hipStreamSynchronize(st));   // hq / hr are stack buffers reused next column
+        QVZ_HIP_CHECK(hipMemcpyAsync(W.rprev, hr, A * sizeof(double), hipMemcpyHostToDevice, st));
         nprev = nu;
     }
     return QVZ_OK;
