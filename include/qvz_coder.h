@@ -85,8 +85,8 @@ int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint6
  *          bit-masks in LDS; chunks in which a table passes the rescale threshold (n > 2^19) are replayed serially.
  *          It leaves a 16-byte record per symbol: cum_lo / n and (n - cum_hi) / n as doubles (pre-scaled by 2^-10).
  *   coder  one lane per stream walks its records: two fused multiply-adds give the new bounds exactly
- *          (arith.c:47-48), then E1/E2/E3 renormalisation (arith.c:50-97) and the bit output, split over three
- *          waves (record loader / interval chain / bit emitter) that hand blocks over through LDS.
+ *          (arith.c:47-48), then E1/E2/E3 renormalisation (arith.c:50-97) and the bit output, split over four
+ *          waves (record loader / interval chain / pending-bit count / byte stream) that hand blocks over through LDS.
  * Records pass through d_work (work_bytes, 16-byte aligned) in segments of as many reads per stream as fit:
  * 16 bytes x (shards rounded up to 64) x (columns + (clusters > 1), rounded up to 8) per read; d_work = NULL: a workspace of up to 4 GiB is allocated
  * for the call. Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel
