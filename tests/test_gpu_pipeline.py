@@ -180,3 +180,29 @@ def test_rd_sweep_equals_separate_encodes(name):
     assert swept[-1]["total_stream_bytes"] >= G.CASES[name]["size"] * 0.98
     rates = [8.0 * r["total_stream_bytes"] / (n * c) for r in swept[:3]]
     assert rates[0] < rates[2]                       # -f 0.3 codes fewer bits than -f 0.8
+
+
+def test_rccl_group_of_one_rank_changes_nothing():
+    """The multi-GPU code path (RCCL all_reduce of k-means sums, counts, PMF counters and the distortion) on a
+    one-rank process group: same streams as without a group. (More ranks are covered on CPU with gloo, test_dist_cpu.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from qvz_amd import pipeline as P
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for name in ("t2k_c3_f05_M", "cfg1_f05_L"):
+            rows, opts, n, c, sym, means0 = setup_case(name)
+            kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=4, coder="gpu", keep=True)
+            a = P.encode_pass(sym, n, 0, n, means0, **kw)
+            b = P.encode_pass(sym, n, 0, n, means0, group=dist.group.WORLD, **kw)
+            assert a["streams"] == b["streams"] and a["distortion"] == b["distortion"]
+            assert a["kmeans_iterations"] == b["kmeans_iterations"]
+    finally:
+        dist.destroy_process_group()
