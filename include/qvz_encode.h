@@ -58,6 +58,15 @@ int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu,
 /* mmaps `in_path` like load_file (lines.c:27-82) and encodes it to `out_path`. */
 int qvz_encode_file(const char *in_path, const char *out_path, const qvz_options_t *opts, qvz_result_t *res);
 
+/* Sharded output (option B): the same pipeline, but the reads are cut into `shards` contiguous
+ * ranges (qvz_shard_bounds) coded as independent streams by the GPU coder, and every range is written as a complete
+ * reference-format file "<out_prefix>.0000", "<out_prefix>.0001", ...: header with the shard's line count, the whole
+ * file's codebooks, the WELL state advanced to the shard's first draw, the stream. The unmodified reference decoder
+ * decodes each; the decodes concatenate to the -u text of the single-stream encode. res->stream_bytes is the sum of
+ * the streams (what -s reports), res->file_bytes the sum of the files. */
+int qvz_encode_file_sharded(const char *in_path, const char *out_prefix, const qvz_options_t *opts, uint32_t shards,
+                            qvz_result_t *res);
+
 const char *qvz_encode_last_error(void);
 
 #ifdef __cplusplus

@@ -403,6 +403,128 @@ done:
     return rc;
 }
 
+/* start_qv_compression for sharded output (option B): the whole matrix is quantized on the GPU,
+ * `shards` contiguous read ranges are coded as independent streams by the GPU coder (qvz_hip_encode_planes), and every
+ * stream is written as a complete reference-format file "<prefix>.<g>" (header with the shard's line count, the whole
+ * file's codebooks, the WELL state advanced to the shard's first draw, the stream): the unmodified reference decoder
+ * decodes each, and the decodes concatenate to the -u text. The distortion is the reference's sequential sum. */
+int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
+                             double *distortion_out) {
+    int rc = 0;
+    const double t0 = now();
+    const uint32_t C = job->C, K = job->K;
+    const uint64_t N = job->N, ld = job->ld, stride = (uint64_t)C + 1;
+    uint16_t *d_ct = NULL, *d_qs = NULL, *h_ct = NULL, *h_qs = NULL;
+    double *d_dist = NULL, *d_err = NULL, *h_err = NULL;
+    uint8_t *d_draws = NULL, *d_qv = NULL, *d_qi = NULL, *d_st = NULL, *d_out = NULL, *d_text = NULL, *h_buf = NULL, *image = NULL;
+    int32_t *d_status = NULL, status = 0;
+    uint64_t *sizes = NULL, *first = NULL;
+    if (!shards || shards > N / 4 + 1) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads", shards, (unsigned long long)N);
+
+    if (job->opts.seed_mode == QVZ_SEED_EXPLICIT) {                             /* qv_stream.c:70-89 */
+        memcpy(job->well_state, job->opts.well_state, sizeof(job->well_state));
+    } else {
+        srand((uint32_t)time(0));
+        for (int i = 0; i < 32; ++i) job->well_state[i] = job->opts.seed_mode == QVZ_SEED_DEBUG ? 0x55555555u : (uint32_t)rand();
+    }
+    {
+        const size_t ctn = (size_t)K * C * QVZ_CT_STRIDE, qsn = (size_t)K * C * QVZ_QS_STRIDE;
+        h_ct = (uint16_t *)malloc(ctn * sizeof(uint16_t));
+        h_qs = (uint16_t *)malloc(qsn * sizeof(uint16_t));
+        sizes = (uint64_t *)calloc(shards, sizeof(uint64_t));
+        first = (uint64_t *)calloc((size_t)shards + 1, sizeof(uint64_t));
+        if (!h_ct || !h_qs || !sizes || !first) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        for (uint32_t j = 0; j < K; ++j)
+            qvz_codebook_tables(job->cbs[j], h_ct + (size_t)j * C * QVZ_CT_STRIDE, h_qs + (size_t)j * C * QVZ_QS_STRIDE);
+        HIP(qvz_hip_malloc((void **)&d_ct, ctn * sizeof(uint16_t)));
+        HIP(qvz_hip_malloc((void **)&d_qs, qsn * sizeof(uint16_t)));
+        HIP(qvz_hip_malloc((void **)&d_dist, sizeof(job->h_dist)));
+        HIP(qvz_hip_copy_h2d(d_ct, h_ct, ctn * sizeof(uint16_t), NULL));
+        HIP(qvz_hip_copy_h2d(d_qs, h_qs, qsn * sizeof(uint16_t), NULL));
+        HIP(qvz_hip_copy_h2d(d_dist, job->h_dist, sizeof(job->h_dist), NULL));
+    }
+    qvz_shard_bounds(N, shards, first);
+    /* WELL draws, quantizer */
+    HIP(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
+    HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
+    HIP(qvz_hip_malloc((void **)&d_qi, (size_t)C * ld));
+    HIP(qvz_hip_malloc((void **)&d_st, (size_t)C * ld));
+    HIP(qvz_hip_malloc((void **)&d_err, N * sizeof(double)));
+    HIP(qvz_hip_malloc((void **)&d_status, sizeof(int32_t)));
+    HIP(qvz_hip_memset(d_status, 0, sizeof(int32_t), NULL));
+    HIP(qvz_hip_well_draws(job->well_state, 0, N, C, d_draws, ld, NULL));
+    HIP(qvz_hip_quantize(job->d_sym, K > 1 ? job->d_labels : NULL, N, C, ld, K, d_ct, d_qs, d_draws, ld, d_dist, d_qv, d_qi, d_st,
+                         ld, d_err, d_status, NULL));
+    HIP(qvz_hip_copy_d2h(&status, d_status, sizeof(status), NULL));
+    HIP(qvz_hip_stream_sync(NULL));
+    if (status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
+    qvz_hip_free(d_draws); d_draws = NULL;
+    {   /* distortion: the reference's sequential sum over reads (qv_compressor.c:127,139-140) */
+        double distortion = 0.0;
+        h_err = (double *)malloc(N * sizeof(double));
+        if (!h_err) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        HIP(qvz_hip_copy_d2h(h_err, d_err, N * sizeof(double), NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+        for (uint64_t i = 0; i < N; ++i) distortion += h_err[i] / ((double)C);
+        if (distortion_out) *distortion_out = distortion / ((double)N);
+        free(h_err); h_err = NULL;
+        qvz_hip_free(d_err); d_err = NULL;
+    }
+    if (fu) {                                                                   /* -u text (qv_compressor.c:100-125) */
+        h_buf = (uint8_t *)malloc(N * stride);
+        if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        HIP(qvz_hip_malloc((void **)&d_text, N * stride));
+        HIP(qvz_hip_untranspose_text(d_qv, N, C, ld, d_text, NULL));
+        HIP(qvz_hip_copy_d2h(h_buf, d_text, N * stride, NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+        if (fwrite(h_buf, 1, N * stride, fu) != N * stride) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+        free(h_buf); h_buf = NULL;
+        qvz_hip_free(d_text); d_text = NULL;
+    }
+    qvz_hip_free(d_qv); d_qv = NULL;
+    {   /* coding: 6 bits per symbol of room per stream */
+        const uint64_t per = (N + shards - 1) / shards + 4;
+        const uint64_t cap = ((per * C * 3) / 4 + 512 + 3) & ~3ull;
+        uint64_t total = 0, img_cap = 0;
+        HIP(qvz_hip_malloc((void **)&d_out, (size_t)shards * cap));
+        if (qvz_hip_encode_planes(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
+                                  shards, d_out, cap, sizes, NULL, 0, NULL)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+        h_buf = (uint8_t *)malloc((size_t)shards * cap);
+        if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        HIP(qvz_hip_copy_d2h(h_buf, d_out, (size_t)shards * cap, NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+        for (uint32_t g = 0; g < shards; ++g) {
+            uint32_t wstate[32];
+            char name[4096];
+            const uint64_t reads = first[g + 1] - first[g];
+            FILE *f;
+            size_t need;
+            total += sizes[g];
+            if ((size_t)snprintf(name, sizeof(name), "%s.%04u", prefix, g) >= sizeof(name)) { rc = qvz_job_fail(QVZ_E_ARG, "output name too long"); goto done; }
+            HIP(qvz_hip_well_jump(job->well_state, first[g] * C / 4, wstate));   /* generator at the shard's first draw, n = 0 */
+            need = qvz_shard_file_image(NULL, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstate, NULL, sizes[g]);
+            if (need > img_cap) {
+                free(image);
+                image = (uint8_t *)malloc(need);
+                img_cap = need;
+                if (!image) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+            }
+            qvz_shard_file_image(image, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstate, h_buf + (size_t)g * cap, sizes[g]);
+            f = fopen(name, "wb");
+            if (!f) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
+            if (fwrite(image, 1, need, f) != need) { fclose(f); rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+            fclose(f);
+        }
+        if (stream_bytes) *stream_bytes = total;
+    }
+    job->t_encode = now() - t0;
+done:
+    free(h_ct); free(h_qs); free(sizes); free(first); free(h_err); free(h_buf); free(image);
+    qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist); qvz_hip_free(d_err); qvz_hip_free(d_draws); qvz_hip_free(d_qv);
+    qvz_hip_free(d_qi); qvz_hip_free(d_st); qvz_hip_free(d_out); qvz_hip_free(d_text); qvz_hip_free(d_status);
+    return rc;
+}
+
 void qvz_job_release(qvz_job_t *job) {
     if (job->cbs) { for (uint32_t j = 0; j < job->K; ++j) qvz_codebook_free(job->cbs[j]); free(job->cbs); }
     free(job->h_labels); free(job->h_means); free(job->h_counts); free(job->h_acc);
@@ -412,8 +534,16 @@ void qvz_job_release(qvz_job_t *job) {
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
+static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
+                         qvz_result_t *res, const char *shard_prefix, uint32_t shards);
+
 int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
                       qvz_result_t *res) {
+    return encode_buffer(text, bytes, fout, fu, opts, res, NULL, 0);
+}
+
+static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
+                         qvz_result_t *res, const char *shard_prefix, uint32_t shards) {
     qvz_job_t job;
     qvz_result_t R;
     memset(&R, 0, sizeof(R));
@@ -427,11 +557,17 @@ int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu,
     if ((rc = qvz_job_stats(&job))) goto done;
     if ((rc = qvz_job_codebooks(&job))) goto done;
     if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", job.t_stats + job.t_codebook);   /* main.c:66-67 */
-    if ((rc = qvz_job_write_codebooks(&job, fout, &head_bytes))) goto done;
-    if ((rc = qvz_job_compress(&job, fout, fu, &R.stream_bytes, &R.distortion))) goto done;
+    if (shards) {
+        if ((rc = qvz_job_compress_sharded(&job, shard_prefix, fu, shards, &R.stream_bytes, &R.distortion))) goto done;
+        head_bytes = qvz_shard_file_image(NULL, job.K, job.C, 0, (const qvz_codebook_t *const *)job.cbs, job.well_state, NULL, 0) - 128;
+        R.file_bytes = (uint64_t)shards * (head_bytes + 128) + R.stream_bytes;
+    } else {
+        if ((rc = qvz_job_write_codebooks(&job, fout, &head_bytes))) goto done;
+        if ((rc = qvz_job_compress(&job, fout, fu, &R.stream_bytes, &R.distortion))) goto done;
+        R.file_bytes = head_bytes + 128 + R.stream_bytes;
+    }
     R.lines = job.N;
     R.columns = job.C;
-    R.file_bytes = head_bytes + 128 + R.stream_bytes;
     R.kmeans_iterations = job.kmeans_iterations;
     R.deferred_decisions = job.deferred_decisions;
     R.t_upload = job.t_upload; R.t_cluster = job.t_cluster; R.t_stats = job.t_stats; R.t_codebook = job.t_codebook;
@@ -476,6 +612,27 @@ int qvz_encode_file(const char *in_path, const char *out_path, const qvz_options
     const int rc = qvz_encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, fout, fu, opts, res);
     if (fu) fclose(fu);
     fclose(fout);
+    munmap(map, (size_t)st.st_size);
+    close(fd);
+    return rc;
+}
+
+int qvz_encode_file_sharded(const char *in_path, const char *out_prefix, const qvz_options_t *opts, uint32_t shards,
+                            qvz_result_t *res) {
+    if (!shards) return qvz_job_fail(QVZ_E_ARG, "shards must be positive");
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) return qvz_job_fail(QVZ_E_ARG, "load_file returned error: 1");
+    struct stat st;
+    if (fstat(fd, &st) || st.st_size == 0) { close(fd); return qvz_job_fail(QVZ_E_DATA, "empty or unreadable input"); }
+    void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    if (map == MAP_FAILED) { close(fd); return qvz_job_fail(QVZ_E_NOMEM, "mmap failed"); }
+    FILE *fu = NULL;
+    if (opts->uncompressed_name) {
+        fu = fopen(opts->uncompressed_name, "w");
+        if (!fu) { munmap(map, (size_t)st.st_size); close(fd); return qvz_job_fail(QVZ_E_ARG, "Unable to open uncompressed file"); }
+    }
+    const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, NULL, fu, opts, res, out_prefix, shards);
+    if (fu) fclose(fu);
     munmap(map, (size_t)st.st_size);
     close(fd);
     return rc;

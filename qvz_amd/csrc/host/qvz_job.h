@@ -51,6 +51,9 @@ int qvz_job_codebooks(qvz_job_t *job);                    /* generate_codebooks 
 int qvz_job_write_codebooks(qvz_job_t *job, FILE *fout, uint64_t *bytes);   /* write_codebooks             */
 /* start_qv_compression: writes the WELL state and the stream to fout, the -u text to fu (may be NULL) */
 int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_bytes, double *distortion);
+/* the same for sharded output: `shards` reference-format files "<prefix>.<g>" coded by the GPU coder */
+int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
+                             double *distortion);
 void qvz_job_release(qvz_job_t *job);
 
 int qvz_job_fail(int code, const char *fmt, ...);

@@ -107,7 +107,10 @@ int main(int argc, char **argv) {
     if (getenv("QVZ_CHUNK_READS")) opts.chunk_reads = strtoull(getenv("QVZ_CHUNK_READS"), 0, 10);
 
     qvz_result_t res;
-    const int rc = qvz_encode_file(input_name, output_name, &opts, &res);
+    /* QVZ_SHARDS=N (not a reference option, so not on the command line): N reference-format files <output>.0000 ... */
+    const uint32_t shards = getenv("QVZ_SHARDS") ? (uint32_t)strtoul(getenv("QVZ_SHARDS"), 0, 10) : 0;
+    const int rc = shards ? qvz_encode_file_sharded(input_name, output_name, &opts, shards, &res)
+                          : qvz_encode_file(input_name, output_name, &opts, &res);
     if (rc) {
         printf("%s\n", qvz_encode_last_error());                  /* reference: printf + exit(1), main.c:43-46 */
         exit(1);

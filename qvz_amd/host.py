@@ -54,6 +54,24 @@ def encode_file(in_path, out_path, clusters=1, mode=MODE_RATIO, ratio=0.5, dist=
     return r
 
 
+def encode_file_sharded(in_path, out_prefix, shards, clusters=1, mode=MODE_RATIO, ratio=0.5, dist="M", threshold=4.0,
+                        u_path=None, seed_mode=None, device=0):
+    """Whole-file encode with sharded output (qvz_encode_file_sharded): writes out_prefix.0000 ... as reference-format
+    files coded by the GPU coder. Returns a Result."""
+    o = default_options()
+    o.clusters, o.mode, o.ratio, o.distortion, o.cluster_threshold = clusters, mode, ratio, DIST.get(dist, dist), threshold
+    o.device = device
+    if u_path:
+        o.uncompressed_name = u_path.encode()
+    if seed_mode is not None:
+        o.seed_mode = seed_mode
+    r = Result()
+    rc = lib().qvz_encode_file_sharded(in_path.encode(), out_prefix.encode(), C.byref(o), shards, C.byref(r))
+    if rc:
+        raise QvzHipError(f"qvz_encode_file_sharded failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return r
+
+
 def shard_bounds(n, shards):
     """first[g] for g = 0..shards; every shard starts at a multiple of 4 reads (a WELL word boundary)."""
     first = (C.c_uint64 * (shards + 1))()

@@ -120,3 +120,48 @@ def test_cli_verbose_lines_and_errors(tmp_path):
     bad.write_bytes(rows.tobytes())
     r = subprocess.run([QVZ_BIN, str(bad), str(tmp_path / "o.q")], capture_output=True, text=True)
     assert r.returncode == 1 and "outside" in r.stdout
+
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "qvz_ref")
+
+
+def decode_with_reference_or_oracle(path, tmp_path):
+    """`qvz -x` of the unmodified reference when its binary travelled with the repo (oracle/_ref), else the oracle's decoder."""
+    if os.path.exists(REF_BIN):
+        out = str(tmp_path / (os.path.basename(path) + ".dec"))
+        subprocess.run([REF_BIN, "-x", path, out], check=True, capture_output=True)
+        return open(out, "rb").read()
+    return O.decode(open(path, "rb").read())
+
+
+@pytest.mark.parametrize("name,shards", [("t2k_r10_M", 3), ("t2k_c3_f05_M", 2), ("cfg1_f05_L", 7), ("wide_c151", 2)])
+def test_sharded_files_decode_with_the_reference_decoder(tmp_path, name, shards):
+    """QVZ_SHARDS / qvz_encode_file_sharded: every <prefix>.<g> is a complete reference-format file; decoded one by one
+    (by the reference binary itself where it is available) and concatenated they give the reference's -u text."""
+    from qvz_amd import host
+    e = G.CASES[name]
+    inp, rows = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    prefix, u = str(tmp_path / "sh.q"), str(tmp_path / "sh.u")
+    fresh_process_rand()
+    r = host.encode_file_sharded(inp, prefix, shards, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"],
+                                 dist=opts["dist"], u_path=u, seed_mode=host.SEED_DEBUG)
+    assert G.md5(open(u, "rb").read()) == e["u_md5"]
+    files = [f"{prefix}.{g:04d}" for g in range(shards)]
+    decoded = b"".join(decode_with_reference_or_oracle(f, tmp_path) for f in files)
+    assert G.md5(decoded) == e["u_md5"]
+    assert r.file_bytes == sum(os.path.getsize(f) for f in files)
+    assert f"{r.distortion:.4f}" == f"{e['distortion']:.4f}"
+    assert r.stream_bytes >= e["size"] * 0.98
+
+
+def test_cli_qvz_shards_env(tmp_path):
+    name = "t2k_r10_M"
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    q = str(tmp_path / "cli_sh.q")
+    env = dict(os.environ, QVZ_WELL_SEED="debug", QVZ_SHARDS="4")
+    out = subprocess.run([QVZ_BIN] + e["flags"].split() + ["-s", inp, q], env=env, capture_output=True, text=True, check=True).stdout
+    assert re.search(r"rate, [\d.]+, distortion, ([\d.]+)", out).group(1) == f"{e['distortion']:.4f}"
+    decoded = b"".join(decode_with_reference_or_oracle(f"{q}.{g:04d}", tmp_path) for g in range(4))
+    assert G.md5(decoded) == e["u_md5"]
