@@ -185,21 +185,9 @@ __global__ __launch_bounds__(64) void k_arith_shards(const uint16_t *__restrict_
     if (c.overflow) atomicOr(status, 2);
 }
 
-// ---- software-pipelined variant -------------------------------------------------------------------------------
-// The simple kernel above is a chain of four dependent memory round trips per symbol (feed -> table offset ->
-// table -> interval). Here the data-independent part runs ahead of the interval chain in blocks of 4 symbols:
-//   iteration b:  issue table-header loads for block b+1 (offsets loaded one iteration ago)
-//                 issue offset look-ups      for block b+2 (feed loaded one iteration ago)
-//                 issue the 8-byte feed load for block b+3
-//                 then code block b from registers: {n, card, c0..c5} of each table were loaded one block ago.
-// Tables start on 16-byte boundaries (QVZ_MODEL_ALIGN16) so a header is two dwordx4 loads. A header prefetched up
-// to 7 symbols early is still current because two symbols less than C apart never share a table (a table belongs
-// to one column); hence the kernel is used for C >= 8 only.
-//
-// Measured limits (MI355X, 100M x 150): the compiler still drains vmcnt(0) around the
-// data-dependent stores, but giving the loads a wave of their own (loader wave -> LDS ring -> coder wave, tried and
-// removed) did not make a stream faster: a lone wave issues one VALU instruction per ~4 cycles and the per-symbol
-// chain is ~450 instructions (~0.9 us). Stream speed is instruction-count bound; throughput scales with streams.
+// ---- helpers of the model-wave / coder-wave kernel below --------------------------------------------------------
+// (A software-pipelined single-wave variant - feed, table offsets and table headers prefetched a block ahead - stood
+// here until the kernels further down replaced it: 1.72 s on the 100M x 150 workload)
 struct Hdr { uint4 a, b; };   // a = {n, card, c0, c1}, b = {c2, c3, c4, c5}
 
 // Branch-light interval step. Lanes of a wave are different streams, so every data-dependent `if` costs the whole
@@ -248,148 +236,6 @@ __device__ __forceinline__ void lc_interval(LaneCoder &c, uint32_t n, uint32_t c
     c.u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
 }
 
-__device__ __forceinline__ void lc_encode_hdr(LaneCoder &c, uint32_t *__restrict__ t, const Hdr &h, uint32_t x) {
-    const uint32_t n = h.a.x, card = h.a.y;
-    uint32_t cum_lo, fx;
-    if (x < 6) {
-        const uint32_t c0 = h.a.z, c1 = h.a.w, c2 = h.b.x, c3 = h.b.y, c4 = h.b.z, c5 = h.b.w;
-        cum_lo = (x > 0 ? c0 : 0u) + (x > 1 ? c1 : 0u) + (x > 2 ? c2 : 0u) + (x > 3 ? c3 : 0u) + (x > 4 ? c4 : 0u);
-        fx = x == 0 ? c0 : x == 1 ? c1 : x == 2 ? c2 : x == 3 ? c3 : x == 4 ? c4 : c5;
-    } else {
-        cum_lo = h.a.z + h.a.w + h.b.x + h.b.y + h.b.z + h.b.w;
-        for (uint32_t i = 6; i < x; ++i) cum_lo += t[2 + i];
-        fx = t[2 + x];
-    }
-    lc_interval(c, n, cum_lo, fx);
-    t[2 + x] = fx + STEP;
-    uint32_t nn = n + STEP;
-    if (nn > RESCALE) {
-        nn = 0;
-        for (uint32_t i = 0; i < card; ++i) {
-            const uint32_t v = t[2 + i];
-            if (v) { const uint32_t hv = (v >> 1) + 1; t[2 + i] = hv; nn += hv; }
-        }
-    }
-    t[0] = nn;
-}
-
-template <bool HAVE_LABELS>
-__global__ __launch_bounds__(64) void k_arith_shards_pf(const uint16_t *__restrict__ feed, const uint8_t *__restrict__ labels,
-                                                        uint32_t C, uint32_t K, const uint64_t *__restrict__ first,
-                                                        uint32_t shards, const uint32_t *__restrict__ off,
-                                                        uint32_t *__restrict__ arena, uint32_t arena_words,
-                                                        uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ sizes,
-                                                        int32_t *__restrict__ status) {
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= shards) return;
-    const uint64_t r0 = first[g], r1 = first[g + 1];
-    const uint64_t T = (r1 - r0) * C;                            // symbols of this shard
-    const uint16_t *fbase = feed + r0 * C;                       // 8-byte aligned: r0 is a multiple of 4
-    uint32_t *ar = arena + (uint64_t)g * arena_words;
-    LaneCoder c;
-    c.l = 0; c.u = MASK_M; c.scale3 = 0; c.nbits = 0; c.acc = 0;
-    c.out = out + (uint64_t)g * cap; c.pos = 0; c.cap = cap; c.overflow = false;
-    bool bad = false;
-
-    auto load_feed = [&](uint64_t blk) -> uint2 {                // 4 feed entries of block blk
-        const uint64_t t0 = blk * 4;
-        if (t0 + 4 <= T) return *reinterpret_cast<const uint2 *>(fbase + t0);
-        uint32_t v[4] = {0, 0, 0, 0};
-        for (int j = 0; j < 4; ++j) if (t0 + j < T) v[j] = fbase[t0 + j];
-        return make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
-    };
-    auto entry = [](const uint2 &w, int j) -> uint32_t { return ((j < 2 ? w.x : w.y) >> (16 * (j & 1))) & 0xFFFF; };
-    auto label_of = [&](uint64_t i) -> uint32_t {
-        if (!HAVE_LABELS) return 0u;
-        const uint32_t cl = labels[i];
-        return cl < K ? cl : 0u;
-    };
-
-    // prefetch cursor: (read, column) of the next symbol whose table offset has not been looked up yet
-    uint64_t pi = r0;
-    uint32_t ps = 0;
-    const uint32_t *poffc = off + (uint64_t)(r0 < r1 ? label_of(r0) : 0u) * C * 2 * A;
-    auto lookup_block = [&](const uint2 &w, uint64_t blk, uint32_t *o) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (blk * 4 + j < T) {
-                const uint32_t qi = entry(w, j) & 0xFF;
-                o[j] = qi < 2 * A ? poffc[ps * 2 * A + qi] : NO_TABLE;
-                if (++ps == C) {
-                    ps = 0;
-                    ++pi;
-                    if (pi < r1) poffc = off + (uint64_t)label_of(pi) * C * 2 * A;
-                }
-            } else {
-                o[j] = NO_TABLE;
-            }
-        }
-    };
-    auto load_hdrs = [&](const uint32_t *o, Hdr *h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(ar + (o[j] == NO_TABLE ? 0u : o[j]));
-            h[j].a = p[0];
-            h[j].b = p[1];                                       // may over-read into the next table: never used then
-        }
-    };
-
-    uint2 f0 = load_feed(0), f1 = load_feed(1), f2 = load_feed(2);
-    uint32_t o_cur[4], o_next[4], o_nn[4];
-    Hdr h_cur[4], h_next[4];
-    lookup_block(f0, 0, o_cur);
-    lookup_block(f1, 1, o_next);
-    load_hdrs(o_cur, h_cur);
-
-    uint64_t ci = r0;        // compute cursor
-    uint32_t cs = 0;
-    const uint64_t nblk = (T + 3) / 4;
-    for (uint64_t b = 0; b < nblk; ++b) {
-        load_hdrs(o_next, h_next);                               // block b+1
-        lookup_block(f2, b + 2, o_nn);                           // block b+2
-        const uint2 f3 = load_feed(b + 3);                       // block b+3
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (b * 4 + j < T) {
-                if (HAVE_LABELS) {
-                    if (cs == 0) {
-                        const uint32_t raw = labels[ci];
-                        if (raw >= K) bad = true;
-                        lc_encode(c, ar, raw < K ? raw : 0u);    // qv_write_cluster: table 0, straight from memory
-                    }
-                    if (++cs == C) { cs = 0; ++ci; }
-                }
-                const uint32_t st = entry(f0, j) >> 8;
-                const uint32_t o = o_cur[j];
-                if (o == NO_TABLE || st >= h_cur[j].a.y) bad = true;
-                else lc_encode_hdr(c, ar + o, h_cur[j], st);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { h_cur[j] = h_next[j]; o_cur[j] = o_next[j]; o_next[j] = o_nn[j]; }
-        f0 = f1; f1 = f2; f2 = f3;
-    }
-
-    const uint32_t bb = c.l >> (M_BITS - 1);                     // encoder_last_step + stream_finish_byte
-    lc_put(c, bb, 1);
-    if (c.scale3) { lc_run(c, !bb, c.scale3); c.scale3 = 0; }
-    lc_put(c, c.l & MASK_M1, M_BITS - 1);
-    uint64_t total_bits = c.pos * 8 + c.nbits;
-    if (total_bits % 8) { const uint32_t pad = 8 - (uint32_t)(total_bits % 8); lc_put(c, 0, pad); total_bits += pad; }
-    else { lc_put(c, 0, 8); total_bits += 8; }
-    const uint64_t bytes = total_bits / 8;
-    while (c.nbits) {
-        const uint32_t take = c.nbits >= 8 ? 8 : c.nbits;
-        const uint8_t byte = (uint8_t)((c.acc >> (c.nbits - take)) << (8 - take));
-        if (c.pos < c.cap) c.out[c.pos] = byte; else c.overflow = true;
-        c.pos += 1;
-        c.nbits -= take;
-    }
-    sizes[g] = bytes;
-    if (bad) atomicOr(status, 1);
-    if (c.overflow) atomicOr(status, 2);
-}
-
 // ---- model wave + coder wave ---------------------------------------------------------------------------------------
 // A stream's speed is its instruction count (see above), so the per-symbol chain is cut in two and run on two SIMDs.
 // Workgroup = 2 waves serving the same 64 streams:
@@ -401,7 +247,7 @@ __global__ __launch_bounds__(64) void k_arith_shards_pf(const uint16_t *__restri
 // The model never needs the coder's state and the coder never needs the tables, so the two chains are independent
 // given the triples; one raw s_barrier per block (no fence: __syncthreads() would drain vmcnt) and two ring slots
 // keep the model at most one block ahead. The tables are private to the model wave, so its header prefetch is safe
-// for the same reason as in k_arith_shards_pf (a table is touched again only C symbols later; C >= 32 here).
+// because a table is touched again only C symbols later (a table belongs to one column; C >= 32 here).
 #define MC_BS 8
 template <bool HAVE_LABELS>
 __global__ __launch_bounds__(128) void k_arith_shards_mc(const uint16_t *__restrict__ feed, const uint8_t *__restrict__ labels,
@@ -812,6 +658,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
     __syncthreads();
 
+    Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index)
     bool bad = false;
     uint32_t chunk = 0;
     // Input staging: a wave takes its column 256 reads at a time (one dword per lane and plane = 256 contiguous bytes)
@@ -948,8 +795,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         __syncthreads();
         {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
             const uint32_t rd = threadIdx.x >> log2w, cw = threadIdx.x & (W - 1);
-            if (rb + rd < r1 && cg * W + cw < Cp)                // columns Cx .. Cp-1 belong to idle waves: zero records
-                rec[rec_index(g, ((rb - r0) + rd) * Cp + cg * W + cw, nblk8)] = buf[rd * rb_stride + cw];
+            const uint32_t col = cg * W + cw;                    // rec_index with the stream's part hoisted out of the loop
+            if (rb + rd < r1 && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
+                rec_g[(((uint32_t)(rb - r0) + rd) * (Cp >> 3) + (col >> 3)) * 512 + (col & 7)] = buf[rd * rb_stride + cw];
         }
     }
     if (active && !is_last)
@@ -1268,13 +1116,6 @@ extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_la
                                clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
         else
             hipLaunchKernelGGL(k_arith_shards_mc<false>, dim3((shards + 63) / 64), dim3(128), 0, st, d_feed, d_labels, columns,
-                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
-    } else if (columns >= 8 && !(variant && strcmp(variant, "simple") == 0)) {
-        if (clusters > 1)
-            hipLaunchKernelGGL(k_arith_shards_pf<true>, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns,
-                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
-        else
-            hipLaunchKernelGGL(k_arith_shards_pf<false>, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns,
                                clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
     } else {
         hipLaunchKernelGGL(k_arith_shards, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns, clusters,
