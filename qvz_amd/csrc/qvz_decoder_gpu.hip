@@ -20,6 +20,8 @@
 // change, 64-bit comparison.
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -77,16 +79,31 @@ __device__ __forceinline__ uint32_t ld_take(LaneDecoder &d, uint32_t nb) {   // 
 
 // One symbol with table t ([n][card][counts...]); returns the state, or card on a corrupt stream.
 __device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restrict__ t, bool last) {
-    const uint32_t n = t[0], card = t[1];
+    // The first 14 counts come in with the header in four independent 16-byte loads (tables are 16-byte aligned and
+    // the arena has slack behind it), so the cumulative search runs in registers: walking the counts one dependent
+    // load at a time cost several cache round trips per symbol.
+    const uint4 h0 = reinterpret_cast<const uint4 *>(t)[0], h1 = reinterpret_cast<const uint4 *>(t)[1],
+                h2 = reinterpret_cast<const uint4 *>(t)[2], h3 = reinterpret_cast<const uint4 *>(t)[3];
+    const uint32_t n = h0.x, card = h0.y;
+    const uint32_t cn[14] = {h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
     const uint32_t range = d.u - d.l + 1;
     const uint64_t gap = (uint64_t)(d.t - d.l) + 1;
     const uint32_t sub = dec_div(gap * n - 1, range);           // arith.c:134 / :199 (below n, so 32 bits hold it either way)
-    uint32_t cum = 0, k = 0;
-    while (k < card && sub >= cum) cum += t[2 + k++];            // arith.c:136-139
+    uint32_t cum = 0, k = 0, fxr = 0;                            // arith.c:136-139: first k with c_0 + .. + c_k > sub
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const bool take = !found && (uint32_t)i < card && sub >= cum;
+        cum += take ? cn[i] : 0u;
+        fxr = take ? cn[i] : fxr;
+        k += take ? 1u : 0u;
+        found = found || !take;
+    }
+    while (k >= 14 && k < card && sub >= cum) { fxr = t[2 + k++]; cum += fxr; }   // long tables: the rest from memory
     if (sub >= cum) return card;                                 // ran off the table: not a stream of this model
     const uint32_t x = k - 1;
     if (last) return x;                                          // decoder_last_step: nothing else changes
-    const uint32_t fx = t[2 + x], cum_lo = cum - fx;
+    const uint32_t fx = fxr, cum_lo = cum - fx;
     uint32_t u = d.l + dec_div((uint64_t)range * cum, n) - 1;    // arith.c:146-147
     uint32_t l = d.l + dec_div((uint64_t)range * cum_lo, n);
     uint32_t tg = d.t;
@@ -118,15 +135,25 @@ __device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restri
     return x;
 }
 
-template <bool HAVE_LABELS>
+// The per-symbol chain is context -> table -> output alphabet. Two of its three memory round trips are shortened:
+//  * `ctx2[cluster][column][previous value]` = {lo table offset | qratio << 24, hi table offset}: one look-up instead
+//    of context index, then table offset; it lives in LDS when it fits beside the staging area (CTX_LDS);
+//  * the output alphabet (reconstruction points) of a quantizer is appended to its model table in the arena
+//    ([n][card][counts...][recon bytes...]), so the value comes out of the cache line the decode just used.
+template <bool HAVE_LABELS, bool CTX_LDS>
 __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict__ in, uint64_t cap, const uint64_t *__restrict__ sizes,
                                                       const uint64_t *__restrict__ first, uint32_t shards, uint32_t C, uint32_t K,
-                                                      const uint16_t *__restrict__ ct, const uint8_t *__restrict__ recon,
-                                                      const uint32_t *__restrict__ off, uint32_t *__restrict__ arena,
+                                                      const uint2 *__restrict__ ctx2, uint32_t *__restrict__ arena,
                                                       uint32_t arena_words, const uint8_t *__restrict__ draws, uint64_t ld,
                                                       uint8_t *__restrict__ qv, uint8_t *__restrict__ labels,
                                                       int32_t *__restrict__ status) {
-    extern __shared__ uint32_t stage[];                          // [C][64] dwords: 4 reads of a column per lane
+    extern __shared__ uint32_t stage[];                          // [C][64] dwords: 4 reads of a column per lane; then ctx2 (CTX_LDS)
+    uint2 *lctx = reinterpret_cast<uint2 *>(stage + (size_t)C * 64);
+    if (CTX_LDS) {
+        for (uint32_t i = threadIdx.x; i < K * C * A; i += 64) lctx[i] = ctx2[i];
+        __syncthreads();
+    }
+    const uint2 *cx = CTX_LDS ? lctx : ctx2;
     const uint32_t lane = threadIdx.x;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
@@ -146,6 +173,13 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
 
     for (uint64_t i = 0; i < most; ++i) {
         const bool on = i < nreads && !bad;
+        if ((i & 3) == 0 && i < nreads) {
+            // the WELL draws of the next 4 reads, all columns, in one burst of independent dword loads (fetched one by
+            // one inside the symbol chain each of them was a cache miss of its own); a draw sits in the staging byte
+            // that the decoded value of the same (read, column) overwrites
+            for (uint32_t s = 0; s < C; ++s)
+                stage[s * 64 + lane] = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)s * ld + r0 + i);
+        }
         if (on) {
             uint32_t cl = 0;
             if (HAVE_LABELS) {                                   // qv_read_cluster, qv_compressor.c:36-43
@@ -155,17 +189,16 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
             }
             uint32_t prev = 0;
             for (uint32_t s = 0; s < C && !bad; ++s) {
-                const uint32_t cv = ct[((uint64_t)cl * C + s) * QVZ_CT_STRIDE + prev];
-                const uint32_t ctx = cv & 0xFF;
-                if (ctx == QVZ_NOT_FOUND) { bad = true; break; }
-                const uint32_t draw = draws[(uint64_t)s * ld + r0 + i] & 127;        // well.c:33-46
-                const uint32_t qi = 2 * ctx + (draw >= (cv >> 8) ? 1u : 0u);        // codebook.c:165-170
-                const uint32_t o = off[((uint64_t)cl * C + s) * 2 * A + qi];
-                if (o == NO_TABLE) { bad = true; break; }
+                const uint2 cv = cx[((size_t)cl * C + s) * A + prev];
+                if (cv.x == NO_TABLE) { bad = true; break; }                         // previous value is no context of this column
+                const uint32_t draw = sb[(s * 64 + lane) * 4 + (uint32_t)(i & 3)] & 127;   // well.c:33-46
+                const uint32_t o = draw >= (cv.x >> 24) ? cv.y : (cv.x & 0xFFFFFFu); // hi : lo quantizer, codebook.c:165-170
+                if (o == 0xFFFFFFu) { bad = true; break; }                           // dead context: no table
                 const bool last = i + 1 == nreads && s + 1 == C;                     // qv_compressor.c:222-225
                 const uint32_t x = ld_decode(d, ar + o, last);
-                if (x >= ar[o + 1]) { bad = true; break; }
-                prev = recon[(((uint64_t)cl * C + s) * 2 * A + qi) * A + x];
+                const uint32_t card = ar[o + 1];
+                if (x >= card) { bad = true; break; }
+                prev = (ar[o + 2 + card + (x >> 2)] >> (8 * (x & 3))) & 0xFF;        // the quantizer's output alphabet
                 sb[(s * 64 + lane) * 4 + (uint32_t)(i & 3)] = (uint8_t)prev;
             }
         }
@@ -198,69 +231,101 @@ extern "C" int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard
     if (!d_in || !h_sizes || !n || !columns || !clusters || !cbs || !shards || !d_draws || !d_qv || ld < n || (ld & 3) || (cap_per_shard & 3))
         return qvz_set_error(QVZ_E_ARG, "bad shard-decoder arguments");
     if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "a label buffer is required for clusters > 1");
-    if ((size_t)columns * 64 * 4 > 160 * 1024) return qvz_set_error(QVZ_E_ARG, "%u columns exceed the decoder's LDS staging (640 at most)", columns);
+    if ((size_t)columns * 64 * 4 > 150 * 1024) return qvz_set_error(QVZ_E_ARG, "%u columns exceed the decoder's LDS staging (600 at most)", columns);
     for (uint32_t g = 0; g < shards; ++g)
         if (h_sizes[g] > cap_per_shard) return qvz_set_error(QVZ_E_ARG, "stream %u is longer than cap_per_shard", g);
     hipStream_t st = (hipStream_t)stream;
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
     if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
         return qvz_set_error(QVZ_E_NOMEM, "model build failed");
-    const size_t ctn = (size_t)clusters * columns * QVZ_CT_STRIDE, rcn = (size_t)clusters * columns * 2 * A * A;
-    const size_t offn = (size_t)clusters * columns * 2 * A;
-    uint16_t *h_ct = (uint16_t *)malloc(ctn * 2), *h_qs = (uint16_t *)malloc((size_t)columns * QVZ_QS_STRIDE * 2);
-    uint8_t *h_rc = (uint8_t *)malloc(rcn);
+    // decoder model: every table of qvz_model_build followed by its quantizer's output alphabet, 4 values per word
+    const size_t ctxn = (size_t)clusters * columns * A, offn = (size_t)clusters * columns * 2 * A;
+    std::vector<uint32_t> h_dar;
+    std::vector<uint32_t> h_doff(offn, NO_TABLE);
+    std::vector<uint2> h_ctx(ctxn);
     uint64_t *h_first = (uint64_t *)malloc((shards + 1) * sizeof(uint64_t));
-    uint32_t *d_tmpl = nullptr, *d_off = nullptr, *d_arena = nullptr;
-    uint16_t *d_ct = nullptr;
-    uint8_t *d_rc = nullptr;
+    uint32_t *d_tmpl = nullptr, *d_arena = nullptr;
+    uint2 *d_ctx = nullptr;
     uint64_t *d_first = nullptr, *d_sizes = nullptr;
     int32_t *d_status = nullptr;
     int rc = QVZ_OK;
     int32_t status = 0;
-    const size_t lds = (size_t)columns * 64 * 4;
+    uint32_t dwords = 0;
+    const size_t lds_stage = (size_t)columns * 64 * 4, lds_ctx = ctxn * sizeof(uint2);
+    const bool ctx_lds = lds_stage + lds_ctx <= 150 * 1024;
+    const size_t lds = lds_stage + (ctx_lds ? lds_ctx : 0);
 #define TRY(expr)                                                                                                    \
     do {                                                                                                             \
         hipError_t e_ = (expr);                                                                                      \
         if (e_ != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); goto done; } \
     } while (0)
-    if (!h_ct || !h_qs || !h_rc || !h_first) { rc = qvz_set_error(QVZ_E_NOMEM, "host alloc"); goto done; }
-    for (uint32_t c = 0; c < clusters; ++c) {
-        qvz_codebook_tables(cbs[c], h_ct + (size_t)c * columns * QVZ_CT_STRIDE, h_qs);
-        memcpy(h_rc + (size_t)c * columns * 2 * A * A, cbs[c]->recon, (size_t)columns * 2 * A * A);
+    if (!h_first) { rc = qvz_set_error(QVZ_E_NOMEM, "host alloc"); goto done; }
+    {
+        const uint32_t head = 2 + clusters;                      // the cluster-id table stays first
+        for (uint32_t i = 0; i < head; ++i) h_dar.push_back(h_arena[i]);
+        while (h_dar.size() & 3) h_dar.push_back(0);
+        for (uint32_t c = 0; c < clusters; ++c)
+            for (uint32_t s = 0; s < columns; ++s)
+                for (uint32_t j = 0; j < 2 * A; ++j) {
+                    const uint32_t o = h_off[((size_t)c * columns + s) * 2 * A + j];
+                    if (o == NO_TABLE) continue;
+                    const uint32_t card = h_arena[o + 1];
+                    h_doff[((size_t)c * columns + s) * 2 * A + j] = (uint32_t)h_dar.size();
+                    for (uint32_t i = 0; i < 2 + card; ++i) h_dar.push_back(h_arena[o + i]);
+                    const uint8_t *rc8 = cbs[c]->recon + (((size_t)s * 2 * A) + j) * A;
+                    for (uint32_t i = 0; i < card; i += 4) {
+                        uint32_t w = 0;
+                        for (uint32_t b = 0; b < 4 && i + b < card; ++b) w |= (uint32_t)rc8[i + b] << (8 * b);
+                        h_dar.push_back(w);
+                    }
+                    while (h_dar.size() & 3) h_dar.push_back(0);
+                }
+        if (h_dar.size() >= 0xFFFFFFu) { rc = qvz_set_error(QVZ_E_ARG, "model too large for the decoder's 24-bit table offsets"); goto done; }
+        dwords = (uint32_t)h_dar.size();
+        for (uint32_t c = 0; c < clusters; ++c)
+            for (uint32_t s = 0; s < columns; ++s)
+                for (uint32_t pv = 0; pv < A; ++pv) {
+                    const uint8_t ctx = cbs[c]->ctx_idx[(size_t)s * A + pv];
+                    uint2 e = make_uint2(NO_TABLE, NO_TABLE);
+                    if (ctx != QVZ_NOT_FOUND) {
+                        const uint32_t lo = h_doff[((size_t)c * columns + s) * 2 * A + 2 * ctx];
+                        const uint32_t hi = h_doff[((size_t)c * columns + s) * 2 * A + 2 * ctx + 1];
+                        e.x = (lo == NO_TABLE ? 0xFFFFFFu : lo) | ((uint32_t)cbs[c]->qratio[(size_t)s * A + ctx] << 24);
+                        e.y = hi == NO_TABLE ? 0xFFFFFFu : hi;
+                    }
+                    h_ctx[((size_t)c * columns + s) * A + pv] = e;
+                }
     }
     qvz_shard_bounds(n, shards, h_first);
-    TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
-    TRY(hipMalloc(&d_off, offn * 4));
-    TRY(hipMalloc(&d_arena, ((size_t)words * shards + 8) * 4));
-    TRY(hipMalloc(&d_ct, ctn * 2));
-    TRY(hipMalloc(&d_rc, rcn));
+    TRY(hipMalloc(&d_tmpl, (size_t)dwords * 4));
+    TRY(hipMalloc(&d_arena, ((size_t)dwords * shards + 16) * 4));   // + slack: a header read covers 64 bytes
+    TRY(hipMalloc(&d_ctx, ctxn * sizeof(uint2)));
     TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
     TRY(hipMalloc(&d_status, sizeof(int32_t)));
-    TRY(hipMemcpyAsync(d_tmpl, h_arena, (size_t)words * 4, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_ct, h_ct, ctn * 2, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_rc, h_rc, rcn, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_tmpl, h_dar.data(), (size_t)dwords * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_ctx, h_ctx.data(), ctxn * sizeof(uint2), hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_sizes, h_sizes, shards * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_dec_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
-    TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode_shards<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode_shards<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (clusters > 1)
-        hipLaunchKernelGGL(k_decode_shards<true>, dim3((shards + 63) / 64), dim3(64), lds, st, d_in, cap_per_shard, d_sizes, d_first,
-                           shards, columns, clusters, d_ct, d_rc, d_off, d_arena, words, d_draws, ld, d_qv, d_labels, d_status);
-    else
-        hipLaunchKernelGGL(k_decode_shards<false>, dim3((shards + 63) / 64), dim3(64), lds, st, d_in, cap_per_shard, d_sizes, d_first,
-                           shards, columns, clusters, d_ct, d_rc, d_off, d_arena, words, d_draws, ld, d_qv, d_labels, d_status);
+    hipLaunchKernelGGL(k_dec_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, dwords, shards, d_arena);
+#define DEC_LAUNCH(LBL, CLDS)                                                                                                       \
+    do {                                                                                                                            \
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode_shards<LBL, CLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_decode_shards<LBL, CLDS>), dim3((shards + 63) / 64), dim3(64), lds, st, d_in, cap_per_shard, d_sizes,    \
+                           d_first, shards, columns, clusters, d_ctx, d_arena, dwords, d_draws, ld, d_qv, d_labels, d_status);      \
+    } while (0)
+    if (clusters > 1) { if (ctx_lds) DEC_LAUNCH(true, true); else DEC_LAUNCH(true, false); }
+    else { if (ctx_lds) DEC_LAUNCH(false, true); else DEC_LAUNCH(false, false); }
+#undef DEC_LAUNCH
     TRY(hipGetLastError());
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
     if (status) rc = qvz_set_error(QVZ_E_DATA, "a stream does not decode with these codebooks (unknown context, table or state)");
 done:
 #undef TRY
-    (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_ct); (void)hipFree(d_rc);
+    (void)hipFree(d_tmpl); (void)hipFree(d_arena); (void)hipFree(d_ctx);
     (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
-    free(h_arena); free(h_off); free(h_ct); free(h_qs); free(h_rc); free(h_first);
+    free(h_arena); free(h_off); free(h_first);
     return rc;
 }
