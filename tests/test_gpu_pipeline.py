@@ -65,7 +65,8 @@ def test_every_shard_is_reference_decodable(name, shards, threads):
 @pytest.mark.parametrize("name,shards", [("t2k_r10_M", 1), ("t2k_r10_M", 7), ("t2k_c3_f05_M", 4), ("cfg1_f05_L", 64),
                                          ("cfg1_r10_M", 300), ("const_f05", 2), ("uniform72_r20_A", 5), ("tiny5_r10", 2),
                                          ("rescale_140k_c4", 1), ("rescale_c2_100k_c3", 1), ("rescale_c2_100k_c3", 3),
-                                         ("r35_high_rate", 3), ("wide_c151", 2)])
+                                         ("r35_high_rate", 3), ("wide_c151", 2), ("tiny5_r10", 4), ("c2_f08", 70),
+                                         ("t2k_c3_f05_M", 130)])
 def test_gpu_coder_streams_equal_host_coder_streams(name, shards):
     """The lane-per-shard GPU coder and the host C coder must emit the same bytes for every shard; with one shard
     that is the reference's own stream."""
