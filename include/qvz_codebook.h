@@ -69,6 +69,11 @@ void qvz_codebook_tables(const qvz_codebook_t *cb, uint16_t *h_ct, uint16_t *h_q
  * buf == NULL returns the size only. */
 size_t qvz_codebook_write_header(uint8_t *buf, uint32_t clusters, uint32_t columns, uint64_t lines);
 size_t qvz_codebook_write(uint8_t *buf, const qvz_codebook_t *cb);
+/* The inverse, read_codebooks (reference src/codebook.c:560-669) for one cluster: parses the codebook text at
+ * buf[*pos ...] into cb (allocated for the file's column count), advancing *pos. Output alphabets are derived the
+ * way the reference's decoder derives them (run de-duplication of each table, src/quantizer.c:167-191); `ratio` is
+ * qratio / 128 and every context counts as live. */
+int qvz_codebook_read(const uint8_t *buf, size_t size, size_t *pos, qvz_codebook_t *cb);
 
 #ifdef __cplusplus
 }

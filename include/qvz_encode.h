@@ -67,6 +67,15 @@ int qvz_encode_file(const char *in_path, const char *out_path, const qvz_options
 int qvz_encode_file_sharded(const char *in_path, const char *out_prefix, const qvz_options_t *opts, uint32_t shards,
                             qvz_result_t *res);
 
+/* Decode direction (`qvz -x`, reference src/main.c:132-183, start_qv_decompression src/qv_compressor.c:145-231).
+ * qvz_decode_file: a reference-format .q file (one stream) -> text; the serial arithmetic decoder runs on one host
+ * core as in the reference, the WELL draws come from the GPU word stream. qvz_decode_shard_files: the files
+ * "<prefix>.0000" ... written by qvz_encode_file_sharded, all shards decoded at once by the GPU decoder
+ * (qvz_hip_decode_shards); the output is the concatenation of the decodes. res (may be NULL): lines, columns,
+ * stream_bytes, file_bytes. */
+int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_result_t *res);
+int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_path, int device, qvz_result_t *res);
+
 const char *qvz_encode_last_error(void);
 
 #ifdef __cplusplus

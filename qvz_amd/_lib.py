@@ -86,6 +86,9 @@ SIGNATURES = {
     "qvz_options_default": (None, [C.c_void_p]),
     "qvz_encode_buffer": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qvz_encode_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "qvz_decode_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p]),
+    "qvz_decode_shard_files": (C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_int, C.c_void_p]),
+    "qvz_codebook_read": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "qvz_encode_file_sharded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qvz_encode_last_error": (C.c_char_p, []),
 }

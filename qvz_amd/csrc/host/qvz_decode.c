@@ -1,0 +1,348 @@
+/* qvz_decode.c - the decode direction of the drop-in surface (`qvz -x`), host C.
+ *
+ *   qvz_codebook_read      read_codebooks (reference src/codebook.c:560-669): codebook text -> qvz_codebook_t, output
+ *                          alphabets by run de-duplication of the quantizer tables (find_output_alphabet,
+ *                          src/quantizer.c:167-191), context sets by merging them (alphabet_union, src/pmf.c:312-357)
+ *   qvz_decode_file        start_qv_decompression (src/qv_compressor.c:145-231) for the reference's one-stream file:
+ *                          the serial chain (arithmetic_decoder_step / decoder_last_step, src/arith.c:118-205) runs on
+ *                          one host core as in the reference; the WELL draws come from the GPU word stream
+ *                          (qvz_hip_well_words) chunk by chunk
+ *   qvz_decode_shard_files the files written by qvz_encode_file_sharded ("<prefix>.0000" ...): every shard is one lane of
+ *                          the GPU decoder (qvz_hip_decode_shards); output = the decodes in order
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qvz_codebook.h"
+#include "qvz_coder.h"
+#include "qvz_encode.h"
+#include "qvz_hip.h"
+#include "qvz_job.h"
+
+#define A QVZ_A
+#define M_BITS 22u
+#define MSB (1u << (M_BITS - 1))
+#define MASK_M ((1u << M_BITS) - 1)
+#define MASK_M1 ((1u << (M_BITS - 1)) - 1)
+#define RESCALE (1u << (M_BITS - 3))
+#define STEP 8u
+#define NO_TABLE 0xFFFFFFFFu
+
+/* find_output_alphabet, quantizer.c:167-191: a new symbol whenever the table value changes */
+static uint32_t dedup_alphabet(const uint8_t *q, uint8_t *out) {
+    uint32_t size = 1;
+    uint8_t p = q[0];
+    out[0] = p;
+    for (int x = 1; x < A; ++x)
+        if (q[x] != p) { p = q[x]; out[size++] = p; }
+    return size;
+}
+
+/* alphabet_union, pmf.c:312-357: merge of two ascending symbol lists */
+static uint32_t union_lists(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, uint8_t *out) {
+    uint8_t tmp[4 * A];
+    uint32_t i = 0, j = 0, k = 0;
+    while (i < na && j < nb && k < 4 * A) {
+        if (a[i] < b[j]) tmp[k] = a[i++];
+        else if (a[i] == b[j]) { tmp[k] = a[i]; ++i; ++j; }
+        else tmp[k] = b[j++];
+        ++k;
+    }
+    while (i < na && k < 4 * A) tmp[k++] = a[i++];
+    while (j < nb && k < 4 * A) tmp[k++] = b[j++];
+    memcpy(out, tmp, k);
+    return k;
+}
+
+static void set_quantizer(qvz_codebook_t *cb, size_t t, const uint8_t *text) {
+    for (int i = 0; i < A; ++i) cb->q[t * A + i] = (uint8_t)(text[i] - 33);
+    const uint32_t ns = dedup_alphabet(cb->q + t * A, cb->recon + t * A);
+    cb->nstates[t] = (uint8_t)ns;
+    memset(cb->out_idx + t * A, QVZ_NOT_FOUND, A);
+    for (uint32_t z = 0; z < ns; ++z) cb->out_idx[t * A + cb->recon[t * A + z]] = (uint8_t)z;
+}
+
+int qvz_codebook_read(const uint8_t *f, size_t size, size_t *ppos, qvz_codebook_t *cb) {
+    size_t pos = *ppos;
+    const uint32_t C = cb->C;
+    uint8_t uni[4 * A];
+    uint32_t nu;
+#define NEED(nb) do { if (pos + (nb) > size) return qvz_job_fail(QVZ_E_DATA, "codebook ends early"); } while (0)
+    memset(cb->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
+    memset(cb->live, 1, (size_t)C * A);
+    NEED(2 + 2 * (A + 1));                                                     /* codebook.c:596-618 */
+    cb->nctx[0] = 1; cb->ctx_sym[0] = 0; cb->ctx_idx[0] = 0;
+    cb->qratio[0] = (uint8_t)(f[pos] - 33);
+    cb->ratio[0] = cb->qratio[0] / 128.0;
+    pos += 2;
+    for (int b = 0; b < 2; ++b) { set_quantizer(cb, (size_t)b, f + pos); pos += A + 1; }
+    nu = union_lists(cb->recon, cb->nstates[0], cb->recon + A, cb->nstates[1], uni);
+    for (uint32_t s = 1; s < C; ++s) {                                         /* :623-663 */
+        const uint32_t n = nu;
+        if (n == 0 || n > A) return qvz_job_fail(QVZ_E_DATA, "column %u: %u contexts", s, n);
+        cb->nctx[s] = (uint8_t)n;
+        memcpy(cb->ctx_sym + (size_t)s * A, uni, n);
+        for (uint32_t i = 0; i < n; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
+        NEED(n + 1 + 2 * ((size_t)n * A + 1));
+        for (uint32_t j = 0; j < n; ++j) {
+            cb->qratio[(size_t)s * A + j] = (uint8_t)(f[pos + j] - 33);
+            cb->ratio[(size_t)s * A + j] = cb->qratio[(size_t)s * A + j] / 128.0;
+        }
+        pos += n + 1;
+        nu = 0;
+        for (int b = 0; b < 2; ++b) {
+            for (uint32_t j = 0; j < n; ++j) {
+                const size_t t = (size_t)s * 2 * A + 2 * j + b;
+                set_quantizer(cb, t, f + pos);
+                pos += A;
+                nu = union_lists(uni, nu, cb->recon + t * A, cb->nstates[t], uni);
+            }
+            pos += 1;
+        }
+    }
+#undef NEED
+    *ppos = pos;
+    return QVZ_OK;
+}
+
+/* ---- the serial chain on the host ---------------------------------------------------------------------------- */
+typedef struct {
+    const uint8_t *buf;
+    uint64_t size, pos;
+    uint32_t bitpos;
+    uint32_t l, u, t;
+} hdec_t;
+
+static inline uint32_t rd_bit(hdec_t *d) {                                      /* stream_read_bit, os_stream.c:36-52 */
+    uint32_t b = 0;
+    if (d->pos < d->size) b = (d->buf[d->pos] >> (7 - d->bitpos)) & 1;
+    if (++d->bitpos == 8) { d->bitpos = 0; d->pos++; }
+    return b;
+}
+
+/* arithmetic_decoder_step (arith.c:118-188) / decoder_last_step (:190-205) + update_stats (qv_stream.c:9-25) */
+static uint32_t hdec_symbol(hdec_t *d, uint32_t *t, int last) {
+    const uint32_t n = t[0], card = t[1];
+    const uint64_t range = (uint64_t)d->u - d->l + 1, gap = (uint64_t)d->t - d->l + 1;
+    const uint64_t sub = (gap * n - 1) / range;
+    uint64_t cum = 0;
+    uint32_t k = 0;
+    while (k < card && sub >= cum) cum += t[2 + k++];
+    if (sub >= cum) return card;
+    const uint32_t x = k - 1;
+    if (last) return x;
+    const uint32_t fx = t[2 + x];
+    d->u = d->l + (uint32_t)((range * cum) / n) - 1;
+    d->l = d->l + (uint32_t)((range * (cum - fx)) / n);
+    for (;;) {
+        if ((d->l >> (M_BITS - 1)) == (d->u >> (M_BITS - 1))) {                 /* E1 / E2 */
+            d->l = (d->l & MASK_M1) << 1;
+            d->u = ((d->u & MASK_M1) << 1) + 1;
+            d->t = ((d->t & MASK_M1) << 1) + rd_bit(d);
+        } else if ((d->l >> (M_BITS - 2)) == 1 && (d->u >> (M_BITS - 2)) == 2) {   /* E3 */
+            d->l = (d->l << 1) & MASK_M1;
+            d->u = (((d->u << 1) & MASK_M1) | MSB) + 1;
+            d->t = (((d->t & MASK_M1) << 1) ^ MSB) + rd_bit(d);
+        } else break;
+    }
+    t[2 + x] = fx + STEP;
+    uint32_t nn = n + STEP;
+    if (nn > RESCALE) {
+        nn = 0;
+        for (uint32_t i = 0; i < card; ++i)
+            if (t[2 + i]) { t[2 + i] = (t[2 + i] >> 1) + 1; nn += t[2 + i]; }
+    }
+    t[0] = nn;
+    return x;
+}
+
+typedef struct {
+    uint32_t K, C;
+    uint64_t lines;
+    qvz_codebook_t **cbs;
+    uint32_t well[32];
+    size_t stream_at;
+} qfile_t;
+
+static void qfile_release(qfile_t *q) {
+    if (q->cbs) { for (uint32_t j = 0; j < q->K; ++j) qvz_codebook_free(q->cbs[j]); free(q->cbs); }
+    memset(q, 0, sizeof(*q));
+}
+
+/* header (codebook.c:565-573), codebooks, WELL state (qv_stream.c:72-74) */
+static int qfile_parse(const uint8_t *f, size_t size, qfile_t *q) {
+    memset(q, 0, sizeof(*q));
+    if (size < 9) return qvz_job_fail(QVZ_E_DATA, "not a qvz file");
+    q->K = f[0];
+    q->C = ((uint32_t)f[1] << 24) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 8) | f[4];
+    q->lines = ((uint32_t)f[5] << 24) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 8) | f[8];
+    if (q->K < 1 || q->C < 1 || q->C > (1u << 20)) return qvz_job_fail(QVZ_E_DATA, "implausible header (%u clusters, %u columns)", q->K, q->C);
+    size_t pos = 9;
+    q->cbs = (qvz_codebook_t **)calloc(q->K, sizeof(*q->cbs));
+    if (!q->cbs) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
+    for (uint32_t j = 0; j < q->K; ++j) {
+        q->cbs[j] = qvz_codebook_alloc(q->C);
+        if (!q->cbs[j]) { qfile_release(q); return qvz_job_fail(QVZ_E_NOMEM, "host alloc"); }
+        const int rc = qvz_codebook_read(f, size, &pos, q->cbs[j]);
+        if (rc) { qfile_release(q); return rc; }
+    }
+    if (pos + 128 > size) { qfile_release(q); return qvz_job_fail(QVZ_E_DATA, "file ends before the WELL state"); }
+    memcpy(q->well, f + pos, 128);
+    q->stream_at = pos + 128;
+    return QVZ_OK;
+}
+
+static int read_whole_file(const char *path, uint8_t **buf, size_t *size) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return qvz_job_fail(QVZ_E_ARG, "Unable to open input file %s", path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    *buf = (uint8_t *)malloc(sz > 0 ? (size_t)sz : 1);
+    if (!*buf || sz < 0 || fread(*buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(*buf); *buf = NULL; return qvz_job_fail(QVZ_E_ARG, "cannot read %s", path); }
+    fclose(f);
+    *size = (size_t)sz;
+    return QVZ_OK;
+}
+
+int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_result_t *res) {
+    uint8_t *f = NULL, *row = NULL;
+    size_t size = 0;
+    qfile_t q;
+    uint32_t *arena = NULL, *off = NULL, words = 0, *h_words = NULL, *d_words = NULL;
+    FILE *fo = NULL;
+    int rc;
+    memset(&q, 0, sizeof(q));
+    if ((rc = read_whole_file(in_path, &f, &size))) return rc;
+    if ((rc = qfile_parse(f, size, &q))) { free(f); return rc; }
+    const uint32_t C = q.C, K = q.K;
+    const uint64_t chunk = 1u << 16;                                            /* reads per batch of draws */
+    if (qvz_hip_set_device(device)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+    if (qvz_model_build(K, C, (const qvz_codebook_t *const *)q.cbs, 0, &arena, &off, &words)) { rc = qvz_job_fail(QVZ_E_NOMEM, "model build failed"); goto done; }
+    h_words = (uint32_t *)malloc((chunk * C / 4 + 2) * sizeof(uint32_t));
+    row = (uint8_t *)malloc((size_t)C + 1);
+    fo = fopen(out_path, "w");
+    if (!h_words || !row) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+    if (!fo) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
+    if (qvz_hip_malloc((void **)&d_words, (chunk * C / 4 + 2) * sizeof(uint32_t))) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+    {
+        hdec_t d = { f + q.stream_at, size - q.stream_at, 0, 0, 0, MASK_M, 0 };
+        for (int bit = (int)M_BITS - 1; bit >= 0; --bit) d.t |= rd_bit(&d) << bit;   /* qv_stream.c:112-113 */
+        for (uint64_t r0 = 0; r0 < q.lines; r0 += chunk) {
+            const uint64_t nr = q.lines - r0 < chunk ? q.lines - r0 : chunk;
+            const uint64_t w0 = r0 * C / 4, w1 = ((r0 + nr) * C + 3) / 4;      /* chunk is a multiple of 4 reads */
+            if (qvz_hip_well_words(q.well, w0, w1 - w0, d_words, NULL) || qvz_hip_copy_d2h(h_words, d_words, (w1 - w0) * 4, NULL) ||
+                qvz_hip_stream_sync(NULL)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+            for (uint64_t i = 0; i < nr; ++i) {
+                /* qv_read_cluster, qv_compressor.c:36-43: coded for every read (a no-op on the interval when K = 1) */
+                const uint32_t cl = hdec_symbol(&d, arena, 0);
+                if (cl >= K) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (cluster id)"); goto done; }
+                const qvz_codebook_t *cb = q.cbs[cl];
+                uint32_t prev = 0;
+                for (uint32_t s = 0; s < C; ++s) {
+                    const uint32_t ctx = cb->ctx_idx[(size_t)s * A + prev];
+                    if (ctx == QVZ_NOT_FOUND) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (context)"); goto done; }
+                    const uint64_t g = (r0 + i) * C + s - w0 * 4;               /* draw index inside this batch of words */
+                    const uint32_t draw = (h_words[g >> 2] >> (7 * (g & 3))) & 127;   /* well.c:33-46 */
+                    const uint32_t qi = 2 * ctx + (draw >= cb->qratio[(size_t)s * A + ctx] ? 1u : 0u);
+                    const uint32_t o = off[((size_t)cl * C + s) * 2 * A + qi];
+                    const int last = r0 + i + 1 == q.lines && s + 1 == C;      /* qv_compressor.c:222-225 */
+                    const uint32_t x = hdec_symbol(&d, arena + o, last);
+                    if (x >= arena[o + 1]) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (state)"); goto done; }
+                    prev = cb->recon[((size_t)s * 2 * A + qi) * A + x];
+                    row[s] = (uint8_t)(prev + 33);
+                }
+                row[C] = '\n';
+                if (fwrite(row, 1, (size_t)C + 1, fo) != (size_t)C + 1) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+            }
+        }
+    }
+    if (res) { memset(res, 0, sizeof(*res)); res->lines = q.lines; res->columns = C; res->stream_bytes = size - q.stream_at; res->file_bytes = size; }
+done:
+    if (fo) fclose(fo);
+    qvz_hip_free(d_words);
+    free(h_words); free(row); free(arena); free(off); free(f);
+    qfile_release(&q);
+    return rc;
+}
+
+int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_path, int device, qvz_result_t *res) {
+    int rc = QVZ_OK;
+    uint8_t **files = NULL, *h_in = NULL, *d_in = NULL, *d_draws = NULL, *d_qv = NULL, *d_labels = NULL, *d_text = NULL, *h_text = NULL;
+    size_t *fsize = NULL;
+    uint64_t *sizes = NULL, *first = NULL;
+    qfile_t q0, qg;
+    FILE *fo = NULL;
+    memset(&q0, 0, sizeof(q0));
+    memset(&qg, 0, sizeof(qg));
+    if (!shards) return qvz_job_fail(QVZ_E_ARG, "shards must be positive");
+    files = (uint8_t **)calloc(shards, sizeof(*files));
+    fsize = (size_t *)calloc(shards, sizeof(*fsize));
+    sizes = (uint64_t *)calloc(shards, sizeof(*sizes));
+    first = (uint64_t *)calloc((size_t)shards + 1, sizeof(*first));
+    if (!files || !fsize || !sizes || !first) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+    uint64_t N = 0, cap = 0;
+    size_t head = 0;
+    for (uint32_t g = 0; g < shards; ++g) {
+        char name[4096];
+        if ((size_t)snprintf(name, sizeof(name), "%s.%04u", prefix, g) >= sizeof(name)) { rc = qvz_job_fail(QVZ_E_ARG, "name too long"); goto done; }
+        if ((rc = read_whole_file(name, &files[g], &fsize[g]))) goto done;
+        if (g == 0) {
+            if ((rc = qfile_parse(files[0], fsize[0], &q0))) goto done;
+            head = q0.stream_at;
+        } else {                                                                /* same codebooks in every shard: compare the bytes */
+            if (fsize[g] < head || memcmp(files[g] + 9, files[0] + 9, head - 128 - 9) != 0 || files[g][0] != files[0][0] ||
+                memcmp(files[g] + 1, files[0] + 1, 4) != 0) { rc = qvz_job_fail(QVZ_E_DATA, "%s does not carry the codebooks of shard 0", name); goto done; }
+        }
+        const uint64_t lines = ((uint32_t)files[g][5] << 24) | ((uint32_t)files[g][6] << 16) | ((uint32_t)files[g][7] << 8) | files[g][8];
+        first[g] = N;
+        N += lines;
+        sizes[g] = fsize[g] - head;
+        if (sizes[g] > cap) cap = sizes[g];
+    }
+    first[shards] = N;
+    {   /* the shard boundaries must be the ones qvz_shard_bounds gives for N reads: the decoder derives them itself */
+        uint64_t *chk = (uint64_t *)calloc((size_t)shards + 1, sizeof(*chk));
+        if (!chk) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        qvz_shard_bounds(N, shards, chk);
+        const int same = memcmp(chk, first, ((size_t)shards + 1) * sizeof(*chk)) == 0;
+        free(chk);
+        if (!same) { rc = qvz_job_fail(QVZ_E_DATA, "line counts of the shard files are not those of %u equal shards", shards); goto done; }
+    }
+    cap = (cap + 7) & ~3ull;
+    const uint32_t C = q0.C, K = q0.K;
+    const uint64_t ld = qvz_hip_ld(N), stride = (uint64_t)C + 1;
+    if (qvz_hip_set_device(device)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+    h_in = (uint8_t *)calloc((size_t)shards, cap);
+    h_text = (uint8_t *)malloc(N * stride);
+    if (!h_in || !h_text) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+    for (uint32_t g = 0; g < shards; ++g) memcpy(h_in + (size_t)g * cap, files[g] + head, sizes[g]);
+#define HIPC(call) do { if ((call) != QVZ_OK) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; } } while (0)
+    HIPC(qvz_hip_malloc((void **)&d_in, (size_t)shards * cap));
+    HIPC(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
+    HIPC(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
+    HIPC(qvz_hip_malloc((void **)&d_labels, ld));
+    HIPC(qvz_hip_malloc((void **)&d_text, N * stride));
+    HIPC(qvz_hip_copy_h2d(d_in, h_in, (size_t)shards * cap, NULL));
+    HIPC(qvz_hip_well_draws(q0.well, 0, N, C, d_draws, ld, NULL));             /* shard 0 carries the file's WELL state */
+    if (qvz_hip_decode_shards(d_in, cap, sizes, N, C, K, (const qvz_codebook_t *const *)q0.cbs, shards, d_draws, ld, d_qv, d_labels, NULL)) {
+        rc = qvz_job_fail(QVZ_E_DATA, "%s", qvz_hip_last_error());
+        goto done;
+    }
+    HIPC(qvz_hip_untranspose_text(d_qv, N, C, ld, d_text, NULL));
+    HIPC(qvz_hip_copy_d2h(h_text, d_text, N * stride, NULL));
+    HIPC(qvz_hip_stream_sync(NULL));
+#undef HIPC
+    fo = fopen(out_path, "w");
+    if (!fo) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
+    if (fwrite(h_text, 1, N * stride, fo) != N * stride) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+    if (res) { memset(res, 0, sizeof(*res)); res->lines = N; res->columns = C; for (uint32_t g = 0; g < shards; ++g) { res->stream_bytes += sizes[g]; res->file_bytes += fsize[g]; } }
+done:
+    if (fo) fclose(fo);
+    qvz_hip_free(d_in); qvz_hip_free(d_draws); qvz_hip_free(d_qv); qvz_hip_free(d_labels); qvz_hip_free(d_text);
+    if (files) for (uint32_t g = 0; g < shards; ++g) free(files[g]);
+    free(files); free(fsize); free(sizes); free(first); free(h_in); free(h_text);
+    qfile_release(&q0); qfile_release(&qg);
+    return rc;
+}

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "qvz_encode.h"
 
@@ -97,9 +98,24 @@ int main(int argc, char **argv) {
             printf("Compression will use %d clusters, with a movement threshold of %.0f.\n", opts.clusters, opts.cluster_threshold);
         }
     }
-    if (extract) {
-        printf("Decoding (-x) is not part of this build: use the reference decoder on the .q file (SURVEY.md section 8f).\n");
-        return 1;
+    if (extract) {                                                /* main.c:132-183 */
+        /* QVZ_SHARDS=N: the input is the prefix of N shard files written by a sharded encode */
+        const uint32_t nsh = getenv("QVZ_SHARDS") ? (uint32_t)strtoul(getenv("QVZ_SHARDS"), 0, 10) : 0;
+        const int dev = getenv("QVZ_DEVICE") ? atoi(getenv("QVZ_DEVICE")) : 0;
+        qvz_result_t dres;
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        const int drc = nsh ? qvz_decode_shard_files(input_name, nsh, output_name, dev, &dres)
+                            : qvz_decode_file(input_name, output_name, dev, &dres);
+        if (drc) {
+            printf("%s\n", qvz_encode_last_error());
+            exit(1);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (opts.verbose)                                         /* main.c:158-160 */
+            printf("Decoded %llu lines in %f seconds.\n", (unsigned long long)dres.lines,
+                   (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+        return 0;
     }
     const char *seed = getenv("QVZ_WELL_SEED");
     if (seed && strcmp(seed, "debug") == 0) opts.seed_mode = QVZ_SEED_DEBUG;

@@ -165,3 +165,48 @@ def test_cli_qvz_shards_env(tmp_path):
     assert re.search(r"rate, [\d.]+, distortion, ([\d.]+)", out).group(1) == f"{e['distortion']:.4f}"
     decoded = b"".join(decode_with_reference_or_oracle(f"{q}.{g:04d}", tmp_path) for g in range(4))
     assert G.md5(decoded) == e["u_md5"]
+
+
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "t2k_c3_f05_M", "cfg1_r10_M", "const_f05", "uniform72_r20_A",
+                                  "c2_f08", "tiny5_r10", "twolevel_c2_f05", "f00_zero_rate", "r35_high_rate"])
+def test_decode_file_of_the_reference_encoders_q(tmp_path, name):
+    """qvz_decode_file / `qvz -x` on the .q file the REFERENCE wrote (fixture) gives the reference's -u text."""
+    import ctypes as C
+    from qvz_amd._lib import lib
+    q = tmp_path / (name + ".q")
+    q.write_bytes(G.gz(name + ".q.gz"))
+    out = str(tmp_path / "dec.txt")
+    rc = lib().qvz_decode_file(str(q).encode(), out.encode(), 0, None)
+    assert rc == 0, lib().qvz_encode_last_error().decode()
+    assert open(out, "rb").read() == G.gz(name + ".u.gz")
+    cli = str(tmp_path / "cli.txt")
+    v = subprocess.run([QVZ_BIN, "-x", "-v", str(q), cli], capture_output=True, text=True, check=True).stdout
+    assert open(cli, "rb").read() == G.gz(name + ".u.gz")
+    assert re.search(rf"Decoded {G.CASES[name]['input']['n']} lines in [\d.]+ seconds\.", v)
+
+
+def test_encode_then_decode_round_trips_through_files(tmp_path):
+    """qvz (this build) -> .q -> qvz -x (this build) == -u, for one stream and for QVZ_SHARDS."""
+    name = "cfg1_f05_L"
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    q, u, d = str(tmp_path / "rt.q"), str(tmp_path / "rt.u"), str(tmp_path / "rt.dec")
+    env = dict(os.environ)                                       # time-seeded WELL state, as the reference does by default
+    subprocess.run([QVZ_BIN] + e["flags"].split() + ["-u", u, inp, q], env=env, check=True, capture_output=True)
+    subprocess.run([QVZ_BIN, "-x", q, d], env=env, check=True, capture_output=True)
+    assert open(d, "rb").read() == open(u, "rb").read()
+    env5 = dict(os.environ, QVZ_SHARDS="5")
+    subprocess.run([QVZ_BIN] + e["flags"].split() + ["-u", u, inp, q], env=env5, check=True, capture_output=True)
+    subprocess.run([QVZ_BIN, "-x", q, d], env=env5, check=True, capture_output=True)
+    assert open(d, "rb").read() == open(u, "rb").read()
+
+
+def test_decode_rejects_damaged_files(tmp_path):
+    name = "t2k_r10_M"
+    blob = bytearray(G.gz(name + ".q.gz"))
+    bad = tmp_path / "bad.q"
+    bad.write_bytes(bytes(blob[:5000]))                          # cut inside the codebooks
+    r = subprocess.run([QVZ_BIN, "-x", str(bad), str(tmp_path / "o.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "codebook" in r.stdout
+    r = subprocess.run([QVZ_BIN, "-x", str(tmp_path / "missing.q"), str(tmp_path / "o.txt")], capture_output=True, text=True)
+    assert r.returncode == 1
