@@ -59,7 +59,9 @@ int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h
  * (reference src/codebook.c:208-219, combine_pmfs src/pmf.c:189-205), bit-identical to the reference's values. */
 int qvz_hip_marginals(const uint32_t *d_cnt, uint32_t C, double *h_marg, void *stream);
 
-/* Number of host-side decisions the last qvz_hip_generate_codebook call had to take inside the guard band */
+/* Number of host-side decisions the last qvz_hip_generate_codebook call OF THE CALLING THREAD had to take inside the
+ * guard band. (qvz_hip_generate_codebook may run concurrently on several host threads, one cluster and one stream each:
+ * the clusters' codebooks are independent, and a generation is a chain of small kernels and host round trips.) */
 uint64_t qvz_hip_codebook_deferred_decisions(void);
 
 /* Device tables for the quantizer (layout in qvz_hip.h) from a host codebook: h_ct [C][72], h_qs [C][144][72] */

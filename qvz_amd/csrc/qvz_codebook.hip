@@ -506,7 +506,7 @@ struct CbWork {
     }
 };
 
-static uint64_t g_deferred = 0;
+static thread_local uint64_t g_deferred = 0;   // per calling thread: clusters may be generated by concurrent host threads
 extern "C" uint64_t qvz_hip_codebook_deferred_decisions(void) { return g_deferred; }
 
 #define LM_LDS_BYTES ((A * A + A + A) * sizeof(double) + sizeof(LmLds))

@@ -183,10 +183,25 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     t2 = time.perf_counter()
     dmat = K.distortion_matrix(dist)
     cbs, deferred = [], 0
-    for j in range(k):
-        cb, d = K.generate_codebook(cnt[j], dmat, mode, ratio)
+    if k == 1:
+        cb, deferred = K.generate_codebook(cnt[0], dmat, mode, ratio)
         cbs.append(cb)
-        deferred += d
+    else:
+        # the clusters' codebooks are independent and each generation is latency-bound (small kernels, two host round
+        # trips per column): one host thread and one HIP stream per cluster (ctypes releases the GIL in the call)
+        from concurrent.futures import ThreadPoolExecutor
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
+
+        def one(j):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[j]):
+                return K.generate_codebook(cnt[j], dmat, mode, ratio)
+
+        with ThreadPoolExecutor(max_workers=k) as pool:
+            for cb, d in pool.map(one, range(k)):
+                cbs.append(cb)
+                deferred += d
     ct, qs = K.upload_tables(cbs, dev)
     torch.cuda.synchronize()
     wall["codebook"] = time.perf_counter() - t2
