@@ -97,22 +97,38 @@ int qvz_job_upload(qvz_job_t *job) {
     const double t0 = now();
     const uint64_t N = job->N, stride = (uint64_t)job->C + 1, ld = job->ld;
     const uint32_t C = job->C;
-    uint8_t *d_up = NULL;
+    uint8_t *d_up[2] = {NULL, NULL}, *h_up[2] = {NULL, NULL};
+    void *st[2] = {NULL, NULL};
     uint32_t *d_bad = NULL;
     if (job->uploaded) return 0;
     HIP(qvz_hip_set_device(job->opts.device));
-    const uint64_t up_reads = 1u << 21;   /* ~2M reads per staging copy; a multiple of 256 */
+    /* Streaming, transposing ingest (replaces load_file's row-pointer table, lines.c:27-82): the mmap'd text goes
+     * through two pinned staging buffers so that the host copy of chunk k+1 (page cache -> pinned), the PCIe transfer
+     * of chunk k and its transposition into the column-major matrix overlap. */
+    const uint64_t up_reads = 1u << 18;   /* reads per staging buffer; a multiple of 256 */
+    const uint64_t up_n = N < up_reads ? N : up_reads;
     HIP(qvz_hip_malloc((void **)&job->d_sym, (size_t)C * ld));
     HIP(qvz_hip_malloc((void **)&job->d_labels, ld));
-    HIP(qvz_hip_malloc((void **)&d_up, (size_t)(N < up_reads ? N : up_reads) * stride));
     HIP(qvz_hip_malloc((void **)&d_bad, sizeof(uint32_t)));
     HIP(qvz_hip_memset(d_bad, 0, sizeof(uint32_t), NULL));
     HIP(qvz_hip_memset(job->d_labels, 0, ld, NULL));               /* calloc'd line_t.cluster, lines.c:116 */
-    for (uint64_t r0 = 0; r0 < N; r0 += up_reads) {
-        const uint64_t n = N - r0 < up_reads ? N - r0 : up_reads;
-        HIP(qvz_hip_copy_h2d(d_up, job->text + r0 * stride, n * stride, NULL));
-        HIP(qvz_hip_transpose_text(d_up, n, C, job->d_sym + r0, ld, d_bad, NULL));
-        HIP(qvz_hip_stream_sync(NULL));
+    HIP(qvz_hip_stream_sync(NULL));
+    for (int b = 0; b < 2; ++b) {
+        HIP(qvz_hip_malloc((void **)&d_up[b], (size_t)up_n * stride));
+        HIP(qvz_hip_malloc_host((void **)&h_up[b], (size_t)up_n * stride));
+        HIP(qvz_hip_stream_create(&st[b]));
+    }
+    {
+        int b = 0;
+        for (uint64_t r0 = 0; r0 < N; r0 += up_reads, b ^= 1) {
+            const uint64_t n = N - r0 < up_reads ? N - r0 : up_reads;
+            HIP(qvz_hip_stream_sync(st[b]));                       /* this staging pair was used two chunks ago */
+            memcpy(h_up[b], job->text + r0 * stride, n * stride);
+            HIP(qvz_hip_copy_h2d(d_up[b], h_up[b], n * stride, st[b]));
+            HIP(qvz_hip_transpose_text(d_up[b], n, C, job->d_sym + r0, ld, d_bad, st[b]));
+        }
+        HIP(qvz_hip_stream_sync(st[0]));
+        HIP(qvz_hip_stream_sync(st[1]));
     }
     {
         uint32_t bad = 0;
@@ -123,7 +139,11 @@ int qvz_job_upload(qvz_job_t *job) {
     job->uploaded = 1;
     job->t_upload = now() - t0;
 done:
-    qvz_hip_free(d_up);
+    for (int b = 0; b < 2; ++b) {
+        qvz_hip_free(d_up[b]);
+        qvz_hip_free_host(h_up[b]);
+        if (st[b]) qvz_hip_stream_destroy(st[b]);
+    }
     qvz_hip_free(d_bad);
     return rc;
 }
