@@ -618,6 +618,15 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 // adjacent columns of the same stream) writes W * 16 contiguous bytes per read of the stream's read-major record area.
 // Table state crosses segment boundaries through `save` (one slice per (stream, column)).
 #define RK_NONE 0xFFFFu
+#ifdef QVZ_PROFILE          // development build (make HIPFLAGS+=-DQVZ_PROFILE): shader-clock cycles per section of the chunk loop, summed over waves
+__device__ unsigned long long g_rk_prof[8];
+__device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no record store, 2 no transposition/barriers, 4 no cumulative loop, 8 no table update, 16 no timers
+#define RK_T(i) do { if (!(exp_ & 16)) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
+#define RK_EXP(bit) if (!(exp_ & (bit)))
+#else
+#define RK_T(i) do { } while (0)
+#define RK_EXP(bit)
+#endif
 template <bool HAVE_LABELS>
 __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                       const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
@@ -627,23 +636,28 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                                                       uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       uint32_t log2w, Record *__restrict__ rec, int32_t *__restrict__ status) {
     extern __shared__ uint4 rk_smem[];
-    const uint32_t W = 1u << log2w, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is wave-uniform, which the compiler cannot see: readfirstlane keeps everything derived from it
+    // (column, table slice, activity) in scalar registers and its tests in scalar branches
+    const uint32_t W = 1u << log2w, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t Cx = C + (HAVE_LABELS ? 1u : 0u);
     const uint32_t g = blockIdx.x, cg = blockIdx.y;
     const uint32_t sx = cg * W + wave;                           // position in the read's record group: [cluster id,] column 0 ..
     const uint32_t Cp = (Cx + 7) & ~7u;
     const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;
-    const uint64_t r0 = first[g] + seg_lo, rend = first[g + 1];
+    auto uniform64 = [](uint64_t v) -> uint64_t {               // same value in every lane: keep it in scalar registers
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const uint64_t r0 = uniform64(first[g] + seg_lo), rend = uniform64(first[g + 1]);
     if (r0 >= rend) return;                                      // whole workgroup
-    const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
+    const uint32_t nr = rend - r0 < seg_reads ? (uint32_t)(rend - r0) : seg_reads;   // reads of this stream in this segment
     const uint32_t rb_stride = W + 1;                            // +1: conflict-free transposition
     Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [64][W + 1]
-    const uint32_t cof_words = (K * 2 * A + 1) / 2;
-    // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, table offsets of the column [K][144] u16
+    // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, and per (cluster, quantizer) of the column its table's
+    // offset in the slice | alphabet size << 16 (RK_NONE, size 0: no table), so that one LDS read resolves a symbol
     unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride) +
-                              (size_t)wave * ((3 * slice_cap + cof_words + 192) / 2);
+                              (size_t)wave * ((3 * slice_cap + K * 2 * A) / 2);
     uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
-    uint16_t *cof = reinterpret_cast<uint16_t *>(tab + slice_cap);
+    uint32_t *cof = tab + slice_cap;
     const bool active = sx < Cx;
     const bool cluster_wave = HAVE_LABELS && sx == 0;
     const uint32_t s = HAVE_LABELS ? sx - 1 : sx;
@@ -654,68 +668,72 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         const uint32_t *src = is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0;
         for (uint32_t i = lane; i < sw; i += 64) { tab[i] = src[i]; msk[i] = 0ull; }
         if (!cluster_wave)
-            for (uint32_t i = lane; i < K * 2 * A; i += 64) cof[i] = coff[(uint64_t)sx * K * 2 * A + i];
+            for (uint32_t i = lane; i < K * 2 * A; i += 64) {
+                const uint32_t o = coff[(uint64_t)sx * K * 2 * A + i];
+                cof[i] = o == RK_NONE ? (uint32_t)RK_NONE : (o | src[o + 1] << 16);
+            }
     }
     __syncthreads();
 
     Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index)
     bool bad = false;
     uint32_t chunk = 0;
-    // Input staging: a wave takes its column 256 reads at a time (one dword per lane and plane = 256 contiguous bytes)
-    // and requests the next 256 while it works through the current four chunks out of LDS, so the HBM latency of the
-    // planes (several chunk times) stays off the chunk loop.
-    uint8_t *stage = reinterpret_cast<uint8_t *>(cof + ((K * 2 * A + 1) & ~1u)) ;   // [3][256]: qi, st, labels of the current block
-    uint32_t q_nx = 0, x_nx = 0, lab_nx = 0;
-    auto fetch = [&](uint64_t rbn) {                             // rbn is a multiple of 4, and so are r1 rounded up and ld
-        const uint64_t r = rbn + 4 * lane;
-        q_nx = 0; x_nx = 0; lab_nx = 0;
-        if (active && r < r1) {
-            if (!cluster_wave) {
-                q_nx = *reinterpret_cast<const uint32_t *>(qi + (uint64_t)s * ld + r);
-                x_nx = *reinterpret_cast<const uint32_t *>(st + (uint64_t)s * ld + r);
-            }
-            if (HAVE_LABELS) lab_nx = *reinterpret_cast<const uint32_t *>(labels + r);
+    // Input: every lane loads the bytes of its own read for the next four chunks (a wave instruction = 64 contiguous bytes
+    // of a plane) and keeps them in registers until the current four are used up, so the HBM latency stays off the chunk
+    // loop and nothing is staged through LDS. No bounds branch: a read index past the stream's last read is clamped to
+    // it, idle waves read plane 0, and `on` below ignores what such lanes loaded.
+    uint32_t q_cur = 0, x_cur = 0, lab_cur = 0, q_nx[4], x_nx[4], lab_nx[4] = {0, 0, 0, 0};
+    const uint8_t *const qplane = qi + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + r0;
+    const uint8_t *const xplane = st + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + r0;
+    auto fetch = [&](uint32_t ro) {                              // ro = read offset in the segment
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t r = ro + j * 64 + lane, rc = r < nr ? r : nr - 1;
+            q_nx[j] = qplane[rc];
+            x_nx[j] = xplane[rc];
+            if (HAVE_LABELS) lab_nx[j] = labels[r0 + rc];
         }
     };
-    // Table look-up of a chunk (stage -> table offset -> alphabet size): three dependent LDS round trips that do not
-    // depend on the counts, so they are issued one chunk ahead and overlap the barrier and the record drain.
-    // Written without per-lane branches (selects and safe indices instead): every exec-mask change costs a wave
-    // several scalar instructions and their latencies.
+    // Table look-up of a chunk: one LDS read (table offset and alphabet size) that does not depend on the counts; it is
+    // issued one chunk ahead. Written without per-lane branches (selects and safe indices instead): every exec-mask
+    // change costs a wave several scalar instructions and their latencies.
     uint32_t tb_nx = 0, x_lk = 0, card_nx = 1;
     bool ok_nx = false;
-    auto lookup = [&](uint64_t rbn, uint32_t ch) {
-        const bool on = active && rbn + lane < r1;
-        const uint32_t in_blk = (ch & 3) * 64 + lane;
-        const uint32_t q = stage[in_blk], xs = stage[256 + in_blk];
-        const uint32_t raw = HAVE_LABELS ? stage[512 + in_blk] : 0u;
+    auto lookup = [&](uint32_t ro, uint32_t ch) {
+        const bool on = active && ro + lane < nr;
+        const uint32_t sh = (ch & 3) * 8;
+        const uint32_t q = (q_cur >> sh) & 0xFF, xs = (x_cur >> sh) & 0xFF;
+        const uint32_t raw = HAVE_LABELS ? (lab_cur >> sh) & 0xFF : 0u;
         const uint32_t cl = raw < K ? raw : 0u;
-        const uint32_t tbr = cof[cl * 2 * A + (q < 2 * A ? q : 0u)];
-        const uint32_t tb = cluster_wave ? 0u : (q < 2 * A ? tbr : (uint32_t)RK_NONE);
+        const uint32_t ent = cof[cl * 2 * A + (q < 2 * A ? q : 0u)];
+        const uint32_t tb = cluster_wave ? 0u : (q < 2 * A ? ent & 0xFFFFu : (uint32_t)RK_NONE);
+        const uint32_t card = cluster_wave ? K : ent >> 16;
         const uint32_t x = cluster_wave ? cl : xs;
         bool ok = on && tb != RK_NONE && raw < K;
         const uint32_t tbs = ok ? tb : 0u;                       // lanes without a symbol work on table 0 and contribute nothing
-        const uint32_t card = tab[tbs + 1];
         ok = ok && x < card;
         bad = bad || (on && !ok);
         tb_nx = tbs; x_lk = ok ? x : 0u; card_nx = card; ok_nx = ok;
     };
-    auto park = [&](uint64_t rbn) {                              // the requested dwords become the current block; request the next
-        reinterpret_cast<uint32_t *>(stage)[lane] = q_nx;
-        reinterpret_cast<uint32_t *>(stage)[64 + lane] = x_nx;
-        if (HAVE_LABELS) reinterpret_cast<uint32_t *>(stage)[128 + lane] = lab_nx;
-        fetch(rbn + 256);
+    auto park = [&](uint32_t ro) {                               // the requested bytes become the current block; request the next
+        q_cur = q_nx[0] | q_nx[1] << 8 | q_nx[2] << 16 | q_nx[3] << 24;
+        x_cur = x_nx[0] | x_nx[1] << 8 | x_nx[2] << 16 | x_nx[3] << 24;
+        if (HAVE_LABELS) lab_cur = lab_nx[0] | lab_nx[1] << 8 | lab_nx[2] << 16 | lab_nx[3] << 24;
+        fetch(ro + 256);
     };
-    fetch(r0);
-    park(r0);
-    lookup(r0, 0);
-    for (uint64_t rb = r0; rb < r1; rb += 64, ++chunk) {
+    fetch(0);
+    park(0);
+    lookup(0, 0);
+#ifdef QVZ_PROFILE
+    const int exp_ = __builtin_amdgcn_readfirstlane(g_rk_exp);
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
+    for (uint32_t rb = 0; rb < nr; rb += 64, ++chunk) {       // rb = read offset in the segment
         Record outr = make_double2(0.0, 0.0);
         const uint32_t tb = tb_nx, x = x_lk, card = card_nx;
         const bool ok = ok_nx;
-        if (rb + 64 < r1) {
-            if (((chunk + 1) & 3) == 0) park(rb + 64);
-            lookup(rb + 64, chunk + 1);
-        }
+        if (rb + 64 < nr) lookup(rb + 64, chunk + 1);
+        RK_T(0);
         if (active) {
             // every lane marks its table and its (table, state) entry (lanes without a symbol OR in nothing)
             const unsigned long long bit = ok ? 1ull << lane : 0ull;
@@ -736,29 +754,44 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 const bool up = 2 * x < card;
                 uint32_t y = up ? 0u : x + 1, yend = up ? x : card, acc = 0, accm = 0;
                 if (!ok) yend = y;
-                while (__ballot(y < yend)) {                     // four entries per LDS round trip
-                    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-                    if (y < yend) { c0 = tab[tb + 2 + y]; m0 = msk[tb + 2 + y]; }
-                    if (y + 1 < yend) { c1 = tab[tb + 3 + y]; m1 = msk[tb + 3 + y]; }
-                    if (y + 2 < yend) { c2 = tab[tb + 4 + y]; m2 = msk[tb + 4 + y]; }
-                    if (y + 3 < yend) { c3 = tab[tb + 5 + y]; m3 = msk[tb + 5 + y]; }
+                // four entries per LDS round trip; all four are loaded whatever yend is (a read past the table stays
+                // inside the wave's LDS: msk runs into tab, tab into cof) and dropped by selects -
+                // no exec-mask changes
+                const uint32_t *tp = tab + tb + 2 + y;
+                const unsigned long long *mp = msk + tb + 2 + y;
+                int32_t left = (int32_t)(yend - y);
+                RK_EXP(4)
+                while (__ballot(left > 0)) {
+                    uint32_t c0 = tp[0], c1 = tp[1], c2 = tp[2], c3 = tp[3];
+                    unsigned long long m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+                    c0 = left > 0 ? c0 : 0u; m0 = left > 0 ? m0 : 0ull;
+                    c1 = left > 1 ? c1 : 0u; m1 = left > 1 ? m1 : 0ull;
+                    c2 = left > 2 ? c2 : 0u; m2 = left > 2 ? m2 : 0ull;
+                    c3 = left > 3 ? c3 : 0u; m3 = left > 3 ? m3 : 0ull;
                     acc += c0 + c1 + c2 + c3;
                     accm = earlier(m3, earlier(m2, earlier(m1, earlier(m0, accm))));
-                    y += 4;
+                    tp += 4; mp += 4; left -= 4;
                 }
                 cum_b = up ? acc : n_b - c_x - acc;
                 L = up ? accm : e - E - accm;
             }
-            msk[tb] = 0ull;                                      // leave the masks clean for the next chunk
-            msk[tb + 2 + x] = 0ull;
+            RK_T(1);
             const uint32_t key = ok ? ((tb << 8) | x) : 0xFFFFFFFFu;
             uint32_t n = n_b + STEP * e, fx = c_x + STEP * E, cum_lo = cum_b + STEP * L;
-            if (!__ballot(ok && n_b + STEP * hits > RESCALE)) {
-                const uint32_t step = ok ? STEP : 0u;            // update_stats for the whole chunk (order-free sums)
+            const bool rescale = __ballot(ok && n_b + STEP * hits > RESCALE) != 0;
+            msk[tb] = 0ull;                                      // leave the masks clean for the next chunk
+            msk[tb + 2 + x] = 0ull;
+            if (!rescale) {
+                // update_stats for the whole chunk (order-free sums). (One plain store per table and per (table, state)
+                // by the first lane that holds it avoids the same-address atomics but needs two exec-mask regions:
+                // measured 4 % slower.)
+                const uint32_t step = ok ? STEP : 0u;
+                RK_EXP(8) {
                 atomicAdd(&tab[tb + 2 + x], step);
                 atomicAdd(&tab[tb], step);
-            } else {
+                }
+            }
+            if (rescale) {
                 // a table rescales inside this chunk: replay the chunk serially (qv_stream.c:9-25), every lane doing the
                 // same uniform work on the LDS tables, lane i keeping symbol i's values
                 unsigned long long rest = __ballot(ok);
@@ -790,16 +823,32 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             }
         }
         Record *buf = recbuf;
+        RK_T(2);
+        RK_EXP(2)
         __syncthreads();                                         // the previous chunk has been drained
+        RK_T(3);
         buf[lane * rb_stride + wave] = outr;
+        RK_EXP(2)
         __syncthreads();
+        RK_T(4);
         {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
             const uint32_t rd = threadIdx.x >> log2w, cw = threadIdx.x & (W - 1);
             const uint32_t col = cg * W + cw;                    // rec_index with the stream's part hoisted out of the loop
-            if (rb + rd < r1 && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
-                rec_g[(((uint32_t)(rb - r0) + rd) * (Cp >> 3) + (col >> 3)) * 512 + (col & 7)] = buf[rd * rb_stride + cw];
+            // The input bytes of chunks c+2 .. c+5 are taken over here (and the following four requested): the wait for
+            // them also waits for every store issued so far, and at this point the latest one is a whole chunk old.
+            if (((chunk + 2) & 3) == 0) park(rb + 128);
+            if (rb + rd < nr && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
+                RK_EXP(1)
+                rec_g[((uint64_t)(rb + rd) * (Cp >> 3) + (col >> 3)) * 512 + (col & 7)] = buf[rd * rb_stride + cw];
         }
+        RK_T(5);
     }
+#ifdef QVZ_PROFILE
+    if (lane == 0 && (g & 127) == 5 && (cg & 7) == 3) {             // a sample of the workgroups: same-address atomics are slow
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_rk_prof[i], prof[i]);
+        atomicAdd(&g_rk_prof[6], (unsigned long long)chunk);
+    }
+#endif
     if (active && !is_last)
         for (uint32_t i = lane; i < sw; i += 64) save[(uint64_t)g * total_words + b0 + i] = tab[i];
     if (bad) atomicOr(status, 1);
@@ -1211,12 +1260,11 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         slice_cap = (slice_cap + 3) & ~3u;
         const char *mk = getenv("QVZ_MODEL_KERNEL");             // development knob: "columns" forces the lane-per-column kernel
         if (fits && !(mk && strcmp(mk, "columns") == 0)) {
-            const uint32_t cof_words = (clusters * 2 * A + 1) / 2;
             // W = columns (waves) per workgroup: records leave as W * 16-byte runs, so wider is better for the stores,
             // but LDS decides how many waves a CU holds (k_code_records wants ~21 KB beside them). Take W = 4 if it
             // keeps 8 waves on a CU, else whichever of 4, 2, 8, 1 keeps the most.
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
-            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + cof_words + 192) * 4; };
+            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + clusters * 2 * A) * 4; };
             const size_t budget = 160 * 1024 - 21 * 1024;
             const uint32_t order[4] = {4, 2, 8, 1};
             uint32_t best_waves = 0;
@@ -1261,6 +1309,14 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         }
     }
     if (seg_reads < 4 || seg_reads > 0xFFFFFFFCull) { rc = qvz_set_error(QVZ_E_ARG, "workspace of %llu bytes holds fewer than 4 reads of %u streams", (unsigned long long)work_bytes, shards); goto done; }
+#ifdef QVZ_PROFILE
+    {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_prof), z, sizeof(z));
+        const int e = getenv("QVZ_RK_EXP") ? atoi(getenv("QVZ_RK_EXP")) : 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_exp), &e, sizeof(e));
+    }
+#endif
     if (getenv("QVZ_CODER_DEBUG"))
         fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu\n",
                 shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size());
@@ -1343,6 +1399,15 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipEventElapsedTime(&tb, evs[(size_t)i * 4 + 2], evs[(size_t)i * 4 + 3]));
         g_planes_ms[0] += ta; g_planes_ms[1] += tb;
     }
+#ifdef QVZ_PROFILE
+    {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rk_prof), sizeof(z));
+        const double ch = z[6] ? (double)z[6] : 1.0;
+        fprintf(stderr, "k_model_ranks cycles per wave and chunk: lookup %.0f  ranks %.0f  update+record %.0f  barrier1 %.0f  park+barrier2 %.0f  drain %.0f  (%.3g wave-chunks)\n",
+                z[0] / ch, z[1] / ch, z[2] / ch, z[3] / ch, z[4] / ch, z[5] / ch, ch);
+    }
+#endif
     if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder input addresses a quantizer without a model table (dead context or bad state)");
     else if (status & 2) rc = qvz_set_error(QVZ_E_NOMEM, "a shard's stream exceeded cap_per_shard=%llu bytes", (unsigned long long)cap_per_shard);
 done:

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Reduces two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of one bench.py step to HBM bytes per kernel and step.
+
+    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> > profiles/rNN_pmc_traffic.json
+
+Both counters are in KiB. FETCH_SIZE is doubled (gfx950 counts a 128-byte request as 64 bytes; every kernel here reads
+with wide coalesced loads - /opt/skills/guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is.
+"""
+import csv, glob, json, os, sys
+
+NAMES = {"k_model_ranks": "model_records", "k_model_columns": "model_records", "k_code_records": "code_records",
+         "k_quantize": "quantize", "k_pmf_walk": "pmf_hist", "k_kmeans_accum": "kmeans_accumulate",
+         "k_draws_transpose": "draws_transpose", "k_well_gen": "well_gen"}
+
+
+def collect(d, counter):
+    tot, launches = {}, {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                k = row["Kernel_Name"]
+                k = k[5:] if k.startswith("void ") else k
+                tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
+                launches.setdefault(k, set()).add(row["Dispatch_Id"])
+    return tot, {k: len(v) for k, v in launches.items()}
+
+
+def main():
+    fetch, nl = collect(sys.argv[1], "FETCH_SIZE")
+    write, _ = collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for kern in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0))):
+        short = next((v for p, v in NAMES.items() if kern.startswith(p)), None)
+        if short is None:
+            continue
+        fb, wb = int(fetch[kern] * 2 * 1024), int(write.get(kern, 0.0) * 1024)
+        e = out.setdefault(short, {"kernel": kern.split("(")[0], "launches_per_step": 0, "fetch_bytes": 0, "write_bytes": 0})
+        e["launches_per_step"] += nl[kern]
+        e["fetch_bytes"] += fb
+        e["write_bytes"] += wb
+    for e in out.values():
+        e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
