@@ -620,6 +620,7 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 #define RK_NONE 0xFFFFu
 #ifdef QVZ_PROFILE          // development build (make HIPFLAGS+=-DQVZ_PROFILE): shader-clock cycles per section of the chunk loop, summed over waves
 __device__ unsigned long long g_rk_prof[8];
+__device__ unsigned long long g_cr_prof[16];
 __device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no record store, 2 no transposition/barriers, 4 no cumulative loop, 8 no table update, 16 no timers
 #define RK_T(i) do { if (!(exp_ & 16)) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
 #define RK_EXP(bit) if (!(exp_ & (bit)))
@@ -879,6 +880,7 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     __shared__ uint32_t words[3][CR_B][64];                      // three slots: the bytes wave re-reads a rare symbol's word two blocks later
     __shared__ uint32_t ebits[2][CR_B][64];                      // value (16 bits) | bit count << 16, or CR_RARE | pending run
     __shared__ uint32_t final_l[64], final_s3[64];
+    __shared__ uint4 oring[64 * 5];                              // the bytes wave's output ring: 16 words per lane, 80-byte stride
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
@@ -897,7 +899,16 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     }
     const uint64_t nblk = (Tmax + CR_B - 1) / CR_B;              // the same in all four waves
     const bool fresh = is_first || !live;
+#ifdef QVZ_PROFILE          // busy / waiting cycles of each role between the block barriers
+    unsigned long long cr_busy = 0, cr_wait = 0, cr_t = __builtin_readcyclecounter();
+#define CR_BARRIER() do { const unsigned long long a_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+                          const unsigned long long b_ = __builtin_readcyclecounter(); cr_busy += a_ - cr_t; cr_wait += b_ - a_; cr_t = b_; } while (0)
+#define CR_REPORT() do { if (lane == 0 && (blockIdx.x & 15) == 3) { atomicAdd(&g_cr_prof[wave * 2], cr_busy); atomicAdd(&g_cr_prof[wave * 2 + 1], cr_wait); \
+                                                                    if (wave == 0) atomicAdd(&g_cr_prof[8], (unsigned long long)nblk); } } while (0)
+#else
 #define CR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define CR_REPORT() do { } while (0)
+#endif
     // barriers 0 .. nblk + 1 in every wave (+ one more on the last segment for the hand-over of l and scale3)
 
     if (wave == 3) {
@@ -952,6 +963,7 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         CR_BARRIER();                                            // barriers nblk and nblk + 1: the other waves run behind
         CR_BARRIER();
         if (is_last) CR_BARRIER();
+        CR_REPORT();
         return;
     }
 
@@ -992,6 +1004,7 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         } else if (live) {
             cs[g].l = l32 >> 10; cs[g].u = ~(nu32 >> 10) & MASK_M;
         }
+        CR_REPORT();
         return;
     }
 
@@ -1012,12 +1025,13 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
 #pragma unroll
             for (int jx = 0; jx < CR_B; ++jx) {
                 const uint32_t k = (w[jx] >> 5) & 31, j = w[jx] & 31;
-                const uint32_t top = (w[jx] >> 1) >> (31 - k);   // the k leading bits of l (0 when k = 0)
-                const uint32_t km1 = k ? k - 1 : 0u;
+                const uint32_t top = __builtin_amdgcn_ubfe(w[jx], 32 - k, k);   // the k leading bits of l (0 when k = 0)
                 const uint32_t s3 = k ? scale3 : 0u;             // the pending run goes out only when a bit is decided
                 const uint32_t nb = k + s3;
-                const uint32_t value = top + (((1u << (s3 & 31)) - 1) << km1);
-                ebits[slot][jx][lane] = nb > 16 ? (CR_RARE | s3) : (value | (nb << 16));
+                // (2^s3 - 1) << (k - 1): nothing when k = 0 (s3 = 0 then), so the shift count may wrap
+                uint32_t normal = (top + (((1u << (s3 & 31)) - 1) << ((k - 1) & 31))) | (nb << 16);
+                asm volatile("" : "+v"(normal));                 // computed in every lane: a select below, not an exec-mask region
+                ebits[slot][jx][lane] = nb > 16 ? (CR_RARE | s3) : normal;
                 scale3 = scale3 - s3 + j;
             }
             wslot = wslot == 2 ? 0u : wslot + 1;
@@ -1029,31 +1043,43 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         } else if (live) {
             cs[g].scale3 = scale3;
         }
+        CR_REPORT();
         return;
     }
 
     // ------------------------------------ bytes ------------------------------------
     // Symbols are taken in pairs (at most 16 bits each on top of fewer than 32 pending ones: the 64-bit accumulator
-    // holds them). After a pair the word at the top of the accumulator is STORED UNCONDITIONALLY at the write pointer
-    // and the pointer advances by 4 only if the word was complete (nbits >= 32): an incomplete word is overwritten
-    // later. No test, no exec-mask change, one store per pair. A pair with a long symbol in some lane goes through a
-    // wave-uniform branch to the code with exact bounds. Room is checked once per block, which makes a stream that
-    // comes within 128 bytes of cap_per_shard count as overflowed.
-    // Lanes past the last stream store too (zeros, never advancing): they are parked on the last 4 bytes of the output
-    // area, inside the 128-byte margin no stream may reach.
+    // holds them). After a pair the word at the top of the accumulator is WRITTEN UNCONDITIONALLY at the lane's write
+    // index and the index advances only if the word was complete (nbits >= 32): an incomplete word is overwritten
+    // later. No test, no exec-mask change. The words go to a 16-word ring per lane in LDS, not to memory: a store
+    // whose 64 lanes hit 64 different lines costs the wave (and the memory pipeline it shares with the model kernel)
+    // about as many cycles, four of them per block made this wave the slowest of the four. Once per block the lanes
+    // that have four complete words move them out as one 16-byte store (about five lanes per block at 1.4 bits per
+    // symbol). A block adds at most four complete words, so at most seven are ever waiting.
+    // A pair with a long symbol in some lane goes through a wave-uniform branch to the code with exact bounds (the
+    // ring is emptied first). Room is checked once per block, which makes a stream that comes within 128 bytes of
+    // cap_per_shard count as overflowed. Lanes past the last stream produce zero bits and never store.
     uint8_t *const base = live ? out + (uint64_t)g * cap : out + (uint64_t)shards * cap - 4;
     uint8_t *const end = live ? base + cap : base + 4 + 128;
-    uint8_t *p = base;
+    uint8_t *rb = base;                                          // where word 0 of the ring numbering lies
+    uint32_t wi = 0, fi = 0;                                     // words completed / moved out since rb (fi a multiple of 4)
     uint32_t nbits = 0;
     uint64_t acc = 0;
     bool ovf = false;
     if (!fresh) {
         const CoderState s = cs[g];
-        nbits = s.nbits; acc = s.acc; p = base + s.pos; ovf = s.overflow != 0;
+        nbits = s.nbits; acc = s.acc; rb = base + s.pos; ovf = s.overflow != 0;
     }
-    auto piecewise = [&](uint32_t e, uint32_t w) {               // one symbol, any number of bits, exact bounds
+    uint32_t *const myring = reinterpret_cast<uint32_t *>(oring) + lane * 20;   // 80-byte lane stride: 16-byte aligned, spreads the banks
+    auto drain = [&]() {                                         // everything complete goes out, word by word; the numbering restarts
+        for (uint32_t t = fi; __ballot(t < wi); ++t)
+            if (t < wi) *reinterpret_cast<uint32_t *>(rb + (uint64_t)t * 4) = myring[t & 15];
+        rb += (uint64_t)wi * 4;
+        wi = fi = 0;
+    };
+    auto piecewise = [&](uint32_t e, uint32_t w) {               // one symbol, any number of bits, exact bounds; ring empty
         LaneCoder c;
-        c.out = base; c.cap = cap; c.pos = (uint64_t)(p - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
+        c.out = base; c.cap = cap; c.pos = (uint64_t)(rb - base); c.acc = acc; c.nbits = nbits; c.overflow = ovf;
         c.l = 0; c.u = 0; c.scale3 = 0;
         if (e & CR_RARE) {
             const uint32_t k = (w >> 5) & 31, km1 = k - 1, top = w >> (32 - k);   // k >= 1 here
@@ -1065,7 +1091,14 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
             lc_put(c, e & 0xFFFF, e >> 16);
         }
         acc = c.acc; nbits = c.nbits; ovf = c.overflow;
-        p = base + c.pos;
+        rb = base + c.pos;
+    };
+    auto room = [&]() {                                          // out of room: keep the stores inside the stream's area
+        const bool tight = rb + (uint64_t)wi * 4 + 128 > end;
+        ovf = ovf || tight;
+        rb = tight ? base : rb;
+        wi = tight ? 0u : wi;
+        fi = tight ? 0u : fi;
     };
     uint32_t wslot = 0;                                          // (b - 2) % 3
     for (uint64_t b = 0; b <= nblk + 1; ++b) {
@@ -1075,30 +1108,34 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         uint32_t e[CR_B];
 #pragma unroll
         for (int jx = 0; jx < CR_B; ++jx) e[jx] = ebits[slot][jx][lane];
-        {                                                        // out of room: keep the stores inside the stream's area
-            const bool tight = p + 128 > end;
-            ovf = ovf || tight;
-            p = tight ? base : p;
-        }
+        room();
 #pragma unroll
         for (int jx = 0; jx < CR_B; jx += 2) {
             if (__ballot((e[jx] | e[jx + 1]) & CR_RARE)) {       // wave-uniform, rare
+                drain();
                 piecewise(e[jx], words[wslot][jx][lane]);
                 piecewise(e[jx + 1], words[wslot][jx + 1][lane]);
-                const bool tight = p + 128 > end;
-                ovf = ovf || tight;
-                p = tight ? base : p;
+                room();
                 continue;
             }
             acc = (acc << (e[jx] >> 16)) | (uint64_t)(e[jx] & 0xFFFF);
             acc = (acc << (e[jx + 1] >> 16)) | (uint64_t)(e[jx + 1] & 0xFFFF);
             nbits += (e[jx] >> 16) + (e[jx + 1] >> 16);          // < 32 + 32
-            *reinterpret_cast<uint32_t *>(p) = __builtin_bswap32((uint32_t)(acc >> ((nbits - 32) & 63)));
-            p += (nbits >> 5) << 2;                              // keep the word only if it was complete
+            myring[wi & 15] = __builtin_bswap32((uint32_t)(acc >> ((nbits - 32) & 63)));
+            wi += nbits >> 5;                                    // keep the word only if it was complete
             nbits &= 31;
+        }
+        if (__ballot(wi - fi >= 4)) {                            // wave-uniform; then only the lanes with four words store
+            if (wi - fi >= 4) {
+                *reinterpret_cast<uint4 *>(rb + (uint64_t)fi * 4) = *reinterpret_cast<const uint4 *>(myring + (fi & 15));
+                fi += 4;
+            }
         }
         wslot = wslot == 2 ? 0u : wslot + 1;
     }
+    drain();
+    uint8_t *const p = rb;
+    CR_REPORT();
     if (is_last) {
         CR_BARRIER();
         if (!live) return;
@@ -1112,6 +1149,7 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         cs[g].nbits = nbits; cs[g].acc = acc; cs[g].pos = (uint64_t)(p - base); cs[g].overflow = ovf ? 1u : 0u;
     }
 #undef CR_BARRIER
+#undef CR_REPORT
 }
 
 // every shard starts from the same initial model
@@ -1313,6 +1351,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     {
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_prof), z, sizeof(z));
+        { unsigned long long zc[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cr_prof), zc, sizeof(zc)); }
         const int e = getenv("QVZ_RK_EXP") ? atoi(getenv("QVZ_RK_EXP")) : 0;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_exp), &e, sizeof(e));
     }
@@ -1404,6 +1443,11 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         unsigned long long z[8] = {0};
         (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rk_prof), sizeof(z));
         const double ch = z[6] ? (double)z[6] : 1.0;
+        unsigned long long cr[16] = {0};
+        (void)hipMemcpyFromSymbol(cr, HIP_SYMBOL(g_cr_prof), sizeof(cr));
+        const double nb = cr[8] ? (double)cr[8] : 1.0;
+        fprintf(stderr, "k_code_records cycles per block of 8 symbols, busy/waiting: interval %.0f/%.0f  bits %.0f/%.0f  bytes %.0f/%.0f  loader %.0f/%.0f\n",
+                cr[0] / nb, cr[1] / nb, cr[2] / nb, cr[3] / nb, cr[4] / nb, cr[5] / nb, cr[6] / nb, cr[7] / nb);
         fprintf(stderr, "k_model_ranks cycles per wave and chunk: lookup %.0f  ranks %.0f  update+record %.0f  barrier1 %.0f  park+barrier2 %.0f  drain %.0f  (%.3g wave-chunks)\n",
                 z[0] / ch, z[1] / ch, z[2] / ch, z[3] / ch, z[4] / ch, z[5] / ch, ch);
     }

@@ -105,6 +105,21 @@ int main() {
     RUN(k_cvt_rt, 2, 3u, 1.5);
     RUN(k_rcp_f64, 1, 3u, 1.5);
     RUN(k_interval, 24, 3u, 1.5);
+    // partially filled waves: does a wave with 32 or 16 live lanes issue dependent instructions faster?
+#define RUNW(k, per, w, ...)                                                                         \
+    do {                                                                                             \
+        hipLaunchKernelGGL(k, dim3(1), dim3(w), 0, 0, d, __VA_ARGS__);                               \
+        hipLaunchKernelGGL(k, dim3(1), dim3(w), 0, 0, d, __VA_ARGS__);                               \
+        hipDeviceSynchronize();                                                                      \
+        hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);                                                  \
+        printf("%-14s %2d lanes %7.2f cycles per step (%d instr)\n", #k, w, (double)h[0] / (64.0 * REP), per); \
+    } while (0)
+    RUNW(k_add_u32, 1, 32, 3u, 1.5);
+    RUNW(k_add_u32, 1, 16, 3u, 1.5);
+    RUNW(k_fma_f64, 1, 32, 3u, 1.0000001);
+    RUNW(k_fma_f64, 1, 16, 3u, 1.0000001);
+    RUNW(k_interval, 24, 32, 3u, 1.5);
+    RUNW(k_interval, 24, 16, 3u, 1.5);
     hipLaunchKernelGGL(k_lds, dim3(1), dim3(64), 0, 0, d, 3u);
     hipDeviceSynchronize();
     hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
