@@ -1272,6 +1272,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> evs;                                // per segment: model start, model end, coder start, coder end
     uint32_t nseg = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> segs;            // (first read, reads) of every segment, relative to a stream's start
     {
         bool fits = true;
         for (uint32_t sx = 0; sx < Cx; ++sx) {
@@ -1299,11 +1300,11 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         const char *mk = getenv("QVZ_MODEL_KERNEL");             // development knob: "columns" forces the lane-per-column kernel
         if (fits && !(mk && strcmp(mk, "columns") == 0)) {
             // W = columns (waves) per workgroup: records leave as W * 16-byte runs, so wider is better for the stores,
-            // but LDS decides how many waves a CU holds (k_code_records wants ~21 KB beside them). Take W = 4 if it
+            // but LDS decides how many waves a CU holds (k_code_records wants 32 KB beside them). Take W = 4 if it
             // keeps 8 waves on a CU, else whichever of 4, 2, 8, 1 keeps the most.
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
             auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + clusters * 2 * A) * 4; };
-            const size_t budget = 160 * 1024 - 21 * 1024;
+            const size_t budget = 160 * 1024 - 32 * 1024;
             const uint32_t order[4] = {4, 2, 8, 1};
             uint32_t best_waves = 0;
             for (uint32_t w : order) {
@@ -1383,7 +1384,21 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
     }
-    nseg = (uint32_t)((longest + seg_reads - 1) / seg_reads);
+    // Segment list. When the two kernels overlap, the first model kernel and the last coder kernel still run alone:
+    // those two segments are a quarter of the others.
+    if (overlap && seg_reads >= 256 && longest > seg_reads) {
+        const uint64_t q = (seg_reads / 4) & ~(uint64_t)63;
+        const uint64_t tail_lo = (longest - q) & ~(uint64_t)63;                  // segment starts stay multiples of 64
+        const uint64_t mid = tail_lo - q;
+        const uint64_t nm = (mid + seg_reads - 1) / seg_reads;
+        const uint64_t each = (((mid + nm - 1) / nm) + 63) & ~(uint64_t)63;      // <= seg_reads (a multiple of 64 itself)
+        segs.push_back({0, q});
+        for (uint64_t lo = q; lo < tail_lo; lo += each) segs.push_back({lo, lo + each <= tail_lo ? each : tail_lo - lo});
+        segs.push_back({tail_lo, longest - tail_lo});
+    } else {
+        for (uint64_t lo = 0; lo < longest; lo += seg_reads) segs.push_back({lo, lo + seg_reads <= longest ? seg_reads : longest - lo});
+    }
+    nseg = (uint32_t)segs.size();
     evs.assign((size_t)nseg * 4, nullptr);
     for (size_t i = 0; i < evs.size(); ++i) TRY(hipEventCreate(&evs[i]));
     g_planes_ms[0] = g_planes_ms[1] = 0.0;
@@ -1397,7 +1412,8 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipStreamWaitEvent(s_coder, ev_start, 0));
     }
     for (uint32_t i = 0; i < nseg; ++i) {
-        seg_lo = (uint64_t)i * seg_reads;
+        seg_lo = segs[i].first;
+        const uint32_t seg_len = (uint32_t)segs[i].second;       // both kernels lay the segment's records out for this many reads
         const uint32_t mblocks = (uint32_t)(((uint64_t)shards * Cx + 255) / 256);
         const int is_first = i == 0, is_last = i + 1 == nseg;
         Record *buf = (Record *)((char *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * per_read : 0));
@@ -1409,22 +1425,22 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
             if (clusters > 1)
                 hipLaunchKernelGGL(k_model_ranks<true>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
+                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
             else
                 hipLaunchKernelGGL(k_model_ranks<false>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   (uint32_t)seg_reads, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
+                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
         } else if (clusters > 1)
             hipLaunchKernelGGL(k_model_columns<true>, dim3(mblocks), dim3(256), 0, s_model, d_qi, d_st, ld, d_labels, columns, clusters,
-                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, buf, d_status);
+                               d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status);
         else
             hipLaunchKernelGGL(k_model_columns<false>, dim3(mblocks), dim3(256), 0, s_model, d_qi, d_st, ld, d_labels, columns, clusters,
-                               d_first, shards, d_off, d_arena, words, seg_lo, (uint32_t)seg_reads, buf, d_status);
+                               d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status);
         TRY(hipEventRecord(e[1], s_model));
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
         hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(256), 0, s_coder, (const Record *)buf, Cx, d_first, shards,
-                           seg_lo, (uint32_t)seg_reads, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
+                           seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
         TRY(hipEventRecord(e[3], s_coder));
     }
     TRY(hipGetLastError());
