@@ -1117,6 +1117,123 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
     if (dead) atomicOr(status, 1);
 }
 
+// The same quantizer with the current column's tables in LDS. k_quantize above is bound by its two 2-byte gathers per
+// symbol: 64 lanes, 64 addresses - the texture path takes ~47 cycles per such instruction (measured: 0.68 symbols
+// per cycle and CU, 26 % of the HBM peak). Here a 512-thread workgroup (2048 reads) copies column s+1's tables
+// (ct 144 B + qs 20 736 B per cluster, 16-byte loads that hit L2) into the other half of a double buffer while it
+// quantizes column s out of LDS (ds_read_u16 gathers), one barrier per column; three workgroups share a CU so that
+// one's barrier wait is another's work. The copy costs 10 B per symbol of L2 traffic. It needs a distortion matrix
+// that depends on |x - y| only (all of the reference's -d choices, distortion.c:50-95): 72 doubles in LDS instead of
+// 72 x 72. With three clusters one buffer and two barriers per column; otherwise (more clusters, or a general
+// matrix) k_quantize.
+#define QZ_THREADS 512
+#define QZ_CLUSTER4 (10 + QVZ_QS_STRIDE / 8)       // uint4 per cluster and column: ct (9) + pad (1) + qs (1296)
+template <int NBUF, int NQ>
+__global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
+                                                             uint64_t n, uint32_t C, uint64_t ld, uint32_t K,
+                                                             const uint16_t *__restrict__ ct, const uint16_t *__restrict__ qs,
+                                                             const uint8_t *__restrict__ draws, uint64_t ldd,
+                                                             const double *__restrict__ dist, uint8_t *__restrict__ qv_out,
+                                                             uint8_t *__restrict__ qi_out, uint8_t *__restrict__ st_out,
+                                                             uint64_t ldo, double *__restrict__ err_out,
+                                                             int32_t *__restrict__ status) {
+    extern __shared__ uint4 qz_smem[];
+    double *sdist = reinterpret_cast<double *>(qz_smem);         // d(|x - y|), from row 0 of the matrix
+    uint4 *tbuf = qz_smem + QVZ_A / 2;
+    const uint32_t per_col4 = K * QZ_CLUSTER4;                   // uint4 per column (all clusters)
+    if (threadIdx.x < QVZ_A) sdist[threadIdx.x] = dist[threadIdx.x];
+    const uint64_t t = (uint64_t)blockIdx.x * QZ_THREADS + threadIdx.x;
+    const uint64_t i0 = 4 * t;
+    const bool active = i0 < n;                                  // idle threads still copy tables and meet the barriers
+    uint32_t lab4 = 0;
+    if (labels && active) lab4 = *reinterpret_cast<const uint32_t *>(labels + i0);
+    uint32_t cbase[4], prev[4] = {0, 0, 0, 0};                   // cluster's table base in the column buffer, in u16
+    double err[4] = {0.0, 0.0, 0.0, 0.0};
+    bool dead = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t l = (lab4 >> (8 * r)) & 0xFF;
+        cbase[r] = (l < K ? l : 0u) * (QZ_CLUSTER4 * 8);
+        dead = dead || (active && i0 + r < n && l >= K);
+    }
+    uint4 stg[NQ];
+    auto fetch = [&](uint32_t s) {                               // column s's tables -> registers
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t i = threadIdx.x + q * QZ_THREADS;
+            if (i < per_col4) {
+                const uint32_t l = i / QZ_CLUSTER4, j = i % QZ_CLUSTER4;
+                const uint64_t cs = (uint64_t)l * C + s;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (j < 9) v = reinterpret_cast<const uint4 *>(ct + cs * QVZ_CT_STRIDE)[j];
+                else if (j >= 10) v = reinterpret_cast<const uint4 *>(qs + cs * QVZ_QS_STRIDE)[j - 10];
+                stg[q] = v;
+            }
+        }
+    };
+    auto park = [&](uint4 *dst) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t i = threadIdx.x + q * QZ_THREADS;
+            if (i < per_col4) dst[i] = stg[q];
+        }
+    };
+    fetch(0);
+    park(tbuf);
+    __syncthreads();
+    // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
+    // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
+    const uint64_t io = active ? i0 : 0;
+    uint32_t x4n = *reinterpret_cast<const uint32_t *>(D + io);
+    uint32_t d4n = *reinterpret_cast<const uint32_t *>(draws + io);              // 7-bit draws, same layout
+    for (uint32_t s = 0; s < C; ++s) {
+        const uint16_t *cur = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s & 1) * per_col4 : 0u));
+        const uint32_t x4 = x4n, d4 = d4n;
+        if (s + 1 < C) {
+            fetch(s + 1);
+            x4n = *reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io);
+            d4n = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io);
+        }
+        uint32_t qv4 = 0, qi4 = 0, st4 = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t draw = (d4 >> (8 * r)) & 127;                                 // well.c:33-46
+            uint32_t x = (x4 >> (8 * r)) & 0xFF;
+            if (x >= QVZ_A) x = 0;
+            const uint16_t *cb = cur + cbase[r];
+            const uint32_t cv = cb[prev[r]];
+            uint32_t ctx = cv & 0xFF;
+            if (ctx == QVZ_NOT_FOUND) { dead = dead || (active && i0 + r < n); ctx = 0; }   // assert, codebook.c:164
+            const uint32_t qi = 2 * ctx + (draw >= (cv >> 8) ? 1u : 0u);                // codebook.c:165-170
+            const uint32_t qsv = cb[80 + qi * QVZ_A + x];
+            const uint32_t qv = qsv & 0xFF;
+            const uint32_t qvc = qv < QVZ_A ? qv : 0u;
+            const double dd = sdist[x > qvc ? x - qvc : qvc - x];                        // distortion.c:151
+            err[r] = (s == 0) ? dd : err[r] + dd;
+            prev[r] = qvc;
+            qv4 |= qv << (8 * r);
+            qi4 |= qi << (8 * r);
+            st4 |= (qsv >> 8) << (8 * r);
+        }
+        if (active) {
+            if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0) = qv4;
+            if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0) = qi4;
+            if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0) = st4;
+        }
+        if (s + 1 < C) {
+            if (NBUF == 1) __syncthreads();                      // everybody is done with column s's tables
+            park(tbuf + (NBUF == 2 ? ((s + 1) & 1) * per_col4 : 0u));
+        }
+        __syncthreads();
+    }
+    if (err_out && active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (i0 + r < n) err_out[i0 + r] = err[r];
+    }
+    if (dead) atomicOr(status, 1);
+}
+
 extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
                                 uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
                                 uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
@@ -1129,9 +1246,37 @@ extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, u
     if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
     if (!d_ct || !d_qs || !d_draws || !d_dist || !d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
     uint64_t n4 = (n + 3) / 4;
-    dim3 grid((unsigned)((n4 + 255) / 256));
-    hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, (hipStream_t)stream, d_sym, k > 1 ? d_labels : nullptr, n, c, ld,
-                       d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status);
+    const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // development knob: "global" keeps the tables in L1/L2
+    bool in_lds = k <= 3 && !(force && strcmp(force, "global") == 0);
+    if (in_lds) {                                                // the LDS kernel wants d(x, y) = f(|x - y|)
+        static thread_local double h_dist[QVZ_A * QVZ_A];
+        QVZ_HIP_CHECK(hipMemcpyAsync(h_dist, d_dist, sizeof(h_dist), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        QVZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        for (int y = 0; y < QVZ_A && in_lds; ++y)
+            for (int x = 0; x < QVZ_A; ++x)
+                if (memcmp(&h_dist[x + QVZ_A * y], &h_dist[x > y ? x - y : y - x], sizeof(double)) != 0) { in_lds = false; break; }
+    }
+    if (in_lds) {
+        dim3 grid((unsigned)((n4 + QZ_THREADS - 1) / QZ_THREADS));
+        const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
+#define QZ_LAUNCH(NBUF, NQ)                                                                                                      \
+        do {                                                                                                                     \
+            QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ>),                         \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+            hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,              \
+                               k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, \
+                               ld_out, d_err, d_status);                                                                         \
+        } while (0)
+        static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4, "stage registers");
+        if (k == 1) QZ_LAUNCH(2, 3);
+        else if (k == 2) QZ_LAUNCH(2, 6);
+        else QZ_LAUNCH(1, 8);
+#undef QZ_LAUNCH
+    } else {
+        dim3 grid((unsigned)((n4 + 255) / 256));
+        hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, (hipStream_t)stream, d_sym, k > 1 ? d_labels : nullptr, n, c, ld,
+                           d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status);
+    }
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
 }

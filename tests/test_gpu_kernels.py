@@ -281,6 +281,37 @@ def test_quantize_shard_equals_slice_of_full(K):
     assert torch.equal(part["err"], full["err"][a:b])
 
 
+def test_quantize_kernels_agree_and_general_distortion_matrix(K, monkeypatch):
+    """The LDS-table kernel (distortion = f(|x - y|)) and the L1/L2-gather kernel give the same planes and the same
+    per-read error bits; a matrix that is not a function of |x - y| goes through the general kernel and its per-read
+    error is the column-ordered sum of d[x + 72 * qv]."""
+    n, c = 9001, 29
+    rows = O.qgen1_rows(5, n, c)
+    cnt = O.stats(rows, np.zeros(n, np.uint8), 1)
+    d = O.distortion("L")
+    cb = O.generate_codebook(cnt[0], d, O.MODE_RATIO, 0.8)
+    ct, qs = tables_from_codebooks([cb])
+    sym = upload_sym(K, rows)
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    a = K.quantize(sym, n, ct, qs, draws, torch.from_numpy(d).cuda())
+    monkeypatch.setenv("QVZ_QUANTIZE_KERNEL", "global")
+    b = K.quantize(sym, n, ct, qs, draws, torch.from_numpy(d).cuda())
+    monkeypatch.delenv("QVZ_QUANTIZE_KERNEL")
+    for key in ("qv", "qi", "st"):
+        assert torch.equal(a[key][:, :n], b[key][:, :n]), key
+    assert torch.equal(a["err"], b["err"])
+    rng = np.random.default_rng(7)
+    g = np.ascontiguousarray(rng.random((72, 72)))               # no symmetry, no |x - y| structure
+    e = K.quantize(sym, n, ct, qs, draws, torch.from_numpy(g.reshape(-1)).cuda())
+    assert torch.equal(e["qv"][:, :n], a["qv"][:, :n])
+    qv = e["qv"][:, :n].cpu().numpy().astype(np.int64)           # (c, n)
+    x = (rows[:, :c].T.astype(np.int64) - 33)
+    want = np.zeros(n)
+    for s_ in range(c):
+        want = g.reshape(-1)[x[s_] + 72 * qv[s_]] if s_ == 0 else want + g.reshape(-1)[x[s_] + 72 * qv[s_]]
+    np.testing.assert_array_equal(e["err"].cpu().numpy(), want)
+
+
 def test_quantize_reports_undefined_context(K):
     rows = O.qgen1_rows(4, 400, 12)
     cnt = O.stats(rows, np.zeros(400, np.uint8), 1)
