@@ -47,6 +47,11 @@ void qvz_codebook_free(qvz_codebook_t *cb);
 
 /* distortion matrices d[x + 72*y] (reference src/distortion.c:50-95); host, 41 KB */
 int qvz_distortion_matrix(int type, double *h_dist /*[72*72]*/);
+/* -D FILE (reference src/distortion.c:100-145): up to 72 rows of comma-separated doubles (atof), row x column y =
+ * the cost of reconstructing true value x as y = d[x + 72*y]; lines starting with '#' are comments. Entries or rows
+ * the file does not hold are 0.0, with the reference's warning on stdout (there the short-row case never returns:
+ * its fill loop does not advance). Returns QVZ_OK, or QVZ_E_ARG when the file cannot be opened. */
+int qvz_distortion_matrix_file(const char *path, double *h_dist /*[72*72]*/);
 
 /* d_cnt: this cluster's counters [C][72][72] (device). mode/ratio: -f / -r and its argument.
  * guard: width of the band (absolute, on entropies in bits) inside which device-side search decisions are

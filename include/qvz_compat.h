@@ -87,7 +87,7 @@ struct quality_file_t {                                                         
 /* the calls of encode(), in order (main.c:20-91) */
 struct alphabet_t *alloc_alphabet(uint32_t size);                                    /* pmf.h:48,  pmf.c:11    */
 struct distortion_t *generate_distortion_matrix(uint8_t symbols, int type);          /* distortion.h:25, distortion.c:30 */
-struct distortion_t *gen_custom_distortion(uint8_t symbols, const char *filename);   /* not supported: exits   */
+struct distortion_t *gen_custom_distortion(uint8_t symbols, const char *filename);   /* distortion.h:26, distortion.c:100 */
 uint32_t load_file(const char *path, struct quality_file_t *info, uint64_t max_lines);  /* lines.h:80, lines.c:27 */
 struct cluster_list_t *alloc_cluster_list(struct quality_file_t *info);              /* cluster.h:12, cluster.c:24 */
 void do_kmeans_clustering(struct quality_file_t *info);                              /* cluster.h:24, cluster.c:212 */

@@ -37,6 +37,7 @@ typedef struct qvz_options {
     int seed_mode;            /* QVZ_SEED_* */
     uint32_t well_state[32];  /* used when seed_mode == QVZ_SEED_EXPLICIT */
     uint64_t chunk_reads;     /* reads per quantize/encode chunk (0 = default) */
+    const char *dist_file;    /* -D FILE when distortion == QVZ_DIST_CUSTOM (reference codebook.h:35, main.c:30-32) */
 } qvz_options_t;
 
 typedef struct qvz_result {

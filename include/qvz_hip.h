@@ -44,6 +44,7 @@ extern "C" {
 #define QVZ_DIST_MANHATTAN 1 /* reference include/distortion.h:7-9 */
 #define QVZ_DIST_MSE 2
 #define QVZ_DIST_LORENTZ 3
+#define QVZ_DIST_CUSTOM 4    /* -D FILE, reference include/distortion.h:10 */
 
 const char *qvz_hip_last_error(void);
 uint64_t qvz_hip_ld(uint64_t n);

@@ -69,10 +69,16 @@ struct distortion_t *generate_distortion_matrix(uint8_t symbols, int type) {   /
     return d;
 }
 
-struct distortion_t *gen_custom_distortion(uint8_t symbols, const char *filename) {
-    (void)symbols; (void)filename;
-    printf("Custom distortion matrices (-D) are not part of this build (SURVEY.md section 8f).\n");
-    exit(1);
+struct distortion_t *gen_custom_distortion(uint8_t symbols, const char *filename) {     /* distortion.c:100-145 */
+    (void)symbols;
+    struct distortion_t *d = (struct distortion_t *)calloc(1, sizeof(*d));
+    d->symbols = A;
+    d->distortion = (double *)calloc((size_t)A * A, sizeof(double));
+    if (qvz_distortion_matrix_file(filename, d->distortion)) {
+        perror("Unable to open distortion definition file");
+        exit(1);
+    }
+    return d;
 }
 
 uint32_t load_file(const char *path, struct quality_file_t *info, uint64_t max_lines) {   /* lines.c:27-82 */
@@ -139,6 +145,7 @@ static void options_from(const struct quality_file_t *info, qvz_options_t *o) {
     o->mode = r->mode == QVZ_MODE_FIXED ? QVZ_MODE_FIXED : QVZ_MODE_RATIO;        /* uninitialised in main.c without -f/-r */
     o->clusters = info->cluster_count;
     o->distortion = r->distortion;
+    o->dist_file = r->dist_file;                                                   /* -D, main.c:293-297 */
     o->ratio = r->ratio;
     o->cluster_threshold = r->cluster_threshold;
     const char *seed = getenv("QVZ_WELL_SEED");
@@ -165,7 +172,10 @@ void do_kmeans_clustering(struct quality_file_t *info) {                        
     }
     if (g_info) qvz_job_release(&g_job);
     g_info = info;
+    /* the matrix the caller built (main.c:30-38) is the one that counts; qvz_job_init makes its own from the options */
+    if (info->dist && info->dist->distortion && o.distortion == QVZ_DIST_CUSTOM) o.distortion = QVZ_DIST_MSE;
     if (qvz_job_init(&g_job, base, 0, info->lines, info->columns, &o)) die("do_kmeans_clustering");
+    if (info->dist && info->dist->distortion) memcpy(g_job.h_dist, info->dist->distortion, sizeof(g_job.h_dist));
     if (qvz_job_kmeans(&g_job, 1)) die("do_kmeans_clustering");
     uint64_t i = 0;
     for (uint32_t b = 0; b < info->block_count; ++b)

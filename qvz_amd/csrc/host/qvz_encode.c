@@ -75,7 +75,11 @@ int qvz_job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_t l
     job->C = columns;
     job->K = (uint32_t)opts->clusters;
     job->ld = qvz_hip_ld(lines);
-    if (qvz_distortion_matrix(opts->distortion, job->h_dist)) return qvz_job_fail(QVZ_E_ARG, "%s", qvz_hip_last_error());
+    if (opts->distortion == QVZ_DIST_CUSTOM) {                                /* main.c:30-32 */
+        if (qvz_distortion_matrix_file(opts->dist_file, job->h_dist)) return qvz_job_fail(QVZ_E_ARG, "%s", qvz_hip_last_error());
+    } else if (qvz_distortion_matrix(opts->distortion, job->h_dist)) {
+        return qvz_job_fail(QVZ_E_ARG, "%s", qvz_hip_last_error());
+    }
 
     /* Centroid picks (cluster.c:198-204) use libc rand() in whatever state the process is in. They are drawn here,
      * BEFORE the first HIP call: initialising the HIP runtime consumes rand() values of its own, which would shift
@@ -622,6 +626,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
             case QVZ_DIST_MANHATTAN: printf("L1 distortion: %f\n", R.distortion); break;
             case QVZ_DIST_MSE: printf("MSE distortion: %f\n", R.distortion); break;
             case QVZ_DIST_LORENTZ: printf("log(1+L1) distortion: %f\n", R.distortion); break;
+            case QVZ_DIST_CUSTOM: printf("Custom distortion: %f\n", R.distortion); break;          /* main.c:110-112 */
             default: break;
         }
         printf("Lines: %llu\n", (unsigned long long)R.lines);

@@ -69,9 +69,11 @@ int main(int argc, char **argv) {
                 }
                 i += 2;
                 break;
-            case 'D':
-                printf("Custom distortion matrices (-D) are not part of this build (SURVEY.md section 8f).\n");
-                exit(1);
+            case 'D':                                             /* main.c:293-297 */
+                opts.distortion = QVZ_DIST_CUSTOM;
+                opts.dist_file = has_value ? argv[i + 1] : NULL;
+                i += 2;
+                break;
             default:
                 printf("Unrecognized option -%c.\n", argv[i][1]);
                 usage(argv[0]);
@@ -94,6 +96,7 @@ int main(int argc, char **argv) {
                 case QVZ_DIST_MSE: printf("MSE will be used as a distortion metric.\n"); break;
                 case QVZ_DIST_LORENTZ: printf("log(1+L1) will be used as a distortion metric.\n"); break;
                 case QVZ_DIST_MANHATTAN: printf("L1 will be used as a distortion metric.\n"); break;
+                case QVZ_DIST_CUSTOM: printf("A custom distortion metric stored in %s will be used.\n", opts.dist_file); break;   /* main.c:334-336 */
             }
             printf("Compression will use %d clusters, with a movement threshold of %.0f.\n", opts.clusters, opts.cluster_threshold);
         }

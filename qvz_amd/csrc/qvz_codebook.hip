@@ -24,6 +24,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -80,6 +81,33 @@ extern "C" int qvz_distortion_matrix(int type, double *d) {
             }
             d[x + A * y] = v;
         }
+    return QVZ_OK;
+}
+
+extern "C" int qvz_distortion_matrix_file(const char *path, double *d) {       // distortion.c:100-145
+    if (!path || !d) return qvz_set_error(QVZ_E_ARG, "null distortion file name");
+    FILE *fp = fopen(path, "rt");
+    if (!fp) return qvz_set_error(QVZ_E_ARG, "Unable to open distortion definition file %s", path);
+    memset(d, 0, sizeof(double) * A * A);
+    static thread_local char line[65536];
+    int x = 0;
+    while (x < A && fgets(line, sizeof(line), fp) != nullptr) {
+        if (line[0] == '#') continue;
+        const char *field = line;
+        int y = 0;
+        while (y < A && field != nullptr) {
+            d[x + A * y] = atof(field);
+            field = strchr(field, ',');
+            if (field) field += 1;
+            y += 1;
+        }
+        if (y < A) {
+            printf("Warning: one or more entries in the distortion matrix on line %d were missing", x);
+            printf(" they have been filled with 0.0\n");
+        }
+        x += 1;
+    }
+    fclose(fp);
     return QVZ_OK;
 }
 

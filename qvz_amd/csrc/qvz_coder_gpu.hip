@@ -1299,20 +1299,18 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         slice_cap = (slice_cap + 3) & ~3u;
         const char *mk = getenv("QVZ_MODEL_KERNEL");             // development knob: "columns" forces the lane-per-column kernel
         if (fits && !(mk && strcmp(mk, "columns") == 0)) {
-            // W = columns (waves) per workgroup: records leave as W * 16-byte runs, so wider is better for the stores,
-            // but LDS decides how many waves a CU holds (k_code_records wants 32 KB beside them). Take W = 4 if it
-            // keeps 8 waves on a CU, else whichever of 4, 2, 8, 1 keeps the most.
+            // W = columns (waves) per workgroup: records leave as W * 16-byte runs. W = 4 wherever a workgroup fits
+            // beside k_code_records' 32 KB of LDS (measured with three clusters, where LDS holds one such workgroup
+            // per CU: W = 4 0.40 s, W = 2 0.42 s, W = 1 0.67 s for the model kernels; W = 8 never paid).
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
             auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + clusters * 2 * A) * 4; };
             const size_t budget = 160 * 1024 - 32 * 1024;
-            const uint32_t order[4] = {4, 2, 8, 1};
-            uint32_t best_waves = 0;
+            const uint32_t order[3] = {4, 2, 1};
             for (uint32_t w : order) {
                 const size_t need = need_of(w);
-                if (need > 160 * 1024) continue;
-                const uint32_t resident = (uint32_t)(need <= budget ? budget / need : 1) * w;
-                if (resident > best_waves) { best_waves = resident; rk_waves = w; rk_lds = need; }
-                if (best_waves >= 8) break;
+                if (need > (w == 1 ? (size_t)160 * 1024 : budget)) continue;
+                rk_waves = w; rk_lds = need;
+                break;
             }
             if (we) {
                 const uint32_t w = (uint32_t)atoi(we);

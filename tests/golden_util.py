@@ -10,7 +10,13 @@ import oracle_lib as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
-CASES = MANIFEST["cases"]
+CUSTOM_DIST_CASES = {n: e for n, e in MANIFEST["cases"].items() if e.get("custom_dist")}   # -D FILE: CLI-level tests only
+CASES = {n: e for n, e in MANIFEST["cases"].items() if not e.get("custom_dist")}
+
+
+def cli_flags(entry):
+    """The reference CLI flags of a fixture as an argv list ("@name" = a file in tests/golden/)."""
+    return [os.path.join(GOLD, f[1:]) if f.startswith("@") else f for f in entry["flags"].split()]
 
 
 def md5(b):

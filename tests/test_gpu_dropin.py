@@ -26,14 +26,16 @@ COMPAT = os.path.join(ROOT, "qvz_amd", "libqvzcompat.so")
 
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="qvz_dropin is built only where /root/reference is present")
-@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "t2k_c3_f05_M", "twolevel_c2_f05", "cfg1_r10_M", "uniform72_r20_A"])
+@pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "t2k_c3_f05_M", "twolevel_c2_f05", "cfg1_r10_M", "uniform72_r20_A",
+                                  "t2k_D_asym_f06"])
 def test_reference_main_on_compat_library_is_byte_identical(tmp_path, name):
-    e = G.CASES[name]
+    e = G.MANIFEST["cases"][name]
     inp = tmp_path / "in.txt"
-    inp.write_bytes(G.case_rows(name).tobytes())
+    inp.write_bytes(O.qgen1_rows(e["input"]["seed"], e["input"]["n"], e["input"]["c"]).tobytes() if e.get("custom_dist")
+                    else G.case_rows(name).tobytes())
     q, u = str(tmp_path / "d.q"), str(tmp_path / "d.u")
     env = dict(os.environ, QVZ_WELL_SEED="debug")
-    out = subprocess.run([DROPIN] + e["flags"].split() + ["-s", "-v", "-u", u, str(inp), q], env=env, capture_output=True,
+    out = subprocess.run([DROPIN] + G.cli_flags(e) + ["-s", "-v", "-u", u, str(inp), q], env=env, capture_output=True,
                          text=True, check=True).stdout
     assert G.md5(open(q, "rb").read()) == e["q_md5"]
     assert G.md5(open(u, "rb").read()) == e["u_md5"]

@@ -94,6 +94,37 @@ def test_cli_binary_matches_reference_output_and_stats_line(tmp_path, name):
     assert m.group(1) == f"{e['rate']:.4f}" and m.group(2) == f"{e['distortion']:.4f}" and int(m.group(4)) == e["size"]
 
 
+def test_cli_custom_distortion_file_matches_reference(tmp_path):
+    """-D FILE (src/distortion.c:100-145, main.c:293-297): an asymmetric matrix; .q, -u and the -s line are the reference's
+    (fixture made by the reference binary), the file decodes to the -u text, and a file holding the MSE matrix gives
+    the bytes of -d M."""
+    name = "t2k_D_asym_f06"
+    e = G.CUSTOM_DIST_CASES[name]
+    rows = O.qgen1_rows(e["input"]["seed"], e["input"]["n"], e["input"]["c"])
+    assert G.md5(rows.tobytes()) == e["input_md5"]
+    inp = str(tmp_path / "in.txt")
+    open(inp, "wb").write(rows.tobytes())
+    q, u, d = str(tmp_path / "c.q"), str(tmp_path / "c.u"), str(tmp_path / "c.dec")
+    env = dict(os.environ, QVZ_WELL_SEED="debug")
+    out = subprocess.run([QVZ_BIN] + G.cli_flags(e) + ["-s", "-v", "-u", u, inp, q], env=env, capture_output=True,
+                         text=True, check=True).stdout
+    assert G.md5(open(q, "rb").read()) == e["q_md5"] == G.md5(G.gz(name + ".q.gz"))
+    assert G.md5(open(u, "rb").read()) == e["u_md5"]
+    m = re.search(r"rate, ([\d.]+), distortion, ([\d.]+), time, ([\d.]+), size, (\d+) ", out)
+    assert m and m.group(1) == f"{e['rate']:.4f}" and m.group(2) == f"{e['distortion']:.4f}" and int(m.group(4)) == e["size"]
+    assert "A custom distortion metric stored in" in out and "Custom distortion: " in out
+    subprocess.run([QVZ_BIN, "-x", q, d], env=env, check=True, capture_output=True)
+    assert open(d, "rb").read() == open(u, "rb").read()
+    mse = tmp_path / "mse.txt"
+    mse.write_text("# (x - y)^2\n" + "\n".join(",".join(str((x - y) ** 2) for y in range(72)) for x in range(72)) + "\n")
+    qa, qb = str(tmp_path / "a.q"), str(tmp_path / "b.q")
+    subprocess.run([QVZ_BIN, "-c", "1", "-D", str(mse), "-f", "0.6", inp, qa], env=env, check=True, capture_output=True)
+    subprocess.run([QVZ_BIN, "-c", "1", "-d", "M", "-f", "0.6", inp, qb], env=env, check=True, capture_output=True)
+    assert open(qa, "rb").read() == open(qb, "rb").read()
+    r = subprocess.run([QVZ_BIN, "-D", str(tmp_path / "missing.txt"), inp, qa], env=env, capture_output=True, text=True)
+    assert r.returncode != 0
+
+
 def test_cli_verbose_lines_and_errors(tmp_path):
     inp, _ = write_input(tmp_path, "t2k_c3_f05_M")
     env = dict(os.environ, QVZ_WELL_SEED="debug")

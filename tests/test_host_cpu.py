@@ -128,6 +128,29 @@ def test_quantizer_tables_from_host_builder():
                 np.testing.assert_array_equal(qs[s, qi], want)
 
 
+def test_distortion_matrix_file_parser(tmp_path, capfd):
+    """qvz_distortion_matrix_file = gen_custom_distortion (src/distortion.c:100-145): comma-separated atof fields,
+    row x column y -> d[x + 72*y], '#' lines skipped, short rows / missing rows are 0.0 with the reference's warning."""
+    import ctypes as C
+    from qvz_amd._lib import lib
+    rng = np.random.default_rng(3)
+    m = np.round(rng.random((72, 72)) * 50, 3)
+    text = ["# a comment"] + [",".join(repr(float(v)) for v in m[x]) for x in range(72)]
+    text[5] = ",".join(text[5].split(",")[:10])                     # row 4 keeps 10 entries
+    text = text[:60]                                                # rows 59.. are missing
+    f = tmp_path / "d.txt"
+    f.write_text("\n".join(text) + "\n")
+    d = np.full(72 * 72, -1.0)
+    assert lib().qvz_distortion_matrix_file(str(f).encode(), d.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    want = np.zeros((72, 72))
+    want[:59] = m[:59]
+    want[4, 10:] = 0.0
+    np.testing.assert_array_equal(d.reshape(72, 72).T, want)       # d[x + 72*y]
+    C.CDLL(None).fflush(None)                                       # the library prints through C stdio
+    assert "Warning: one or more entries in the distortion matrix on line 4 were missing" in capfd.readouterr().out
+    assert lib().qvz_distortion_matrix_file(str(tmp_path / "none.txt").encode(), d.ctypes.data_as(C.POINTER(C.c_double))) != 0
+
+
 def test_distortion_matrix_host():
     from qvz_amd import kernels as K
     for kind in "MLA":

@@ -83,7 +83,19 @@ CASES = [
     # long enough for update_stats to rescale (a table passes n > 2^19 after 65536 hits, qv_stream.c:15-24)
     dict(name="rescale_140k_c4", inp=dict(kind="qgen1", seed=12, n=140000, c=4), flags="-c 1 -d M -f 0.5", store=False),
     dict(name="rescale_c2_100k_c3", inp=dict(kind="qgen1", seed=13, n=100000, c=3), flags="-c 2 -d M -r 0.8", store=False),
+    # -D FILE (src/distortion.c:100-145): an asymmetric matrix, "@name" = tests/golden/name (written by dist_asym_text below)
+    dict(name="t2k_D_asym_f06", inp=dict(kind="qgen1", seed=1, n=2000, c=30), flags="-c 1 -D @dist_asym.txt -f 0.6", store=True,
+         custom_dist=True),
 ]
+
+
+def dist_asym_text():
+    """72 rows x 72 columns, row x column y = cost of reconstructing x as y: overshoot costs 1.5|x-y|, undershoot 2|x-y|.
+    Short numbers: the reference reads rows through a 1024-byte line buffer (distortion.c:105,117)."""
+    lines = ["# asymmetric distortion matrix for the -D fixture: row = true value, column = reconstruction"]
+    for x in range(72):
+        lines.append(",".join(repr(1.5 * (y - x) if y > x else 2.0 * (x - y)) for y in range(72)))
+    return ("\n".join(lines) + "\n").encode()
 
 
 def md5(b):
@@ -115,15 +127,22 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     manifest = {"generator": "tools/make_golden.py", "reference_binary": "oracle/_ref/qvz_ref_fixedseed "
                 "(reference sources + -DLINUX -DDEBUG -O3: WELL state = 32 x 0x55555555)", "cases": {}}
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None      # regenerate one case, keep the rest
+    if only:
+        manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+    open(os.path.join(GOLD, "dist_asym.txt"), "wb").write(dist_asym_text())
     with tempfile.TemporaryDirectory() as td:
         for case in CASES:
+            if only and case["name"] != only:
+                continue
             name, spec = case["name"], case["inp"]
             rows = input_rows(spec)
             text = rows.tobytes()
             inp = os.path.join(td, name + ".txt")
             open(inp, "wb").write(text)
             q, u = os.path.join(td, name + ".q"), os.path.join(td, name + ".u")
-            out = subprocess.run([os.path.join(REF, "qvz_ref_fixedseed")] + case["flags"].split() +
+            flags = [os.path.join(GOLD, f[1:]) if f.startswith("@") else f for f in case["flags"].split()]
+            out = subprocess.run([os.path.join(REF, "qvz_ref_fixedseed")] + flags +
                                  ["-s", "-u", u, inp, q], check=True, capture_output=True, text=True).stdout
             dec = os.path.join(td, name + ".dec")
             subprocess.run([os.path.join(REF, "qvz_ref_fixedseed"), "-x", q, dec], check=True, capture_output=True)
@@ -133,6 +152,8 @@ def main():
             entry = dict(input=spec, flags=case["flags"], input_md5=md5(text), q_md5=md5(qb), u_md5=md5(ub),
                          q_size=len(qb), rate=float(sline[1]), distortion=float(sline[3]), size=int(sline[7]),
                          stored=bool(case.get("store")), phase=bool(case.get("phase")))
+            if case.get("custom_dist"):
+                entry["custom_dist"] = True
             if spec["kind"] != "qgen1":
                 gz_write(os.path.join(GOLD, name + ".in.gz"), text)
             if case.get("store"):
