@@ -28,6 +28,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "qvz_codebook.h"
 #include "qvz_internal.h"
 
@@ -526,13 +529,33 @@ struct CbWork {
     LmDesign *lout = nullptr, *hout = nullptr;     // device window results and their pinned host mirror
     uint32_t *stop = nullptr;
     uint8_t *pin = nullptr;                        // pinned staging for everything else that crosses PCIe per column
+    uint32_t capC = 0;                             // columns the buffers were sized for (0: nothing allocated)
+    int device = -1;
     void release() {
         void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, qprev, ctx_sym, lin, lout, stop};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (hout) (void)hipHostFree(hout);
         if (pin) (void)hipHostFree(pin);
+        *this = CbWork();
     }
 };
+
+// Workspaces are kept between calls (one per concurrent caller): hipMalloc / hipFree of a dozen small buffers per
+// codebook costs milliseconds, and hipFree waits for every stream of the device - including kernels of other work the
+// caller overlaps with the generation.
+static std::mutex g_cbw_mu;
+static std::vector<CbWork *> g_cbw_free;
+static CbWork *cbw_acquire() {
+    std::lock_guard<std::mutex> lk(g_cbw_mu);
+    if (g_cbw_free.empty()) return new CbWork();
+    CbWork *w = g_cbw_free.back();
+    g_cbw_free.pop_back();
+    return w;
+}
+static void cbw_give_back(CbWork *w) {
+    std::lock_guard<std::mutex> lk(g_cbw_mu);
+    g_cbw_free.push_back(w);
+}
 
 static thread_local uint64_t g_deferred = 0;   // per calling thread: clusters may be generated by concurrent host threads
 extern "C" uint64_t qvz_hip_codebook_deferred_decisions(void) { return g_deferred; }
@@ -552,20 +575,28 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
                     qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
     const size_t tile = (size_t)A * A;
-    QVZ_HIP_CHECK(hipMalloc(&W.P, (size_t)C * tile * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.marg, (size_t)C * A * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.qpmf[0], tile * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.qpmf[1], tile * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.xpmf, tile * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.dist, tile * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.zero_rows, tile * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.rprev, A * sizeof(double)));
-    QVZ_HIP_CHECK(hipMalloc(&W.qprev, 2 * tile));
-    QVZ_HIP_CHECK(hipMalloc(&W.ctx_sym, A));
-    QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
-    QVZ_HIP_CHECK(hipMalloc(&W.lout, tile * sizeof(LmDesign)));
-    QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocDefault));
-    QVZ_HIP_CHECK(hipMalloc(&W.stop, A * sizeof(uint32_t)));
+    int dev = 0;
+    QVZ_HIP_CHECK(hipGetDevice(&dev));
+    if (W.capC < C || W.device != dev) {
+        W.release();
+        QVZ_HIP_CHECK(hipMalloc(&W.P, (size_t)C * tile * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.marg, (size_t)C * A * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.qpmf[0], tile * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.qpmf[1], tile * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.xpmf, tile * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.dist, tile * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.zero_rows, tile * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.rprev, A * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.qprev, 2 * tile));
+        QVZ_HIP_CHECK(hipMalloc(&W.ctx_sym, A));
+        QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
+        QVZ_HIP_CHECK(hipMalloc(&W.lout, tile * sizeof(LmDesign)));
+        QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocDefault));
+        QVZ_HIP_CHECK(hipMalloc(&W.stop, A * sizeof(uint32_t)));
+        QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A), hipHostMallocDefault));
+        W.capC = C;
+        W.device = dev;
+    }
     {
         double hT[A * A];                          // d(i, r) = dist[i + 72 r] laid out with r fastest
         for (int i = 0; i < A; ++i)
@@ -584,7 +615,6 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     // Per column two stream syncs (after the context propagation, after the design window). Everything copied per
     // column sits in pinned memory (pageable hipMemcpyAsync calls block and go through a bounce buffer), and what the
     // next column's propagation needs from this one is double-buffered so that no third sync is needed.
-    QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A), hipHostMallocDefault));
     double *hx = reinterpret_cast<double *>(W.pin);
     LmIn *hin = reinterpret_cast<LmIn *>(hx + tile);
     double *hr2 = reinterpret_cast<double *>(hin + A);                  // [2][A]
@@ -751,10 +781,10 @@ extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, cons
     if (guard <= 0.0) guard = 1e-9;
     g_deferred = 0;
     memset(out->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
-    CbWork W;
-    const int rc = generate(d_cnt, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, W);
+    CbWork *W = cbw_acquire();
+    const int rc = generate(d_cnt, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
     (void)hipStreamSynchronize((hipStream_t)stream);
-    W.release();
+    cbw_give_back(W);
     return rc;
 }
 
