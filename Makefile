@@ -10,7 +10,7 @@ HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -std=c++17 -Iincl
 CFLAGS   ?= -O2 -ffp-contract=off -fPIC -std=gnu11 -Wall -Wextra -Iinclude
 CSRC     := qvz_amd/csrc
 HIP_SRCS := $(wildcard $(CSRC)/*.hip)
-HOST_SRCS:= $(CSRC)/host/qvz_coder.c $(CSRC)/host/qvz_encode.c $(CSRC)/host/qvz_shard.c $(CSRC)/host/qvz_decode.c
+HOST_SRCS:= $(CSRC)/host/qvz_coder.c $(CSRC)/host/qvz_encode.c $(CSRC)/host/qvz_shard.c $(CSRC)/host/qvz_decode.c $(CSRC)/host/qvz_fastq.c
 HOST_OBJS:= $(HOST_SRCS:.c=.o)
 HIP_OBJS := $(HIP_SRCS:.hip=.hip.o)
 HDRS     := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h)

@@ -22,6 +22,10 @@ extern "C" {
 #define QVZ_SEED_DEBUG 1     /* 32 x 0x55555555                      (reference -DDEBUG, qv_stream.c:83)   */
 #define QVZ_SEED_EXPLICIT 2  /* options.well_state                                                          */
 
+#define QVZ_INPUT_AUTO 0      /* FASTQ if the text starts with a four-line record whose second line is bases, else qualities */
+#define QVZ_INPUT_QUAL 1      /* one quality string per line: what the reference reads (src/lines.c:27-82) */
+#define QVZ_INPUT_FASTQ 2     /* four-line FASTQ records: the fourth lines are encoded (reference README.md:30-34 leaves this to the user) */
+
 typedef struct qvz_options {
     /* the fields of qv_options_t the encoder reads (reference include/codebook.h:28-40) */
     int verbose;
@@ -38,6 +42,7 @@ typedef struct qvz_options {
     uint32_t well_state[32];  /* used when seed_mode == QVZ_SEED_EXPLICIT */
     uint64_t chunk_reads;     /* reads per quantize/encode chunk (0 = default) */
     const char *dist_file;    /* -D FILE when distortion == QVZ_DIST_CUSTOM (reference codebook.h:35, main.c:30-32) */
+    int input_format;         /* QVZ_INPUT_*: what the input text is (default: look at it) */
 } qvz_options_t;
 
 typedef struct qvz_result {
@@ -53,7 +58,15 @@ typedef struct qvz_result {
 
 void qvz_options_default(qvz_options_t *o);   /* reference defaults, main.c:198-204 (+ mode = RATIO) */
 
-/* text: the whole input file image (rows of c+1 bytes). fout receives the .q file, fu (may be NULL) the -u text. */
+/* FASTQ front end (host/qvz_fastq.c). detect: does the text start with a four-line record (line 1 '@', line 2 bases,
+ * line 3 '+', lines 2 and 4 equally long)? qualities: the fourth line of every record as rows of columns+1 bytes
+ * ('\n'-terminated, the layout of src/lines.c:44-71) in a malloc'd buffer the caller frees; all reads must have the
+ * length of the first (QVZ_E_DATA otherwise, with the byte offset of the offending record in the message). */
+int qvz_fastq_detect(const uint8_t *text, uint64_t bytes);
+int qvz_fastq_qualities(const uint8_t *text, uint64_t bytes, uint8_t **rows_out, uint64_t *reads_out, uint32_t *columns_out);
+
+/* text: the whole input file image (rows of c+1 bytes, or FASTQ: see input_format). fout receives the .q file, fu (may be
+ * NULL) the -u text. */
 int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
                       qvz_result_t *res);
 /* mmaps `in_path` like load_file (lines.c:27-82) and encodes it to `out_path`. */

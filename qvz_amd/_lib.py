@@ -50,6 +50,8 @@ SIGNATURES = {
     "qvz_codebook_free": (None, [C.c_void_p]),
     "qvz_distortion_matrix": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "qvz_distortion_matrix_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
+    "qvz_fastq_detect": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "qvz_fastq_qualities": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "qvz_hip_generate_codebook": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.c_int, C.c_double,
                                             C.c_double, C.c_void_p, C.c_void_p]),
     "qvz_hip_codebook_deferred_decisions": (C.c_uint64, []),

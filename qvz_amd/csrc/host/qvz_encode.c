@@ -596,8 +596,18 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     qvz_result_t R;
     memset(&R, 0, sizeof(R));
     const double t_start = now();
+    uint8_t *fq_rows = NULL;                                      /* FASTQ input: the quality lines, in load_file's layout */
+    if (opts->input_format == QVZ_INPUT_FASTQ || (opts->input_format == QVZ_INPUT_AUTO && qvz_fastq_detect(text, bytes))) {
+        uint64_t reads = 0;
+        uint32_t columns = 0;
+        int frc = qvz_fastq_qualities(text, bytes, &fq_rows, &reads, &columns);
+        if (frc) return frc;
+        if (opts->verbose) printf("FASTQ input: %llu reads of %u quality values\n", (unsigned long long)reads, columns);
+        text = fq_rows;
+        bytes = reads * ((uint64_t)columns + 1);
+    }
     int rc = qvz_job_init(&job, text, bytes, 0, 0, opts);
-    if (rc) return rc;
+    if (rc) { free(fq_rows); return rc; }
     uint64_t head_bytes = 0;
     if ((rc = qvz_job_upload(&job))) goto done;
     if ((rc = qvz_job_kmeans(&job, 0))) goto done;
@@ -640,6 +650,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
                R.distortion, R.t_total, (unsigned long long)R.stream_bytes);
 done:
     qvz_job_release(&job);
+    free(fq_rows);
     if (res) *res = R;
     return rc;
 }

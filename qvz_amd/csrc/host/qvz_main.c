@@ -80,6 +80,9 @@ int main(int argc, char **argv) {
                 exit(1);
         }
     }
+    if (getenv("QVZ_INPUT")) {                                    /* "fastq" / "qual": skip the look at the input */
+        opts.input_format = strcmp(getenv("QVZ_INPUT"), "fastq") == 0 ? QVZ_INPUT_FASTQ : strcmp(getenv("QVZ_INPUT"), "qual") == 0 ? QVZ_INPUT_QUAL : QVZ_INPUT_AUTO;
+    }
     if (file_idx != 2) {                                          /* main.c:305-309 */
         printf("Missing required filenames.\n");
         usage(argv[0]);

@@ -16,7 +16,7 @@ class Options(C.Structure):
     _fields_ = [("verbose", C.c_int), ("stats", C.c_int), ("mode", C.c_int), ("clusters", C.c_int),
                 ("distortion", C.c_int), ("ratio", C.c_double), ("cluster_threshold", C.c_double),
                 ("uncompressed_name", C.c_char_p), ("device", C.c_int), ("seed_mode", C.c_int),
-                ("well_state", C.c_uint32 * 32), ("chunk_reads", C.c_uint64), ("dist_file", C.c_char_p)]
+                ("well_state", C.c_uint32 * 32), ("chunk_reads", C.c_uint64), ("dist_file", C.c_char_p), ("input_format", C.c_int)]
 
 
 class Result(C.Structure):

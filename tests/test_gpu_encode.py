@@ -125,6 +125,27 @@ def test_cli_custom_distortion_file_matches_reference(tmp_path):
     assert r.returncode != 0
 
 
+def test_cli_fastq_input_equals_quality_file_input(tmp_path):
+    """A FASTQ file (four-line records) is detected and encoded exactly like the file of its quality lines; QVZ_INPUT=qual
+    turns the detection off (the FASTQ text is then an ordinary, malformed, quality file)."""
+    from test_host_cpu import make_fastq
+    name = "t2k_f05_L"
+    e = G.CASES[name]
+    inp, rows = write_input(tmp_path, name)
+    fq = tmp_path / "reads.fastq"
+    fq.write_bytes(make_fastq(rows, seed=3))
+    qa, qb, ua = str(tmp_path / "a.q"), str(tmp_path / "b.q"), str(tmp_path / "a.u")
+    env = dict(os.environ, QVZ_WELL_SEED="debug")
+    out = subprocess.run([QVZ_BIN] + e["flags"].split() + ["-v", "-u", ua, str(fq), qa], env=env, check=True, capture_output=True,
+                         text=True).stdout
+    assert f"FASTQ input: {rows.shape[0]} reads of {rows.shape[1] - 1} quality values" in out
+    subprocess.run([QVZ_BIN] + e["flags"].split() + [inp, qb], env=env, check=True, capture_output=True)
+    assert open(qa, "rb").read() == open(qb, "rb").read()
+    assert G.md5(open(qa, "rb").read()) == e["q_md5"] and G.md5(open(ua, "rb").read()) == e["u_md5"]
+    r = subprocess.run([QVZ_BIN] + e["flags"].split() + [str(fq), qa], env=dict(env, QVZ_INPUT="qual"), capture_output=True, text=True)
+    assert r.returncode != 0
+
+
 def test_cli_verbose_lines_and_errors(tmp_path):
     inp, _ = write_input(tmp_path, "t2k_c3_f05_M")
     env = dict(os.environ, QVZ_WELL_SEED="debug")

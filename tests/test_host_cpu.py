@@ -128,6 +128,59 @@ def test_quantizer_tables_from_host_builder():
                 np.testing.assert_array_equal(qs[s, qi], want)
 
 
+def make_fastq(rows, seed=0, crlf=False, final_newline=True):
+    """FASTQ text around the quality rows: headers of varying length, '+' or '+name' third lines, random bases."""
+    rng = np.random.default_rng(seed)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        name = b"@read%d/%s len=%d" % (i, b"x" * int(rng.integers(0, 40)), c)
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=c))
+        plus = b"+" if i % 3 else b"+" + name[1:]
+        out += [name, eol, seq, eol, plus, eol, rows[i, :c].tobytes(), eol]
+    if not final_newline:
+        out.pop()
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("n,c,crlf,final_newline", [(7, 12, False, True), (300, 40, True, False), (9000, 150, False, True)])
+def test_fastq_front_end_extracts_the_quality_lines(n, c, crlf, final_newline):
+    """qvz_fastq_detect / qvz_fastq_qualities: the rows handed on are exactly the quality strings,
+    also when they begin with '@' or '+', with CRLF line ends, without a final newline, and across the four scanner
+    threads (inputs above 1 MiB)."""
+    import ctypes as C
+    from qvz_amd._lib import lib
+    rows = O.qgen1_rows(21, n, c).copy()
+    rows[::5, 0] = ord("@")                                          # quality strings that look like headers ...
+    rows[1::7, 0] = ord("+")                                         # ... or like separator lines
+    fq = make_fastq(rows, seed=n, crlf=crlf, final_newline=final_newline)
+    buf = np.frombuffer(fq, dtype=np.uint8)
+    assert lib().qvz_fastq_detect(buf.ctypes.data, buf.size) == 1
+    plain = np.ascontiguousarray(rows).reshape(-1)
+    assert lib().qvz_fastq_detect(plain.ctypes.data, plain.size) == 0     # a quality file is not FASTQ
+    out, reads, cols = C.c_void_p(), C.c_uint64(), C.c_uint32()
+    assert lib().qvz_fastq_qualities(buf.ctypes.data, buf.size, C.byref(out), C.byref(reads), C.byref(cols)) == 0
+    assert (reads.value, cols.value) == (n, c)
+    got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n * (c + 1),)).copy()
+    C.CDLL(None).free(out)
+    assert got.tobytes() == rows.tobytes()
+
+
+def test_fastq_front_end_refuses_ragged_reads():
+    import ctypes as C
+    from qvz_amd._lib import lib
+    rows = O.qgen1_rows(22, 50, 20)
+    fq = make_fastq(rows)
+    lines = fq.split(b"\n")
+    lines[4 * 17 + 1] = lines[4 * 17 + 1][:-3]                       # read 17 is three bases / qualities short
+    lines[4 * 17 + 3] = lines[4 * 17 + 3][:-3]
+    bad = np.frombuffer(b"\n".join(lines), dtype=np.uint8)
+    out, reads, cols = C.c_void_p(), C.c_uint64(), C.c_uint32()
+    assert lib().qvz_fastq_qualities(bad.ctypes.data, bad.size, C.byref(out), C.byref(reads), C.byref(cols)) != 0
+    assert b"read length differs" in lib().qvz_encode_last_error()
+
+
 def test_distortion_matrix_file_parser(tmp_path, capfd):
     """qvz_distortion_matrix_file = gen_custom_distortion (src/distortion.c:100-145): comma-separated atof fields,
     row x column y -> d[x + 72*y], '#' lines skipped, short rows / missing rows are 0.0 with the reference's warning."""
