@@ -47,7 +47,7 @@ ALG_BYTES_PER_SYMBOL = {
     "pmf_hist": 1.0,             # each symbol read once (+1 B/read of labels when k > 1, added below)
     "kmeans_assign": 1.0,
     "kmeans_accumulate": 1.0,    # + labels re-read per column when k > 1 (2 B/sym)
-    "quantize": 5.0,             # symbol in, draw in, qv out, (qi, st) out
+    "quantize": 4.0,             # symbol in, draw in, (qi, st) out; qv (the -u product) is written only when asked for (+1)
     "well_draws": 3.0,           # word stream written once and read once, draw matrix written once
     "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out (host / gpu-feed coders only)
     "model_records": 18.0,       # qi + st in, one 16-byte record out

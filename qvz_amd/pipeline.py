@@ -210,8 +210,11 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     t3 = time.perf_counter()
     main_stream.wait_stream(side)
     ddist = torch.from_numpy(dmat).to(dev)
+    # the quantized values themselves (the -u product) are written only for a caller that keeps them: the coder needs
+    # the quantizer index and the state, the distortion the per-read error
+    want = ("qv", "qi", "st", "err") if (keep or keep_device) else ("qi", "st", "err")
     with timer.span("quantize"):
-        out = K.quantize(sym, n, ct, qs, draws, ddist, labels=labels if k > 1 else None, k=k)
+        out = K.quantize(sym, n, ct, qs, draws, ddist, labels=labels if k > 1 else None, k=k, want=want)
     if not want_reuse and reuse is None:
         del draws
     feed = None
