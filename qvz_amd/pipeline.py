@@ -117,20 +117,9 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     iters = 0
     if reuse is not None:
         labels, means, iters = reuse["labels"], reuse["means"], reuse["kmeans_iterations"]
-    while k == 1 and reuse is None:
-        # One cluster: every read is in it whatever the centroid is (cluster.c:75-98 finds the nearest of one), so the
-        # assignment pass is skipped, and a second iteration would recompute the same sums - the means cannot move
-        # again. What remains of the reference's loop is one accumulation and its iteration count (2 if the first
-        # update moved the centroid by more than the threshold, cluster.c:230-233, else 1).
-        counts.fill_(n)
-        with timer.span("kmeans_accumulate"):
-            K.kmeans_accumulate(sym, n, labels, k, acc=acc)
-        if group is not None:
-            dist_mod.all_reduce(acc, group=group)
-            dist_mod.all_reduce(counts, group=group)
-        moved, status = K.kmeans_update(acc, counts, means)
-        iters = 2 if moved[0].item() > threshold else 1
-        break
+    # One cluster: every read is in it whatever the centroid is (cluster.c:75-98 finds the nearest of one), so there is
+    # no assignment pass, and the one accumulation the reference's loop amounts to (column sums of the bytes) is read off
+    # the PMF counters below instead of costing a pass over the symbols of its own.
     while k > 1 and reuse is None:
         counts.zero_()
         acc.zero_()
@@ -161,6 +150,15 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
             K.pmf_hist(sym, n, labels=labels if k > 1 else None, k=k, cnt=cnt)
         if group is not None:
             dist_mod.all_reduce(cnt, group=group)
+    if k == 1 and reuse is None:
+        # sum over the reads of byte_s = sum over x of (x + 33) * #(X_s = x), exact in int64; a second iteration would
+        # recompute the same sums, so the iteration count is 2 if this update moved the centroid by more than the
+        # threshold (cluster.c:230-233), else 1
+        col = cnt[0].sum(dim=1, dtype=torch.int64)                                   # (c, 72)
+        acc[0] = (col * (torch.arange(72, device=dev, dtype=torch.int64) + 33)).sum(dim=1)
+        counts[0] = col[0].sum().to(torch.int32)
+        moved, status = K.kmeans_update(acc, counts, means)
+        iters = 2 if moved[0].item() > threshold else 1
     torch.cuda.synchronize()
     wall["pmf"] = time.perf_counter() - t1
 
