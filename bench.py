@@ -263,7 +263,7 @@ def main():
         }
         if args.roundtrip and args.coder != "host":
             line["roundtrip"] = roundtrip
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:               # the CPU baseline is timed on rank 0 of the 1-GPU run only
             line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")
         print(json.dumps(line), flush=True)
     if world > 1:
