@@ -3,6 +3,8 @@
 #   qvz_amd/bin/qvz       the drop-in command line front end (C), linked against the library
 # hipcc cross-compiles without a GPU. -ffp-contract=off: the codebook path is decision-bearing FP64 and the
 # reference is built without FMA (hard part 2).
+MAKEFLAGS += -r          # no built-in rules ("%: %.o" would make x.hip depend on x.hip.o)
+.SUFFIXES:
 HIPCC    ?= hipcc
 CC       ?= gcc
 ARCH     ?= gfx950
