@@ -38,6 +38,29 @@ def test_single_shard_equals_reference_stream(name):
     assert abs(r["distortion"] - e["distortion"]) < 1e-4
 
 
+@pytest.mark.parametrize("k,dist,mode,ratio", [(5, "M", "f", 0.6), (4, "L", "r", 1.5)])
+def test_more_clusters_than_the_lds_quantizer_holds_equals_the_oracle(k, dist, mode, ratio):
+    """Four and five clusters (the general quantizer kernel, model tables of several clusters per column, a cluster-id
+    symbol per read): whole file image and -u text equal the oracle's, single stream and three shards through both coders."""
+    from qvz_amd import host, kernels as K, pipeline as P
+    from test_gpu_kernels import upload_sym
+    n, c = 6000, 21
+    rows = O.qgen1_rows(31 + k, n, c)
+    omode = O.MODE_RATIO if mode == "f" else O.MODE_FIXED
+    ref = O.encode(rows, k=k, mode=omode, ratio=ratio, dist=dist)
+    sym = upload_sym(K, rows)
+    lines = P.reference_centroid_lines(n, k)
+    means0 = torch.from_numpy(np.stack([rows[i, :c] - 33 for i in lines]).astype(np.uint8)).cuda()
+    kw = dict(clusters=k, mode=host.MODE_RATIO if mode == "f" else host.MODE_FIXED, ratio=ratio, dist=dist, keep=True)
+    r = P.encode_pass(sym, n, 0, n, means0, shards=1, coder="gpu", **kw)
+    assert K.untranspose_text(r["qv"], n).cpu().numpy().tobytes() == ref["u"]
+    blob = K.write_header(k, c, n) + b"".join(cb.serialize() for cb in r["codebooks"]) + O.WELL_DEBUG_STATE.tobytes()
+    assert blob + r["streams"][0] == ref["q"]
+    a = P.encode_pass(sym, n, 0, n, means0, shards=3, threads=2, coder="host", **kw)
+    b = P.encode_pass(sym, n, 0, n, means0, shards=3, coder="gpu", **kw)
+    assert a["streams"] == b["streams"]
+
+
 @pytest.mark.parametrize("name,shards,threads", [("t2k_r10_M", 2, 2), ("t2k_c3_f05_M", 5, 3), ("cfg1_f05_L", 16, 8),
                                                   ("tiny5_r10", 3, 2)])
 def test_every_shard_is_reference_decodable(name, shards, threads):
