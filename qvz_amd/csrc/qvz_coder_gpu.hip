@@ -492,6 +492,7 @@ __device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint3
 // record t of stream g is at ((g / 64 * nblk8 + t / 8) * 64 + g % 64) * 8 + t % 8 with nblk8 = seg_reads * Cp / 8.
 // So the coder reads one contiguous 8 KiB per block of 8 symbols (sequential for HBM) instead of 64 runs of 128
 // bytes 2-30 MB apart, while the model kernel still writes W * 16-byte runs.
+#define QVZ_CID_SLOTS 8   // several clusters: record positions 0 (cluster id) .. 7 (zero records) precede the columns (k_model_ranks)
 __device__ __forceinline__ uint64_t rec_index(uint32_t g, uint64_t t, uint64_t nblk8) {
     return (((uint64_t)(g >> 6) * nblk8 + (t >> 3)) * 64 + (g & 63)) * 8 + (t & 7);
 }
@@ -503,10 +504,12 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                                                        const uint32_t *__restrict__ off, uint32_t *__restrict__ arena,
                                                        uint32_t arena_words, uint64_t seg_lo, uint32_t seg_reads,
                                                        Record *__restrict__ rec, int32_t *__restrict__ status) {
-    const uint32_t Cx = C + (HAVE_LABELS ? 1u : 0u);             // records per read: [cluster id,] column 0 .. C-1
+    const uint32_t Cw = C + (HAVE_LABELS ? 1u : 0u);             // lanes per stream: [cluster id,] column 0 .. C-1
+    const uint32_t Cx = C + (HAVE_LABELS ? (uint32_t)QVZ_CID_SLOTS : 0u);   // record positions per read (see k_model_ranks)
     const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (uint64_t)shards * Cx) return;
-    const uint32_t g = (uint32_t)(id / Cx), sx = (uint32_t)(id % Cx);
+    if (id >= (uint64_t)shards * Cw) return;
+    const uint32_t g = (uint32_t)(id / Cw), sx = (uint32_t)(id % Cw);
+    const uint32_t pos = !HAVE_LABELS ? sx : sx == 0 ? 0u : sx - 1 + QVZ_CID_SLOTS;
     const uint64_t r0 = first[g] + seg_lo, rend = first[g + 1];  // r0 is a multiple of 4
     if (r0 >= rend) return;
     const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
@@ -576,8 +579,10 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                     w = make_record(n, cum_lo, fx);
                 }
             }
-            rec[rec_index(g, (r + j - r0) * Cp + sx, nblk8)] = w;
-            if (sx + 1 == Cx)                                    // the read's pad records
+            rec[rec_index(g, (r + j - r0) * Cp + pos, nblk8)] = w;
+            if (cluster_lane)                                    // the reserved positions behind the cluster id
+                for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec[rec_index(g, (r + j - r0) * Cp + pc, nblk8)] = make_double2(0.0, 0.0);
+            if (sx + 1 == Cw)                                    // the read's pad records
                 for (uint32_t pc = Cx; pc < Cp; ++pc) rec[rec_index(g, (r + j - r0) * Cp + pc, nblk8)] = make_double2(0.0, 0.0);
         }
     }
@@ -628,6 +633,78 @@ __device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no rec
 #define RK_T(i) do { } while (0)
 #define RK_EXP(bit)
 #endif
+// Read lists per (stream, cluster) for k_model_ranks<true>: list[cstart[g*K + l] + j] = number (relative to the stream's
+// first read) of the j-th read of stream g that belongs to cluster l. One workgroup of four waves per stream; wave w owns
+// the w-th quarter of the stream's reads, pass 1 counts, pass 2 writes in ascending order (a chunk of 64 reads is taken
+// cluster by cluster: ballot of the first remaining lane's label).
+__global__ __launch_bounds__(256) void k_cluster_lists(const uint8_t *__restrict__ labels, const uint64_t *__restrict__ first,
+                                                       uint32_t K, uint32_t *__restrict__ clist, uint64_t *__restrict__ cstart,
+                                                       int32_t *__restrict__ status) {
+    __shared__ uint32_t cntw[4][256], basew[4][256];
+    const uint32_t g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t f0 = first[g], f1 = first[g + 1];
+    const uint64_t len = f1 - f0, per = ((len + 3) / 4 + 63) & ~(uint64_t)63;
+    const uint64_t lo = per * wave < len ? per * wave : len, hi = lo + per < len ? lo + per : len;
+    for (uint32_t i = threadIdx.x; i < 4 * 256; i += 256) (&cntw[0][0])[i] = 0;
+    __syncthreads();
+    bool bad = false;
+    for (uint64_t j = lo + lane; j < hi; j += 64) {
+        const uint32_t l = labels[f0 + j];
+        if (l < K) atomicAdd(&cntw[wave][l], 1u); else bad = true;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t l = 0; l < K; ++l) {
+            cstart[(uint64_t)g * K + l] = f0 + run;
+            for (uint32_t w = 0; w < 4; ++w) { basew[w][l] = run; run += cntw[w][l]; }
+        }
+    }
+    __syncthreads();
+    for (uint64_t j0 = lo; j0 < hi; j0 += 64) {
+        const uint64_t j = j0 + lane;
+        const bool valid = j < hi;
+        const uint32_t l = valid ? labels[f0 + j] : 0xFFFFFFFFu;
+        unsigned long long rest = __ballot(valid && l < K);
+        while (rest) {
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)l, __builtin_ctzll(rest));
+            const unsigned long long m = __ballot(l == lead);
+            const uint32_t base = __hip_atomic_load(&basew[wave][lead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // wave-uniform
+            if (l == lead) clist[f0 + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)j;
+            if (lane == 0) __hip_atomic_store(&basew[wave][lead], base + (uint32_t)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rest &= ~m;
+        }
+    }
+    if (bad) atomicOr(status, 1);
+}
+
+// segpos[i * S*K + g*K + l] = number of entries of list (g, l) below segment boundary i (bounds[i] reads into the stream)
+__global__ __launch_bounds__(256) void k_cluster_segpos(const uint32_t *__restrict__ clist, const uint64_t *__restrict__ cstart,
+                                                        const uint64_t *__restrict__ first, uint32_t shards, uint32_t K,
+                                                        const uint32_t *__restrict__ bounds, uint32_t nbounds,
+                                                        uint32_t *__restrict__ segpos) {
+    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t SK = (uint64_t)shards * K;
+    if (id >= SK * nbounds) return;
+    const uint32_t i = (uint32_t)(id / SK), gl = (uint32_t)(id % SK), g = gl / K, l = gl % K;
+    const uint64_t a = cstart[gl], e = l + 1 < K ? cstart[gl + 1] : first[g + 1];   // the lists of a stream lie back to back
+    const uint32_t *lst = clist + a;
+    uint32_t lo = 0, hi = (uint32_t)(e - a);
+    const uint32_t b = bounds[i];
+    while (lo < hi) {                                            // first entry >= b
+        const uint32_t mid = (lo + hi) / 2;
+        if (lst[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    segpos[id] = lo;
+}
+
+// With several clusters (HAVE_LABELS) a read's record group is [cluster id, 7 zero records, column 0 .. C-1, zero pad]
+// (QVZ_CID_SLOTS reserved positions, so that no workgroup mixes the two kinds of work below), and a workgroup of the
+// column positions serves ONE cluster (blockIdx.z): it walks the list of that cluster's reads in the stream
+// (k_cluster_lists) 64 at a time, so a wave needs the tables of one cluster only - the LDS footprint, and with it the
+// number of waves a CU holds, is that of the one-cluster case - and every lane of a chunk has a symbol. The workgroups
+// of the reserved positions (cluster z = 0 only) take the reads in file order: the cluster id of every read is a symbol
+// of its own table (qv_compressor.c:86), the other reserved positions are zero records.
 template <bool HAVE_LABELS>
 __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                       const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
@@ -635,45 +712,63 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                                                       const uint32_t *__restrict__ colbase, const uint32_t *__restrict__ tmpl,
                                                       uint32_t *__restrict__ save, uint32_t total_words, uint32_t slice_cap,
                                                       uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
-                                                      uint32_t log2w, Record *__restrict__ rec, int32_t *__restrict__ status) {
+                                                      uint32_t log2w, Record *__restrict__ rec, int32_t *__restrict__ status,
+                                                      const uint32_t *__restrict__ clist, const uint64_t *__restrict__ cstart,
+                                                      const uint32_t *__restrict__ segpos_lo, const uint32_t *__restrict__ segpos_hi) {
     extern __shared__ uint4 rk_smem[];
     // the wave index is wave-uniform, which the compiler cannot see: readfirstlane keeps everything derived from it
     // (column, table slice, activity) in scalar registers and its tests in scalar branches
     const uint32_t W = 1u << log2w, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const uint32_t Cx = C + (HAVE_LABELS ? 1u : 0u);
-    const uint32_t g = blockIdx.x, cg = blockIdx.y;
-    const uint32_t sx = cg * W + wave;                           // position in the read's record group: [cluster id,] column 0 ..
+    const uint32_t Cx = C + (HAVE_LABELS ? (uint32_t)QVZ_CID_SLOTS : 0u);
+    const uint32_t g = blockIdx.x, cg = blockIdx.y, z = HAVE_LABELS ? blockIdx.z : 0u;
+    const uint32_t sx = cg * W + wave;                           // position in the read's record group
+    const bool lists = HAVE_LABELS && cg * W >= QVZ_CID_SLOTS;   // this workgroup walks cluster z's reads
+    if (HAVE_LABELS && !lists && z) return;                      // the reserved positions belong to the z = 0 workgroups
     const uint32_t Cp = (Cx + 7) & ~7u;
     const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;
     auto uniform64 = [](uint64_t v) -> uint64_t {               // same value in every lane: keep it in scalar registers
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     };
-    const uint64_t r0 = uniform64(first[g] + seg_lo), rend = uniform64(first[g + 1]);
+    const uint64_t f0 = uniform64(first[g]);
+    const uint64_t r0 = f0 + seg_lo, rend = uniform64(first[g + 1]);
     if (r0 >= rend) return;                                      // whole workgroup
-    const uint32_t nr = rend - r0 < seg_reads ? (uint32_t)(rend - r0) : seg_reads;   // reads of this stream in this segment
+    uint32_t nr = rend - r0 < seg_reads ? (uint32_t)(rend - r0) : seg_reads;   // reads of this stream in this segment
+    const uint32_t *lp = nullptr;                                // list entries of this segment (stream-relative read numbers)
+    if (lists) {
+        const uint32_t j0 = segpos_lo[g * K + z], j1 = segpos_hi[g * K + z];
+        nr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(j1 - j0));
+        lp = clist + uniform64(cstart[g * K + z]) + j0;
+    }
     const uint32_t rb_stride = W + 1;                            // +1: conflict-free transposition
     Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [64][W + 1]
-    // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, and per (cluster, quantizer) of the column its table's
+    uint32_t *rowbuf = reinterpret_cast<uint32_t *>(recbuf + 64 * rb_stride);   // [2][4][64]: segment rows of the reads of two blocks of four chunks (lists)
+    // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, and per quantizer of the column its table's
     // offset in the slice | alphabet size << 16 (RK_NONE, size 0: no table), so that one LDS read resolves a symbol
-    unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride) +
-                              (size_t)wave * ((3 * slice_cap + K * 2 * A) / 2);
+    unsigned long long *msk = reinterpret_cast<unsigned long long *>(rowbuf + (HAVE_LABELS ? 512 : 0)) + (size_t)wave * ((3 * slice_cap + 2 * A) / 2);
     uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
     uint32_t *cof = tab + slice_cap;
-    const bool active = sx < Cx;
     const bool cluster_wave = HAVE_LABELS && sx == 0;
-    const uint32_t s = HAVE_LABELS ? sx - 1 : sx;
+    const bool active = HAVE_LABELS ? (cluster_wave || (lists && sx < Cx)) : sx < Cx;
+    const uint32_t s = HAVE_LABELS ? sx - QVZ_CID_SLOTS : sx;
+    const uint32_t slice = !HAVE_LABELS ? sx : cluster_wave ? 0u : 1u + s * K + z;   // tables of (column, cluster)
     uint32_t b0 = 0, sw = 0;
     if (active) {
-        b0 = colbase[sx];
-        sw = colbase[sx + 1] - b0;
+        b0 = colbase[slice];
+        sw = colbase[slice + 1] - b0;
         const uint32_t *src = is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0;
-        for (uint32_t i = lane; i < sw; i += 64) { tab[i] = src[i]; msk[i] = 0ull; }
-        if (!cluster_wave)
-            for (uint32_t i = lane; i < K * 2 * A; i += 64) {
-                const uint32_t o = coff[(uint64_t)sx * K * 2 * A + i];
-                cof[i] = o == RK_NONE ? (uint32_t)RK_NONE : (o | src[o + 1] << 16);
-            }
+        if (nr == 0) {                                           // no read of this cluster here: the state passes through
+            if (is_first && !is_last)
+                for (uint32_t i = lane; i < sw; i += 64) save[(uint64_t)g * total_words + b0 + i] = src[i];
+        } else {
+            for (uint32_t i = lane; i < sw; i += 64) { tab[i] = src[i]; msk[i] = 0ull; }
+            if (!cluster_wave)
+                for (uint32_t i = lane; i < 2 * A; i += 64) {
+                    const uint32_t o = coff[(uint64_t)slice * 2 * A + i];
+                    cof[i] = o == RK_NONE ? (uint32_t)RK_NONE : (o | src[o + 1] << 16);
+                }
+        }
     }
+    if (nr == 0) return;                                         // whole workgroup (lists only)
     __syncthreads();
 
     Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index)
@@ -684,15 +779,23 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // loop and nothing is staged through LDS. No bounds branch: a read index past the stream's last read is clamped to
     // it, idle waves read plane 0, and `on` below ignores what such lanes loaded.
     uint32_t q_cur = 0, x_cur = 0, lab_cur = 0, q_nx[4], x_nx[4], lab_nx[4] = {0, 0, 0, 0};
-    const uint8_t *const qplane = qi + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + r0;
-    const uint8_t *const xplane = st + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + r0;
-    auto fetch = [&](uint32_t ro) {                              // ro = read offset in the segment
+    uint32_t r_cur[4] = {0, 0, 0, 0}, r_nx[4] = {0, 0, 0, 0}, r_nn[4] = {0, 0, 0, 0};   // lists: stream-relative read numbers
+    const uint8_t *const qplane = qi + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + (lists ? f0 : r0);
+    const uint8_t *const xplane = st + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + (lists ? f0 : r0);
+    auto fetch_list = [&](uint32_t ro) {                         // lists: the read numbers of chunks ro/64 .. ro/64 + 3
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t r = ro + j * 64 + lane, rc = r < nr ? r : nr - 1;
+            const uint32_t e = ro + j * 64 + lane;
+            r_nn[j] = lp[e < nr ? e : nr - 1];
+        }
+    };
+    auto fetch = [&](uint32_t ro) {                              // ro = read (or list entry) offset in the segment
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t r = ro + j * 64 + lane, rc = lists ? r_nx[j] : (r < nr ? r : nr - 1);
             q_nx[j] = qplane[rc];
             x_nx[j] = xplane[rc];
-            if (HAVE_LABELS) lab_nx[j] = labels[r0 + rc];
+            if (HAVE_LABELS && cluster_wave) lab_nx[j] = labels[r0 + rc];
         }
     };
     // Table look-up of a chunk: one LDS read (table offset and alphabet size) that does not depend on the counts; it is
@@ -704,9 +807,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         const bool on = active && ro + lane < nr;
         const uint32_t sh = (ch & 3) * 8;
         const uint32_t q = (q_cur >> sh) & 0xFF, xs = (x_cur >> sh) & 0xFF;
-        const uint32_t raw = HAVE_LABELS ? (lab_cur >> sh) & 0xFF : 0u;
+        const uint32_t raw = HAVE_LABELS && cluster_wave ? (lab_cur >> sh) & 0xFF : 0u;
         const uint32_t cl = raw < K ? raw : 0u;
-        const uint32_t ent = cof[cl * 2 * A + (q < 2 * A ? q : 0u)];
+        const uint32_t ent = cof[q < 2 * A ? q : 0u];
         const uint32_t tb = cluster_wave ? 0u : (q < 2 * A ? ent & 0xFFFFu : (uint32_t)RK_NONE);
         const uint32_t card = cluster_wave ? K : ent >> 16;
         const uint32_t x = cluster_wave ? cl : xs;
@@ -719,9 +822,20 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     auto park = [&](uint32_t ro) {                               // the requested bytes become the current block; request the next
         q_cur = q_nx[0] | q_nx[1] << 8 | q_nx[2] << 16 | q_nx[3] << 24;
         x_cur = x_nx[0] | x_nx[1] << 8 | x_nx[2] << 16 | x_nx[3] << 24;
-        if (HAVE_LABELS) lab_cur = lab_nx[0] | lab_nx[1] << 8 | lab_nx[2] << 16 | lab_nx[3] << 24;
+        if (HAVE_LABELS && cluster_wave) lab_cur = lab_nx[0] | lab_nx[1] << 8 | lab_nx[2] << 16 | lab_nx[3] << 24;
+        if (lists) {                                             // read numbers: current <- next <- the list entries requested a block ago
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { r_cur[j] = r_nx[j]; r_nx[j] = r_nn[j]; }
+            fetch_list(ro + 512);
+        }
         fetch(ro + 256);
     };
+    if (lists) {
+        fetch_list(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r_nx[j] = r_nn[j];
+        fetch_list(256);
+    }
     fetch(0);
     park(0);
     lookup(0, 0);
@@ -733,6 +847,10 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         Record outr = make_double2(0.0, 0.0);
         const uint32_t tb = tb_nx, x = x_lk, card = card_nx;
         const bool ok = ok_nx;
+        if (lists && wave == 0 && (chunk & 3) == 0) {            // where in the segment the reads of this block of four chunks lie
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rowbuf[((chunk >> 2) & 1) * 256 + j * 64 + lane] = r_cur[j] - (uint32_t)seg_lo;
+        }
         if (rb + 64 < nr) lookup(rb + 64, chunk + 1);
         RK_T(0);
         if (active) {
@@ -835,12 +953,13 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
             const uint32_t rd = threadIdx.x >> log2w, cw = threadIdx.x & (W - 1);
             const uint32_t col = cg * W + cw;                    // rec_index with the stream's part hoisted out of the loop
+            const uint32_t row = lists ? rowbuf[((chunk >> 2) & 1) * 256 + (chunk & 3) * 64 + rd] : rb + rd;
             // The input bytes of chunks c+2 .. c+5 are taken over here (and the following four requested): the wait for
             // them also waits for every store issued so far, and at this point the latest one is a whole chunk old.
             if (((chunk + 2) & 3) == 0) park(rb + 128);
             if (rb + rd < nr && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
                 RK_EXP(1)
-                rec_g[((uint64_t)(rb + rd) * (Cp >> 3) + (col >> 3)) * 512 + (col & 7)] = buf[rd * rb_stride + cw];
+                rec_g[((uint64_t)row * (Cp >> 3) + (col >> 3)) * 512 + (col & 7)] = buf[rd * rb_stride + cw];
         }
         RK_T(5);
     }
@@ -1236,7 +1355,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
     if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t Cx = columns + (clusters > 1 ? 1u : 0u);
+    const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);   // record positions per read (k_model_ranks)
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
     if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
         return qvz_set_error(QVZ_E_NOMEM, "model build failed");
@@ -1259,14 +1378,18 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(Record);  // record bytes for one read of every stream
     uint64_t seg_reads = 0, seg_lo = 0;
 
-    // Column slices for k_model_ranks: the tables of record position sx (all clusters) packed back to back, with
-    // coff[sx][cluster][quantizer] = word offset inside the slice. W = columns per workgroup, as many as LDS holds.
-    std::vector<uint32_t> h_slices, h_colbase(Cx + 1, 0);
-    std::vector<uint16_t> h_coff((size_t)Cx * clusters * 2 * A, (uint16_t)RK_NONE);
+    // Slices for k_model_ranks: the tables of one (column, cluster) packed back to back, coff[slice][quantizer] = word
+    // offset inside the slice. Slice numbering: one cluster: slice = column; several: 0 = the cluster-id table,
+    // 1 + column * clusters + cluster. W = columns per workgroup.
+    const uint32_t nslices = clusters > 1 ? 1 + columns * clusters : columns;
+    std::vector<uint32_t> h_slices, h_colbase(nslices + 1, 0);
+    std::vector<uint16_t> h_coff((size_t)nslices * 2 * A, (uint16_t)RK_NONE);
     uint32_t slice_cap = 0, rk_waves = 0;
     size_t rk_lds = 0;
     uint32_t *d_slices = nullptr, *d_colbase = nullptr, *d_save = nullptr;
     uint16_t *d_coff = nullptr;
+    uint32_t *d_clist = nullptr, *d_segpos = nullptr, *d_bounds = nullptr;   // several clusters: read lists per (stream, cluster)
+    uint64_t *d_cstart = nullptr;
     bool overlap = false;
     hipStream_t s_model = nullptr, s_coder = nullptr;
     hipEvent_t ev_start = nullptr;
@@ -1275,27 +1398,26 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     std::vector<std::pair<uint64_t, uint64_t>> segs;            // (first read, reads) of every segment, relative to a stream's start
     {
         bool fits = true;
-        for (uint32_t sx = 0; sx < Cx; ++sx) {
-            h_colbase[sx] = (uint32_t)h_slices.size();
-            if (clusters > 1 && sx == 0) {                       // cluster_stats: n = card = k, counts 1
+        for (uint32_t sl = 0; sl < nslices; ++sl) {
+            h_colbase[sl] = (uint32_t)h_slices.size();
+            if (clusters > 1 && sl == 0) {                       // cluster_stats: n = card = k, counts 1
                 h_slices.push_back(clusters); h_slices.push_back(clusters);
                 for (uint32_t c = 0; c < clusters; ++c) h_slices.push_back(1);
             } else {
-                const uint32_t s = clusters > 1 ? sx - 1 : sx;
-                for (uint32_t c = 0; c < clusters; ++c)
-                    for (uint32_t j = 0; j < 2 * A; ++j) {
-                        const uint32_t o = h_off[((size_t)c * columns + s) * 2 * A + j];
-                        if (o == NO_TABLE) continue;
-                        const size_t rel = h_slices.size() - h_colbase[sx];
-                        if (rel >= RK_NONE) { fits = false; continue; }
-                        h_coff[((size_t)sx * clusters + c) * 2 * A + j] = (uint16_t)rel;
-                        for (uint32_t i = 0; i < 2 + h_arena[o + 1]; ++i) h_slices.push_back(h_arena[o + i]);
-                    }
+                const uint32_t s = clusters > 1 ? (sl - 1) / clusters : sl, c = clusters > 1 ? (sl - 1) % clusters : 0;
+                for (uint32_t j = 0; j < 2 * A; ++j) {
+                    const uint32_t o = h_off[((size_t)c * columns + s) * 2 * A + j];
+                    if (o == NO_TABLE) continue;
+                    const size_t rel = h_slices.size() - h_colbase[sl];
+                    if (rel >= RK_NONE) { fits = false; continue; }
+                    h_coff[(size_t)sl * 2 * A + j] = (uint16_t)rel;
+                    for (uint32_t i = 0; i < 2 + h_arena[o + 1]; ++i) h_slices.push_back(h_arena[o + i]);
+                }
             }
-            const uint32_t len = (uint32_t)h_slices.size() - h_colbase[sx];
+            const uint32_t len = (uint32_t)h_slices.size() - h_colbase[sl];
             if (len > slice_cap) slice_cap = len;
         }
-        h_colbase[Cx] = (uint32_t)h_slices.size();
+        h_colbase[nslices] = (uint32_t)h_slices.size();
         slice_cap = (slice_cap + 3) & ~3u;
         const char *mk = getenv("QVZ_MODEL_KERNEL");             // development knob: "columns" forces the lane-per-column kernel
         if (fits && !(mk && strcmp(mk, "columns") == 0)) {
@@ -1303,7 +1425,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
             // beside k_code_records' 32 KB of LDS (measured with three clusters, where LDS holds one such workgroup
             // per CU: W = 4 0.40 s, W = 2 0.42 s, W = 1 0.67 s for the model kernels; W = 8 never paid).
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
-            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + clusters * 2 * A) * 4; };
+            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (clusters > 1 ? 2048 : 0) + (size_t)w * (3 * slice_cap + 2 * A) * 4; };   // records, list rows, per wave masks + tables + offsets
             const size_t budget = 160 * 1024 - 32 * 1024;
             const uint32_t order[3] = {4, 2, 1};
             for (uint32_t w : order) {
@@ -1397,6 +1519,22 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         for (uint64_t lo = 0; lo < longest; lo += seg_reads) segs.push_back({lo, lo + seg_reads <= longest ? seg_reads : longest - lo});
     }
     nseg = (uint32_t)segs.size();
+    if (rk_waves && clusters > 1) {                              // read lists per (stream, cluster) and where the segments cut them
+        std::vector<uint32_t> h_bounds(nseg + 1);
+        for (uint32_t i = 0; i < nseg; ++i) h_bounds[i] = (uint32_t)segs[i].first;
+        h_bounds[nseg] = 0xFFFFFFFFu;
+        const size_t SK = (size_t)shards * clusters;
+        TRY(hipMalloc(&d_clist, (size_t)n * sizeof(uint32_t)));
+        TRY(hipMalloc(&d_cstart, SK * sizeof(uint64_t)));
+        TRY(hipMalloc(&d_segpos, SK * (nseg + 1) * sizeof(uint32_t)));
+        TRY(hipMalloc(&d_bounds, (nseg + 1) * sizeof(uint32_t)));
+        TRY(hipMemcpyAsync(d_bounds, h_bounds.data(), (nseg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_cluster_lists, dim3(shards), dim3(256), 0, st, d_labels, (const uint64_t *)d_first, clusters, d_clist, d_cstart, d_status);
+        hipLaunchKernelGGL(k_cluster_segpos, dim3((unsigned)((SK * (nseg + 1) + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_clist,
+                           (const uint64_t *)d_cstart, (const uint64_t *)d_first, shards, clusters, (const uint32_t *)d_bounds, nseg + 1, d_segpos);
+        TRY(hipGetLastError());
+        TRY(hipStreamSynchronize(st));                           // h_bounds goes out of scope; the lists are ready for both streams
+    }
     evs.assign((size_t)nseg * 4, nullptr);
     for (size_t i = 0; i < evs.size(); ++i) TRY(hipEventCreate(&evs[i]));
     g_planes_ms[0] = g_planes_ms[1] = 0.0;
@@ -1412,22 +1550,26 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     for (uint32_t i = 0; i < nseg; ++i) {
         seg_lo = segs[i].first;
         const uint32_t seg_len = (uint32_t)segs[i].second;       // both kernels lay the segment's records out for this many reads
-        const uint32_t mblocks = (uint32_t)(((uint64_t)shards * Cx + 255) / 256);
+        const uint32_t mblocks = (uint32_t)(((uint64_t)shards * (columns + (clusters > 1 ? 1u : 0u)) + 255) / 256);
         const int is_first = i == 0, is_last = i + 1 == nseg;
         Record *buf = (Record *)((char *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * per_read : 0));
         hipEvent_t *e = &evs[(size_t)i * 4];
         if (overlap && i >= 2) TRY(hipStreamWaitEvent(s_model, evs[(size_t)(i - 2) * 4 + 3], 0));   // the coder has drained this buffer
         TRY(hipEventRecord(e[0], s_model));
         if (rk_waves) {
-            const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves), block(64 * rk_waves);
+            const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves, clusters), block(64 * rk_waves);   // z: the cluster a workgroup of column positions serves
+            const size_t SK = (size_t)shards * clusters;
             if (clusters > 1)
                 hipLaunchKernelGGL(k_model_ranks<true>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
+                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status,
+                                   (const uint32_t *)d_clist, (const uint64_t *)d_cstart, (const uint32_t *)(d_segpos + (size_t)i * SK),
+                                   (const uint32_t *)(d_segpos + (size_t)(i + 1) * SK));
             else
                 hipLaunchKernelGGL(k_model_ranks<false>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status);
+                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status,
+                                   (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
         } else if (clusters > 1)
             hipLaunchKernelGGL(k_model_columns<true>, dim3(mblocks), dim3(256), 0, s_model, d_qi, d_st, ld, d_labels, columns, clusters,
                                d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status);
@@ -1476,6 +1618,7 @@ done:
     if (s_model && s_model != st) { (void)hipStreamSynchronize(s_model); (void)hipStreamDestroy(s_model); }
     if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); (void)hipStreamDestroy(s_coder); }
     (void)hipFree(d_cs); (void)hipFree(own_work); (void)hipFree(d_slices); (void)hipFree(d_colbase); (void)hipFree(d_coff); (void)hipFree(d_save);
+    (void)hipFree(d_clist); (void)hipFree(d_cstart); (void)hipFree(d_segpos); (void)hipFree(d_bounds);
     free(h_arena); free(h_off); free(h_first);
     return rc;
 }

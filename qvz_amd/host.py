@@ -125,8 +125,9 @@ def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_pe
 
 def planes_bytes_per_read(shards, columns, k):
     """Record-workspace bytes that one read of every stream takes in qvz_hip_encode_planes: 16 bytes per record, streams
-    padded to a multiple of 64, records per read (columns + a cluster id when k > 1) padded to a multiple of 8."""
-    return 16 * ((shards + 63) // 64 * 64) * ((columns + (1 if k > 1 else 0) + 7) // 8 * 8)
+    padded to a multiple of 64, records per read (columns, behind 8 reserved positions - the cluster id and seven zero
+    records - when k > 1) padded to a multiple of 8."""
+    return 16 * ((shards + 63) // 64 * 64) * ((columns + (8 if k > 1 else 0) + 7) // 8 * 8)
 
 
 def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True,
