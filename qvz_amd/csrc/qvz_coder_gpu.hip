@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void k_cluster_segpos(const uint32_t *__restri
 template <bool HAVE_LABELS>
 __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                       const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
-                                                      const uint64_t *__restrict__ first, const uint16_t *__restrict__ coff,
+                                                      const uint64_t *__restrict__ first, const uint32_t *__restrict__ coff,
                                                       const uint32_t *__restrict__ colbase, const uint32_t *__restrict__ tmpl,
                                                       uint32_t *__restrict__ save, uint32_t total_words, uint32_t slice_cap,
                                                       uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
@@ -755,17 +755,20 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     if (active) {
         b0 = colbase[slice];
         sw = colbase[slice + 1] - b0;
-        const uint32_t *src = is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0;
+        // a workgroup lives for some twenty chunks, so what it does before the first one counts: the slice comes in as
+        // 16-byte loads issued back to back, the offset table is ready-made on the host (no dependent second load)
+        const uint4 *src = reinterpret_cast<const uint4 *>(is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0);
         if (nr == 0) {                                           // no read of this cluster here: the state passes through
             if (is_first && !is_last)
-                for (uint32_t i = lane; i < sw; i += 64) save[(uint64_t)g * total_words + b0 + i] = src[i];
+                for (uint32_t i = lane; i < sw / 4; i += 64) reinterpret_cast<uint4 *>(save + (uint64_t)g * total_words + b0)[i] = src[i];
         } else {
-            for (uint32_t i = lane; i < sw; i += 64) { tab[i] = src[i]; msk[i] = 0ull; }
+            for (uint32_t i = lane; i < sw / 4; i += 64) {
+                reinterpret_cast<uint4 *>(tab)[i] = src[i];
+                reinterpret_cast<uint4 *>(msk)[2 * i] = make_uint4(0u, 0u, 0u, 0u);
+                reinterpret_cast<uint4 *>(msk)[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
+            }
             if (!cluster_wave)
-                for (uint32_t i = lane; i < 2 * A; i += 64) {
-                    const uint32_t o = coff[(uint64_t)slice * 2 * A + i];
-                    cof[i] = o == RK_NONE ? (uint32_t)RK_NONE : (o | src[o + 1] << 16);
-                }
+                for (uint32_t i = lane; i < 2 * A; i += 64) cof[i] = coff[(uint64_t)slice * 2 * A + i];
         }
     }
     if (nr == 0) return;                                         // whole workgroup (lists only)
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
 #endif
     if (active && !is_last)
-        for (uint32_t i = lane; i < sw; i += 64) save[(uint64_t)g * total_words + b0 + i] = tab[i];
+        for (uint32_t i = lane; i < sw / 4; i += 64) reinterpret_cast<uint4 *>(save + (uint64_t)g * total_words + b0)[i] = reinterpret_cast<const uint4 *>(tab)[i];
     if (bad) atomicOr(status, 1);
 }
 
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read (rec_index)
-    if (wave == 0) asm volatile("s_setprio 3");                  // the latency chain issues ahead of the throughput kernels sharing the CU
+    asm volatile("s_setprio 3");                                 // all four waves of the latency chain issue ahead of the throughput kernels sharing the CU
     uint64_t T = 0;
     if (live) {
         const uint64_t rend = first[g + 1], a = first[g] + seg_lo, b = a + seg_reads;
@@ -1383,11 +1386,11 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     // 1 + column * clusters + cluster. W = columns per workgroup.
     const uint32_t nslices = clusters > 1 ? 1 + columns * clusters : columns;
     std::vector<uint32_t> h_slices, h_colbase(nslices + 1, 0);
-    std::vector<uint16_t> h_coff((size_t)nslices * 2 * A, (uint16_t)RK_NONE);
+    std::vector<uint32_t> h_coff((size_t)nslices * 2 * A, (uint32_t)RK_NONE);   // offset | alphabet size << 16; RK_NONE (size 0): no table
     uint32_t slice_cap = 0, rk_waves = 0;
     size_t rk_lds = 0;
     uint32_t *d_slices = nullptr, *d_colbase = nullptr, *d_save = nullptr;
-    uint16_t *d_coff = nullptr;
+    uint32_t *d_coff = nullptr;
     uint32_t *d_clist = nullptr, *d_segpos = nullptr, *d_bounds = nullptr;   // several clusters: read lists per (stream, cluster)
     uint64_t *d_cstart = nullptr;
     bool overlap = false;
@@ -1395,6 +1398,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> evs;                                // per segment: model start, model end, coder start, coder end
     uint32_t nseg = 0;
+    size_t cr_pad = 0;
     std::vector<std::pair<uint64_t, uint64_t>> segs;            // (first read, reads) of every segment, relative to a stream's start
     {
         bool fits = true;
@@ -1410,10 +1414,11 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
                     if (o == NO_TABLE) continue;
                     const size_t rel = h_slices.size() - h_colbase[sl];
                     if (rel >= RK_NONE) { fits = false; continue; }
-                    h_coff[(size_t)sl * 2 * A + j] = (uint16_t)rel;
+                    h_coff[(size_t)sl * 2 * A + j] = (uint32_t)rel | h_arena[o + 1] << 16;
                     for (uint32_t i = 0; i < 2 + h_arena[o + 1]; ++i) h_slices.push_back(h_arena[o + i]);
                 }
             }
+            while (h_slices.size() & 3) h_slices.push_back(0);   // slices start on 16 bytes: they are copied as uint4
             const uint32_t len = (uint32_t)h_slices.size() - h_colbase[sl];
             if (len > slice_cap) slice_cap = len;
         }
@@ -1489,11 +1494,11 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     if (rk_waves) {
         TRY(hipMalloc(&d_slices, h_slices.size() * 4));
         TRY(hipMalloc(&d_colbase, h_colbase.size() * 4));
-        TRY(hipMalloc(&d_coff, h_coff.size() * 2));
+        TRY(hipMalloc(&d_coff, h_coff.size() * 4));
         if (seg_reads < longest) TRY(hipMalloc(&d_save, h_slices.size() * 4 * (size_t)shards));   // table state between segments
         TRY(hipMemcpyAsync(d_slices, h_slices.data(), h_slices.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_colbase, h_colbase.data(), h_colbase.size() * 4, hipMemcpyHostToDevice, st));
-        TRY(hipMemcpyAsync(d_coff, h_coff.data(), h_coff.size() * 2, hipMemcpyHostToDevice, st));
+        TRY(hipMemcpyAsync(d_coff, h_coff.data(), h_coff.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     } else {                                                     // lane-per-column kernel with per-stream arenas in HBM
@@ -1547,6 +1552,19 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipStreamWaitEvent(s_model, ev_start, 0));
         TRY(hipStreamWaitEvent(s_coder, ev_start, 0));
     }
+    // The coder kernel is the longer of the two once they overlap, and what slows it is the model waves it shares its CUs
+    // with (0.11 s alone, 0.16-0.17 s beside three model workgroups per CU, 0.15 s beside two). So when three or more
+    // model workgroups would fit beside a coder workgroup, the coder asks for just enough LDS it never touches to keep
+    // the last of them away (measured: -8 ms per step at 100M x 150; more padding than that delays the coder's own
+    // dispatch and costs 30 ms).
+    if (overlap && rk_waves) {
+        hipFuncAttributes fa;
+        TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_code_records)));
+        const size_t lds_cu = 160 * 1024, beside = (lds_cu - fa.sharedSizeBytes) / rk_lds;
+        if (beside >= 3) cr_pad = ((lds_cu - fa.sharedSizeBytes - beside * rk_lds) + 1024) & ~(size_t)255;
+    }
+    if (getenv("QVZ_CODER_LDS_PAD")) cr_pad = (size_t)atoi(getenv("QVZ_CODER_LDS_PAD"));   // development knob
+    if (cr_pad) TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_code_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
     for (uint32_t i = 0; i < nseg; ++i) {
         seg_lo = segs[i].first;
         const uint32_t seg_len = (uint32_t)segs[i].second;       // both kernels lay the segment's records out for this many reads
@@ -1579,7 +1597,7 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipEventRecord(e[1], s_model));
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
-        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(256), 0, s_coder, (const Record *)buf, Cx, d_first, shards,
+        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, (const Record *)buf, Cx, d_first, shards,
                            seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
         TRY(hipEventRecord(e[3], s_coder));
     }
