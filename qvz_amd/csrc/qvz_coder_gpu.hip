@@ -1459,15 +1459,16 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
     }
     // Segments. With room for two record buffers the model kernel of segment i+1 runs beside the coder kernel of
     // segment i on a second HIP stream (the coder keeps three waves on half of the CUs busy with a latency chain; the
-    // model kernel is throughput work that fills the rest); segments are then cut to about an eighth of a stream so
-    // that the un-overlapped head and tail stay small.
+    // model kernel is throughput work that fills the rest); segments are then at most a quarter of a stream (every segment
+    // costs the model kernel a table load and save per workgroup: 104 ms + 5 ms per segment at 100M x 150), the first
+    // and the last a quarter of that.
     seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
     if (seg_reads > longest) seg_reads = longest;
     {
         const char *ov = getenv("QVZ_CODER_OVERLAP");            // development knob: "0" keeps everything on the caller's stream
         const uint64_t half = (work_bytes / 2 / per_read) & ~(uint64_t)63;
         if (!(ov && atoi(ov) == 0) && longest >= 1024 && half >= 64) {
-            uint64_t target = ((longest + 7) / 8 + 63) & ~(uint64_t)63;
+            uint64_t target = ((longest + 3) / 4 + 63) & ~(uint64_t)63;
             seg_reads = half < target ? half : target;
             overlap = true;
         }

@@ -134,7 +134,7 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
                       work_bytes=None):
     """GPU sharded coder fed from the quantizer's planes (qvz_hip_encode_planes): the model runs with a lane per
     (stream, column), the interval arithmetic with a lane per stream. qi/st: (columns, ld) uint8 device tensors.
-    work_bytes: size of the record workspace (default: everything at once, capped at 48 GiB).
+    work_bytes: size of the record workspace (default: everything at once, capped at 96 GiB).
     Returns (sizes, streams|None, out_tensor)."""
     import torch
     k = len(codebook_handles)
@@ -147,10 +147,10 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     per_read = planes_bytes_per_read(shards, columns, k)
     longest = ((n + shards - 1) // shards + 7) & ~3
     if work_bytes is None:
-        # default: everything at once, capped (QVZ_WORK_GIB, 48 GiB unless set); fewer, longer segments mean fewer
-        # save/restore round trips of the model tables between segments
+        # default: everything at once, capped (QVZ_WORK_GIB, 96 GiB of the 288 unless set); fewer, longer segments mean
+        # fewer save/restore round trips of the model tables between segments
         import os
-        work_bytes = min(per_read * longest, int(os.environ.get("QVZ_WORK_GIB", "48")) << 30)
+        work_bytes = min(per_read * longest, int(os.environ.get("QVZ_WORK_GIB", "96")) << 30)
     work_bytes = max(work_bytes, per_read * 4)
     work = torch.empty(work_bytes, dtype=torch.uint8, device=qi.device)
     out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=qi.device)
