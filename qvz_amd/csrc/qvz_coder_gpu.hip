@@ -488,13 +488,17 @@ __device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint3
 }
 
 // Record area of one segment. A read has Cp = Cx rounded up to 8 records (the pad records are zero = no-ops), streams
-// go in groups of 64 (one coder workgroup), and inside a group the lanes' blocks of 8 records lie side by side:
-// record t of stream g is at ((g / 64 * nblk8 + t / 8) * 64 + g % 64) * 8 + t % 8 with nblk8 = seg_reads * Cp / 8.
-// So the coder reads one contiguous 8 KiB per block of 8 symbols (sequential for HBM) instead of 64 runs of 128
-// bytes 2-30 MB apart, while the model kernel still writes W * 16-byte runs.
+// go in groups of 64 (one coder workgroup). A stream's records are cut into units of 2 reads x 4 columns (8 records,
+// 128 bytes: [read parity][column & 3]) and the 64 streams' units of the same (read pair, column group) lie side by
+// side: record (row, col) of stream g is at
+//   (((g / 64) * nblk8 + (row / 2) * (Cp / 4) + col / 4) * 64 + g % 64) * 8 + (row % 2) * 4 + col % 4,  nblk8 = seg_reads * Cp / 8.
+// A model workgroup (4 adjacent columns, 64 consecutive reads) therefore writes whole 128-byte lines - two reads' four
+// records - and the coder's loader still finds a lane's 8 symbols of a block in two 64-byte halves of two units whose
+// other halves it reads a read later (out of L2). (With 8 columns of one read per unit the model kernel wrote half
+// lines, and those writes slowed the coder's reads beside them.)
 #define QVZ_CID_SLOTS 8   // several clusters: record positions 0 (cluster id) .. 7 (zero records) precede the columns (k_model_ranks)
-__device__ __forceinline__ uint64_t rec_index(uint32_t g, uint64_t t, uint64_t nblk8) {
-    return (((uint64_t)(g >> 6) * nblk8 + (t >> 3)) * 64 + (g & 63)) * 8 + (t & 7);
+__device__ __forceinline__ uint64_t rec_index(uint32_t g, uint64_t row, uint32_t col, uint32_t Cp, uint64_t nblk8) {
+    return (((uint64_t)(g >> 6) * nblk8 + (row >> 1) * (Cp >> 2) + (col >> 2)) * 64 + (g & 63)) * 8 + (row & 1) * 4 + (col & 3);
 }
 
 template <bool HAVE_LABELS>
@@ -579,11 +583,11 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                     w = make_record(n, cum_lo, fx);
                 }
             }
-            rec[rec_index(g, (r + j - r0) * Cp + pos, nblk8)] = w;
+            rec[rec_index(g, r + j - r0, pos, Cp, nblk8)] = w;
             if (cluster_lane)                                    // the reserved positions behind the cluster id
-                for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec[rec_index(g, (r + j - r0) * Cp + pc, nblk8)] = make_double2(0.0, 0.0);
+                for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec[rec_index(g, r + j - r0, pc, Cp, nblk8)] = make_double2(0.0, 0.0);
             if (sx + 1 == Cw)                                    // the read's pad records
-                for (uint32_t pc = Cx; pc < Cp; ++pc) rec[rec_index(g, (r + j - r0) * Cp + pc, nblk8)] = make_double2(0.0, 0.0);
+                for (uint32_t pc = Cx; pc < Cp; ++pc) rec[rec_index(g, r + j - r0, pc, Cp, nblk8)] = make_double2(0.0, 0.0);
         }
     }
     if (bad) atomicOr(status, 1);
@@ -962,7 +966,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             if (((chunk + 2) & 3) == 0) park(rb + 128);
             if (rb + rd < nr && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
                 RK_EXP(1)
-                rec_g[((uint64_t)row * (Cp >> 3) + (col >> 3)) * 512 + (col & 7)] = buf[rd * rb_stride + cw];
+                rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * 512 + (row & 1) * 4 + (col & 3)] = buf[rd * rb_stride + cw];
         }
         RK_T(5);
     }
@@ -1036,16 +1040,27 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     if (wave == 3) {
         // ------------------------------------ loader ------------------------------------
         const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // blocks of 8 records in a stream's area
-        const Record *p = rec + ((uint64_t)blockIdx.x * nblk8 * 64 + lane) * 8;   // + blk * 512 + i (rec_index)
+        const Record *p = rec + ((uint64_t)blockIdx.x * nblk8 * 64 + lane) * 8;   // the lane's slot of unit 0 (rec_index)
         const uint64_t nfull = Tmin / CR_B;                      // blocks that are whole in every lane: no padding test
         // A register stage holds LD_B ring blocks (a 256-byte run of the lane's records); three stages in rotation
         // keep two of them (512 bytes per lane) in flight. No copies between stages: a copy would wait for its load.
         constexpr int LD_B = 2;
+        // block b of a lane = columns 8m .. 8m+7 of read `row` (b = row * Cp/8 + m): the halves [row & 1] of the units
+        // (row / 2, 2m) and (row / 2, 2m + 1). Stages are requested in order, so (row, m) are counted along; past the last
+        // block the last one is loaded again (unconditional loads keep vmcnt countable).
+        uint64_t l_blk = 0;
+        uint32_t l_row = 0, l_m = 0;
         auto load_stage = [&](uint64_t stg, Record *d) {
+            (void)stg;
 #pragma unroll
-            for (int i = 0; i < LD_B * CR_B; ++i) {
-                const uint64_t blk = stg * LD_B + i / CR_B;      // unconditional (clamped) so that vmcnt stays countable
-                d[i] = p[(blk < nblk8 ? blk : nblk8 - 1) * 512 + (i % CR_B)];
+            for (int k = 0; k < LD_B; ++k) {
+                const uint64_t base = ((uint64_t)(l_row >> 1) * (Cp >> 2) + 2 * l_m) * 512 + (l_row & 1) * 4;
+#pragma unroll
+                for (int i = 0; i < CR_B; ++i) d[k * CR_B + i] = p[base + (i >> 2) * 512 + (i & 3)];
+                if (l_blk + 1 < nblk8) {
+                    ++l_blk;
+                    if (++l_m == (Cp >> 3)) { l_m = 0; ++l_row; }
+                }
             }
         };
         auto park = [&](uint64_t b, const Record *d) {           // block b -> slot b & 1, then barrier b
