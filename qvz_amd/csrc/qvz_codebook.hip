@@ -325,8 +325,13 @@ struct LmLds {
 // One Lloyd-Max design (quantizer.c:34-132) for S states into slot `b`. All 64 lanes call it together.
 // `stop` (may be null) holds the smallest S of this context known to reach the target: a design with a larger S
 // is not needed by the walk and gives up (returns false).
+// TOEP: the distortion is a function of |i - r| only (all of the reference's -d choices): `dl` then holds those 72
+// values instead of the 72 x 72 matrix - 0.6 KB of LDS per design instead of 41 KB, i.e. twenty designs per CU instead
+// of three, and no 41 KB copy at the start of every design.
+template <bool TOEP>
 __device__ bool lm_design(const double *__restrict__ p, const double *__restrict__ dl, uint32_t S, LmLds *L,
                           double *__restrict__ o, int b, const uint32_t *stop) {
+    auto D = [&](uint32_t i, uint32_t r) -> double { return TOEP ? dl[i > r ? i - r : r - i] : dl[i * A + r]; };
     const uint32_t lane = threadIdx.x;
     uint8_t *bounds = L->bounds, *recon = L->recon[b], *q = L->q[b];
     if (lane == 0) { bounds[0] = 0; bounds[S] = A; }                                  // :45-46
@@ -352,7 +357,7 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 for (uint32_t t = 1; t < S; ++t) j += bounds[t] <= rr ? 1u : 0u;
                 const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
                 double m = 0.0;
-                for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + rr];
+                for (uint32_t i = b0; i < b1; ++i) m += p[i] * D(i, rr);
                 L->mv[rr] = m;
             }
             __syncthreads();
@@ -376,12 +381,12 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 uint32_t best_r = b0;
                 if (r1 < b1) {
                     double m = 0.0;
-                    for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r1];
+                    for (uint32_t i = b0; i < b1; ++i) m += p[i] * D(i, r1);
                     if (m < best_v) { best_v = m; best_r = r1; }
                 }
                 if (r2 < b1) {
                     double m = 0.0;
-                    for (uint32_t i = b0; i < b1; ++i) m += p[i] * dl[i * A + r2];
+                    for (uint32_t i = b0; i < b1; ++i) m += p[i] * D(i, r2);
                     if (m < best_v) { best_v = m; best_r = r2; }
                 }
                 // first minimum wins (strict '<' scan in r order) == lexicographic min of (value, r)
@@ -405,8 +410,8 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
             for (uint32_t t = 0; t + 1 < S; ++t) {
                 const uint32_t ra = recon[t], rb = recon[t + 1];
                 const uint32_t j1 = lane, j2 = lane + 64;
-                const int f1 = (j1 >= 1) && (dl[j1 * A + rb] < dl[j1 * A + ra]);
-                const int f2 = (j2 <= A - 2) && (dl[j2 * A + rb] < dl[j2 * A + ra]);
+                const int f1 = (j1 >= 1) && (D(j1, rb) < D(j1, ra));
+                const int f2 = (j2 <= A - 2) && (D(j2 <= A - 1 ? j2 : A - 1, rb) < D(j2 <= A - 1 ? j2 : A - 1, ra));
                 const unsigned long long m1 = __ballot(f1), m2 = __ballot(f2);
                 const unsigned long long a1 = jprev < 63 ? (m1 & (~0ull << (jprev + 1))) : 0ull;
                 uint32_t jn;
@@ -457,12 +462,13 @@ __device__ double lm_entropy_dev(const double *o) {   // steering value only (de
 
 // grid (contexts, window); block (ctx, w) designs S = startS + w. distT[i*72 + r] = d(i, r) (lanes walk r: no LDS
 // bank conflicts). blockIdx.x runs fastest, so the small S of every context are dispatched first.
+template <bool TOEP>
 __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm, const double *__restrict__ distT,
                                                   const LmIn *__restrict__ in, LmDesign *__restrict__ out,
                                                   uint32_t *__restrict__ stop, double guard) {
     extern __shared__ double sm[];
     double *dl = sm;
-    double *p = sm + A * A;
+    double *p = sm + (TOEP ? A : A * A);
     double *o = p + A;
     LmLds *L = reinterpret_cast<LmLds *>(o + A);
     const uint32_t ctx = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
@@ -474,10 +480,10 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
         if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
         return;
     }
-    for (uint32_t e = lane; e < A * A; e += 64) dl[e] = distT[e];
+    for (uint32_t e = lane; e < (TOEP ? A : A * A); e += 64) dl[e] = distT[e];   // TOEP: row 0 = d(0, r) = f(r)
     for (uint32_t e = lane; e < A; e += 64) p[e] = pm[(uint64_t)ctx * A + e];
     __syncthreads();
-    if (!lm_design(p, dl, S, L, o, 0, I.mode == 1 ? stop + ctx : nullptr)) {
+    if (!lm_design<TOEP>(p, dl, S, L, o, 0, I.mode == 1 ? stop + ctx : nullptr)) {
         if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
         return;
     }
@@ -560,7 +566,7 @@ static void cbw_give_back(CbWork *w) {
 static thread_local uint64_t g_deferred = 0;   // per calling thread: clusters may be generated by concurrent host threads
 extern "C" uint64_t qvz_hip_codebook_deferred_decisions(void) { return g_deferred; }
 
-#define LM_LDS_BYTES ((A * A + A + A) * sizeof(double) + sizeof(LmLds))
+#define LM_LDS_BYTES(toep) (((toep ? A : A * A) + A + A) * sizeof(double) + sizeof(LmLds))
 
 static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint8_t *q, const uint8_t *recon, uint32_t S) {
     const size_t t = ((size_t)s * 2 * A + qi) * A;
@@ -597,6 +603,10 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
         W.capC = C;
         W.device = dev;
     }
+    bool toep = true;                              // d(i, r) a function of |i - r|: the Lloyd-Max kernel keeps 72 values
+    for (int i = 0; i < A && toep; ++i)
+        for (int r = 0; r < A; ++r)
+            if (memcmp(&h_dist[i + A * r], &h_dist[(i > r ? i - r : r - i)], sizeof(double)) != 0) { toep = false; break; }
     {
         double hT[A * A];                          // d(i, r) = dist[i + 72 r] laid out with r fastest
         for (int i = 0; i < A; ++i)
@@ -628,7 +638,8 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     memset(hin, 0, A * sizeof(LmIn));
     for (int S = 1; S <= A; ++S) { hin[S - 1].mode = 2; hin[S - 1].startS = (uint8_t)S; }
     QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, A * sizeof(LmIn), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_lm_window, dim3(A, 1), dim3(64), LM_LDS_BYTES, st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
+    if (toep) hipLaunchKernelGGL(k_lm_window<true>, dim3(A, 1), dim3(64), LM_LDS_BYTES(true), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
+    else hipLaunchKernelGGL(k_lm_window<false>, dim3(A, 1), dim3(64), LM_LDS_BYTES(false), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
     QVZ_HIP_CHECK(hipGetLastError());
     QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, A * sizeof(LmDesign), hipMemcpyDeviceToHost, st));
     QVZ_HIP_CHECK(hipStreamSynchronize(st));
@@ -688,7 +699,8 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(LmIn) * nu, hipMemcpyHostToDevice, st));
             if (s == 0 || round) QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));   // (k_ctx_propagate resets it otherwise)
             ++round;
-            hipLaunchKernelGGL(k_lm_window, dim3(nu, win), dim3(64), LM_LDS_BYTES, st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            if (toep) hipLaunchKernelGGL(k_lm_window<true>, dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            else hipLaunchKernelGGL(k_lm_window<false>, dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
             QVZ_HIP_CHECK(hipGetLastError());
             QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win, hipMemcpyDeviceToHost, st));
             QVZ_HIP_CHECK(hipStreamSynchronize(st));
