@@ -328,7 +328,7 @@ struct LmLds {
 // TOEP: the distortion is a function of |i - r| only (all of the reference's -d choices): `dl` then holds those 72
 // values instead of the 72 x 72 matrix - 0.6 KB of LDS per design instead of 41 KB, i.e. twenty designs per CU instead
 // of three, and no 41 KB copy at the start of every design.
-template <bool TOEP>
+template <bool TOEP, bool MONO>
 __device__ bool lm_design(const double *__restrict__ p, const double *__restrict__ dl, uint32_t S, LmLds *L,
                           double *__restrict__ o, int b, const uint32_t *stop) {
     auto D = [&](uint32_t i, uint32_t r) -> double { return TOEP ? dl[i > r ? i - r : r - i] : dl[i * A + r]; };
@@ -405,7 +405,21 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
         // Boundary walk (:93-107). flag(t, j) = d(j, recon[t+1]) < d(j, recon[t]) for j = 1..70 as two ballot masks;
         // "advance at the first flagged j after the previous boundary" is a count-trailing-zeros. The walk stops at
         // the first state without such a j; the bounds beyond it keep their old values, as in the reference.
-        {
+        if (MONO) {
+            // d(j, r) = f(|j - r|) with f strictly increasing: d(j, rb) < d(j, ra) <=> |j - rb| < |j - ra|, i.e. j beyond
+            // the midpoint of ra and rb on rb's side. The first flagged j after the previous boundary is then arithmetic,
+            // not a search: no LDS gathers, no ballots.
+            uint32_t jprev = 0;
+            for (uint32_t t = 0; t + 1 < S; ++t) {
+                const uint32_t ra = recon[t], rb = recon[t + 1];
+                uint32_t jn = jprev + 1;
+                if (rb > ra) { const uint32_t c = (ra + rb) / 2 + 1; jn = c > jn ? c : jn; }     // j > (ra + rb) / 2
+                else if (rb == ra || 2 * jn >= ra + rb) break;                                    // j < (ra + rb) / 2
+                if (jn > A - 2) break;
+                if (lane == 0) bounds[t + 1] = (uint8_t)jn;
+                jprev = jn;
+            }
+        } else {
             uint32_t jprev = 0;
             for (uint32_t t = 0; t + 1 < S; ++t) {
                 const uint32_t ra = recon[t], rb = recon[t + 1];
@@ -462,7 +476,7 @@ __device__ double lm_entropy_dev(const double *o) {   // steering value only (de
 
 // grid (contexts, window); block (ctx, w) designs S = startS + w. distT[i*72 + r] = d(i, r) (lanes walk r: no LDS
 // bank conflicts). blockIdx.x runs fastest, so the small S of every context are dispatched first.
-template <bool TOEP>
+template <bool TOEP, bool MONO>
 __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm, const double *__restrict__ distT,
                                                   const LmIn *__restrict__ in, LmDesign *__restrict__ out,
                                                   uint32_t *__restrict__ stop, double guard) {
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     for (uint32_t e = lane; e < (TOEP ? A : A * A); e += 64) dl[e] = distT[e];   // TOEP: row 0 = d(0, r) = f(r)
     for (uint32_t e = lane; e < A; e += 64) p[e] = pm[(uint64_t)ctx * A + e];
     __syncthreads();
-    if (!lm_design<TOEP>(p, dl, S, L, o, 0, I.mode == 1 ? stop + ctx : nullptr)) {
+    if (!lm_design<TOEP, MONO>(p, dl, S, L, o, 0, I.mode == 1 ? stop + ctx : nullptr)) {
         if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
         return;
     }
@@ -607,6 +621,8 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     for (int i = 0; i < A && toep; ++i)
         for (int r = 0; r < A; ++r)
             if (memcmp(&h_dist[i + A * r], &h_dist[(i > r ? i - r : r - i)], sizeof(double)) != 0) { toep = false; break; }
+    bool mono = toep;                              // ... and strictly increasing in |i - r|: the boundary walk is arithmetic
+    for (int d = 1; d < A && mono; ++d) mono = h_dist[d] > h_dist[d - 1];
     {
         double hT[A * A];                          // d(i, r) = dist[i + 72 r] laid out with r fastest
         for (int i = 0; i < A; ++i)
@@ -638,8 +654,9 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     memset(hin, 0, A * sizeof(LmIn));
     for (int S = 1; S <= A; ++S) { hin[S - 1].mode = 2; hin[S - 1].startS = (uint8_t)S; }
     QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, A * sizeof(LmIn), hipMemcpyHostToDevice, st));
-    if (toep) hipLaunchKernelGGL(k_lm_window<true>, dim3(A, 1), dim3(64), LM_LDS_BYTES(true), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
-    else hipLaunchKernelGGL(k_lm_window<false>, dim3(A, 1), dim3(64), LM_LDS_BYTES(false), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
+    if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(A, 1), dim3(64), LM_LDS_BYTES(true), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
+    else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(A, 1), dim3(64), LM_LDS_BYTES(true), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
+    else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(A, 1), dim3(64), LM_LDS_BYTES(false), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
     QVZ_HIP_CHECK(hipGetLastError());
     QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, A * sizeof(LmDesign), hipMemcpyDeviceToHost, st));
     QVZ_HIP_CHECK(hipStreamSynchronize(st));
@@ -699,8 +716,9 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(LmIn) * nu, hipMemcpyHostToDevice, st));
             if (s == 0 || round) QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));   // (k_ctx_propagate resets it otherwise)
             ++round;
-            if (toep) hipLaunchKernelGGL(k_lm_window<true>, dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
-            else hipLaunchKernelGGL(k_lm_window<false>, dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
             QVZ_HIP_CHECK(hipGetLastError());
             QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win, hipMemcpyDeviceToHost, st));
             QVZ_HIP_CHECK(hipStreamSynchronize(st));
