@@ -205,17 +205,33 @@ __global__ __launch_bounds__(128) void k_marginals(const double *__restrict__ P,
     }
 }
 
-// One column of the context recursion. Inputs (device): P, marg, previous column's qpmf, quantizer tables and
-// ratios of column s-1, context symbols of column s. Outputs: qpmf[72][72] (row x, entry idx) and
+// One column of the context recursion, in three launches. Inputs (device): P, marg, previous column's qpmf, quantizer
+// tables and ratios of column s-1, context symbols of column s. Outputs: qpmf[72][72] (row x, entry idx) and
 // xpmf[nu][72] (row idx).
-__global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict__ P, const double *__restrict__ marg,
-                                                        uint32_t s, uint32_t nprev, uint32_t nu,
+// The two 72-term sums (p_temp, and the xpmf rows) gather three operands per term from L1/L2; in one workgroup - one
+// CU - they were bound by that CU's load path (64 us and 30 us of the 96 us per column). They are spread over the
+// chip: a thread per output element as before, the same terms in the same order.
+__global__ __launch_bounds__(256) void k_ctx_ptemp(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
+                                                   uint32_t nprev, const double *__restrict__ prev_qpmf,   // [72][72]
+                                                   double *__restrict__ ptemp) {                           // [72][72]: (k, j)
+    // hoisted p_temp(k,j) = sum_x prev_qpmf[x][j] * P_{s-1}(k|x) * marg_{s-2}[x]   (codebook.c:318-321)
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= A * nprev) return;
+    const double *Pc = P + (uint64_t)(s - 1) * A * A;
+    const double *mm = marg + (uint64_t)(s - 2) * A;
+    const uint32_t k = e / nprev, j = e % nprev;
+    double pt = 0;
+#pragma unroll 8
+    for (int x = 0; x < A; ++x) pt += prev_qpmf[x * A + j] * Pc[x * A + k] * mm[x];   // loads run ahead, the sum stays in order
+    ptemp[k * A + j] = pt;
+}
+
+__global__ __launch_bounds__(1024) void k_ctx_propagate(uint32_t s, uint32_t nprev, uint32_t nu,
                                                         const uint8_t *__restrict__ ctx_sym,   // [nu] symbols of column s
                                                         const uint8_t *__restrict__ qprev,     // [144][72] tables of column s-1
                                                         const double *__restrict__ rprev,      // [72] ratios of column s-1
-                                                        const double *__restrict__ prev_qpmf,  // [72][72]
-                                                        double *__restrict__ qpmf, double *__restrict__ xpmf,
-                                                        uint32_t *__restrict__ stop) {
+                                                        const double *__restrict__ ptemp,      // [72][72] (s >= 2)
+                                                        double *__restrict__ qpmf, uint32_t *__restrict__ stop) {
     extern __shared__ double lds[];
     if (threadIdx.x < A) stop[threadIdx.x] = 0xFFFFFFFFu;        // the design window that follows starts with no stop marks
     double *bufA = lds;             // p_temp[k][j], later the final qpmf[x][idx]
@@ -234,15 +250,9 @@ __global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict
             bufA[x * A + idx] = v;
         }
     } else {
-        // hoisted p_temp(k,j) = sum_x prev_qpmf[x][j] * P_{s-1}(k|x) * marg_{s-2}[x]   (codebook.c:318-321)
-        const double *Pc = P + (uint64_t)(s - 1) * A * A;
-        const double *mm = marg + (uint64_t)(s - 2) * A;
         for (uint32_t e = tid; e < A * nprev; e += 1024) {
             const uint32_t k = e / nprev, j = e % nprev;
-            double pt = 0;
-#pragma unroll 8
-            for (int x = 0; x < A; ++x) pt += prev_qpmf[x * A + j] * Pc[x * A + k] * mm[x];   // loads run ahead, the sum stays in order
-            bufA[k * A + j] = pt;
+            bufA[k * A + j] = ptemp[k * A + j];
         }
         __syncthreads();
         // qpmf[k][idx] += p_q_xq * p_temp over j                                      (codebook.c:301-322)
@@ -274,22 +284,26 @@ __global__ __launch_bounds__(1024) void k_ctx_propagate(const double *__restrict
         const uint32_t x = e / nu, idx = e % nu;
         qpmf[x * A + idx] = bufA[x * A + idx];
     }
-    // compute_xpmf_list (codebook.c:332-349)
+}
+
+// compute_xpmf_list (codebook.c:332-349): one workgroup per context idx, a thread per symbol k
+__global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
+                                                  const double *__restrict__ qpmf, double *__restrict__ xpmf) {
+    __shared__ double row[A];
+    const uint32_t idx = blockIdx.x, k = threadIdx.x;
     const double *Ps = P + (uint64_t)s * A * A;
     const double *m1 = marg + (uint64_t)(s - 1) * A;
-    for (uint32_t e = tid; e < nu * A; e += 1024) {
-        const uint32_t idx = e / A, k = e % A;
+    if (k < A) {
         double acc = 0.0;
 #pragma unroll 8
-        for (int x = 0; x < A; ++x) acc += bufA[x * A + idx] * Ps[x * A + k] * m1[x];
-        bufB[idx * A + k] = acc;
+        for (int x = 0; x < A; ++x) acc += qpmf[x * A + idx] * Ps[x * A + k] * m1[x];
+        row[k] = acc;
     }
     __syncthreads();
-    for (uint32_t e = tid; e < nu * A; e += 1024) {
-        const uint32_t idx = e / A, k = e % A;
+    if (k < A) {
         double total = 0;
-        for (int i = 0; i < A; ++i) total += bufB[idx * A + i];
-        const double v = bufB[idx * A + k];
+        for (int i = 0; i < A; ++i) total += row[i];
+        const double v = row[k];
         xpmf[idx * A + k] = total > 0 ? v / total : v;
     }
 }
@@ -543,7 +557,7 @@ struct ZeroDesign { uint8_t q[A], recon[A]; };
 
 struct CbWork {
     double *P = nullptr, *marg = nullptr, *qpmf[2] = {nullptr, nullptr}, *xpmf = nullptr, *dist = nullptr, *zero_rows = nullptr;
-    double *rprev = nullptr;
+    double *rprev = nullptr, *ptemp = nullptr;
     uint8_t *qprev = nullptr, *ctx_sym = nullptr;
     LmIn *lin = nullptr;
     LmDesign *lout = nullptr, *hout = nullptr;     // device window results and their pinned host mirror
@@ -552,7 +566,7 @@ struct CbWork {
     uint32_t capC = 0;                             // columns the buffers were sized for (0: nothing allocated)
     int device = -1;
     void release() {
-        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, qprev, ctx_sym, lin, lout, stop};
+        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, ptemp, qprev, ctx_sym, lin, lout, stop};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (hout) (void)hipHostFree(hout);
         if (pin) (void)hipHostFree(pin);
@@ -604,6 +618,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
         QVZ_HIP_CHECK(hipMalloc(&W.qpmf[0], tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.qpmf[1], tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.xpmf, tile * sizeof(double)));
+        QVZ_HIP_CHECK(hipMalloc(&W.ptemp, tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.dist, tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.zero_rows, tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.rprev, A * sizeof(double)));
@@ -682,8 +697,11 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
                 nu = merge_lists(uni, nu, cb->recon + b0 + (size_t)j * A, cb->nstates[(size_t)(s - 1) * 2 * A + j], uni);
             if (nu > A) return qvz_set_error(QVZ_E_DATA, "column %u: %u contexts exceed the alphabet", s, nu);
             QVZ_HIP_CHECK(hipMemcpyAsync(W.ctx_sym, uni, nu, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_ctx_propagate, dim3(1), dim3(1024), 2 * tile * sizeof(double), st, W.P, W.marg, s, nprev, nu,
-                               W.ctx_sym, W.qprev, W.rprev, W.qpmf[pq], W.qpmf[pq ^ 1], W.xpmf, W.stop);
+            if (s >= 2)
+                hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nprev + 255) / 256), dim3(256), 0, st, W.P, W.marg, s, nprev, W.qpmf[pq], W.ptemp);
+            hipLaunchKernelGGL(k_ctx_propagate, dim3(1), dim3(1024), 2 * tile * sizeof(double), st, s, nprev, nu,
+                               W.ctx_sym, W.qprev, W.rprev, W.ptemp, W.qpmf[pq ^ 1], W.stop);
+            hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf);
             QVZ_HIP_CHECK(hipGetLastError());
             pq ^= 1;
             d_rows = W.xpmf;
