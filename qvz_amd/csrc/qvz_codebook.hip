@@ -10,7 +10,7 @@
 // (this file is compiled with -ffp-contract=off). Parallelism comes from the independent dimensions only:
 //   k_cond_pmf      one wave per (column, previous symbol) row: counts -> P(x | prev) by true division
 //   k_marginals     one block, sequential over columns and over j (pmf.c:200-202 order), lanes over x
-//   k_ctx_propagate one 1024-thread block per column: thread per output element, each a sequential 72-term sum;
+//   k_ctx_ptemp / k_ctx_propagate / k_ctx_xpmf  one column of the context recursion: thread per output element, each a sequential 72-term sum;
 //                   p_temp(k,j) hoisted out of the idx loop (same per-term order => bit-identical)
 //   k_lm_window     one wave per (context, state count): Lloyd-Max with a lane per candidate reconstruction point, exact
 //                   (value, index) arg-min by wave shuffles, ballot masks + count-trailing-zeros for the
@@ -226,63 +226,56 @@ __global__ __launch_bounds__(256) void k_ctx_ptemp(const double *__restrict__ P,
     ptemp[k * A + j] = pt;
 }
 
-__global__ __launch_bounds__(1024) void k_ctx_propagate(uint32_t s, uint32_t nprev, uint32_t nu,
-                                                        const uint8_t *__restrict__ ctx_sym,   // [nu] symbols of column s
-                                                        const uint8_t *__restrict__ qprev,     // [144][72] tables of column s-1
-                                                        const double *__restrict__ rprev,      // [72] ratios of column s-1
-                                                        const double *__restrict__ ptemp,      // [72][72] (s >= 2)
-                                                        double *__restrict__ qpmf, uint32_t *__restrict__ stop) {
-    extern __shared__ double lds[];
-    if (threadIdx.x < A) stop[threadIdx.x] = 0xFFFFFFFFu;        // the design window that follows starts with no stop marks
-    double *bufA = lds;             // p_temp[k][j], later the final qpmf[x][idx]
-    double *bufB = lds + A * A;     // raw sums before renormalisation
-    const uint32_t tid = threadIdx.x;
-
+// qpmf rows: one workgroup per symbol k (rows are renormalised on their own), a thread per context idx
+__global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t nprev, uint32_t nu,
+                                                       const uint8_t *__restrict__ ctx_sym,   // [nu] symbols of column s
+                                                       const uint8_t *__restrict__ qprev,     // [144][72] tables of column s-1
+                                                       const double *__restrict__ rprev,      // [72] ratios of column s-1
+                                                       const double *__restrict__ ptemp,      // [72][72] (s >= 2)
+                                                       double *__restrict__ qpmf, uint32_t *__restrict__ stop) {
+    __shared__ double pt[A], raw[A], sr[A];
+    __shared__ uint8_t slo[A], shi[A];
+    const uint32_t k = blockIdx.x, idx = threadIdx.x;
+    if (k == 0 && idx < A) stop[idx] = 0xFFFFFFFFu;              // the design window that follows starts with no stop marks
     if (s == 1) {
         // compute_qpmf_quan_list (codebook.c:274-289): not renormalised
-        const double r0 = rprev[0];
-        for (uint32_t e = tid; e < A * nu; e += 1024) {
-            const uint32_t x = e / nu, idx = e % nu;
+        if (idx < nu) {
+            const double r0 = rprev[0];
             const uint32_t sym = ctx_sym[idx];
             double v = 0.0;
-            if (qprev[x] == sym) v += r0;
-            if (qprev[A + x] == sym) v += (1 - r0);
-            bufA[x * A + idx] = v;
+            if (qprev[k] == sym) v += r0;
+            if (qprev[A + k] == sym) v += (1 - r0);
+            qpmf[k * A + idx] = v;
         }
-    } else {
-        for (uint32_t e = tid; e < A * nprev; e += 1024) {
-            const uint32_t k = e / nprev, j = e % nprev;
-            bufA[k * A + j] = ptemp[k * A + j];
-        }
-        __syncthreads();
-        // qpmf[k][idx] += p_q_xq * p_temp over j                                      (codebook.c:301-322)
-        for (uint32_t e = tid; e < A * nu; e += 1024) {
-            const uint32_t k = e / nu, idx = e % nu;
-            const uint32_t sym = ctx_sym[idx];
-            double acc = 0.0;
-            for (uint32_t j = 0; j < nprev; ++j) {
-                double p_q_xq = 0.0;
-                const double rj = rprev[j];
-                if (qprev[(2 * j) * A + k] == sym) p_q_xq += rj;            // q_lo->ratio
-                if (qprev[(2 * j + 1) * A + k] == sym) p_q_xq += (1 - rj);  // q_hi->ratio
-                acc += p_q_xq * bufA[k * A + j];
-            }
-            bufB[k * A + idx] = acc;
-        }
-        __syncthreads();
-        // renormalize_pmf per row k (pmf.c:235-254): sequential total, true division when total > 0
-        for (uint32_t e = tid; e < A * nu; e += 1024) {
-            const uint32_t k = e / nu, idx = e % nu;
-            double total = 0;
-            for (uint32_t i = 0; i < nu; ++i) total += bufB[k * A + i];
-            const double v = bufB[k * A + idx];
-            bufA[k * A + idx] = total > 0 ? v / total : v;
-        }
+        return;
+    }
+    if (idx < nprev) {                                           // row k of p_temp, the ratios and what the quantizers map k to
+        pt[idx] = ptemp[k * A + idx];
+        sr[idx] = rprev[idx];
+        slo[idx] = qprev[(2 * idx) * A + k];
+        shi[idx] = qprev[(2 * idx + 1) * A + k];
     }
     __syncthreads();
-    for (uint32_t e = tid; e < A * nu; e += 1024) {
-        const uint32_t x = e / nu, idx = e % nu;
-        qpmf[x * A + idx] = bufA[x * A + idx];
+    // qpmf[k][idx] += p_q_xq * p_temp over j                                          (codebook.c:301-322)
+    if (idx < nu) {
+        const uint32_t sym = ctx_sym[idx];
+        double acc = 0.0;
+        for (uint32_t j = 0; j < nprev; ++j) {
+            double p_q_xq = 0.0;
+            const double rj = sr[j];
+            if (slo[j] == sym) p_q_xq += rj;                     // q_lo->ratio
+            if (shi[j] == sym) p_q_xq += (1 - rj);               // q_hi->ratio
+            acc += p_q_xq * pt[j];
+        }
+        raw[idx] = acc;
+    }
+    __syncthreads();
+    // renormalize_pmf of the row (pmf.c:235-254): sequential total, true division when total > 0
+    if (idx < nu) {
+        double total = 0;
+        for (uint32_t i = 0; i < nu; ++i) total += raw[i];
+        const double v = raw[idx];
+        qpmf[k * A + idx] = total > 0 ? v / total : v;
     }
 }
 
@@ -646,8 +639,6 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
         QVZ_HIP_CHECK(hipStreamSynchronize(st));
     }
     QVZ_HIP_CHECK(hipMemsetAsync(W.zero_rows, 0, tile * sizeof(double), st));
-    QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ctx_propagate),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile * sizeof(double))));
 
     hipLaunchKernelGGL(k_cond_pmf, dim3(C * A), dim3(64), 0, st, d_cnt, W.P);
     hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
@@ -699,7 +690,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             QVZ_HIP_CHECK(hipMemcpyAsync(W.ctx_sym, uni, nu, hipMemcpyHostToDevice, st));
             if (s >= 2)
                 hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nprev + 255) / 256), dim3(256), 0, st, W.P, W.marg, s, nprev, W.qpmf[pq], W.ptemp);
-            hipLaunchKernelGGL(k_ctx_propagate, dim3(1), dim3(1024), 2 * tile * sizeof(double), st, s, nprev, nu,
+            hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu,
                                W.ctx_sym, W.qprev, W.rprev, W.ptemp, W.qpmf[pq ^ 1], W.stop);
             hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf);
             QVZ_HIP_CHECK(hipGetLastError());
