@@ -359,13 +359,25 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
         bool mono = true;
         for (uint32_t t = lane; t < S; t += 64) mono = mono && bounds[t] <= bounds[t + 1];
         if (!__ballot(!mono)) {
-            for (uint32_t rr = lane; rr < A; rr += 64) {
-                uint32_t j = 0;
-                for (uint32_t t = 1; t < S; ++t) j += bounds[t] <= rr ? 1u : 0u;
-                const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
-                double m = 0.0;
-                for (uint32_t i = b0; i < b1; ++i) m += p[i] * D(i, rr);
-                L->mv[rr] = m;
+            {
+                // 72 candidates on 64 lanes: lanes 0..7 carry a second one (rr + 64) through the same loop iterations
+                // instead of a second pass of the whole wave. A term outside a lane's region is added as +0.0, which
+                // leaves a sum of non-negative terms bit for bit what it was.
+                const uint32_t rrA = lane, rrB = lane + 64 < A ? lane + 64 : A - 1;
+                const bool hasB = lane + 64 < A;
+                uint32_t jA = 0, jB = 0;
+                for (uint32_t t = 1; t < S; ++t) { const uint32_t bt = bounds[t]; jA += bt <= rrA ? 1u : 0u; jB += bt <= rrB ? 1u : 0u; }
+                const uint32_t a0 = bounds[jA], a1 = bounds[jA + 1], c0 = bounds[jB], c1 = hasB ? bounds[jB + 1] : c0;
+                const uint32_t lenA = a1 - a0, lenB = c1 - c0;
+                double mA = 0.0, mB = 0.0;
+                for (uint32_t k = 0; __ballot(k < lenA || k < lenB); ++k) {
+                    const uint32_t iA = k < lenA ? a0 + k : a0, iB = k < lenB ? c0 + k : c0;
+                    const double vA = p[iA] * D(iA, rrA), vB = p[iB] * D(iB, rrB);
+                    mA += k < lenA ? vA : 0.0;
+                    mB += k < lenB ? vB : 0.0;
+                }
+                L->mv[rrA] = mA;
+                if (hasB) L->mv[rrB] = mB;
             }
             __syncthreads();
             uint32_t chg = 0;
