@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -205,6 +206,14 @@ __global__ __launch_bounds__(128) void k_marginals(const double *__restrict__ P,
     }
 }
 
+// what the Lloyd-Max window kernel is told per context (k_lm_window)
+struct LmIn {
+    double target;
+    uint8_t mode;      // 0 skip, 1 window [startS, startS + W), 2 the single design startS
+    uint8_t startS;
+    uint8_t pad[6];
+};
+
 // One column of the context recursion, in three launches. Inputs (device): P, marg, previous column's qpmf, quantizer
 // tables and ratios of column s-1, context symbols of column s. Outputs: qpmf[72][72] (row x, entry idx) and
 // xpmf[nu][72] (row idx).
@@ -280,9 +289,14 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
 }
 
 // compute_xpmf_list (codebook.c:332-349): one workgroup per context idx, a thread per symbol k
+// It also writes the plan of the first design window (LmIn), so that the window can be launched without a host round
+// trip: whether the row is all zero (no design), whether its target is exactly 0 (entropy 0 <=> every entry is 0 or 1;
+// or a target of 0 was asked for), else a target from the device's own log2 - in the kernel that value only steers
+// which designs give up early, by more than the guard band; every decision is the host's, from libm values.
 __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
-                                                  const double *__restrict__ qpmf, double *__restrict__ xpmf) {
-    __shared__ double row[A];
+                                                  const double *__restrict__ qpmf, double *__restrict__ xpmf,
+                                                  LmIn *__restrict__ lin, int ratio_mode, double opt_ratio) {
+    __shared__ double row[A], nrow[A], ent[A];
     const uint32_t idx = blockIdx.x, k = threadIdx.x;
     const double *Ps = P + (uint64_t)s * A * A;
     const double *m1 = marg + (uint64_t)(s - 1) * A;
@@ -297,7 +311,28 @@ __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, 
         double total = 0;
         for (int i = 0; i < A; ++i) total += row[i];
         const double v = row[k];
-        xpmf[idx * A + k] = total > 0 ? v / total : v;
+        const double nv = total > 0 ? v / total : v;
+        xpmf[idx * A + k] = nv;
+        nrow[k] = nv;
+        ent[k] = lin && nv > 0.0 ? nv * log2(nv) : 0.0;          // every thread its own term
+    }
+    __syncthreads();
+    if (k == 0 && lin) {
+        bool zero = true, degenerate = true;
+        double h = 0.0;
+        for (int i = 0; i < A; ++i) {
+            const double x = nrow[i];
+            if (x != 0.0) zero = false;
+            if (x != 0.0 && x != 1.0) degenerate = false;
+            h -= ent[i];
+        }
+        const bool target0 = ratio_mode ? (degenerate || opt_ratio == 0.0) : opt_ratio == 0.0;
+        LmIn I;
+        I.target = target0 ? 0.0 : ratio_mode ? h * opt_ratio : opt_ratio;
+        I.mode = zero ? 0 : target0 ? 2 : 1;
+        I.startS = 1;
+        for (int i = 0; i < 6; ++i) I.pad[i] = 0;
+        lin[idx] = I;
     }
 }
 
@@ -305,12 +340,6 @@ __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, 
 // The reference walks S = 1, 2, 3 ... until the design's entropy reaches the target (codebook.c:244-258). The
 // designs for different S do not depend on each other, only the stopping decision is sequential, so a launch
 // computes a window of consecutive S per context on separate CUs and the host replays the walk over the results.
-struct LmIn {
-    double target;
-    uint8_t mode;      // 0 skip, 1 window [startS, startS + W), 2 the single design startS
-    uint8_t startS;
-    uint8_t pad[6];
-};
 
 struct LmDesign {
     double o[A];       // output pmf (apply_quantizer, quantizer.c:139-161)
@@ -611,6 +640,7 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
     cb->nstates[(size_t)s * 2 * A + qi] = (uint8_t)S;
 }
 
+static std::atomic<int> g_cb_active{0};   // qvz_hip_generate_codebook calls in flight (one per cluster when a caller runs them concurrently)
 static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
                     qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
     const size_t tile = (size_t)A * A;
@@ -684,7 +714,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     uint32_t nprev = 0;
     int pq = 0;   // index of the qpmf buffer holding the previous column
     for (uint32_t s = 0; s < C; ++s) {
-        uint32_t nu;
+        uint32_t nu, win0 = 0;                                                      // win0: width of a first window already run (s >= 1)
         uint8_t *uni = hu2 + (size_t)(s & 1) * 4 * A;
         const double *d_rows;
         if (s == 0) {                                                               // codebook.c:392-411
@@ -704,11 +734,25 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
                 hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nprev + 255) / 256), dim3(256), 0, st, W.P, W.marg, s, nprev, W.qpmf[pq], W.ptemp);
             hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu,
                                W.ctx_sym, W.qprev, W.rprev, W.ptemp, W.qpmf[pq ^ 1], W.stop);
-            hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf);
+            // With several generations running side by side (one host thread per cluster) a host round trip costs more
+            // than the device-side plan; alone it is the other way round (+1 ms per codebook).
+            const bool one_trip = g_cb_active.load(std::memory_order_relaxed) > 1;
+            hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf,
+                               one_trip ? W.lin : (LmIn *)nullptr, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio);
             QVZ_HIP_CHECK(hipGetLastError());
             pq ^= 1;
             d_rows = W.xpmf;
             QVZ_HIP_CHECK(hipMemcpyAsync(hx, W.xpmf, (size_t)nu * A * sizeof(double), hipMemcpyDeviceToHost, st));
+            // the first design window follows at once, planned on the device (k_ctx_xpmf): one host round trip per
+            // column instead of two
+            if (one_trip) {
+            win0 = window0;
+            if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win0), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win0), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win0), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            QVZ_HIP_CHECK(hipGetLastError());
+            QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win0, hipMemcpyDeviceToHost, st));
+            }
         }
         QVZ_HIP_CHECK(hipStreamSynchronize(st));
         cb->nctx[s] = (uint8_t)nu;
@@ -734,6 +778,11 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
         }
         uint32_t win = window0, smax = 1, round = 0;
         while (any_gpu) {
+            if (round == 0 && win0) {
+                // this window has been run already, with the same plan (all-zero rows and zero targets are exact on
+                // both sides; the device's target differs from the libm one in the last bits, which only steers)
+                ++round;
+            } else {
             QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(LmIn) * nu, hipMemcpyHostToDevice, st));
             if (s == 0 || round) QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));   // (k_ctx_propagate resets it otherwise)
             ++round;
@@ -743,6 +792,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             QVZ_HIP_CHECK(hipGetLastError());
             QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win, hipMemcpyDeviceToHost, st));
             QVZ_HIP_CHECK(hipStreamSynchronize(st));
+            }
             any_gpu = false;
             for (uint32_t j = 0; j < nu; ++j) {
                 const LmDesign *d = hout + (size_t)j * win;
@@ -833,8 +883,10 @@ extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, cons
     g_deferred = 0;
     memset(out->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
     CbWork *W = cbw_acquire();
+    g_cb_active.fetch_add(1);
     const int rc = generate(d_cnt, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
     (void)hipStreamSynchronize((hipStream_t)stream);
+    g_cb_active.fetch_sub(1);
     cbw_give_back(W);
     return rc;
 }
