@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <mutex>
@@ -640,6 +641,8 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
     cb->nstates[(size_t)s * 2 * A + qi] = (uint8_t)S;
 }
 
+static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static thread_local double cb_wait[2];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 static std::atomic<int> g_cb_active{0};   // qvz_hip_generate_codebook calls in flight (one per cluster when a caller runs them concurrently)
 static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
                     qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
@@ -754,7 +757,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win0, hipMemcpyDeviceToHost, st));
             }
         }
-        QVZ_HIP_CHECK(hipStreamSynchronize(st));
+        { const double t_ = cb_now(); QVZ_HIP_CHECK(hipStreamSynchronize(st)); cb_wait[0] += cb_now() - t_; }
         cb->nctx[s] = (uint8_t)nu;
         memcpy(cb->ctx_sym + (size_t)s * A, uni, nu);
         for (uint32_t i = 0; i < nu; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
@@ -791,7 +794,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
             QVZ_HIP_CHECK(hipGetLastError());
             QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win, hipMemcpyDeviceToHost, st));
-            QVZ_HIP_CHECK(hipStreamSynchronize(st));
+            { const double t_ = cb_now(); QVZ_HIP_CHECK(hipStreamSynchronize(st)); cb_wait[1] += cb_now() - t_; }
             }
             any_gpu = false;
             for (uint32_t j = 0; j < nu; ++j) {
@@ -884,10 +887,15 @@ extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, cons
     memset(out->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
     CbWork *W = cbw_acquire();
     g_cb_active.fetch_add(1);
+    cb_wait[0] = cb_wait[1] = 0.0;
+    const double t_gen = cb_now();
     const int rc = generate(d_cnt, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
     (void)hipStreamSynchronize((hipStream_t)stream);
     g_cb_active.fetch_sub(1);
     cbw_give_back(W);
+    if (getenv("QVZ_CB_DEBUG"))                                  // development knob
+        fprintf(stderr, "qvz_hip_generate_codebook: %.1f ms, of which waiting for the context propagation %.1f ms, for the design windows %.1f ms\n",
+                (cb_now() - t_gen) * 1e3, cb_wait[0] * 1e3, cb_wait[1] * 1e3);
     return rc;
 }
 
