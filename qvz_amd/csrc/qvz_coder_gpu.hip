@@ -1627,6 +1627,13 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipEventElapsedTime(&ta, evs[(size_t)i * 4], evs[(size_t)i * 4 + 1]));
         TRY(hipEventElapsedTime(&tb, evs[(size_t)i * 4 + 2], evs[(size_t)i * 4 + 3]));
         g_planes_ms[0] += ta; g_planes_ms[1] += tb;
+        if (getenv("QVZ_CODER_DEBUG")) {                         // the segment's kernels on the time line of the call
+            float m0 = 0.f, c0 = 0.f;
+            TRY(hipEventElapsedTime(&m0, evs[0], evs[(size_t)i * 4]));
+            TRY(hipEventElapsedTime(&c0, evs[0], evs[(size_t)i * 4 + 2]));
+            fprintf(stderr, "  segment %u (%llu reads): model %.2f .. %.2f ms, coder %.2f .. %.2f ms\n", i, (unsigned long long)segs[i].second,
+                    m0, m0 + ta, c0, c0 + tb);
+        }
     }
 #ifdef QVZ_PROFILE
     {
