@@ -88,8 +88,9 @@ int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint6
  *          (arith.c:47-48), then E1/E2/E3 renormalisation (arith.c:50-97) and the bit output, split over four
  *          waves (record loader / interval chain / pending-bit count / byte stream) that hand blocks over through LDS.
  * Records pass through d_work (work_bytes, 16-byte aligned) in segments of as many reads per stream as fit:
- * 16 bytes x (shards rounded up to 64) x (columns + (clusters > 1), rounded up to 8) per read; d_work = NULL: a workspace of up to 4 GiB is allocated
- * for the call. Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel
+ * 16 bytes x (shards rounded up to 64) x (columns, + 8 reserved positions when clusters > 1, rounded up to 8) per read;
+ * d_work = NULL: a workspace of 4/5 of the free device memory, at most 96 GiB and what the whole input needs, is
+ * allocated for the call. With room for two segments the model kernel of one runs beside the coder kernel of the other. Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel
  * with one lane per (stream, column) and the tables in HBM.
  * d_labels must be readable up to n rounded up to a multiple of 4. The emitter checks its room once per 16 symbols:
  * a stream that comes within 128 bytes of cap_per_shard is reported as overflowed (QVZ_E_NOMEM). */

@@ -1465,9 +1465,13 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         hipError_t e_ = (expr);                                                                                      \
         if (e_ != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); goto done; } \
     } while (0)
-    if (!d_work) {                                               // no workspace given: up to 4 GiB of our own
+    if (!d_work) {                                               // no workspace given: our own, up to 96 GiB of what is free
         work_bytes = per_read * longest;
-        if (work_bytes > (4ull << 30)) work_bytes = 4ull << 30;
+        size_t mem_free = 0, mem_total = 0;
+        uint64_t limit = 4ull << 30;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && (uint64_t)mem_free / 5 * 4 > limit) limit = (uint64_t)mem_free / 5 * 4;
+        if (limit > (96ull << 30)) limit = 96ull << 30;
+        if (work_bytes > limit) work_bytes = limit;
         if (work_bytes < per_read * 4) work_bytes = per_read * 4;
         TRY(hipMalloc(&own_work, work_bytes));
         d_work = own_work;
