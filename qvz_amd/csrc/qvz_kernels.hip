@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
 // matrix) k_quantize.
 #define QZ_THREADS 512
 #define QZ_CLUSTER4 (10 + QVZ_QS_STRIDE / 8)       // uint4 per cluster and column: ct (9) + pad (1) + qs (1296)
-template <int NBUF, int NQ>
+template <int NBUF, int NQ, int RW>   // RW dwords = 4 * RW consecutive reads per thread
 __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                              uint64_t n, uint32_t C, uint64_t ld, uint32_t K,
                                                              const uint16_t *__restrict__ ct, const uint16_t *__restrict__ qs,
@@ -1143,18 +1143,20 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
     const uint32_t per_col4 = K * QZ_CLUSTER4;                   // uint4 per column (all clusters)
     if (threadIdx.x < QVZ_A) sdist[threadIdx.x] = dist[threadIdx.x];
     const uint64_t t = (uint64_t)blockIdx.x * QZ_THREADS + threadIdx.x;
-    const uint64_t i0 = 4 * t;
+    constexpr int R = 4 * RW;
+    const uint64_t i0 = (uint64_t)R * t;
     const bool active = i0 < n;                                  // idle threads still copy tables and meet the barriers
-    uint32_t lab4 = 0;
-    if (labels && active) lab4 = *reinterpret_cast<const uint32_t *>(labels + i0);
-    uint32_t cbase[4], prev[4] = {0, 0, 0, 0};                   // cluster's table base in the column buffer, in u16
-    double err[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t cbase[R], prev[R];                                  // cluster's table base in the column buffer, in u16
+    double err[R];
     bool dead = false;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t l = (lab4 >> (8 * r)) & 0xFF;
+    for (int r = 0; r < R; ++r) {
+        uint32_t l = 0;
+        if (labels && active && i0 + r < ld) l = labels[i0 + r];
         cbase[r] = (l < K ? l : 0u) * (QZ_CLUSTER4 * 8);
         dead = dead || (active && i0 + r < n && l >= K);
+        prev[r] = 0;
+        err[r] = 0.0;
     }
     uint4 stg[NQ];
     auto fetch = [&](uint32_t s) {                               // column s's tables -> registers
@@ -1184,21 +1186,29 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
     // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
     // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
     const uint64_t io = active ? i0 : 0;
-    uint32_t x4n = *reinterpret_cast<const uint32_t *>(D + io);
-    uint32_t d4n = *reinterpret_cast<const uint32_t *>(draws + io);              // 7-bit draws, same layout
+    uint32_t x4n[RW], d4n[RW];
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+        x4n[w] = *reinterpret_cast<const uint32_t *>(D + io + 4 * w);
+        d4n[w] = *reinterpret_cast<const uint32_t *>(draws + io + 4 * w);        // 7-bit draws, same layout
+    }
     for (uint32_t s = 0; s < C; ++s) {
         const uint16_t *cur = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s & 1) * per_col4 : 0u));
-        const uint32_t x4 = x4n, d4 = d4n;
+        uint32_t x4[RW], d4[RW], qv4[RW], qi4[RW], st4[RW];
+#pragma unroll
+        for (int w = 0; w < RW; ++w) { x4[w] = x4n[w]; d4[w] = d4n[w]; qv4[w] = qi4[w] = st4[w] = 0; }
         if (s + 1 < C) {
             fetch(s + 1);
-            x4n = *reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io);
-            d4n = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io);
-        }
-        uint32_t qv4 = 0, qi4 = 0, st4 = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t draw = (d4 >> (8 * r)) & 127;                                 // well.c:33-46
-            uint32_t x = (x4 >> (8 * r)) & 0xFF;
+            for (int w = 0; w < RW; ++w) {
+                x4n[w] = *reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io + 4 * w);
+                d4n[w] = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io + 4 * w);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t draw = (d4[r >> 2] >> (8 * (r & 3))) & 127;                   // well.c:33-46
+            uint32_t x = (x4[r >> 2] >> (8 * (r & 3))) & 0xFF;
             if (x >= QVZ_A) x = 0;
             const uint16_t *cb = cur + cbase[r];
             const uint32_t cv = cb[prev[r]];
@@ -1211,14 +1221,17 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
             const double dd = sdist[x > qvc ? x - qvc : qvc - x];                        // distortion.c:151
             err[r] = (s == 0) ? dd : err[r] + dd;
             prev[r] = qvc;
-            qv4 |= qv << (8 * r);
-            qi4 |= qi << (8 * r);
-            st4 |= (qsv >> 8) << (8 * r);
+            qv4[r >> 2] |= qv << (8 * (r & 3));
+            qi4[r >> 2] |= qi << (8 * (r & 3));
+            st4[r >> 2] |= (qsv >> 8) << (8 * (r & 3));
         }
         if (active) {
-            if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0) = qv4;
-            if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0) = qi4;
-            if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0) = st4;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) {
+                if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0 + 4 * w) = qv4[w];
+                if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0 + 4 * w) = qi4[w];
+                if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0 + 4 * w) = st4[w];
+            }
         }
         if (s + 1 < C) {
             if (NBUF == 1) __syncthreads();                      // everybody is done with column s's tables
@@ -1228,7 +1241,7 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
     }
     if (err_out && active) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < R; ++r)
             if (i0 + r < n) err_out[i0 + r] = err[r];
     }
     if (dead) atomicOr(status, 1);
@@ -1257,15 +1270,27 @@ extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, u
                 if (memcmp(&h_dist[x + QVZ_A * y], &h_dist[x > y ? x - y : y - x], sizeof(double)) != 0) { in_lds = false; break; }
     }
     if (in_lds) {
-        dim3 grid((unsigned)((n4 + QZ_THREADS - 1) / QZ_THREADS));
+        // dwords (4 reads each) per thread: 8 reads = 8 independent chains pay with one cluster (22.6 -> 20.4 ms at 100M x 150),
+        // not with the single table buffer of three (40 -> 50 ms); QVZ_QUANTIZE_RW is a development knob
+        const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 ? 2 : 1);
+        const uint64_t per_wg = (uint64_t)QZ_THREADS * (rw == 2 ? 2 : 1);
+        dim3 grid((unsigned)((n4 + per_wg - 1) / per_wg));
         const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
 #define QZ_LAUNCH(NBUF, NQ)                                                                                                      \
         do {                                                                                                                     \
-            QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ>),                         \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
-            hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,              \
-                               k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, \
-                               ld_out, d_err, d_status);                                                                         \
+            if (rw == 2) {                                                                                                       \
+                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 2>),                  \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 2>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,       \
+                                   k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi,   \
+                                   d_st, ld_out, d_err, d_status);                                                               \
+            } else {                                                                                                             \
+                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 1>),                  \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 1>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,       \
+                                   k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi,   \
+                                   d_st, ld_out, d_err, d_status);                                                               \
+            }                                                                                                                    \
         } while (0)
         static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4, "stage registers");
         if (k == 1) QZ_LAUNCH(2, 3);
