@@ -642,7 +642,7 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 }
 
 static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-static thread_local double cb_wait[2];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
+static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 static std::atomic<int> g_cb_active{0};   // qvz_hip_generate_codebook calls in flight (one per cluster when a caller runs them concurrently)
 static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
                     qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
@@ -767,6 +767,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
         double target[A];
         bool any_gpu = false;
         memset(hin, 0, A * sizeof(LmIn));
+        const double t_tg = cb_now();
         for (uint32_t j = 0; j < nu; ++j) {
             const double *pj = hx + (size_t)j * A;
             zero[j] = true;
@@ -779,6 +780,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
                 any_gpu = true;
             }
         }
+        cb_wait[2] += cb_now() - t_tg;
         uint32_t win = window0, smax = 1, round = 0;
         while (any_gpu) {
             if (round == 0 && win0) {
@@ -834,6 +836,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
         window0 = smax + 3 < 8 ? 8 : (smax + 3 > A ? A : smax + 3);
 
         // ratios from libm entropies, store (optimize_for_entropy :263-268, store_cond_quantizers_indexed :152-157)
+        const double t_rt = cb_now();
         for (uint32_t j = 0; j < nu; ++j) {
             double ratio;
             if (zero[j]) {
@@ -866,6 +869,7 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
             cb->qratio[(size_t)s * A + j] = (uint8_t)(ratio * 128.);
             cb->live[(size_t)s * A + j] = zero[j] ? 0 : 1;
         }
+        cb_wait[3] += cb_now() - t_rt;
         // hand this column's tables and ratios to the next column's propagation
         uint8_t *hq = hq2 + (size_t)(s & 1) * 2 * tile;   // slot s & 1: its last use (column s - 2) finished before column s - 1's syncs
         double *hr = hr2 + (size_t)(s & 1) * A;
@@ -887,15 +891,15 @@ extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, cons
     memset(out->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
     CbWork *W = cbw_acquire();
     g_cb_active.fetch_add(1);
-    cb_wait[0] = cb_wait[1] = 0.0;
+    cb_wait[0] = cb_wait[1] = cb_wait[2] = cb_wait[3] = 0.0;
     const double t_gen = cb_now();
     const int rc = generate(d_cnt, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
     (void)hipStreamSynchronize((hipStream_t)stream);
     g_cb_active.fetch_sub(1);
     cbw_give_back(W);
     if (getenv("QVZ_CB_DEBUG"))                                  // development knob
-        fprintf(stderr, "qvz_hip_generate_codebook: %.1f ms, of which waiting for the context propagation %.1f ms, for the design windows %.1f ms\n",
-                (cb_now() - t_gen) * 1e3, cb_wait[0] * 1e3, cb_wait[1] * 1e3);
+        fprintf(stderr, "qvz_hip_generate_codebook: %.1f ms, of which waiting for the context propagation %.1f ms, for the design windows %.1f ms; host: targets %.1f ms, ratios and storing %.1f ms\n",
+                (cb_now() - t_gen) * 1e3, cb_wait[0] * 1e3, cb_wait[1] * 1e3, cb_wait[2] * 1e3, cb_wait[3] * 1e3);
     return rc;
 }
 
