@@ -399,12 +399,22 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 for (uint32_t t = 1; t < S; ++t) { const uint32_t bt = bounds[t]; jA += bt <= rrA ? 1u : 0u; jB += bt <= rrB ? 1u : 0u; }
                 const uint32_t a0 = bounds[jA], a1 = bounds[jA + 1], c0 = bounds[jB], c1 = hasB ? bounds[jB + 1] : c0;
                 const uint32_t lenA = a1 - a0, lenB = c1 - c0;
+                // A design is one wave alone on its SIMD: every LDS access it waits for costs its full latency (~130
+                // cycles), so four terms are fetched and multiplied at a time and then added in index order.
                 double mA = 0.0, mB = 0.0;
-                for (uint32_t k = 0; __ballot(k < lenA || k < lenB); ++k) {
-                    const uint32_t iA = k < lenA ? a0 + k : a0, iB = k < lenB ? c0 + k : c0;
-                    const double vA = p[iA] * D(iA, rrA), vB = p[iB] * D(iB, rrB);
-                    mA += k < lenA ? vA : 0.0;
-                    mB += k < lenB ? vB : 0.0;
+                for (uint32_t k = 0; __ballot(k < lenA || k < lenB); k += 4) {
+                    double vA[4], vB[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t iA = k + u < lenA ? a0 + k + u : a0, iB = k + u < lenB ? c0 + k + u : c0;
+                        vA[u] = p[iA] * D(iA, rrA);
+                        vB[u] = p[iB] * D(iB, rrB);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        mA += k + u < lenA ? vA[u] : 0.0;
+                        mB += k + u < lenB ? vB[u] : 0.0;
+                    }
                 }
                 L->mv[rrA] = mA;
                 if (hasB) L->mv[rrB] = mB;
@@ -415,9 +425,13 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
                 double best_v = DBL_MAX;
                 uint32_t best_r = b0;                                                // min_r = bounds[j]
-                for (uint32_t r = b0; r < b1; ++r) {
-                    const double v = L->mv[r];
-                    if (v < best_v) { best_v = v; best_r = r; }
+                for (uint32_t r = b0; r < b1; r += 4) {              // four candidates per LDS round trip, compared in order
+                    double v[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) v[u] = L->mv[r + u < b1 ? r + u : b0];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)
+                        if (r + u < b1 && v[u] < best_v) { best_v = v[u]; best_r = r + u; }
                 }
                 if (best_r != recon[j]) { chg = 1; recon[j] = (uint8_t)best_r; }
             }
@@ -495,18 +509,43 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
 
     for (uint32_t i = lane; i < A; i += 64) q[i] = 0;                                 // calloc, quantizer.c:14
     __syncthreads();
-    for (uint32_t j = 0; j < S; ++j) {                                               // :112-116, later regions overwrite
-        const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
-        const uint8_t rj = recon[j];
-        if (b0 + lane < b1) q[b0 + lane] = rj;
-        if (b0 + lane + 64 < b1) q[b0 + lane + 64] = rj;
+    bool part = true;                                                                // the bounds are a partition of 0 .. 71
+    for (uint32_t t = lane; t < S; t += 64) part = part && bounds[t] <= bounds[t + 1];
+    if (!__ballot(!part)) {
+        // :112-116 with regions that do not overlap: every symbol takes the reconstruction point of its own region
+        const uint32_t iA = lane, iB = lane + 64 < A ? lane + 64 : A - 1;
+        uint32_t jA = 0, jB = 0;
+        for (uint32_t t = 1; t < S; ++t) { const uint32_t bt = bounds[t]; jA += bt <= iA ? 1u : 0u; jB += bt <= iB ? 1u : 0u; }
+        q[iA] = recon[jA];
+        if (lane + 64 < A) q[iB] = recon[jB];
         __syncthreads();
+    } else {
+        for (uint32_t j = 0; j < S; ++j) {                                           // :112-116, later regions overwrite
+            const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
+            const uint8_t rj = recon[j];
+            if (b0 + lane < b1) q[b0 + lane] = rj;
+            if (b0 + lane + 64 < b1) q[b0 + lane + 64] = rj;
+            __syncthreads();
+        }
     }
-    for (uint32_t v = lane; v < A; v += 64) {                                        // apply_quantizer :155-157
-        double acc = 0.0;
-        for (int i = 0; i < A; ++i)
-            if (q[i] == v) acc += p[i];
-        o[v] = acc;
+    {                                                                                // apply_quantizer :155-157
+        // both output symbols of a lane (v, v + 64) in one sweep over i, eight inputs per LDS round trip; what does
+        // not map to the lane's symbol is added as +0.0 (the sums are of non-negative terms, in index order)
+        const uint32_t vA = lane, vB = lane + 64;
+        double accA = 0.0, accB = 0.0;
+        for (uint32_t i = 0; i < A; i += 8) {
+            uint32_t qq[8];
+            double pp[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) { qq[u] = q[i + u]; pp[u] = p[i + u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                accA += qq[u] == vA ? pp[u] : 0.0;
+                accB += qq[u] == vB ? pp[u] : 0.0;
+            }
+        }
+        o[vA] = accA;
+        if (vB < A) o[vB] = accB;
     }
     __syncthreads();
     return true;
