@@ -352,8 +352,25 @@ struct LmDesign {
     uint8_t pad[6];
 };
 
+// Region index of two symbols under a partition: the number of interior bounds (t = 1 .. S-1) not above the symbol.
+// The bounds are read sixteen at a time (one LDS round trip) and compared from registers.
+__device__ __forceinline__ void lm_region_of(const uint8_t *bounds, uint32_t S, uint32_t xa, uint32_t xb, uint32_t &ja,
+                                             uint32_t &jb) {
+    for (uint32_t t0 = 0; t0 < S; t0 += 16) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(bounds + t0);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {
+            const uint32_t bt = (ww[u >> 2] >> (8 * (u & 3))) & 0xFFu, t = t0 + u;
+            const bool in = t >= 1 && t < S;
+            ja += in && bt <= xa ? 1u : 0u;
+            jb += in && bt <= xb ? 1u : 0u;
+        }
+    }
+}
+
 struct LmLds {
-    uint8_t bounds[80];
+    alignas(16) uint8_t bounds[80];      // read sixteen at a time (lm_region_of)
     uint8_t q[2][A];
     uint8_t recon[2][A];
     double mv[A];            // expected distortion of every candidate reconstruction point within its own region
@@ -396,7 +413,7 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 const uint32_t rrA = lane, rrB = lane + 64 < A ? lane + 64 : A - 1;
                 const bool hasB = lane + 64 < A;
                 uint32_t jA = 0, jB = 0;
-                for (uint32_t t = 1; t < S; ++t) { const uint32_t bt = bounds[t]; jA += bt <= rrA ? 1u : 0u; jB += bt <= rrB ? 1u : 0u; }
+                lm_region_of(bounds, S, rrA, rrB, jA, jB);
                 const uint32_t a0 = bounds[jA], a1 = bounds[jA + 1], c0 = bounds[jB], c1 = hasB ? bounds[jB + 1] : c0;
                 const uint32_t lenA = a1 - a0, lenB = c1 - c0;
                 // A design is one wave alone on its SIMD: every LDS access it waits for costs its full latency (~130
@@ -472,15 +489,25 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
             // d(j, r) = f(|j - r|) with f strictly increasing: d(j, rb) < d(j, ra) <=> |j - rb| < |j - ra|, i.e. j beyond
             // the midpoint of ra and rb on rb's side. The first flagged j after the previous boundary is then arithmetic,
             // not a search: no LDS gathers, no ballots.
+            // The reconstruction points are read eight at a time (recon[] is 8-byte aligned in both slots).
             uint32_t jprev = 0;
-            for (uint32_t t = 0; t + 1 < S; ++t) {
-                const uint32_t ra = recon[t], rb = recon[t + 1];
-                uint32_t jn = jprev + 1;
-                if (rb > ra) { const uint32_t c = (ra + rb) / 2 + 1; jn = c > jn ? c : jn; }     // j > (ra + rb) / 2
-                else if (rb == ra || 2 * jn >= ra + rb) break;                                    // j < (ra + rb) / 2
-                if (jn > A - 2) break;
-                if (lane == 0) bounds[t + 1] = (uint8_t)jn;
-                jprev = jn;
+            bool walking = true;
+            for (uint32_t t0 = 0; t0 + 1 < S && walking; t0 += 8) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(recon + t0);
+                const uint32_t nx = recon[t0 + 8 < A ? t0 + 8 : A - 1];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t t = t0 + u;
+                    if (!walking || t + 1 >= S) { walking = walking && t + 1 < S; continue; }
+                    const uint32_t ra = ((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xFFu;
+                    const uint32_t rb = u == 7 ? nx : ((u + 1 < 4 ? w.x : w.y) >> (8 * ((u + 1) & 3))) & 0xFFu;
+                    uint32_t jn = jprev + 1;
+                    if (rb > ra) { const uint32_t c = (ra + rb) / 2 + 1; jn = c > jn ? c : jn; }     // j > (ra + rb) / 2
+                    else if (rb == ra || 2 * jn >= ra + rb) { walking = false; continue; }            // j < (ra + rb) / 2
+                    if (jn > A - 2) { walking = false; continue; }
+                    if (lane == 0) bounds[t + 1] = (uint8_t)jn;
+                    jprev = jn;
+                }
             }
         } else {
             uint32_t jprev = 0;
@@ -515,7 +542,7 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
         // :112-116 with regions that do not overlap: every symbol takes the reconstruction point of its own region
         const uint32_t iA = lane, iB = lane + 64 < A ? lane + 64 : A - 1;
         uint32_t jA = 0, jB = 0;
-        for (uint32_t t = 1; t < S; ++t) { const uint32_t bt = bounds[t]; jA += bt <= iA ? 1u : 0u; jB += bt <= iB ? 1u : 0u; }
+        lm_region_of(bounds, S, iA, iB, jA, jB);
         q[iA] = recon[jA];
         if (lane + 64 < A) q[iB] = recon[jB];
         __syncthreads();
