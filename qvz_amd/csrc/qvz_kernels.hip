@@ -514,6 +514,7 @@ __global__ void k_pmf_hist(const uint8_t *__restrict__ D, const uint8_t *__restr
 // consecutive column tiles live in LDS at a time (flushed with global atomics every G columns).
 #define PMF_WALK_T 1024
 typedef unsigned short pmf_u16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t pmf_lds_u32;
 
 // One (prev, cur) pair that did not pass the packed fast check: full per-symbol logic (cold path).
 template <bool HAVE_LABELS>
@@ -540,10 +541,12 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
     const uint64_t slab0 = (uint64_t)blockIdx.x * T * 16 * Q;
     uint64_t row[Q];
     uint4 prv[Q], cur[Q], lab[Q];
+    uint32_t pbad[Q];                                            // range check of prv[q], made when it was cur[q]
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         row[q] = slab0 + ((uint64_t)q * T + threadIdx.x) * 16;
         prv[q] = make_uint4(0, 0, 0, 0);                         // column 0 counts under prev = 0 (codebook.c:200)
+        pbad[q] = 0;
         lab[q] = make_uint4(0, 0, 0, 0);
         if (HAVE_LABELS && row[q] < n) lab[q] = *reinterpret_cast<const uint4 *>(labels + row[q]);
         cur[q] = row[q] < n ? *reinterpret_cast<const uint4 *>(D + row[q]) : make_uint4(0, 0, 0, 0);
@@ -564,33 +567,51 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                                                    : make_uint4(0, 0, 0, 0);
             uint32_t *col_tile = mine + (s - g0) * cs;
             uint32_t *gcol = cnt + ((uint64_t)kb * C + s) * PMF_TILE;
-            const uint32_t base = (uint32_t)((col_tile - tile) * 4);
+            const uint32_t base = (uint32_t)(uintptr_t)(pmf_lds_u32 *)tile + (uint32_t)((col_tile - tile) * 4);
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const uint32_t cw[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
                 const uint32_t pw[4] = {prv[q].x, prv[q].y, prv[q].z, prv[q].w};
                 const uint32_t lw[4] = {lab[q].x, lab[q].y, lab[q].z, lab[q].w};
-                if (row[q] + 16 <= n) {
+                // one range check per 16-byte group and column: bit 7 of a byte of cbad is set iff that symbol is outside
+                // the tile; the group's check as `prev` is the one it got as `cur` a column earlier
+                const uint32_t cbad = (((cw[0] + k80) | cw[0]) | ((cw[1] + k80) | cw[1]) | ((cw[2] + k80) | cw[2]) |
+                                       ((cw[3] + k80) | cw[3])) & 0x80808080u;
+                const uint32_t gbad = cbad | pbad[q];
+                pbad[q] = cbad;
+                auto fast_word = [&](int w) {
+                    uint32_t addr[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        // [x, 0, p, 0] as two u16 lanes, then 4*x + 4*AA*p + base in one dot product
+                        const uint32_t sel = 0x0C000C00u | ((4u + b) << 16) | (uint32_t)b;
+                        const uint32_t xp = __builtin_amdgcn_perm(pw[w], cw[w], sel);
+                        pmf_u16x2 v;
+                        v.x = (unsigned short)(xp & 0xFFFF);
+                        v.y = (unsigned short)(xp >> 16);
+                        addr[b] = __builtin_amdgcn_udot2(v, coef, base, false);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (HAVE_LABELS) {
+                            const uint32_t l = ((lw[w] >> (8 * b)) & 0xFF) - kb;
+                            if (l >= kt) continue;
+                            addr[b] += l * ts * 4;
+                        }
+                        // `base` holds the tile's LDS address: the sum is the operand of ds_add_u32 as it stands
+                        __hip_atomic_fetch_add((pmf_lds_u32 *)(uintptr_t)addr[b], 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                };
+                if (row[q] + 16 <= n && gbad == 0) {             // the usual case: sixteen pairs inside the tile
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) fast_word(w);
+                } else if (row[q] + 16 <= n) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const uint32_t bad = ((cw[w] + k80) | (pw[w] + k80) | cw[w] | pw[w]) & 0x80808080u;
                         if (bad == 0) {
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                // [x, 0, p, 0] as two u16 lanes, then 4*x + 4*AA*p + base in one dot product
-                                const uint32_t sel = 0x0C000C00u | ((4u + b) << 16) | (uint32_t)b;
-                                const uint32_t xp = __builtin_amdgcn_perm(pw[w], cw[w], sel);
-                                pmf_u16x2 v;
-                                v.x = (unsigned short)(xp & 0xFFFF);
-                                v.y = (unsigned short)(xp >> 16);
-                                uint32_t addr = __builtin_amdgcn_udot2(v, coef, base, false);
-                                if (HAVE_LABELS) {
-                                    const uint32_t l = ((lw[w] >> (8 * b)) & 0xFF) - kb;
-                                    if (l >= kt) continue;
-                                    addr += l * ts * 4;
-                                }
-                                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tile) + addr), 1u);
-                            }
+                            fast_word(w);
                         } else {
 #pragma unroll
                             for (int b = 0; b < 4; ++b)
@@ -608,12 +629,17 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
             }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < (g1 - g0) * cs; i += T) {
-            uint32_t v = 0;
-            for (uint32_t r = 0; r < R; ++r) v += tile[r * rs + i];
-            if (v) {
-                const uint32_t s = g0 + i / cs, l = (i % cs) / ts, e = i % ts;
-                atomicAdd(&cnt[(((uint64_t)(kb + l) * C + s) * QVZ_A + e / AA) * QVZ_A + e % AA], v);
+        // Two neighbouring counters (x even, x + 1) leave in one 64-bit atomic: a counter stays below 2^32 (n < 2^32,
+        // checked by the launcher), so the low half never carries into the high one. The global atomics of the flush
+        // are a visible share of the kernel: 1526 blocks x 150 columns x AA^2 counters at 100M reads.
+        for (uint32_t i = 2 * threadIdx.x; i < (g1 - g0) * cs; i += 2 * T) {
+            uint32_t v0 = 0, v1 = 0;
+            for (uint32_t r = 0; r < R; ++r) { v0 += tile[r * rs + i]; v1 += tile[r * rs + i + 1]; }
+            if (v0 | v1) {
+                const uint32_t s = g0 + i / cs, l = (i % cs) / ts, e = i % ts;          // AA is even: e and e + 1 share a row
+                atomicAdd(reinterpret_cast<unsigned long long *>(
+                              &cnt[(((uint64_t)(kb + l) * C + s) * QVZ_A + e / AA) * QVZ_A + e % AA]),
+                          (unsigned long long)v0 | ((unsigned long long)v1 << 32));
             }
         }
         __syncthreads();
@@ -676,17 +702,19 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
     // The walking kernel needs >= ~1000 slabs of 16384 rows to fill the chip; smaller inputs use the two-read kernel.
     const unsigned algo = env_uint("QVZ_PMF_ALGO", n >= 1000ull * 16384 ? 1 : 0);
     if (algo >= 1) {
-        // column-walking kernel: slabs of 16384*Q rows, G column tiles x R replicas in <= 80 KB (two blocks per CU)
+        // column-walking kernel: slabs of 16384*Q rows, G column tiles x R replicas of the counters in LDS
         for (uint32_t kb = 0; kb < k; kb += PMF_KT) {
             const uint32_t kt = (k - kb) < PMF_KT ? (k - kb) : PMF_KT;
             const size_t tile_bytes = (size_t)kt * AA * AA * sizeof(uint32_t);
-            const size_t budget = tile_bytes * 2 + 4 <= lds_budget / 2 ? lds_budget / 2 : lds_budget;
+            // The kernel's ~96 VGPRs leave room for one 1024-thread block per CU, so a block may use the whole LDS.
+            // Measured (tools/tune_pmf2.py, 100M x 150, 42 symbols): G = 3 column tiles x R = 5 replicas is the best
+            // (4.30 ms; R = 5, G = 2: 4.43; R = 3, G = 3: 4.59; more than 5 replicas buy nothing).
             unsigned R = env_uint("QVZ_PMF_R", 0), G = env_uint("QVZ_PMF_G", 0);
-            // measured (tools/tune_pmf2.py, 100M x 150): replicas stop paying beyond ~5, G = 2..3 column tiles are enough
-            if (G == 0) G = 2 * tile_bytes + 4 <= budget ? 2 : 1;
+            if (G == 0) G = 3;
             if (R == 0) {
-                R = (unsigned)(budget / (G * tile_bytes + 4));
+                R = (unsigned)(lds_budget / (G * tile_bytes + 4));
                 if (R > 5) R = 5;
+                if (R < 1) R = 1;
             }
             if (G < 1) G = 1;
             if (G > c) G = c;
@@ -695,7 +723,7 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
             const size_t lds = (size_t)R * (G * tile_bytes + 4);
             unsigned Q = env_uint("QVZ_PMF_Q", 0);
             if (Q == 0) Q = n >= 768ull * 65536 ? 4 : (n >= 768ull * 32768 ? 2 : 1);
-            const uint64_t slab = 16384ull * Q;
+            const uint64_t slab = (uint64_t)PMF_WALK_T * 16 * Q;
             dim3 grid((unsigned)((n + slab - 1) / slab));
 #define LAUNCH_WALK(LBL, QQ)                                                                                           \
     do {                                                                                                               \

@@ -159,6 +159,21 @@ def test_pmf_full_alphabet_and_fixture(K):
     np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ph["cnt"])
 
 
+@pytest.mark.parametrize("aa", [0, 20, 50, 72])
+def test_pmf_kernel_variants_agree(K, aa, monkeypatch):
+    """The two PMF kernels (two reads per symbol; column walk) count the same pairs, with a tile hint smaller than the
+    alphabet (symbols beyond it take the global-atomic path) and a ragged last group."""
+    n, c = 70001, 12
+    rows = O.qgen1_rows(11, n, c)
+    ref = O.stats(rows, np.zeros(n, np.uint8), 1)
+    sym = upload_sym(K, rows)
+    monkeypatch.setenv("QVZ_PMF_AA", str(aa))
+    for algo in ("0", "1"):
+        monkeypatch.setenv("QVZ_PMF_ALGO", algo)
+        cnt = K.pmf_hist(sym, n)
+        np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ref, err_msg=f"algo={algo}")
+
+
 def test_pmf_accumulates_across_calls(K):
     """Counters are += : two shards of reads give the single-pass counts (the multi-GPU reduction relies on it)."""
     rows = O.qgen1_rows(8, 9000, 25)
@@ -327,8 +342,10 @@ def test_quantize_reports_undefined_context(K):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json shapes: properties that do not need the oracle to finish at this size
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,c", [(10_000_000, 150)])
-def test_full_size_pmf_properties(K, n, c):
+@pytest.mark.parametrize("n,c,algo", [(10_000_000, 150, ""), (10_000_000, 150, "1")])
+def test_full_size_pmf_properties(K, n, c, algo, monkeypatch):
+    if algo:
+        monkeypatch.setenv("QVZ_PMF_ALGO", algo)          # the walking kernels bench.py's 100M reads select
     sym = K.qgen1(2, n, c)
     cnt = K.pmf_hist(sym, n).to(torch.int64)[0]          # (c, 72, 72)
     per_col = cnt.sum(dim=(1, 2))
