@@ -722,7 +722,9 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
             while (G > 1 && (size_t)R * (G * tile_bytes + 4) > lds_budget) G -= 1;
             const size_t lds = (size_t)R * (G * tile_bytes + 4);
             unsigned Q = env_uint("QVZ_PMF_Q", 0);
-            if (Q == 0) Q = n >= 768ull * 65536 ? 4 : (n >= 768ull * 32768 ? 2 : 1);
+            // bigger slabs = fewer blocks = fewer flush atomics; six groups per thread is what 128 VGPRs hold (k = 1)
+            if (Q == 0) Q = (k == 1 && n >= 768ull * 98304) ? 6 : n >= 768ull * 65536 ? 4 : (n >= 768ull * 32768 ? 2 : 1);
+            if (Q != 1 && Q != 2 && Q != 4 && !(Q == 6 && k == 1)) Q = 4;
             const uint64_t slab = (uint64_t)PMF_WALK_T * 16 * Q;
             dim3 grid((unsigned)((n + slab - 1) / slab));
 #define LAUNCH_WALK(LBL, QQ)                                                                                           \
@@ -734,9 +736,9 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
                            R, AA, G, d_cnt);                                                                           \
     } while (0)
             if (k == 1) {
-                if (Q == 4) LAUNCH_WALK(false, 4); else if (Q == 2) LAUNCH_WALK(false, 2); else LAUNCH_WALK(false, 1);
+                if (Q == 6) LAUNCH_WALK(false, 6); else if (Q >= 4) LAUNCH_WALK(false, 4); else if (Q == 2) LAUNCH_WALK(false, 2); else LAUNCH_WALK(false, 1);
             } else {
-                if (Q == 4) LAUNCH_WALK(true, 4); else if (Q == 2) LAUNCH_WALK(true, 2); else LAUNCH_WALK(true, 1);
+                if (Q >= 4) LAUNCH_WALK(true, 4); else if (Q == 2) LAUNCH_WALK(true, 2); else LAUNCH_WALK(true, 1);
             }
 #undef LAUNCH_WALK
             QVZ_HIP_CHECK(hipGetLastError());

@@ -168,10 +168,11 @@ def test_pmf_kernel_variants_agree(K, aa, monkeypatch):
     ref = O.stats(rows, np.zeros(n, np.uint8), 1)
     sym = upload_sym(K, rows)
     monkeypatch.setenv("QVZ_PMF_AA", str(aa))
-    for algo in ("0", "1"):
+    for algo, q in (("0", "0"), ("1", "0"), ("1", "4"), ("1", "6")):
         monkeypatch.setenv("QVZ_PMF_ALGO", algo)
+        monkeypatch.setenv("QVZ_PMF_Q", q)                 # 16-byte groups per thread of the walking kernel (0 = by size)
         cnt = K.pmf_hist(sym, n)
-        np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ref, err_msg=f"algo={algo}")
+        np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ref, err_msg=f"algo={algo} Q={q}")
 
 
 def test_pmf_accumulates_across_calls(K):
@@ -345,7 +346,8 @@ def test_quantize_reports_undefined_context(K):
 @pytest.mark.parametrize("n,c,algo", [(10_000_000, 150, ""), (10_000_000, 150, "1")])
 def test_full_size_pmf_properties(K, n, c, algo, monkeypatch):
     if algo:
-        monkeypatch.setenv("QVZ_PMF_ALGO", algo)          # the walking kernels bench.py's 100M reads select
+        monkeypatch.setenv("QVZ_PMF_ALGO", algo)          # the walking kernel with six groups per thread, as bench.py's
+        monkeypatch.setenv("QVZ_PMF_Q", "6")              # 100M reads select it
     sym = K.qgen1(2, n, c)
     cnt = K.pmf_hist(sym, n).to(torch.int64)[0]          # (c, 72, 72)
     per_col = cnt.sum(dim=(1, 2))
