@@ -1151,8 +1151,8 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
 // symbol: 64 lanes, 64 addresses - the texture path takes ~47 cycles per such instruction (measured: 0.68 symbols
 // per cycle and CU, 26 % of the HBM peak). Here a 512-thread workgroup (2048 reads) copies column s+1's tables
 // (ct 144 B + qs 20 736 B per cluster, 16-byte loads that hit L2) into the other half of a double buffer while it
-// quantizes column s out of LDS (ds_read_u16 gathers), one barrier per column; three workgroups share a CU so that
-// one's barrier wait is another's work. The copy costs 10 B per symbol of L2 traffic. It needs a distortion matrix
+// quantizes column s out of LDS (ds_read_u16 gathers), one barrier per column; two or three workgroups share a CU (eight or four reads
+// per thread) so that one's barrier wait is another's work. The copy costs 10 B per symbol of L2 traffic. It needs a distortion matrix
 // that depends on |x - y| only (all of the reference's -d choices, distortion.c:50-95): 72 doubles in LDS instead of
 // 72 x 72. With three clusters one buffer and two barriers per column; otherwise (more clusters, or a general
 // matrix) k_quantize.
