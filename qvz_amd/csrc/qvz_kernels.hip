@@ -723,7 +723,8 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
             const size_t lds = (size_t)R * (G * tile_bytes + 4);
             unsigned Q = env_uint("QVZ_PMF_Q", 0);
             // bigger slabs = fewer blocks = fewer flush atomics; six groups per thread is what 128 VGPRs hold (k = 1)
-            if (Q == 0) Q = (k == 1 && n >= 768ull * 98304) ? 6 : n >= 768ull * 65536 ? 4 : (n >= 768ull * 32768 ? 2 : 1);
+            // with labels (k > 1) two groups: four spill (measured at 100M x 150, k = 3: 16.9 ms against 7.2)
+            if (Q == 0) Q = (k == 1 && n >= 768ull * 98304) ? 6 : (k == 1 && n >= 768ull * 65536) ? 4 : (n >= 768ull * 32768 ? 2 : 1);
             if (Q != 1 && Q != 2 && Q != 4 && !(Q == 6 && k == 1)) Q = 4;
             const uint64_t slab = (uint64_t)PMF_WALK_T * 16 * Q;
             dim3 grid((unsigned)((n + slab - 1) / slab));
