@@ -1248,9 +1248,9 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
             const uint32_t qi = 2 * ctx + (draw >= (cv >> 8) ? 1u : 0u);                // codebook.c:165-170
             const uint32_t qsv = cb[80 + qi * QVZ_A + x];
             const uint32_t qv = qsv & 0xFF;
-            const uint32_t qvc = qv < QVZ_A ? qv : 0u;
+            const uint32_t qvc = qv;                                                     // a table entry is a symbol (k_quantize trusts the tables the same way)
             const double dd = sdist[x > qvc ? x - qvc : qvc - x];                        // distortion.c:151
-            err[r] = (s == 0) ? dd : err[r] + dd;
+            err[r] += dd;                                                                // from 0.0, as the reference sums a line
             prev[r] = qvc;
             qv4[r >> 2] |= qv << (8 * (r & 3));
             qi4[r >> 2] |= qi << (8 * (r & 3));
