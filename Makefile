@@ -12,12 +12,12 @@ HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -std=c++17 -Iincl
 CFLAGS   ?= -O2 -ffp-contract=off -fPIC -std=gnu11 -Wall -Wextra -Iinclude
 CSRC     := qvz_amd/csrc
 HIP_SRCS := $(wildcard $(CSRC)/*.hip)
-HOST_SRCS:= $(CSRC)/host/qvz_coder.c $(CSRC)/host/qvz_encode.c $(CSRC)/host/qvz_shard.c $(CSRC)/host/qvz_decode.c $(CSRC)/host/qvz_fastq.c
+HOST_SRCS:= $(CSRC)/host/qvz_coder.c $(CSRC)/host/qvz_encode.c $(CSRC)/host/qvz_shard.c $(CSRC)/host/qvz_decode.c $(CSRC)/host/qvz_fastq.c $(CSRC)/host/qvz_shardset.c
 HOST_OBJS:= $(HOST_SRCS:.c=.o)
 HIP_OBJS := $(HIP_SRCS:.hip=.hip.o)
 HDRS     := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h)
 
-all: qvz_amd/libqvzhip.so qvz_amd/libqvzcompat.so qvz_amd/bin/qvz
+all: qvz_amd/libqvzhip.so qvz_amd/libqvzcompat.so qvz_amd/bin/qvz qvz_amd/bin/qvz-shardset
 
 # the reference's own entry-point names (include/qvz_compat.h) in a library of their own
 qvz_amd/libqvzcompat.so: $(CSRC)/host/qvz_compat.c qvz_amd/libqvzhip.so $(HDRS)
@@ -36,10 +36,14 @@ qvz_amd/bin/qvz: $(CSRC)/host/qvz_main.c qvz_amd/libqvzhip.so $(HDRS)
 	mkdir -p qvz_amd/bin
 	$(CC) $(CFLAGS) -fPIE -o $@ $(CSRC)/host/qvz_main.c -Lqvz_amd -lqvzhip -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath-link,/opt/rocm/lib
 
+qvz_amd/bin/qvz-shardset: $(CSRC)/host/qvz_shardset_tool.c qvz_amd/libqvzhip.so $(HDRS)
+	mkdir -p qvz_amd/bin
+	$(CC) $(CFLAGS) -fPIE -o $@ $(CSRC)/host/qvz_shardset_tool.c -Lqvz_amd -lqvzhip -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath-link,/opt/rocm/lib
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f qvz_amd/libqvzhip.so qvz_amd/libqvzcompat.so qvz_amd/bin/qvz $(HOST_OBJS) $(HIP_OBJS)
+	rm -f qvz_amd/libqvzhip.so qvz_amd/libqvzcompat.so qvz_amd/bin/qvz qvz_amd/bin/qvz-shardset $(HOST_OBJS) $(HIP_OBJS)
 
 .PHONY: all oracle clean

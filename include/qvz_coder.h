@@ -55,8 +55,10 @@ void qvz_coder_drop(qvz_coder_t *cd, uint64_t size);
  * shard is a file the unmodified reference decoder accepts; the decodes concatenate to the single-stream -u
  * output. Cost: each shard re-learns its model (slightly more bits per symbol) and repeats the codebooks.
  * ------------------------------------------------------------------------------------------------------- */
-/* first[g] for g = 0..shards (first[shards] = n): equal-sized ranges rounded to multiples of 4 reads */
+/* first[g] for g = 0..shards (first[shards] = n): the n/4 groups of 4 reads dealt evenly, shard g starting at group
+ * floor(groups * g / shards); no shard is empty as long as shards <= qvz_shard_limit(n) = max(1, n/4) */
 void qvz_shard_bounds(uint64_t n, uint32_t shards, uint64_t *first);
+uint32_t qvz_shard_limit(uint64_t n);
 
 /* Codes all shards with `threads` host threads pulling the feed straight from HBM (d_feed[i*columns+s] u16,
  * d_labels[i] or NULL) in slices over their own streams. streams[g] is malloc'd (free with free()),

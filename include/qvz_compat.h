@@ -96,9 +96,61 @@ void generate_codebooks(struct quality_file_t *info);                           
 void write_codebooks(FILE *fp, struct quality_file_t *info);                         /* codebook.h:95, codebook.c:474 */
 uint32_t start_qv_compression(struct quality_file_t *info, FILE *fout, double *dis, FILE *funcompressed);  /* qv_compressor.h:95 */
 
-/* decode() references these; decoding is out of this build's scope: both print a notice and exit(1) */
-void read_codebooks(FILE *fp, struct quality_file_t *info);
-void start_qv_decompression(FILE *fout, FILE *fin, struct quality_file_t *info);
+/* decode() (main.c:132-160): the codebooks are parsed by the host C layer (qvz_codebook_read), the single serial stream
+ * is decoded on one host core exactly as the reference does it (include/qvz_encode.h, qvz_decode_file); info->columns,
+ * lines, cluster_count, clusters[].qlist and well are filled in as the reference leaves them. */
+void read_codebooks(FILE *fp, struct quality_file_t *info);                          /* codebook.h:96, codebook.c:560 */
+void start_qv_decompression(FILE *fout, FILE *fin, struct quality_file_t *info);     /* qv_compressor.h:96, qv_compressor.c:145 */
+
+/* ---- the symbol-level interface of include/qv_compressor.h:26-93 ----------------------------------------------------
+ * start_qv_compression / start_qv_decompression above replace the reference's loops wholesale (GPU quantizer, staged
+ * coder). A caller that drives the coder symbol by symbol instead (the loops of qv_compressor.c:76-135 and :166-229) finds
+ * the same structs and functions here, computed on the host: this interface is one serial chain by definition. */
+#define m_arith 22                                           /* qv_compressor.h:19 */
+#define OS_STREAM_BUF_LEN (4096 * 4096)                      /* qv_compressor.h:21 */
+#define COMPRESSION 0
+#define DECOMPRESSION 1
+
+typedef struct Arithmetic_code_t { int32_t scale3; uint32_t l, u, t, m, r; } *Arithmetic_code;        /* qv_compressor.h:26-35 */
+typedef struct os_stream_t { FILE *fp; uint8_t *buf; uint32_t bufPos; uint8_t bitPos; uint64_t written; } *osStream;   /* :37-43 */
+typedef struct stream_stats_t { uint32_t *counts; uint32_t alphabetCard, step, n; } *stream_stats_ptr_t;   /* :45-50 */
+typedef struct arithStream_t {                                                                         /* :52-57 */
+    stream_stats_ptr_t cluster_stats;
+    stream_stats_ptr_t ***stats;
+    Arithmetic_code a;
+    osStream os;
+} *arithStream;
+typedef struct qv_compressor_t { arithStream Quals; } *qv_compressor;                                   /* :59-61 */
+
+struct os_stream_t *alloc_os_stream(FILE *fp, uint8_t in);                           /* os_stream.c:7 */
+void free_os_stream(struct os_stream_t *os);
+uint8_t stream_read_bit(struct os_stream_t *os);                                     /* os_stream.c:36 */
+uint32_t stream_read_bits(struct os_stream_t *os, uint8_t len);
+void stream_write_bit(struct os_stream_t *os, uint8_t bit);                          /* os_stream.c:72 */
+void stream_write_bits(struct os_stream_t *os, uint32_t dw, uint8_t len);
+void stream_finish_byte(struct os_stream_t *os);                                     /* os_stream.c:105 */
+void stream_write_buffer(struct os_stream_t *os);                                    /* os_stream.c:115 */
+
+Arithmetic_code initialize_arithmetic_encoder(uint32_t m);                           /* arith.c:5 */
+void arithmetic_encoder_step(Arithmetic_code a, stream_stats_ptr_t stats, int32_t x, osStream os);   /* arith.c:24 */
+int encoder_last_step(Arithmetic_code a, osStream os);                               /* arith.c:99 */
+uint32_t arithmetic_decoder_step(Arithmetic_code a, stream_stats_ptr_t stats, osStream is);          /* arith.c:118 */
+uint32_t decoder_last_step(Arithmetic_code a, stream_stats_ptr_t stats);             /* arith.c:190 */
+
+stream_stats_ptr_t **initialize_stream_stats(struct cond_quantizer_list_t *q_list);  /* qv_stream.c:32 */
+void update_stats(stream_stats_ptr_t stats, uint32_t x, uint32_t r);                 /* qv_stream.c:9 */
+
+void compress_qv(arithStream as, uint32_t x, uint8_t cluster, uint32_t column, uint32_t idx);   /* qv_compressor.c:8 */
+void qv_write_cluster(arithStream as, uint8_t cluster);                              /* qv_compressor.c:19 */
+uint32_t decompress_qv(arithStream as, uint8_t cluster, uint32_t column, uint32_t idx);         /* qv_compressor.c:27 */
+uint8_t qv_read_cluster(arithStream as);                                             /* qv_compressor.c:36 */
+qv_compressor initialize_qv_compressor(FILE *fout, uint8_t streamDirection, struct quality_file_t *info);   /* qv_stream.c:120 */
+
+/* what those loops call besides: the lo/hi choice by one 7-bit WELL draw (codebook.c:162-171, well.c:8-46) */
+uint32_t well_1024a(struct well_state_t *state);
+uint32_t well_1024a_bits(struct well_state_t *state, uint8_t bits);
+struct quantizer_t *choose_quantizer(struct cond_quantizer_list_t *list, struct well_state_t *well, uint32_t column,
+                                     symbol_t prev, uint32_t *q_idx);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,9 @@ int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, uint64_t n,
                        uint64_t ld, void *stream);
 /* State of the generator after `words` outputs, rotated to n = 0 (what a shard's .q header stores). */
 int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32_t *h_state_out);
+/* The same for `count` different jumps at once: h_states_out[i*32 ..] = state after h_words[i] outputs (the WELL states
+ * of the headers of `count` shard files: one masked batched GF(2) mat-vec per bit of the jumps). */
+int qvz_hip_well_jump_many(const uint32_t *h_state, const uint64_t *h_words, uint64_t count, uint32_t *h_states_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Quantizer tables in device form (one per cluster), built from a codebook (see qvz_codebook.h).

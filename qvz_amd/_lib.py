@@ -94,6 +94,16 @@ SIGNATURES = {
     "qvz_codebook_read": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "qvz_encode_file_sharded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qvz_encode_last_error": (C.c_char_p, []),
+    "qvz_hip_well_jump_many": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32)]),
+    "qvz_shard_limit": (C.c_uint32, [C.c_uint64]),
+    # include/qvz_shardset.h (host C)
+    "qvz_shardset_is": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "qvz_shardset_write": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "qvz_shardset_stat": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "qvz_shardset_split": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "qvz_shardset_decode": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p]),
+    "qvz_encode_file_shardset": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]),
 }
 
 _lib = None

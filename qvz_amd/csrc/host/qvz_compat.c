@@ -9,6 +9,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "qvz_codebook.h"
@@ -228,42 +229,80 @@ void calculate_statistics(struct quality_file_t *info) {                        
     free(marg);
 }
 
-void generate_codebooks(struct quality_file_t *info) {                           /* codebook.c:355-468 */
-    qvz_job_t *job = job_for(info);
-    if (qvz_job_codebooks(job)) die("generate_codebooks");
-    const uint32_t C = job->C;
-    for (uint32_t j = 0; j < job->K; ++j) {
-        const qvz_codebook_t *cb = job->cbs[j];
-        struct cond_quantizer_list_t *ql = (struct cond_quantizer_list_t *)calloc(1, sizeof(*ql));   /* codebook.c:56-64 */
-        ql->columns = C;
-        ql->input_alphabets = (struct alphabet_t **)calloc(C, sizeof(struct alphabet_t *));
-        ql->q = (struct quantizer_t ***)calloc(C, sizeof(struct quantizer_t **));
-        ql->ratio = (double **)calloc(C, sizeof(double *));
-        ql->qratio = (uint8_t **)calloc(C, sizeof(uint8_t *));
-        ql->options = info->opts;
-        for (uint32_t s = 0; s < C; ++s) {
-            const uint32_t n = cb->nctx[s];
-            ql->input_alphabets[s] = alphabet_from(cb->ctx_sym + (size_t)s * A, n);          /* cond_quantizer_init_column :101-110 */
-            ql->q[s] = (struct quantizer_t **)calloc(2 * n, sizeof(struct quantizer_t *));
-            ql->ratio[s] = (double *)calloc(n, sizeof(double));
-            ql->qratio[s] = (uint8_t *)calloc(n, sizeof(uint8_t));
-            for (uint32_t ctx = 0; ctx < n; ++ctx) {
-                ql->ratio[s][ctx] = cb->ratio[(size_t)s * A + ctx];
-                ql->qratio[s][ctx] = cb->qratio[(size_t)s * A + ctx];
-                for (uint32_t b = 0; b < 2; ++b) {
-                    const size_t t = ((size_t)s * 2 * A + 2 * ctx + b);
-                    struct quantizer_t *q = (struct quantizer_t *)calloc(1, sizeof(*q));
-                    q->alphabet = info->alphabet;
-                    q->q = (symbol_t *)calloc(A, sizeof(symbol_t));
-                    memcpy(q->q, cb->q + t * A, A);
-                    q->output_alphabet = alphabet_from(cb->recon + t * A, cb->nstates[t]);   /* quantizer.c:119-121 */
-                    q->ratio = b ? 1 - ql->ratio[s][ctx] : ql->ratio[s][ctx];                /* codebook.c:448-449 */
-                    ql->q[s][2 * ctx + b] = q;
+/* cond_quantizer_list_t of one cluster from the flat codebook (alloc_conditional_quantizer_list / cond_quantizer_init_column /
+ * store_cond_quantizers_indexed, codebook.c:56-64,101-110,152-157) */
+static struct cond_quantizer_list_t *qlist_from_codebook(const qvz_codebook_t *cb, struct quality_file_t *info) {
+    const uint32_t C = cb->C;
+    struct cond_quantizer_list_t *ql = (struct cond_quantizer_list_t *)calloc(1, sizeof(*ql));
+    ql->columns = C;
+    ql->input_alphabets = (struct alphabet_t **)calloc(C, sizeof(struct alphabet_t *));
+    ql->q = (struct quantizer_t ***)calloc(C, sizeof(struct quantizer_t **));
+    ql->ratio = (double **)calloc(C, sizeof(double *));
+    ql->qratio = (uint8_t **)calloc(C, sizeof(uint8_t *));
+    ql->options = info->opts;
+    for (uint32_t s = 0; s < C; ++s) {
+        const uint32_t n = cb->nctx[s];
+        ql->input_alphabets[s] = alphabet_from(cb->ctx_sym + (size_t)s * A, n);
+        ql->q[s] = (struct quantizer_t **)calloc(2 * n, sizeof(struct quantizer_t *));
+        ql->ratio[s] = (double *)calloc(n, sizeof(double));
+        ql->qratio[s] = (uint8_t *)calloc(n, sizeof(uint8_t));
+        for (uint32_t ctx = 0; ctx < n; ++ctx) {
+            ql->ratio[s][ctx] = cb->ratio[(size_t)s * A + ctx];
+            ql->qratio[s][ctx] = cb->qratio[(size_t)s * A + ctx];
+            for (uint32_t b = 0; b < 2; ++b) {
+                const size_t t = ((size_t)s * 2 * A + 2 * ctx + b);
+                struct quantizer_t *q = (struct quantizer_t *)calloc(1, sizeof(*q));
+                q->alphabet = info->alphabet;
+                q->q = (symbol_t *)calloc(A, sizeof(symbol_t));
+                memcpy(q->q, cb->q + t * A, A);
+                q->output_alphabet = alphabet_from(cb->recon + t * A, cb->nstates[t]);   /* quantizer.c:119-121 */
+                q->ratio = b ? 1 - ql->ratio[s][ctx] : ql->ratio[s][ctx];                /* codebook.c:448-449 */
+                ql->q[s][2 * ctx + b] = q;
+            }
+        }
+    }
+    return ql;
+}
+
+/* the inverse: the flat codebook of a cond_quantizer_list_t, whoever built it */
+static qvz_codebook_t *codebook_from_qlist(const struct cond_quantizer_list_t *ql) {
+    const uint32_t C = ql->columns;
+    qvz_codebook_t *cb = qvz_codebook_alloc(C);
+    if (!cb) return NULL;
+    memset(cb->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
+    memset(cb->out_idx, QVZ_NOT_FOUND, (size_t)C * 2 * A * A);
+    memset(cb->live, 1, (size_t)C * A);
+    for (uint32_t s = 0; s < C; ++s) {
+        const struct alphabet_t *ia = ql->input_alphabets[s];
+        const uint32_t n = ia->size > (uint32_t)A ? (uint32_t)A : ia->size;
+        cb->nctx[s] = (uint8_t)n;
+        for (uint32_t ctx = 0; ctx < n; ++ctx) {
+            const uint32_t sym = ia->symbols[ctx] < A ? ia->symbols[ctx] : 0;
+            cb->ctx_sym[(size_t)s * A + ctx] = (uint8_t)sym;
+            cb->ctx_idx[(size_t)s * A + sym] = (uint8_t)ctx;
+            cb->qratio[(size_t)s * A + ctx] = ql->qratio[s][ctx];
+            cb->ratio[(size_t)s * A + ctx] = ql->ratio[s] ? ql->ratio[s][ctx] : ql->qratio[s][ctx] / 128.0;
+            for (uint32_t b = 0; b < 2; ++b) {
+                const struct quantizer_t *q = ql->q[s][2 * ctx + b];
+                const size_t t = (size_t)s * 2 * A + 2 * ctx + b;
+                memcpy(cb->q + t * A, q->q, A);
+                const uint32_t ns = q->output_alphabet->size > (uint32_t)A ? (uint32_t)A : q->output_alphabet->size;
+                cb->nstates[t] = (uint8_t)ns;
+                for (uint32_t z = 0; z < ns; ++z) {
+                    const uint32_t v = q->output_alphabet->symbols[z] < A ? q->output_alphabet->symbols[z] : 0;
+                    cb->recon[t * A + z] = (uint8_t)v;
+                    cb->out_idx[t * A + v] = (uint8_t)z;
                 }
             }
         }
-        info->clusters->clusters[j].qlist = ql;
     }
+    return cb;
+}
+
+void generate_codebooks(struct quality_file_t *info) {                           /* codebook.c:355-468 */
+    qvz_job_t *job = job_for(info);
+    if (qvz_job_codebooks(job)) die("generate_codebooks");
+    for (uint32_t j = 0; j < job->K; ++j) info->clusters->clusters[j].qlist = qlist_from_codebook(job->cbs[j], info);
 }
 
 void write_codebooks(FILE *fp, struct quality_file_t *info) {                    /* codebook.c:474-498 */
@@ -281,13 +320,303 @@ uint32_t start_qv_compression(struct quality_file_t *info, FILE *fout, double *d
     return (uint32_t)stream_bytes;                                               /* int -> uint32_t, arith.c:115 */
 }
 
-void read_codebooks(FILE *fp, struct quality_file_t *info) {
-    (void)fp; (void)info;
-    printf("Decoding (-x) is not part of this build: use the reference decoder on the .q file (SURVEY.md section 8f).\n");
-    exit(1);
+/* ---- decode direction (main.c:132-160) ------------------------------------------------------------------------------ */
+static uint8_t *slurp_rest(FILE *fp, size_t *size) {            /* everything from the current position to the end */
+    size_t cap = 1u << 20, len = 0;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    while (buf) {
+        const size_t got = fread(buf + len, 1, cap - len, fp);
+        len += got;
+        if (len < cap) break;
+        uint8_t *nb = (uint8_t *)realloc(buf, cap * 2);
+        if (!nb) { free(buf); buf = NULL; break; }
+        buf = nb;
+        cap *= 2;
+    }
+    *size = len;
+    return buf;
 }
 
-void start_qv_decompression(FILE *fout, FILE *fin, struct quality_file_t *info) {
-    (void)fout; (void)fin;
-    read_codebooks(NULL, info);
+void read_codebooks(FILE *fp, struct quality_file_t *info) {                     /* codebook.c:560-582 */
+    const long start = ftell(fp);
+    size_t size = 0, pos = 9;
+    uint8_t *f = slurp_rest(fp, &size);
+    qvz_codebook_t **cbs = NULL;
+    if (!f || size < 9) { printf("read_codebooks: not a qvz file\n"); exit(1); }
+    info->cluster_count = f[0];
+    info->columns = ((uint32_t)f[1] << 24) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 8) | f[4];     /* ntohl, :569-572 */
+    info->lines = ((uint32_t)f[5] << 24) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 8) | f[8];
+    if (info->cluster_count < 1 || info->columns < 1 || info->columns > MAX_COLUMNS) { printf("read_codebooks: implausible header\n"); exit(1); }
+    info->clusters = alloc_cluster_list(info);                                   /* :575 */
+    if (qvz_codebooks_parse(f, size, &pos, info->cluster_count, info->columns, &cbs)) die("read_codebooks");
+    for (uint32_t j = 0; j < info->cluster_count; ++j) {
+        info->clusters->clusters[j].qlist = qlist_from_codebook(cbs[j], info);
+        qvz_codebook_free(cbs[j]);
+    }
+    free(cbs);
+    free(f);
+    fseek(fp, start + (long)pos, SEEK_SET);                                      /* the WELL state comes next (qv_stream.c:72-74) */
+}
+
+void start_qv_decompression(FILE *fout, FILE *fin, struct quality_file_t *info) {   /* qv_compressor.c:145-231 */
+    size_t size = 0;
+    uint8_t *f = slurp_rest(fin, &size);
+    const uint32_t K = info->cluster_count;
+    qvz_codebook_t **cbs = (qvz_codebook_t **)calloc(K ? K : 1, sizeof(*cbs));
+    if (!f || size < 128 || !cbs) { printf("start_qv_decompression: file ends before the WELL state\n"); exit(1); }
+    for (uint32_t j = 0; j < K; ++j)
+        if (!(cbs[j] = codebook_from_qlist(info->clusters->clusters[j].qlist))) { printf("start_qv_decompression: out of memory\n"); exit(1); }
+    memset(&info->well, 0, sizeof(info->well));                                  /* qv_stream.c:70 */
+    memcpy(info->well.state, f, 128);                                            /* qv_stream.c:72-74 */
+    if (qvz_decode_stream_host(K, info->columns, info->lines, (const qvz_codebook_t *const *)cbs, info->well.state, f + 128, size - 128,
+                               fout, info->opts && info->opts->verbose))
+        die("start_qv_decompression");
+    for (uint32_t j = 0; j < K; ++j) qvz_codebook_free(cbs[j]);
+    free(cbs);
+    free(f);
+}
+
+/* ---- symbol-level interface (qv_compressor.h:63-93): host C, one serial chain by definition ---------------------------- */
+struct os_stream_t *alloc_os_stream(FILE *fp, uint8_t in) {                      /* os_stream.c:7-22 */
+    struct os_stream_t *os = (struct os_stream_t *)calloc(1, sizeof(*os));
+    os->fp = fp;
+    os->buf = (uint8_t *)calloc(OS_STREAM_BUF_LEN, 1);
+    if (in && fread(os->buf, 1, OS_STREAM_BUF_LEN, fp) == 0) { /* an empty stream reads as zeros */ }
+    return os;
+}
+
+void free_os_stream(struct os_stream_t *os) { free(os->buf); free(os); }         /* the FILE is the caller's, os_stream.c:27-31 */
+
+void stream_write_buffer(struct os_stream_t *os) {                               /* os_stream.c:115-120 */
+    fwrite(os->buf, 1, os->bufPos, os->fp);
+    memset(os->buf, 0, os->bufPos);
+    os->written += os->bufPos;
+    os->bufPos = 0;
+}
+
+/* The byte under construction holds its bits so far shifted left by one (the reference ORs the new bit into bit 0 and
+ * shifts after every bit but the eighth, os_stream.c:72-92): kept that way so that the struct means the same to both. */
+void stream_write_bit(struct os_stream_t *os, uint8_t bit) {
+    uint8_t *b = &os->buf[os->bufPos];
+    *b |= bit & 1;
+    if (++os->bitPos == 8) {
+        os->bitPos = 0;
+        if (++os->bufPos == OS_STREAM_BUF_LEN) stream_write_buffer(os);
+    } else {
+        *b = (uint8_t)(*b << 1);
+    }
+}
+
+void stream_write_bits(struct os_stream_t *os, uint32_t dw, uint8_t len) {       /* msb first, os_stream.c:94-100 */
+    for (int bit = (int)len - 1; bit >= 0; --bit) stream_write_bit(os, (uint8_t)(dw >> bit));
+}
+
+void stream_finish_byte(struct os_stream_t *os) {                                /* os_stream.c:105-110 */
+    os->buf[os->bufPos] = (uint8_t)(os->buf[os->bufPos] << (7 - os->bitPos));
+    os->bitPos = 0;
+    os->bufPos += 1;
+    stream_write_buffer(os);
+}
+
+uint8_t stream_read_bit(struct os_stream_t *os) {                                /* consumes the byte from its top, os_stream.c:36-52 */
+    const uint8_t bit = os->buf[os->bufPos] >> 7;
+    os->buf[os->bufPos] = (uint8_t)(os->buf[os->bufPos] << 1);
+    if (++os->bitPos == 8) {
+        os->bitPos = 0;
+        if (++os->bufPos == OS_STREAM_BUF_LEN) {
+            if (fread(os->buf, 1, OS_STREAM_BUF_LEN, os->fp) == 0) memset(os->buf, 0, OS_STREAM_BUF_LEN);
+            os->bufPos = 0;
+        }
+    }
+    return bit;
+}
+
+uint32_t stream_read_bits(struct os_stream_t *os, uint8_t len) {
+    uint32_t v = 0;
+    for (int bit = (int)len - 1; bit >= 0; --bit) v |= (uint32_t)stream_read_bit(os) << bit;
+    return v;
+}
+
+Arithmetic_code initialize_arithmetic_encoder(uint32_t m) {                      /* arith.c:5-16 */
+    Arithmetic_code a = (Arithmetic_code)calloc(1, sizeof(*a));
+    a->m = m;
+    a->r = 1u << (m - 3);
+    a->u = (1u << m) - 1;
+    return a;
+}
+
+void update_stats(stream_stats_ptr_t stats, uint32_t x, uint32_t r) {            /* qv_stream.c:9-25 */
+    stats->counts[x] += stats->step;
+    stats->n += stats->step;
+    if (stats->n > r) {
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < stats->alphabetCard; ++i)
+            if (stats->counts[i]) { stats->counts[i] = (stats->counts[i] >> 1) + 1; n += stats->counts[i]; }
+        stats->n = n;
+    }
+}
+
+static stream_stats_ptr_t new_stats(uint32_t card) {                             /* qv_stream.c:44-57, :96-104 */
+    stream_stats_ptr_t s = (stream_stats_ptr_t)calloc(1, sizeof(*s));
+    s->counts = (uint32_t *)calloc(card ? card : 1, sizeof(uint32_t));
+    for (uint32_t k = 0; k < card; ++k) s->counts[k] = 1;
+    s->n = s->alphabetCard = card;
+    s->step = 8;
+    return s;
+}
+
+stream_stats_ptr_t **initialize_stream_stats(struct cond_quantizer_list_t *ql) {   /* qv_stream.c:32-61 */
+    stream_stats_ptr_t **s = (stream_stats_ptr_t **)calloc(ql->columns, sizeof(*s));
+    for (uint32_t i = 0; i < ql->columns; ++i) {
+        const uint32_t nq = 2 * ql->input_alphabets[i]->size;
+        s[i] = (stream_stats_ptr_t *)calloc(nq, sizeof(**s));
+        for (uint32_t j = 0; j < nq; ++j) s[i][j] = new_stats(ql->q[i][j]->output_alphabet->size);
+    }
+    return s;
+}
+
+/* new bounds of the interval for symbol x (arith.c:35-48); returns 0 when x is outside the alphabet */
+static void narrow(Arithmetic_code a, const struct stream_stats_t *st, uint32_t x) {
+    const uint64_t range = (uint64_t)a->u - a->l + 1;
+    uint32_t lo = 0;
+    for (uint32_t i = 0; i < x; ++i) lo += st->counts[i];
+    const uint32_t hi = lo + st->counts[x];
+    a->u = a->l + (uint32_t)((range * hi) / st->n) - 1;
+    a->l = a->l + (uint32_t)((range * lo) / st->n);
+}
+
+static inline uint32_t lead_zeros(uint32_t v, uint32_t width) { return v ? (uint32_t)__builtin_clz(v) - (32 - width) : width; }
+
+void arithmetic_encoder_step(Arithmetic_code a, stream_stats_ptr_t stats, int32_t x, osStream os) {   /* arith.c:24-97 */
+    const uint32_t m = a->m, msb = 1u << (m - 1), mask = (1u << m) - 1, mask1 = msb - 1;
+    if (x < 0 || (uint32_t)x >= stats->alphabetCard) { printf("arithmetic_encoder_step: symbol outside the alphabet\n"); exit(1); }   /* assert, :37 */
+    narrow(a, stats, (uint32_t)x);
+    /* E1/E2 then E3, each as one batch: after the k shared leading bits are out, msb(l) = 0 and msb(u) = 1, and E3 shifts
+     * keep it so (same integers as the loop of :66-96) */
+    const uint32_t diff = a->l ^ a->u;
+    if (!(diff & msb)) {
+        const uint32_t k = lead_zeros(diff, m), top = a->l >> (m - k), first = top >> (k - 1);
+        stream_write_bit(os, (uint8_t)first);
+        for (; a->scale3 > 0; a->scale3 -= 1) stream_write_bit(os, (uint8_t)!first);
+        if (k > 1) stream_write_bits(os, top & ((1u << (k - 1)) - 1), (uint8_t)(k - 1));
+        a->l = (a->l << k) & mask;
+        a->u = ((a->u << k) & mask) | ((1u << k) - 1);
+    }
+    const uint32_t ones = lead_zeros(~a->l & mask1, m - 1), zeros = lead_zeros(a->u & mask1, m - 1), j = ones < zeros ? ones : zeros;
+    if (j) {
+        a->scale3 += (int32_t)j;
+        a->l = (a->l << j) & mask1;
+        a->u = ((a->u << j) & mask1) | msb | ((1u << j) - 1);
+    }
+}
+
+int encoder_last_step(Arithmetic_code a, osStream os) {                          /* arith.c:99-116 */
+    const uint8_t first = (uint8_t)(a->l >> (a->m - 1));
+    stream_write_bit(os, first);
+    for (; a->scale3 > 0; a->scale3 -= 1) stream_write_bit(os, !first);
+    stream_write_bits(os, a->l, (uint8_t)(a->m - 1));
+    stream_finish_byte(os);
+    return (int)os->written;
+}
+
+static uint32_t symbol_under_tag(const struct Arithmetic_code_t *a, const struct stream_stats_t *st) {   /* arith.c:130-136, :196-203 */
+    const uint64_t range = (uint64_t)a->u - a->l + 1, gap = (uint64_t)a->t - a->l + 1;
+    const uint64_t sub = (gap * st->n - 1) / range;
+    uint64_t cum = 0;
+    uint32_t k = 0;
+    while (k < st->alphabetCard && sub >= cum) cum += st->counts[k++];
+    return k ? k - 1 : 0;
+}
+
+uint32_t decoder_last_step(Arithmetic_code a, stream_stats_ptr_t stats) { return symbol_under_tag(a, stats); }
+
+uint32_t arithmetic_decoder_step(Arithmetic_code a, stream_stats_ptr_t stats, osStream is) {            /* arith.c:118-188 */
+    const uint32_t m = a->m, msb = 1u << (m - 1), mask1 = msb - 1;
+    const uint32_t x = symbol_under_tag(a, stats);
+    narrow(a, stats, x);
+    for (;;) {
+        if ((a->l >> (m - 1)) == (a->u >> (m - 1))) {                            /* E1 / E2 */
+            a->l = (a->l & mask1) << 1;
+            a->u = ((a->u & mask1) << 1) + 1;
+            a->t = ((a->t & mask1) << 1) + stream_read_bit(is);
+        } else if ((a->l >> (m - 2)) == 1 && (a->u >> (m - 2)) == 2) {           /* E3 */
+            a->l = (a->l << 1) & mask1;
+            a->u = (((a->u << 1) & mask1) | msb) + 1;
+            a->t = (((a->t & mask1) << 1) ^ msb) + stream_read_bit(is);
+        } else break;
+    }
+    return x;
+}
+
+void compress_qv(arithStream as, uint32_t x, uint8_t cluster, uint32_t column, uint32_t idx) {          /* qv_compressor.c:8-11 */
+    arithmetic_encoder_step(as->a, as->stats[cluster][column][idx], (int32_t)x, as->os);
+    update_stats(as->stats[cluster][column][idx], x, as->a->r);
+}
+
+void qv_write_cluster(arithStream as, uint8_t cluster) {                                                /* qv_compressor.c:19-22 */
+    arithmetic_encoder_step(as->a, as->cluster_stats, cluster, as->os);
+    update_stats(as->cluster_stats, cluster, as->a->r);
+}
+
+uint32_t decompress_qv(arithStream as, uint8_t cluster, uint32_t column, uint32_t idx) {                /* qv_compressor.c:27-34 */
+    const uint32_t x = arithmetic_decoder_step(as->a, as->stats[cluster][column][idx], as->os);
+    update_stats(as->stats[cluster][column][idx], x, as->a->r);
+    return x;
+}
+
+uint8_t qv_read_cluster(arithStream as) {                                                               /* qv_compressor.c:36-43 */
+    const uint32_t x = arithmetic_decoder_step(as->a, as->cluster_stats, as->os);
+    update_stats(as->cluster_stats, x, as->a->r);
+    return (uint8_t)x;
+}
+
+qv_compressor initialize_qv_compressor(FILE *fout, uint8_t streamDirection, struct quality_file_t *info) {   /* qv_stream.c:66-125 */
+    memset(&info->well, 0, sizeof(info->well));
+    if (streamDirection) {
+        if (fread(info->well.state, sizeof(uint32_t), 32, fout) != 32) { printf("initialize_qv_compressor: file ends before the WELL state\n"); exit(1); }
+    } else {
+        const char *seed = getenv("QVZ_WELL_SEED");
+        const int debug = seed && strcmp(seed, "debug") == 0;                    /* the reference's -DDEBUG build, qv_stream.c:79-83 */
+        srand((uint32_t)time(0));                                                /* qv_stream.c:77 */
+        for (int i = 0; i < 32; ++i) info->well.state[i] = debug ? 0x55555555u : (uint32_t)rand();
+        fwrite(info->well.state, sizeof(uint32_t), 32, fout);
+    }
+    arithStream as = (arithStream)calloc(1, sizeof(*as));
+    as->cluster_stats = new_stats(info->cluster_count);
+    as->stats = (stream_stats_ptr_t ***)calloc(info->cluster_count, sizeof(*as->stats));
+    for (uint32_t j = 0; j < info->cluster_count; ++j) as->stats[j] = initialize_stream_stats(info->clusters->clusters[j].qlist);
+    as->a = initialize_arithmetic_encoder(m_arith);
+    as->os = alloc_os_stream(fout, streamDirection);
+    as->a->t = streamDirection ? stream_read_bits(as->os, (uint8_t)as->a->m) : 0;
+    qv_compressor qvc = (qv_compressor)calloc(1, sizeof(*qvc));
+    qvc->Quals = as;
+    return qvc;
+}
+
+uint32_t well_1024a(struct well_state_t *w) {                                    /* well.c:8-24 */
+    uint32_t *s = w->state;
+    const uint32_t n = w->n & 31;
+    const uint32_t z0 = s[(n + 31) & 31], v1 = s[(n + 3) & 31], v2 = s[(n + 24) & 31], v3 = s[(n + 10) & 31];
+    const uint32_t z1 = s[n] ^ v1 ^ (v1 >> 8);
+    const uint32_t z2 = v2 ^ (v2 << 19) ^ v3 ^ (v3 << 14);
+    s[n] = z1 ^ z2;
+    w->n = (n + 31) & 31;
+    s[w->n] = z0 ^ (z0 << 11) ^ z1 ^ (z1 << 7) ^ z2 ^ (z2 << 13);
+    return s[w->n];
+}
+
+uint32_t well_1024a_bits(struct well_state_t *w, uint8_t bits) {                 /* well.c:33-46 */
+    if (w->bits_left < bits) { w->bit_output = well_1024a(w); w->bits_left = 32; }
+    const uint32_t v = w->bit_output & ((1u << bits) - 1);
+    w->bit_output >>= bits;
+    w->bits_left -= bits;
+    return v;
+}
+
+struct quantizer_t *choose_quantizer(struct cond_quantizer_list_t *list, struct well_state_t *well, uint32_t column,
+                                     symbol_t prev, uint32_t *q_idx) {           /* codebook.c:162-171 */
+    const uint32_t idx = list->input_alphabets[column]->indexes[prev];
+    if (idx == NOT_FOUND_U32) { printf("choose_quantizer: no context for value %u in column %u\n", prev, column); exit(1); }   /* assert, :164 */
+    *q_idx = 2 * idx + (well_1024a_bits(well, 7) >= list->qratio[column][idx] ? 1u : 0u);
+    return list->q[column][*q_idx];
 }

@@ -4,9 +4,9 @@
  *                          alphabets by run de-duplication of the quantizer tables (find_output_alphabet,
  *                          src/quantizer.c:167-191), context sets by merging them (alphabet_union, src/pmf.c:312-357)
  *   qvz_decode_file        start_qv_decompression (src/qv_compressor.c:145-231) for the reference's one-stream file:
- *                          the serial chain (arithmetic_decoder_step / decoder_last_step, src/arith.c:118-205) runs on
- *                          one host core as in the reference; the WELL draws come from the GPU word stream
- *                          (qvz_hip_well_words) chunk by chunk
+ *                          the serial chain (arithmetic_decoder_step / decoder_last_step, src/arith.c:118-205) and the
+ *                          WELL draws (src/well.c:8-46) run on one host core as in the reference: a single stream offers
+ *                          the GPU one lane. A shard set (qvz_shardset.h) given as input goes to the GPU decoder instead.
  *   qvz_decode_shard_files the files written by qvz_encode_file_sharded ("<prefix>.0000" ...): every shard is one lane of
  *                          the GPU decoder (qvz_hip_decode_shards); output = the decodes in order
  */
@@ -19,6 +19,7 @@
 #include "qvz_encode.h"
 #include "qvz_hip.h"
 #include "qvz_job.h"
+#include "qvz_shardset.h"
 
 #define A QVZ_A
 #define M_BITS 22u
@@ -55,12 +56,24 @@ static uint32_t union_lists(const uint8_t *a, uint32_t na, const uint8_t *b, uin
     return k;
 }
 
-static void set_quantizer(qvz_codebook_t *cb, size_t t, const uint8_t *text) {
-    for (int i = 0; i < A; ++i) cb->q[t * A + i] = (uint8_t)(text[i] - 33);
+/* A table byte is a quality value + 33 ('!'..'h'), a ratio byte (uint8)(ratio * 128) + 33 with ratio <= 1: anything else
+ * would index past the 72-entry rows below (the reference does so, codebook.c:586-663: undefined behaviour there). */
+static int set_quantizer(qvz_codebook_t *cb, size_t t, const uint8_t *text) {
+    for (int i = 0; i < A; ++i) {
+        if (text[i] < 33 || text[i] >= 33 + A) return qvz_job_fail(QVZ_E_DATA, "codebook byte 0x%02x is not a quality value", text[i]);
+        cb->q[t * A + i] = (uint8_t)(text[i] - 33);
+    }
     const uint32_t ns = dedup_alphabet(cb->q + t * A, cb->recon + t * A);
     cb->nstates[t] = (uint8_t)ns;
     memset(cb->out_idx + t * A, QVZ_NOT_FOUND, A);
     for (uint32_t z = 0; z < ns; ++z) cb->out_idx[t * A + cb->recon[t * A + z]] = (uint8_t)z;
+    return QVZ_OK;
+}
+
+static int ratio_byte(uint8_t b, uint8_t *out) {
+    if (b < 33 || b > 33 + 128) return qvz_job_fail(QVZ_E_DATA, "codebook ratio byte 0x%02x out of range", b);
+    *out = (uint8_t)(b - 33);
+    return QVZ_OK;
 }
 
 int qvz_codebook_read(const uint8_t *f, size_t size, size_t *ppos, qvz_codebook_t *cb) {
@@ -73,10 +86,10 @@ int qvz_codebook_read(const uint8_t *f, size_t size, size_t *ppos, qvz_codebook_
     memset(cb->live, 1, (size_t)C * A);
     NEED(2 + 2 * (A + 1));                                                     /* codebook.c:596-618 */
     cb->nctx[0] = 1; cb->ctx_sym[0] = 0; cb->ctx_idx[0] = 0;
-    cb->qratio[0] = (uint8_t)(f[pos] - 33);
+    if (ratio_byte(f[pos], &cb->qratio[0])) return QVZ_E_DATA;
     cb->ratio[0] = cb->qratio[0] / 128.0;
     pos += 2;
-    for (int b = 0; b < 2; ++b) { set_quantizer(cb, (size_t)b, f + pos); pos += A + 1; }
+    for (int b = 0; b < 2; ++b) { if (set_quantizer(cb, (size_t)b, f + pos)) return QVZ_E_DATA; pos += A + 1; }
     nu = union_lists(cb->recon, cb->nstates[0], cb->recon + A, cb->nstates[1], uni);
     for (uint32_t s = 1; s < C; ++s) {                                         /* :623-663 */
         const uint32_t n = nu;
@@ -86,7 +99,7 @@ int qvz_codebook_read(const uint8_t *f, size_t size, size_t *ppos, qvz_codebook_
         for (uint32_t i = 0; i < n; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
         NEED(n + 1 + 2 * ((size_t)n * A + 1));
         for (uint32_t j = 0; j < n; ++j) {
-            cb->qratio[(size_t)s * A + j] = (uint8_t)(f[pos + j] - 33);
+            if (ratio_byte(f[pos + j], &cb->qratio[(size_t)s * A + j])) return QVZ_E_DATA;
             cb->ratio[(size_t)s * A + j] = cb->qratio[(size_t)s * A + j] / 128.0;
         }
         pos += n + 1;
@@ -94,7 +107,7 @@ int qvz_codebook_read(const uint8_t *f, size_t size, size_t *ppos, qvz_codebook_
         for (int b = 0; b < 2; ++b) {
             for (uint32_t j = 0; j < n; ++j) {
                 const size_t t = (size_t)s * 2 * A + 2 * j + b;
-                set_quantizer(cb, t, f + pos);
+                if (set_quantizer(cb, t, f + pos)) return QVZ_E_DATA;
                 pos += A;
                 nu = union_lists(uni, nu, cb->recon + t * A, cb->nstates[t], uni);
             }
@@ -157,21 +170,48 @@ static uint32_t hdec_symbol(hdec_t *d, uint32_t *t, int last) {
     return x;
 }
 
-typedef struct {
-    uint32_t K, C;
-    uint64_t lines;
-    qvz_codebook_t **cbs;
-    uint32_t well[32];
-    size_t stream_at;
-} qfile_t;
+/* WELL-1024a on the host (reference src/well.c:8-46) for the serial decoder: one stream means one draw at a time */
+typedef struct { uint32_t s[32]; uint32_t n, word, left; } hwell_t;
 
-static void qfile_release(qfile_t *q) {
+static inline uint32_t hwell_draw(hwell_t *w) {                                  /* well_1024a_bits(w, 7) */
+    if (w->left < 7) {
+        uint32_t *s = w->s;
+        const uint32_t n = w->n;
+        const uint32_t z0 = s[(n + 31) & 31], v1 = s[(n + 3) & 31], v2 = s[(n + 24) & 31], v3 = s[(n + 10) & 31];
+        const uint32_t z1 = s[n] ^ v1 ^ (v1 >> 8);
+        const uint32_t z2 = v2 ^ (v2 << 19) ^ v3 ^ (v3 << 14);
+        s[n] = z1 ^ z2;
+        w->n = (n + 31) & 31;
+        s[w->n] = z0 ^ (z0 << 11) ^ z1 ^ (z1 << 7) ^ z2 ^ (z2 << 13);
+        w->word = s[w->n];
+        w->left = 32;
+    }
+    const uint32_t d = w->word & 127;
+    w->word >>= 7;
+    w->left -= 7;
+    return d;
+}
+
+void qvz_qfile_release(qvz_qfile_t *q) {
     if (q->cbs) { for (uint32_t j = 0; j < q->K; ++j) qvz_codebook_free(q->cbs[j]); free(q->cbs); }
     memset(q, 0, sizeof(*q));
 }
 
+/* `clusters` codebooks (read_codebook, codebook.c:586-669) starting at f[*pos] */
+int qvz_codebooks_parse(const uint8_t *f, size_t size, size_t *pos, uint32_t K, uint32_t C, qvz_codebook_t ***out) {
+    qvz_codebook_t **cbs = (qvz_codebook_t **)calloc(K, sizeof(*cbs));
+    if (!cbs) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
+    for (uint32_t j = 0; j < K; ++j) {
+        cbs[j] = qvz_codebook_alloc(C);
+        const int rc = cbs[j] ? qvz_codebook_read(f, size, pos, cbs[j]) : qvz_job_fail(QVZ_E_NOMEM, "host alloc");
+        if (rc) { for (uint32_t i = 0; i <= j; ++i) qvz_codebook_free(cbs[i]); free(cbs); return rc; }
+    }
+    *out = cbs;
+    return QVZ_OK;
+}
+
 /* header (codebook.c:565-573), codebooks, WELL state (qv_stream.c:72-74) */
-static int qfile_parse(const uint8_t *f, size_t size, qfile_t *q) {
+int qvz_qfile_parse(const uint8_t *f, size_t size, qvz_qfile_t *q) {
     memset(q, 0, sizeof(*q));
     if (size < 9) return qvz_job_fail(QVZ_E_DATA, "not a qvz file");
     q->K = f[0];
@@ -179,21 +219,15 @@ static int qfile_parse(const uint8_t *f, size_t size, qfile_t *q) {
     q->lines = ((uint32_t)f[5] << 24) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 8) | f[8];
     if (q->K < 1 || q->C < 1 || q->C > (1u << 20)) return qvz_job_fail(QVZ_E_DATA, "implausible header (%u clusters, %u columns)", q->K, q->C);
     size_t pos = 9;
-    q->cbs = (qvz_codebook_t **)calloc(q->K, sizeof(*q->cbs));
-    if (!q->cbs) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
-    for (uint32_t j = 0; j < q->K; ++j) {
-        q->cbs[j] = qvz_codebook_alloc(q->C);
-        if (!q->cbs[j]) { qfile_release(q); return qvz_job_fail(QVZ_E_NOMEM, "host alloc"); }
-        const int rc = qvz_codebook_read(f, size, &pos, q->cbs[j]);
-        if (rc) { qfile_release(q); return rc; }
-    }
-    if (pos + 128 > size) { qfile_release(q); return qvz_job_fail(QVZ_E_DATA, "file ends before the WELL state"); }
+    const int rc = qvz_codebooks_parse(f, size, &pos, q->K, q->C, &q->cbs);
+    if (rc) { memset(q, 0, sizeof(*q)); return rc; }
+    if (pos + 128 > size) { qvz_qfile_release(q); return qvz_job_fail(QVZ_E_DATA, "file ends before the WELL state"); }
     memcpy(q->well, f + pos, 128);
     q->stream_at = pos + 128;
     return QVZ_OK;
 }
 
-static int read_whole_file(const char *path, uint8_t **buf, size_t *size) {
+int qvz_read_whole_file(const char *path, uint8_t **buf, size_t *size) {
     FILE *f = fopen(path, "rb");
     if (!f) return qvz_job_fail(QVZ_E_ARG, "Unable to open input file %s", path);
     fseek(f, 0, SEEK_END);
@@ -206,118 +240,90 @@ static int read_whole_file(const char *path, uint8_t **buf, size_t *size) {
     return QVZ_OK;
 }
 
-int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_result_t *res) {
-    uint8_t *f = NULL, *row = NULL;
-    size_t size = 0;
-    qfile_t q;
-    uint32_t *arena = NULL, *off = NULL, words = 0, *h_words = NULL, *d_words = NULL;
-    FILE *fo = NULL;
-    int rc;
-    memset(&q, 0, sizeof(q));
-    if ((rc = read_whole_file(in_path, &f, &size))) return rc;
-    if ((rc = qfile_parse(f, size, &q))) { free(f); return rc; }
-    const uint32_t C = q.C, K = q.K;
-    const uint64_t chunk = 1u << 16;                                            /* reads per batch of draws */
-    if (qvz_hip_set_device(device)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
-    if (qvz_model_build(K, C, (const qvz_codebook_t *const *)q.cbs, 0, &arena, &off, &words)) { rc = qvz_job_fail(QVZ_E_NOMEM, "model build failed"); goto done; }
-    h_words = (uint32_t *)malloc((chunk * C / 4 + 2) * sizeof(uint32_t));
+/* start_qv_decompression (qv_compressor.c:145-231) over memory: one stream, one host core, as in the reference */
+int qvz_decode_stream_host(uint32_t K, uint32_t C, uint64_t lines, const qvz_codebook_t *const *cbs, const uint32_t *well,
+                           const uint8_t *stream, size_t size, FILE *fo, int verbose) {
+    uint32_t *arena = NULL, *off = NULL, words = 0;
+    uint8_t *row = NULL;
+    int rc = QVZ_OK;
+    if (!lines) return QVZ_OK;
+    if (qvz_model_build(K, C, cbs, 0, &arena, &off, &words)) return qvz_job_fail(QVZ_E_NOMEM, "model build failed");
     row = (uint8_t *)malloc((size_t)C + 1);
-    fo = fopen(out_path, "w");
-    if (!h_words || !row) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-    if (!fo) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
-    if (qvz_hip_malloc((void **)&d_words, (chunk * C / 4 + 2) * sizeof(uint32_t))) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+    if (!row) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
     {
-        hdec_t d = { f + q.stream_at, size - q.stream_at, 0, 0, 0, MASK_M, 0 };
+        hwell_t w;
+        hdec_t d = { stream, size, 0, 0, 0, MASK_M, 0 };
+        memcpy(w.s, well, 128);
+        w.n = 0; w.word = 0; w.left = 0;                                        /* qv_stream.c:70,93 */
         for (int bit = (int)M_BITS - 1; bit >= 0; --bit) d.t |= rd_bit(&d) << bit;   /* qv_stream.c:112-113 */
-        for (uint64_t r0 = 0; r0 < q.lines; r0 += chunk) {
-            const uint64_t nr = q.lines - r0 < chunk ? q.lines - r0 : chunk;
-            const uint64_t w0 = r0 * C / 4, w1 = ((r0 + nr) * C + 3) / 4;      /* chunk is a multiple of 4 reads */
-            if (qvz_hip_well_words(q.well, w0, w1 - w0, d_words, NULL) || qvz_hip_copy_d2h(h_words, d_words, (w1 - w0) * 4, NULL) ||
-                qvz_hip_stream_sync(NULL)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
-            for (uint64_t i = 0; i < nr; ++i) {
-                /* qv_read_cluster, qv_compressor.c:36-43: coded for every read (a no-op on the interval when K = 1) */
-                const uint32_t cl = hdec_symbol(&d, arena, 0);
-                if (cl >= K) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (cluster id)"); goto done; }
-                const qvz_codebook_t *cb = q.cbs[cl];
-                uint32_t prev = 0;
-                for (uint32_t s = 0; s < C; ++s) {
-                    const uint32_t ctx = cb->ctx_idx[(size_t)s * A + prev];
-                    if (ctx == QVZ_NOT_FOUND) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (context)"); goto done; }
-                    const uint64_t g = (r0 + i) * C + s - w0 * 4;               /* draw index inside this batch of words */
-                    const uint32_t draw = (h_words[g >> 2] >> (7 * (g & 3))) & 127;   /* well.c:33-46 */
-                    const uint32_t qi = 2 * ctx + (draw >= cb->qratio[(size_t)s * A + ctx] ? 1u : 0u);
-                    const uint32_t o = off[((size_t)cl * C + s) * 2 * A + qi];
-                    const int last = r0 + i + 1 == q.lines && s + 1 == C;      /* qv_compressor.c:222-225 */
-                    const uint32_t x = hdec_symbol(&d, arena + o, last);
-                    if (x >= arena[o + 1]) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (state)"); goto done; }
-                    prev = cb->recon[((size_t)s * 2 * A + qi) * A + x];
-                    row[s] = (uint8_t)(prev + 33);
-                }
-                row[C] = '\n';
-                if (fwrite(row, 1, (size_t)C + 1, fo) != (size_t)C + 1) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+        for (uint64_t i = 0; i < lines; ++i) {
+            if (verbose && i % QVZ_LINES_PER_BLOCK == 0) printf("Line: %dM\n", (int)(i / QVZ_LINES_PER_BLOCK));   /* qv_compressor.c:167-169 */
+            /* qv_read_cluster, qv_compressor.c:36-43: coded for every read (a no-op on the interval when K = 1) */
+            const uint32_t cl = hdec_symbol(&d, arena, 0);
+            if (cl >= K) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (cluster id)"); goto done; }
+            const qvz_codebook_t *cb = cbs[cl];
+            uint32_t prev = 0;
+            for (uint32_t s = 0; s < C; ++s) {
+                const uint32_t ctx = cb->ctx_idx[(size_t)s * A + prev];
+                if (ctx == QVZ_NOT_FOUND) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (context)"); goto done; }
+                const uint32_t draw = hwell_draw(&w);                           /* choose_quantizer, codebook.c:162-171 */
+                const uint32_t qi = 2 * ctx + (draw >= cb->qratio[(size_t)s * A + ctx] ? 1u : 0u);
+                const uint32_t o = off[((size_t)cl * C + s) * 2 * A + qi];
+                const int last = i + 1 == lines && s + 1 == C;                  /* qv_compressor.c:222-225 */
+                const uint32_t x = hdec_symbol(&d, arena + o, last);
+                if (x >= arena[o + 1]) { rc = qvz_job_fail(QVZ_E_DATA, "stream does not fit the codebooks (state)"); goto done; }
+                prev = cb->recon[((size_t)s * 2 * A + qi) * A + x];
+                row[s] = (uint8_t)(prev + 33);
             }
+            row[C] = '\n';
+            if (fwrite(row, 1, (size_t)C + 1, fo) != (size_t)C + 1) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
         }
     }
-    if (res) { memset(res, 0, sizeof(*res)); res->lines = q.lines; res->columns = C; res->stream_bytes = size - q.stream_at; res->file_bytes = size; }
 done:
-    if (fo) fclose(fo);
-    qvz_hip_free(d_words);
-    free(h_words); free(row); free(arena); free(off); free(f);
-    qfile_release(&q);
+    free(row); free(arena); free(off);
     return rc;
 }
 
-int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_path, int device, qvz_result_t *res) {
+int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_result_t *res) {
+    uint8_t *f = NULL;
+    size_t size = 0;
+    qvz_qfile_t q;
+    int rc;
+    memset(&q, 0, sizeof(q));
+    if ((rc = qvz_read_whole_file(in_path, &f, &size))) return rc;
+    if (qvz_shardset_is(f, size)) {                                             /* a shard set (include/qvz_shardset.h): all streams at once on the GPU */
+        free(f);
+        return qvz_shardset_decode(in_path, out_path, device, res);
+    }
+    if ((rc = qvz_qfile_parse(f, size, &q))) { free(f); return rc; }
+    FILE *fo = fopen(out_path, "w");
+    if (!fo) rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
+    else {
+        rc = qvz_decode_stream_host(q.K, q.C, q.lines, (const qvz_codebook_t *const *)q.cbs, q.well, f + q.stream_at, size - q.stream_at, fo, 0);
+        fclose(fo);
+    }
+    if (!rc && res) { memset(res, 0, sizeof(*res)); res->lines = q.lines; res->columns = q.C; res->stream_bytes = size - q.stream_at; res->file_bytes = size; }
+    free(f);
+    qvz_qfile_release(&q);
+    return rc;
+}
+
+/* S streams of one file (stream g = reads [first[g], first[g+1]) with qvz_shard_bounds(N, S)) decoded at once by the GPU
+ * decoder and written as text. streams[g] points at sizes[g] bytes. */
+int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codebook_t *const *cbs, const uint32_t *well,
+                           uint32_t shards, const uint8_t *const *streams, const uint64_t *sizes, const char *out_path, int device) {
     int rc = QVZ_OK;
-    uint8_t **files = NULL, *h_in = NULL, *d_in = NULL, *d_draws = NULL, *d_qv = NULL, *d_labels = NULL, *d_text = NULL, *h_text = NULL;
-    size_t *fsize = NULL;
-    uint64_t *sizes = NULL, *first = NULL;
-    qfile_t q0, qg;
+    uint8_t *h_in = NULL, *d_in = NULL, *d_draws = NULL, *d_qv = NULL, *d_labels = NULL, *d_text = NULL, *h_text = NULL;
     FILE *fo = NULL;
-    memset(&q0, 0, sizeof(q0));
-    memset(&qg, 0, sizeof(qg));
-    if (!shards) return qvz_job_fail(QVZ_E_ARG, "shards must be positive");
-    files = (uint8_t **)calloc(shards, sizeof(*files));
-    fsize = (size_t *)calloc(shards, sizeof(*fsize));
-    sizes = (uint64_t *)calloc(shards, sizeof(*sizes));
-    first = (uint64_t *)calloc((size_t)shards + 1, sizeof(*first));
-    if (!files || !fsize || !sizes || !first) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-    uint64_t N = 0, cap = 0;
-    size_t head = 0;
-    for (uint32_t g = 0; g < shards; ++g) {
-        char name[4096];
-        if ((size_t)snprintf(name, sizeof(name), "%s.%04u", prefix, g) >= sizeof(name)) { rc = qvz_job_fail(QVZ_E_ARG, "name too long"); goto done; }
-        if ((rc = read_whole_file(name, &files[g], &fsize[g]))) goto done;
-        if (g == 0) {
-            if ((rc = qfile_parse(files[0], fsize[0], &q0))) goto done;
-            head = q0.stream_at;
-        } else {                                                                /* same codebooks in every shard: compare the bytes */
-            if (fsize[g] < head || memcmp(files[g] + 9, files[0] + 9, head - 128 - 9) != 0 || files[g][0] != files[0][0] ||
-                memcmp(files[g] + 1, files[0] + 1, 4) != 0) { rc = qvz_job_fail(QVZ_E_DATA, "%s does not carry the codebooks of shard 0", name); goto done; }
-        }
-        const uint64_t lines = ((uint32_t)files[g][5] << 24) | ((uint32_t)files[g][6] << 16) | ((uint32_t)files[g][7] << 8) | files[g][8];
-        first[g] = N;
-        N += lines;
-        sizes[g] = fsize[g] - head;
-        if (sizes[g] > cap) cap = sizes[g];
-    }
-    first[shards] = N;
-    {   /* the shard boundaries must be the ones qvz_shard_bounds gives for N reads: the decoder derives them itself */
-        uint64_t *chk = (uint64_t *)calloc((size_t)shards + 1, sizeof(*chk));
-        if (!chk) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        qvz_shard_bounds(N, shards, chk);
-        const int same = memcmp(chk, first, ((size_t)shards + 1) * sizeof(*chk)) == 0;
-        free(chk);
-        if (!same) { rc = qvz_job_fail(QVZ_E_DATA, "line counts of the shard files are not those of %u equal shards", shards); goto done; }
-    }
+    uint64_t cap = 0;
+    for (uint32_t g = 0; g < shards; ++g) if (sizes[g] > cap) cap = sizes[g];
     cap = (cap + 7) & ~3ull;
-    const uint32_t C = q0.C, K = q0.K;
     const uint64_t ld = qvz_hip_ld(N), stride = (uint64_t)C + 1;
-    if (qvz_hip_set_device(device)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+    if (qvz_hip_set_device(device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
     h_in = (uint8_t *)calloc((size_t)shards, cap);
     h_text = (uint8_t *)malloc(N * stride);
     if (!h_in || !h_text) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-    for (uint32_t g = 0; g < shards; ++g) memcpy(h_in + (size_t)g * cap, files[g] + head, sizes[g]);
+    for (uint32_t g = 0; g < shards; ++g) memcpy(h_in + (size_t)g * cap, streams[g], sizes[g]);
 #define HIPC(call) do { if ((call) != QVZ_OK) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; } } while (0)
     HIPC(qvz_hip_malloc((void **)&d_in, (size_t)shards * cap));
     HIPC(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
@@ -325,8 +331,8 @@ int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_
     HIPC(qvz_hip_malloc((void **)&d_labels, ld));
     HIPC(qvz_hip_malloc((void **)&d_text, N * stride));
     HIPC(qvz_hip_copy_h2d(d_in, h_in, (size_t)shards * cap, NULL));
-    HIPC(qvz_hip_well_draws(q0.well, 0, N, C, d_draws, ld, NULL));             /* shard 0 carries the file's WELL state */
-    if (qvz_hip_decode_shards(d_in, cap, sizes, N, C, K, (const qvz_codebook_t *const *)q0.cbs, shards, d_draws, ld, d_qv, d_labels, NULL)) {
+    HIPC(qvz_hip_well_draws(well, 0, N, C, d_draws, ld, NULL));
+    if (qvz_hip_decode_shards(d_in, cap, sizes, N, C, K, cbs, shards, d_draws, ld, d_qv, d_labels, NULL)) {
         rc = qvz_job_fail(QVZ_E_DATA, "%s", qvz_hip_last_error());
         goto done;
     }
@@ -337,12 +343,62 @@ int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_
     fo = fopen(out_path, "w");
     if (!fo) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
     if (fwrite(h_text, 1, N * stride, fo) != N * stride) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
-    if (res) { memset(res, 0, sizeof(*res)); res->lines = N; res->columns = C; for (uint32_t g = 0; g < shards; ++g) { res->stream_bytes += sizes[g]; res->file_bytes += fsize[g]; } }
 done:
     if (fo) fclose(fo);
     qvz_hip_free(d_in); qvz_hip_free(d_draws); qvz_hip_free(d_qv); qvz_hip_free(d_labels); qvz_hip_free(d_text);
+    free(h_in); free(h_text);
+    return rc;
+}
+
+int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_path, int device, qvz_result_t *res) {
+    int rc = QVZ_OK;
+    uint8_t **files = NULL;
+    const uint8_t **streams = NULL;
+    size_t *fsize = NULL;
+    uint64_t *sizes = NULL, *first = NULL;
+    qvz_qfile_t q0;
+    memset(&q0, 0, sizeof(q0));
+    if (!shards) return qvz_job_fail(QVZ_E_ARG, "shards must be positive");
+    files = (uint8_t **)calloc(shards, sizeof(*files));
+    streams = (const uint8_t **)calloc(shards, sizeof(*streams));
+    fsize = (size_t *)calloc(shards, sizeof(*fsize));
+    sizes = (uint64_t *)calloc(shards, sizeof(*sizes));
+    first = (uint64_t *)calloc((size_t)shards + 1, sizeof(*first));
+    if (!files || !streams || !fsize || !sizes || !first) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+    uint64_t N = 0;
+    size_t head = 0;
+    for (uint32_t g = 0; g < shards; ++g) {
+        char name[4096];
+        if ((size_t)snprintf(name, sizeof(name), "%s.%04u", prefix, g) >= sizeof(name)) { rc = qvz_job_fail(QVZ_E_ARG, "name too long"); goto done; }
+        if ((rc = qvz_read_whole_file(name, &files[g], &fsize[g]))) goto done;
+        if (g == 0) {
+            if ((rc = qvz_qfile_parse(files[0], fsize[0], &q0))) goto done;
+            head = q0.stream_at;
+        } else {                                                                /* same codebooks in every shard: compare the bytes */
+            if (fsize[g] < head || memcmp(files[g] + 9, files[0] + 9, head - 128 - 9) != 0 || files[g][0] != files[0][0] ||
+                memcmp(files[g] + 1, files[0] + 1, 4) != 0) { rc = qvz_job_fail(QVZ_E_DATA, "%s does not carry the codebooks of shard 0", name); goto done; }
+        }
+        const uint64_t lines = ((uint32_t)files[g][5] << 24) | ((uint32_t)files[g][6] << 16) | ((uint32_t)files[g][7] << 8) | files[g][8];
+        first[g] = N;
+        N += lines;
+        sizes[g] = fsize[g] - head;
+        streams[g] = files[g] + head;
+    }
+    first[shards] = N;
+    {   /* the shard boundaries must be the ones qvz_shard_bounds gives for N reads: the decoder derives them itself */
+        uint64_t *chk = (uint64_t *)calloc((size_t)shards + 1, sizeof(*chk));
+        if (!chk) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        qvz_shard_bounds(N, shards, chk);
+        const int same = memcmp(chk, first, ((size_t)shards + 1) * sizeof(*chk)) == 0;
+        free(chk);
+        if (!same) { rc = qvz_job_fail(QVZ_E_DATA, "line counts of the shard files are not those of %u equal shards", shards); goto done; }
+    }
+    /* shard 0 carries the file's WELL state */
+    rc = qvz_decode_streams_gpu(q0.K, q0.C, N, (const qvz_codebook_t *const *)q0.cbs, q0.well, shards, streams, sizes, out_path, device);
+    if (!rc && res) { memset(res, 0, sizeof(*res)); res->lines = N; res->columns = q0.C; for (uint32_t g = 0; g < shards; ++g) { res->stream_bytes += sizes[g]; res->file_bytes += fsize[g]; } }
+done:
     if (files) for (uint32_t g = 0; g < shards; ++g) free(files[g]);
-    free(files); free(fsize); free(sizes); free(first); free(h_in); free(h_text);
-    qfile_release(&q0); qfile_release(&qg);
+    free(files); free(streams); free(fsize); free(sizes); free(first);
+    qvz_qfile_release(&q0);
     return rc;
 }

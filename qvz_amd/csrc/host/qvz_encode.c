@@ -18,6 +18,7 @@
 #include "qvz_codebook.h"
 #include "qvz_coder.h"
 #include "qvz_job.h"
+#include "qvz_shardset.h"
 
 #define A QVZ_A
 #define MAX_COLUMNS 1022u            /* MAX_READS_PER_LINE, reference include/lines.h:13 */
@@ -463,8 +464,8 @@ done:
  * stream is written as a complete reference-format file "<prefix>.<g>" (header with the shard's line count, the whole
  * file's codebooks, the WELL state advanced to the shard's first draw, the stream): the unmodified reference decoder
  * decodes each, and the decodes concatenate to the -u text. The distortion is the reference's sequential sum. */
-int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
-                             double *distortion_out) {
+static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
+                                 uint64_t *file_bytes, double *distortion_out) {
     int rc = 0;
     const double t0 = now();
     const uint32_t C = job->C, K = job->K;
@@ -474,7 +475,8 @@ int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint3
     uint8_t *d_draws = NULL, *d_qv = NULL, *d_qi = NULL, *d_st = NULL, *d_out = NULL, *d_text = NULL, *h_buf = NULL, *image = NULL;
     int32_t *d_status = NULL, status = 0;
     uint64_t *sizes = NULL, *first = NULL;
-    if (!shards || shards > N / 4 + 1) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads", shards, (unsigned long long)N);
+    uint32_t *wstates = NULL;
+    if (!shards || shards > qvz_shard_limit(N)) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads: a shard needs at least 4 reads", shards, (unsigned long long)N);
 
     if (job->opts.seed_mode == QVZ_SEED_EXPLICIT) {                             /* qv_stream.c:70-89 */
         memcpy(job->well_state, job->opts.well_state, sizeof(job->well_state));
@@ -537,47 +539,78 @@ int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint3
         qvz_hip_free(d_text); d_text = NULL;
     }
     qvz_hip_free(d_qv); d_qv = NULL;
-    {   /* coding: 6 bits per symbol of room per stream */
+    {   /* coding. Room per stream: 6 bits per symbol to begin with (real data needs 1-2); a stream that outgrows it
+         * (-r above 6, near-uniform input) makes the coder report QVZ_E_NOMEM and the call is repeated with twice the room,
+         * up to the 22 bits per symbol no symbol can exceed (counts >= 1 of n <= 2^19 + 8, plus the flush) */
         const uint64_t per = (N + shards - 1) / shards + 4;
-        const uint64_t cap = ((per * C * 3) / 4 + 512 + 3) & ~3ull;
-        uint64_t total = 0, img_cap = 0;
-        HIP(qvz_hip_malloc((void **)&d_out, (size_t)shards * cap));
-        if (qvz_hip_encode_planes(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
-                                  shards, d_out, cap, sizes, NULL, 0, NULL)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+        uint64_t cap = 0, total = 0, ftotal = 0;
+        for (uint32_t bits = 6; ; bits *= 2) {
+            cap = ((per * C * bits) / 8 + 512 + 3) & ~3ull;
+            qvz_hip_free(d_out); d_out = NULL;
+            HIP(qvz_hip_malloc((void **)&d_out, (size_t)shards * cap));
+            const int crc = qvz_hip_encode_planes(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
+                                                  shards, d_out, cap, sizes, NULL, 0, NULL);
+            if (crc == QVZ_OK) break;
+            if (crc != QVZ_E_NOMEM || bits >= 24) { rc = qvz_job_fail(crc, "%s", qvz_hip_last_error()); goto done; }
+        }
         h_buf = (uint8_t *)malloc((size_t)shards * cap);
         if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
         HIP(qvz_hip_copy_d2h(h_buf, d_out, (size_t)shards * cap, NULL));
         HIP(qvz_hip_stream_sync(NULL));
-        for (uint32_t g = 0; g < shards; ++g) {
-            uint32_t wstate[32];
-            char name[4096];
-            const uint64_t reads = first[g + 1] - first[g];
-            FILE *f;
-            size_t need;
-            total += sizes[g];
-            if ((size_t)snprintf(name, sizeof(name), "%s.%04u", prefix, g) >= sizeof(name)) { rc = qvz_job_fail(QVZ_E_ARG, "output name too long"); goto done; }
-            HIP(qvz_hip_well_jump(job->well_state, first[g] * C / 4, wstate));   /* generator at the shard's first draw, n = 0 */
-            need = qvz_shard_file_image(NULL, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstate, NULL, sizes[g]);
-            if (need > img_cap) {
-                free(image);
-                image = (uint8_t *)malloc(need);
-                img_cap = need;
-                if (!image) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        for (uint32_t g = 0; g < shards; ++g) total += sizes[g];
+        if (fset) {                                                             /* one shard set: codebooks once (qvz_shardset.h) */
+            qvz_shardset_info_t si;
+            if ((rc = qvz_shardset_write(fset, K, C, N, shards, job->well_state, (const qvz_codebook_t *const *)job->cbs, h_buf, cap, sizes, &si))) goto done;
+            ftotal = si.file_bytes;
+        } else {                                                                /* one reference-format file per shard */
+            uint64_t img_cap = 0;
+            uint64_t *jump = (uint64_t *)malloc((size_t)shards * sizeof(uint64_t));
+            wstates = (uint32_t *)malloc((size_t)shards * 128);
+            if (!jump || !wstates) { free(jump); rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+            for (uint32_t g = 0; g < shards; ++g) jump[g] = first[g] * C / 4;   /* generator at the shard's first draw, n = 0 */
+            const int jrc = qvz_hip_well_jump_many(job->well_state, jump, shards, wstates);
+            free(jump);
+            if (jrc) { rc = qvz_job_fail(jrc, "%s", qvz_hip_last_error()); goto done; }
+            for (uint32_t g = 0; g < shards; ++g) {
+                char name[4096];
+                const uint64_t reads = first[g + 1] - first[g];
+                FILE *f;
+                size_t need;
+                if ((size_t)snprintf(name, sizeof(name), "%s.%04u", prefix, g) >= sizeof(name)) { rc = qvz_job_fail(QVZ_E_ARG, "output name too long"); goto done; }
+                need = qvz_shard_file_image(NULL, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstates + (size_t)g * 32, NULL, sizes[g]);
+                if (need > img_cap) {
+                    free(image);
+                    image = (uint8_t *)malloc(need);
+                    img_cap = need;
+                    if (!image) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+                }
+                qvz_shard_file_image(image, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstates + (size_t)g * 32, h_buf + (size_t)g * cap, sizes[g]);
+                f = fopen(name, "wb");
+                if (!f) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
+                if (fwrite(image, 1, need, f) != need) { fclose(f); rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+                fclose(f);
+                ftotal += need;
             }
-            qvz_shard_file_image(image, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstate, h_buf + (size_t)g * cap, sizes[g]);
-            f = fopen(name, "wb");
-            if (!f) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
-            if (fwrite(image, 1, need, f) != need) { fclose(f); rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
-            fclose(f);
         }
         if (stream_bytes) *stream_bytes = total;
+        if (file_bytes) *file_bytes = ftotal;
     }
     job->t_encode = now() - t0;
 done:
-    free(h_ct); free(h_qs); free(sizes); free(first); free(h_err); free(h_buf); free(image);
+    free(h_ct); free(h_qs); free(sizes); free(first); free(h_err); free(h_buf); free(image); free(wstates);
     qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist); qvz_hip_free(d_err); qvz_hip_free(d_draws); qvz_hip_free(d_qv);
     qvz_hip_free(d_qi); qvz_hip_free(d_st); qvz_hip_free(d_out); qvz_hip_free(d_text); qvz_hip_free(d_status);
     return rc;
+}
+
+int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
+                             double *distortion_out) {
+    return compress_sharded_impl(job, prefix, NULL, fu, shards, stream_bytes, NULL, distortion_out);
+}
+
+int qvz_job_compress_shardset(qvz_job_t *job, FILE *fout, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
+                              uint64_t *file_bytes, double *distortion_out) {
+    return compress_sharded_impl(job, NULL, fout, fu, shards, stream_bytes, file_bytes, distortion_out);
 }
 
 void qvz_job_release(qvz_job_t *job) {
@@ -622,7 +655,9 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     if ((rc = qvz_job_stats(&job))) goto done;
     if ((rc = qvz_job_codebooks(&job))) goto done;
     if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", job.t_stats + job.t_codebook);   /* main.c:66-67 */
-    if (shards) {
+    if (shards && !shard_prefix) {                                              /* one shard-set file */
+        if ((rc = qvz_job_compress_shardset(&job, fout, fu, shards, &R.stream_bytes, &R.file_bytes, &R.distortion))) goto done;
+    } else if (shards) {
         if ((rc = qvz_job_compress_sharded(&job, shard_prefix, fu, shards, &R.stream_bytes, &R.distortion))) goto done;
         head_bytes = qvz_shard_file_image(NULL, job.K, job.C, 0, (const qvz_codebook_t *const *)job.cbs, job.well_state, NULL, 0) - 128;
         R.file_bytes = (uint64_t)shards * (head_bytes + 128) + R.stream_bytes;
@@ -700,6 +735,30 @@ int qvz_encode_file_sharded(const char *in_path, const char *out_prefix, const q
     }
     const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, NULL, fu, opts, res, out_prefix, shards);
     if (fu) fclose(fu);
+    munmap(map, (size_t)st.st_size);
+    close(fd);
+    return rc;
+}
+
+int qvz_encode_file_shardset(const char *in_path, const char *out_path, const qvz_options_t *opts, uint32_t shards,
+                             qvz_result_t *res) {
+    if (!shards) return qvz_job_fail(QVZ_E_ARG, "shards must be positive");
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) return qvz_job_fail(QVZ_E_ARG, "load_file returned error: 1");
+    struct stat st;
+    if (fstat(fd, &st) || st.st_size == 0) { close(fd); return qvz_job_fail(QVZ_E_DATA, "empty or unreadable input"); }
+    void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    if (map == MAP_FAILED) { close(fd); return qvz_job_fail(QVZ_E_NOMEM, "mmap failed"); }
+    FILE *fout = fopen(out_path, "wb");
+    if (!fout) { munmap(map, (size_t)st.st_size); close(fd); return qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); }
+    FILE *fu = NULL;
+    if (opts->uncompressed_name) {
+        fu = fopen(opts->uncompressed_name, "w");
+        if (!fu) { fclose(fout); munmap(map, (size_t)st.st_size); close(fd); return qvz_job_fail(QVZ_E_ARG, "Unable to open uncompressed file"); }
+    }
+    const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, fout, fu, opts, res, NULL, shards);
+    if (fu) fclose(fu);
+    fclose(fout);
     munmap(map, (size_t)st.st_size);
     close(fd);
     return rc;

@@ -54,7 +54,29 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
 /* the same for sharded output: `shards` reference-format files "<prefix>.<g>" coded by the GPU coder */
 int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
                              double *distortion);
+/* the same streams as ONE shard-set file (include/qvz_shardset.h): codebooks stored once */
+int qvz_job_compress_shardset(qvz_job_t *job, FILE *fout, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
+                              uint64_t *file_bytes, double *distortion);
 void qvz_job_release(qvz_job_t *job);
+
+/* ---- decode side, shared by qvz_decode.c, qvz_shardset.c and qvz_compat.c ---- */
+typedef struct qvz_qfile {
+    uint32_t K, C;
+    uint64_t lines;
+    qvz_codebook_t **cbs;
+    uint32_t well[32];
+    size_t stream_at;
+} qvz_qfile_t;
+int qvz_qfile_parse(const uint8_t *f, size_t size, qvz_qfile_t *q);       /* header + codebooks + WELL state of a .q image */
+void qvz_qfile_release(qvz_qfile_t *q);
+int qvz_codebooks_parse(const uint8_t *f, size_t size, size_t *pos, uint32_t K, uint32_t C, qvz_codebook_t ***out);
+int qvz_read_whole_file(const char *path, uint8_t **buf, size_t *size);
+/* start_qv_decompression (qv_compressor.c:145-231) over memory: the serial chain and the WELL draws on one host core */
+int qvz_decode_stream_host(uint32_t K, uint32_t C, uint64_t lines, const qvz_codebook_t *const *cbs, const uint32_t *well,
+                           const uint8_t *stream, size_t size, FILE *fo, int verbose);
+/* S streams of one file (qvz_shard_bounds(N, S)) decoded at once on the GPU, written as text to out_path */
+int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codebook_t *const *cbs, const uint32_t *well,
+                           uint32_t shards, const uint8_t *const *streams, const uint64_t *sizes, const char *out_path, int device);
 
 int qvz_job_fail(int code, const char *fmt, ...);
 

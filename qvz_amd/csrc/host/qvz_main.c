@@ -1,14 +1,17 @@
 /* qvz - command line front end with the reference's grammar (mikelhernaez/qvz src/main.c:189-356):
  *     qvz (options) [input file] [output file]
- * one token per option, an option's value is the next argv, no combined short options. Encoding runs on the
- * MI355X through libqvzhip; `-x` (decoding) is outside this build's scope and is reported as such.
- * Environment (additions): QVZ_WELL_SEED=debug|time (default time), QVZ_DEVICE=<ordinal>, QVZ_CHUNK_READS=<n>. */
+ * one token per option, an option's value is the next argv, no combined short options. Encoding and decoding (`-x`) run
+ * on the MI355X through libqvzhip.
+ * Environment (additions): QVZ_WELL_SEED=debug|time (default time), QVZ_DEVICE=<ordinal>,
+ * QVZ_CHUNK_READS=<n>, QVZ_SHARDS=<n> (sharded output: one shard-set file, include/qvz_shardset.h; with
+ * QVZ_SHARD_FILES=1 one reference-format file per shard instead), QVZ_INPUT=fastq|qual. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
 #include "qvz_encode.h"
+#include "qvz_shardset.h"
 
 static void usage(const char *name) {   /* main.c:166-184 */
     printf("Usage: %s (options) [input file] [output file]\n", name);
@@ -105,8 +108,9 @@ int main(int argc, char **argv) {
         }
     }
     if (extract) {                                                /* main.c:132-183 */
-        /* QVZ_SHARDS=N: the input is the prefix of N shard files written by a sharded encode */
-        const uint32_t nsh = getenv("QVZ_SHARDS") ? (uint32_t)strtoul(getenv("QVZ_SHARDS"), 0, 10) : 0;
+        /* a reference-format file or a shard set: qvz_decode_file looks at the first bytes. QVZ_SHARDS=N with
+         * QVZ_SHARD_FILES=1: the input is the prefix of N reference-format shard files */
+        const uint32_t nsh = getenv("QVZ_SHARDS") && getenv("QVZ_SHARD_FILES") && atoi(getenv("QVZ_SHARD_FILES")) ? (uint32_t)strtoul(getenv("QVZ_SHARDS"), 0, 10) : 0;
         const int dev = getenv("QVZ_DEVICE") ? atoi(getenv("QVZ_DEVICE")) : 0;
         qvz_result_t dres;
         struct timespec t0, t1;
@@ -129,10 +133,13 @@ int main(int argc, char **argv) {
     if (getenv("QVZ_CHUNK_READS")) opts.chunk_reads = strtoull(getenv("QVZ_CHUNK_READS"), 0, 10);
 
     qvz_result_t res;
-    /* QVZ_SHARDS=N (not a reference option, so not on the command line): N reference-format files <output>.0000 ... */
+    /* QVZ_SHARDS=N (not a reference option, so not on the command line): N independent streams coded on the GPU, written
+     * as one shard set, or with QVZ_SHARD_FILES=1 as N reference-format files <output>.0000 ... */
     const uint32_t shards = getenv("QVZ_SHARDS") ? (uint32_t)strtoul(getenv("QVZ_SHARDS"), 0, 10) : 0;
-    const int rc = shards ? qvz_encode_file_sharded(input_name, output_name, &opts, shards, &res)
-                          : qvz_encode_file(input_name, output_name, &opts, &res);
+    const int files = getenv("QVZ_SHARD_FILES") && atoi(getenv("QVZ_SHARD_FILES"));
+    const int rc = !shards ? qvz_encode_file(input_name, output_name, &opts, &res)
+                   : files ? qvz_encode_file_sharded(input_name, output_name, &opts, shards, &res)
+                           : qvz_encode_file_shardset(input_name, output_name, &opts, shards, &res);
     if (rc) {
         printf("%s\n", qvz_encode_last_error());                  /* reference: printf + exit(1), main.c:43-46 */
         exit(1);

@@ -8,14 +8,19 @@
 #include "qvz_coder.h"
 
 void qvz_shard_bounds(uint64_t n, uint32_t shards, uint64_t *first) {
+    /* Shares are dealt in units of 4 reads (4 reads x C draws = C whole WELL words), shard g starting at group
+     * floor(groups * g / shards): with shards <= groups no shard is empty (a reference-format file of 0 lines makes the
+     * reference decoder loop over 2^32 lines, qv_compressor.c:166); the reads past the last whole group go to the last shard. */
     if (shards == 0) shards = 1;
-    const uint64_t per = (n + shards - 1) / shards;
-    const uint64_t per4 = (per + 3) & ~3ull;                 /* 4 reads x C draws = C whole WELL words */
-    for (uint32_t g = 0; g <= shards; ++g) {
-        const uint64_t f = (uint64_t)g * per4;
-        first[g] = f < n ? f : n;
-    }
+    const uint64_t groups = n / 4;
+    for (uint32_t g = 0; g < shards; ++g)
+        first[g] = 4 * (uint64_t)(((unsigned __int128)groups * g) / shards);
     first[shards] = n;
+}
+
+uint32_t qvz_shard_limit(uint64_t n) {                       /* most shards n reads can be cut into without an empty one */
+    const uint64_t groups = n / 4;
+    return groups < 1 ? 1u : groups > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)groups;
 }
 
 typedef struct {

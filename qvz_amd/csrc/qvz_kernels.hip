@@ -977,6 +977,76 @@ extern "C" int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32
     return rc;
 }
 
+// dst[b] = (jump[b] >> bit) & 1 ? M * src[b] : src[b]: one level of many different jumps at once (thread r owns output bit r)
+__global__ __launch_bounds__(1024) void k_gf2_apply_if(const uint32_t *__restrict__ M, const uint32_t *__restrict__ src,
+                                                        uint32_t *__restrict__ dst, const uint64_t *__restrict__ jump, int bit,
+                                                        uint64_t count) {
+    __shared__ uint32_t sv[WELL_SPB][32];
+    const uint64_t b0 = (uint64_t)blockIdx.x * WELL_SPB;
+    const uint32_t r = threadIdx.x;
+    if (r < WELL_SPB * 32) {
+        const uint64_t st = b0 + (r >> 5);
+        sv[r >> 5][r & 31] = st < count ? src[st * 32 + (r & 31)] : 0;
+    }
+    uint32_t row[32];
+    const uint4 *mrow = reinterpret_cast<const uint4 *>(M + (uint64_t)r * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint4 t = mrow[q];
+        row[4 * q] = t.x; row[4 * q + 1] = t.y; row[4 * q + 2] = t.z; row[4 * q + 3] = t.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sidx = 0; sidx < WELL_SPB; ++sidx) {
+        if (b0 + sidx >= count) break;                            // block-uniform
+        const bool on = (jump[b0 + sidx] >> bit) & 1;             // block-uniform
+        uint32_t x = 0;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) x ^= row[w] & sv[sidx][w];
+        const unsigned long long bal = __ballot(__popc(x) & 1);
+        if ((r & 63) == 0) {
+            dst[(b0 + sidx) * 32 + (r >> 5)] = on ? (uint32_t)bal : sv[sidx][r >> 5];
+            dst[(b0 + sidx) * 32 + (r >> 5) + 1] = on ? (uint32_t)(bal >> 32) : sv[sidx][(r >> 5) + 1];
+        }
+    }
+}
+
+// Generator states after h_jump[i] outputs each (rotated to n = 0), i = 0 .. count-1: what the .q headers of `count`
+// shards store. One masked batched mat-vec per bit of the jumps instead of a chain of launches per shard.
+extern "C" int qvz_hip_well_jump_many(const uint32_t *h_state, const uint64_t *h_jump, uint64_t count, uint32_t *h_states_out) {
+    if (!h_state || !h_jump || !h_states_out) return qvz_set_error(QVZ_E_ARG, "null argument");
+    if (count == 0) return QVZ_OK;
+    int rc = well_init(0);
+    if (rc) return rc;
+    uint64_t top = 0;
+    for (uint64_t i = 0; i < count; ++i) top |= h_jump[i];
+    if (top >> WELL_MAXJ) return qvz_set_error(QVZ_E_ARG, "WELL jump too large");
+    uint32_t *d_a = nullptr, *d_b = nullptr;
+    uint64_t *d_jump = nullptr;
+    uint32_t *h_init = (uint32_t *)malloc(count * 128);
+    if (!h_init) return qvz_set_error(QVZ_E_NOMEM, "host alloc");
+    for (uint64_t i = 0; i < count; ++i) memcpy(h_init + i * 32, h_state, 128);
+    hipError_t e = hipMalloc(&d_a, count * 128);
+    if (e == hipSuccess) e = hipMalloc(&d_b, count * 128);
+    if (e == hipSuccess) e = hipMalloc(&d_jump, count * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemcpy(d_a, h_init, count * 128, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_jump, h_jump, count * sizeof(uint64_t), hipMemcpyHostToDevice);
+    free(h_init);
+    if (e == hipSuccess) {
+        for (int j = 0; j < WELL_MAXJ && (top >> j); ++j) {
+            if (!((top >> j) & 1)) continue;
+            hipLaunchKernelGGL(k_gf2_apply_if, dim3((unsigned)((count + WELL_SPB - 1) / WELL_SPB)), dim3(1024), 0, 0,
+                               g_well.d_pow + (size_t)j * 1024 * 32, d_a, d_b, d_jump, j, count);
+            uint32_t *t = d_a; d_a = d_b; d_b = t;
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_states_out, d_a, count * 128, hipMemcpyDeviceToHost);
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_jump);
+    if (e != hipSuccess) return qvz_set_error(QVZ_E_HIP, "qvz_hip_well_jump_many: %s", hipGetErrorString(e));
+    return QVZ_OK;
+}
+
 extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
                                   void *stream) {
     if (nwords == 0) return QVZ_OK;

@@ -72,6 +72,50 @@ def encode_file_sharded(in_path, out_prefix, shards, clusters=1, mode=MODE_RATIO
     return r
 
 
+class ShardsetInfo(C.Structure):
+    """qvz_shardset_info_t (include/qvz_shardset.h)."""
+    _fields_ = [("clusters", C.c_uint32), ("columns", C.c_uint32), ("shards", C.c_uint32), ("lines", C.c_uint64),
+                ("header_bytes", C.c_uint64), ("codebook_bytes", C.c_uint64), ("stream_bytes", C.c_uint64),
+                ("file_bytes", C.c_uint64)]
+
+
+def encode_file_shardset(in_path, out_path, shards, clusters=1, mode=MODE_RATIO, ratio=0.5, dist="M", threshold=4.0,
+                         u_path=None, seed_mode=None, device=0):
+    """Whole-file sharded encode into ONE shard-set file (qvz_encode_file_shardset): codebooks stored once."""
+    o = default_options()
+    o.clusters, o.mode, o.ratio, o.distortion, o.cluster_threshold = clusters, mode, ratio, DIST.get(dist, dist), threshold
+    o.device = device
+    if u_path:
+        o.uncompressed_name = u_path.encode()
+    if seed_mode is not None:
+        o.seed_mode = seed_mode
+    r = Result()
+    rc = lib().qvz_encode_file_shardset(in_path.encode(), out_path.encode(), C.byref(o), shards, C.byref(r))
+    if rc:
+        raise QvzHipError(f"qvz_encode_file_shardset failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return r
+
+
+def shardset_stat(path):
+    si = ShardsetInfo()
+    rc = lib().qvz_shardset_stat(path.encode(), C.byref(si))
+    if rc:
+        raise QvzHipError(f"qvz_shardset_stat failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return si
+
+
+def shardset_split(path, prefix, first=0, count=0, device=0):
+    rc = lib().qvz_shardset_split(path.encode(), prefix.encode(), first, count, device)
+    if rc:
+        raise QvzHipError(f"qvz_shardset_split failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+
+
+def shardset_bytes(clusters_handles, columns, lines, well_state, streams):
+    """Size bookkeeping of a shard set holding `streams` (list of bytes) without writing it: (header, codebooks, streams)."""
+    cb = sum(int(lib().qvz_codebook_write(None, h)) for h in clusters_handles)
+    return 160 + 8 * len(streams), cb, sum(len(s) for s in streams)
+
+
 def shard_bounds(n, shards):
     """first[g] for g = 0..shards; every shard starts at a multiple of 4 reads (a WELL word boundary)."""
     first = (C.c_uint64 * (shards + 1))()
