@@ -16,6 +16,10 @@ scaling: every rank holds --reads reads); the only exchanges are the small all-r
 Prints ONE JSON line on rank 0: metric/value/unit, ms_per_step, bits_per_symbol, per-phase seconds, a `roofline`
 object for the dominant GPU kernel (HIP events around each launch on the launch stream) and a `cpu_baseline`
 object (reference qvz, or the CPU oracle when the reference binary is absent, on a bounded sample).
+Beside the headline number the line says what the product of a step costs outside the timed region: `product` (bytes on
+disk of the shard set: codebooks once + streams; D2H and file assembly seconds, measured once after the timed steps),
+`ingest` (text -> HBM, a bounded sample through the C driver's staging path), `strict` (the byte-identical single-stream
+.q on a bounded sample) and a PMF pass over a full 72-symbol alphabet.
 """
 import argparse
 import json
@@ -47,7 +51,7 @@ ALG_BYTES_PER_SYMBOL = {
     "pmf_hist": 1.0,             # each symbol read once (+1 B/read of labels when k > 1, added below)
     "kmeans_assign": 1.0,
     "kmeans_accumulate": 1.0,    # + labels re-read per column when k > 1 (2 B/sym)
-    "quantize": 4.0,             # symbol in, draw in, (qi, st) out; qv (the -u product) is written only when asked for (+1)
+    "quantize": 5.0,             # symbol in, draw in, (qv, qi, st) out: the -u product and the coder's two planes
     "well_draws": 3.0,           # word stream written once and read once, draw matrix written once
     "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out (host / gpu-feed coders only)
     "model_records": 18.0,       # qi + st in, one 16-byte record out
@@ -107,6 +111,91 @@ def cpu_baseline(cfg, cores_note):
                 extrapolated_full_workload_value=round(full / (fixed + slope * full), 1), host=cores_note)
 
 
+def product_report(r, n, c, k, shards, steps, elapsed):
+    """What the streams of the last timed step cost as a product: packed on the device, copied to the host, written as ONE
+    shard set (include/qvz_shardset.h: codebooks once + stream index + streams); measured once, outside the timed steps."""
+    import torch
+    from qvz_amd import host
+    sizes = r["stream_bytes"]
+    handles = [cb.handle for cb in r["codebooks"]]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    packed = host.gather_streams(r["coded"], r["cap_per_shard"], sizes)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    pinned = torch.empty(packed.numel(), dtype=torch.uint8, pin_memory=True)
+    t2 = time.perf_counter()
+    pinned.copy_(packed, non_blocking=True)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "out.qvzset")
+        si = host.shardset_write(path, c, n, np.full(32, 0x55555555, dtype=np.uint32), handles, pinned, sizes)
+        t4 = time.perf_counter()
+        assert os.path.getsize(path) == si.file_bytes
+    cb_bytes = int(si.codebook_bytes)
+    ref_files = shards * (9 + cb_bytes + 128) + int(si.stream_bytes)     # the same streams as `shards` reference-format files
+    sym = float(n) * c
+    step_s = elapsed / steps
+    return dict(container="one shard set (include/qvz_shardset.h): 160-byte header + 8 B per stream + the codebooks once + the streams",
+                streams=shards, file_bytes_total=int(si.file_bytes), file_bits_per_symbol=round(si.file_bytes * 8.0 / sym, 5),
+                stream_bytes=int(si.stream_bytes), codebook_bytes=cb_bytes, header_bytes=int(si.header_bytes),
+                as_reference_format_shard_files_bytes=ref_files,
+                as_reference_format_shard_files_bits_per_symbol=round(ref_files * 8.0 / sym, 5),
+                pack_on_device_seconds=round(t1 - t0, 4), d2h_seconds=round(t3 - t2, 4), pinned_alloc_seconds=round(t2 - t1, 4),
+                file_write_seconds=round(t4 - t3, 4), e2e_seconds=round(step_s + (t1 - t0) + (t3 - t2) + (t4 - t3), 4),
+                e2e_note="ms_per_step + device pack + D2H + shard-set write to a temporary file (page cache); input already in HBM")
+
+
+def ingest_report(cfg, n, c):
+    """Text -> HBM through the C driver's staging path (qvz_ingest_rows: threaded host copy into pinned buffers, PCIe,
+    transposing kernel, overlapped), on a bounded sample; the full workload's input is n * (c + 1) bytes."""
+    import torch
+    from qvz_amd import host
+    from qvz_amd import kernels as K
+    m = min(n, 4_000_000)
+    sample = K.untranspose_text(K.qgen1(cfg["seed"], m, c), m).cpu()            # m rows of text in (pageable) host memory
+    sym = K.empty_matrix(m, c)
+    host.ingest_rows(sample, m, c, sym)                                          # first call: allocations, page faults
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bad = host.ingest_rows(sample, m, c, sym)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nbytes = m * (c + 1)
+    full = n * (c + 1)
+    return dict(sample_bytes=nbytes, seconds=round(dt, 4), gb_per_s=round(nbytes / dt / 1e9, 2), bad_bytes=bad,
+                ingest_seconds=round(full / (nbytes / dt), 3), full_input_bytes=full,
+                note="PCIe-inclusive; not part of `value` (inputs are resident in HBM when the timed region starts)")
+
+
+def pmf72_report(n, c):
+    """The PMF pass over a matrix that uses all 72 symbols of the alphabet uniformly (QGEN-1 populates 40): the counter
+    tiles are 72 x 72 instead of the populated sub-block."""
+    import torch
+    from qvz_amd import kernels as K
+    sym = K.empty_matrix(n, c)
+    step = 1 << 28
+    flat = sym.view(-1)
+    for a in range(0, flat.numel(), step):                                       # torch.randint in pieces (its int64 temporaries are large)
+        flat[a:a + step] = torch.randint(0, 72, (min(step, flat.numel() - a),), dtype=torch.uint8, device=sym.device)
+    cnt = torch.zeros((1, c, 72, 72), dtype=torch.int32, device=sym.device)
+    K.pmf_hist(sym, n, cnt=cnt)
+    ms = []
+    for _ in range(3):
+        cnt.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        K.pmf_hist(sym, n, cnt=cnt)
+        b.record()
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    assert int(cnt.sum(dtype=torch.int64).item()) == n * c
+    ach = n * c / (min(ms) * 1e-3) / 1e9
+    return dict(kernel="pmf_hist", alphabet=72, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                frac=round(ach / HBM_PEAK_GBPS, 4), ms_per_launch=round(min(ms), 4))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +208,8 @@ def main():
     ap.add_argument("--coder", choices=["host", "gpu", "gpu-feed"], default="gpu",
                     help="arithmetic coder: host threads, or one GPU lane per shard (byte-identical streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the product / ingest / strict / 72-symbol PMF measurements after the timed steps")
+    ap.add_argument("--no-u", action="store_true", help="do not write the quantized-value plane (the -u product) in the timed step")
     ap.add_argument("--roundtrip", action="store_true",
                     help="after the timed steps, decode every stream on the GPU and compare with the quantizer's output")
     args = ap.parse_args()
@@ -157,9 +248,8 @@ def main():
     mode = host.MODE_RATIO if cfg["mode"] == "f" else host.MODE_FIXED
 
     sym = K.qgen1(cfg["seed"], n, c, first=first)          # synthetic input, resident in HBM before timing
-    lines = P.reference_centroid_lines(n_total, k)        # the reads the reference's rand() would pick
-    means0 = torch.stack([K.qgen1(cfg["seed"], 4, c, first=ln - ln % 4)[:, ln % 4] for ln in lines]).contiguous()
     torch.cuda.synchronize()
+    means0 = None      # the k centroid reads the reference's rand() picks are fetched from the ranks that own them, inside the step
 
     def barrier():
         if world > 1:
@@ -169,14 +259,19 @@ def main():
     def step(timer=None):
         return P.encode_pass(sym, n, first, n_total, means0, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"],
                              shards=shards, threads=threads, group=group, timer=timer, device_index=local,
-                             coder=args.coder)
+                             coder=args.coder, keep_device=not args.no_u and args.coder != "host")
 
     for _ in range(args.warmup):
         step()
     timer = P.Timer(True)
     barrier()
     t0 = time.perf_counter()
-    results = [step(timer) for _ in range(args.steps)]
+    results = []
+    for _ in range(args.steps):
+        if results:                        # the device outputs of a finished step (qv plane, coded streams) make room for the next
+            for key in ("coded", "qv", "labels"):
+                results[-1].pop(key, None)
+        results.append(step(timer))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -220,6 +315,8 @@ def main():
         streaming = {kname: v for kname, v in per_step.items() if kname not in CHAIN_KERNELS}
         dom = max(streaming, key=streaming.get)
         bps = ALG_BYTES_PER_SYMBOL[dom]
+        if dom == "quantize" and (args.no_u or args.coder == "host"):
+            bps = 4.0
         extra = 0.0
         if k > 1 and dom == "pmf_hist":
             extra = float(n)
@@ -263,6 +360,13 @@ def main():
         }
         if args.roundtrip and args.coder != "host":
             line["roundtrip"] = roundtrip
+        line["qv_plane_written_in_step"] = not args.no_u and args.coder != "host"
+        if not args.no_extras and world == 1 and args.coder == "gpu" and "coded" in results[-1]:
+            line["product"] = product_report(results[-1], n, c, k, shards, args.steps, elapsed)
+            for key in ("coded", "qv", "labels"):
+                results[-1].pop(key, None)
+            line["ingest"] = ingest_report(cfg, n, c)
+            line["roofline_pmf_hist_72_symbols"] = pmf72_report(n, c)
         if not args.no_cpu_baseline and world == 1:               # the CPU baseline is timed on rank 0 of the 1-GPU run only
             line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")
         print(json.dumps(line), flush=True)

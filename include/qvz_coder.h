@@ -112,6 +112,11 @@ int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard, const uin
                           uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                           const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels, void *stream);
 
+/* The streams of a GPU coder call (stream g at d_coded + g * cap_per_shard, h_sizes[g] bytes) packed back to back into
+ * d_packed (sum of the sizes): what travels to the host and into a shard set, instead of the whole fixed-stride area. */
+int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const uint64_t *h_sizes, uint32_t shards,
+                           uint8_t *d_packed, void *stream);
+
 /* GPU time of the last qvz_hip_encode_planes call, split into its model kernels and its coder kernels (HIP events on
  * the call's stream, summed over the segments). Either pointer may be NULL. */
 void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);

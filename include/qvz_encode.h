@@ -65,6 +65,11 @@ void qvz_options_default(qvz_options_t *o);   /* reference defaults, main.c:198-
 int qvz_fastq_detect(const uint8_t *text, uint64_t bytes);
 int qvz_fastq_qualities(const uint8_t *text, uint64_t bytes, uint8_t **rows_out, uint64_t *reads_out, uint32_t *columns_out);
 
+/* Text rows in host memory (n rows of c+1 bytes, Q+33 ... '\n': the layout load_file maps, src/lines.c:44-71) -> the
+ * column-major symbol matrix d_sym (c x ld, include/qvz_hip.h) through two pinned staging buffers: host copy, PCIe transfer
+ * and the transposing kernel of consecutive chunks overlap. *bad_out: bytes outside '!'..'h' or rows without '\n'. */
+int qvz_ingest_rows(const uint8_t *text, uint64_t n, uint32_t c, uint8_t *d_sym, uint64_t ld, uint32_t *bad_out);
+
 /* text: the whole input file image (rows of c+1 bytes, or FASTQ: see input_format). fout receives the .q file, fu (may be
  * NULL) the -u text. */
 int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,

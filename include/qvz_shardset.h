@@ -50,8 +50,9 @@ typedef struct qvz_shardset_info {
 /* does this buffer start like a shard set? */
 int qvz_shardset_is(const uint8_t *buf, size_t size);
 
-/* Writes a shard set to f. streams: stream g at streams + g * stride, sizes[g] bytes of it valid (the layout the GPU
- * coder leaves in host memory after one copy). info (may be NULL) receives the byte counts. */
+/* Writes a shard set to f. streams: stream g at streams + g * stride, sizes[g] bytes of it valid (the GPU coder's
+ * fixed-stride layout), or with stride = 0 the streams packed back to back (qvz_hip_gather_streams). info (may be NULL)
+ * receives the byte counts. */
 int qvz_shardset_write(FILE *f, uint32_t clusters, uint32_t columns, uint64_t lines, uint32_t shards,
                        const uint32_t *well_state, const qvz_codebook_t *const *cbs, const uint8_t *streams,
                        uint64_t stride, const uint64_t *sizes, qvz_shardset_info_t *info);

@@ -128,26 +128,20 @@ static void parallel_memcpy(uint8_t *dst, const uint8_t *src, size_t n) {
     for (int i = 0; i < T; ++i) if (started[i]) pthread_join(th[i], NULL);
 }
 
-int qvz_job_upload(qvz_job_t *job) {
+/* Streaming, transposing ingest (replaces load_file's row-pointer table, lines.c:27-82): the text goes through two
+ * pinned staging buffers so that the host copy of chunk k+1 (page cache -> pinned), the PCIe transfer of chunk k and its
+ * transposition into the column-major matrix overlap. */
+int qvz_ingest_rows(const uint8_t *text, uint64_t N, uint32_t C, uint8_t *d_sym, uint64_t ld, uint32_t *bad_out) {
     int rc = 0;
-    const double t0 = now();
-    const uint64_t N = job->N, stride = (uint64_t)job->C + 1, ld = job->ld;
-    const uint32_t C = job->C;
+    const uint64_t stride = (uint64_t)C + 1;
     uint8_t *d_up[2] = {NULL, NULL}, *h_up[2] = {NULL, NULL};
     void *st[2] = {NULL, NULL};
     uint32_t *d_bad = NULL;
-    if (job->uploaded) return 0;
-    HIP(qvz_hip_set_device(job->opts.device));
-    /* Streaming, transposing ingest (replaces load_file's row-pointer table, lines.c:27-82): the mmap'd text goes
-     * through two pinned staging buffers so that the host copy of chunk k+1 (page cache -> pinned), the PCIe transfer
-     * of chunk k and its transposition into the column-major matrix overlap. */
     const uint64_t up_reads = 1u << 18;   /* reads per staging buffer; a multiple of 256 */
     const uint64_t up_n = N < up_reads ? N : up_reads;
-    HIP(qvz_hip_malloc((void **)&job->d_sym, (size_t)C * ld));
-    HIP(qvz_hip_malloc((void **)&job->d_labels, ld));
+    if (!text || !N || !C || !d_sym || ld < N) return qvz_job_fail(QVZ_E_ARG, "bad ingest arguments");
     HIP(qvz_hip_malloc((void **)&d_bad, sizeof(uint32_t)));
     HIP(qvz_hip_memset(d_bad, 0, sizeof(uint32_t), NULL));
-    HIP(qvz_hip_memset(job->d_labels, 0, ld, NULL));               /* calloc'd line_t.cluster, lines.c:116 */
     HIP(qvz_hip_stream_sync(NULL));
     for (int b = 0; b < 2; ++b) {
         HIP(qvz_hip_malloc((void **)&d_up[b], (size_t)up_n * stride));
@@ -159,9 +153,9 @@ int qvz_job_upload(qvz_job_t *job) {
         for (uint64_t r0 = 0; r0 < N; r0 += up_reads, b ^= 1) {
             const uint64_t n = N - r0 < up_reads ? N - r0 : up_reads;
             HIP(qvz_hip_stream_sync(st[b]));                       /* this staging pair was used two chunks ago */
-            parallel_memcpy(h_up[b], job->text + r0 * stride, n * stride);
+            parallel_memcpy(h_up[b], text + r0 * stride, n * stride);
             HIP(qvz_hip_copy_h2d(d_up[b], h_up[b], n * stride, st[b]));
-            HIP(qvz_hip_transpose_text(d_up[b], n, C, job->d_sym + r0, ld, d_bad, st[b]));
+            HIP(qvz_hip_transpose_text(d_up[b], n, C, d_sym + r0, ld, d_bad, st[b]));
         }
         HIP(qvz_hip_stream_sync(st[0]));
         HIP(qvz_hip_stream_sync(st[1]));
@@ -170,10 +164,8 @@ int qvz_job_upload(qvz_job_t *job) {
         uint32_t bad = 0;
         HIP(qvz_hip_copy_d2h(&bad, d_bad, sizeof(bad), NULL));
         HIP(qvz_hip_stream_sync(NULL));
-        if (bad) { rc = qvz_job_fail(QVZ_E_DATA, "%u input bytes outside '!'..'h' or lines without '\\n' (undefined behaviour in the reference, pmf.c:372-381)", bad); goto done; }
+        if (bad_out) *bad_out = bad;
     }
-    job->uploaded = 1;
-    job->t_upload = now() - t0;
 done:
     for (int b = 0; b < 2; ++b) {
         qvz_hip_free(d_up[b]);
@@ -181,6 +173,24 @@ done:
         if (st[b]) qvz_hip_stream_destroy(st[b]);
     }
     qvz_hip_free(d_bad);
+    return rc;
+}
+
+int qvz_job_upload(qvz_job_t *job) {
+    int rc = 0;
+    const double t0 = now();
+    const uint64_t ld = job->ld;
+    uint32_t bad = 0;
+    if (job->uploaded) return 0;
+    HIP(qvz_hip_set_device(job->opts.device));
+    HIP(qvz_hip_malloc((void **)&job->d_sym, (size_t)job->C * ld));
+    HIP(qvz_hip_malloc((void **)&job->d_labels, ld));
+    HIP(qvz_hip_memset(job->d_labels, 0, ld, NULL));               /* calloc'd line_t.cluster, lines.c:116 */
+    if ((rc = qvz_ingest_rows(job->text, job->N, job->C, job->d_sym, ld, &bad))) goto done;
+    if (bad) { rc = qvz_job_fail(QVZ_E_DATA, "%u input bytes outside '!'..'h' or lines without '\\n' (undefined behaviour in the reference, pmf.c:372-381)", bad); goto done; }
+    job->uploaded = 1;
+    job->t_upload = now() - t0;
+done:
     return rc;
 }
 
@@ -553,14 +563,19 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
             if (crc == QVZ_OK) break;
             if (crc != QVZ_E_NOMEM || bits >= 24) { rc = qvz_job_fail(crc, "%s", qvz_hip_last_error()); goto done; }
         }
-        h_buf = (uint8_t *)malloc((size_t)shards * cap);
-        if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        HIP(qvz_hip_copy_d2h(h_buf, d_out, (size_t)shards * cap, NULL));
-        HIP(qvz_hip_stream_sync(NULL));
         for (uint32_t g = 0; g < shards; ++g) total += sizes[g];
+        /* the streams leave the device packed back to back: 1-2 bits per symbol instead of the 6 the area was sized for */
+        qvz_hip_free(d_qi); d_qi = NULL;
+        qvz_hip_free(d_st); d_st = NULL;
+        HIP(qvz_hip_malloc((void **)&d_text, total ? total : 1));
+        HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_text, NULL));
+        h_buf = (uint8_t *)malloc(total ? total : 1);
+        if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        HIP(qvz_hip_copy_d2h(h_buf, d_text, total, NULL));
+        HIP(qvz_hip_stream_sync(NULL));
         if (fset) {                                                             /* one shard set: codebooks once (qvz_shardset.h) */
             qvz_shardset_info_t si;
-            if ((rc = qvz_shardset_write(fset, K, C, N, shards, job->well_state, (const qvz_codebook_t *const *)job->cbs, h_buf, cap, sizes, &si))) goto done;
+            if ((rc = qvz_shardset_write(fset, K, C, N, shards, job->well_state, (const qvz_codebook_t *const *)job->cbs, h_buf, 0, sizes, &si))) goto done;
             ftotal = si.file_bytes;
         } else {                                                                /* one reference-format file per shard */
             uint64_t img_cap = 0;
@@ -571,7 +586,8 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
             const int jrc = qvz_hip_well_jump_many(job->well_state, jump, shards, wstates);
             free(jump);
             if (jrc) { rc = qvz_job_fail(jrc, "%s", qvz_hip_last_error()); goto done; }
-            for (uint32_t g = 0; g < shards; ++g) {
+            uint64_t at = 0;
+            for (uint32_t g = 0; g < shards; at += sizes[g], ++g) {
                 char name[4096];
                 const uint64_t reads = first[g + 1] - first[g];
                 FILE *f;
@@ -584,7 +600,7 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
                     img_cap = need;
                     if (!image) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
                 }
-                qvz_shard_file_image(image, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstates + (size_t)g * 32, h_buf + (size_t)g * cap, sizes[g]);
+                qvz_shard_file_image(image, K, C, reads, (const qvz_codebook_t *const *)job->cbs, wstates + (size_t)g * 32, h_buf + at, sizes[g]);
                 f = fopen(name, "wb");
                 if (!f) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
                 if (fwrite(image, 1, need, f) != need) { fclose(f); rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }

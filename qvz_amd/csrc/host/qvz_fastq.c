@@ -66,6 +66,7 @@ typedef struct {
     uint32_t columns;
     uint8_t *out;                 /* NULL in the counting pass */
     uint64_t first_row, count;
+    uint64_t start, end;          /* where this range's first record starts and its last one ends (count > 0) */
     int rc;
     uint64_t bad_at;
 } fq_range;
@@ -100,8 +101,10 @@ static void *fq_worker(void *arg) {
             memcpy(row, L[3].p, r->columns);
             row[r->columns] = '\n';
         }
+        if (n == 0) r->start = o;
         n += 1;
         o = next;
+        r->end = o;
     }
     r->count = n;
     return NULL;
@@ -144,6 +147,21 @@ int qvz_fastq_qualities(const uint8_t *text, uint64_t bytes, uint8_t **rows_out,
                                     (unsigned long long)R[i].bad_at, columns);
             }
             total += R[i].count;
+        }
+        if (pass == 0) {
+            /* A range other than the first finds its first record by skipping lines until one starts a record; a malformed
+             * record (or one of another read length) right at the boundary would be skipped without a word. So the ranges
+             * must chain: each one's first record starts where the previous one's last record ended. */
+            uint64_t expect = 0;
+            for (int i = 0; i < nt; ++i) {
+                if (!R[i].count) continue;
+                if (R[i].start != expect) {
+                    free(rows);
+                    return qvz_job_fail(QVZ_E_DATA, "FASTQ record at byte %llu is malformed or its read length differs from %u",
+                                        (unsigned long long)expect, columns);
+                }
+                expect = R[i].end;
+            }
         }
         if (pass == 0) {
             rows = (uint8_t *)malloc((size_t)(total ? total : 1) * ((size_t)columns + 1));

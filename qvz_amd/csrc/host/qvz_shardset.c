@@ -46,9 +46,12 @@ int qvz_shardset_write(FILE *f, uint32_t clusters, uint32_t columns, uint64_t li
         if (w != sz) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
         cb_total += sz;
     }
-    for (uint32_t g = 0; g < shards; ++g) {
-        if (sizes[g] && fwrite(streams + (size_t)g * stride, 1, sizes[g], f) != sizes[g]) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
-        st_total += sizes[g];
+    for (uint32_t g = 0; g < shards; ++g) st_total += sizes[g];
+    if (stride == 0) {                                                          /* packed: one write */
+        if (st_total && fwrite(streams, 1, st_total, f) != st_total) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+    } else {
+        for (uint32_t g = 0; g < shards; ++g)
+            if (sizes[g] && fwrite(streams + (size_t)g * stride, 1, sizes[g], f) != sizes[g]) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
     }
     if (info) {
         memset(info, 0, sizeof(*info));

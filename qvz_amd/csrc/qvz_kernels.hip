@@ -1450,6 +1450,42 @@ extern "C" int qvz_hip_pack_feed(const uint8_t *d_qi, const uint8_t *d_st, uint6
 // ------------------------------------------------------------------------------------------------
 // memory / stream plumbing for host C callers
 // ------------------------------------------------------------------------------------------------
+// ---- streams out of the coder's fixed-stride area into one packed run (what goes to the host / into a shard set) ----
+__global__ __launch_bounds__(256) void k_gather_streams(const uint8_t *__restrict__ in, uint64_t cap, const uint64_t *__restrict__ sizes,
+                                                        const uint64_t *__restrict__ at, uint8_t *__restrict__ out) {
+    const uint32_t g = blockIdx.x;
+    const uint64_t sz = sizes[g];
+    const uint8_t *src = in + (uint64_t)g * cap;                 // 4-byte aligned (cap is a multiple of 4)
+    uint8_t *dst = out + at[g];                                  // any alignment
+    for (uint64_t i = (uint64_t)blockIdx.y * 256 + threadIdx.x; i < sz; i += (uint64_t)gridDim.y * 256) dst[i] = src[i];
+}
+
+extern "C" int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const uint64_t *h_sizes, uint32_t shards,
+                                      uint8_t *d_packed, void *stream) {
+    if (!d_coded || !h_sizes || !shards || !d_packed) return qvz_set_error(QVZ_E_ARG, "bad gather arguments");
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t *h = (uint64_t *)malloc((size_t)shards * 2 * sizeof(uint64_t)), *d = nullptr;
+    if (!h) return qvz_set_error(QVZ_E_NOMEM, "host alloc");
+    uint64_t at = 0, longest = 0;
+    for (uint32_t g = 0; g < shards; ++g) {
+        if (h_sizes[g] > cap_per_shard) { free(h); return qvz_set_error(QVZ_E_ARG, "stream %u longer than cap_per_shard", g); }
+        h[g] = h_sizes[g]; h[shards + g] = at; at += h_sizes[g];
+        if (h_sizes[g] > longest) longest = h_sizes[g];
+    }
+    hipError_t e = hipMalloc(&d, (size_t)shards * 2 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d, h, (size_t)shards * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const unsigned ny = (unsigned)((longest + 16383) / 16384);       // 64 bytes per thread at most
+        hipLaunchKernelGGL(k_gather_streams, dim3(shards, ny ? ny : 1), dim3(256), 0, st, d_coded, cap_per_shard, d, d + shards, d_packed);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);            // h and d go away below
+    free(h);
+    (void)hipFree(d);
+    if (e != hipSuccess) return qvz_set_error(QVZ_E_HIP, "qvz_hip_gather_streams: %s", hipGetErrorString(e));
+    return QVZ_OK;
+}
+
 extern "C" int qvz_hip_set_device(int device) { QVZ_HIP_CHECK(hipSetDevice(device)); return QVZ_OK; }
 extern "C" int qvz_hip_malloc(void **d_ptr, size_t bytes) { QVZ_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1)); return QVZ_OK; }
 extern "C" int qvz_hip_free(void *d_ptr) { if (d_ptr) QVZ_HIP_CHECK(hipFree(d_ptr)); return QVZ_OK; }

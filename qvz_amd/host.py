@@ -110,10 +110,53 @@ def shardset_split(path, prefix, first=0, count=0, device=0):
         raise QvzHipError(f"qvz_shardset_split failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
 
 
-def shardset_bytes(clusters_handles, columns, lines, well_state, streams):
-    """Size bookkeeping of a shard set holding `streams` (list of bytes) without writing it: (header, codebooks, streams)."""
-    cb = sum(int(lib().qvz_codebook_write(None, h)) for h in clusters_handles)
-    return 160 + 8 * len(streams), cb, sum(len(s) for s in streams)
+def gather_streams(coded, cap_per_shard, sizes):
+    """Packs the streams of a GPU coder call (stream g at g * cap_per_shard) back to back on the device."""
+    import torch
+    shards = len(sizes)
+    total = int(sum(sizes))
+    packed = torch.empty(max(total, 1), dtype=torch.uint8, device=coded.device)
+    sz = (C.c_uint64 * shards)(*[int(x) for x in sizes])
+    rc = lib().qvz_hip_gather_streams(C.c_void_p(coded.data_ptr()), cap_per_shard, sz, shards, C.c_void_p(packed.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        raise QvzHipError(f"qvz_hip_gather_streams failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
+    return packed[:total]
+
+
+def shardset_write(path, columns, lines, well_state, codebook_handles, packed_host, sizes):
+    """Writes a shard set (include/qvz_shardset.h) from streams packed back to back in host memory (numpy uint8 / pinned
+    tensor). Returns its ShardsetInfo."""
+    k, shards = len(codebook_handles), len(sizes)
+    arr = (C.c_void_p * k)(*codebook_handles)
+    sz = (C.c_uint64 * shards)(*[int(x) for x in sizes])
+    ws = np.ascontiguousarray(well_state, dtype=np.uint32)
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    f = libc.fopen(path.encode(), b"wb")
+    if not f:
+        raise OSError(f"cannot open {path}")
+    si = ShardsetInfo()
+    ptr = packed_host.data_ptr() if hasattr(packed_host, "data_ptr") else packed_host.ctypes.data
+    rc = lib().qvz_shardset_write(f, k, columns, lines, shards, ws.ctypes.data_as(C.POINTER(C.c_uint32)), arr, C.c_void_p(ptr), 0, sz,
+                                  C.byref(si))
+    libc.fclose(f)
+    if rc:
+        raise QvzHipError(f"qvz_shardset_write failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return si
+
+
+def ingest_rows(text_host, n, columns, sym):
+    """qvz_ingest_rows: host text rows (numpy uint8 / tensor, n * (columns+1) bytes) -> the device symbol matrix `sym`
+    through the C driver's pinned staging path. Returns the number of bad bytes."""
+    bad = C.c_uint32(0)
+    ptr = text_host.data_ptr() if hasattr(text_host, "data_ptr") else text_host.ctypes.data
+    rc = lib().qvz_ingest_rows(C.c_void_p(ptr), n, columns, C.c_void_p(sym.data_ptr()), sym.shape[1], C.byref(bad))
+    if rc:
+        raise QvzHipError(f"qvz_ingest_rows failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return int(bad.value)
 
 
 def shard_bounds(n, shards):

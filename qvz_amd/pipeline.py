@@ -38,13 +38,12 @@ def reference_centroid_lines(n_total, k, reseed=True):
 
 
 def rank_read_range(n_total, world, rank):
-    """Contiguous reads [first, last) of `rank` when a file of n_total reads is sharded over `world` ranks: equal
-    shares rounded up to a multiple of 4 reads, so every shard's first draw (first*C) sits on a WELL word boundary
-    (4 reads x C draws = C whole 4-draw words) for any C."""
-    per = -(-n_total // world)
-    per4 = (per + 3) & ~3
-    first = min(rank * per4, n_total)
-    last = n_total if rank == world - 1 else min((rank + 1) * per4, n_total)
+    """Contiguous reads [first, last) of `rank` when a file of n_total reads is sharded over `world` ranks: the same
+    split as the coder's shards (qvz_shard_bounds: groups of 4 reads dealt evenly), so every rank's first draw (first*C)
+    sits on a WELL word boundary (4 reads x C draws = C whole 4-draw words) for any C."""
+    groups = n_total // 4
+    first = 4 * (groups * rank // world)
+    last = n_total if rank == world - 1 else 4 * (groups * (rank + 1) // world)
     return first, last
 
 
@@ -83,37 +82,158 @@ class _Span:
             self.t.spans.append((self.name, self.a, b))
 
 
+class HipBackend:
+    """The compute side of encode_pass: every method is one call into the C-ABI (HIP kernels / host C) on this process's
+    GPU. encode_pass itself holds only what ranks have to agree on - which reads a rank owns, what is summed across ranks
+    and when, which WELL offset a shard starts from - so that the same schedule can be driven by another backend (the
+    tests run it over two gloo ranks with the CPU oracle as backend, tests/cpu_backend.py)."""
+
+    def __init__(self, device_index=0, timer=None):
+        self.device = torch.device("cuda", device_index)
+        self.device_index = device_index
+        self.timer = timer or Timer(False)
+        self._side = None
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def read_rows(self, sym, idx):
+        """symbols of the reads idx (local indices) as a (len(idx), c) uint8 tensor"""
+        return sym[:, torch.as_tensor(idx, dtype=torch.long, device=sym.device)].t().contiguous()
+
+    def kmeans_assign(self, sym, n, means, labels, counts):
+        with self.timer.span("kmeans_assign"):
+            K.kmeans_assign(sym, n, means, labels=labels, counts=counts)
+
+    def kmeans_accumulate(self, sym, n, labels, k, acc):
+        with self.timer.span("kmeans_accumulate"):
+            K.kmeans_accumulate(sym, n, labels, k, acc=acc)
+
+    def kmeans_update(self, acc, counts, means):
+        return K.kmeans_update(acc, counts, means)
+
+    def pmf_hist(self, sym, n, labels, k, cnt):
+        with self.timer.span("pmf_hist"):
+            K.pmf_hist(sym, n, labels=labels, k=k, cnt=cnt)
+
+    def start_draws(self, well_state, first_read, n, c):
+        """WELL draws (well.c:8-46) of this shard: they depend on the seed only, so they are generated on a side stream
+        while k-means, the counters and the codebooks (small latency-bound kernels + host work) are being made."""
+        main_stream = torch.cuda.current_stream()
+        self._side = torch.cuda.Stream(device=self.device)
+        draws = K.empty_matrix(n, c)         # allocated on the main stream (the caching allocator pools per stream)
+        self._side.wait_stream(main_stream)
+        with torch.cuda.stream(self._side):
+            with self.timer.span("well_draws"):
+                K.well_draws(well_state, first_read, n, c, out=draws)
+        return draws
+
+    def codebooks(self, cnt, dmat, mode, ratio):
+        k = cnt.shape[0]
+        cbs, deferred = [], 0
+        if k == 1:
+            cb, deferred = K.generate_codebook(cnt[0], dmat, mode, ratio)
+            return [cb], deferred
+        # the clusters' codebooks are independent and each generation is latency-bound (small kernels, host round trips):
+        # one host thread and one HIP stream per cluster (ctypes releases the GIL in the call)
+        from concurrent.futures import ThreadPoolExecutor
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=self.device) for _ in range(k)]
+
+        def one(j):
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(streams[j]):
+                return K.generate_codebook(cnt[j], dmat, mode, ratio)
+
+        with ThreadPoolExecutor(max_workers=k) as pool:
+            for cb, d in pool.map(one, range(k)):
+                cbs.append(cb)
+                deferred += d
+        return cbs, deferred
+
+    def quantize(self, sym, n, cbs, draws, dmat, labels, k, want):
+        ct, qs = K.upload_tables(cbs, self.device)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        ddist = torch.from_numpy(dmat).to(self.device)
+        with self.timer.span("quantize"):
+            return K.quantize(sym, n, ct, qs, draws, ddist, labels=labels, k=k, want=want)
+
+    def code(self, out, labels, n, c, cbs, shards, threads, coder, keep, work_bytes):
+        """-> (stream sizes, streams as bytes | None, coded device tensor | None, feed | None, (model ms, coder ms) | None)"""
+        handles = [cb.handle for cb in cbs]
+        feed = None
+        if coder != "gpu" or keep:
+            with self.timer.span("pack_feed"):
+                feed = K.pack_feed(out["qi"], out["st"], n)
+        if coder == "gpu":
+            with self.timer.span("arith_shards"):
+                sizes, streams, coded = host.encode_planes_gpu(out["qi"], out["st"], labels, n, c, handles, shards,
+                                                               want_streams=keep, work_bytes=work_bytes)
+            return sizes, streams, coded, feed, host.encode_planes_gpu.last_ms
+        if coder == "gpu-feed":
+            with self.timer.span("arith_shards"):
+                sizes, streams, coded = host.encode_shards_gpu(feed, labels, n, c, handles, shards, want_streams=keep)
+            return sizes, streams, coded, feed, None
+        streams = host.encode_shards_device(feed, labels, n, c, handles, shards, threads, device=self.device_index)
+        return [len(s) for s in streams], streams, None, feed, None
+
+
+def fetch_centroids(backend, sym, n, first_read, n_total, k, group=None, lines=None):
+    """The k reads the reference copies as initial centroids (cluster.c:198-201): their global numbers come from libc
+    rand() in a fresh process's state, identical on every rank; each is fetched from the rank that owns it and made
+    global by a SUM over ranks (k * c bytes; SURVEY.md section 8e, collective 1)."""
+    import torch.distributed as dist_mod
+    if lines is None:
+        lines = reference_centroid_lines(n_total, k)
+    c = sym.shape[0]
+    means = backend.zeros((k, c), torch.int32)
+    mine = [(j, ln - first_read) for j, ln in enumerate(lines) if first_read <= ln < first_read + n]
+    if mine:
+        rows = backend.read_rows(sym, [i for _, i in mine])
+        means[torch.as_tensor([j for j, _ in mine], dtype=torch.long, device=means.device)] = rows.to(torch.int32)
+    if group is not None:
+        dist_mod.all_reduce(means, group=group)
+    return means.to(torch.uint8).contiguous()
+
+
 def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MODE_RATIO, ratio=0.5, dist="M",
                 threshold=4.0, well_state=None, shards=1, threads=1, group=None, timer=None, keep=False, device_index=0,
-                coder="host", work_bytes=None, keep_device=False, reuse=None, want_reuse=False):
+                coder="host", work_bytes=None, keep_device=False, reuse=None, want_reuse=False, backend=None):
     """Runs k-means -> PMF -> codebooks -> WELL -> quantize -> feed -> sharded arithmetic coding for the reads
     [first_read, first_read+n) held in `sym` (this rank's shard of a file with n_total reads).
     coder: "host" = `threads` host threads over the packed feed (qvz_encode_shards_device); "gpu" = the column-parallel
     model + lane-per-stream coder fed from the quantizer's planes (qvz_hip_encode_planes); "gpu-feed" = the older
     lane-per-stream kernel over the packed feed (qvz_hip_encode_shards). All produce byte-identical streams.
 
-    means0: (clusters, c) uint8 device tensor of the initial centroids (symbols). first_read must be a multiple of 4.
+    means0: (clusters, c) uint8 device tensor of the initial centroids (symbols), or None: fetch_centroids gets them from
+    the ranks that own them. first_read must be a multiple of 4.
     Returns a dict with stream sizes, distortion, codebooks, phase wall times; with keep=True also the device outputs
     and the streams as host bytes; with keep_device=True (GPU coders) the coded streams stay on the device
     (`coded`, stream g at g * `cap_per_shard`) next to `qv` and `labels`.
     reuse / want_reuse: the cluster labels, the PMF counters and the WELL draws do not depend on -f / -r / -d, so a
     rate-distortion sweep (the reference's generate_rd.sh: 20 encodes of one file) computes them once: pass
     want_reuse=True on the first operating point and hand its result["reuse"] to the others (rd_sweep below).
+    backend: who computes (default: HipBackend, the HIP kernels on this process's GPU).
     """
     import torch.distributed as dist_mod
     c, ld = sym.shape
     k = clusters
     assert first_read % 4 == 0, "shards must start on a WELL word boundary"
-    timer = timer or Timer(False)
-    dev = sym.device
+    be = backend or HipBackend(device_index, timer)
     wall = {}
     t0 = time.perf_counter()
 
     # ---- k-means (cluster.c:212-244) ----
+    if means0 is None:
+        means0 = fetch_centroids(be, sym, n, first_read, n_total, k, group)
     means = means0.clone()
-    labels = torch.zeros(ld, dtype=torch.uint8, device=dev)
-    counts = torch.zeros(k, dtype=torch.int32, device=dev)
-    acc = torch.zeros((k, c), dtype=torch.int64, device=dev)
+    labels = be.zeros(ld, torch.uint8)
+    counts = be.zeros(k, torch.int32)
+    acc = be.zeros((k, c), torch.int64)
     iters = 0
     if reuse is not None:
         labels, means, iters = reuse["labels"], reuse["means"], reuse["kmeans_iterations"]
@@ -123,21 +243,19 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     while k > 1 and reuse is None:
         counts.zero_()
         acc.zero_()
-        with timer.span("kmeans_assign"):
-            K.kmeans_assign(sym, n, means, labels=labels, counts=counts)
-        with timer.span("kmeans_accumulate"):
-            K.kmeans_accumulate(sym, n, labels, k, acc=acc)
+        be.kmeans_assign(sym, n, means, labels, counts)
+        be.kmeans_accumulate(sym, n, labels, k, acc)
         if group is not None:
             dist_mod.all_reduce(acc, group=group)
             dist_mod.all_reduce(counts, group=group)
-        moved, status = K.kmeans_update(acc, counts, means)
+        moved, status = be.kmeans_update(acc, counts, means)
         iters += 1
         mv = moved[0].item()
         if int(status.item()):
             raise RuntimeError("a cluster went empty during k-means (reference: division by zero, cluster.c:113)")
         if not (mv > threshold) or iters >= 1000:
             break
-    torch.cuda.synchronize()
+    be.sync()
     wall["kmeans"] = time.perf_counter() - t0
 
     # ---- conditional-PMF counters (codebook.c:193-205) ----
@@ -145,103 +263,57 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     if reuse is not None:
         cnt = reuse["cnt"]
     else:
-        cnt = torch.zeros((k, c, 72, 72), dtype=torch.int32, device=dev)
-        with timer.span("pmf_hist"):
-            K.pmf_hist(sym, n, labels=labels if k > 1 else None, k=k, cnt=cnt)
+        cnt = be.zeros((k, c, 72, 72), torch.int32)
+        be.pmf_hist(sym, n, labels if k > 1 else None, k, cnt)
         if group is not None:
             dist_mod.all_reduce(cnt, group=group)
     if k == 1 and reuse is None:
-        # sum over the reads of byte_s = sum over x of (x + 33) * #(X_s = x), exact in int64; a second iteration would
-        # recompute the same sums, so the iteration count is 2 if this update moved the centroid by more than the
-        # threshold (cluster.c:230-233), else 1
+        # sum over the reads of symbol_s = sum over x of x * #(X_s = x), exact in int64 (means are kept as symbols, byte - 33:
+        # floor((sum + 33 n) / n) = floor(sum / n) + 33); a second iteration would recompute the same sums, so the iteration
+        # count is 2 if this update moved the centroid by more than the threshold (cluster.c:230-233), else 1
         col = cnt[0].sum(dim=1, dtype=torch.int64)                                   # (c, 72)
-        acc[0] = (col * (torch.arange(72, device=dev, dtype=torch.int64) + 33)).sum(dim=1)
+        acc[0] = (col * torch.arange(72, device=col.device, dtype=torch.int64)).sum(dim=1)
         counts[0] = col[0].sum().to(torch.int32)
-        moved, status = K.kmeans_update(acc, counts, means)
+        moved, status = be.kmeans_update(acc, counts, means)
         iters = 2 if moved[0].item() > threshold else 1
-    torch.cuda.synchronize()
+    be.sync()
     wall["pmf"] = time.perf_counter() - t1
 
-    # ---- WELL draws (well.c:8-46): they depend on the seed only, so they are generated on a side stream while the
-    # codebooks (small latency-bound kernels + host work) are being made ----
+    # ---- WELL draws of this shard: generator offset first_read * c (jump-ahead). They depend on the seed only and run on a
+    # side stream beside the codebook generation (after the bandwidth-bound passes above, which they would slow down) ----
     if well_state is None:
         well_state = np.full(32, 0x55555555, dtype=np.uint32)
-    main_stream = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=dev)
     if reuse is not None and reuse.get("draws") is not None:
         draws = reuse["draws"]
     else:
-        draws = K.empty_matrix(n, c)         # allocated on the main stream (the caching allocator pools per stream)
-        side.wait_stream(main_stream)
-        with torch.cuda.stream(side):
-            with timer.span("well_draws"):
-                K.well_draws(well_state, first_read, n, c, out=draws)
+        draws = be.start_draws(well_state, first_read, n, c)
 
     # ---- codebooks (codebook.c:208-468), identical on every rank ----
     t2 = time.perf_counter()
     dmat = K.distortion_matrix(dist)
-    cbs, deferred = [], 0
-    if k == 1:
-        cb, deferred = K.generate_codebook(cnt[0], dmat, mode, ratio)
-        cbs.append(cb)
-    else:
-        # the clusters' codebooks are independent and each generation is latency-bound (small kernels, two host round
-        # trips per column): one host thread and one HIP stream per cluster (ctypes releases the GIL in the call)
-        from concurrent.futures import ThreadPoolExecutor
-        torch.cuda.synchronize()
-        streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
-
-        def one(j):
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(streams[j]):
-                return K.generate_codebook(cnt[j], dmat, mode, ratio)
-
-        with ThreadPoolExecutor(max_workers=k) as pool:
-            for cb, d in pool.map(one, range(k)):
-                cbs.append(cb)
-                deferred += d
-    ct, qs = K.upload_tables(cbs, dev)
-    torch.cuda.synchronize()
+    cbs, deferred = be.codebooks(cnt, dmat, mode, ratio)
+    be.sync()
     wall["codebook"] = time.perf_counter() - t2
 
     # ---- quantize (qv_compressor.c:76-135) ----
     t3 = time.perf_counter()
-    main_stream.wait_stream(side)
-    ddist = torch.from_numpy(dmat).to(dev)
     # the quantized values themselves (the -u product) are written only for a caller that keeps them: the coder needs
     # the quantizer index and the state, the distortion the per-read error
     want = ("qv", "qi", "st", "err") if (keep or keep_device) else ("qi", "st", "err")
-    with timer.span("quantize"):
-        out = K.quantize(sym, n, ct, qs, draws, ddist, labels=labels if k > 1 else None, k=k, want=want)
+    out = be.quantize(sym, n, cbs, draws, dmat, labels if k > 1 else None, k, want)
     if not want_reuse and reuse is None:
         del draws
-    feed = None
-    if coder != "gpu" or keep:
-        with timer.span("pack_feed"):
-            feed = K.pack_feed(out["qi"], out["st"], n)
     if int(out["status"].item()):
         raise RuntimeError("quantizer met a context the codebook does not define")
-    torch.cuda.synchronize()
+    be.sync()
     wall["quantize"] = time.perf_counter() - t3
 
-    # ---- arithmetic coding: `shards` independent reference-format streams on `threads` host threads ----
+    # ---- arithmetic coding: `shards` independent reference-format streams ----
     t4 = time.perf_counter()
-    if coder == "gpu":
-        with timer.span("arith_shards"):
-            sizes, streams, coded = host.encode_planes_gpu(out["qi"], out["st"], labels if k > 1 else None, n, c,
-                                                           [cb.handle for cb in cbs], shards, want_streams=keep,
-                                                           work_bytes=work_bytes)
-        wall["coder_model_kernels"], wall["coder_interval_kernels"] = (x * 1e-3 for x in host.encode_planes_gpu.last_ms)
-        stream_sizes = sizes
-    elif coder == "gpu-feed":
-        with timer.span("arith_shards"):
-            sizes, streams, coded = host.encode_shards_gpu(feed, labels if k > 1 else None, n, c, [cb.handle for cb in cbs],
-                                                           shards, want_streams=keep)
-        stream_sizes = sizes
-    else:
-        streams = host.encode_shards_device(feed, labels if k > 1 else None, n, c, [cb.handle for cb in cbs], shards, threads,
-                                            device=device_index)
-        stream_sizes = [len(s) for s in streams]
+    stream_sizes, streams, coded, feed, kernel_ms = be.code(out, labels if k > 1 else None, n, c, cbs, shards, threads, coder,
+                                                            keep, work_bytes)
+    if kernel_ms is not None:
+        wall["coder_model_kernels"], wall["coder_interval_kernels"] = (x * 1e-3 for x in kernel_ms)
     wall["coder"] = time.perf_counter() - t4
 
     err_sum = (out["err"] / float(c)).sum()

@@ -170,3 +170,18 @@ def test_shardset_file_layout(tmp_path):
     assert (si.file_bytes, si.codebook_bytes) == (len(data), len(cb_bytes))
     for h in cbs:
         L.qvz_codebook_free(h)
+
+
+def test_compat_library_exports_every_reference_entry_point():
+    """libqvzcompat.so carries every function include/qvz_compat.h declares under the reference's own name."""
+    import re
+    text = open(os.path.join(ROOT, "include", "qvz_compat.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b([a-z_0-9A-Z]+)\s*\([^;{]*\)\s*;", text))
+    must = {"load_file", "alloc_cluster_list", "do_kmeans_clustering", "calculate_statistics", "generate_codebooks", "write_codebooks",
+            "start_qv_compression", "read_codebooks", "start_qv_decompression", "compress_qv", "qv_write_cluster",
+            "initialize_qv_compressor", "decompress_qv", "qv_read_cluster", "choose_quantizer", "encoder_last_step"}
+    assert must <= names, must - names
+    L = C.CDLL(os.path.join(PKG, "libqvzcompat.so"))
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} is declared in include/qvz_compat.h but not exported by libqvzcompat.so"

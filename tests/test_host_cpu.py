@@ -181,6 +181,32 @@ def test_fastq_front_end_refuses_ragged_reads():
     assert b"read length differs" in lib().qvz_encode_last_error()
 
 
+def test_fastq_front_end_refuses_a_bad_record_at_a_thread_boundary():
+    """A malformed record right where a scanner thread's byte range begins must be an error too, not silently skipped by
+    that thread's resynchronisation (inputs above 1 MiB are scanned by several threads)."""
+    import ctypes as C
+    from qvz_amd._lib import lib
+    n, c = 9000, 150
+    rows = O.qgen1_rows(23, n, c)
+    fq = make_fastq(rows, seed=5)
+    assert len(fq) > (1 << 20)
+    nt = min(4, os.cpu_count() or 1)
+    out, reads, cols = C.c_void_p(), C.c_uint64(), C.c_uint32()
+    hits = 0
+    for i in range(1, nt):
+        lo = len(fq) // nt * i                                        # the range start qvz_fastq_qualities uses
+        rec = fq.index(b"\n@read", lo) + 1                            # first record starting at or after it
+        end_hdr = fq.index(b"\n", rec)
+        seq_end = fq.index(b"\n", end_hdr + 1)
+        bad = fq[:seq_end - 2] + fq[seq_end:]                         # that record's sequence loses two bases
+        buf = np.frombuffer(bad, dtype=np.uint8)
+        rc = lib().qvz_fastq_qualities(buf.ctypes.data, buf.size, C.byref(out), C.byref(reads), C.byref(cols))
+        assert rc != 0, f"record at the start of range {i} was dropped silently ({reads.value} reads)"
+        hits += 1
+    if nt > 1:
+        assert hits
+
+
 def test_distortion_matrix_file_parser(tmp_path, capfd):
     """qvz_distortion_matrix_file = gen_custom_distortion (src/distortion.c:100-145): comma-separated atof fields,
     row x column y -> d[x + 72*y], '#' lines skipped, short rows / missing rows are 0.0 with the reference's warning."""
