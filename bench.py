@@ -169,6 +169,42 @@ def ingest_report(cfg, n, c):
                 note="PCIe-inclusive; not part of `value` (inputs are resident in HBM when the timed region starts)")
 
 
+def strict_report(cfg, c):
+    """The byte-identical single-stream .q (the reference's own format: ONE serial arithmetic stream) through the C driver
+    (qvz_encode_file) on a bounded sample file: the adaptive model runs on the GPU (a wave per column), one host core keeps
+    the interval chain. Reported beside `value`, never part of it. `host_model` is the same with QVZ_STRICT_MODEL=host
+    (model and chain both on the host core: the first round's strict path)."""
+    import torch
+    from qvz_amd import host
+    from qvz_amd import kernels as K
+    m = 2_000_000
+    mode = host.MODE_RATIO if cfg["mode"] == "f" else host.MODE_FIXED
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        inp, q = os.path.join(td, "s.txt"), os.path.join(td, "s.q")
+        K.untranspose_text(K.qgen1(cfg["seed"], m, c), m).cpu().numpy().tofile(inp)
+        torch.cuda.synchronize()
+        md5 = {}
+        for label, env in (("gpu_model", None), ("host_model", "host")):
+            if env:
+                os.environ["QVZ_STRICT_MODEL"] = env
+            else:
+                os.environ.pop("QVZ_STRICT_MODEL", None)
+            t0 = time.perf_counter()
+            r = host.encode_file(inp, q, clusters=cfg["clusters"], mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], seed_mode=host.SEED_DEBUG)
+            dt = time.perf_counter() - t0
+            import hashlib
+            md5[label] = hashlib.md5(open(q, "rb").read()).hexdigest()
+            out[label] = dict(encode_phase_seconds=round(r.t_encode, 3), ns_per_symbol=round(r.t_encode / (m * c) * 1e9, 2),
+                              whole_file_seconds=round(dt, 3), symbols_per_second=round(m * c / dt, 1), bits_per_symbol=round(r.stream_bytes * 8.0 / (m * c), 5))
+        os.environ.pop("QVZ_STRICT_MODEL", None)
+    out.update(sample=f"QGEN-1 seed {cfg['seed']}, {m} reads x {c} cols as a text file, whole qvz_encode_file incl. ingest and codebooks",
+               identical_files=md5["gpu_model"] == md5["host_model"], streams=1,
+               note="one reference-format .q with a single arithmetic stream; ns_per_symbol is the start_qv_compression phase "
+                    "(GPU quantize + model, host interval chain, overlapped); compare cpu_baseline.seconds_per_symbol for the reference")
+    return out
+
+
 def pmf72_report(n, c):
     """The PMF pass over a matrix that uses all 72 symbols of the alphabet uniformly (QGEN-1 populates 40): the counter
     tiles are 72 x 72 instead of the populated sub-block."""
@@ -367,6 +403,7 @@ def main():
                 results[-1].pop(key, None)
             line["ingest"] = ingest_report(cfg, n, c)
             line["roofline_pmf_hist_72_symbols"] = pmf72_report(n, c)
+            line["strict"] = strict_report(cfg, c)
         if not args.no_cpu_baseline and world == 1:               # the CPU baseline is timed on rank 0 of the 1-GPU run only
             line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")
         print(json.dumps(line), flush=True)

@@ -121,6 +121,30 @@ int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const
  * the call's stream, summed over the segments). Either pointer may be NULL. */
 void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Strict single-stream mode with the model on the GPU. The reference's file has ONE serial arithmetic stream
+ * (src/qv_stream.c:109-110); its interval chain (src/arith.c:35-97) stays on one host core, but update_stats and the
+ * cumulative counts (src/qv_stream.c:9-25, src/arith.c:39-43) do not: a table belongs to one column, so a model session
+ * runs the adaptive model of the whole file on the GPU (a wave per column, tables in LDS, state carried from chunk to
+ * chunk) and leaves, per symbol, the 16-byte record (cum_lo / n, (n - cum_hi) / n) / 1024 as doubles. The host coder
+ * (qvz_coder_encode_records) turns a record into the new bounds with two multiply-adds - exactly floor(range*cum/n) of
+ * arith.c:47-48, see qvz_coder.c - renormalises and writes bits. Byte-identical to qvz_coder_encode on the feed.
+ * open fails with QVZ_E_NOMEM when a column's tables do not fit LDS (the caller then keeps the model on the host).
+ * Record (row, pos) of a chunk lies at ((row / 2) * (pitch / 4) + pos / 4) * 8 + (row % 2) * 4 + pos % 4 (in records);
+ * positions per read: one cluster: pos = column; several: pos 0 = the cluster id, 1..7 unused, 8 + column.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct qvz_model_session qvz_model_session_t;
+int qvz_hip_model_session_open(uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, qvz_model_session_t **out);
+uint32_t qvz_hip_model_session_pitch(const qvz_model_session_t *s);     /* record positions per read, a multiple of 8 */
+/* records of the next n reads of the stream (planes d_qi / d_st / d_labels start at this chunk's first read) into d_rec
+ * ((n rounded up to 2) * pitch * 16 bytes); asynchronous on `stream`, chunks in file order */
+int qvz_hip_model_session_records(qvz_model_session_t *s, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld,
+                                  const uint8_t *d_labels, uint64_t n, void *d_rec, void *stream);
+int qvz_hip_model_session_status(qvz_model_session_t *s, void *stream); /* QVZ_E_DEAD_CTX if a symbol had no table; synchronises */
+void qvz_hip_model_session_close(qvz_model_session_t *s);
+/* the host half: `reads` reads of records (layout above; h_rec in host memory) through the interval chain of `cd` */
+int qvz_coder_encode_records(qvz_coder_t *cd, const double *h_rec, uint64_t reads, uint32_t pitch);
+
 /* Initial adaptive model as a flat arena of tables [n][card][counts...] (cluster-id table at index 0) plus the
  * (cluster, column, quantizer) -> arena index map (0xFFFFFFFF = none). Shared by the host and GPU coders.
  * Caller frees *arena_out and *offset_out with free(). Returns 0 on success. */

@@ -67,6 +67,12 @@ SIGNATURES = {
     "qvz_coder_bytes": (C.c_uint64, [C.c_void_p]),
     "qvz_coder_data": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "qvz_coder_drop": (None, [C.c_void_p, C.c_uint64]),
+    "qvz_coder_encode_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
+    "qvz_hip_model_session_open": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "qvz_hip_model_session_pitch": (C.c_uint32, [C.c_void_p]),
+    "qvz_hip_model_session_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "qvz_hip_model_session_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "qvz_hip_model_session_close": (None, [C.c_void_p]),
     "qvz_shard_bounds": (None, [C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "qvz_encode_shards_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int,

@@ -193,6 +193,80 @@ int qvz_coder_encode(qvz_coder_t *cd, const uint8_t *labels, const uint16_t *fee
     return 0;
 }
 
+/* The interval chain over records (include/qvz_coder.h, "strict single-stream mode with the model on the GPU"): per
+ * symbol the model left x = cum_lo / n / 1024 and y = (n - cum_hi) / n / 1024 as doubles (relative error < 2^-50). With l
+ * and ~u kept left-aligned in 32 bits (l32 = l << 10, nu32 = (~u & mask) << 10), R * 1024 = 2^32 - (l32 + nu32) and
+ *     floor(R * cum_lo / n)     = trunc(R*1024 * x + 2^-24)                                        (arith.c:48)
+ *     R - floor(R * cum_hi / n) = ceil(R * (n - cum_hi) / n) = trunc(R*1024 * y + 1 - 2^-24)       (arith.c:47)
+ * exactly: R <= 2^22, so the product is off by at most 2^22 * 2^-50 from the true quotient, each of the two roundings
+ * (product, sum: no fused multiply-add is assumed) by at most 2^-31, together less than 2^-24.9; a true quotient is an
+ * integer Q - then the sum lies strictly between Q and Q + 1 for either constant - or has a fractional part in
+ * [2^-19, 1 - 2^-19] (n <= 2^19 + 8), 2^-24 + 2^-24.9 away from the next integer on both sides. The record (0, 0) adds
+ * nothing and leaves the (already renormalised) interval alone: positions without a symbol need no test.
+ * E1/E2/E3 as in encode_symbol above, on the aligned words: k = leading bits on which l and u agree, j = leading
+ * positions below the top where l has 1 and u has 0. Same integers, same bits as arith.c:50-97. */
+int qvz_coder_encode_records(qvz_coder_t *cd, const double *rec, uint64_t reads, uint32_t pitch) {
+    const uint32_t C = cd->columns, pos0 = cd->clusters > 1 ? 8u : 0u;             /* several clusters: 0 = cluster id, 8 + column */
+    if (!rec || (pitch & 7) || pitch < pos0 + C) return -1;
+    uint32_t l32 = cd->l << 10, nu32 = (~cd->u & MASK_M) << 10;
+    uint64_t scale3 = cd->scale3, acc = cd->acc;
+    uint32_t nbits = cd->nbits;
+    const uint32_t quads = pitch >> 2;
+    for (uint64_t i = 0; i < reads; ++i) {
+        if (cd->len + (uint64_t)(C + 1) * 4 + 64 > cd->cap) {
+            cd->acc = acc; cd->nbits = nbits;
+            if (buf_reserve(cd, (uint64_t)(C + 1) * 4 + 64)) return -1;
+        }
+        const double *row = rec + ((i >> 1) * quads * 8 + (i & 1) * 4) * 2;        /* unit (i / 2, 0), half i % 2 */
+        for (uint32_t t = 0; t < C + (pos0 ? 1u : 0u); ++t) {
+            const uint32_t p = !pos0 ? t : t == 0 ? 0u : pos0 + t - 1;              /* qv_write_cluster first (qv_compressor.c:86), then the columns */
+            const double *r = row + ((size_t)(p >> 2) * 8 + (p & 3)) * 2;
+            const double rd = 4294967296.0 - (double)(l32 + nu32);                 /* (u - l + 1) * 1024 */
+            l32 += (uint32_t)(rd * r[0] + 0x1p-24) << 10;
+            nu32 += (uint32_t)(rd * r[1] + (1.0 - 0x1p-24)) << 10;
+            const uint32_t k = (uint32_t)__builtin_clz(~(l32 ^ nu32));             /* the zero low bits stop it at 22 */
+            if (k) {                                                               /* E1/E2 batch */
+                const uint32_t top = l32 >> (32 - k);
+                if (scale3 <= 9) {                                                 /* first bit, the pending run, the other k - 1 bits: at most 31 bits */
+                    const uint32_t nb = k + (uint32_t)scale3;
+                    acc = (acc << nb) | (uint64_t)(top + ((((uint32_t)1 << scale3) - 1) << (k - 1)));
+                    nbits += nb;
+                } else {
+                    const uint32_t b = top >> (k - 1);
+                    cd->acc = acc; cd->nbits = nbits;
+                    put_bits(cd, b, 1);
+                    put_run(cd, !b, scale3);
+                    if (k > 1) put_bits(cd, top & ((1u << (k - 1)) - 1), k - 1);
+                    acc = cd->acc; nbits = cd->nbits;
+                }
+                scale3 = 0;
+                l32 <<= k;
+                nu32 <<= k;
+                if (nbits >= 32) {                                                 /* four whole bytes, most significant first */
+                    nbits -= 32;
+                    const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nbits));
+                    memcpy(cd->buf + cd->len, &w, 4);
+                    cd->len += 4;
+                }
+            }
+            const uint32_t j = (uint32_t)__builtin_clz(~(l32 & nu32) << 1);        /* E3 batch (j = 0: nothing) */
+            scale3 += j;
+            l32 = (l32 << j) & 0x7FFFFFFFu;
+            nu32 = (nu32 << j) & 0x7FFFFFFFu;
+        }
+    }
+    cd->l = l32 >> 10;
+    cd->u = ~(nu32 >> 10) & MASK_M;
+    cd->scale3 = scale3;
+    cd->acc = acc;
+    cd->nbits = nbits;
+    while (cd->nbits >= 8) {                                                      /* back to the byte-wise invariant of put_bits */
+        cd->nbits -= 8;
+        cd->buf[cd->len++] = (uint8_t)(cd->acc >> cd->nbits);
+    }
+    return 0;
+}
+
 void qvz_coder_finish(qvz_coder_t *cd) {                        /* encoder_last_step, arith.c:99-116 */
     buf_reserve(cd, 64);
     const uint32_t b = cd->l >> (M_BITS - 1);

@@ -315,6 +315,7 @@ typedef struct {
     uint8_t *d_draws;
     double *d_err;
     int32_t *d_status;
+    double *d_rec, *h_rec;        /* model on the GPU: 16-byte records instead of the feed (qvz_hip_model_session_records) */
     uint16_t *h_feed;
     uint8_t *h_labels, *h_text;
     double *h_err;
@@ -325,6 +326,7 @@ typedef struct {
 static void chunk_free(chunk_t *ck) {
     qvz_hip_free(ck->d_qv); qvz_hip_free(ck->d_qi); qvz_hip_free(ck->d_st); qvz_hip_free(ck->d_text);
     qvz_hip_free(ck->d_feed); qvz_hip_free(ck->d_draws); qvz_hip_free(ck->d_err); qvz_hip_free(ck->d_status);
+    qvz_hip_free(ck->d_rec); qvz_hip_free_host(ck->h_rec);
     qvz_hip_free_host(ck->h_feed); qvz_hip_free_host(ck->h_labels); qvz_hip_free_host(ck->h_text);
     qvz_hip_free_host(ck->h_err); qvz_hip_free_host(ck->h_status);
     if (ck->stream) qvz_hip_stream_destroy(ck->stream);
@@ -332,7 +334,7 @@ static void chunk_free(chunk_t *ck) {
 }
 
 static int issue_chunk(qvz_job_t *job, chunk_t *q, uint64_t r0, uint64_t chunk, const uint16_t *d_ct, const uint16_t *d_qs,
-                       const double *d_dist, int want_text) {
+                       const double *d_dist, int want_text, qvz_model_session_t *model) {
     int rc = 0;
     const uint32_t C = job->C, K = job->K;
     const uint64_t stride = (uint64_t)C + 1;
@@ -343,11 +345,17 @@ static int issue_chunk(qvz_job_t *job, chunk_t *q, uint64_t r0, uint64_t chunk, 
     HIP(qvz_hip_well_draws(job->well_state, q->r0, q->n, C, q->d_draws, ldn, q->stream));
     HIP(qvz_hip_quantize(job->d_sym + q->r0, K > 1 ? job->d_labels + q->r0 : NULL, q->n, C, job->ld, K, d_ct, d_qs, q->d_draws,
                          ldn, d_dist, q->d_qv, q->d_qi, q->d_st, ldn, q->d_err, q->d_status, q->stream));
-    HIP(qvz_hip_pack_feed(q->d_qi, q->d_st, q->n, C, ldn, q->d_feed, q->stream));
-    HIP(qvz_hip_copy_d2h(q->h_feed, q->d_feed, q->n * C * sizeof(uint16_t), q->stream));
+    if (model) {       /* the adaptive model of this chunk on the GPU: the host gets records, not (quantizer, state) pairs */
+        const uint64_t rec_bytes = ((q->n + 1) & ~1ull) * qvz_hip_model_session_pitch(model) * 16;
+        HIP(qvz_hip_model_session_records(model, q->d_qi, q->d_st, ldn, K > 1 ? job->d_labels + q->r0 : NULL, q->n, q->d_rec, q->stream));
+        HIP(qvz_hip_copy_d2h(q->h_rec, q->d_rec, rec_bytes, q->stream));
+    } else {
+        HIP(qvz_hip_pack_feed(q->d_qi, q->d_st, q->n, C, ldn, q->d_feed, q->stream));
+        HIP(qvz_hip_copy_d2h(q->h_feed, q->d_feed, q->n * C * sizeof(uint16_t), q->stream));
+        if (K > 1) HIP(qvz_hip_copy_d2h(q->h_labels, job->d_labels + q->r0, q->n, q->stream));
+    }
     HIP(qvz_hip_copy_d2h(q->h_err, q->d_err, q->n * sizeof(double), q->stream));
     HIP(qvz_hip_copy_d2h(q->h_status, q->d_status, sizeof(int32_t), q->stream));
-    if (K > 1) HIP(qvz_hip_copy_d2h(q->h_labels, job->d_labels + q->r0, q->n, q->stream));
     if (want_text) {
         HIP(qvz_hip_untranspose_text(q->d_qv, q->n, C, ldn, q->d_text, q->stream));
         HIP(qvz_hip_copy_d2h(q->h_text, q->d_text, q->n * stride, q->stream));
@@ -364,6 +372,7 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
     uint16_t *d_ct = NULL, *d_qs = NULL, *h_ct = NULL, *h_qs = NULL;
     double *d_dist = NULL;
     qvz_coder_t *coder = NULL;
+    qvz_model_session_t *model = NULL;
     chunk_t ck[2];
     memset(ck, 0, sizeof(ck));
 
@@ -395,7 +404,13 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
     /* quantize (GPU) + arithmetic coding (host), chunked and overlapped (qv_compressor.c:48-143) */
     coder = qvz_coder_create(K, C, (const qvz_codebook_t *const *)job->cbs);
     if (!coder) { rc = qvz_job_fail(QVZ_E_NOMEM, "coder alloc"); goto done; }
-    uint64_t chunk = job->opts.chunk_reads ? job->opts.chunk_reads : (1u << 20);
+    /* Where the adaptive model runs. Default: on the GPU (a wave per column over the whole file, include/qvz_coder.h), the
+     * host core keeps only the interval chain; QVZ_STRICT_MODEL=host, or tables too large for LDS: the host does both. */
+    {
+        const char *sm = getenv("QVZ_STRICT_MODEL");
+        if (!(sm && strcmp(sm, "host") == 0) && qvz_hip_model_session_open(C, K, (const qvz_codebook_t *const *)job->cbs, &model) != QVZ_OK) model = NULL;
+    }
+    uint64_t chunk = job->opts.chunk_reads ? job->opts.chunk_reads : (model ? 1u << 18 : 1u << 20);   /* records are 8x the feed's bytes */
     chunk = (chunk + 255) & ~255ull;
     if (chunk > ((N + 255) & ~255ull)) chunk = (N + 255) & ~255ull;
     const uint64_t ldc = qvz_hip_ld(chunk);
@@ -405,11 +420,17 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
         HIP(qvz_hip_malloc((void **)&k_->d_qv, (size_t)C * ldc));
         HIP(qvz_hip_malloc((void **)&k_->d_qi, (size_t)C * ldc));
         HIP(qvz_hip_malloc((void **)&k_->d_st, (size_t)C * ldc));
-        HIP(qvz_hip_malloc((void **)&k_->d_feed, chunk * C * sizeof(uint16_t)));
+        if (model) {
+            const size_t rec_bytes = (size_t)((chunk + 1) & ~1ull) * qvz_hip_model_session_pitch(model) * 16;
+            HIP(qvz_hip_malloc((void **)&k_->d_rec, rec_bytes));
+            HIP(qvz_hip_malloc_host((void **)&k_->h_rec, rec_bytes));
+        } else {
+            HIP(qvz_hip_malloc((void **)&k_->d_feed, chunk * C * sizeof(uint16_t)));
+            HIP(qvz_hip_malloc_host((void **)&k_->h_feed, chunk * C * sizeof(uint16_t)));
+        }
         HIP(qvz_hip_malloc((void **)&k_->d_draws, (size_t)C * ldc));
         HIP(qvz_hip_malloc((void **)&k_->d_err, chunk * sizeof(double)));
         HIP(qvz_hip_malloc((void **)&k_->d_status, sizeof(int32_t)));
-        HIP(qvz_hip_malloc_host((void **)&k_->h_feed, chunk * C * sizeof(uint16_t)));
         HIP(qvz_hip_malloc_host((void **)&k_->h_labels, chunk));
         HIP(qvz_hip_malloc_host((void **)&k_->h_err, chunk * sizeof(double)));
         HIP(qvz_hip_malloc_host((void **)&k_->h_status, sizeof(int32_t)));
@@ -423,14 +444,14 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
         uint64_t next = 0;       /* first read not yet issued to the GPU */
         int cur = 0;
         HIP(qvz_hip_stream_sync(NULL));
-        if ((rc = issue_chunk(job, &ck[cur], next, chunk, d_ct, d_qs, d_dist, fu != NULL))) goto done;
+        if ((rc = issue_chunk(job, &ck[cur], next, chunk, d_ct, d_qs, d_dist, fu != NULL, model))) goto done;
         next += ck[cur].n;
         while (ck[cur].n) {
             chunk_t *q = &ck[cur];
             HIP(qvz_hip_stream_sync(q->stream));
             ck[cur ^ 1].n = 0;
             if (next < N) {      /* the GPU prepares the next chunk while this one is coded */
-                if ((rc = issue_chunk(job, &ck[cur ^ 1], next, chunk, d_ct, d_qs, d_dist, fu != NULL))) goto done;
+                if ((rc = issue_chunk(job, &ck[cur ^ 1], next, chunk, d_ct, d_qs, d_dist, fu != NULL, model))) goto done;
                 next += ck[cur ^ 1].n;
             }
             if (*q->h_status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
@@ -439,7 +460,8 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
                 for (uint64_t blk = (q->r0 + QVZ_LINES_PER_BLOCK - 1) / QVZ_LINES_PER_BLOCK; blk * QVZ_LINES_PER_BLOCK < q->r0 + q->n; ++blk)
                     printf("Line: %dM\n", (int)blk);
             }
-            if (qvz_coder_encode(coder, K > 1 ? q->h_labels : NULL, q->h_feed, q->n)) { rc = qvz_job_fail(QVZ_E_DATA, "coder feed out of range"); goto done; }
+            if (model ? qvz_coder_encode_records(coder, q->h_rec, q->n, qvz_hip_model_session_pitch(model))
+                      : qvz_coder_encode(coder, K > 1 ? q->h_labels : NULL, q->h_feed, q->n)) { rc = qvz_job_fail(QVZ_E_DATA, "coder feed out of range"); goto done; }
             for (uint64_t i = 0; i < q->n; ++i) distortion += q->h_err[i] / ((double)C);   /* qv_compressor.c:127 */
             if (fu && fwrite(q->h_text, 1, q->n * stride, fu) != q->n * stride) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
             {
@@ -450,6 +472,7 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
             }
             cur ^= 1;
         }
+        if (model && qvz_hip_model_session_status(model, NULL)) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "%s", qvz_hip_last_error()); goto done; }
         qvz_coder_finish(coder);                                               /* encoder_last_step, arith.c:99-116 */
         {
             uint64_t sz;
@@ -463,6 +486,7 @@ int qvz_job_compress(qvz_job_t *job, FILE *fout, FILE *fu, uint64_t *stream_byte
     job->t_encode = now() - t0;
 done:
     for (int b = 0; b < 2; ++b) chunk_free(&ck[b]);
+    qvz_hip_model_session_close(model);
     qvz_coder_destroy(coder);
     free(h_ct); free(h_qs);
     qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist);

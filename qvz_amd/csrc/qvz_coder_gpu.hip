@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void k_cluster_segpos(const uint32_t *__restri
 // number of waves a CU holds, is that of the one-cluster case - and every lane of a chunk has a symbol. The workgroups
 // of the reserved positions (cluster z = 0 only) take the reads in file order: the cluster id of every read is a symbol
 // of its own table (qv_compressor.c:86), the other reserved positions are zero records.
-template <bool HAVE_LABELS>
+template <bool HAVE_LABELS, bool DENSE>
 __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                       const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
                                                       const uint64_t *__restrict__ first, const uint32_t *__restrict__ coff,
@@ -719,6 +719,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                                                       uint32_t log2w, Record *__restrict__ rec, int32_t *__restrict__ status,
                                                       const uint32_t *__restrict__ clist, const uint64_t *__restrict__ cstart,
                                                       const uint32_t *__restrict__ segpos_lo, const uint32_t *__restrict__ segpos_hi) {
+    // records between consecutive units of a stream: 512 = 8 records x 64 interleaved streams (rec_index, the coder
+    // kernel's layout); DENSE: one stream alone, its units back to back (qvz_hip_model_session_records)
+    constexpr uint32_t unit_recs = DENSE ? 8u : 512u;
     extern __shared__ uint4 rk_smem[];
     // the wave index is wave-uniform, which the compiler cannot see: readfirstlane keeps everything derived from it
     // (column, table slice, activity) in scalar registers and its tests in scalar branches
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     if (nr == 0) return;                                         // whole workgroup (lists only)
     __syncthreads();
 
-    Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index)
+    Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index; g = 0 when unit_recs = 8)
     bool bad = false;
     uint32_t chunk = 0;
     // Input: every lane loads the bytes of its own read for the next four chunks (a wave instruction = 64 contiguous bytes
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             if (((chunk + 2) & 3) == 0) park(rb + 128);
             if (rb + rd < nr && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
                 RK_EXP(1)
-                rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * 512 + (row & 1) * 4 + (col & 3)] = buf[rd * rb_stride + cw];
+                rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 1) * 4 + (col & 3)] = buf[rd * rb_stride + cw];
         }
         RK_T(5);
     }
@@ -1519,8 +1522,8 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         TRY(hipMemcpyAsync(d_slices, h_slices.data(), h_slices.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_colbase, h_colbase.data(), h_colbase.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_coff, h_coff.data(), h_coff.size() * 4, hipMemcpyHostToDevice, st));
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     } else {                                                     // lane-per-column kernel with per-stream arenas in HBM
         TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
         TRY(hipMalloc(&d_off, offn * 4));
@@ -1598,13 +1601,13 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
             const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves, clusters), block(64 * rk_waves);   // z: the cluster a workgroup of column positions serves
             const size_t SK = (size_t)shards * clusters;
             if (clusters > 1)
-                hipLaunchKernelGGL(k_model_ranks<true>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
+                hipLaunchKernelGGL((k_model_ranks<true, false>), grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
                                    seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status,
                                    (const uint32_t *)d_clist, (const uint64_t *)d_cstart, (const uint32_t *)(d_segpos + (size_t)i * SK),
                                    (const uint32_t *)(d_segpos + (size_t)(i + 1) * SK));
             else
-                hipLaunchKernelGGL(k_model_ranks<false>, grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
+                hipLaunchKernelGGL((k_model_ranks<false, false>), grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
                                    d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
                                    seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status,
                                    (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
@@ -1666,4 +1669,157 @@ done:
     (void)hipFree(d_clist); (void)hipFree(d_cstart); (void)hipFree(d_segpos); (void)hipFree(d_bounds);
     free(h_arena); free(h_off); free(h_first);
     return rc;
+}
+
+// ---- the adaptive model of ONE stream on the GPU, chunk by chunk (strict single-stream mode) ---------------------------
+// The reference's .q holds one serial arithmetic stream (qv_stream.c:109-110): the interval chain (arith.c:35-97) cannot
+// be spread over lanes, but its model can: update_stats touches one table, a table belongs to one column
+// (qv_stream.c:9-25,46-53), so k_model_ranks runs the model of the whole file with a wave per column, and what is left to
+// the one host core that owns the chain is two multiply-adds, the renormalisation and the bit output per symbol
+// (host/qvz_coder.c, qvz_coder_encode_records) - no table look-ups, no cumulative sums, no division.
+// A session carries the tables from chunk to chunk (`save`); records of a chunk are laid out for one stream alone:
+//   record (row, pos) at ((row / 2) * (Cp / 4) + pos / 4) * 8 + (row % 2) * 4 + pos % 4,   Cp = positions per read rounded up to 8
+// (positions: one cluster: the columns; several: 0 = cluster id, 1..7 empty, 8 + column).
+struct qvz_model_session {
+    uint32_t columns, clusters, Cx, Cp, nslices, slice_cap, rk_waves, total_words;
+    size_t rk_lds;
+    uint32_t *d_slices, *d_colbase, *d_coff, *d_save;
+    uint64_t *d_first, *d_cstart;
+    uint32_t *d_clist, *d_segpos, *d_bounds;
+    int32_t *d_status;
+    uint64_t list_cap;           // reads d_clist holds
+    int started;                 // 0 until the first chunk has run (it starts from the template tables)
+};
+
+extern "C" void qvz_hip_model_session_close(qvz_model_session *s) {
+    if (!s) return;
+    (void)hipFree(s->d_slices); (void)hipFree(s->d_colbase); (void)hipFree(s->d_coff); (void)hipFree(s->d_save);
+    (void)hipFree(s->d_first); (void)hipFree(s->d_cstart); (void)hipFree(s->d_clist); (void)hipFree(s->d_segpos);
+    (void)hipFree(s->d_bounds); (void)hipFree(s->d_status);
+    delete s;
+}
+
+extern "C" int qvz_hip_model_session_open(uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs,
+                                          qvz_model_session **out) {
+    if (!columns || !clusters || !cbs || !out) return qvz_set_error(QVZ_E_ARG, "bad model-session arguments");
+    uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
+    if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))   // every context: a single stream may meet any
+        return qvz_set_error(QVZ_E_NOMEM, "model build failed");
+    qvz_model_session *s = new qvz_model_session();
+    memset(s, 0, sizeof(*s));
+    s->columns = columns; s->clusters = clusters;
+    s->Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);
+    s->Cp = (s->Cx + 7) & ~7u;
+    s->nslices = clusters > 1 ? 1 + columns * clusters : columns;
+    std::vector<uint32_t> h_slices, h_colbase(s->nslices + 1, 0);
+    std::vector<uint32_t> h_coff((size_t)s->nslices * 2 * A, (uint32_t)RK_NONE);
+    bool fits = true;
+    for (uint32_t sl = 0; sl < s->nslices; ++sl) {              // the slices of qvz_hip_encode_planes
+        h_colbase[sl] = (uint32_t)h_slices.size();
+        if (clusters > 1 && sl == 0) {
+            h_slices.push_back(clusters); h_slices.push_back(clusters);
+            for (uint32_t c = 0; c < clusters; ++c) h_slices.push_back(1);
+        } else {
+            const uint32_t col = clusters > 1 ? (sl - 1) / clusters : sl, c = clusters > 1 ? (sl - 1) % clusters : 0;
+            for (uint32_t j = 0; j < 2 * A; ++j) {
+                const uint32_t o = h_off[((size_t)c * columns + col) * 2 * A + j];
+                if (o == NO_TABLE) continue;
+                const size_t rel = h_slices.size() - h_colbase[sl];
+                if (rel >= RK_NONE) { fits = false; continue; }
+                h_coff[(size_t)sl * 2 * A + j] = (uint32_t)rel | h_arena[o + 1] << 16;
+                for (uint32_t i = 0; i < 2 + h_arena[o + 1]; ++i) h_slices.push_back(h_arena[o + i]);
+            }
+        }
+        while (h_slices.size() & 3) h_slices.push_back(0);
+        const uint32_t len = (uint32_t)h_slices.size() - h_colbase[sl];
+        if (len > s->slice_cap) s->slice_cap = len;
+    }
+    h_colbase[s->nslices] = (uint32_t)h_slices.size();
+    s->slice_cap = (s->slice_cap + 3) & ~3u;
+    s->total_words = (uint32_t)h_slices.size();
+    free(h_arena); free(h_off);
+    auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (clusters > 1 ? 2048 : 0) + (size_t)w * (3 * s->slice_cap + 2 * A) * 4; };
+    const uint32_t order[3] = {4, 2, 1};
+    for (uint32_t w : order)
+        if (fits && need_of(w) <= (size_t)160 * 1024) { s->rk_waves = w; s->rk_lds = need_of(w); break; }
+    if (!s->rk_waves) {
+        delete s;
+        return qvz_set_error(QVZ_E_NOMEM, "a column's tables (%u words) do not fit LDS", s->slice_cap);
+    }
+    int rc = QVZ_OK;
+#define TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess && rc == QVZ_OK) rc = qvz_set_error(QVZ_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); } while (0)
+    TRY(hipMalloc(&s->d_slices, h_slices.size() * 4));
+    TRY(hipMalloc(&s->d_colbase, h_colbase.size() * 4));
+    TRY(hipMalloc(&s->d_coff, h_coff.size() * 4));
+    TRY(hipMalloc(&s->d_save, h_slices.size() * 4));
+    TRY(hipMalloc(&s->d_first, 2 * sizeof(uint64_t)));
+    TRY(hipMalloc(&s->d_status, sizeof(int32_t)));
+    if (clusters > 1) {
+        TRY(hipMalloc(&s->d_cstart, clusters * sizeof(uint64_t)));
+        TRY(hipMalloc(&s->d_segpos, (size_t)clusters * 2 * sizeof(uint32_t)));
+        TRY(hipMalloc(&s->d_bounds, 2 * sizeof(uint32_t)));
+    }
+    if (rc == QVZ_OK) {
+        const uint32_t bounds[2] = {0u, 0xFFFFFFFFu};
+        TRY(hipMemcpy(s->d_slices, h_slices.data(), h_slices.size() * 4, hipMemcpyHostToDevice));
+        TRY(hipMemcpy(s->d_colbase, h_colbase.data(), h_colbase.size() * 4, hipMemcpyHostToDevice));
+        TRY(hipMemcpy(s->d_coff, h_coff.data(), h_coff.size() * 4, hipMemcpyHostToDevice));
+        TRY(hipMemset(s->d_status, 0, sizeof(int32_t)));
+        TRY(hipMemset(s->d_first, 0, 2 * sizeof(uint64_t)));
+        if (clusters > 1) TRY(hipMemcpy(s->d_bounds, bounds, sizeof(bounds), hipMemcpyHostToDevice));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->rk_lds));
+    }
+#undef TRY
+    if (rc != QVZ_OK) { qvz_hip_model_session_close(s); return rc; }
+    *out = s;
+    return QVZ_OK;
+}
+
+extern "C" uint32_t qvz_hip_model_session_pitch(const qvz_model_session *s) { return s ? s->Cp : 0; }
+
+// The records of the next n reads of the stream (their planes start at index 0 of d_qi / d_st / d_labels) into d_rec
+// (n rounded up to 2, times pitch, times 16 bytes). Asynchronous on `stream`; chunks must be issued in file order on
+// one stream. *d_status_out (device, may be NULL): |= 1 if a symbol had no table.
+extern "C" int qvz_hip_model_session_records(qvz_model_session *s, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld,
+                                             const uint8_t *d_labels, uint64_t n, void *d_rec, void *stream) {
+    if (!s || !d_qi || !d_st || !n || !d_rec || ld < n || n > 0xFFFFFFF0ull) return qvz_set_error(QVZ_E_ARG, "bad model-session chunk");
+    if (s->clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
+    hipStream_t st = (hipStream_t)stream;
+    // first[] = {0, n} for the kernels: the value travels inside the command (n < 2^32: the high word stays zero)
+    QVZ_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(s->d_first + 1), (int)(uint32_t)n, 1, st));
+    const dim3 grid(1, (s->Cp + s->rk_waves - 1) / s->rk_waves, s->clusters), block(64 * s->rk_waves);
+    const int is_first = s->started ? 0 : 1;
+    if (s->clusters > 1) {
+        if (n > s->list_cap) {
+            if (s->d_clist) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(s->d_clist); s->d_clist = nullptr; }
+            QVZ_HIP_CHECK(hipMalloc(&s->d_clist, (size_t)n * sizeof(uint32_t)));
+            s->list_cap = n;
+        }
+        hipLaunchKernelGGL(k_cluster_lists, dim3(1), dim3(256), 0, st, d_labels, (const uint64_t *)s->d_first, s->clusters, s->d_clist, s->d_cstart, s->d_status);
+        hipLaunchKernelGGL(k_cluster_segpos, dim3((s->clusters * 2 + 255) / 256), dim3(256), 0, st, (const uint32_t *)s->d_clist,
+                           (const uint64_t *)s->d_cstart, (const uint64_t *)s->d_first, 1u, s->clusters, (const uint32_t *)s->d_bounds, 2u, s->d_segpos);
+        hipLaunchKernelGGL((k_model_ranks<true, true>), grid, block, s->rk_lds, st, d_qi, d_st, ld, d_labels, s->columns, s->clusters,
+                           (const uint64_t *)s->d_first, s->d_coff, s->d_colbase, s->d_slices, s->d_save, s->total_words, s->slice_cap,
+                           (uint64_t)0, (uint32_t)n, is_first, 0, (uint32_t)__builtin_ctz(s->rk_waves), (Record *)d_rec, s->d_status,
+                           (const uint32_t *)s->d_clist, (const uint64_t *)s->d_cstart, (const uint32_t *)s->d_segpos,
+                           (const uint32_t *)(s->d_segpos + s->clusters));
+    } else {
+        hipLaunchKernelGGL((k_model_ranks<false, true>), grid, block, s->rk_lds, st, d_qi, d_st, ld, d_labels, s->columns, s->clusters,
+                           (const uint64_t *)s->d_first, s->d_coff, s->d_colbase, s->d_slices, s->d_save, s->total_words, s->slice_cap,
+                           (uint64_t)0, (uint32_t)n, is_first, 0, (uint32_t)__builtin_ctz(s->rk_waves), (Record *)d_rec, s->d_status,
+                           (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    }
+    QVZ_HIP_CHECK(hipGetLastError());
+    s->started = 1;
+    return QVZ_OK;
+}
+
+// status bits gathered so far (1: a symbol addressed a quantizer without a table / a state outside its alphabet); synchronises `stream`
+extern "C" int qvz_hip_model_session_status(qvz_model_session *s, void *stream) {
+    int32_t v = 0;
+    if (!s) return QVZ_E_ARG;
+    QVZ_HIP_CHECK(hipMemcpyAsync(&v, s->d_status, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    QVZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return v ? qvz_set_error(QVZ_E_DEAD_CTX, "coder input addresses a quantizer without a model table (dead context or bad state)") : QVZ_OK;
 }

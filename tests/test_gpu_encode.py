@@ -208,14 +208,76 @@ def test_sharded_files_decode_with_the_reference_decoder(tmp_path, name, shards)
 
 
 def test_cli_qvz_shards_env(tmp_path):
+    """QVZ_SHARDS=N: the default product is ONE shard-set file (codebooks once, include/qvz_shardset.h); `qvz -x` decodes
+    it, qvz-shardset splits it into reference-format files the unmodified reference decoder reads; QVZ_SHARD_FILES=1 writes
+    those files directly."""
+    from qvz_amd import host
     name = "t2k_r10_M"
     e = G.CASES[name]
     inp, _ = write_input(tmp_path, name)
-    q = str(tmp_path / "cli_sh.q")
+    q = str(tmp_path / "cli_sh.qset")
     env = dict(os.environ, QVZ_WELL_SEED="debug", QVZ_SHARDS="4")
     out = subprocess.run([QVZ_BIN] + e["flags"].split() + ["-s", inp, q], env=env, capture_output=True, text=True, check=True).stdout
     assert re.search(r"rate, [\d.]+, distortion, ([\d.]+)", out).group(1) == f"{e['distortion']:.4f}"
-    decoded = b"".join(decode_with_reference_or_oracle(f"{q}.{g:04d}", tmp_path) for g in range(4))
+    blob = open(q, "rb").read()
+    assert blob[:8] == b"\0QVZSET1"
+    si = host.shardset_stat(q)
+    c, n = e["input"]["c"], e["input"]["n"]
+    assert (si.clusters, si.columns, si.lines, si.shards) == (1, c, n, 4)
+    ref_q = G.gz(name + ".q.gz")
+    assert si.codebook_bytes == len(ref_q) - 9 - 128 - e["size"]                 # the reference's codebook text, once
+    assert si.file_bytes == len(blob) == 160 + 8 * 4 + si.codebook_bytes + si.stream_bytes
+    # decode the set directly
+    dec = str(tmp_path / "set.dec")
+    subprocess.run([QVZ_BIN, "-x", q, dec], env=dict(os.environ), check=True, capture_output=True)
+    assert G.md5(open(dec, "rb").read()) == e["u_md5"]
+    # split it: every piece is a reference-format file
+    tool = os.path.join(os.path.dirname(QVZ_BIN), "qvz-shardset")
+    st = subprocess.run([tool, "stat", q], capture_output=True, text=True, check=True).stdout
+    assert f"shards, 4" in st and "rate on disk" in st
+    prefix = str(tmp_path / "piece")
+    subprocess.run([tool, "split", q, prefix], check=True, capture_output=True)
+    decoded = b"".join(decode_with_reference_or_oracle(f"{prefix}.{g:04d}", tmp_path) for g in range(4))
+    assert G.md5(decoded) == e["u_md5"]
+    # ... and the same files written directly
+    q2 = str(tmp_path / "cli_files.q")
+    subprocess.run([QVZ_BIN] + e["flags"].split() + [inp, q2], env=dict(env, QVZ_SHARD_FILES="1"), capture_output=True, check=True)
+    for g in range(4):
+        assert open(f"{q2}.{g:04d}", "rb").read() == open(f"{prefix}.{g:04d}", "rb").read()
+    d2 = str(tmp_path / "files.dec")
+    subprocess.run([QVZ_BIN, "-x", q2, d2], env=dict(env, QVZ_SHARD_FILES="1"), check=True, capture_output=True)
+    assert G.md5(open(d2, "rb").read()) == e["u_md5"]
+
+
+@pytest.mark.parametrize("name,shards", [("t2k_c3_f05_M", 3), ("cfg1_f05_L", 64), ("tiny5_r10", 1), ("r35_high_rate", 5)])
+def test_shardset_round_trip_and_well_jumps(tmp_path, name, shards):
+    """qvz_encode_file_shardset -> qvz_shardset_decode == the reference's -u; the split pieces carry the WELL state advanced to
+    each shard's first draw (qvz_hip_well_jump_many == one qvz_hip_well_jump per shard) and decode with the reference."""
+    from qvz_amd import host, kernels as K
+    from qvz_amd._lib import lib
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    q = str(tmp_path / "x.qset")
+    r = host.encode_file_shardset(inp, q, shards, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"],
+                                  seed_mode=host.SEED_DEBUG)
+    si = host.shardset_stat(q)
+    assert r.file_bytes == si.file_bytes == os.path.getsize(q) and r.stream_bytes == si.stream_bytes
+    dec = str(tmp_path / "x.dec")
+    assert lib().qvz_shardset_decode(q.encode(), dec.encode(), 0, None) == 0, lib().qvz_encode_last_error()
+    assert G.md5(open(dec, "rb").read()) == e["u_md5"]
+    prefix = str(tmp_path / "p")
+    host.shardset_split(q, prefix)
+    n, c = e["input"]["n"], e["input"]["c"]
+    first = host.shard_bounds(n, shards)
+    decoded = b""
+    for g in range(shards):
+        piece = open(f"{prefix}.{g:04d}", "rb").read()
+        assert int.from_bytes(piece[5:9], "big") == first[g + 1] - first[g]
+        well_at = len(piece) - 128 - int.from_bytes(open(q, "rb").read()[160 + 8 * g:168 + 8 * g], "little")
+        want = K.well_jump(O.WELL_DEBUG_STATE, first[g] * c // 4)
+        assert piece[well_at:well_at + 128] == want.tobytes(), f"WELL state of shard {g}"
+        decoded += decode_with_reference_or_oracle(f"{prefix}.{g:04d}", tmp_path)
     assert G.md5(decoded) == e["u_md5"]
 
 
@@ -238,7 +300,7 @@ def test_decode_file_of_the_reference_encoders_q(tmp_path, name):
 
 
 def test_encode_then_decode_round_trips_through_files(tmp_path):
-    """qvz (this build) -> .q -> qvz -x (this build) == -u, for one stream and for QVZ_SHARDS."""
+    """qvz (this build) -> .q -> qvz -x (this build) == -u, for one stream and for QVZ_SHARDS (one shard-set file)."""
     name = "cfg1_f05_L"
     e = G.CASES[name]
     inp, _ = write_input(tmp_path, name)
@@ -262,3 +324,71 @@ def test_decode_rejects_damaged_files(tmp_path):
     assert r.returncode == 1 and "codebook" in r.stdout
     r = subprocess.run([QVZ_BIN, "-x", str(tmp_path / "missing.q"), str(tmp_path / "o.txt")], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+@pytest.mark.parametrize("name", ["t2k_c3_f05_M", "cfg1_f05_L", "rescale_140k_c4", "rescale_c2_100k_c3", "wide_c151", "tiny5_r10"])
+def test_strict_stream_with_the_model_on_the_gpu(tmp_path, name, monkeypatch):
+    """The single-stream .q with the adaptive model on the GPU (qvz_hip_model_session_records + qvz_coder_encode_records,
+    the default) equals the one with model and chain on the host (QVZ_STRICT_MODEL=host) and the reference's file - with
+    several clusters, a table rescale inside the stream, 151 columns, and chunks of a few hundred reads (model state carried
+    from chunk to chunk)."""
+    from qvz_amd import host
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], seed_mode=host.SEED_DEBUG)
+    files = {}
+    for label, env, chunk in (("gpu", None, 0), ("gpu_small_chunks", None, 512), ("host", "host", 0)):
+        if env:
+            monkeypatch.setenv("QVZ_STRICT_MODEL", env)
+        else:
+            monkeypatch.delenv("QVZ_STRICT_MODEL", raising=False)
+        q = str(tmp_path / f"{label}.q")
+        r = host.encode_file(inp, q, chunk_reads=chunk, **kw)
+        assert r.stream_bytes == e["size"]
+        files[label] = open(q, "rb").read()
+    assert files["gpu"] == files["host"] == files["gpu_small_chunks"]
+    assert G.md5(files["gpu"]) == e["q_md5"]
+
+
+def test_model_session_records_equal_a_serial_model():
+    """qvz_hip_model_session_records against a plain serial model in Python (tests/test_host_cpu.records_from_feed): the
+    records must carry the same (cum_lo / n, (n - cum_hi) / n) to within the 2^-47 the exactness argument allows, chunk
+    after chunk."""
+    import ctypes as C
+    import torch
+    from qvz_amd import kernels as K
+    from qvz_amd._lib import lib
+    from test_host_cpu import oracle_side, product_codebook_from_oracle, records_from_feed
+    rows, opts, labels, ocbs, ref = oracle_side("t2k_c3_f05_M")
+    n, c = rows.shape[0], rows.shape[1] - 1
+    k = opts["k"]
+    cbs = [product_codebook_from_oracle(o) for o in ocbs]
+    feed = (ref["qi"].astype(np.uint16) | (ref["st"].astype(np.uint16) << 8))
+    want, pitch = records_from_feed(feed, labels, ocbs, k)
+    sess = C.c_void_p()
+    arr = (C.c_void_p * k)(*[cb.handle for cb in cbs])
+    assert lib().qvz_hip_model_session_open(c, k, arr, C.byref(sess)) == 0
+    assert lib().qvz_hip_model_session_pitch(sess) == pitch
+    cuts = [0, 700, 702, n]
+    pos = [0] + list(range(8, 8 + c))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        m = b - a
+        ld = (m + 255) & ~255
+        qi = torch.zeros((c, ld), dtype=torch.uint8, device="cuda")
+        st = torch.zeros((c, ld), dtype=torch.uint8, device="cuda")
+        qi[:, :m] = torch.from_numpy(np.ascontiguousarray(ref["qi"][a:b].T)).cuda()
+        st[:, :m] = torch.from_numpy(np.ascontiguousarray(ref["st"][a:b].T)).cuda()
+        lab = torch.zeros(ld, dtype=torch.uint8, device="cuda")
+        lab[:m] = torch.from_numpy(labels[a:b]).cuda()
+        rec = torch.zeros((((m + 1) // 2) * 2 * pitch, 2), dtype=torch.float64, device="cuda")
+        assert lib().qvz_hip_model_session_records(sess, qi.data_ptr(), st.data_ptr(), ld, lab.data_ptr(), m, rec.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        got = rec.cpu().numpy()
+        for i in range(m):
+            for p_ in pos:
+                src = (((a + i) >> 1) * (pitch >> 2) + (p_ >> 2)) * 8 + ((a + i) & 1) * 4 + (p_ & 3)
+                dst = ((i >> 1) * (pitch >> 2) + (p_ >> 2)) * 8 + (i & 1) * 4 + (p_ & 3)
+                assert abs(got[dst, 0] - want[src, 0]) <= 2.0 ** -57 and abs(got[dst, 1] - want[src, 1]) <= 2.0 ** -57, (a + i, p_)
+    assert lib().qvz_hip_model_session_status(sess, None) == 0
+    lib().qvz_hip_model_session_close(sess)

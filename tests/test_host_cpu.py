@@ -93,6 +93,75 @@ def test_coder_reproduces_reference_stream(name):
     assert blob + out == q
 
 
+def records_from_feed(feed, labels, ocbs, k):
+    """The records the GPU model leaves for one stream (include/qvz_coder.h), made here by a plain serial model in Python:
+    x = cum_lo / n / 1024, y = (n - cum_hi) / n / 1024; layout ((row/2)*(pitch/4) + pos/4)*8 + (row%2)*4 + pos%4."""
+    n, c = feed.shape
+    pos0 = 8 if k > 1 else 0
+    pitch = (pos0 + c + 7) & ~7
+    rec = np.zeros((((n + 1) // 2) * 2 * pitch, 2), dtype=np.float64)
+    tables = {}
+
+    def step(key, card, x):
+        t = tables.setdefault(key, [card, [1] * card])
+        tot, cnts = t
+        lo, f = sum(cnts[:x]), cnts[x]
+        out = (lo / tot / 1024.0, (tot - lo - f) / tot / 1024.0)
+        cnts[x] += 8
+        t[0] += 8
+        if t[0] > (1 << 19):                                        # update_stats rescale, qv_stream.c:15-24
+            t[1] = [(v >> 1) + 1 if v else 0 for v in cnts]
+            t[0] = sum(t[1])
+        return out
+
+    def at(row, pos):
+        return ((row >> 1) * (pitch >> 2) + (pos >> 2)) * 8 + (row & 1) * 4 + (pos & 3)
+
+    for i in range(n):
+        cl = int(labels[i]) if k > 1 else 0
+        if k > 1:
+            rec[at(i, 0)] = step(("cluster",), k, cl)
+        for s_ in range(c):
+            qi, st = int(feed[i, s_]) & 0xFF, int(feed[i, s_]) >> 8
+            rec[at(i, pos0 + s_)] = step((cl, s_, qi), int(ocbs[cl].nstates[s_, qi]), st)
+    return rec, pitch
+
+
+@pytest.mark.parametrize("name", ["t2k_f05_L", "t2k_c3_f05_M", "const_r05", "tiny5_r10", "uniform72_r20_A", "rescale_140k_c4"])
+def test_host_interval_chain_over_model_records(name):
+    """Strict single-stream mode, host half: qvz_coder_encode_records over the (cum_lo/n, (n - cum_hi)/n) records equals
+    qvz_coder_encode over the feed, i.e. the reference's stream - including a stream long enough for update_stats to
+    rescale, pending-bit runs (constant input) and chunked calls with an odd number of reads."""
+    from qvz_amd import host
+    rows, opts, labels, ocbs, ref = oracle_side(name)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    cbs = [product_codebook_from_oracle(o) for o in ocbs]
+    feed = (ref["qi"].astype(np.uint16) | (ref["st"].astype(np.uint16) << 8))
+    coder = host.Coder(c, [cb.handle for cb in cbs])
+    cuts = sorted(set([0, 1, (n // 3) | 1, n]))                     # chunks are laid out on their own: rows restart at 0
+    state = {}
+    out = b""
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b <= a:
+            continue
+        rec_all, pitch = state.get("rec") or records_from_feed(feed, labels, ocbs, opts["k"])
+        state["rec"] = (rec_all, pitch)
+        # re-lay the chunk's rows from row 0
+        pos0 = 8 if opts["k"] > 1 else 0
+        m = b - a
+        chunk = np.zeros((((m + 1) // 2) * 2 * pitch, 2), dtype=np.float64)
+        for i in range(m):
+            for pos in ([0] if pos0 else []) + list(range(pos0, pos0 + c)):
+                src = (((a + i) >> 1) * (pitch >> 2) + (pos >> 2)) * 8 + ((a + i) & 1) * 4 + (pos & 3)
+                dst = ((i >> 1) * (pitch >> 2) + (pos >> 2)) * 8 + (i & 1) * 4 + (pos & 3)
+                chunk[dst] = rec_all[src]
+        coder.encode_records(chunk, m, pitch)
+        out += coder.take()
+    coder.finish()
+    out += coder.take()
+    assert out == ref["stream"], "interval chain over records differs from the reference's stream"
+
+
 def test_coder_rejects_undefined_feed():
     from qvz_amd import host
     rows, opts, labels, ocbs, ref = oracle_side("t2k_f05_L")
