@@ -100,6 +100,13 @@ int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld,
                           uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                           uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,
                           void *stream);
+/* The same with the caller's cut of the n reads into `shards` ranges: h_bounds[0] = 0 < ... < h_bounds[shards] = n, every
+ * bound but the last a multiple of 4 reads (NULL: qvz_shard_bounds(n, shards)). A device that holds reads
+ * [first[a], first[b]) of a file cut by qvz_shard_bounds(N, S) codes its shards a .. b-1 with h_bounds[g] = first[a+g] - first[a]. */
+int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
+                                 uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                                 const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work,
+                                 uint64_t work_bytes, void *stream);
 /* Decoder of sharded streams on the GPU, one lane per stream: the reference's
  * start_qv_decompression (src/qv_compressor.c:145-231) with arithmetic_decoder_step / decoder_last_step
  * (src/arith.c:118-205) and update_stats (src/qv_stream.c:9-25), per shard. d_in holds stream g at
@@ -126,9 +133,10 @@ void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);
  * (src/qv_stream.c:109-110); its interval chain (src/arith.c:35-97) stays on one host core, but update_stats and the
  * cumulative counts (src/qv_stream.c:9-25, src/arith.c:39-43) do not: a table belongs to one column, so a model session
  * runs the adaptive model of the whole file on the GPU (a wave per column, tables in LDS, state carried from chunk to
- * chunk) and leaves, per symbol, the 16-byte record (cum_lo / n, (n - cum_hi) / n) / 1024 as doubles. The host coder
- * (qvz_coder_encode_records) turns a record into the new bounds with two multiply-adds - exactly floor(range*cum/n) of
- * arith.c:47-48, see qvz_coder.c - renormalises and writes bits. Byte-identical to qvz_coder_encode on the feed.
+ * chunk) and leaves, per symbol, a 16-byte record of two 64-bit integers: floor(2^62 * c / n) + 1 for c = cum_lo and
+ * c = cum_hi. The host coder (qvz_coder_encode_records) turns a record into the new bounds with two 64 x 64 -> 128 bit
+ * multiplies - exactly floor(range * c / n) of arith.c:47-48, proof in qvz_coder.c - renormalises and writes bits.
+ * Byte-identical to qvz_coder_encode on the feed.
  * open fails with QVZ_E_NOMEM when a column's tables do not fit LDS (the caller then keeps the model on the host).
  * Record (row, pos) of a chunk lies at ((row / 2) * (pitch / 4) + pos / 4) * 8 + (row % 2) * 4 + pos % 4 (in records);
  * positions per read: one cluster: pos = column; several: pos 0 = the cluster id, 1..7 unused, 8 + column.
@@ -143,7 +151,7 @@ int qvz_hip_model_session_records(qvz_model_session_t *s, const uint8_t *d_qi, c
 int qvz_hip_model_session_status(qvz_model_session_t *s, void *stream); /* QVZ_E_DEAD_CTX if a symbol had no table; synchronises */
 void qvz_hip_model_session_close(qvz_model_session_t *s);
 /* the host half: `reads` reads of records (layout above; h_rec in host memory) through the interval chain of `cd` */
-int qvz_coder_encode_records(qvz_coder_t *cd, const double *h_rec, uint64_t reads, uint32_t pitch);
+int qvz_coder_encode_records(qvz_coder_t *cd, const void *h_rec, uint64_t reads, uint32_t pitch);
 
 /* Initial adaptive model as a flat arena of tables [n][card][counts...] (cluster-id table at index 0) plus the
  * (cluster, column, quantizer) -> arena index map (0xFFFFFFFF = none). Shared by the host and GPU coders.

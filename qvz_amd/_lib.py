@@ -83,6 +83,9 @@ SIGNATURES = {
     "qvz_hip_encode_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "qvz_hip_encode_planes_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                               C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
+                                               C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.c_void_p]),
     "qvz_hip_decode_shards": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),

@@ -194,18 +194,17 @@ int qvz_coder_encode(qvz_coder_t *cd, const uint8_t *labels, const uint16_t *fee
 }
 
 /* The interval chain over records (include/qvz_coder.h, "strict single-stream mode with the model on the GPU"): per
- * symbol the model left x = cum_lo / n / 1024 and y = (n - cum_hi) / n / 1024 as doubles (relative error < 2^-50). With l
- * and ~u kept left-aligned in 32 bits (l32 = l << 10, nu32 = (~u & mask) << 10), R * 1024 = 2^32 - (l32 + nu32) and
- *     floor(R * cum_lo / n)     = trunc(R*1024 * x + 2^-24)                                        (arith.c:48)
- *     R - floor(R * cum_hi / n) = ceil(R * (n - cum_hi) / n) = trunc(R*1024 * y + 1 - 2^-24)       (arith.c:47)
- * exactly: R <= 2^22, so the product is off by at most 2^22 * 2^-50 from the true quotient, each of the two roundings
- * (product, sum: no fused multiply-add is assumed) by at most 2^-31, together less than 2^-24.9; a true quotient is an
- * integer Q - then the sum lies strictly between Q and Q + 1 for either constant - or has a fractional part in
- * [2^-19, 1 - 2^-19] (n <= 2^19 + 8), 2^-24 + 2^-24.9 away from the next integer on both sides. The record (0, 0) adds
- * nothing and leaves the (already renormalised) interval alone: positions without a symbol need no test.
+ * symbol the model left two 64-bit integers, X(c) = floor(2^62 * c / n) + 1 for c = cum_lo and c = cum_hi. With l and ~u
+ * kept left-aligned in 32 bits (l32 = l << 10, nu32 = (~u & mask) << 10), rd = 2^32 - (l32 + nu32) = (u - l + 1) * 1024 and
+ *     floor((u - l + 1) * c / n) = (rd * X(c)) >> 72                                               (arith.c:47-48)
+ * exactly: rd * X / 2^72 = R * X / 2^62 lies in (R c / n, R c / n + 2^-40] (R = u - l + 1 <= 2^22), and R c / n is an
+ * integer or at least 1 / n >= 2^-19.1 below the next one. So a symbol costs this core two independent 64 x 64 -> 128 bit
+ * multiplies, the renormalisation and the bit output - no table, no cumulative sum, no division, no floating point.
+ * The new bounds: l += q_lo; u = l_old + q_hi - 1, i.e. ~u loses q_hi and gains R: nu += R - q_hi.
  * E1/E2/E3 as in encode_symbol above, on the aligned words: k = leading bits on which l and u agree, j = leading
  * positions below the top where l has 1 and u has 0. Same integers, same bits as arith.c:50-97. */
-int qvz_coder_encode_records(qvz_coder_t *cd, const double *rec, uint64_t reads, uint32_t pitch) {
+int qvz_coder_encode_records(qvz_coder_t *cd, const void *records, uint64_t reads, uint32_t pitch) {
+    const uint64_t *rec = (const uint64_t *)records;
     const uint32_t C = cd->columns, pos0 = cd->clusters > 1 ? 8u : 0u;             /* several clusters: 0 = cluster id, 8 + column */
     if (!rec || (pitch & 7) || pitch < pos0 + C) return -1;
     uint32_t l32 = cd->l << 10, nu32 = (~cd->u & MASK_M) << 10;
@@ -217,37 +216,40 @@ int qvz_coder_encode_records(qvz_coder_t *cd, const double *rec, uint64_t reads,
             cd->acc = acc; cd->nbits = nbits;
             if (buf_reserve(cd, (uint64_t)(C + 1) * 4 + 64)) return -1;
         }
-        const double *row = rec + ((i >> 1) * quads * 8 + (i & 1) * 4) * 2;        /* unit (i / 2, 0), half i % 2 */
+        const uint64_t *row = rec + ((i >> 1) * quads * 8 + (i & 1) * 4) * 2;      /* unit (i / 2, 0), half i % 2 */
         for (uint32_t t = 0; t < C + (pos0 ? 1u : 0u); ++t) {
             const uint32_t p = !pos0 ? t : t == 0 ? 0u : pos0 + t - 1;              /* qv_write_cluster first (qv_compressor.c:86), then the columns */
-            const double *r = row + ((size_t)(p >> 2) * 8 + (p & 3)) * 2;
-            const double rd = 4294967296.0 - (double)(l32 + nu32);                 /* (u - l + 1) * 1024 */
-            l32 += (uint32_t)(rd * r[0] + 0x1p-24) << 10;
-            nu32 += (uint32_t)(rd * r[1] + (1.0 - 0x1p-24)) << 10;
+            const uint64_t *r = row + ((size_t)(p >> 2) * 8 + (p & 3)) * 2;
+            const uint64_t rd = 0x100000000ull - (uint64_t)(l32 + nu32);           /* (u - l + 1) * 1024; l32 + nu32 < 2^32 */
+            const uint32_t q_lo = (uint32_t)(((unsigned __int128)rd * r[0]) >> 72);
+            const uint32_t q_hi = (uint32_t)(((unsigned __int128)rd * r[1]) >> 72);
+            l32 += q_lo << 10;
+            nu32 += (uint32_t)rd - (q_hi << 10);                                   /* (R - q_hi) << 10; rd = 2^32 wraps to 0 with q_hi = R = 2^22 */
             const uint32_t k = (uint32_t)__builtin_clz(~(l32 ^ nu32));             /* the zero low bits stop it at 22 */
-            if (k) {                                                               /* E1/E2 batch */
-                const uint32_t top = l32 >> (32 - k);
-                if (scale3 <= 9) {                                                 /* first bit, the pending run, the other k - 1 bits: at most 31 bits */
-                    const uint32_t nb = k + (uint32_t)scale3;
-                    acc = (acc << nb) | (uint64_t)(top + ((((uint32_t)1 << scale3) - 1) << (k - 1)));
-                    nbits += nb;
-                } else {
-                    const uint32_t b = top >> (k - 1);
-                    cd->acc = acc; cd->nbits = nbits;
-                    put_bits(cd, b, 1);
-                    put_run(cd, !b, scale3);
-                    if (k > 1) put_bits(cd, top & ((1u << (k - 1)) - 1), k - 1);
-                    acc = cd->acc; nbits = cd->nbits;
-                }
-                scale3 = 0;
-                l32 <<= k;
-                nu32 <<= k;
-                if (nbits >= 32) {                                                 /* four whole bytes, most significant first */
-                    nbits -= 32;
-                    const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nbits));
-                    memcpy(cd->buf + cd->len, &w, 4);
-                    cd->len += 4;
-                }
+            /* E1/E2 batch, written without a branch on k (it is zero for about every other symbol, unpredictably): the k
+             * agreed bits with the pending run behind the first of them are top + ((2^s3 - 1) << (k - 1)) whatever the first
+             * bit is, k + s3 bits long; k = 0 makes that zero bits of value 0 and leaves the run pending */
+            const uint64_t s3 = k ? scale3 : 0;
+            if (__builtin_expect(s3 > 9, 0)) {                                     /* a long run: piecewise, any length */
+                const uint32_t top = l32 >> (32 - k), b = top >> (k - 1);
+                cd->acc = acc; cd->nbits = nbits;
+                put_bits(cd, b, 1);
+                put_run(cd, !b, s3);
+                if (k > 1) put_bits(cd, top & ((1u << (k - 1)) - 1), k - 1);
+                acc = cd->acc; nbits = cd->nbits;
+            } else {                                                               /* at most 22 + 9 bits */
+                const uint64_t top = (uint64_t)l32 >> (32 - k);
+                acc = (acc << (k + s3)) | (top + ((((uint64_t)1 << s3) - 1) << ((k - 1) & 63)));
+                nbits += k + (uint32_t)s3;
+            }
+            scale3 -= s3;
+            l32 <<= k;
+            nu32 <<= k;
+            if (nbits >= 32) {                                                     /* four whole bytes, most significant first */
+                nbits -= 32;
+                const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nbits));
+                memcpy(cd->buf + cd->len, &w, 4);
+                cd->len += 4;
             }
             const uint32_t j = (uint32_t)__builtin_clz(~(l32 & nu32) << 1);        /* E3 batch (j = 0: nothing) */
             scale3 += j;

@@ -57,8 +57,26 @@ void qvz_options_default(qvz_options_t *o) {
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
+static int job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_t lines, uint32_t columns,
+                    const qvz_options_t *opts, int draw_centroids);
+
 int qvz_job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_t lines, uint32_t columns,
                  const qvz_options_t *opts) {
+    return job_init(job, text, bytes, lines, columns, opts, 1);
+}
+
+int qvz_job_init_part(qvz_job_t *job, const uint8_t *text, uint64_t lines, uint32_t columns, const qvz_options_t *opts,
+                      uint64_t first_read, const uint8_t *centroid_rows) {
+    const int rc = job_init(job, text, 0, lines, columns, opts, 0);
+    if (rc) return rc;
+    if (first_read & 3) return qvz_job_fail(QVZ_E_ARG, "a part must start at a multiple of 4 reads (a WELL word boundary)");
+    job->first_read = first_read;
+    job->centroid_rows = centroid_rows;
+    return 0;
+}
+
+static int job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_t lines, uint32_t columns,
+                    const qvz_options_t *opts, int draw_centroids) {
     memset(job, 0, sizeof(*job));
     job->opts = *opts;
     job->text = text;
@@ -82,6 +100,7 @@ int qvz_job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_t l
         return qvz_job_fail(QVZ_E_ARG, "%s", qvz_hip_last_error());
     }
 
+    if (!draw_centroids) return 0;      /* a part of a file (qvz_multi.c): the whole file's centroid reads were drawn by the caller */
     /* Centroid picks (cluster.c:198-204) use libc rand() in whatever state the process is in. They are drawn here,
      * BEFORE the first HIP call: initialising the HIP runtime consumes rand() values of its own, which would shift
      * the sequence away from what the reference binary sees in a fresh process. */
@@ -207,7 +226,7 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
     h_moved = (double *)malloc((K + 1) * sizeof(double));
     if (!job->h_means || !job->h_counts || !job->h_acc || !h_moved) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
     for (uint32_t j = 0; j < K; ++j) {                                          /* memcpy of the read, cluster.c:201 */
-        const uint8_t *row = job->text + job->centroid_lines[j] * stride;
+        const uint8_t *row = job->centroid_rows ? job->centroid_rows + (size_t)j * stride : job->text + job->centroid_lines[j] * stride;
         for (uint32_t s = 0; s < C; ++s) job->h_means[(size_t)j * C + s] = (uint8_t)(row[s] - 33);
     }
     HIP(qvz_hip_malloc((void **)&job->d_means, (size_t)K * C));
@@ -225,6 +244,10 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
         HIP(qvz_hip_memset(job->d_acc, 0, (size_t)K * C * sizeof(uint64_t), NULL));
         HIP(qvz_hip_kmeans_assign(job->d_sym, N, C, ld, K, job->d_means, job->d_labels, job->d_counts, NULL));
         HIP(qvz_hip_kmeans_accumulate(job->d_sym, job->d_labels, N, C, ld, K, job->d_acc, NULL));
+        if (job->allreduce) {                                                   /* the sums of every part of the file */
+            HIP(job->allreduce(job->allreduce_ctx, job->d_acc, (uint64_t)K * C, 8, NULL));
+            HIP(job->allreduce(job->allreduce_ctx, job->d_counts, K, 4, NULL));
+        }
         HIP(qvz_hip_kmeans_update(job->d_acc, job->d_counts, K, C, job->d_means, job->d_moved, job->d_kstat, NULL));
         HIP(qvz_hip_copy_d2h(h_moved, job->d_moved, (K + 1) * sizeof(double), NULL));
         HIP(qvz_hip_copy_d2h(&kstat, job->d_kstat, sizeof(kstat), NULL));
@@ -263,6 +286,7 @@ int qvz_job_stats(qvz_job_t *job) {
     HIP(qvz_hip_malloc((void **)&job->d_cnt, words * sizeof(uint32_t)));
     HIP(qvz_hip_memset(job->d_cnt, 0, words * sizeof(uint32_t), NULL));
     HIP(qvz_hip_pmf_hist(job->d_sym, job->K > 1 ? job->d_labels : NULL, job->N, job->C, job->ld, job->K, job->d_cnt, NULL));
+    if (job->allreduce) HIP(job->allreduce(job->allreduce_ctx, job->d_cnt, words, 4, NULL));   /* counters of the whole file */
     HIP(qvz_hip_stream_sync(NULL));
     job->counted = 1;
     job->t_stats = now() - t0;
@@ -315,7 +339,7 @@ typedef struct {
     uint8_t *d_draws;
     double *d_err;
     int32_t *d_status;
-    double *d_rec, *h_rec;        /* model on the GPU: 16-byte records instead of the feed (qvz_hip_model_session_records) */
+    uint64_t *d_rec, *h_rec;      /* model on the GPU: 16-byte records instead of the feed (qvz_hip_model_session_records) */
     uint16_t *h_feed;
     uint8_t *h_labels, *h_text;
     double *h_err;
@@ -510,7 +534,7 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     int32_t *d_status = NULL, status = 0;
     uint64_t *sizes = NULL, *first = NULL;
     uint32_t *wstates = NULL;
-    if (!shards || shards > qvz_shard_limit(N)) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads: a shard needs at least 4 reads", shards, (unsigned long long)N);
+    if (!shards || (!job->shard_bounds && shards > qvz_shard_limit(N))) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads: a shard needs at least 4 reads", shards, (unsigned long long)N);
 
     if (job->opts.seed_mode == QVZ_SEED_EXPLICIT) {                             /* qv_stream.c:70-89 */
         memcpy(job->well_state, job->opts.well_state, sizeof(job->well_state));
@@ -534,8 +558,9 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         HIP(qvz_hip_copy_h2d(d_qs, h_qs, qsn * sizeof(uint16_t), NULL));
         HIP(qvz_hip_copy_h2d(d_dist, job->h_dist, sizeof(job->h_dist), NULL));
     }
-    qvz_shard_bounds(N, shards, first);
-    /* WELL draws, quantizer */
+    if (job->shard_bounds) memcpy(first, job->shard_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
+    else qvz_shard_bounds(N, shards, first);
+    /* WELL draws (this part's first draw is first_read * C draws into the file's stream), quantizer */
     HIP(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
     HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
     HIP(qvz_hip_malloc((void **)&d_qi, (size_t)C * ld));
@@ -543,7 +568,7 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     HIP(qvz_hip_malloc((void **)&d_err, N * sizeof(double)));
     HIP(qvz_hip_malloc((void **)&d_status, sizeof(int32_t)));
     HIP(qvz_hip_memset(d_status, 0, sizeof(int32_t), NULL));
-    HIP(qvz_hip_well_draws(job->well_state, 0, N, C, d_draws, ld, NULL));
+    HIP(qvz_hip_well_draws(job->well_state, job->first_read, N, C, d_draws, ld, NULL));
     HIP(qvz_hip_quantize(job->d_sym, K > 1 ? job->d_labels : NULL, N, C, ld, K, d_ct, d_qs, d_draws, ld, d_dist, d_qv, d_qi, d_st,
                          ld, d_err, d_status, NULL));
     HIP(qvz_hip_copy_d2h(&status, d_status, sizeof(status), NULL));
@@ -558,6 +583,7 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         HIP(qvz_hip_stream_sync(NULL));
         for (uint64_t i = 0; i < N; ++i) distortion += h_err[i] / ((double)C);
         if (distortion_out) *distortion_out = distortion / ((double)N);
+        if (job->collect) { job->out_err = h_err; h_err = NULL; }               /* the caller sums all parts in file order */
         free(h_err); h_err = NULL;
         qvz_hip_free(d_err); d_err = NULL;
     }
@@ -582,8 +608,8 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
             cap = ((per * C * bits) / 8 + 512 + 3) & ~3ull;
             qvz_hip_free(d_out); d_out = NULL;
             HIP(qvz_hip_malloc((void **)&d_out, (size_t)shards * cap));
-            const int crc = qvz_hip_encode_planes(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
-                                                  shards, d_out, cap, sizes, NULL, 0, NULL);
+            const int crc = qvz_hip_encode_planes_bounds(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
+                                                         shards, job->shard_bounds, d_out, cap, sizes, NULL, 0, NULL);
             if (crc == QVZ_OK) break;
             if (crc != QVZ_E_NOMEM || bits >= 24) { rc = qvz_job_fail(crc, "%s", qvz_hip_last_error()); goto done; }
         }
@@ -597,7 +623,10 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
         HIP(qvz_hip_copy_d2h(h_buf, d_text, total, NULL));
         HIP(qvz_hip_stream_sync(NULL));
-        if (fset) {                                                             /* one shard set: codebooks once (qvz_shardset.h) */
+        if (job->collect) {                                                     /* a part of a file: the caller assembles the whole */
+            job->out_streams = h_buf; h_buf = NULL;
+            job->out_sizes = sizes; sizes = NULL;
+        } else if (fset) {                                                      /* one shard set: codebooks once (qvz_shardset.h) */
             qvz_shardset_info_t si;
             if ((rc = qvz_shardset_write(fset, K, C, N, shards, job->well_state, (const qvz_codebook_t *const *)job->cbs, h_buf, 0, sizes, &si))) goto done;
             ftotal = si.file_bytes;

@@ -38,12 +38,29 @@ typedef struct qvz_job {
     int32_t *d_kstat;
     int uploaded, clustered, counted;
     double t_upload, t_cluster, t_stats, t_codebook, t_encode;
+    /* ---- a job that holds PART of a file (one device of a multi-device encode, qvz_multi.c); all zero otherwise ---- */
+    uint64_t first_read;        /* global number of this job's first read: WELL offset of its draws (a multiple of 4)         */
+    const uint8_t *centroid_rows;  /* [K][C+1] text rows of the k centroid reads, wherever in the file they lie (cluster.c:198-201) */
+    /* sum of a device buffer over all parts (count elements of width 4 or 8 bytes, unsigned), in place, on `stream`:
+     * the k-means accumulators and counts per iteration, the PMF counters once */
+    int (*allreduce)(void *ctx, void *d_buf, uint64_t count, int width, void *stream);
+    void *allreduce_ctx;
+    const uint64_t *shard_bounds;  /* [shards + 1] this part's cut into shards, relative to its first read (NULL: qvz_shard_bounds) */
+    /* sharded compress hands its products back instead of writing files when `collect` is set */
+    int collect;
+    uint8_t *out_streams;       /* malloc'd: the part's streams packed back to back                                            */
+    uint64_t *out_sizes;        /* malloc'd: [shards]                                                                          */
+    double *out_err;            /* malloc'd: [N] per-read error sums, for the file-order distortion sum (qv_compressor.c:127)  */
 } qvz_job_t;
 
 /* Draws the centroid reads with libc rand() (cluster.c:198-204). Must run before the first HIP call of the process:
  * HIP runtime start-up consumes rand() values. No device work. */
 int qvz_job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes_or_zero, uint64_t lines, uint32_t columns,
                  const qvz_options_t *opts);
+/* A job over PART of a file: reads [first_read, first_read + lines) at `text`; no rand() draws (the whole file's centroid
+ * reads come as centroid_rows, K rows of columns + 1 bytes). The caller sets allreduce / shard_bounds / collect. */
+int qvz_job_init_part(qvz_job_t *job, const uint8_t *text, uint64_t lines, uint32_t columns, const qvz_options_t *opts,
+                      uint64_t first_read, const uint8_t *centroid_rows);
 int qvz_job_upload(qvz_job_t *job);                       /* text -> column-major symbols in HBM            */
 int qvz_job_kmeans(qvz_job_t *job, int want_host_labels); /* do_kmeans_clustering, cluster.c:212-244        */
 int qvz_job_stats(qvz_job_t *job);                        /* counting loop of calculate_statistics           */

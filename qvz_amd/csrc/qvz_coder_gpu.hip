@@ -487,6 +487,25 @@ __device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint3
     return make_double2((double)cum_lo * rn, (double)(n - cum_lo - fx) * rn);
 }
 
+// The record for the HOST's interval chain (strict single-stream mode, qvz_coder_encode_records): two 64-bit integers in
+// the record's 16 bytes, X(c) = floor(2^62 * c / n) + 1 for c = cum_lo and c = cum_hi. With rd = (u - l + 1) * 1024 <= 2^32
+//     floor((u - l + 1) * c / n) = (rd * X(c)) >> 72                                                  (arith.c:47-48)
+// exactly: rd * X / 2^72 = R * X / 2^62 lies in (R c / n, R c / n + 2^-40] (R <= 2^22), and R c / n is an integer or at
+// least 1 / n >= 2^-19.1 below the next one. One 64 x 64 -> 128 bit multiply per bound on the host instead of a
+// conversion, a multiply-add and a conversion back: the host's dependent chain per symbol is what the strict mode's
+// speed is. The quotient of the 82-bit numerator comes from two 64-bit divisions (long division in base 2^31; the
+// remainder of the first is below n < 2^20). This kernel variant has the GPU to itself (one stream: a few dozen
+// workgroups), the divisions cost nothing that matters.
+__device__ __forceinline__ uint64_t frac62(uint32_t c, uint32_t n) {
+    const uint64_t a = (uint64_t)c << 31;
+    const uint64_t hi = a / n, rem = a - hi * n;
+    const uint64_t lo = (rem << 31) / n;
+    return ((hi << 31) | lo) + 1;                                // hi < 2^32 (c <= n), lo < 2^31
+}
+__device__ __forceinline__ Record make_record_fixed(uint32_t n, uint32_t cum_lo, uint32_t fx) {
+    return make_double2(__longlong_as_double((long long)frac62(cum_lo, n)), __longlong_as_double((long long)frac62(cum_lo + fx, n)));
+}
+
 // Record area of one segment. A read has Cp = Cx rounded up to 8 records (the pad records are zero = no-ops), streams
 // go in groups of 64 (one coder workgroup). A stream's records are cut into units of 2 reads x 4 columns (8 records,
 // 128 bytes: [read parity][column & 3]) and the 64 streams' units of the same (read pair, column group) lie side by
@@ -947,7 +966,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 }
             }
             {
-                const Record rr = make_record(n ? n : 1u, cum_lo, fx);
+                const Record rr = DENSE ? make_record_fixed(n ? n : 1u, cum_lo, fx) : make_record(n ? n : 1u, cum_lo, fx);
                 outr = make_double2(ok ? rr.x : 0.0, ok ? rr.y : 0.0);
             }
         }
@@ -1361,7 +1380,11 @@ done:
     return rc;
 }
 
-static double g_planes_ms[2] = {0.0, 0.0};   // model kernels, coder kernels of the last qvz_hip_encode_planes call
+extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
+                                            uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                                            const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
+                                            void *d_work, uint64_t work_bytes, void *stream);
+static thread_local double g_planes_ms[2] = {0.0, 0.0};   // model kernels, coder kernels of the calling thread's last qvz_hip_encode_planes call
 extern "C" void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms) {
     if (model_ms) *model_ms = g_planes_ms[0];
     if (coder_ms) *coder_ms = g_planes_ms[1];
@@ -1371,8 +1394,21 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
                                      uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                      uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,
                                      void *stream) {
+    return qvz_hip_encode_planes_bounds(d_qi, d_st, ld, d_labels, n, columns, clusters, cbs, shards, nullptr, d_out, cap_per_shard,
+                                        h_sizes, d_work, work_bytes, stream);
+}
+
+extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
+                                            uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                                            const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
+                                            void *d_work, uint64_t work_bytes, void *stream) {
     if (!d_qi || !d_st || !n || !columns || !clusters || !shards || !d_out || !h_sizes || ld < n || (ld & 3))
         return qvz_set_error(QVZ_E_ARG, "bad plane-coder arguments");
+    if (h_bounds) {                                              // the caller's cut of these n reads (a device's part of a larger file)
+        if (h_bounds[0] != 0 || h_bounds[shards] != n) return qvz_set_error(QVZ_E_ARG, "shard bounds must run from 0 to n");
+        for (uint32_t g = 0; g < shards; ++g)
+            if ((h_bounds[g] & 3) || h_bounds[g + 1] <= h_bounds[g]) return qvz_set_error(QVZ_E_ARG, "shard %u: bounds must ascend in multiples of 4 reads", g);
+    }
     if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
     if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
     hipStream_t st = (hipStream_t)stream;
@@ -1382,7 +1418,8 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
         return qvz_set_error(QVZ_E_NOMEM, "model build failed");
     uint64_t *h_first = (uint64_t *)malloc((shards + 1) * sizeof(uint64_t));
     if (!h_first) { free(h_arena); free(h_off); return qvz_set_error(QVZ_E_NOMEM, "host alloc"); }
-    qvz_shard_bounds(n, shards, h_first);
+    if (h_bounds) memcpy(h_first, h_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
+    else qvz_shard_bounds(n, shards, h_first);
     uint64_t longest = 0;
     for (uint32_t g = 0; g < shards; ++g) if (h_first[g + 1] - h_first[g] > longest) longest = h_first[g + 1] - h_first[g];
     longest = (longest + 3) & ~(uint64_t)3;

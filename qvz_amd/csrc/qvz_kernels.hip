@@ -8,6 +8,8 @@
 // Reference behaviour restated by each kernel is cited as file:line of mikelhernaez/qvz.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -668,6 +670,46 @@ __global__ __launch_bounds__(256) void k_sym_max(const uint8_t *__restrict__ D, 
     if ((threadIdx.x & 63) == 0) atomicMax(result, m);
 }
 
+// ---- per-device scratch --------------------------------------------------------------------------------------------
+// Small device buffers that outlive a call (the symbol-maximum word of the PMF pass, the WELL jump tables and their
+// workspaces) belong to the device they were allocated on: a process may encode on several ordinals (qvz_options_t.device,
+// QVZ_DEVICES). They are kept per ordinal; a caller holds the ordinal's lock while it enqueues work that uses them, and a
+// second stream that takes them over first waits (stream-ordered, hipStreamWaitEvent) for the previous user's last kernel.
+#define QVZ_MAX_DEVICES 64
+struct DevScratch {
+    std::mutex mu;
+    uint32_t *d_max = nullptr;      // k_sym_max result
+    uint32_t *d_pow = nullptr;      // [WELL_MAXJ][1024*32] : T^(2^j)
+    uint32_t *d_states = nullptr;   // chunk start states
+    uint64_t states_cap = 0;
+    uint32_t *d_tmp = nullptr;      // 2 x 32 words ping-pong for single-state jumps
+    uint32_t *d_ws = nullptr;       // word stream of one pass of qvz_hip_well_draws
+    uint64_t ws_words = 0;
+    hipEvent_t busy = nullptr;      // recorded after the last kernel that used the scratch
+    hipStream_t last = nullptr;
+    bool used = false;
+};
+static DevScratch g_dev[QVZ_MAX_DEVICES];
+
+struct ScratchLock {                // RAII: lock the current device's scratch for work on `st`
+    DevScratch *d = nullptr;
+    hipStream_t st;
+    int rc = QVZ_OK;
+    explicit ScratchLock(hipStream_t stream) : st(stream) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= QVZ_MAX_DEVICES) { rc = qvz_set_error(QVZ_E_HIP, "no current device"); return; }
+        d = &g_dev[dev];
+        d->mu.lock();
+        if (!d->busy && hipEventCreateWithFlags(&d->busy, hipEventDisableTiming) != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "event create failed"); return; }
+        if (d->used && d->last != st && hipStreamWaitEvent(st, d->busy, 0) != hipSuccess) rc = qvz_set_error(QVZ_E_HIP, "stream wait failed");
+    }
+    ~ScratchLock() {
+        if (!d) return;
+        if (d->busy && hipEventRecord(d->busy, st) == hipSuccess) { d->used = true; d->last = st; }
+        d->mu.unlock();
+    }
+};
+
 static unsigned env_uint(const char *name, unsigned dflt) {
     const char *v = getenv(name);
     return v && *v ? (unsigned)strtoul(v, nullptr, 10) : dflt;
@@ -685,8 +727,10 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
     // tile side from a device-side sample of the data (one tiny launch + a 4-byte read back)
     unsigned AA = env_uint("QVZ_PMF_AA", 0);
     if (AA == 0) {
-        static uint32_t *d_max = nullptr;
-        if (!d_max) QVZ_HIP_CHECK(hipMalloc(&d_max, sizeof(uint32_t)));
+        ScratchLock lk(st);
+        if (lk.rc) return lk.rc;
+        if (!lk.d->d_max) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_max, sizeof(uint32_t)));
+        uint32_t *d_max = lk.d->d_max;
         uint32_t h_max = 0;
         QVZ_HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_sym_max, dim3(c), dim3(256), 0, st, d_sym, n, ld, d_max);
@@ -915,47 +959,32 @@ __global__ __launch_bounds__(64) void k_well_gen(const uint32_t *__restrict__ st
     }
 }
 
-struct WellTables {
-    int device = -1;
-    uint32_t *d_pow = nullptr;      // [WELL_MAXJ][1024*32] : T^(2^j)
-    uint32_t *d_states = nullptr;   // chunk start states
-    uint64_t states_cap = 0;
-    uint32_t *d_tmp = nullptr;      // 2 x 32 words ping-pong for single-state jumps
-};
-static WellTables g_well;
-
-static int well_init(hipStream_t st) {
-    int dev = 0;
-    QVZ_HIP_CHECK(hipGetDevice(&dev));
-    if (g_well.d_pow && g_well.device == dev) return QVZ_OK;
-    if (g_well.d_pow) {   // device changed: rebuild (single-device-per-process is the supported model)
-        (void)hipFree(g_well.d_pow); (void)hipFree(g_well.d_states); (void)hipFree(g_well.d_tmp);
-        g_well = WellTables();
-    }
+// T^(2^j) for the current device (built once per ordinal); the caller holds the ordinal's ScratchLock
+static int well_init(DevScratch &W, hipStream_t st) {
+    if (W.d_pow) return QVZ_OK;
     const size_t msz = 1024 * 32 * sizeof(uint32_t);
     uint32_t *T = (uint32_t *)malloc(msz);
     if (!T) return qvz_set_error(QVZ_E_NOMEM, "host alloc");
     well_build_T(T);
-    QVZ_HIP_CHECK(hipMalloc(&g_well.d_pow, WELL_MAXJ * msz));
-    QVZ_HIP_CHECK(hipMalloc(&g_well.d_tmp, 2 * 32 * sizeof(uint32_t)));
-    QVZ_HIP_CHECK(hipMemcpy(g_well.d_pow, T, msz, hipMemcpyHostToDevice));
+    QVZ_HIP_CHECK(hipMalloc(&W.d_pow, WELL_MAXJ * msz));
+    QVZ_HIP_CHECK(hipMalloc(&W.d_tmp, 2 * 32 * sizeof(uint32_t)));
+    QVZ_HIP_CHECK(hipMemcpy(W.d_pow, T, msz, hipMemcpyHostToDevice));
     free(T);
     for (int j = 1; j < WELL_MAXJ; ++j)
-        hipLaunchKernelGGL(k_gf2_square, dim3(1024), dim3(64), 0, st, g_well.d_pow + (size_t)(j - 1) * 1024 * 32,
-                           g_well.d_pow + (size_t)j * 1024 * 32);
+        hipLaunchKernelGGL(k_gf2_square, dim3(1024), dim3(64), 0, st, W.d_pow + (size_t)(j - 1) * 1024 * 32,
+                           W.d_pow + (size_t)j * 1024 * 32);
     QVZ_HIP_CHECK(hipGetLastError());
-    g_well.device = dev;
     return QVZ_OK;
 }
 
 // d_out (32 words) = T^words * state ; uses d_tmp ping-pong
-static int well_jump_device(const uint32_t *h_state, uint64_t words, uint32_t *d_out, hipStream_t st) {
+static int well_jump_device(DevScratch &W, const uint32_t *h_state, uint64_t words, uint32_t *d_out, hipStream_t st) {
     if (words >> WELL_MAXJ) return qvz_set_error(QVZ_E_ARG, "WELL jump too large");
-    uint32_t *a = g_well.d_tmp, *b = g_well.d_tmp + 32;
+    uint32_t *a = W.d_tmp, *b = W.d_tmp + 32;
     QVZ_HIP_CHECK(hipMemcpyAsync(a, h_state, 128, hipMemcpyHostToDevice, st));
     for (int j = 0; j < WELL_MAXJ; ++j) {
         if ((words >> j) & 1) {
-            hipLaunchKernelGGL(k_gf2_apply, dim3(1), dim3(1024), 0, st, g_well.d_pow + (size_t)j * 1024 * 32, a, b,
+            hipLaunchKernelGGL(k_gf2_apply, dim3(1), dim3(1024), 0, st, W.d_pow + (size_t)j * 1024 * 32, a, b,
                                (uint64_t)1);
             uint32_t *t = a; a = b; b = t;
         }
@@ -966,11 +995,13 @@ static int well_jump_device(const uint32_t *h_state, uint64_t words, uint32_t *d
 }
 
 extern "C" int qvz_hip_well_jump(const uint32_t *h_state, uint64_t words, uint32_t *h_state_out) {
-    int rc = well_init(0);
+    ScratchLock lk(0);
+    if (lk.rc) return lk.rc;
+    int rc = well_init(*lk.d, 0);
     if (rc) return rc;
     uint32_t *d = nullptr;
     QVZ_HIP_CHECK(hipMalloc(&d, 128));
-    rc = well_jump_device(h_state, words, d, 0);
+    rc = well_jump_device(*lk.d, h_state, words, d, 0);
     if (!rc && hipMemcpy(h_state_out, d, 128, hipMemcpyDeviceToHost) != hipSuccess)
         rc = qvz_set_error(QVZ_E_HIP, "copy back failed");
     (void)hipFree(d);
@@ -1016,7 +1047,9 @@ __global__ __launch_bounds__(1024) void k_gf2_apply_if(const uint32_t *__restric
 extern "C" int qvz_hip_well_jump_many(const uint32_t *h_state, const uint64_t *h_jump, uint64_t count, uint32_t *h_states_out) {
     if (!h_state || !h_jump || !h_states_out) return qvz_set_error(QVZ_E_ARG, "null argument");
     if (count == 0) return QVZ_OK;
-    int rc = well_init(0);
+    ScratchLock lk(0);
+    if (lk.rc) return lk.rc;
+    int rc = well_init(*lk.d, 0);
     if (rc) return rc;
     uint64_t top = 0;
     for (uint64_t i = 0; i < count; ++i) top |= h_jump[i];
@@ -1036,7 +1069,7 @@ extern "C" int qvz_hip_well_jump_many(const uint32_t *h_state, const uint64_t *h
         for (int j = 0; j < WELL_MAXJ && (top >> j); ++j) {
             if (!((top >> j) & 1)) continue;
             hipLaunchKernelGGL(k_gf2_apply_if, dim3((unsigned)((count + WELL_SPB - 1) / WELL_SPB)), dim3(1024), 0, 0,
-                               g_well.d_pow + (size_t)j * 1024 * 32, d_a, d_b, d_jump, j, count);
+                               lk.d->d_pow + (size_t)j * 1024 * 32, d_a, d_b, d_jump, j, count);
             uint32_t *t = d_a; d_a = d_b; d_b = t;
         }
         e = hipGetLastError();
@@ -1047,20 +1080,19 @@ extern "C" int qvz_hip_well_jump_many(const uint32_t *h_state, const uint64_t *h
     return QVZ_OK;
 }
 
-extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
-                                  void *stream) {
+static int well_words_locked(DevScratch &W, const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
+                             hipStream_t st) {
     if (nwords == 0) return QVZ_OK;
     if ((uintptr_t)d_words & 15) return qvz_set_error(QVZ_E_ARG, "d_words must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    int rc = well_init(st);
+    int rc = well_init(W, st);
     if (rc) return rc;
     const uint64_t nchunks = (nwords + WELL_CHUNK - 1) / WELL_CHUNK;
-    if (nchunks > g_well.states_cap) {
-        if (g_well.d_states) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(g_well.d_states); }
-        g_well.states_cap = nchunks + nchunks / 4 + 64;
-        QVZ_HIP_CHECK(hipMalloc(&g_well.d_states, g_well.states_cap * 128));
+    if (nchunks > W.states_cap) {
+        if (W.d_states) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(W.d_states); }
+        W.states_cap = nchunks + nchunks / 4 + 64;
+        QVZ_HIP_CHECK(hipMalloc(&W.d_states, W.states_cap * 128));
     }
-    rc = well_jump_device(h_state, first_word, g_well.d_states, st);
+    rc = well_jump_device(W, h_state, first_word, W.d_states, st);
     if (rc) return rc;
     // doubling: states [2^l, 2^(l+1)) = T^(CHUNK*2^l) * states [0, 2^l)
     for (int l = 0; (1ull << l) < nchunks; ++l) {
@@ -1069,12 +1101,19 @@ extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, 
         const int j = WELL_CHUNK_LOG2 + l;
         if (j >= WELL_MAXJ) return qvz_set_error(QVZ_E_ARG, "WELL range too large");
         hipLaunchKernelGGL(k_gf2_apply, dim3((unsigned)((make + WELL_SPB - 1) / WELL_SPB)), dim3(1024), 0, st,
-                           g_well.d_pow + (size_t)j * 1024 * 32, g_well.d_states, g_well.d_states + have * 32, make);
+                           W.d_pow + (size_t)j * 1024 * 32, W.d_states, W.d_states + have * 32, make);
     }
-    hipLaunchKernelGGL(k_well_gen, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, g_well.d_states, nchunks,
+    hipLaunchKernelGGL(k_well_gen, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, W.d_states, nchunks,
                        nwords, d_words);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
+}
+
+extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
+                                  void *stream) {
+    ScratchLock lk((hipStream_t)stream);
+    if (lk.rc) return lk.rc;
+    return well_words_locked(*lk.d, h_state, first_word, nwords, d_words, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1121,8 +1160,10 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
     int rc = check_matrix(n, c, ld);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    static uint32_t *d_ws = nullptr;
-    static uint64_t ws_words = 0;
+    ScratchLock lk(st);
+    if (lk.rc) return lk.rc;
+    uint32_t *&d_ws = lk.d->d_ws;
+    uint64_t &ws_words = lk.d->ws_words;
     uint32_t TR = (DT_MAX_WORDS * 4 - 8) / c;                    // reads per tile: TR*c draws fit the LDS buffer
     TR &= ~3u;
     if (TR > 256) TR = 256;
@@ -1139,7 +1180,7 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
         const uint64_t m = n - r0 < chunk_reads ? n - r0 : chunk_reads;
         const uint64_t g0 = (first_read + r0) * c, g1 = g0 + m * c;
         const uint64_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
-        rc = qvz_hip_well_words(h_state, w0, w1 - w0, d_ws, stream);
+        rc = well_words_locked(*lk.d, h_state, w0, w1 - w0, d_ws, st);
         if (rc) return rc;
         dim3 grid((unsigned)((m + TR - 1) / TR));
         hipLaunchKernelGGL(k_draws_transpose, grid, dim3(256), 0, st, d_ws, w0, g0, m, c, TR, d_draws + r0, ld);

@@ -315,8 +315,8 @@ class Coder:
             raise QvzHipError("coder feed addresses an undefined quantizer or state")
 
     def encode_records(self, rec, reads, pitch):
-        """rec: float64 array of records in the single-stream layout of qvz_hip_model_session_records."""
-        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        """rec: uint64 array (.., 2) of records in the single-stream layout of qvz_hip_model_session_records."""
+        rec = np.ascontiguousarray(rec, dtype=np.uint64)
         if lib().qvz_coder_encode_records(self.h, rec.ctypes.data_as(C.c_void_p), reads, pitch):
             raise QvzHipError("qvz_coder_encode_records failed")
 

@@ -259,6 +259,7 @@ def test_shardset_round_trip_and_well_jumps(tmp_path, name, shards):
     inp, _ = write_input(tmp_path, name)
     opts = G.case_opts(name)
     q = str(tmp_path / "x.qset")
+    fresh_process_rand()
     r = host.encode_file_shardset(inp, q, shards, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"],
                                   seed_mode=host.SEED_DEBUG)
     si = host.shardset_stat(q)
@@ -344,6 +345,7 @@ def test_strict_stream_with_the_model_on_the_gpu(tmp_path, name, monkeypatch):
         else:
             monkeypatch.delenv("QVZ_STRICT_MODEL", raising=False)
         q = str(tmp_path / f"{label}.q")
+        fresh_process_rand()
         r = host.encode_file(inp, q, chunk_reads=chunk, **kw)
         assert r.stream_bytes == e["size"]
         files[label] = open(q, "rb").read()
@@ -352,9 +354,8 @@ def test_strict_stream_with_the_model_on_the_gpu(tmp_path, name, monkeypatch):
 
 
 def test_model_session_records_equal_a_serial_model():
-    """qvz_hip_model_session_records against a plain serial model in Python (tests/test_host_cpu.records_from_feed): the
-    records must carry the same (cum_lo / n, (n - cum_hi) / n) to within the 2^-47 the exactness argument allows, chunk
-    after chunk."""
+    """qvz_hip_model_session_records against a plain serial model in Python integers (tests/test_host_cpu.records_from_feed):
+    the records - floor(2^62 * c / n) + 1 for c = cum_lo, cum_hi - must be equal to the last bit, chunk after chunk."""
     import ctypes as C
     import torch
     from qvz_amd import kernels as K
@@ -381,14 +382,14 @@ def test_model_session_records_equal_a_serial_model():
         st[:, :m] = torch.from_numpy(np.ascontiguousarray(ref["st"][a:b].T)).cuda()
         lab = torch.zeros(ld, dtype=torch.uint8, device="cuda")
         lab[:m] = torch.from_numpy(labels[a:b]).cuda()
-        rec = torch.zeros((((m + 1) // 2) * 2 * pitch, 2), dtype=torch.float64, device="cuda")
+        rec = torch.zeros((((m + 1) // 2) * 2 * pitch, 2), dtype=torch.int64, device="cuda")
         assert lib().qvz_hip_model_session_records(sess, qi.data_ptr(), st.data_ptr(), ld, lab.data_ptr(), m, rec.data_ptr(), None) == 0
         torch.cuda.synchronize()
-        got = rec.cpu().numpy()
+        got = rec.cpu().numpy().view(np.uint64)
         for i in range(m):
             for p_ in pos:
                 src = (((a + i) >> 1) * (pitch >> 2) + (p_ >> 2)) * 8 + ((a + i) & 1) * 4 + (p_ & 3)
                 dst = ((i >> 1) * (pitch >> 2) + (p_ >> 2)) * 8 + (i & 1) * 4 + (p_ & 3)
-                assert abs(got[dst, 0] - want[src, 0]) <= 2.0 ** -57 and abs(got[dst, 1] - want[src, 1]) <= 2.0 ** -57, (a + i, p_)
+                assert got[dst, 0] == want[src, 0] and got[dst, 1] == want[src, 1], (a + i, p_)
     assert lib().qvz_hip_model_session_status(sess, None) == 0
     lib().qvz_hip_model_session_close(sess)

@@ -94,19 +94,19 @@ def test_coder_reproduces_reference_stream(name):
 
 
 def records_from_feed(feed, labels, ocbs, k):
-    """The records the GPU model leaves for one stream (include/qvz_coder.h), made here by a plain serial model in Python:
-    x = cum_lo / n / 1024, y = (n - cum_hi) / n / 1024; layout ((row/2)*(pitch/4) + pos/4)*8 + (row%2)*4 + pos%4."""
+    """The records the GPU model leaves for one stream (include/qvz_coder.h), made here by a plain serial model in Python
+    integers: floor(2^62 * c / n) + 1 for c = cum_lo, cum_hi; layout ((row/2)*(pitch/4) + pos/4)*8 + (row%2)*4 + pos%4."""
     n, c = feed.shape
     pos0 = 8 if k > 1 else 0
     pitch = (pos0 + c + 7) & ~7
-    rec = np.zeros((((n + 1) // 2) * 2 * pitch, 2), dtype=np.float64)
+    rec = np.zeros((((n + 1) // 2) * 2 * pitch, 2), dtype=np.uint64)
     tables = {}
 
     def step(key, card, x):
         t = tables.setdefault(key, [card, [1] * card])
         tot, cnts = t
         lo, f = sum(cnts[:x]), cnts[x]
-        out = (lo / tot / 1024.0, (tot - lo - f) / tot / 1024.0)
+        out = ((lo << 62) // tot + 1, ((lo + f) << 62) // tot + 1)
         cnts[x] += 8
         t[0] += 8
         if t[0] > (1 << 19):                                        # update_stats rescale, qv_stream.c:15-24
@@ -129,7 +129,7 @@ def records_from_feed(feed, labels, ocbs, k):
 
 @pytest.mark.parametrize("name", ["t2k_f05_L", "t2k_c3_f05_M", "const_r05", "tiny5_r10", "uniform72_r20_A", "rescale_140k_c4"])
 def test_host_interval_chain_over_model_records(name):
-    """Strict single-stream mode, host half: qvz_coder_encode_records over the (cum_lo/n, (n - cum_hi)/n) records equals
+    """Strict single-stream mode, host half: qvz_coder_encode_records over the fixed-point (cum_lo/n, cum_hi/n) records equals
     qvz_coder_encode over the feed, i.e. the reference's stream - including a stream long enough for update_stats to
     rescale, pending-bit runs (constant input) and chunked calls with an odd number of reads."""
     from qvz_amd import host
@@ -149,7 +149,7 @@ def test_host_interval_chain_over_model_records(name):
         # re-lay the chunk's rows from row 0
         pos0 = 8 if opts["k"] > 1 else 0
         m = b - a
-        chunk = np.zeros((((m + 1) // 2) * 2 * pitch, 2), dtype=np.float64)
+        chunk = np.zeros((((m + 1) // 2) * 2 * pitch, 2), dtype=np.uint64)
         for i in range(m):
             for pos in ([0] if pos0 else []) + list(range(pos0, pos0 + c)):
                 src = (((a + i) >> 1) * (pitch >> 2) + (pos >> 2)) * 8 + ((a + i) & 1) * 4 + (pos & 3)
