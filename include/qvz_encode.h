@@ -86,6 +86,15 @@ int qvz_encode_file(const char *in_path, const char *out_path, const qvz_options
 int qvz_encode_file_sharded(const char *in_path, const char *out_prefix, const qvz_options_t *opts, uint32_t shards,
                             qvz_result_t *res);
 
+/* The same encode on SEVERAL devices of this process (host/qvz_multi.c; QVZ_DEVICES=0,1,... in the qvz front end): the reads
+ * are dealt to the devices in whole shards of qvz_shard_bounds(N, shards), every device runs the single-device stages on
+ * its reads, the k-means accumulators (per iteration) and the PMF counters (once) are summed over the devices - RCCL
+ * (ncclAllReduce over xGMI) when the ordinals are distinct, a host-staged sum when an ordinal is listed more than once -
+ * and the output is the one shard set a single device writes for the same `shards`, byte for byte; distortion and -u too.
+ * shards >= ndev. */
+int qvz_encode_file_devices(const char *in_path, const char *out_path, const qvz_options_t *opts, const int *devices,
+                            uint32_t ndev, uint32_t shards, qvz_result_t *res);
+
 /* Decode direction (`qvz -x`, reference src/main.c:132-183, start_qv_decompression src/qv_compressor.c:145-231).
  * qvz_decode_file: a reference-format .q file (one stream) -> text; the serial arithmetic decoder runs on one host
  * core as in the reference, the WELL draws come from the GPU word stream. qvz_decode_shard_files: the files

@@ -103,6 +103,7 @@ SIGNATURES = {
     "qvz_codebook_read": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "qvz_encode_file_sharded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qvz_encode_last_error": (C.c_char_p, []),
+    "qvz_encode_file_devices": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_void_p]),
     "qvz_ingest_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_hip_gather_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_void_p]),
     "qvz_hip_well_jump_many": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32)]),

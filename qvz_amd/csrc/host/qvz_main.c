@@ -137,7 +137,22 @@ int main(int argc, char **argv) {
      * as one shard set, or with QVZ_SHARD_FILES=1 as N reference-format files <output>.0000 ... */
     const uint32_t shards = getenv("QVZ_SHARDS") ? (uint32_t)strtoul(getenv("QVZ_SHARDS"), 0, 10) : 0;
     const int files = getenv("QVZ_SHARD_FILES") && atoi(getenv("QVZ_SHARD_FILES"));
-    const int rc = !shards ? qvz_encode_file(input_name, output_name, &opts, &res)
+    /* QVZ_DEVICES=0,1,...: the reads are dealt to several GPUs of this process (host/qvz_multi.c); the output is the shard
+     * set a single GPU writes for the same QVZ_SHARDS (default: 8192 streams per device) */
+    int devices[64];
+    uint32_t ndev = 0;
+    if (getenv("QVZ_DEVICES")) {
+        const char *p = getenv("QVZ_DEVICES");
+        while (*p && ndev < 64) {
+            char *end;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            devices[ndev++] = (int)d;
+            p = *end == ',' ? end + 1 : end;
+        }
+    }
+    const int rc = ndev > 1 ? qvz_encode_file_devices(input_name, output_name, &opts, devices, ndev, shards ? shards : 8192u * ndev, &res)
+                   : !shards ? qvz_encode_file(input_name, output_name, &opts, &res)
                    : files ? qvz_encode_file_sharded(input_name, output_name, &opts, shards, &res)
                            : qvz_encode_file_shardset(input_name, output_name, &opts, shards, &res);
     if (rc) {

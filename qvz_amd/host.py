@@ -96,6 +96,24 @@ def encode_file_shardset(in_path, out_path, shards, clusters=1, mode=MODE_RATIO,
     return r
 
 
+def encode_file_devices(in_path, out_path, devices, shards, clusters=1, mode=MODE_RATIO, ratio=0.5, dist="M", threshold=4.0,
+                        u_path=None, seed_mode=None):
+    """One file on several devices of this process (qvz_encode_file_devices): the shard set a single device writes for
+    the same `shards`."""
+    o = default_options()
+    o.clusters, o.mode, o.ratio, o.distortion, o.cluster_threshold = clusters, mode, ratio, DIST.get(dist, dist), threshold
+    if u_path:
+        o.uncompressed_name = u_path.encode()
+    if seed_mode is not None:
+        o.seed_mode = seed_mode
+    r = Result()
+    dv = (C.c_int * len(devices))(*devices)
+    rc = lib().qvz_encode_file_devices(in_path.encode(), out_path.encode(), C.byref(o), dv, len(devices), shards, C.byref(r))
+    if rc:
+        raise QvzHipError(f"qvz_encode_file_devices failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return r
+
+
 def shardset_stat(path):
     si = ShardsetInfo()
     rc = lib().qvz_shardset_stat(path.encode(), C.byref(si))

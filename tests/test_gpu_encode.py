@@ -393,3 +393,43 @@ def test_model_session_records_equal_a_serial_model():
                 assert got[dst, 0] == want[src, 0] and got[dst, 1] == want[src, 1], (a + i, p_)
     assert lib().qvz_hip_model_session_status(sess, None) == 0
     lib().qvz_hip_model_session_close(sess)
+
+
+@pytest.mark.parametrize("name,devices,shards", [("t2k_c3_f05_M", [0, 0], 6), ("cfg1_f05_L", [0, 0, 0], 16), ("twolevel_c2_f05", [0, 0], 2),
+                                                 ("t2k_c3_f05_M", [0, 1], 6), ("cfg1_f05_L", [0, 1], 16)])
+def test_several_devices_write_the_single_device_shard_set(tmp_path, name, devices, shards):
+    """qvz_encode_file_devices (host/qvz_multi.c): reads dealt to the devices in whole shards, k-means accumulators and PMF
+    counters summed over the devices, centroid rows from wherever they lie, WELL offsets per part - and the shard set, the
+    -u text and the distortion are those of the single-device encode, byte for byte / bit for bit. The same ordinal listed
+    twice runs the parts on one GPU with the host-staged sum (what a one-GPU box can test); distinct ordinals use RCCL and
+    need that many GPUs."""
+    import torch
+    from qvz_amd import host
+    if max(devices) >= torch.cuda.device_count():
+        pytest.skip(f"needs {max(devices) + 1} GPUs")
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], seed_mode=host.SEED_DEBUG)
+    one, many = str(tmp_path / "one.qset"), str(tmp_path / "many.qset")
+    u1, u2 = str(tmp_path / "one.u"), str(tmp_path / "many.u")
+    fresh_process_rand()
+    a = host.encode_file_shardset(inp, one, shards, u_path=u1, **kw)
+    fresh_process_rand()
+    b = host.encode_file_devices(inp, many, devices, shards, u_path=u2, **kw)
+    assert open(many, "rb").read() == open(one, "rb").read()
+    assert open(u2, "rb").read() == open(u1, "rb").read() and G.md5(open(u2, "rb").read()) == e["u_md5"]
+    assert (a.stream_bytes, a.file_bytes, a.kmeans_iterations) == (b.stream_bytes, b.file_bytes, b.kmeans_iterations)
+    assert a.distortion == b.distortion                                          # the same sequential sum in file order
+
+
+def test_cli_qvz_devices_env(tmp_path):
+    name = "t2k_c3_f05_M"
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    q, d = str(tmp_path / "m.qset"), str(tmp_path / "m.dec")
+    env = dict(os.environ, QVZ_WELL_SEED="debug", QVZ_SHARDS="4", QVZ_DEVICES="0,0")
+    out = subprocess.run([QVZ_BIN] + e["flags"].split() + ["-s", inp, q], env=env, capture_output=True, text=True, check=True).stdout
+    assert re.search(r"rate, [\d.]+, distortion, ([\d.]+)", out).group(1) == f"{e['distortion']:.4f}"
+    subprocess.run([QVZ_BIN, "-x", q, d], check=True, capture_output=True)
+    assert G.md5(open(d, "rb").read()) == e["u_md5"]
