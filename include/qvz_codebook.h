@@ -60,6 +60,12 @@ int qvz_distortion_matrix_file(const char *path, double *h_dist /*[72*72]*/);
 int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
                               double guard, qvz_codebook_t *out, void *stream);
 
+/* The same from 64-bit counters: the counters of a file of 2^32 reads or more, summed over the parts that counted it
+ * (host/qvz_multi.c). The reference's u32 counts and totals wrap there (include/pmf.h:35-36), so this is an extension,
+ * not a restatement; whenever the u32 counters do not wrap it gives the same codebook, bit for bit. */
+int qvz_hip_generate_codebook64(const uint64_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
+                                double guard, qvz_codebook_t *out, void *stream);
+
 /* Marginal pmfs of one cluster, h_marg[s*72 + x]: the second half of calculate_statistics
  * (reference src/codebook.c:208-219, combine_pmfs src/pmf.c:189-205), bit-identical to the reference's values. */
 int qvz_hip_marginals(const uint32_t *d_cnt, uint32_t C, double *h_marg, void *stream);

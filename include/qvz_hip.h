@@ -97,6 +97,12 @@ int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_labels, uin
 int qvz_hip_kmeans_update(const uint64_t *d_acc, const uint32_t *d_counts, uint32_t k, uint32_t c,
                           uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream);
 
+/* the same with 64-bit read counts (a file of 2^32 reads or more, counted in parts: host/qvz_multi.c) */
+int qvz_hip_kmeans_update64(const uint64_t *d_acc, const uint64_t *d_counts, uint32_t k, uint32_t c,
+                            uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream);
+/* d_dst[i] = d_src[i]: a part's u32 counters widened so that their sum over the parts cannot wrap */
+int qvz_hip_widen_u32(const uint32_t *d_src, uint64_t *d_dst, uint64_t count, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Conditional-PMF counters. Replaces the counting loop of calculate_statistics
  * (reference src/codebook.c:193-205, pmf_increment src/pmf.c:211-214).

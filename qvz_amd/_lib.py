@@ -26,6 +26,10 @@ SIGNATURES = {
     "qvz_hip_kmeans_accumulate": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u64p,
                                             C.c_void_p]),
     "qvz_hip_kmeans_update": (C.c_int, [u64p, u32p, C.c_uint32, C.c_uint32, u8p, f64p, C.c_void_p, C.c_void_p]),
+    "qvz_hip_kmeans_update64": (C.c_int, [u64p, u64p, C.c_uint32, C.c_uint32, u8p, f64p, C.c_void_p, C.c_void_p]),
+    "qvz_hip_widen_u32": (C.c_int, [u32p, u64p, C.c_uint64, C.c_void_p]),
+    "qvz_hip_generate_codebook64": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.c_int, C.c_double,
+                                              C.c_double, C.c_void_p, C.c_void_p]),
     "qvz_hip_pmf_hist": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_void_p]),
     "qvz_hip_well_words": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, u32p, C.c_void_p]),
     "qvz_hip_well_draws": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint64,

@@ -234,6 +234,7 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
     HIP(qvz_hip_malloc((void **)&job->d_acc, (size_t)K * C * sizeof(uint64_t)));
     HIP(qvz_hip_malloc((void **)&job->d_moved, (K + 1) * sizeof(double)));
     HIP(qvz_hip_malloc((void **)&job->d_kstat, sizeof(int32_t)));
+    if (job->allreduce) HIP(qvz_hip_malloc((void **)&job->d_counts64, K * sizeof(uint64_t)));
     HIP(qvz_hip_copy_h2d(job->d_means, job->h_means, (size_t)K * C, NULL));
     HIP(qvz_hip_memset(job->d_kstat, 0, sizeof(int32_t), NULL));
     uint32_t iter = 0;
@@ -244,10 +245,12 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
         HIP(qvz_hip_memset(job->d_acc, 0, (size_t)K * C * sizeof(uint64_t), NULL));
         HIP(qvz_hip_kmeans_assign(job->d_sym, N, C, ld, K, job->d_means, job->d_labels, job->d_counts, NULL));
         HIP(qvz_hip_kmeans_accumulate(job->d_sym, job->d_labels, N, C, ld, K, job->d_acc, NULL));
-        if (job->allreduce) {                                                   /* the sums of every part of the file */
+        if (job->allreduce) {                                                   /* the sums of every part of the file, 64 bits wide */
+            HIP(qvz_hip_widen_u32(job->d_counts, job->d_counts64, K, NULL));
             HIP(job->allreduce(job->allreduce_ctx, job->d_acc, (uint64_t)K * C, 8, NULL));
-            HIP(job->allreduce(job->allreduce_ctx, job->d_counts, K, 4, NULL));
-        }
+            HIP(job->allreduce(job->allreduce_ctx, job->d_counts64, K, 8, NULL));
+            HIP(qvz_hip_kmeans_update64(job->d_acc, job->d_counts64, K, C, job->d_means, job->d_moved, job->d_kstat, NULL));
+        } else
         HIP(qvz_hip_kmeans_update(job->d_acc, job->d_counts, K, C, job->d_means, job->d_moved, job->d_kstat, NULL));
         HIP(qvz_hip_copy_d2h(h_moved, job->d_moved, (K + 1) * sizeof(double), NULL));
         HIP(qvz_hip_copy_d2h(&kstat, job->d_kstat, sizeof(kstat), NULL));
@@ -286,7 +289,11 @@ int qvz_job_stats(qvz_job_t *job) {
     HIP(qvz_hip_malloc((void **)&job->d_cnt, words * sizeof(uint32_t)));
     HIP(qvz_hip_memset(job->d_cnt, 0, words * sizeof(uint32_t), NULL));
     HIP(qvz_hip_pmf_hist(job->d_sym, job->K > 1 ? job->d_labels : NULL, job->N, job->C, job->ld, job->K, job->d_cnt, NULL));
-    if (job->allreduce) HIP(job->allreduce(job->allreduce_ctx, job->d_cnt, words, 4, NULL));   /* counters of the whole file */
+    if (job->allreduce) {                                                       /* counters of the whole file, 64 bits wide */
+        HIP(qvz_hip_malloc((void **)&job->d_cnt64, words * sizeof(uint64_t)));
+        HIP(qvz_hip_widen_u32(job->d_cnt, job->d_cnt64, words, NULL));
+        HIP(job->allreduce(job->allreduce_ctx, job->d_cnt64, words, 8, NULL));
+    }
     HIP(qvz_hip_stream_sync(NULL));
     job->counted = 1;
     job->t_stats = now() - t0;
@@ -303,6 +310,10 @@ int qvz_job_codebooks(qvz_job_t *job) {
     for (uint32_t j = 0; j < job->K; ++j) {
         job->cbs[j] = qvz_codebook_alloc(job->C);
         if (!job->cbs[j]) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        if (job->d_cnt64)
+            HIP(qvz_hip_generate_codebook64(job->d_cnt64 + (size_t)j * job->C * A * A, job->C, job->h_dist, job->opts.mode,
+                                            job->opts.ratio, 0.0, job->cbs[j], NULL));
+        else
         HIP(qvz_hip_generate_codebook(job->d_cnt + (size_t)j * job->C * A * A, job->C, job->h_dist, job->opts.mode,
                                       job->opts.ratio, 0.0, job->cbs[j], NULL));
         job->deferred_decisions += qvz_hip_codebook_deferred_decisions();
@@ -687,6 +698,7 @@ void qvz_job_release(qvz_job_t *job) {
     free(job->h_labels); free(job->h_means); free(job->h_counts); free(job->h_acc);
     qvz_hip_free(job->d_sym); qvz_hip_free(job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
     qvz_hip_free(job->d_counts); qvz_hip_free(job->d_acc); qvz_hip_free(job->d_moved); qvz_hip_free(job->d_kstat);
+    qvz_hip_free(job->d_cnt64); qvz_hip_free(job->d_counts64);
     memset(job, 0, sizeof(*job));
 }
 

@@ -34,6 +34,7 @@ typedef struct qvz_job {
     uint8_t *d_sym, *d_labels, *d_means;
     uint32_t *d_cnt, *d_counts;
     uint64_t *d_acc;
+    uint64_t *d_cnt64, *d_counts64;   /* a part of a file: this part's counters widened and summed over all parts (u32 sums could wrap) */
     double *d_moved;
     int32_t *d_kstat;
     int uploaded, clustered, counted;

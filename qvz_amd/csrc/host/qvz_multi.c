@@ -9,8 +9,9 @@
  *   centroids    the k reads libc rand() picks (cluster.c:198-201) are drawn once, before any HIP call, and every part is
  *                handed their rows (in one process the mapped input is visible to all host threads; between processes
  *                this is the broadcast from the owning rank, qvz_amd/pipeline.py fetch_centroids)
- *   all-reduce   per k-means iteration the accumulators u64[k][C] and the counts u32[k]; once the PMF counters
- *                u32[k][C][72][72]. RCCL (ncclAllReduce over xGMI, the communicator of ncclCommInitAll) when the ordinals
+ *   all-reduce   per k-means iteration the accumulators u64[k][C] and the counts [k]; once the PMF counters [k][C][72][72] -
+ *                every part's u32 counts widened to 64 bits first, so that a file of 2^32 reads or more (which the
+ *                reference's u32 counters cannot hold, pmf.h:35-36) sums without wrapping. RCCL (ncclAllReduce over xGMI, the communicator of ncclCommInitAll) when the ordinals
  *                are distinct; a host-staged sum otherwise (the same ordinal listed twice: two parts sharing one GPU,
  *                which is how the partition logic is tested on a one-GPU box - RCCL refuses duplicate devices)
  *   codebooks    N-independent and deterministic: generated once (part 0) from the reduced counters, shared as host structs
@@ -260,7 +261,9 @@ int qvz_encode_file_devices(const char *in_path, const char *out_path, const qvz
     if (C == 0 || N == 0) { rc = qvz_job_fail(QVZ_E_DATA, "no complete line in the input"); goto done; }
     if (K < 1 || K > 255) { rc = qvz_job_fail(QVZ_E_ARG, "clusters must be 1..255"); goto done; }
     if (shards > qvz_shard_limit(N)) { rc = qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads: a shard needs at least 4 reads", shards, (unsigned long long)N); goto done; }
-    if (N >= (1ull << 32)) { rc = qvz_job_fail(QVZ_E_ARG, "more than 2^32-1 lines: the u32 PMF counters cannot hold it (pmf.h:35-36)"); goto done; }
+    /* N itself may exceed 2^32 - 1 here (the shard set's header holds 64 bits, and the counters are summed 64 bits wide):
+     * only a single part may not (its u32 counters and the u32 line count of a reference-format shard file) */
+    if ((N + ndev - 1) / ndev + 4 >= (1ull << 32)) { rc = qvz_job_fail(QVZ_E_ARG, "%llu lines over %u devices: a device's part must stay below 2^32 lines (pmf.h:35-36)", (unsigned long long)N, ndev); goto done; }
 
     /* centroid reads (cluster.c:198-204): libc rand() in the process's state, BEFORE the first HIP call (HIP start-up
      * consumes rand() values) - exactly what qvz_job_init does for a whole file */
@@ -305,8 +308,7 @@ int qvz_encode_file_devices(const char *in_path, const char *out_path, const qvz
         const int e = sh.rccl.comm_init_all(sh.comms, (int)ndev, devices);
         if (e) { rc = qvz_job_fail(QVZ_E_HIP, "ncclCommInitAll: %s", sh.rccl.error_string ? sh.rccl.error_string(e) : "error"); goto done; }
     } else {
-        sh.stage_bytes = (size_t)K * C * A * A * sizeof(uint32_t);            /* the largest reduction: the PMF counters */
-        if (sh.stage_bytes < (size_t)K * C * 8) sh.stage_bytes = (size_t)K * C * 8;
+        sh.stage_bytes = (size_t)K * C * A * A * sizeof(uint64_t);            /* the largest reduction: the PMF counters, 64 bits wide */
         sh.stage = (uint8_t *)malloc(sh.stage_bytes * ndev);
         if (!sh.stage) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
     }

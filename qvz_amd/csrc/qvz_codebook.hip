@@ -169,12 +169,15 @@ extern "C" void qvz_codebook_tables(const qvz_codebook_t *cb, uint16_t *ct, uint
 // device kernels
 // ------------------------------------------------------------------------------------------------
 // P[row][x] = cnt[row][x] / total(row)   (recalculate_pmf, pmf.c:219-230; all zero when total == 0)
-__global__ __launch_bounds__(64) void k_cond_pmf(const uint32_t *__restrict__ cnt, double *__restrict__ P) {
+// CountT: u32 as in the reference (pmf.h:35-36: a file of 2^32 reads or more wraps them there), or u64 for the counters of
+// such a file summed over its parts (same doubles whenever the u32 ones do not wrap)
+template <typename CountT>
+__global__ __launch_bounds__(64) void k_cond_pmf(const CountT *__restrict__ cnt, double *__restrict__ P) {
     const uint64_t row = blockIdx.x;
     const uint32_t lane = threadIdx.x;
-    const uint32_t c1 = cnt[row * A + lane];
-    const uint32_t c2 = lane < A - 64 ? cnt[row * A + 64 + lane] : 0;
-    uint32_t tot = c1 + c2;                                      // u32 like pmf_t.total (pmf.h:36)
+    const CountT c1 = cnt[row * A + lane];
+    const CountT c2 = lane < A - 64 ? cnt[row * A + 64 + lane] : 0;
+    CountT tot = c1 + c2;                                        // pmf_t.total (pmf.h:36)
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
     const double t = (double)tot;
     P[row * A + lane] = tot ? ((double)c1) / t : 0.0;
@@ -710,7 +713,7 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 static std::atomic<int> g_cb_active{0};   // qvz_hip_generate_codebook calls in flight (one per cluster when a caller runs them concurrently)
-static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
+static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
                     qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
     const size_t tile = (size_t)A * A;
     int dev = 0;
@@ -751,7 +754,8 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     }
     QVZ_HIP_CHECK(hipMemsetAsync(W.zero_rows, 0, tile * sizeof(double), st));
 
-    hipLaunchKernelGGL(k_cond_pmf, dim3(C * A), dim3(64), 0, st, d_cnt, W.P);
+    if (wide) hipLaunchKernelGGL(k_cond_pmf<unsigned long long>, dim3(C * A), dim3(64), 0, st, (const unsigned long long *)d_cnt, W.P);
+    else hipLaunchKernelGGL(k_cond_pmf<uint32_t>, dim3(C * A), dim3(64), 0, st, (const uint32_t *)d_cnt, W.P);
     hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
     QVZ_HIP_CHECK(hipGetLastError());
 
@@ -948,8 +952,21 @@ static int generate(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int
     return QVZ_OK;
 }
 
+static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double ratio,
+                             double guard, qvz_codebook_t *out, void *stream);
+
 extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
                                          double guard, qvz_codebook_t *out, void *stream) {
+    return generate_codebook(d_cnt, false, C, h_dist, mode, ratio, guard, out, stream);
+}
+
+extern "C" int qvz_hip_generate_codebook64(const uint64_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
+                                           double guard, qvz_codebook_t *out, void *stream) {
+    return generate_codebook(d_cnt, true, C, h_dist, mode, ratio, guard, out, stream);
+}
+
+static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double ratio,
+                             double guard, qvz_codebook_t *out, void *stream) {
     if (!d_cnt || !h_dist || !out || out->C != C || C == 0) return qvz_set_error(QVZ_E_ARG, "bad codebook arguments");
     if (mode != QVZ_MODE_RATIO && mode != QVZ_MODE_FIXED) return qvz_set_error(QVZ_E_ARG, "unknown mode %d", mode);
     if (guard <= 0.0) guard = 1e-9;
@@ -959,7 +976,7 @@ extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, cons
     g_cb_active.fetch_add(1);
     cb_wait[0] = cb_wait[1] = cb_wait[2] = cb_wait[3] = 0.0;
     const double t_gen = cb_now();
-    const int rc = generate(d_cnt, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
+    const int rc = generate(d_cnt, wide, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
     (void)hipStreamSynchronize((hipStream_t)stream);
     g_cb_active.fetch_sub(1);
     cbw_give_back(W);
@@ -980,7 +997,7 @@ extern "C" int qvz_hip_marginals(const uint32_t *d_cnt, uint32_t C, double *h_ma
     if (hipMalloc(&P, (size_t)C * A * A * sizeof(double)) != hipSuccess || hipMalloc(&marg, (size_t)C * A * sizeof(double)) != hipSuccess) {
         rc = qvz_set_error(QVZ_E_NOMEM, "device alloc");
     } else {
-        hipLaunchKernelGGL(k_cond_pmf, dim3(C * A), dim3(64), 0, st, d_cnt, P);
+        hipLaunchKernelGGL(k_cond_pmf<uint32_t>, dim3(C * A), dim3(64), 0, st, d_cnt, P);
         hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, P, C, marg);
         if (hipMemcpyAsync(h_marg, marg, (size_t)C * A * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)

@@ -371,15 +371,16 @@ extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_
 }
 
 // New centroids and how far they moved (cluster.c:104-128). One block; exact integers throughout.
+template <typename CountT>   // uint32_t as the reference keeps them (lines.h:41), or 64 bits for a file of more than 2^32 - 1 reads
 __global__ __launch_bounds__(256) void k_kmeans_update(const unsigned long long *__restrict__ acc,
-                                                       const uint32_t *__restrict__ counts, uint32_t k, uint32_t C,
+                                                       const CountT *__restrict__ counts, uint32_t k, uint32_t C,
                                                        uint8_t *__restrict__ means, double *__restrict__ moved_out,
                                                        int32_t *__restrict__ status) {
     __shared__ unsigned long long red[4];
     __shared__ unsigned long long best;
     if (threadIdx.x == 0) best = 0;
     for (uint32_t j = 0; j < k; ++j) {
-        const uint32_t cnt = counts[j];
+        const CountT cnt = counts[j];
         unsigned long long part = 0;
         if (cnt == 0) {
             if (threadIdx.x == 0) atomicOr(status, 1);
@@ -408,8 +409,32 @@ __global__ __launch_bounds__(256) void k_kmeans_update(const unsigned long long 
 extern "C" int qvz_hip_kmeans_update(const uint64_t *d_acc, const uint32_t *d_counts, uint32_t k, uint32_t c,
                                      uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream) {
     if (k == 0 || c == 0) return qvz_set_error(QVZ_E_ARG, "empty update");
-    hipLaunchKernelGGL(k_kmeans_update, dim3(1), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_kmeans_update<uint32_t>, dim3(1), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned long long *>(d_acc), d_counts, k, c, d_means, d_moved, d_status);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+extern "C" int qvz_hip_kmeans_update64(const uint64_t *d_acc, const uint64_t *d_counts, uint32_t k, uint32_t c,
+                                       uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream) {
+    if (k == 0 || c == 0) return qvz_set_error(QVZ_E_ARG, "empty update");
+    hipLaunchKernelGGL(k_kmeans_update<unsigned long long>, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long *>(d_acc), reinterpret_cast<const unsigned long long *>(d_counts), k, c,
+                       d_means, d_moved, d_status);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// u32 counters of one part of a file -> u64, so that their sum over the parts cannot wrap (a file of 2^32 reads or more)
+__global__ __launch_bounds__(256) void k_widen_u32(const uint32_t *__restrict__ src, unsigned long long *__restrict__ dst, uint64_t count) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int qvz_hip_widen_u32(const uint32_t *d_src, uint64_t *d_dst, uint64_t count, void *stream) {
+    if (!d_src || !d_dst) return qvz_set_error(QVZ_E_ARG, "null argument");
+    if (count == 0) return QVZ_OK;
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_widen_u32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_src, reinterpret_cast<unsigned long long *>(d_dst), count);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
 }

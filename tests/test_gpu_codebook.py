@@ -106,3 +106,41 @@ def test_end_to_end_device_pipeline_reproduces_u_file(K):
     q = G.gz(name + ".q.gz")
     blob = K.write_header(1, c, n) + cb.serialize()
     assert q[: len(blob)] == blob
+
+
+def test_wide_counters_for_files_beyond_the_u32_limit():
+    """More than 2^32 - 1 reads: the reference's u32 counts and totals wrap (include/pmf.h:35-36,
+    src/codebook.c:482), so a file that large is counted in parts (< 2^32 reads each) whose counters are widened to 64 bits
+    and summed (host/qvz_multi.c). The 64-bit route must give the u32 route's codebook wherever both apply, and - counts
+    scaled by 2^13, totals far beyond 2^32 - the very same codebook again (every probability is the same double)."""
+    import ctypes as C
+    from qvz_amd import kernels as K
+    from qvz_amd._lib import check, lib
+    from test_gpu_kernels import upload_sym
+    rows = G.case_rows("t2k_f05_L")
+    n, c = rows.shape[0], rows.shape[1] - 1
+    cnt = K.pmf_hist(upload_sym(K, rows), n)[0]
+    d = O.distortion("L")
+    dp = d.ctypes.data_as(C.POINTER(C.c_double))
+    narrow, _ = K.generate_codebook(cnt, d, O.MODE_RATIO, 0.5)
+    wide = torch.zeros(cnt.numel(), dtype=torch.int64, device="cuda")
+    check(lib().qvz_hip_widen_u32(cnt.data_ptr(), wide.data_ptr(), cnt.numel(), None))
+    assert torch.equal(wide, cnt.to(torch.int64).view(-1))
+    for scale in (1, 1 << 13):
+        big = (wide * scale).contiguous()
+        if scale > 1:
+            assert int(big.view(c, -1).sum(dim=1).max().item()) > 2 ** 32
+        cb = K.Codebook(c)
+        check(lib().qvz_hip_generate_codebook64(big.data_ptr(), c, dp, O.MODE_RATIO, 0.5, 0.0, cb.handle, None))
+        assert cb.serialize() == narrow.serialize()
+    # recalculate_means with 64-bit counts (cluster.c:104-128): 3 * 2^32 reads in a cluster
+    k = 2
+    counts = torch.tensor([3 << 32, 5], dtype=torch.int64, device="cuda")
+    means = torch.tensor([[10, 20, 30], [1, 2, 3]], dtype=torch.uint8, device="cuda")
+    acc = torch.tensor([[(3 << 32) * 12 + 7, (3 << 32) * 20, (3 << 32) * 29 + (3 << 32) - 1], [5 * 4, 5 * 2 + 4, 0]], dtype=torch.int64, device="cuda")
+    moved = torch.zeros(k + 1, dtype=torch.float64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    check(lib().qvz_hip_kmeans_update64(acc.data_ptr(), counts.data_ptr(), k, 3, means.data_ptr(), moved.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert means.cpu().tolist() == [[12, 20, 29], [4, 2, 0]] and int(status.item()) == 0
+    assert moved.cpu().tolist() == [18.0, 5.0, 18.0]                            # [max, cluster 0: 4 + 0 + 1, cluster 1: 9 + 0 + 9]
