@@ -631,6 +631,32 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     }
 }
 
+// ---- the per-column hand-over between device and host without stream synchronisation ------------------------------------
+// A column costs one exchange with the host (its libm entropies decide, section "host driver" below). Through
+// hipMemcpyAsync + hipStreamSynchronize that exchange took ~140 us of a column's ~250; the kernels' own time is ~110 us.
+// So the results go straight into mapped, coherent host memory (the kernels' output pointers are host memory), a last
+// one-thread kernel raises a sequence number there, and the host spins on that word; what the next column needs from the
+// host (quantizer tables, ratios, context symbols) is read from mapped host memory by a first small kernel.
+__global__ __launch_bounds__(64) void k_cb_flag(volatile uint32_t *flag, uint32_t seq) {
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *flag = seq;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cb_copy_f64(const double *__restrict__ src, double *__restrict__ dst, uint32_t count) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+// host (mapped) -> device: the previous column's tables [144][72] and ratios [72], this column's context symbols [nu]
+__global__ __launch_bounds__(256) void k_cb_stage_in(const uint4 *__restrict__ hq, const double *__restrict__ hr, const uint8_t *__restrict__ hu,
+                                                     uint4 *__restrict__ qprev, double *__restrict__ rprev, uint8_t *__restrict__ ctx_sym, uint32_t nu) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 2 * A * A / 16) qprev[t] = hq[t];
+    if (t < A) rprev[t] = hr[t];
+    if (t < nu) ctx_sym[t] = hu[t];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------
@@ -664,16 +690,19 @@ struct CbWork {
     double *rprev = nullptr, *ptemp = nullptr;
     uint8_t *qprev = nullptr, *ctx_sym = nullptr;
     LmIn *lin = nullptr;
-    LmDesign *lout = nullptr, *hout = nullptr;     // device window results and their pinned host mirror
+    LmDesign *hout = nullptr;                      // the design windows' results: mapped host memory the kernels write
     uint32_t *stop = nullptr;
     uint8_t *pin = nullptr;                        // pinned staging for everything else that crosses PCIe per column
+    uint32_t *flag = nullptr;                      // mapped host word the device raises when a column's results are in host memory
+    uint32_t seq = 0;
     uint32_t capC = 0;                             // columns the buffers were sized for (0: nothing allocated)
     int device = -1;
     void release() {
-        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, ptemp, qprev, ctx_sym, lin, lout, stop};
+        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, ptemp, qprev, ctx_sym, lin, stop};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (hout) (void)hipHostFree(hout);
         if (pin) (void)hipHostFree(pin);
+        if (flag) (void)hipHostFree(flag);
         *this = CbWork();
     }
 };
@@ -732,10 +761,12 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         QVZ_HIP_CHECK(hipMalloc(&W.qprev, 2 * tile));
         QVZ_HIP_CHECK(hipMalloc(&W.ctx_sym, A));
         QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
-        QVZ_HIP_CHECK(hipMalloc(&W.lout, tile * sizeof(LmDesign)));
-        QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocDefault));
+        QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocMapped));
         QVZ_HIP_CHECK(hipMalloc(&W.stop, A * sizeof(uint32_t)));
-        QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A), hipHostMallocDefault));
+        QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A), hipHostMallocMapped));
+        QVZ_HIP_CHECK(hipHostMalloc(&W.flag, 64, hipHostMallocMapped));
+        *W.flag = 0;
+        W.seq = 0;
         W.capC = C;
         W.device = dev;
     }
@@ -759,28 +790,61 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
     QVZ_HIP_CHECK(hipGetLastError());
 
-    // Per column two stream syncs (after the context propagation, after the design window). Everything copied per
-    // column sits in pinned memory (pageable hipMemcpyAsync calls block and go through a bounce buffer), and what the
-    // next column's propagation needs from this one is double-buffered so that no third sync is needed.
+    // One exchange with the host per column (two when a context's walk runs off the first design window). Everything that
+    // crosses PCIe sits in mapped host memory that the kernels read and write themselves (see k_cb_flag); what the next
+    // column's propagation needs from this one is double-buffered there.
     double *hx = reinterpret_cast<double *>(W.pin);
     LmIn *hin = reinterpret_cast<LmIn *>(hx + tile);
     double *hr2 = reinterpret_cast<double *>(hin + A);                  // [2][A]
     uint8_t *hq2 = reinterpret_cast<uint8_t *>(hr2 + 2 * A);            // [2][2 * tile]
     uint8_t *hu2 = hq2 + 2 * 2 * tile;                                  // [2][4 * A]
     LmDesign *hout = W.hout;
+    uint8_t *pin_d = nullptr;                                           // the same areas as the device sees them
+    LmDesign *hout_d = nullptr;
+    uint32_t *flag_d = nullptr;
+    QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&pin_d, W.pin, 0));
+    QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&hout_d, W.hout, 0));
+    QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&flag_d, W.flag, 0));
+    double *hx_d = reinterpret_cast<double *>(pin_d);
+    LmIn *hin_d = reinterpret_cast<LmIn *>(hx_d + tile);
+    double *hr2_d = reinterpret_cast<double *>(hin_d + A);
+    uint8_t *hq2_d = reinterpret_cast<uint8_t *>(hr2_d + 2 * A);
+    uint8_t *hu2_d = hq2_d + 2 * 2 * tile;
+    const bool spin = !getenv("QVZ_CB_SYNC");                           // development knob: wait with hipStreamSynchronize instead
+    // everything enqueued on st so far has run and its results are in host memory
+    auto arrived = [&](int which) -> int {
+        const double t_ = cb_now();
+        if (spin) {
+            const uint32_t seq = ++W.seq;
+            hipLaunchKernelGGL(k_cb_flag, dim3(1), dim3(64), 0, st, (volatile uint32_t *)flag_d, seq);
+            QVZ_HIP_CHECK(hipGetLastError());
+            uint64_t polls = 0;
+            while (__atomic_load_n(W.flag, __ATOMIC_ACQUIRE) != seq) {
+                if ((++polls & 0xFFFF) == 0 && cb_now() - t_ > 5.0) {    // something is wrong: let the runtime say what
+                    QVZ_HIP_CHECK(hipStreamSynchronize(st));
+                    if (__atomic_load_n(W.flag, __ATOMIC_ACQUIRE) != seq) return qvz_set_error(QVZ_E_HIP, "codebook hand-over flag never arrived");
+                }
+            }
+        } else {
+            QVZ_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        cb_wait[which] += cb_now() - t_;
+        return QVZ_OK;
+    };
+    auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win) {
+        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard);
+        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard);
+        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard);
+    };
     LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
 
     // designs for the all-zero pmf depend only on (distortion, S): one launch, 72 waves
     ZeroDesign Z[A + 1];
     memset(hin, 0, A * sizeof(LmIn));
     for (int S = 1; S <= A; ++S) { hin[S - 1].mode = 2; hin[S - 1].startS = (uint8_t)S; }
-    QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, A * sizeof(LmIn), hipMemcpyHostToDevice, st));
-    if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(A, 1), dim3(64), LM_LDS_BYTES(true), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
-    else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(A, 1), dim3(64), LM_LDS_BYTES(true), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
-    else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(A, 1), dim3(64), LM_LDS_BYTES(false), st, W.zero_rows, W.dist, W.lin, W.lout, W.stop, guard);
+    launch_window(W.zero_rows, hin_d, A, 1);
     QVZ_HIP_CHECK(hipGetLastError());
-    QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, A * sizeof(LmDesign), hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipStreamSynchronize(st));
+    { const int rc_ = arrived(1); if (rc_) return rc_; }
     for (int S = 1; S <= A; ++S) { memcpy(Z[S].q, hout[S - 1].q, A); memcpy(Z[S].recon, hout[S - 1].recon, A); }
     uint32_t window0 = 16;                         // first window of a column: the previous column's largest S + 3
 
@@ -794,7 +858,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             nu = 1;
             uni[0] = 0;
             d_rows = W.P;                                                           // get_cond_pmf(list, 0, 0)
-            QVZ_HIP_CHECK(hipMemcpyAsync(hx, W.P, A * sizeof(double), hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(k_cb_copy_f64, dim3(1), dim3(256), 0, st, (const double *)W.P, hx_d, (uint32_t)A);
         } else {                                                                    // codebook.c:419-438
             const size_t b0 = ((size_t)(s - 1) * 2 * A) * A;
             nu = cb->nstates[(size_t)(s - 1) * 2 * A];
@@ -802,32 +866,26 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             for (uint32_t j = 1; j < 2 * nprev; ++j)
                 nu = merge_lists(uni, nu, cb->recon + b0 + (size_t)j * A, cb->nstates[(size_t)(s - 1) * 2 * A + j], uni);
             if (nu > A) return qvz_set_error(QVZ_E_DATA, "column %u: %u contexts exceed the alphabet", s, nu);
-            QVZ_HIP_CHECK(hipMemcpyAsync(W.ctx_sym, uni, nu, hipMemcpyHostToDevice, st));
+            // the previous column's tables and ratios (slot (s - 1) & 1) and this column's context symbols, from host memory
+            hipLaunchKernelGGL(k_cb_stage_in, dim3((2 * A * A / 16 + 255) / 256), dim3(256), 0, st,
+                               reinterpret_cast<const uint4 *>(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
+                               (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A), reinterpret_cast<uint4 *>(W.qprev), W.rprev, W.ctx_sym, nu);
             if (s >= 2)
                 hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nprev + 255) / 256), dim3(256), 0, st, W.P, W.marg, s, nprev, W.qpmf[pq], W.ptemp);
             hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu,
                                W.ctx_sym, W.qprev, W.rprev, W.ptemp, W.qpmf[pq ^ 1], W.stop);
-            // With several generations running side by side (one host thread per cluster) a host round trip costs more
-            // than the device-side plan; alone it is the other way round (+1 ms per codebook).
-            const bool one_trip = g_cb_active.load(std::memory_order_relaxed) > 1;
+            // k_ctx_xpmf plans the first design window on the device (all-zero rows and zero targets are exact on both
+            // sides; its log2-based target only steers which designs give up early), so the window follows at once
             hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf,
-                               one_trip ? W.lin : (LmIn *)nullptr, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio);
-            QVZ_HIP_CHECK(hipGetLastError());
+                               W.lin, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio);
             pq ^= 1;
             d_rows = W.xpmf;
-            QVZ_HIP_CHECK(hipMemcpyAsync(hx, W.xpmf, (size_t)nu * A * sizeof(double), hipMemcpyDeviceToHost, st));
-            // the first design window follows at once, planned on the device (k_ctx_xpmf): one host round trip per
-            // column instead of two
-            if (one_trip) {
+            hipLaunchKernelGGL(k_cb_copy_f64, dim3((nu * A + 255) / 256), dim3(256), 0, st, (const double *)W.xpmf, hx_d, nu * (uint32_t)A);
             win0 = window0;
-            if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win0), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
-            else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win0), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
-            else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win0), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
-            QVZ_HIP_CHECK(hipGetLastError());
-            QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win0, hipMemcpyDeviceToHost, st));
-            }
+            launch_window(d_rows, W.lin, nu, win0);
         }
-        { const double t_ = cb_now(); QVZ_HIP_CHECK(hipStreamSynchronize(st)); cb_wait[0] += cb_now() - t_; }
+        QVZ_HIP_CHECK(hipGetLastError());
+        { const int rc_ = arrived(0); if (rc_) return rc_; }
         cb->nctx[s] = (uint8_t)nu;
         memcpy(cb->ctx_sym + (size_t)s * A, uni, nu);
         for (uint32_t i = 0; i < nu; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
@@ -858,15 +916,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                 // both sides; the device's target differs from the libm one in the last bits, which only steers)
                 ++round;
             } else {
-            QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, hin, sizeof(LmIn) * nu, hipMemcpyHostToDevice, st));
             if (s == 0 || round) QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));   // (k_ctx_propagate resets it otherwise)
             ++round;
-            if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
-            else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
-            else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, W.lin, W.lout, W.stop, guard);
+            launch_window(d_rows, hin_d, nu, win);                               // the plan is read from host memory
             QVZ_HIP_CHECK(hipGetLastError());
-            QVZ_HIP_CHECK(hipMemcpyAsync(hout, W.lout, sizeof(LmDesign) * nu * win, hipMemcpyDeviceToHost, st));
-            { const double t_ = cb_now(); QVZ_HIP_CHECK(hipStreamSynchronize(st)); cb_wait[1] += cb_now() - t_; }
+            { const int rc_ = arrived(1); if (rc_) return rc_; }
             }
             any_gpu = false;
             for (uint32_t j = 0; j < nu; ++j) {
@@ -941,13 +995,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         }
         cb_wait[3] += cb_now() - t_rt;
         // hand this column's tables and ratios to the next column's propagation
-        uint8_t *hq = hq2 + (size_t)(s & 1) * 2 * tile;   // slot s & 1: its last use (column s - 2) finished before column s - 1's syncs
+        uint8_t *hq = hq2 + (size_t)(s & 1) * 2 * tile;   // slot s & 1: its last reader (the stage-in of column s - 1) finished before that column's hand-over
         double *hr = hr2 + (size_t)(s & 1) * A;
         memcpy(hq, cb->q + (size_t)s * 2 * tile, 2 * tile);
         for (uint32_t j = 0; j < A; ++j) hr[j] = j < nu ? cb->ratio[(size_t)s * A + j] : 0.0;
-        QVZ_HIP_CHECK(hipMemcpyAsync(W.qprev, hq, 2 * tile, hipMemcpyHostToDevice, st));
-        QVZ_HIP_CHECK(hipMemcpyAsync(W.rprev, hr, A * sizeof(double), hipMemcpyHostToDevice, st));
-        nprev = nu;
+        nprev = nu;                                                              // (k_cb_stage_in of the next column reads hq / hr)
     }
     return QVZ_OK;
 }
