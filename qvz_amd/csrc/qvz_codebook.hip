@@ -298,7 +298,7 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
 // or a target of 0 was asked for), else a target from the device's own log2 - in the kernel that value only steers
 // which designs give up early, by more than the guard band; every decision is the host's, from libm values.
 __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
-                                                  const double *__restrict__ qpmf, double *__restrict__ xpmf,
+                                                  const double *__restrict__ qpmf, double *__restrict__ xpmf, double *__restrict__ xpmf_host,
                                                   LmIn *__restrict__ lin, int ratio_mode, double opt_ratio) {
     __shared__ double row[A], nrow[A], ent[A];
     const uint32_t idx = blockIdx.x, k = threadIdx.x;
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, 
         const double v = row[k];
         const double nv = total > 0 ? v / total : v;
         xpmf[idx * A + k] = nv;
+        xpmf_host[idx * A + k] = nv;                              // the host's copy (mapped memory): its libm entropy is the target
         nrow[k] = nv;
         ent[k] = lin && nv > 0.0 ? nv * log2(nv) : 0.0;          // every thread its own term
     }
@@ -607,6 +608,9 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     const LmIn I = in[ctx];
     LmDesign *O = out + (size_t)ctx * gridDim.y + w;
     const uint32_t S = (uint32_t)I.startS + w;
+    // (`out` is mapped host memory: the results need no copy; the k_cb_flag launched behind this kernel tells the host.
+    // Letting the last block raise the flag instead needs a system-scope fence in every block: measured, with the 72 x 72
+    // block windows of -r 1.0 that cost 13 ms per codebook.)
     const bool wanted = I.mode == 1 ? S <= A : (I.mode == 2 && w == 0);
     if (!wanted || (I.mode == 1 && __atomic_load_n(stop + ctx, __ATOMIC_RELAXED) < S)) {
         if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
@@ -811,13 +815,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     uint8_t *hq2_d = reinterpret_cast<uint8_t *>(hr2_d + 2 * A);
     uint8_t *hu2_d = hq2_d + 2 * 2 * tile;
     const bool spin = !getenv("QVZ_CB_SYNC");                           // development knob: wait with hipStreamSynchronize instead
-    // everything enqueued on st so far has run and its results are in host memory
-    auto arrived = [&](int which) -> int {
+    // Waits for hand-over number `seq`, raised by a k_cb_flag (flag_after): everything enqueued before it has run and its
+    // results are in host memory.
+    auto await = [&](uint32_t seq, int which) -> int {
         const double t_ = cb_now();
         if (spin) {
-            const uint32_t seq = ++W.seq;
-            hipLaunchKernelGGL(k_cb_flag, dim3(1), dim3(64), 0, st, (volatile uint32_t *)flag_d, seq);
-            QVZ_HIP_CHECK(hipGetLastError());
             uint64_t polls = 0;
             while (__atomic_load_n(W.flag, __ATOMIC_ACQUIRE) != seq) {
                 if ((++polls & 0xFFFF) == 0 && cb_now() - t_ > 5.0) {    // something is wrong: let the runtime say what
@@ -831,10 +833,17 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         cb_wait[which] += cb_now() - t_;
         return QVZ_OK;
     };
-    auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win) {
+    auto flag_after = [&]() -> uint32_t {
+        const uint32_t seq = ++W.seq;
+        hipLaunchKernelGGL(k_cb_flag, dim3(1), dim3(64), 0, st, (volatile uint32_t *)flag_d, seq);
+        return seq;
+    };
+    const bool stage_kernel = getenv("QVZ_CB_STAGE") != nullptr;        // development knob: copy the host's tables to the device first
+    auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win) -> uint32_t {
         if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard);
         else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard);
         else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard);
+        return flag_after();
     };
     LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
 
@@ -842,16 +851,19 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     ZeroDesign Z[A + 1];
     memset(hin, 0, A * sizeof(LmIn));
     for (int S = 1; S <= A; ++S) { hin[S - 1].mode = 2; hin[S - 1].startS = (uint8_t)S; }
-    launch_window(W.zero_rows, hin_d, A, 1);
-    QVZ_HIP_CHECK(hipGetLastError());
-    { const int rc_ = arrived(1); if (rc_) return rc_; }
+    {
+        const uint32_t seq = launch_window(W.zero_rows, hin_d, A, 1);
+        QVZ_HIP_CHECK(hipGetLastError());
+        const int rc_ = await(seq, 1);
+        if (rc_) return rc_;
+    }
     for (int S = 1; S <= A; ++S) { memcpy(Z[S].q, hout[S - 1].q, A); memcpy(Z[S].recon, hout[S - 1].recon, A); }
     uint32_t window0 = 16;                         // first window of a column: the previous column's largest S + 3
 
     uint32_t nprev = 0;
     int pq = 0;   // index of the qpmf buffer holding the previous column
     for (uint32_t s = 0; s < C; ++s) {
-        uint32_t nu, win0 = 0;                                                      // win0: width of a first window already run (s >= 1)
+        uint32_t nu, win0 = 0, seq0;                                                // win0: width of a first window already run (s >= 1)
         uint8_t *uni = hu2 + (size_t)(s & 1) * 4 * A;
         const double *d_rows;
         if (s == 0) {                                                               // codebook.c:392-411
@@ -859,6 +871,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             uni[0] = 0;
             d_rows = W.P;                                                           // get_cond_pmf(list, 0, 0)
             hipLaunchKernelGGL(k_cb_copy_f64, dim3(1), dim3(256), 0, st, (const double *)W.P, hx_d, (uint32_t)A);
+            seq0 = flag_after();
         } else {                                                                    // codebook.c:419-438
             const size_t b0 = ((size_t)(s - 1) * 2 * A) * A;
             nu = cb->nstates[(size_t)(s - 1) * 2 * A];
@@ -866,26 +879,32 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             for (uint32_t j = 1; j < 2 * nprev; ++j)
                 nu = merge_lists(uni, nu, cb->recon + b0 + (size_t)j * A, cb->nstates[(size_t)(s - 1) * 2 * A + j], uni);
             if (nu > A) return qvz_set_error(QVZ_E_DATA, "column %u: %u contexts exceed the alphabet", s, nu);
-            // the previous column's tables and ratios (slot (s - 1) & 1) and this column's context symbols, from host memory
-            hipLaunchKernelGGL(k_cb_stage_in, dim3((2 * A * A / 16 + 255) / 256), dim3(256), 0, st,
-                               reinterpret_cast<const uint4 *>(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
-                               (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A), reinterpret_cast<uint4 *>(W.qprev), W.rprev, W.ctx_sym, nu);
-            if (s >= 2)
-                hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nprev + 255) / 256), dim3(256), 0, st, W.P, W.marg, s, nprev, W.qpmf[pq], W.ptemp);
-            hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu,
-                               W.ctx_sym, W.qprev, W.rprev, W.ptemp, W.qpmf[pq ^ 1], W.stop);
+            // (k_ctx_ptemp of this column ran behind the previous column's window, while the host was busy: it needs nothing
+            // from the host.) The propagation reads the previous column's tables and ratios (slot (s - 1) & 1) and this
+            // column's context symbols straight from mapped host memory: a few hundred bytes per workgroup.
+            if (stage_kernel) {
+                hipLaunchKernelGGL(k_cb_stage_in, dim3((2 * A * A / 16 + 255) / 256), dim3(256), 0, st,
+                                   reinterpret_cast<const uint4 *>(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
+                                   (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A), reinterpret_cast<uint4 *>(W.qprev), W.rprev, W.ctx_sym, nu);
+                hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu, (const uint8_t *)W.ctx_sym, (const uint8_t *)W.qprev,
+                                   (const double *)W.rprev, W.ptemp, W.qpmf[pq ^ 1], W.stop);
+            } else
+            hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu, (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A),
+                               (const uint8_t *)(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
+                               W.ptemp, W.qpmf[pq ^ 1], W.stop);
             // k_ctx_xpmf plans the first design window on the device (all-zero rows and zero targets are exact on both
             // sides; its log2-based target only steers which designs give up early), so the window follows at once
-            hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf,
+            hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf, hx_d,
                                W.lin, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio);
             pq ^= 1;
             d_rows = W.xpmf;
-            hipLaunchKernelGGL(k_cb_copy_f64, dim3((nu * A + 255) / 256), dim3(256), 0, st, (const double *)W.xpmf, hx_d, nu * (uint32_t)A);
             win0 = window0;
-            launch_window(d_rows, W.lin, nu, win0);
+            seq0 = launch_window(d_rows, W.lin, nu, win0);
+            if (s + 1 < C)      // p_temp of column s + 1 needs this column's qpmf only: off the critical path, behind the window
+                hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nu + 255) / 256), dim3(256), 0, st, W.P, W.marg, s + 1, nu, W.qpmf[pq], W.ptemp);
         }
         QVZ_HIP_CHECK(hipGetLastError());
-        { const int rc_ = arrived(0); if (rc_) return rc_; }
+        { const int rc_ = await(seq0, 0); if (rc_) return rc_; }
         cb->nctx[s] = (uint8_t)nu;
         memcpy(cb->ctx_sym + (size_t)s * A, uni, nu);
         for (uint32_t i = 0; i < nu; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
@@ -918,9 +937,9 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             } else {
             if (s == 0 || round) QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));   // (k_ctx_propagate resets it otherwise)
             ++round;
-            launch_window(d_rows, hin_d, nu, win);                               // the plan is read from host memory
+            const uint32_t seqw = launch_window(d_rows, hin_d, nu, win);         // the plan is read from host memory
             QVZ_HIP_CHECK(hipGetLastError());
-            { const int rc_ = arrived(1); if (rc_) return rc_; }
+            { const int rc_ = await(seqw, 1); if (rc_) return rc_; }
             }
             any_gpu = false;
             for (uint32_t j = 0; j < nu; ++j) {

@@ -112,7 +112,7 @@ def test_wide_counters_for_files_beyond_the_u32_limit():
     """More than 2^32 - 1 reads: the reference's u32 counts and totals wrap (include/pmf.h:35-36,
     src/codebook.c:482), so a file that large is counted in parts (< 2^32 reads each) whose counters are widened to 64 bits
     and summed (host/qvz_multi.c). The 64-bit route must give the u32 route's codebook wherever both apply, and - counts
-    scaled by 2^13, totals far beyond 2^32 - the very same codebook again (every probability is the same double)."""
+    scaled by 2^22, totals beyond 2^32 - the very same codebook again (every probability is the same double)."""
     import ctypes as C
     from qvz_amd import kernels as K
     from qvz_amd._lib import check, lib
@@ -126,7 +126,7 @@ def test_wide_counters_for_files_beyond_the_u32_limit():
     wide = torch.zeros(cnt.numel(), dtype=torch.int64, device="cuda")
     check(lib().qvz_hip_widen_u32(cnt.data_ptr(), wide.data_ptr(), cnt.numel(), None))
     assert torch.equal(wide, cnt.to(torch.int64).view(-1))
-    for scale in (1, 1 << 13):
+    for scale in (1, 1 << 22):
         big = (wide * scale).contiguous()
         if scale > 1:
             assert int(big.view(c, -1).sum(dim=1).max().item()) > 2 ** 32
