@@ -708,6 +708,7 @@ struct DevScratch {
     uint32_t *d_states = nullptr;   // chunk start states
     uint64_t states_cap = 0;
     uint32_t *d_tmp = nullptr;      // 2 x 32 words ping-pong for single-state jumps
+    int32_t *d_route = nullptr;     // which quantizer kernel serves the current qvz_hip_quantize call (k_quantize_route)
     uint32_t *d_ws = nullptr;       // word stream of one pass of qvz_hip_well_draws
     uint64_t ws_words = 0;
     hipEvent_t busy = nullptr;      // recorded after the last kernel that used the scratch
@@ -1225,14 +1226,36 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
 // contexts of a column are ever touched. The 72x72 distortion table sits in LDS; the per-read error is accumulated in column order so it
 // is bit-identical to the reference's `error` (qv_compressor.c:97,118).
 // ------------------------------------------------------------------------------------------------
+// Which quantizer kernel serves a call is decided on the device: k_quantize_lds wants d(x, y) = f(|x - y|) (all of the
+// reference's -d choices; its LDS holds 72 values instead of the matrix), a general matrix (-D FILE) needs k_quantize.
+// Looking at the matrix on the host meant a 41 KB copy back and a stream synchronisation in every call. Now a one-block
+// kernel looks at it and leaves the route in the second word of the caller's status pair; both quantizer kernels are
+// launched and the one that is not meant returns at once.
+#define QZ_ROUTE_LDS 1
+#define QZ_ROUTE_GENERAL 2
+__global__ __launch_bounds__(256) void k_quantize_route(const double *__restrict__ dist, int32_t *__restrict__ route, int lds_possible) {
+    __shared__ int general;
+    if (threadIdx.x == 0) general = lds_possible ? 0 : 1;
+    __syncthreads();
+    if (lds_possible)
+        for (uint32_t e = threadIdx.x; e < QVZ_A * QVZ_A; e += 256) {
+            const uint32_t x = e % QVZ_A, y = e / QVZ_A;
+            // bit patterns, as the host compared them: -0.0 / NaN entries of a custom file are "different"
+            if (__double_as_longlong(dist[e]) != __double_as_longlong(dist[x > y ? x - y : y - x])) general = 1;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) *route = general ? QZ_ROUTE_GENERAL : QZ_ROUTE_LDS;
+}
+
 __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                   uint64_t n, uint32_t C, uint64_t ld, const uint16_t *__restrict__ ct,
                                                   const uint16_t *__restrict__ qs, const uint8_t *__restrict__ draws,
                                                   uint64_t ldd, const double *__restrict__ dist,
                                                   uint8_t *__restrict__ qv_out, uint8_t *__restrict__ qi_out,
                                                   uint8_t *__restrict__ st_out, uint64_t ldo, double *__restrict__ err_out,
-                                                  int32_t *__restrict__ status) {
+                                                  int32_t *__restrict__ status, const int32_t *__restrict__ route) {
     __shared__ double sdist[QVZ_A * QVZ_A];
+    if (route[1] == QZ_ROUTE_LDS) return;                       // the other kernel's job (qvz_hip_quantize: routing without a host round trip)
     for (uint32_t i = threadIdx.x; i < QVZ_A * QVZ_A; i += 256) sdist[i] = dist[i];
     __syncthreads();
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1303,8 +1326,9 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
                                                              const double *__restrict__ dist, uint8_t *__restrict__ qv_out,
                                                              uint8_t *__restrict__ qi_out, uint8_t *__restrict__ st_out,
                                                              uint64_t ldo, double *__restrict__ err_out,
-                                                             int32_t *__restrict__ status) {
+                                                             int32_t *__restrict__ status, const int32_t *__restrict__ route) {
     extern __shared__ uint4 qz_smem[];
+    if (route[1] != QZ_ROUTE_LDS) return;                       // a general distortion matrix: k_quantize does this call
     double *sdist = reinterpret_cast<double *>(qz_smem);         // d(|x - y|), from row 0 of the matrix
     uint4 *tbuf = qz_smem + QVZ_A / 2;
     const uint32_t per_col4 = K * QZ_CLUSTER4;                   // uint4 per column (all clusters)
@@ -1427,47 +1451,49 @@ extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, u
     if (!d_ct || !d_qs || !d_draws || !d_dist || !d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
     uint64_t n4 = (n + 3) / 4;
     const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // development knob: "global" keeps the tables in L1/L2
-    bool in_lds = k <= 3 && !(force && strcmp(force, "global") == 0);
-    if (in_lds) {                                                // the LDS kernel wants d(x, y) = f(|x - y|)
-        static thread_local double h_dist[QVZ_A * QVZ_A];
-        QVZ_HIP_CHECK(hipMemcpyAsync(h_dist, d_dist, sizeof(h_dist), hipMemcpyDeviceToHost, (hipStream_t)stream));
-        QVZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-        for (int y = 0; y < QVZ_A && in_lds; ++y)
-            for (int x = 0; x < QVZ_A; ++x)
-                if (memcmp(&h_dist[x + QVZ_A * y], &h_dist[x > y ? x - y : y - x], sizeof(double)) != 0) { in_lds = false; break; }
-    }
-    if (in_lds) {
-        // dwords (4 reads each) per thread: 8 reads = 8 independent chains pay with one cluster (22.6 -> 20.4 ms at 100M x 150),
-        // not with the single table buffer of three (40 -> 50 ms); QVZ_QUANTIZE_RW is a development knob
-        const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 ? 2 : 1);
-        const uint64_t per_wg = (uint64_t)QZ_THREADS * (rw == 2 ? 2 : 1);
-        dim3 grid((unsigned)((n4 + per_wg - 1) / per_wg));
-        const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
+    const bool lds_possible = k <= 3 && !(force && strcmp(force, "global") == 0);
+    // the route word lives behind the caller's status word in this device's scratch pair (stream-ordered like the rest of it)
+    int32_t *d_route = nullptr;
+    {
+        ScratchLock lk((hipStream_t)stream);
+        if (lk.rc) return lk.rc;
+        if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, 2 * sizeof(int32_t)));
+        d_route = lk.d->d_route;
+        // [0] mirrors nothing (the kernels write the caller's d_status); [1] = route of this call
+        hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, (hipStream_t)stream, d_dist, d_route + 1, lds_possible ? 1 : 0);
+        QVZ_HIP_CHECK(hipGetLastError());
+        if (lds_possible) {
+            // dwords (4 reads each) per thread: 8 reads = 8 independent chains pay with one cluster (22.6 -> 20.4 ms at 100M x 150),
+            // not with the single table buffer of three (40 -> 50 ms); QVZ_QUANTIZE_RW is a development knob
+            const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 ? 2 : 1);
+            const uint64_t per_wg = (uint64_t)QZ_THREADS * (rw == 2 ? 2 : 1);
+            dim3 grid((unsigned)((n4 + per_wg - 1) / per_wg));
+            const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
 #define QZ_LAUNCH(NBUF, NQ)                                                                                                      \
-        do {                                                                                                                     \
-            if (rw == 2) {                                                                                                       \
-                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 2>),                  \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 2>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,       \
-                                   k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi,   \
-                                   d_st, ld_out, d_err, d_status);                                                               \
-            } else {                                                                                                             \
-                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 1>),                  \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 1>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,       \
-                                   k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi,   \
-                                   d_st, ld_out, d_err, d_status);                                                               \
-            }                                                                                                                    \
-        } while (0)
-        static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4, "stage registers");
-        if (k == 1) QZ_LAUNCH(2, 3);
-        else if (k == 2) QZ_LAUNCH(2, 6);
-        else QZ_LAUNCH(1, 8);
+            do {                                                                                                                 \
+                if (rw == 2) {                                                                                                   \
+                    QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 2>),              \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+                    hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 2>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,   \
+                                       k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, \
+                                       d_st, ld_out, d_err, d_status, d_route);                                                  \
+                } else {                                                                                                         \
+                    QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 1>),              \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+                    hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 1>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,   \
+                                       k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, \
+                                       d_st, ld_out, d_err, d_status, d_route);                                                  \
+                }                                                                                                                \
+            } while (0)
+            static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4, "stage registers");
+            if (k == 1) QZ_LAUNCH(2, 3);
+            else if (k == 2) QZ_LAUNCH(2, 6);
+            else QZ_LAUNCH(1, 8);
 #undef QZ_LAUNCH
-    } else {
+        }
         dim3 grid((unsigned)((n4 + 255) / 256));
         hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, (hipStream_t)stream, d_sym, k > 1 ? d_labels : nullptr, n, c, ld,
-                           d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status);
+                           d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status, d_route);
     }
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
