@@ -63,14 +63,15 @@ CHAIN_KERNELS = ("code_records", "arith_shards")
 
 
 def measured_traffic(kernel, args, cfg, shards, world):
-    """HBM bytes per step of `kernel` from the committed PMC passes (profiles/r01_t_pmc_traffic.json), if they were taken
-    on this very workload; None otherwise. (The counters need rocprofv3 around the process, bench.py cannot read them.)"""
+    """HBM bytes per step of `kernel` from the committed PMC passes of this round (profiles/r02_pmc_traffic_cfgN.json), if
+    they were taken on this very workload; None otherwise. (The counters need rocprofv3 around the process: tools/
+    collect_profiles.sh runs this very script under it; bench.py itself cannot read them.)"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_t_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r02_pmc_traffic_cfg{args.config}.json")) as f:
             t = json.load(f)
         w = t["workload"]
         same = (w["config"] == args.config and w["reads"] == cfg["reads"] and w["columns"] == cfg["cols"] and
-                w["coder"] == args.coder and w["shards"] == shards and world == 1)
+                w["coder"] == args.coder and w["shards"] == shards and world == 1 and w.get("qv_plane_written", False) == (not args.no_u))
         return t["kernels"][kernel]["hbm_bytes"] if same and kernel in t["kernels"] else None
     except (OSError, KeyError, ValueError):
         return None
@@ -363,7 +364,7 @@ def main():
         roof = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(dom, args, cfg, shards, world),
                     ms_per_launch=round(per_launch[dom], 4), algorithmic_bytes_per_launch=int(alg_bytes),
-                    bytes_per_symbol=bps, traffic_source="profiles/r01_t_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                    bytes_per_symbol=bps, traffic_source=f"profiles/r02_pmc_traffic_cfg{args.config}.json (rocprofv3 --pmc FETCH_SIZE / "
                     "WRITE_SIZE passes of this workload, FETCH_SIZE x2 per the gfx950 correction); null if the workload differs")
         pmf_ach = (n * c + (n if k > 1 else 0)) / (per_launch["pmf_hist"] * 1e-3) / 1e9
         wall = {ph: round(float(np.mean([r["wall"][ph] for r in results])), 4) for ph in results[-1]["wall"]}

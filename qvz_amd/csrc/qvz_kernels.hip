@@ -1194,9 +1194,12 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
     TR &= ~3u;
     if (TR > 256) TR = 256;
     if (TR < 4) return qvz_set_error(QVZ_E_ARG, "c=%u too wide for the draw transposer", c);
-    const uint64_t chunk = 1ull << 22;                           // reads per generator pass (multiple of TR? not needed)
+    // Reads per generator pass. A generator thread runs 8192 words (218 reads at C = 150) serially, so a pass of 2^22 reads
+    // is only ~300 waves - fewer than the chip has SIMDs - and each of them a dependent chain: the passes took 0.5 ms each
+    // for 0.6 GB of words. 2^24 reads per pass (2.5 GB of words at C = 150) fill every SIMD.
+    const uint64_t chunk = 1ull << (getenv("QVZ_WELL_PASS_LOG2") ? atoi(getenv("QVZ_WELL_PASS_LOG2")) : 24);
     const uint64_t chunk_reads = (chunk / TR) * TR;
-    const uint64_t need = chunk_reads * c / 4 + 8;
+    const uint64_t need = (n < chunk_reads ? ((n + TR - 1) / TR) * TR : chunk_reads) * c / 4 + 8;
     if (need > ws_words) {
         if (d_ws) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(d_ws); d_ws = nullptr; }
         QVZ_HIP_CHECK(hipMalloc(&d_ws, need * sizeof(uint32_t)));

@@ -10,7 +10,8 @@ import csv, glob, json, os, sys
 
 NAMES = {"k_model_ranks": "model_records", "k_model_columns": "model_records", "k_code_records": "code_records",
          "k_quantize": "quantize", "k_pmf_walk": "pmf_hist", "k_kmeans_accum": "kmeans_accumulate",
-         "k_draws_transpose": "draws_transpose", "k_well_gen": "well_gen"}
+         "k_draws_transpose": "draws_transpose", "k_well_gen": "well_gen", "k_kmeans_assign": "kmeans_assign",
+         "k_lm_window": "lm_window"}
 
 
 # FETCH_SIZE x 2 is calibrated for 128-byte requests (wide coalesced reads). k_code_records' loader now asks for 64-byte
@@ -34,9 +35,16 @@ def collect(d, counter):
     return tot, {k: len(v) for k, v in launches.items()}
 
 
+METHOD = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE (one pass) and --pmc WRITE_SIZE (second pass) around `python3 bench.py --steps 1 "
+          "--warmup 0 --no-cpu-baseline --no-extras [--config N]` (tools/collect_profiles.sh, reduced by tools/pmc_traffic.py); counters are "
+          "in KiB, summed over the launches of one step; FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64, "
+          "MI355X_MICROARCH.md HBM section) except for k_code_records, whose loader asks for 64-byte half lines; WRITE_SIZE as is")
+
+
 def main():
     fetch, nl = collect(sys.argv[1], "FETCH_SIZE")
     write, _ = collect(sys.argv[2], "WRITE_SIZE")
+    workload = json.loads(sys.argv[3]) if len(sys.argv) > 3 else None
     out = {}
     for kern in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0))):
         short = next((v for p, v in NAMES.items() if kern.startswith(p)), None)
@@ -49,7 +57,7 @@ def main():
         e["write_bytes"] += wb
     for e in out.values():
         e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
-    json.dump(out, sys.stdout, indent=1)
+    json.dump({"method": METHOD, "workload": workload, "kernels": out} if workload else out, sys.stdout, indent=1)
     print()
 
 
