@@ -21,6 +21,8 @@
 // column at a time: ~2 small launches and 2 small copies per column.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
@@ -362,13 +364,17 @@ __device__ __forceinline__ void lm_region_of(const uint8_t *bounds, uint32_t S, 
                                              uint32_t &jb) {
     for (uint32_t t0 = 0; t0 < S; t0 += 16) {
         const uint4 w = *reinterpret_cast<const uint4 *>(bounds + t0);
-        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        // every lane read the same sixteen bounds: kept in scalar registers, so that picking them apart is scalar work and
+        // a lane spends two vector instructions per bound and symbol (compare, add) instead of six
+        const uint32_t ww[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)w.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)w.y),
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)w.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)w.w)};
 #pragma unroll
         for (uint32_t u = 0; u < 16; ++u) {
-            const uint32_t bt = (ww[u >> 2] >> (8 * (u & 3))) & 0xFFu, t = t0 + u;
-            const bool in = t >= 1 && t < S;
-            ja += in && bt <= xa ? 1u : 0u;
-            jb += in && bt <= xb ? 1u : 0u;
+            const uint32_t t = t0 + u;
+            // t = 0 never counts; bounds past S - 1 are made unreachable (a scalar select) instead of masking two vector results
+            const uint32_t bt = (t >= 1 && t < S) ? (ww[u >> 2] >> (8 * (u & 3))) & 0xFFu : 0xFFFFu;
+            ja += bt <= xa ? 1u : 0u;
+            jb += bt <= xb ? 1u : 0u;
         }
     }
 }
@@ -378,6 +384,7 @@ struct LmLds {
     uint8_t q[2][A];
     uint8_t recon[2][A];
     double mv[A];            // expected distortion of every candidate reconstruction point within its own region
+    uint32_t iters;          // Lloyd-Max iterations of the last design (diagnostics: QVZ_CB_DEBUG)
 };
 
 // One Lloyd-Max design (quantizer.c:34-132) for S states into slot `b`. All 64 lanes call it together.
@@ -386,6 +393,16 @@ struct LmLds {
 // TOEP: the distortion is a function of |i - r| only (all of the reference's -d choices): `dl` then holds those 72
 // values instead of the 72 x 72 matrix - 0.6 KB of LDS per design instead of 41 KB, i.e. twenty designs per CU instead
 // of three, and no 41 KB copy at the start of every design.
+#ifdef QVZ_PROFILE          // development build: shader cycles per phase of a Lloyd-Max design, summed over the designs
+__device__ unsigned long long g_lm_prof[8];
+#define LM_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); lmp[i] += t_ - lmt; lmt = t_; } while (0)
+#else
+#define LM_T(i) do { } while (0)
+#endif
+// A design is ONE wave (k_lm_window: 64-thread blocks): its lanes run in lockstep and its LDS operations complete in issue
+// order, so what a block-wide barrier would order is ordered once the LDS counter has drained. __syncthreads() would also
+// wait for every outstanding global access - here the look at `stop`, ~1000 cycles that are meant to overlap an iteration.
+#define LM_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <bool TOEP, bool MONO>
 __device__ bool lm_design(const double *__restrict__ p, const double *__restrict__ dl, uint32_t S, LmLds *L,
                           double *__restrict__ o, int b, const uint32_t *stop) {
@@ -394,15 +411,32 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
     uint8_t *bounds = L->bounds, *recon = L->recon[b], *q = L->q[b];
     if (lane == 0) { bounds[0] = 0; bounds[S] = A; }                                  // :45-46
     for (uint32_t j = lane; j < S; j += 64) if (j >= 1) bounds[j] = (uint8_t)((j * A) / S);   // :47-49
-    __syncthreads();
+    LM_SYNC();
     for (uint32_t j = lane; j < S; j += 64) recon[j] = (uint8_t)((bounds[j] + bounds[j + 1] - 1) / 2);   // :50-52
-    __syncthreads();
+    LM_SYNC();
 
+#ifdef QVZ_PROFILE
+    unsigned long long lmp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lmt = __builtin_readcyclecounter();
+#endif
     uint32_t changed = 1, iter = 0;
+    // Symbols below zlo and from zhi on have p = 0 (real quality values use 40 of the 72): their terms in the sums of (:62-87)
+    // are p * d = +0.0 exactly (TOEP: d is finite, the host checks) and adding +0.0 leaves a sum of non-negative terms bit
+    // for bit what it was, so the candidate sums run over [zlo, zhi) only. The last region typically reaches from ~40 to
+    // 72: the longest loop of an iteration shrinks from 8 batches of four terms to 1.
+    uint32_t zlo = 0, zhi = A;
+    if (TOEP) {
+        const unsigned long long nzA = __ballot(p[lane] != 0.0), nzB = __ballot(lane + 64 < A && p[lane + 64 < A ? lane + 64 : A - 1] != 0.0);
+        zlo = nzA ? (uint32_t)__builtin_ctzll(nzA) : nzB ? 64u + (uint32_t)__builtin_ctzll(nzB) : 0u;
+        zhi = nzB ? 128u - (uint32_t)__builtin_clzll(nzB) : nzA ? 64u - (uint32_t)__builtin_clzll(nzA) : 0u;
+    }
     while (changed && iter < 100) {                                                  // :57, quantizer.h:10
         changed = 0;
         iter += 1;
-        if (stop && __atomic_load_n(stop, __ATOMIC_RELAXED) < S) return false;       // wave-uniform
+        // `stop` lives in global memory: looking at it costs this lone wave ~1100 cycles, a tenth of an iteration (asking an
+        // iteration ahead did not hide it). Every fourth iteration is enough: a design learns of a smaller S that reached
+        // the target at most three iterations late.
+        if (stop && (iter & 3) == 1 && __atomic_load_n(stop, __ATOMIC_RELAXED) < S) return false;   // wave-uniform
+        LM_T(0);
         // New reconstruction points (:62-87). The regions of one iteration depend on the bounds only, which do not
         // move in this phase, so when the bounds form a partition (they always do unless an earlier walk left stale
         // ones behind) every candidate r is evaluated in its own region at once: the loop is as long as the widest
@@ -418,8 +452,11 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 const bool hasB = lane + 64 < A;
                 uint32_t jA = 0, jB = 0;
                 lm_region_of(bounds, S, rrA, rrB, jA, jB);
-                const uint32_t a0 = bounds[jA], a1 = bounds[jA + 1], c0 = bounds[jB], c1 = hasB ? bounds[jB + 1] : c0;
+                uint32_t a0 = bounds[jA], a1 = bounds[jA + 1], c0 = bounds[jB], c1 = hasB ? bounds[jB + 1] : c0;
+                a0 = a0 > zlo ? a0 : zlo; a1 = a1 < zhi ? a1 : zhi; a1 = a1 > a0 ? a1 : a0;   // the region's part with mass
+                c0 = c0 > zlo ? c0 : zlo; c1 = c1 < zhi ? c1 : zhi; c1 = c1 > c0 ? c1 : c0;
                 const uint32_t lenA = a1 - a0, lenB = c1 - c0;
+                LM_T(1);
                 // A design is one wave alone on its SIMD: every LDS access it waits for costs its full latency (~130
                 // cycles), so four terms are fetched and multiplied at a time and then added in index order.
                 double mA = 0.0, mB = 0.0;
@@ -440,23 +477,25 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 L->mv[rrA] = mA;
                 if (hasB) L->mv[rrB] = mB;
             }
-            __syncthreads();
+            LM_SYNC();
+            LM_T(2);
             uint32_t chg = 0;
             for (uint32_t j = lane; j < S; j += 64) {
                 const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
                 double best_v = DBL_MAX;
                 uint32_t best_r = b0;                                                // min_r = bounds[j]
-                for (uint32_t r = b0; r < b1; r += 4) {              // four candidates per LDS round trip, compared in order
-                    double v[4];
+                for (uint32_t r = b0; r < b1; r += 8) {              // eight candidates per LDS round trip, compared in order
+                    double v[8];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) v[u] = L->mv[r + u < b1 ? r + u : b0];
+                    for (uint32_t u = 0; u < 8; ++u) v[u] = L->mv[r + u < b1 ? r + u : b0];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u)
+                    for (uint32_t u = 0; u < 8; ++u)
                         if (r + u < b1 && v[u] < best_v) { best_v = v[u]; best_r = r + u; }
                 }
                 if (best_r != recon[j]) { chg = 1; recon[j] = (uint8_t)best_r; }
             }
             changed = __ballot(chg) ? 1u : 0u;
+            LM_T(3);
         } else {
             for (uint32_t j = 0; j < S; ++j) {
                 const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
@@ -485,7 +524,7 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 }
             }
         }
-        __syncthreads();
+        LM_SYNC();
         // Boundary walk (:93-107). flag(t, j) = d(j, recon[t+1]) < d(j, recon[t]) for j = 1..70 as two ballot masks;
         // "advance at the first flagged j after the previous boundary" is a count-trailing-zeros. The walk stops at
         // the first state without such a j; the bounds beyond it keep their old values, as in the reference.
@@ -494,17 +533,21 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
             // the midpoint of ra and rb on rb's side. The first flagged j after the previous boundary is then arithmetic,
             // not a search: no LDS gathers, no ballots.
             // The reconstruction points are read eight at a time (recon[] is 8-byte aligned in both slots).
+            // Every lane would compute the same walk: the eight reconstruction points of a step go to scalar registers and
+            // the walk is scalar arithmetic with scalar branches (as vector code every `if` of it was an exec-mask region).
             uint32_t jprev = 0;
             bool walking = true;
             for (uint32_t t0 = 0; t0 + 1 < S && walking; t0 += 8) {
-                const uint2 w = *reinterpret_cast<const uint2 *>(recon + t0);
-                const uint32_t nx = recon[t0 + 8 < A ? t0 + 8 : A - 1];
+                const uint2 wv = *reinterpret_cast<const uint2 *>(recon + t0);
+                const uint32_t nxv = recon[t0 + 8 < A ? t0 + 8 : A - 1];
+                const uint32_t wx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv.x), wy = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv.y);
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxv);
 #pragma unroll
                 for (uint32_t u = 0; u < 8; ++u) {
                     const uint32_t t = t0 + u;
                     if (!walking || t + 1 >= S) { walking = walking && t + 1 < S; continue; }
-                    const uint32_t ra = ((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xFFu;
-                    const uint32_t rb = u == 7 ? nx : ((u + 1 < 4 ? w.x : w.y) >> (8 * ((u + 1) & 3))) & 0xFFu;
+                    const uint32_t ra = ((u < 4 ? wx : wy) >> (8 * (u & 3))) & 0xFFu;
+                    const uint32_t rb = u == 7 ? nx : ((u + 1 < 4 ? wx : wy) >> (8 * ((u + 1) & 3))) & 0xFFu;
                     uint32_t jn = jprev + 1;
                     if (rb > ra) { const uint32_t c = (ra + rb) / 2 + 1; jn = c > jn ? c : jn; }     // j > (ra + rb) / 2
                     else if (rb == ra || 2 * jn >= ra + rb) { walking = false; continue; }            // j < (ra + rb) / 2
@@ -535,11 +578,12 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 jprev = jn;
             }
         }
-        __syncthreads();
+        LM_SYNC();
+        LM_T(4);
     }
 
     for (uint32_t i = lane; i < A; i += 64) q[i] = 0;                                 // calloc, quantizer.c:14
-    __syncthreads();
+    LM_SYNC();
     bool part = true;                                                                // the bounds are a partition of 0 .. 71
     for (uint32_t t = lane; t < S; t += 64) part = part && bounds[t] <= bounds[t + 1];
     if (!__ballot(!part)) {
@@ -549,14 +593,14 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
         lm_region_of(bounds, S, iA, iB, jA, jB);
         q[iA] = recon[jA];
         if (lane + 64 < A) q[iB] = recon[jB];
-        __syncthreads();
+        LM_SYNC();
     } else {
         for (uint32_t j = 0; j < S; ++j) {                                           // :112-116, later regions overwrite
             const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
             const uint8_t rj = recon[j];
             if (b0 + lane < b1) q[b0 + lane] = rj;
             if (b0 + lane + 64 < b1) q[b0 + lane + 64] = rj;
-            __syncthreads();
+            LM_SYNC();
         }
     }
     {                                                                                // apply_quantizer :155-157
@@ -578,7 +622,16 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
         o[vA] = accA;
         if (vB < A) o[vB] = accB;
     }
-    __syncthreads();
+    if (lane == 0) L->iters = iter;
+    LM_SYNC();
+    LM_T(5);
+#ifdef QVZ_PROFILE
+    if (lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_lm_prof[i], lmp[i]);
+        atomicAdd(&g_lm_prof[6], (unsigned long long)iter);
+        atomicAdd(&g_lm_prof[7], 1ull);
+    }
+#endif
     return true;
 }
 
@@ -611,6 +664,7 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     // (`out` is mapped host memory: the results need no copy; the k_cb_flag launched behind this kernel tells the host.
     // Letting the last block raise the flag instead needs a system-scope fence in every block: measured, with the 72 x 72
     // block windows of -r 1.0 that cost 13 ms per codebook.)
+    const unsigned long long t_begin = __builtin_readcyclecounter();
     const bool wanted = I.mode == 1 ? S <= A : (I.mode == 2 && w == 0);
     if (!wanted || (I.mode == 1 && __atomic_load_n(stop + ctx, __ATOMIC_RELAXED) < S)) {
         if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
@@ -631,6 +685,10 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     }
     if (lane == 0) {
         O->S = (uint8_t)S; O->valid = 1; O->hdev = H;
+        O->pad[0] = (uint8_t)(L->iters > 255 ? 255 : L->iters);                       // diagnostics (QVZ_CB_DEBUG): iterations,
+        const unsigned long long dt = (__builtin_readcyclecounter() - t_begin) >> 8;   // shader cycles / 256
+        O->pad[1] = (uint8_t)(dt > 65535 ? 255 : dt >> 8);
+        O->pad[2] = (uint8_t)dt;
         if (I.mode == 1 && S > 1 && H - I.target > guard) atomicMin(stop + ctx, S);   // surely >= target: the walk ends here or earlier
     }
 }
@@ -744,6 +802,7 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 }
 
 static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static thread_local unsigned long long cb_stat[6];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns
 static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 static std::atomic<int> g_cb_active{0};   // qvz_hip_generate_codebook calls in flight (one per cluster when a caller runs them concurrently)
 static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
@@ -778,6 +837,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     for (int i = 0; i < A && toep; ++i)
         for (int r = 0; r < A; ++r)
             if (memcmp(&h_dist[i + A * r], &h_dist[(i > r ? i - r : r - i)], sizeof(double)) != 0) { toep = false; break; }
+    for (int d = 0; d < A && toep; ++d) toep = std::isfinite(h_dist[d]) && h_dist[d] >= 0.0;   // (the zero-mass terms are skipped: 0 * d must be +0.0)
     bool mono = toep;                              // ... and strictly increasing in |i - r|: the boundary walk is arithmetic
     for (int d = 1; d < A && mono; ++d) mono = h_dist[d] > h_dist[d - 1];
     {
@@ -814,6 +874,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     double *hr2_d = reinterpret_cast<double *>(hin_d + A);
     uint8_t *hq2_d = reinterpret_cast<uint8_t *>(hr2_d + 2 * A);
     uint8_t *hu2_d = hq2_d + 2 * 2 * tile;
+    const bool cb_debug = getenv("QVZ_CB_DEBUG") != nullptr;
     const bool spin = !getenv("QVZ_CB_SYNC");                           // development knob: wait with hipStreamSynchronize instead
     // Waits for hand-over number `seq`, raised by a k_cb_flag (flag_after): everything enqueued before it has run and its
     // results are in host memory.
@@ -905,6 +966,17 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         }
         QVZ_HIP_CHECK(hipGetLastError());
         { const int rc_ = await(seq0, 0); if (rc_) return rc_; }
+        if (cb_debug && win0) {                                                     // the first window's designs: how long, how many iterations
+            uint32_t max_it = 0, max_cyc = 0, nvalid = 0, sum_it = 0, at_s = 0;
+            for (uint32_t e = 0; e < nu * win0; ++e)
+                if (hout[e].valid) {
+                    const uint32_t cyc = ((uint32_t)hout[e].pad[1] << 8 | hout[e].pad[2]) << 8;
+                    nvalid += 1; sum_it += hout[e].pad[0];
+                    if (hout[e].pad[0] > max_it) max_it = hout[e].pad[0];
+                    if (cyc > max_cyc) { max_cyc = cyc; at_s = hout[e].S; }
+                }
+            cb_stat[0] += nvalid; cb_stat[1] += sum_it; cb_stat[2] += max_it; cb_stat[3] += max_cyc; cb_stat[4] += nu * win0; cb_stat[5] += at_s;
+        }
         cb->nctx[s] = (uint8_t)nu;
         memcpy(cb->ctx_sym + (size_t)s * A, uni, nu);
         for (uint32_t i = 0; i < nu; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
@@ -1046,6 +1118,7 @@ static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const dou
     CbWork *W = cbw_acquire();
     g_cb_active.fetch_add(1);
     cb_wait[0] = cb_wait[1] = cb_wait[2] = cb_wait[3] = 0.0;
+    for (auto &v : cb_stat) v = 0;
     const double t_gen = cb_now();
     const int rc = generate(d_cnt, wide, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
     (void)hipStreamSynchronize((hipStream_t)stream);
@@ -1054,6 +1127,18 @@ static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const dou
     if (getenv("QVZ_CB_DEBUG"))                                  // development knob
         fprintf(stderr, "qvz_hip_generate_codebook: %.1f ms, of which waiting for the context propagation %.1f ms, for the design windows %.1f ms; host: targets %.1f ms, ratios and storing %.1f ms\n",
                 (cb_now() - t_gen) * 1e3, cb_wait[0] * 1e3, cb_wait[1] * 1e3, cb_wait[2] * 1e3, cb_wait[3] * 1e3);
+#ifdef QVZ_PROFILE
+    {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_lm_prof), sizeof(z));
+        const double it = z[6] ? (double)z[6] : 1.0;
+        fprintf(stderr, "  lm_design cycles per iteration (cumulative over this process): stop check %.0f, mono check + region + bounds %.0f, candidate sums %.0f, arg-min + recon %.0f, walk %.0f; per design after the loop %.0f; %.0f designs, %.1f iterations each\n",
+                z[0] / it, z[1] / it, z[2] / it, z[3] / it, z[4] / it, z[7] ? (double)z[5] / z[7] : 0.0, (double)z[7], z[7] ? it / z[7] : 0.0);
+    }
+#endif
+    if (getenv("QVZ_CB_DEBUG") && C > 1)
+        fprintf(stderr, "  first windows: %llu blocks, %llu designs completed, %.1f iterations on average; per column the longest design: %.1f iterations at most, %.0f shader cycles (S = %.1f on average)\n",
+                cb_stat[4], cb_stat[0], cb_stat[0] ? (double)cb_stat[1] / cb_stat[0] : 0.0, (double)cb_stat[2] / (C - 1), (double)cb_stat[3] / (C - 1), (double)cb_stat[5] / (C - 1));
     return rc;
 }
 

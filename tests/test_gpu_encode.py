@@ -433,3 +433,23 @@ def test_cli_qvz_devices_env(tmp_path):
     assert re.search(r"rate, [\d.]+, distortion, ([\d.]+)", out).group(1) == f"{e['distortion']:.4f}"
     subprocess.run([QVZ_BIN, "-x", q, d], check=True, capture_output=True)
     assert G.md5(open(d, "rb").read()) == e["u_md5"]
+
+
+def test_sharded_streams_that_outgrow_their_first_allotment(tmp_path):
+    """Near-uniform input over all 72 symbols at -f 1.0 needs more than the 6 bits per symbol a stream is given at first
+    (log2 72 = 6.17): the GPU coder reports the overflow, the driver repeats the coding with twice the room, and the set
+    decodes to the -u text."""
+    from qvz_amd import host
+    from qvz_amd._lib import lib
+    rng = np.random.default_rng(5)
+    n, c = 6000, 24
+    rows = np.full((n, c + 1), 10, dtype=np.uint8)
+    rows[:, :c] = rng.integers(33, 33 + 72, size=(n, c), dtype=np.uint8)
+    inp = str(tmp_path / "uni.txt")
+    open(inp, "wb").write(rows.tobytes())
+    q, u, d = str(tmp_path / "uni.qset"), str(tmp_path / "uni.u"), str(tmp_path / "uni.dec")
+    r = host.encode_file_shardset(inp, q, 7, mode=host.MODE_RATIO, ratio=1.0, dist="M", u_path=u, seed_mode=host.SEED_DEBUG)
+    assert r.stream_bytes * 8 > 6.0 * n * c, "this input was meant to need more than 6 bits per symbol"
+    assert lib().qvz_shardset_decode(q.encode(), d.encode(), 0, None) == 0, lib().qvz_encode_last_error()
+    assert open(d, "rb").read() == open(u, "rb").read()
+    assert open(u, "rb").read() == rows.tobytes()                                # -f 1.0 on this input keeps every value
