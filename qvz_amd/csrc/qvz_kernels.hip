@@ -575,10 +575,11 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
         prv[q] = make_uint4(0, 0, 0, 0);                         // column 0 counts under prev = 0 (codebook.c:200)
         pbad[q] = 0;
         lab[q] = make_uint4(0, 0, 0, 0);
-        if (HAVE_LABELS && row[q] < n) lab[q] = *reinterpret_cast<const uint4 *>(labels + row[q]);
+        if (HAVE_LABELS && Q <= 2 && row[q] < n) lab[q] = *reinterpret_cast<const uint4 *>(labels + row[q]);
         cur[q] = row[q] < n ? *reinterpret_cast<const uint4 *>(D + row[q]) : make_uint4(0, 0, 0, 0);
     }
     const uint32_t k80 = 0x01010101u * (0x80u - AA);             // byte + (128 - AA) sets bit 7 iff byte >= AA
+    const uint32_t dump = (uint32_t)(uintptr_t)(pmf_lds_u32 *)tile + (uint32_t)(((mine - tile) + rs - 1) * 4);   // the replica's skew dword
     pmf_u16x2 coef;
     coef.x = 4;                                                  // byte address = 4*x + 4*AA*p + tile base
     coef.y = (unsigned short)(4 * AA);
@@ -592,6 +593,14 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
             for (int q = 0; q < Q; ++q)                          // prefetch column s+1 while column s is counted
                 nxt[q] = (s + 1 < C && row[q] < n) ? *reinterpret_cast<const uint4 *>(D + (uint64_t)(s + 1) * ld + row[q])
                                                    : make_uint4(0, 0, 0, 0);
+            // With more than two groups per thread the labels do not stay in registers beside prv / cur / nxt (four groups
+            // spilled: 16.6 ms instead of 7.1 at 100M x 150, k = 3): they are asked for again in every column - 1 byte per read
+            // and column out of L2 / the Infinity Cache (the label vector is 100 MB) - and bigger slabs mean fewer flushes.
+            if (HAVE_LABELS && Q > 2) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    lab[q] = row[q] < n ? *reinterpret_cast<const uint4 *>(labels + row[q]) : make_uint4(0, 0, 0, 0);
+            }
             uint32_t *col_tile = mine + (s - g0) * cs;
             uint32_t *gcol = cnt + ((uint64_t)kb * C + s) * PMF_TILE;
             const uint32_t base = (uint32_t)(uintptr_t)(pmf_lds_u32 *)tile + (uint32_t)((col_tile - tile) * 4);
@@ -622,8 +631,9 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                     for (int b = 0; b < 4; ++b) {
                         if (HAVE_LABELS) {
                             const uint32_t l = ((lw[w] >> (8 * b)) & 0xFF) - kb;
-                            if (l >= kt) continue;
-                            addr[b] += l * ts * 4;
+                            // a read of a cluster outside this pass's tiles (or of no cluster at all) counts into the
+                            // replica's skew dword, which nobody reads: a select instead of an exec-mask region per symbol
+                            addr[b] = l < kt ? addr[b] + __umul24(l, ts * 4) : dump;
                         }
                         // `base` holds the tile's LDS address: the sum is the operand of ds_add_u32 as it stands
                         __hip_atomic_fetch_add((pmf_lds_u32 *)(uintptr_t)addr[b], 1u, __ATOMIC_RELAXED,
@@ -793,9 +803,10 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
             const size_t lds = (size_t)R * (G * tile_bytes + 4);
             unsigned Q = env_uint("QVZ_PMF_Q", 0);
             // bigger slabs = fewer blocks = fewer flush atomics; six groups per thread is what 128 VGPRs hold (k = 1)
-            // with labels (k > 1) two groups: four spill (measured at 100M x 150, k = 3: 16.9 ms against 7.2)
-            if (Q == 0) Q = (k == 1 && n >= 768ull * 98304) ? 6 : (k == 1 && n >= 768ull * 65536) ? 4 : (n >= 768ull * 32768 ? 2 : 1);
-            if (Q != 1 && Q != 2 && Q != 4 && !(Q == 6 && k == 1)) Q = 4;
+            // with labels (k > 1) kept in registers two groups are the limit: four spill (100M x 150, k = 3: 16.9 ms against 7.2)
+            // (k > 1, labels re-read per column: four groups 6.4 ms, two 7.1, six 9.0 at 100M x 150, k = 3)
+            if (Q == 0) Q = (k == 1 && n >= 768ull * 98304) ? 6 : (n >= 768ull * 65536) ? 4 : (n >= 768ull * 32768 ? 2 : 1);
+            if (Q != 1 && Q != 2 && Q != 4 && Q != 6) Q = 4;
             const uint64_t slab = (uint64_t)PMF_WALK_T * 16 * Q;
             dim3 grid((unsigned)((n + slab - 1) / slab));
 #define LAUNCH_WALK(LBL, QQ)                                                                                           \
@@ -809,7 +820,7 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
             if (k == 1) {
                 if (Q == 6) LAUNCH_WALK(false, 6); else if (Q >= 4) LAUNCH_WALK(false, 4); else if (Q == 2) LAUNCH_WALK(false, 2); else LAUNCH_WALK(false, 1);
             } else {
-                if (Q >= 4) LAUNCH_WALK(true, 4); else if (Q == 2) LAUNCH_WALK(true, 2); else LAUNCH_WALK(true, 1);
+                if (Q == 6) LAUNCH_WALK(true, 6); else if (Q >= 4) LAUNCH_WALK(true, 4); else if (Q == 2) LAUNCH_WALK(true, 2); else LAUNCH_WALK(true, 1);
             }
 #undef LAUNCH_WALK
             QVZ_HIP_CHECK(hipGetLastError());
