@@ -206,6 +206,47 @@ def strict_report(cfg, c):
     return out
 
 
+def other_configs_report(args, done_cfg, sym_done, threads):
+    """The other single-GPU BASELINE configurations, a short run each (1 warm-up + 2 timed steps, same step as the headline:
+    nothing cached between steps), so that one default invocation shows all of them. configs[3] re-uses the resident
+    matrix when the headline ran configs[2] (same reads, other flags)."""
+    import torch
+    from qvz_amd import host
+    from qvz_amd import kernels as K
+    from qvz_amd import pipeline as P
+    out = []
+    for cid in sorted(CONFIGS):
+        if cid == args.config or args.reads:
+            continue
+        cfg = CONFIGS[cid]
+        n, c, k = cfg["reads"] - cfg["reads"] % 4, cfg["cols"], cfg["clusters"]
+        same = cfg["reads"] == done_cfg["reads"] and cfg["seed"] == done_cfg["seed"] and c == done_cfg["cols"]
+        sym = sym_done if same else K.qgen1(cfg["seed"], n, c)
+        mode = host.MODE_RATIO if cfg["mode"] == "f" else host.MODE_FIXED
+
+        def step():
+            return P.encode_pass(sym, n, 0, n, None, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], shards=8192,
+                                 threads=threads, coder="gpu", keep_device=not args.no_u)
+
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rs = []
+        for _ in range(2):
+            rs = [step()]                                        # (the previous step's device outputs are released)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        r = rs[-1]
+        out.append(dict(config=cid, workload=cfg["name"], ms_per_step=round(dt * 1e3, 3), value=round(n * c / dt, 1),
+                        bits_per_symbol=round(r["total_stream_bytes"] * 8.0 / (n * c), 5), kmeans_iterations=r["kmeans_iterations"],
+                        phase_seconds={ph: round(v, 4) for ph, v in r["wall"].items()}))
+        del rs, r
+        if not same:
+            del sym
+        torch.cuda.empty_cache()
+    return out
+
+
 def pmf72_report(n, c):
     """The PMF pass over a matrix that uses all 72 symbols of the alphabet uniformly (QGEN-1 populates 40): the counter
     tiles are 72 x 72 instead of the populated sub-block."""
@@ -405,6 +446,7 @@ def main():
             line["ingest"] = ingest_report(cfg, n, c)
             line["roofline_pmf_hist_72_symbols"] = pmf72_report(n, c)
             line["strict"] = strict_report(cfg, c)
+            line["other_configs"] = other_configs_report(args, cfg, sym, threads)
         if not args.no_cpu_baseline and world == 1:               # the CPU baseline is timed on rank 0 of the 1-GPU run only
             line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")
         print(json.dumps(line), flush=True)

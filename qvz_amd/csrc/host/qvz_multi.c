@@ -300,7 +300,9 @@ int qvz_encode_file_devices(const char *in_path, const char *out_path, const qvz
         for (uint32_t b = a + 1; b < ndev; ++b)
             if (devices[a] == devices[b]) sh.use_rccl = 0;                    /* parts sharing a GPU: RCCL refuses duplicate devices */
     if (getenv("QVZ_MULTI_REDUCE") && strcmp(getenv("QVZ_MULTI_REDUCE"), "host") == 0) sh.use_rccl = 0;
-    if (ndev == 1) sh.use_rccl = 0;
+    /* one part has nothing to sum; QVZ_MULTI_REDUCE=rccl sends it through a one-rank communicator all the same (what a
+     * one-GPU box can test of the RCCL binding: library, symbols, data-type and operator codes) */
+    if (ndev == 1 && !(getenv("QVZ_MULTI_REDUCE") && strcmp(getenv("QVZ_MULTI_REDUCE"), "rccl") == 0)) sh.use_rccl = 0;
     if (sh.use_rccl) {
         if ((rc = rccl_open(&sh.rccl))) goto done;
         sh.comms = (ncclComm_t *)calloc(ndev, sizeof(ncclComm_t));

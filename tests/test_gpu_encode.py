@@ -453,3 +453,21 @@ def test_sharded_streams_that_outgrow_their_first_allotment(tmp_path):
     assert lib().qvz_shardset_decode(q.encode(), d.encode(), 0, None) == 0, lib().qvz_encode_last_error()
     assert open(d, "rb").read() == open(u, "rb").read()
     assert open(u, "rb").read() == rows.tobytes()                                # -f 1.0 on this input keeps every value
+
+
+def test_one_rank_rccl_communicator_in_the_c_driver(tmp_path, monkeypatch):
+    """QVZ_MULTI_REDUCE=rccl with a single device: the k-means accumulators and the PMF counters go through ncclAllReduce on a
+    one-rank communicator (librccl.so bound with dlopen, ncclCommInitAll, ncclUint64 / ncclSum by their numeric codes) and
+    the output must still be the single-device shard set."""
+    from qvz_amd import host
+    name = "t2k_c3_f05_M"
+    inp, _ = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], seed_mode=host.SEED_DEBUG)
+    one, rc = str(tmp_path / "one.qset"), str(tmp_path / "rccl.qset")
+    fresh_process_rand()
+    host.encode_file_shardset(inp, one, 4, **kw)
+    monkeypatch.setenv("QVZ_MULTI_REDUCE", "rccl")
+    fresh_process_rand()
+    host.encode_file_devices(inp, rc, [0], 4, **kw)
+    assert open(rc, "rb").read() == open(one, "rb").read()
