@@ -215,7 +215,7 @@ def other_configs_report(args, done_cfg, sym_done, threads):
     from qvz_amd import kernels as K
     from qvz_amd import pipeline as P
     out = []
-    for cid in sorted(CONFIGS):
+    for cid in sorted(CONFIGS, reverse=True):                    # the one that shares the resident matrix first
         if cid == args.config or args.reads:
             continue
         cfg = CONFIGS[cid]
@@ -228,19 +228,18 @@ def other_configs_report(args, done_cfg, sym_done, threads):
             return P.encode_pass(sym, n, 0, n, None, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], shards=8192,
                                  threads=threads, coder="gpu", keep_device=not args.no_u)
 
-        step()
+        r = step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rs = []
         for _ in range(2):
-            rs = [step()]                                        # (the previous step's device outputs are released)
+            r = None                                             # the previous step's device outputs (qv plane, coded streams) make room first
+            r = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 2
-        r = rs[-1]
         out.append(dict(config=cid, workload=cfg["name"], ms_per_step=round(dt * 1e3, 3), value=round(n * c / dt, 1),
                         bits_per_symbol=round(r["total_stream_bytes"] * 8.0 / (n * c), 5), kmeans_iterations=r["kmeans_iterations"],
                         phase_seconds={ph: round(v, 4) for ph, v in r["wall"].items()}))
-        del rs, r
+        del r
         if not same:
             del sym
         torch.cuda.empty_cache()

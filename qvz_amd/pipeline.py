@@ -140,8 +140,11 @@ class HipBackend:
         # the clusters' codebooks are independent and each generation is latency-bound (small kernels, host round trips):
         # one host thread and one HIP stream per cluster (ctypes releases the GIL in the call)
         from concurrent.futures import ThreadPoolExecutor
-        torch.cuda.synchronize()
+        main = torch.cuda.current_stream()
         streams = [torch.cuda.Stream(device=self.device) for _ in range(k)]
+        for st in streams:
+            st.wait_stream(main)      # the counters are ready when the main stream gets here; NOT a device-wide synchronise:
+                                      # that would wait for the WELL draws on the side stream, which are meant to run beside this
 
         def one(j):
             torch.cuda.set_device(self.device)
