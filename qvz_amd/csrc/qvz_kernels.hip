@@ -265,6 +265,72 @@ __global__ __launch_bounds__(256) void k_kmeans_assign(const uint8_t *__restrict
         if (blk_counts[i]) atomicAdd(&counts[i], blk_counts[i]);
 }
 
+// The same assignment for 2 .. 4 clusters with 16 reads per thread. The distance of read x to centroid m is
+// sum (x_s - m_s)^2 = sum x_s^2 - 2 sum x_s m_s + sum m_s^2, and sum x_s^2 is the same for every centroid: the order of the
+// distances, ties included, is the order of c_j - 2 dot_j with c_j = sum m_js^2 and dot_j = sum x_s m_js (exact integers
+// either way). So a symbol costs one multiply-add per centroid instead of a subtraction and a multiply-add, a thread asks
+// for 16 bytes per column instead of 4 (the 4-read kernel ran at a third of the HBM rate: too few bytes in flight), and
+// the centroid bytes of a column are the same in every lane: scalar operands.
+template <int K>
+__global__ __launch_bounds__(256) void k_kmeans_assign16(const uint8_t *__restrict__ D, uint64_t n, uint32_t C, uint64_t ld,
+                                                         const uint8_t *__restrict__ means, uint8_t *__restrict__ labels,
+                                                         uint32_t *__restrict__ counts) {
+    extern __shared__ uint32_t lds_m[];                          // [C] the K centroid bytes of a column packed into a dword
+    __shared__ uint32_t blk_counts[K];
+    __shared__ int32_t csq[K];                                   // sum of m_js^2
+    if (threadIdx.x < K) { blk_counts[threadIdx.x] = 0; csq[threadIdx.x] = 0; }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < C; s += 256) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t m = means[(uint64_t)j * C + s];
+            w |= m << (8 * j);
+            atomicAdd(&csq[j], (int32_t)(m * m));
+        }
+        lds_m[s] = w;
+    }
+    __syncthreads();
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i0 < n) {                                                // (ld is a multiple of 256: the 16-byte loads stay inside the column)
+        uint32_t dot[16][K];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < K; ++j) dot[r][j] = 0;
+        const uint8_t *p = D + i0;
+        uint4 cur = *reinterpret_cast<const uint4 *>(p);
+        for (uint32_t s = 0; s < C; ++s) {
+            const uint4 nxt = s + 1 < C ? *reinterpret_cast<const uint4 *>(p + (uint64_t)(s + 1) * ld) : cur;
+            const uint32_t mw = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_m[s]);
+            const uint32_t xw[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t m = (mw >> (8 * j)) & 0xFFu;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot[r][j] = __umul24((xw[r >> 2] >> (8 * (r & 3))) & 0xFFu, m) + dot[r][j];
+            }
+            cur = nxt;
+        }
+        uint32_t lw[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int32_t best = csq[0] - 2 * (int32_t)dot[r][0];
+            uint32_t lab = 0;
+#pragma unroll
+            for (int j = 1; j < K; ++j) {
+                const int32_t d = csq[j] - 2 * (int32_t)dot[r][j];
+                if (d < best) { best = d; lab = j; }             // strict: the lowest cluster id wins ties (cluster.c:155-163)
+            }
+            lw[r >> 2] |= lab << (8 * (r & 3));
+            if (i0 + r < n) atomicAdd(&blk_counts[lab], 1u);
+        }
+        *reinterpret_cast<uint4 *>(labels + i0) = make_uint4(lw[0], lw[1], lw[2], lw[3]);   // the label vector is ld long
+    }
+    __syncthreads();
+    if (threadIdx.x < K && blk_counts[threadIdx.x]) atomicAdd(&counts[threadIdx.x], blk_counts[threadIdx.x]);
+}
+
 extern "C" int qvz_hip_kmeans_assign(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint32_t k,
                                      const uint8_t *d_means, uint8_t *d_labels, uint32_t *d_counts, void *stream) {
     int rc = check_matrix(n, c, ld);
@@ -273,7 +339,14 @@ extern "C" int qvz_hip_kmeans_assign(const uint8_t *d_sym, uint64_t n, uint32_t 
     uint64_t n4 = (n + 3) / 4;
     dim3 grid((unsigned)((n4 + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-    if (k == 1) {
+    const char *old_k = getenv("QVZ_KMEANS_KERNEL");             // development knob: "4" keeps the 4-reads-per-thread kernels
+    if (k >= 2 && k <= 4 && !(old_k && atoi(old_k) == 4)) {
+        dim3 g16((unsigned)((n + 4095) / 4096));
+        const size_t lds = (size_t)c * sizeof(uint32_t);
+        if (k == 2) hipLaunchKernelGGL(k_kmeans_assign16<2>, g16, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts);
+        else if (k == 3) hipLaunchKernelGGL(k_kmeans_assign16<3>, g16, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts);
+        else hipLaunchKernelGGL(k_kmeans_assign16<4>, g16, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts);
+    } else if (k == 1) {
         size_t lds = (size_t)c;
         hipLaunchKernelGGL(k_kmeans_assign<1>, grid, dim3(256), lds, st, d_sym, n, c, ld, k, d_means, d_labels, d_counts);
     } else if (k <= 4) {
@@ -349,6 +422,61 @@ __global__ __launch_bounds__(256) void k_kmeans_accum(const uint8_t *__restrict_
     }
 }
 
+// The same sums for 2 .. 4 clusters with the reads' labels loaded once: a thread owns 16 consecutive reads, turns their
+// labels into one byte mask per cluster and dword (0xFF where the read belongs to the cluster) and walks the columns; a
+// column's 16 symbols are one 16-byte load, a cluster's share of a dword is one AND and one byte-wise dot product with
+// 0x01010101. The sums of a wave go through a shuffle tree into the block's LDS accumulators, those to memory once.
+// (The column-per-block kernel above reads the label vector again for every column - 150 times - out of L2.)
+template <int K>
+__global__ __launch_bounds__(256) void k_kmeans_accum16(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
+                                                        uint64_t n, uint32_t C, uint64_t ld, unsigned long long *__restrict__ acc) {
+    extern __shared__ uint32_t blk_acc[];                        // [K][C]; a block adds at most 4096 x 71 per entry
+    for (uint32_t i = threadIdx.x; i < K * C; i += 256) blk_acc[i] = 0;
+    __syncthreads();
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint32_t mask[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mask[j][w] = 0;
+    const bool live = i0 < n;
+    if (live) {
+        const uint4 lv = *reinterpret_cast<const uint4 *>(labels + i0);
+        const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t l = (lw[r >> 2] >> (8 * (r & 3))) & 0xFFu;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (l == (uint32_t)j && i0 + r < n) mask[j][r >> 2] |= 0xFFu << (8 * (r & 3));
+        }
+    }
+    const uint8_t *p = D + (live ? i0 : 0);
+    uint4 cur = *reinterpret_cast<const uint4 *>(p);
+    for (uint32_t s = 0; s < C; ++s) {
+        const uint4 nxt = s + 1 < C ? *reinterpret_cast<const uint4 *>(p + (uint64_t)(s + 1) * ld) : cur;
+        const uint32_t xw[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t sum[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t = __builtin_amdgcn_udot4(xw[w] & mask[j][w], 0x01010101u, t, false);
+            sum[j] = t;                                          // (idle threads have empty masks)
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            uint32_t v = sum[j];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&blk_acc[j * C + s], v);
+        }
+        cur = nxt;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < K * C; i += 256)
+        if (blk_acc[i]) atomicAdd(&acc[i], (unsigned long long)blk_acc[i]);
+}
+
 extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c,
                                          uint64_t ld, uint32_t k, uint64_t *d_acc, void *stream) {
     int rc = check_matrix(n, c, ld);
@@ -360,7 +488,14 @@ extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_
     dim3 grid(c, slabs);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(d_acc);
-    if (k == 1) {
+    const char *old_k = getenv("QVZ_KMEANS_KERNEL");             // development knob: "4" keeps the column-per-block kernel
+    if (k >= 2 && k <= 4 && !(old_k && atoi(old_k) == 4)) {
+        dim3 g16((unsigned)((n + 4095) / 4096));
+        const size_t lds = (size_t)k * c * sizeof(uint32_t);
+        if (k == 2) hipLaunchKernelGGL(k_kmeans_accum16<2>, g16, dim3(256), lds, st, d_sym, d_labels, n, c, ld, acc);
+        else if (k == 3) hipLaunchKernelGGL(k_kmeans_accum16<3>, g16, dim3(256), lds, st, d_sym, d_labels, n, c, ld, acc);
+        else hipLaunchKernelGGL(k_kmeans_accum16<4>, g16, dim3(256), lds, st, d_sym, d_labels, n, c, ld, acc);
+    } else if (k == 1) {
         hipLaunchKernelGGL((k_kmeans_accum<1, false>), grid, dim3(256), 0, st, d_sym, d_labels, n, c, ld, 0u, k, acc);
     } else {
         for (uint32_t kb = 0; kb < k; kb += 4)
