@@ -746,7 +746,20 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // (column, table slice, activity) in scalar registers and its tests in scalar branches
     const uint32_t W = 1u << log2w, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t Cx = C + (HAVE_LABELS ? (uint32_t)QVZ_CID_SLOTS : 0u);
-    const uint32_t g = blockIdx.x, cg = blockIdx.y, z = HAVE_LABELS ? blockIdx.z : 0u;
+    // Several clusters: the K workgroups of one (stream, column group) read the same lines of the qi / st planes (each
+    // walks its own cluster's reads, which interleave). In grid order they would run a third of the launch apart and
+    // each fetch the lines from HBM again (PMC: 160 GB fetched against 52 with one cluster). The linear workgroup number
+    // is re-read so that they are dispatched 8 apart: close in time and - workgroups go round-robin over the 8 XCDs -
+    // behind the same L2.
+    uint32_t g = blockIdx.x, cg = blockIdx.y, z = HAVE_LABELS ? blockIdx.z : 0u;
+    if (HAVE_LABELS && (gridDim.x & 7) == 0) {
+        const uint64_t lin = blockIdx.x + (uint64_t)gridDim.x * (blockIdx.y + (uint64_t)gridDim.y * blockIdx.z);
+        const uint32_t span = 8 * gridDim.z, within = (uint32_t)(lin % span);
+        const uint64_t pair = lin / span * 8 + (within & 7);     // (stream, column group) number
+        z = within >> 3;
+        g = (uint32_t)(pair % gridDim.x);
+        cg = (uint32_t)(pair / gridDim.x);
+    }
     const uint32_t sx = cg * W + wave;                           // position in the read's record group
     const bool lists = HAVE_LABELS && cg * W >= QVZ_CID_SLOTS;   // this workgroup walks cluster z's reads
     if (HAVE_LABELS && !lists && z) return;                      // the reserved positions belong to the z = 0 workgroups
