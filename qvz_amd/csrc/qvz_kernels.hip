@@ -1467,8 +1467,8 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
 // matrix) k_quantize.
 #define QZ_THREADS 512
 #define QZ_CLUSTER4 (10 + QVZ_QS_STRIDE / 8)       // uint4 per cluster and column: ct (9) + pad (1) + qs (1296)
-template <int NBUF, int NQ, int RW>   // RW dwords = 4 * RW consecutive reads per thread
-__global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
+template <int NBUF, int NQ, int RW, int T>   // RW dwords = 4 * RW consecutive reads per thread, T threads per workgroup
+__global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                              uint64_t n, uint32_t C, uint64_t ld, uint32_t K,
                                                              const uint16_t *__restrict__ ct, const uint16_t *__restrict__ qs,
                                                              const uint8_t *__restrict__ draws, uint64_t ldd,
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
     uint4 *tbuf = qz_smem + QVZ_A / 2;
     const uint32_t per_col4 = K * QZ_CLUSTER4;                   // uint4 per column (all clusters)
     if (threadIdx.x < QVZ_A) sdist[threadIdx.x] = dist[threadIdx.x];
-    const uint64_t t = (uint64_t)blockIdx.x * QZ_THREADS + threadIdx.x;
+    const uint64_t t = (uint64_t)blockIdx.x * T + threadIdx.x;
     constexpr int R = 4 * RW;
     const uint64_t i0 = (uint64_t)R * t;
     const bool active = i0 < n;                                  // idle threads still copy tables and meet the barriers
@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
     auto fetch = [&](uint32_t s) {                               // column s's tables -> registers
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const uint32_t i = threadIdx.x + q * QZ_THREADS;
+            const uint32_t i = threadIdx.x + q * T;
             if (i < per_col4) {
                 const uint32_t l = i / QZ_CLUSTER4, j = i % QZ_CLUSTER4;
                 const uint64_t cs = (uint64_t)l * C + s;
@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(QZ_THREADS) void k_quantize_lds(const uint8_t *__re
     auto park = [&](uint4 *dst) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const uint32_t i = threadIdx.x + q * QZ_THREADS;
+            const uint32_t i = threadIdx.x + q * T;
             if (i < per_col4) dst[i] = stg[q];
         }
     };
@@ -1612,32 +1612,30 @@ extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, u
         hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, (hipStream_t)stream, d_dist, d_route + 1, lds_possible ? 1 : 0);
         QVZ_HIP_CHECK(hipGetLastError());
         if (lds_possible) {
-            // dwords (4 reads each) per thread: 8 reads = 8 independent chains pay with one cluster (22.6 -> 20.4 ms at 100M x 150),
-            // not with the single table buffer of three (40 -> 50 ms); QVZ_QUANTIZE_RW is a development knob
-            const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 ? 2 : 1);
-            const uint64_t per_wg = (uint64_t)QZ_THREADS * (rw == 2 ? 2 : 1);
+            // dwords (4 reads each) per thread: 8 reads = 8 independent chains (22.6 -> 20.4 ms at 100M x 150 with one cluster)
+            // Three clusters: a column's tables are 63 KB, copied from L2 by every workgroup for every column - with 512
+            // threads x 4 reads that was 459 GB of copies per step at 100M x 150. 1024-thread workgroups with eight reads
+            // per thread copy a quarter of that: 43.2 -> 27.5 ms (1024 threads x 4 reads: 39.4; eight reads per thread in
+            // 512-thread workgroups had been slower than four). QVZ_QUANTIZE_T / _RW are development knobs.
+            const int wide = k == 3 && !(getenv("QVZ_QUANTIZE_T") && atoi(getenv("QVZ_QUANTIZE_T")) == 512);
+            const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 || wide ? 2 : 1);
+            const uint64_t per_wg = (uint64_t)(wide ? 1024 : QZ_THREADS) * (rw == 2 ? 2 : 1);
             dim3 grid((unsigned)((n4 + per_wg - 1) / per_wg));
             const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
-#define QZ_LAUNCH(NBUF, NQ)                                                                                                      \
+#define QZ_LAUNCH(NBUF, NQ, RWV, TT)                                                                                             \
             do {                                                                                                                 \
-                if (rw == 2) {                                                                                                   \
-                    QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 2>),              \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-                    hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 2>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,   \
-                                       k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, \
-                                       d_st, ld_out, d_err, d_status, d_route);                                                  \
-                } else {                                                                                                         \
-                    QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 1>),              \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-                    hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 1>), grid, dim3(QZ_THREADS), lds, (hipStream_t)stream, d_sym,   \
-                                       k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, \
-                                       d_st, ld_out, d_err, d_status, d_route);                                                  \
-                }                                                                                                                \
+                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT>),            \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT>), grid, dim3(TT), lds, (hipStream_t)stream, d_sym,         \
+                                   k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi,   \
+                                   d_st, ld_out, d_err, d_status, d_route);                                                      \
             } while (0)
-            static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4, "stage registers");
-            if (k == 1) QZ_LAUNCH(2, 3);
-            else if (k == 2) QZ_LAUNCH(2, 6);
-            else QZ_LAUNCH(1, 8);
+            static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4 &&
+                          4 * 1024 >= 3 * QZ_CLUSTER4, "stage registers");
+            if (k == 1) { if (rw == 2) QZ_LAUNCH(2, 3, 2, QZ_THREADS); else QZ_LAUNCH(2, 3, 1, QZ_THREADS); }
+            else if (k == 2) { if (rw == 2) QZ_LAUNCH(2, 6, 2, QZ_THREADS); else QZ_LAUNCH(2, 6, 1, QZ_THREADS); }
+            else if (wide) { if (rw == 2) QZ_LAUNCH(1, 4, 2, 1024); else QZ_LAUNCH(1, 4, 1, 1024); }
+            else { if (rw == 2) QZ_LAUNCH(1, 8, 2, QZ_THREADS); else QZ_LAUNCH(1, 8, 1, QZ_THREADS); }
 #undef QZ_LAUNCH
         }
         dim3 grid((unsigned)((n4 + 255) / 256));
