@@ -49,8 +49,7 @@ CONFIGS = {
 # algorithmic bytes per symbol of each kernel (DESIGN.md "Kernels")
 ALG_BYTES_PER_SYMBOL = {
     "pmf_hist": 1.0,             # each symbol read once (+1 B/read of labels when k > 1, added below)
-    "kmeans_assign": 1.0,
-    "kmeans_accumulate": 1.0,    # + labels re-read per column when k > 1 (2 B/sym)
+    "kmeans_step": 1.0,          # one pass per iteration: each symbol read once (+1 B/read of labels written)
     "quantize": 5.0,             # symbol in, draw in, (qv, qi, st) out: the -u product and the coder's two planes
     "well_draws": 3.0,           # word stream written once and read once, draw matrix written once
     "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out (host / gpu-feed coders only)
@@ -397,8 +396,8 @@ def main():
         extra = 0.0
         if k > 1 and dom == "pmf_hist":
             extra = float(n)
-        if k > 1 and dom == "kmeans_accumulate":
-            bps = 2.0
+        if k > 1 and dom == "kmeans_step":
+            extra = float(n)
         alg_bytes = bps * n * c + extra
         achieved = alg_bytes / (per_launch[dom] * 1e-3) / 1e9
         roof = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
@@ -411,7 +410,8 @@ def main():
         line = {
             "metric": "quality-symbols/s (encode)", "value": round(n_total * c * args.steps / elapsed, 1),
             "unit": "quality-symbols/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "step_ms": [round(r["wall"]["total"] * 1e3, 1) for r in results],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic QGEN-1 (SURVEY.md Appendix D), generated on device",
             "config": {"workload": cfg["name"] + f" per GPU, reads sharded over {world} GPU(s)", "reads_per_gpu": n,
                        "columns": c, "clusters": k, "coder": f"{shards} independent reference-format streams per GPU "

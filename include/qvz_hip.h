@@ -91,6 +91,12 @@ int qvz_hip_kmeans_assign(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t
 /* first pass of recalculate_means (cluster.c:92-101): d_acc[j][s] += sum of symbols of reads labelled j */
 int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c,
                               uint64_t ld, uint32_t k, uint64_t *d_acc /*[k][c], +=*/, void *stream);
+/* One iteration's assignment AND sums in a single pass over the symbols: exactly qvz_hip_kmeans_assign followed by
+ * qvz_hip_kmeans_accumulate (same labels, counts and sums), which it calls for shapes its one-pass kernel does not take
+ * (k outside 2..4, more than 160 columns). This is what the drivers call; symbols must be below 128. */
+int qvz_hip_kmeans_step(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint32_t k,
+                        const uint8_t *d_means /*[k][c]*/, uint8_t *d_labels /*[ld]*/, uint32_t *d_counts /*[k], +=*/,
+                        uint64_t *d_acc /*[k][c], +=*/, void *stream);
 /* second pass of recalculate_means (cluster.c:104-128): mean = acc/count (floor), moved_j = sum (dmean)^2.
  * d_moved: k+1 doubles (exact integers): [0] = max_j moved_j, [1+j] = moved_j.
  * d_status[0] |= 1 if a cluster is empty. */

@@ -243,8 +243,7 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
         int32_t kstat = 0;
         HIP(qvz_hip_memset(job->d_counts, 0, K * sizeof(uint32_t), NULL));
         HIP(qvz_hip_memset(job->d_acc, 0, (size_t)K * C * sizeof(uint64_t), NULL));
-        HIP(qvz_hip_kmeans_assign(job->d_sym, N, C, ld, K, job->d_means, job->d_labels, job->d_counts, NULL));
-        HIP(qvz_hip_kmeans_accumulate(job->d_sym, job->d_labels, N, C, ld, K, job->d_acc, NULL));
+        HIP(qvz_hip_kmeans_step(job->d_sym, N, C, ld, K, job->d_means, job->d_labels, job->d_counts, job->d_acc, NULL));
         if (job->allreduce) {                                                   /* the sums of every part of the file, 64 bits wide */
             HIP(qvz_hip_widen_u32(job->d_counts, job->d_counts64, K, NULL));
             HIP(job->allreduce(job->allreduce_ctx, job->d_acc, (uint64_t)K * C, 8, NULL));

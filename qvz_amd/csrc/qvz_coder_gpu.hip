@@ -780,10 +780,13 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
     const uint32_t rb_stride = W + 1;                            // +1: conflict-free transposition
     Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [64][W + 1]
-    uint32_t *rowbuf = reinterpret_cast<uint32_t *>(recbuf + 64 * rb_stride);   // [2][4][64]: segment rows of the reads of two blocks of four chunks (lists)
+    // lists: the segment rows of the reads of a block of four chunks live in the padding record of the read's row of
+    // recbuf (16 bytes = four row numbers per lane): no LDS of their own - with three clusters on 100M x 150 that is what
+    // lets a third workgroup fit a CU
+    auto rowslot = [&](uint32_t rd, uint32_t j) -> uint32_t * { return reinterpret_cast<uint32_t *>(recbuf + rd * rb_stride + W) + j; };
     // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, and per quantizer of the column its table's
     // offset in the slice | alphabet size << 16 (RK_NONE, size 0: no table), so that one LDS read resolves a symbol
-    unsigned long long *msk = reinterpret_cast<unsigned long long *>(rowbuf + (HAVE_LABELS ? 512 : 0)) + (size_t)wave * ((3 * slice_cap + 2 * A) / 2);
+    unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride) + (size_t)wave * ((3 * slice_cap + 2 * A) / 2);
     uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
     uint32_t *cof = tab + slice_cap;
     const bool cluster_wave = HAVE_LABELS && sx == 0;
@@ -889,9 +892,13 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         Record outr = make_double2(0.0, 0.0);
         const uint32_t tb = tb_nx, x = x_lk, card = card_nx;
         const bool ok = ok_nx;
-        if (lists && wave == 0 && (chunk & 3) == 0) {            // where in the segment the reads of this block of four chunks lie
+        // where in the segment the reads of this block of four chunks lie. Everybody has drained the chunk before the last
+        // (barrier 1 of the last one), so the first three row numbers can be replaced here; the fourth, which the last
+        // chunk's drain may still be reading, after this chunk's first barrier
+        const bool new_rows = lists && wave == 0 && (chunk & 3) == 0;
+        if (new_rows) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rowbuf[((chunk >> 2) & 1) * 256 + j * 64 + lane] = r_cur[j] - (uint32_t)seg_lo;
+            for (int j = 0; j < 3; ++j) *rowslot(lane, j) = r_cur[j] - (uint32_t)seg_lo;
         }
         if (rb + 64 < nr) lookup(rb + 64, chunk + 1);
         RK_T(0);
@@ -989,13 +996,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         __syncthreads();                                         // the previous chunk has been drained
         RK_T(3);
         buf[lane * rb_stride + wave] = outr;
+        if (new_rows) *rowslot(lane, 3) = r_cur[3] - (uint32_t)seg_lo;
         RK_EXP(2)
         __syncthreads();
         RK_T(4);
         {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
             const uint32_t rd = threadIdx.x >> log2w, cw = threadIdx.x & (W - 1);
             const uint32_t col = cg * W + cw;                    // rec_index with the stream's part hoisted out of the loop
-            const uint32_t row = lists ? rowbuf[((chunk >> 2) & 1) * 256 + (chunk & 3) * 64 + rd] : rb + rd;
+            const uint32_t row = lists ? *rowslot(rd, chunk & 3) : rb + rd;
             // The input bytes of chunks c+2 .. c+5 are taken over here (and the following four requested): the wait for
             // them also waits for every store issued so far, and at this point the latest one is a whole chunk old.
             if (((chunk + 2) & 3) == 0) park(rb + 128);
@@ -1498,7 +1506,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
             // beside k_code_records' 32 KB of LDS (measured with three clusters, where LDS holds one such workgroup
             // per CU: W = 4 0.40 s, W = 2 0.42 s, W = 1 0.67 s for the model kernels; W = 8 never paid).
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
-            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (clusters > 1 ? 2048 : 0) + (size_t)w * (3 * slice_cap + 2 * A) * 4; };   // records, list rows, per wave masks + tables + offsets
+            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + 2 * A) * 4; };   // records (list rows in their padding), per wave masks + tables + offsets
             const size_t budget = 160 * 1024 - 32 * 1024;
             const uint32_t order[3] = {4, 2, 1};
             for (uint32_t w : order) {
@@ -1619,6 +1627,8 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     s_model = s_coder = st;
     if (overlap) {
         TRY(hipStreamCreateWithFlags(&s_model, hipStreamNonBlocking));
+        // (a high-priority queue for the coder kernel was tried: its segments got slower, 225 ms against 167 ms of kernel time
+        // per step with three clusters at 100M x 150, and the step with them)
         TRY(hipStreamCreateWithFlags(&s_coder, hipStreamNonBlocking));
         TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         TRY(hipEventRecord(ev_start, st));                       // uploads and whatever the caller queued before us
@@ -1788,7 +1798,7 @@ extern "C" int qvz_hip_model_session_open(uint32_t columns, uint32_t clusters, c
     s->slice_cap = (s->slice_cap + 3) & ~3u;
     s->total_words = (uint32_t)h_slices.size();
     free(h_arena); free(h_off);
-    auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (clusters > 1 ? 2048 : 0) + (size_t)w * (3 * s->slice_cap + 2 * A) * 4; };
+    auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * s->slice_cap + 2 * A) * 4; };
     const uint32_t order[3] = {4, 2, 1};
     for (uint32_t w : order)
         if (fits && need_of(w) <= (size_t)160 * 1024) { s->rk_waves = w; s->rk_lds = need_of(w); break; }

@@ -505,6 +505,216 @@ extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_
     return QVZ_OK;
 }
 
+// One k-means iteration in ONE pass over the symbols (2 .. 4 clusters, up to 160 columns): assignment, counts and the
+// per-cluster column sums. The two kernels above read the matrix twice per iteration, and each runs at the HBM rate
+// already (2.8 + 3.3 ms for 15 GB on MI355X), so the only thing left to save is the second read: a workgroup keeps a tile of
+// 256 reads x C columns in LDS (C x 272 bytes), and everything an iteration needs is computed from that copy.
+//   distances   sum_s x_s m_js for the K centroids, the c_j - 2 dot_j algebra of k_kmeans_assign16. A thread takes four reads
+//               and a quarter of the columns: four dwords (four reads of four adjacent columns) are transposed in registers
+//               (8 v_perm_b32) into one dword per read holding its four columns, and v_dot4_u32_u8 against the four centroid
+//               bytes does four multiply-adds per instruction; the partial sums of the four column quarters meet in LDS.
+//   sums        acc[j][s] = sum_r [label_r = j] x_rs is a (clusters x reads) . (reads x columns) product of small integers:
+//               the one-hot label bytes are the A operand, the tile as it lies in LDS (a column's reads are contiguous) is the
+//               B operand of v_mfma_i32_16x16x64_i8; a wave owns 64 of the tile's reads and keeps its 16 x 16 accumulators in
+//               registers over all the tiles of the workgroup (exact: int32, flushed long before they could wrap).
+// The grid is persistent (three workgroups per CU), the next tile's loads are in flight while the current one is worked on,
+// and a workgroup adds to the global counters once. Symbols must be below 128 (the i8 operand is signed; the encode path
+// has rejected anything above 71 before it clusters). Exact integers throughout: same labels, counts and sums as the
+// two-pass kernels, hence as cluster.c:75-98 and :104-128's inputs.
+#define KMS_R 256
+#define KMS_PITCH 272          // 68 dwords = 4 x odd: the 16-byte operand reads of 16 columns fall on 16 different bank quads
+#define KMS_NT 10              // column tiles of 16: C <= 160
+typedef int kms_v4i __attribute__((ext_vector_type(4)));
+
+template <int K>
+__global__ __launch_bounds__(256, 3) void k_kmeans_step(const uint8_t *__restrict__ D, uint64_t n, uint32_t C, uint64_t ld,
+                                                     const uint8_t *__restrict__ means, uint8_t *__restrict__ labels,
+                                                     uint32_t *__restrict__ counts, unsigned long long *__restrict__ acc,
+                                                     uint64_t ntiles) {
+    extern __shared__ uint4 kms_smem[];
+    const uint32_t CQ = (C + 3) / 4;
+    uint8_t *tile = reinterpret_cast<uint8_t *>(kms_smem);                       // [C][KMS_PITCH]
+    uint32_t *dots = reinterpret_cast<uint32_t *>(tile + (size_t)C * KMS_PITCH); // [K][4][64]: read 4q + i of the tile at [i][q]
+    uint32_t *m4 = dots + K * KMS_R;                                             // [CQ][4]: centroid j's bytes of columns 4cq .. 4cq+3
+    uint32_t *blk = m4 + CQ * 4;                                                 // [K][KMS_NT * 16] sums of this workgroup
+    int32_t *csq = reinterpret_cast<int32_t *>(blk + K * KMS_NT * 16);           // [4] sum of m_js^2
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(csq + 4);                       // [4]
+    uint8_t *oh = reinterpret_cast<uint8_t *>(cnt + 4);                          // [K][KMS_R] one-hot labels (invalid reads: none)
+    uint8_t *labsm = oh + K * KMS_R;                                             // [KMS_R]
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+
+    if (tid < 4) { csq[tid] = 0; cnt[tid] = 0; }
+    for (uint32_t i = tid; i < K * KMS_NT * 16; i += 256) blk[i] = 0;
+    __syncthreads();
+    for (uint32_t cq = tid; cq < CQ; cq += 256) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t w = 0;
+            if (j < K)
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint32_t s = 4 * cq + i, m = s < C ? means[(uint64_t)j * C + s] : 0u;
+                    w |= m << (8 * i);
+                    if (m) atomicAdd(&csq[j], (int32_t)(m * m));
+                }
+            m4[cq * 4 + j] = w;
+        }
+    }
+
+    // loads of a tile: thread t takes bytes 16 (t & 15) .. +15 of columns (t >> 4) + 16 e
+    const uint32_t v16 = (tid & 15) * 16, s0 = tid >> 4;
+    uint4 pf[KMS_NT];
+    auto load_tile = [&](uint64_t t) {
+        const uint64_t r0 = t * KMS_R + v16;
+#pragma unroll
+        for (int e = 0; e < KMS_NT; ++e) {
+            const uint32_t s = s0 + 16 * e;
+            pf[e] = make_uint4(0u, 0u, 0u, 0u);
+            if (s < C && r0 < ld) pf[e] = *reinterpret_cast<const uint4 *>(D + (uint64_t)s * ld + r0);
+        }
+    };
+    kms_v4i accv[KMS_NT];
+#pragma unroll
+    for (int nt = 0; nt < KMS_NT; ++nt) accv[nt] = kms_v4i{0, 0, 0, 0};
+    auto flush = [&]() {                                         // the workgroup's sums and counts -> global (all threads)
+        if (lane < 16) {
+#pragma unroll
+            for (int nt = 0; nt < KMS_NT; ++nt) {
+                const uint32_t s = 16 * nt + lane;
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    if (s < C && accv[nt][j]) atomicAdd(&blk[j * KMS_NT * 16 + s], (uint32_t)accv[nt][j]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < KMS_NT; ++nt) accv[nt] = kms_v4i{0, 0, 0, 0};
+        __syncthreads();
+        for (uint32_t i = tid; i < K * KMS_NT * 16; i += 256) {
+            const uint32_t j = i / (KMS_NT * 16), s = i % (KMS_NT * 16), v = blk[i];
+            if (v) atomicAdd(&acc[(uint64_t)j * C + s], (unsigned long long)v);
+            blk[i] = 0;
+        }
+        if (tid < K && cnt[tid]) { atomicAdd(&counts[tid], cnt[tid]); cnt[tid] = 0; }
+        __syncthreads();
+    };
+
+    uint64_t t = blockIdx.x;
+    if (t < ntiles) load_tile(t);
+    uint32_t done = 0;
+    for (; t < ntiles; t += gridDim.x) {
+        __syncthreads();                                         // the previous tile is finished with (tile, dots, one-hot bytes)
+#pragma unroll
+        for (int e = 0; e < KMS_NT; ++e) {
+            const uint32_t s = s0 + 16 * e;
+            if (s < C) *reinterpret_cast<uint4 *>(tile + (size_t)s * KMS_PITCH + v16) = pf[e];
+        }
+        for (uint32_t i = tid; i < K * KMS_R; i += 256) dots[i] = 0;
+        if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);    // in flight while this tile is worked on
+        __syncthreads();
+        // ---- distances: wave = a quarter of the column quads, lane = reads 4 lane .. 4 lane + 3 ----
+        {
+            const uint32_t per = (CQ + 3) / 4, c0 = wave * per, c1 = c0 + per < CQ ? c0 + per : CQ;
+            uint32_t dot[4][K];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < K; ++j) dot[i][j] = 0;
+            for (uint32_t cq = c0; cq < c1; ++cq) {
+                uint32_t w[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint32_t s = 4 * cq + i < C ? 4 * cq + i : C - 1;   // a column past the last: its centroid bytes are 0
+                    w[i] = *reinterpret_cast<const uint32_t *>(tile + (size_t)s * KMS_PITCH + 4 * lane);
+                }
+                // 4 x 4 byte transpose: r[i] = read i's bytes of the four columns
+                const uint32_t lo01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), hi01 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
+                const uint32_t lo23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), hi23 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+                const uint32_t r[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u), __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),
+                                       __builtin_amdgcn_perm(hi23, hi01, 0x05040100u), __builtin_amdgcn_perm(hi23, hi01, 0x07060302u)};
+                const uint4 mm = *reinterpret_cast<const uint4 *>(m4 + cq * 4);   // the same address in every lane
+                const uint32_t mj[4] = {mm.x, mm.y, mm.z, mm.w};
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dot[i][j] = __builtin_amdgcn_udot4(r[i], mj[j], dot[i][j], false);
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(&dots[j * KMS_R + i * 64 + lane], dot[i][j]);
+        }
+        __syncthreads();
+        // ---- labels: thread = read ----
+        {
+            const uint64_t rd = t * KMS_R + tid;
+            const uint32_t slot = (tid & 3) * 64 + (tid >> 2);
+            int32_t best = csq[0] - 2 * (int32_t)dots[slot];
+            uint32_t lab = 0;
+#pragma unroll
+            for (int j = 1; j < K; ++j) {
+                const int32_t d = csq[j] - 2 * (int32_t)dots[j * KMS_R + slot];
+                if (d < best) { best = d; lab = j; }             // strict: the lowest cluster id wins ties (cluster.c:155-163)
+            }
+            const bool valid = rd < n;
+            labsm[tid] = (uint8_t)lab;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                oh[j * KMS_R + tid] = valid && lab == (uint32_t)j ? 1 : 0;
+                const unsigned long long m = __ballot(valid && lab == (uint32_t)j);
+                if (lane == 0 && m) atomicAdd(&cnt[j], (uint32_t)__builtin_popcountll(m));
+            }
+        }
+        __syncthreads();
+        if (tid < 16 && t * KMS_R + tid * 16 < ld)               // (the label vector is ld long)
+            *reinterpret_cast<uint4 *>(labels + t * KMS_R + tid * 16) = *reinterpret_cast<const uint4 *>(labsm + tid * 16);
+        // ---- sums: wave = reads 64 wave .. +63 (one k-step of 64), lane & 15 = cluster (A) / column of the tile (B) ----
+        {
+            const uint32_t i16 = lane & 15, q = lane >> 4, koff = 64 * wave + 16 * q;
+            kms_v4i a = kms_v4i{0, 0, 0, 0};
+            if (i16 < K) a = *reinterpret_cast<const kms_v4i *>(oh + i16 * KMS_R + koff);
+#pragma unroll
+            for (int nt = 0; nt < KMS_NT; ++nt) {
+                if (16u * nt < C) {
+                    const uint32_t s = 16 * nt + i16 < C ? 16 * nt + i16 : C - 1;   // past the last column: a copy nobody reads
+                    const kms_v4i b = *reinterpret_cast<const kms_v4i *>(tile + (size_t)s * KMS_PITCH + koff);
+                    accv[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, accv[nt], 0, 0, 0);
+                }
+            }
+        }
+        if (++done == 32768) { done = 0; __syncthreads(); flush(); }   // 2^15 tiles x 64 reads x 127 < 2^31
+    }
+    __syncthreads();
+    flush();
+}
+
+extern "C" int qvz_hip_kmeans_step(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint32_t k, const uint8_t *d_means,
+                                   uint8_t *d_labels, uint32_t *d_counts, uint64_t *d_acc, void *stream) {
+    int rc = check_matrix(n, c, ld);
+    if (rc) return rc;
+    if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
+    const char *knob = getenv("QVZ_KMEANS_FUSED");               // development knob: "0" keeps the two-pass kernels
+    if (k < 2 || k > 4 || c > 16 * KMS_NT || (knob && atoi(knob) == 0)) {
+        rc = qvz_hip_kmeans_assign(d_sym, n, c, ld, k, d_means, d_labels, d_counts, stream);
+        if (rc) return rc;
+        return qvz_hip_kmeans_accumulate(d_sym, d_labels, n, c, ld, k, d_acc, stream);
+    }
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t ntiles = (n + KMS_R - 1) / KMS_R;
+    const uint32_t cq = (c + 3) / 4;
+    const size_t lds = (size_t)c * KMS_PITCH + ((size_t)k * KMS_R + cq * 4 + (size_t)k * KMS_NT * 16 + 8) * 4 + (size_t)k * KMS_R + KMS_R;
+    const uint64_t want = (uint64_t)cus * 3;
+    dim3 grid((unsigned)(ntiles < want ? ntiles : want));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(d_acc);
+    if (k == 2) hipLaunchKernelGGL(k_kmeans_step<2>, grid, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts, acc, ntiles);
+    else if (k == 3) hipLaunchKernelGGL(k_kmeans_step<3>, grid, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts, acc, ntiles);
+    else hipLaunchKernelGGL(k_kmeans_step<4>, grid, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts, acc, ntiles);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
 // New centroids and how far they moved (cluster.c:104-128). One block; exact integers throughout.
 template <typename CountT>   // uint32_t as the reference keeps them (lines.h:41), or 64 bits for a file of more than 2^32 - 1 reads
 __global__ __launch_bounds__(256) void k_kmeans_update(const unsigned long long *__restrict__ acc,

@@ -79,6 +79,21 @@ def kmeans_accumulate(sym, n, labels, k, acc=None):
     return acc
 
 
+def kmeans_step(sym, n, means, labels=None, counts=None, acc=None):
+    """Assignment and per-cluster column sums of one k-means iteration in one pass (qvz_hip_kmeans_step)."""
+    c, ld = _dims(sym, n)
+    k = means.shape[0]
+    assert means.dtype == torch.uint8 and means.shape == (k, c) and means.is_contiguous()
+    if labels is None:
+        labels = torch.zeros(ld, dtype=torch.uint8, device=sym.device)
+    if counts is None:
+        counts = torch.zeros(k, dtype=torch.int32, device=sym.device)
+    if acc is None:
+        acc = torch.zeros((k, c), dtype=torch.int64, device=sym.device)
+    check(lib().qvz_hip_kmeans_step(_ptr(sym), n, c, ld, k, _ptr(means), _ptr(labels), _ptr(counts), _ptr(acc), _stream()))
+    return labels, counts, acc
+
+
 def kmeans_update(acc, counts, means):
     k, c = means.shape
     moved = torch.zeros(k + 1, dtype=torch.float64, device=means.device)   # [0] = max, [1+j] per cluster

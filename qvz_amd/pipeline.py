@@ -104,13 +104,9 @@ class HipBackend:
         """symbols of the reads idx (local indices) as a (len(idx), c) uint8 tensor"""
         return sym[:, torch.as_tensor(idx, dtype=torch.long, device=sym.device)].t().contiguous()
 
-    def kmeans_assign(self, sym, n, means, labels, counts):
-        with self.timer.span("kmeans_assign"):
-            K.kmeans_assign(sym, n, means, labels=labels, counts=counts)
-
-    def kmeans_accumulate(self, sym, n, labels, k, acc):
-        with self.timer.span("kmeans_accumulate"):
-            K.kmeans_accumulate(sym, n, labels, k, acc=acc)
+    def kmeans_step(self, sym, n, means, labels, counts, acc):
+        with self.timer.span("kmeans_step"):
+            K.kmeans_step(sym, n, means, labels=labels, counts=counts, acc=acc)
 
     def kmeans_update(self, acc, counts, means):
         return K.kmeans_update(acc, counts, means)
@@ -246,8 +242,7 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     while k > 1 and reuse is None:
         counts.zero_()
         acc.zero_()
-        be.kmeans_assign(sym, n, means, labels, counts)
-        be.kmeans_accumulate(sym, n, labels, k, acc)
+        be.kmeans_step(sym, n, means, labels, counts, acc)
         if group is not None:
             dist_mod.all_reduce(acc, group=group)
             dist_mod.all_reduce(counts, group=group)

@@ -55,6 +55,10 @@ class OracleBackend:
     def read_rows(self, sym, idx):
         return sym[:, torch.as_tensor(idx, dtype=torch.long)].t().contiguous()
 
+    def kmeans_step(self, sym, n, means, labels, counts, acc):
+        self.kmeans_assign(sym, n, means, labels, counts)
+        self.kmeans_accumulate(sym, n, labels, means.shape[0], acc)
+
     def kmeans_assign(self, sym, n, means, labels, counts):
         x = sym[:, :n].numpy().T.astype(np.int64)
         d = ((x[:, None, :] - means.numpy()[None].astype(np.int64)) ** 2).sum(axis=2)

@@ -87,8 +87,7 @@ def test_kmeans_full_loop_matches_reference_phase(K, name):
     means = torch.from_numpy(np.stack([rows[int(i), :c] - 33 for i in cent]).astype(np.uint8)).cuda()
     iters = 0
     while True:
-        labels, counts = K.kmeans_assign(sym, n, means)
-        acc = K.kmeans_accumulate(sym, n, labels, k)
+        labels, counts, acc = K.kmeans_step(sym, n, means)
         moved, status = K.kmeans_update(acc, counts, means)
         iters += 1
         assert int(status.item()) == 0
@@ -121,6 +120,56 @@ def test_kmeans_single_iteration_random_means(K, k):
     np.testing.assert_array_equal(means.cpu().numpy() + 33, omeans)
     ref_acc = np.zeros((k, c), dtype=np.int64)
     np.add.at(ref_acc, olab, (rows[:, :c] - 33).astype(np.int64))
+    np.testing.assert_array_equal(acc.cpu().numpy(), ref_acc)
+
+
+@pytest.mark.parametrize("k,n,c,seed", [(3, 12345, 150, 5), (2, 70001, 100, 6), (4, 4099, 160, 7), (3, 255, 37, 8), (3, 256, 4, 9),
+                                         (2, 17, 1, 10), (3, 1_000_003, 36, 11), (4, 300_000, 151, 12), (3, 5000, 161, 13)])
+def test_kmeans_one_pass_step_equals_the_two_pass_kernels(K, k, n, c, seed):
+    """qvz_hip_kmeans_step (tile in LDS: distances by byte dot products, sums by an i8 MFMA against the one-hot labels)
+    == qvz_hip_kmeans_assign + qvz_hip_kmeans_accumulate == numpy, bit for bit: ragged tails (n not a multiple of 16 or 256),
+    fewer reads than a tile, more tiles than the persistent grid holds at once (1e6 reads), 151 and 160 columns (partial and
+    full last column tile), 161 columns (the fallback), column counts that are not multiples of 4."""
+    rows = O.qgen1_rows(seed, n, c)
+    rng = np.random.default_rng(seed)
+    cent = np.sort(rng.choice(n, size=k, replace=False))
+    sym = upload_sym(K, rows)
+    x = (rows[:, :c] - 33).astype(np.int64)
+    means_np = x[cent].astype(np.uint8)
+    means = torch.from_numpy(means_np.copy()).cuda()
+    labels, counts, acc = K.kmeans_step(sym, n, means)
+    labels2, counts2 = K.kmeans_assign(sym, n, means)
+    acc2 = K.kmeans_accumulate(sym, n, labels2, k)
+    d = np.stack([((x - means_np[j].astype(np.int64)) ** 2).sum(axis=1) for j in range(k)], axis=1)
+    lab = d.argmin(axis=1)
+    ref_acc = np.stack([x[lab == j].sum(axis=0) for j in range(k)])
+    np.testing.assert_array_equal(labels[:n].cpu().numpy(), lab)
+    np.testing.assert_array_equal(counts.cpu().numpy(), np.bincount(lab, minlength=k))
+    np.testing.assert_array_equal(acc.cpu().numpy(), ref_acc)
+    assert torch.equal(labels[:n], labels2[:n]) and torch.equal(counts, counts2) and torch.equal(acc, acc2)
+    # += semantics of counts and sums (the drivers zero them per iteration)
+    K.kmeans_step(sym, n, means, labels=labels, counts=counts, acc=acc)
+    assert torch.equal(counts, 2 * counts2) and torch.equal(acc, 2 * acc2)
+
+
+def test_kmeans_one_pass_step_with_ties_and_extreme_symbols(K):
+    """Equal distances go to the lowest cluster id (cluster.c:155-163) in the dot-product form too, and symbols up to 127
+    (far beyond the 72-symbol alphabet) stay exact in the signed i8 operand."""
+    n, c, k = 3000, 24, 4
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 128, size=(n, c), dtype=np.int64)
+    x[::7] = 127
+    means_np = np.stack([x[1], x[1], x[2], x[2]]).astype(np.uint8)        # duplicate centroids: every read ties between two
+    rows = np.full((n, c + 1), 10, dtype=np.uint8)
+    rows[:, :c] = x + 33
+    sym = upload_sym(K, rows)
+    labels, counts, acc = K.kmeans_step(sym, n, torch.from_numpy(means_np.copy()).cuda())
+    d = ((x[:, None, :] - means_np[None].astype(np.int64)) ** 2).sum(axis=2)
+    lab = d.argmin(axis=1)
+    assert set(np.unique(lab)) <= {0, 2}
+    ref_acc = np.zeros((k, c), dtype=np.int64)
+    np.add.at(ref_acc, lab, x)
+    np.testing.assert_array_equal(labels[:n].cpu().numpy(), lab)
     np.testing.assert_array_equal(acc.cpu().numpy(), ref_acc)
 
 
