@@ -1,6 +1,7 @@
 // qvz_kernels.hip - gfx950 (MI355X / CDNA4) kernels for the N-dependent phases of qvz's encode path
 // and their C-ABI (include/qvz_hip.h). Written for wave64, 256 CUs / 8 XCDs, 160 KB LDS per CU.
-// Nothing here is a dense contraction: the budget is HBM bytes, LDS atomics and latency, not MFMA.
+// The budget is HBM bytes, LDS atomics and latency; the one contraction on the path (the per-cluster column sums of a
+// k-means iteration: one-hot labels times the symbol tile) is the one MFMA use (k_kmeans_step).
 //
 // Data layout: one column-major, offset-removed symbol matrix d_sym[s*ld + i] (see qvz_hip.h). Every
 // kernel streams columns with 4- or 16-byte per-lane accesses, so each wave instruction moves 256 B-1 KiB.

@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 NAMES = {"k_model_ranks": "model_records", "k_model_columns": "model_records", "k_code_records": "code_records",
          "k_quantize": "quantize", "k_pmf_walk": "pmf_hist", "k_kmeans_accum": "kmeans_accumulate",
          "k_draws_transpose": "draws_transpose", "k_well_gen": "well_gen", "k_kmeans_assign": "kmeans_assign",
-         "k_lm_window": "lm_window"}
+         "k_lm_window": "lm_window", "k_kmeans_step": "kmeans_step"}
 
 
 # FETCH_SIZE x 2 is calibrated for 128-byte requests (wide coalesced reads). k_code_records' loader now asks for 64-byte
