@@ -277,6 +277,10 @@ int qvz_decode_stream_host(uint32_t K, uint32_t C, uint64_t lines, const qvz_cod
             }
             row[C] = '\n';
             if (fwrite(row, 1, (size_t)C + 1, fo) != (size_t)C + 1) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+            /* The reference reads zeros past the end of a short file and goes on for as many lines as the header claims
+             * (stream_read_bit, os_stream.c:36-52). A whole stream is never read more than the 22 bits of look-ahead past
+             * its last byte, so further than that means the file was cut or its line count is wrong. */
+            if (d.pos > (uint64_t)size + 8 && i + 1 < lines) { rc = qvz_job_fail(QVZ_E_DATA, "the stream ends before line %llu of %llu", (unsigned long long)(i + 2), (unsigned long long)lines); goto done; }
         }
     }
 done:

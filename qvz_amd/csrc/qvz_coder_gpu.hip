@@ -1515,6 +1515,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
                 rk_waves = w; rk_lds = need;
                 break;
             }
+            if (getenv("QVZ_MODEL_LDS_PAD")) rk_lds += (size_t)atoi(getenv("QVZ_MODEL_LDS_PAD"));   // development knob: occupancy experiments
             if (we) {
                 const uint32_t w = (uint32_t)atoi(we);
                 if (w >= 1 && w <= 16 && !(w & (w - 1)) && need_of(w) <= 160 * 1024) { rk_waves = w; rk_lds = need_of(w); }
