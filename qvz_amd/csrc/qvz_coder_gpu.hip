@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
 // One raw s_barrier per block of CR_B symbols (no fence, nobody but the loader waits on vmcnt): before barrier b the
 // loader has parked records b; after it the interval wave codes block b, the bits wave block b-1, the bytes wave
 // block b-2. (Measured with a single emitter wave: emitter busy 1440 cycles per 8 symbols, loader 1190, chain 1070.)
-#define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps ~27 KB of LDS so that it fits beside the model kernel's workgroups)
+#define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps 31.5 KB of LDS so that it fits beside the model kernel's workgroups: 3 x 42.5 KB + 32.5 KB is exactly a CU's 160 KB at 100M x 150, -f 0.5)
 static_assert(CR_B == 8, "the record layout (rec_index) has 8 records per lane and block");
 #define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
 __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
