@@ -411,6 +411,8 @@ def main():
             "metric": "quality-symbols/s (encode)", "value": round(n_total * c * args.steps / elapsed, 1),
             "unit": "quality-symbols/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "step_ms": [round(r["wall"]["total"] * 1e3, 1) for r in results],
+            "step_phase_ms": {ph: [round(r["wall"][ph] * 1e3, 1) for r in results] for ph in results[-1]["wall"] if ph != "total"},
+            "step_kernel_ms": {name: [round(x, 1) for x in v] for name, v in spans.items() if len(v) == args.steps},
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic QGEN-1 (SURVEY.md Appendix D), generated on device",
             "config": {"workload": cfg["name"] + f" per GPU, reads sharded over {world} GPU(s)", "reads_per_gpu": n,

@@ -892,6 +892,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             QVZ_HIP_CHECK(hipStreamSynchronize(st));
         }
         cb_wait[which] += cb_now() - t_;
+        if (cb_debug && cb_now() - t_ > 5e-3) fprintf(stderr, "  long hand-over wait: %.1f ms for flag %u (kind %d)\n", (cb_now() - t_) * 1e3, seq, which);
         return QVZ_OK;
     };
     auto flag_after = [&]() -> uint32_t {

@@ -14,6 +14,7 @@
 //   E1/E2 and E3 loops: one count-leading-zeros batch each.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 
 #include <stdint.h>
@@ -1471,6 +1472,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     uint64_t *d_cstart = nullptr;
     bool overlap = false;
     hipStream_t s_model = nullptr, s_coder = nullptr;
+    bool own_streams = true;                                    // false: the device's kept pair (not destroyed here)
     hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> evs;                                // per segment: model start, model end, coder start, coder end
     uint32_t nseg = 0;
@@ -1627,10 +1629,31 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     g_planes_ms[0] = g_planes_ms[1] = 0.0;
     s_model = s_coder = st;
     if (overlap) {
-        TRY(hipStreamCreateWithFlags(&s_model, hipStreamNonBlocking));
-        // (a high-priority queue for the coder kernel was tried: its segments got slower, 225 ms against 167 ms of kernel time
-        // per step with three clusters at 100M x 150, and the step with them)
-        TRY(hipStreamCreateWithFlags(&s_coder, hipStreamNonBlocking));
+        // The two streams are made once per device and kept: the runtime spreads streams over a handful of hardware queues
+        // (four by default) and a queue runs its kernels in order, so a pair of streams made afresh for every call lands,
+        // every few calls, on the queue of some other stream of the process that is busy at the time - or on one and the
+        // same queue, and the model kernel of a segment then waits for the coder kernel of the one before it.
+        // (A high-priority queue for the coder kernel was tried: its segments got slower, 225 ms against 167 ms of kernel
+        // time per step with three clusters at 100M x 150, and the step with them.)
+        {
+            static std::mutex mu;
+            static hipStream_t kept[64][2];
+            int dev = 0;
+            TRY(hipGetDevice(&dev));
+            std::lock_guard<std::mutex> lk(mu);
+            if (dev >= 0 && dev < 64) {
+                if (!kept[dev][0]) {
+                    TRY(hipStreamCreateWithFlags(&kept[dev][0], hipStreamNonBlocking));
+                    TRY(hipStreamCreateWithFlags(&kept[dev][1], hipStreamNonBlocking));
+                }
+                s_model = kept[dev][0];
+                s_coder = kept[dev][1];
+                own_streams = false;
+            } else {
+                TRY(hipStreamCreateWithFlags(&s_model, hipStreamNonBlocking));
+                TRY(hipStreamCreateWithFlags(&s_coder, hipStreamNonBlocking));
+            }
+        }
         TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         TRY(hipEventRecord(ev_start, st));                       // uploads and whatever the caller queued before us
         TRY(hipStreamWaitEvent(s_model, ev_start, 0));
@@ -1724,8 +1747,8 @@ done:
     (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
     for (size_t i = 0; i < evs.size(); ++i) if (evs[i]) (void)hipEventDestroy(evs[i]);
     if (ev_start) (void)hipEventDestroy(ev_start);
-    if (s_model && s_model != st) { (void)hipStreamSynchronize(s_model); (void)hipStreamDestroy(s_model); }
-    if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); (void)hipStreamDestroy(s_coder); }
+    if (s_model && s_model != st) { (void)hipStreamSynchronize(s_model); if (own_streams) (void)hipStreamDestroy(s_model); }
+    if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); if (own_streams) (void)hipStreamDestroy(s_coder); }
     (void)hipFree(d_cs); (void)hipFree(own_work); (void)hipFree(d_slices); (void)hipFree(d_colbase); (void)hipFree(d_coff); (void)hipFree(d_save);
     (void)hipFree(d_clist); (void)hipFree(d_cstart); (void)hipFree(d_segpos); (void)hipFree(d_bounds);
     free(h_arena); free(h_off); free(h_first);

@@ -82,6 +82,22 @@ class _Span:
             self.t.spans.append((self.name, self.a, b))
 
 
+_KEPT_STREAMS = {}
+
+
+def kept_stream(device, name):
+    """A side stream that is made once per (device, role) and kept for the life of the process. The runtime spreads streams
+    over a handful of hardware queues (four by default) and a queue runs its kernels in order; torch hands out its pooled
+    streams round robin, so a fresh `torch.cuda.Stream()` per encode lands on the queue of the stream it is meant to run
+    BESIDE every fourth time (measured: every fourth step's codebook phase waited 25 ms for the WELL kernels). The first
+    few streams a process takes get queues of their own, and a kept stream stays there."""
+    key = (str(device), name)
+    st = _KEPT_STREAMS.get(key)
+    if st is None:
+        st = _KEPT_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class HipBackend:
     """The compute side of encode_pass: every method is one call into the C-ABI (HIP kernels / host C) on this process's
     GPU. encode_pass itself holds only what ranks have to agree on - which reads a rank owns, what is summed across ranks
@@ -119,7 +135,7 @@ class HipBackend:
         """WELL draws (well.c:8-46) of this shard: they depend on the seed only, so they are generated on a side stream
         while k-means, the counters and the codebooks (small latency-bound kernels + host work) are being made."""
         main_stream = torch.cuda.current_stream()
-        self._side = torch.cuda.Stream(device=self.device)
+        self._side = kept_stream(self.device, "well")
         draws = K.empty_matrix(n, c)         # allocated on the main stream (the caching allocator pools per stream)
         self._side.wait_stream(main_stream)
         with torch.cuda.stream(self._side):
@@ -137,8 +153,9 @@ class HipBackend:
         # one host thread and one HIP stream per cluster (ctypes releases the GIL in the call)
         from concurrent.futures import ThreadPoolExecutor
         main = torch.cuda.current_stream()
-        streams = [torch.cuda.Stream(device=self.device) for _ in range(k)]
-        for st in streams:
+        # cluster 0 on the caller's stream (idle otherwise), the others on kept streams of their own
+        streams = [main] + [kept_stream(self.device, f"codebook{j}") for j in range(1, k)]
+        for st in streams[1:]:
             st.wait_stream(main)      # the counters are ready when the main stream gets here; NOT a device-wide synchronise:
                                       # that would wait for the WELL draws on the side stream, which are meant to run beside this
 
