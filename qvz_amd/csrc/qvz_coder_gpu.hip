@@ -1604,6 +1604,10 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         segs.push_back({0, q});
         for (uint64_t lo = q; lo < tail_lo; lo += each) segs.push_back({lo, lo + each <= tail_lo ? each : tail_lo - lo});
         segs.push_back({tail_lo, longest - tail_lo});
+        // (Halving the last full segment - and its second half again - so that less of the coder's work is left when the last
+        // model kernel ends was tried: every extra segment costs the model kernel a table save and load per workgroup,
+        // 3 ms at 100M x 150 with one cluster and 8-10 ms with three, more than the shorter tail gives back:
+        // 220.7 -> 221.9 -> 224.3 ms and 349 -> 361 -> 363 ms per step.)
     } else {
         for (uint64_t lo = 0; lo < longest; lo += seg_reads) segs.push_back({lo, lo + seg_reads <= longest ? seg_reads : longest - lo});
     }
