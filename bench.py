@@ -303,7 +303,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("QVZ_BENCH_FORCE_DIST"):   # (the variable: a one-rank RCCL group, to rehearse the N > 1 code path on one GPU)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         group = dist.group.WORLD
 

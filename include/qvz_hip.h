@@ -61,6 +61,10 @@ int qvz_hip_memset(void *d_ptr, int value, size_t bytes, void *stream);
 int qvz_hip_copy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int qvz_hip_copy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int qvz_hip_stream_create(void **stream);
+/* *overlap = 1 if kernels launched on the two streams (NULL = the default stream) run side by side, 0 if the runtime has
+ * put them on one hardware queue (a queue runs its kernels in order): a ~1 ms probe, for streams that are made once and
+ * kept. Both streams are synchronised. */
+int qvz_hip_streams_overlap(void *stream_a, void *stream_b, int *overlap);
 int qvz_hip_stream_destroy(void *stream);
 int qvz_hip_stream_sync(void *stream);
 

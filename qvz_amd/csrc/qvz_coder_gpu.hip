@@ -1647,8 +1647,20 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
             std::lock_guard<std::mutex> lk(mu);
             if (dev >= 0 && dev < 64) {
                 if (!kept[dev][0]) {
-                    TRY(hipStreamCreateWithFlags(&kept[dev][0], hipStreamNonBlocking));
-                    TRY(hipStreamCreateWithFlags(&kept[dev][1], hipStreamNonBlocking));
+                    // ... and the pair is tested for running side by side when it is made (qvz_hip_streams_overlap): a
+                    // partner on the first stream's queue is put aside and another one made, a few times at most
+                    hipStream_t first = nullptr, second = nullptr, aside[8];
+                    int naside = 0, ok = 0;
+                    TRY(hipStreamCreateWithFlags(&first, hipStreamNonBlocking));
+                    while (true) {
+                        TRY(hipStreamCreateWithFlags(&second, hipStreamNonBlocking));
+                        if (qvz_hip_streams_overlap(first, second, &ok) != QVZ_OK || ok || naside == 8) break;
+                        aside[naside++] = second;                // kept alive until the choice is made: destroying it would hand its queue to the next one
+                    }
+                    for (int i = 0; i < naside; ++i) (void)hipStreamDestroy(aside[i]);
+                    if (getenv("QVZ_CODER_DEBUG")) fprintf(stderr, "qvz_hip_encode_planes: model / coder streams made for device %d, %d candidate(s) put aside, side by side: %d\n", dev, naside, ok);
+                    kept[dev][0] = first;
+                    kept[dev][1] = second;
                 }
                 s_model = kept[dev][0];
                 s_coder = kept[dev][1];

@@ -85,16 +85,32 @@ class _Span:
 _KEPT_STREAMS = {}
 
 
-def kept_stream(device, name):
+def kept_stream(device, name, beside=()):
     """A side stream that is made once per (device, role) and kept for the life of the process. The runtime spreads streams
     over a handful of hardware queues (four by default) and a queue runs its kernels in order; torch hands out its pooled
     streams round robin, so a fresh `torch.cuda.Stream()` per encode lands on the queue of the stream it is meant to run
-    BESIDE every fourth time (measured: every fourth step's codebook phase waited 25 ms for the WELL kernels). The first
-    few streams a process takes get queues of their own, and a kept stream stays there."""
+    BESIDE every fourth time (measured: every fourth step's codebook phase waited 25 ms for the WELL kernels) - and which
+    queue a stream gets depends on what the process created before it (with an RCCL group up, the first stream taken
+    shared the default stream's queue: every step's codebook phase waited). So a kept stream is tested, when it is made,
+    for running side by side with the streams in `beside` (qvz_hip_streams_overlap, ~1 ms each); a candidate that does
+    not is dropped for the next one of torch's pool."""
     key = (str(device), name)
     st = _KEPT_STREAMS.get(key)
     if st is None:
-        st = _KEPT_STREAMS[key] = torch.cuda.Stream(device=device)
+        import ctypes
+        from ._lib import check, lib
+        for _ in range(12):
+            st = torch.cuda.Stream(device=device)
+            good = True
+            for other in beside:
+                flag = ctypes.c_int(0)
+                check(lib().qvz_hip_streams_overlap(st.cuda_stream, other.cuda_stream, ctypes.byref(flag)))
+                if not flag.value:
+                    good = False
+                    break
+            if good:
+                break
+        _KEPT_STREAMS[key] = st
     return st
 
 
@@ -135,7 +151,7 @@ class HipBackend:
         """WELL draws (well.c:8-46) of this shard: they depend on the seed only, so they are generated on a side stream
         while k-means, the counters and the codebooks (small latency-bound kernels + host work) are being made."""
         main_stream = torch.cuda.current_stream()
-        self._side = kept_stream(self.device, "well")
+        self._side = kept_stream(self.device, "well", beside=(main_stream,))
         draws = K.empty_matrix(n, c)         # allocated on the main stream (the caching allocator pools per stream)
         self._side.wait_stream(main_stream)
         with torch.cuda.stream(self._side):
@@ -154,7 +170,10 @@ class HipBackend:
         from concurrent.futures import ThreadPoolExecutor
         main = torch.cuda.current_stream()
         # cluster 0 on the caller's stream (idle otherwise), the others on kept streams of their own
-        streams = [main] + [kept_stream(self.device, f"codebook{j}") for j in range(1, k)]
+        streams = [main]
+        for j in range(1, k):
+            beside = tuple(streams) + ((self._side,) if self._side is not None else ())
+            streams.append(kept_stream(self.device, f"codebook{j}", beside=beside))
         for st in streams[1:]:
             st.wait_stream(main)      # the counters are ready when the main stream gets here; NOT a device-wide synchronise:
                                       # that would wait for the WELL draws on the side stream, which are meant to run beside this

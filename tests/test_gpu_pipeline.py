@@ -230,3 +230,28 @@ def test_rccl_group_of_one_rank_changes_nothing():
             assert a["kmeans_iterations"] == b["kmeans_iterations"]
     finally:
         dist.destroy_process_group()
+
+
+def test_kept_streams_run_beside_the_streams_they_are_meant_to():
+    """qvz_hip_streams_overlap: a stream never overlaps itself; the kept WELL / codebook streams of the pipeline were tested
+    against the default stream and each other when they were made (a process's streams share a handful of hardware
+    queues, and a queue runs its kernels in order), and the probe says so again; two encodes give the same stream object."""
+    import ctypes
+    from qvz_amd import pipeline as P
+    from qvz_amd._lib import check, lib
+
+    def overlap(a, b):
+        flag = ctypes.c_int(-1)
+        check(lib().qvz_hip_streams_overlap(a, b, ctypes.byref(flag)))
+        return flag.value
+
+    main = torch.cuda.current_stream()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    assert overlap(main.cuda_stream, main.cuda_stream) == 0
+    well = P.kept_stream(dev, "well", beside=(main,))
+    assert well is P.kept_stream(dev, "well", beside=(main,))
+    cb1 = P.kept_stream(dev, "codebook1", beside=(main, well))
+    cb2 = P.kept_stream(dev, "codebook2", beside=(main, well, cb1))
+    assert overlap(well.cuda_stream, well.cuda_stream) == 0
+    pairs = [(main, well), (main, cb1), (well, cb1), (main, cb2), (well, cb2), (cb1, cb2)]
+    assert all(overlap(a.cuda_stream, b.cuda_stream) == 1 for a, b in pairs)
