@@ -230,12 +230,14 @@ def other_configs_report(args, done_cfg, sym_done, threads):
         r = step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        each = []
         for _ in range(2):
             r = None                                             # the previous step's device outputs (qv plane, coded streams) make room first
             r = step()
+            each.append(round(r["wall"]["total"] * 1e3, 1))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 2
-        out.append(dict(config=cid, workload=cfg["name"], ms_per_step=round(dt * 1e3, 3), value=round(n * c / dt, 1),
+        out.append(dict(config=cid, workload=cfg["name"], ms_per_step=round(dt * 1e3, 3), step_ms=each, value=round(n * c / dt, 1),
                         bits_per_symbol=round(r["total_stream_bytes"] * 8.0 / (n * c), 5), kmeans_iterations=r["kmeans_iterations"],
                         phase_seconds={ph: round(v, 4) for ph, v in r["wall"].items()}))
         del r
