@@ -97,7 +97,7 @@ int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_labels, uin
                               uint64_t ld, uint32_t k, uint64_t *d_acc /*[k][c], +=*/, void *stream);
 /* One iteration's assignment AND sums in a single pass over the symbols: exactly qvz_hip_kmeans_assign followed by
  * qvz_hip_kmeans_accumulate (same labels, counts and sums), which it calls for shapes its one-pass kernel does not take
- * (k outside 2..4, more than 160 columns). This is what the drivers call; symbols must be below 128. */
+ * (k outside 2..8, more than 160 columns). This is what the drivers call; symbols must be below 128. */
 int qvz_hip_kmeans_step(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint32_t k,
                         const uint8_t *d_means /*[k][c]*/, uint8_t *d_labels /*[ld]*/, uint32_t *d_counts /*[k], +=*/,
                         uint64_t *d_acc /*[k][c], +=*/, void *stream);

@@ -506,7 +506,7 @@ extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_
     return QVZ_OK;
 }
 
-// One k-means iteration in ONE pass over the symbols (2 .. 4 clusters, up to 160 columns): assignment, counts and the
+// One k-means iteration in ONE pass over the symbols (2 .. 8 clusters, up to 160 columns): assignment, counts and the
 // per-cluster column sums. The two kernels above read the matrix twice per iteration, and each runs at the HBM rate
 // already (2.8 + 3.3 ms for 15 GB on MI355X), so the only thing left to save is the second read: a workgroup keeps a tile of
 // 256 reads x C columns in LDS (C x 272 bytes), and everything an iteration needs is computed from that copy.
@@ -528,29 +528,30 @@ extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_
 typedef int kms_v4i __attribute__((ext_vector_type(4)));
 
 template <int K>
-__global__ __launch_bounds__(256, 3) void k_kmeans_step(const uint8_t *__restrict__ D, uint64_t n, uint32_t C, uint64_t ld,
+__global__ __launch_bounds__(256, (K <= 4 ? 3 : 2)) void k_kmeans_step(const uint8_t *__restrict__ D, uint64_t n, uint32_t C, uint64_t ld,
                                                      const uint8_t *__restrict__ means, uint8_t *__restrict__ labels,
                                                      uint32_t *__restrict__ counts, unsigned long long *__restrict__ acc,
                                                      uint64_t ntiles) {
     extern __shared__ uint4 kms_smem[];
     const uint32_t CQ = (C + 3) / 4;
+    constexpr int KP = K <= 4 ? 4 : 8;                           // centroid dwords kept per column quad (16-byte reads)
     uint8_t *tile = reinterpret_cast<uint8_t *>(kms_smem);                       // [C][KMS_PITCH]
     uint32_t *dots = reinterpret_cast<uint32_t *>(tile + (size_t)C * KMS_PITCH); // [K][4][64]: read 4q + i of the tile at [i][q]
-    uint32_t *m4 = dots + K * KMS_R;                                             // [CQ][4]: centroid j's bytes of columns 4cq .. 4cq+3
-    uint32_t *blk = m4 + CQ * 4;                                                 // [K][KMS_NT * 16] sums of this workgroup
-    int32_t *csq = reinterpret_cast<int32_t *>(blk + K * KMS_NT * 16);           // [4] sum of m_js^2
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(csq + 4);                       // [4]
-    uint8_t *oh = reinterpret_cast<uint8_t *>(cnt + 4);                          // [K][KMS_R] one-hot labels (invalid reads: none)
+    uint32_t *m4 = dots + K * KMS_R;                                             // [CQ][KP]: centroid j's bytes of columns 4cq .. 4cq+3
+    uint32_t *blk = m4 + CQ * KP;                                                 // [K][KMS_NT * 16] sums of this workgroup
+    int32_t *csq = reinterpret_cast<int32_t *>(blk + K * KMS_NT * 16);           // [8] sum of m_js^2
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(csq + 8);                       // [8]
+    uint8_t *oh = reinterpret_cast<uint8_t *>(cnt + 8);                          // [K][KMS_R] one-hot labels (invalid reads: none)
     uint8_t *labsm = oh + K * KMS_R;                                             // [KMS_R]
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
-    if (tid < 4) { csq[tid] = 0; cnt[tid] = 0; }
+    if (tid < 8) { csq[tid] = 0; cnt[tid] = 0; }
     for (uint32_t i = tid; i < K * KMS_NT * 16; i += 256) blk[i] = 0;
     __syncthreads();
     for (uint32_t cq = tid; cq < CQ; cq += 256) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < KP; ++j) {
             uint32_t w = 0;
             if (j < K)
                 for (uint32_t i = 0; i < 4; ++i) {
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256, 3) void k_kmeans_step(const uint8_t *__restric
                     w |= m << (8 * i);
                     if (m) atomicAdd(&csq[j], (int32_t)(m * m));
                 }
-            m4[cq * 4 + j] = w;
+            m4[cq * KP + j] = w;
         }
     }
 
@@ -578,13 +579,15 @@ __global__ __launch_bounds__(256, 3) void k_kmeans_step(const uint8_t *__restric
 #pragma unroll
     for (int nt = 0; nt < KMS_NT; ++nt) accv[nt] = kms_v4i{0, 0, 0, 0};
     auto flush = [&]() {                                         // the workgroup's sums and counts -> global (all threads)
-        if (lane < 16) {
+        if (lane < (K <= 4 ? 16u : 32u)) {                        // D rows 4 (lane >> 4) + reg = clusters, D columns lane & 15
 #pragma unroll
             for (int nt = 0; nt < KMS_NT; ++nt) {
-                const uint32_t s = 16 * nt + lane;
+                const uint32_t s = 16 * nt + (lane & 15);
 #pragma unroll
-                for (int j = 0; j < K; ++j)
-                    if (s < C && accv[nt][j]) atomicAdd(&blk[j * KMS_NT * 16 + s], (uint32_t)accv[nt][j]);
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t j = 4 * (lane >> 4) + r;
+                    if (j < K && s < C && accv[nt][r]) atomicAdd(&blk[j * KMS_NT * 16 + s], (uint32_t)accv[nt][r]);
+                }
             }
         }
 #pragma unroll
@@ -632,8 +635,12 @@ __global__ __launch_bounds__(256, 3) void k_kmeans_step(const uint8_t *__restric
                 const uint32_t lo23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), hi23 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
                 const uint32_t r[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u), __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),
                                        __builtin_amdgcn_perm(hi23, hi01, 0x05040100u), __builtin_amdgcn_perm(hi23, hi01, 0x07060302u)};
-                const uint4 mm = *reinterpret_cast<const uint4 *>(m4 + cq * 4);   // the same address in every lane
-                const uint32_t mj[4] = {mm.x, mm.y, mm.z, mm.w};
+                const uint4 mm = *reinterpret_cast<const uint4 *>(m4 + cq * KP);  // the same address in every lane
+                uint32_t mj[KP] = {mm.x, mm.y, mm.z, mm.w};
+                if (KP > 4) {
+                    const uint4 m2 = *reinterpret_cast<const uint4 *>(m4 + cq * KP + 4);
+                    mj[KP - 4] = m2.x; mj[KP - 3] = m2.y; mj[KP - 2] = m2.z; mj[KP - 1] = m2.w;
+                }
 #pragma unroll
                 for (int j = 0; j < K; ++j)
 #pragma unroll
@@ -694,7 +701,7 @@ extern "C" int qvz_hip_kmeans_step(const uint8_t *d_sym, uint64_t n, uint32_t c,
     if (rc) return rc;
     if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
     const char *knob = getenv("QVZ_KMEANS_FUSED");               // development knob: "0" keeps the two-pass kernels
-    if (k < 2 || k > 4 || c > 16 * KMS_NT || (knob && atoi(knob) == 0)) {
+    if (k < 2 || k > 8 || c > 16 * KMS_NT || (knob && atoi(knob) == 0)) {
         rc = qvz_hip_kmeans_assign(d_sym, n, c, ld, k, d_means, d_labels, d_counts, stream);
         if (rc) return rc;
         return qvz_hip_kmeans_accumulate(d_sym, d_labels, n, c, ld, k, d_acc, stream);
@@ -704,14 +711,22 @@ extern "C" int qvz_hip_kmeans_step(const uint8_t *d_sym, uint64_t n, uint32_t c,
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t ntiles = (n + KMS_R - 1) / KMS_R;
     const uint32_t cq = (c + 3) / 4;
-    const size_t lds = (size_t)c * KMS_PITCH + ((size_t)k * KMS_R + cq * 4 + (size_t)k * KMS_NT * 16 + 8) * 4 + (size_t)k * KMS_R + KMS_R;
-    const uint64_t want = (uint64_t)cus * 3;
+    const size_t lds = (size_t)c * KMS_PITCH + ((size_t)k * KMS_R + cq * (k <= 4 ? 4 : 8) + (size_t)k * KMS_NT * 16 + 16) * 4 + (size_t)k * KMS_R + KMS_R;
+    const uint64_t want = (uint64_t)cus * (k <= 4 ? 3 : 2);
     dim3 grid((unsigned)(ntiles < want ? ntiles : want));
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(d_acc);
-    if (k == 2) hipLaunchKernelGGL(k_kmeans_step<2>, grid, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts, acc, ntiles);
-    else if (k == 3) hipLaunchKernelGGL(k_kmeans_step<3>, grid, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts, acc, ntiles);
-    else hipLaunchKernelGGL(k_kmeans_step<4>, grid, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts, acc, ntiles);
+#define KMS_LAUNCH(KK) hipLaunchKernelGGL(k_kmeans_step<KK>, grid, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts, acc, ntiles)
+    switch (k) {
+    case 2: KMS_LAUNCH(2); break;
+    case 3: KMS_LAUNCH(3); break;
+    case 4: KMS_LAUNCH(4); break;
+    case 5: KMS_LAUNCH(5); break;
+    case 6: KMS_LAUNCH(6); break;
+    case 7: KMS_LAUNCH(7); break;
+    default: KMS_LAUNCH(8); break;
+    }
+#undef KMS_LAUNCH
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
 }

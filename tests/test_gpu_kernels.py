@@ -124,12 +124,14 @@ def test_kmeans_single_iteration_random_means(K, k):
 
 
 @pytest.mark.parametrize("k,n,c,seed", [(3, 12345, 150, 5), (2, 70001, 100, 6), (4, 4099, 160, 7), (3, 255, 37, 8), (3, 256, 4, 9),
-                                         (2, 17, 1, 10), (3, 1_000_003, 36, 11), (4, 300_000, 151, 12), (3, 5000, 161, 13)])
+                                         (2, 17, 1, 10), (3, 1_000_003, 36, 11), (4, 300_000, 151, 12), (3, 5000, 161, 13),
+                                         (5, 20_000, 150, 14), (7, 9_999, 33, 15), (8, 250_000, 160, 16), (9, 5000, 40, 17)])
 def test_kmeans_one_pass_step_equals_the_two_pass_kernels(K, k, n, c, seed):
     """qvz_hip_kmeans_step (tile in LDS: distances by byte dot products, sums by an i8 MFMA against the one-hot labels)
     == qvz_hip_kmeans_assign + qvz_hip_kmeans_accumulate == numpy, bit for bit: ragged tails (n not a multiple of 16 or 256),
     fewer reads than a tile, more tiles than the persistent grid holds at once (1e6 reads), 151 and 160 columns (partial and
-    full last column tile), 161 columns (the fallback), column counts that are not multiples of 4."""
+    full last column tile), 161 columns and 9 clusters (the two-pass fallback), 5 .. 8 clusters (two 16-byte centroid reads per
+    column quad, sums in the second row group of the MFMA result), column counts that are not multiples of 4."""
     rows = O.qgen1_rows(seed, n, c)
     rng = np.random.default_rng(seed)
     cent = np.sort(rng.choice(n, size=k, replace=False))

@@ -1,12 +1,21 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout -k 10 400 python3 -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "kmeans" 2>&1 | tail -15 || exit 1
-run() {
-  local label=$1 cfg=$2; shift 2
-  echo "== $label"
-  env "$@" timeout -k 10 300 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-u 2> /tmp/err.txt | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], {k:round(v*1e3,1) for k,v in d['phase_seconds'].items()}, d['kmeans_iterations'], {k:round(v,2) for k,v in d['gpu_kernel_ms_per_step'].items() if 'kmeans' in k})"; local rc=$?
-  [ $rc -ne 0 ] && tail -3 /tmp/err.txt
-  return $rc
-}
-run "cfg3 fused" 3 X=1 || exit 1
-run "cfg3 two-pass" 3 QVZ_KMEANS_FUSED=0 || exit 1
+timeout -k 10 400 python3 -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "kmeans" 2>&1 | tail -6 || exit 1
+timeout -k 10 200 python3 - <<'PY'
+import time, torch, numpy as np
+from qvz_amd import kernels as K
+n, c = 100_000_000, 150
+sym = K.qgen1(3, n, c)
+for k in (3, 5, 8):
+    idx = torch.randint(0, n, (k,), device="cuda")
+    means = sym[:, idx].t().contiguous()
+    labels = torch.zeros(sym.shape[1], dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(k, dtype=torch.int32, device="cuda"); acc = torch.zeros((k, c), dtype=torch.int64, device="cuda")
+    for fused in ("1", "0"):
+        import os; os.environ["QVZ_KMEANS_FUSED"] = fused
+        K.kmeans_step(sym, n, means, labels, counts, acc); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3): K.kmeans_step(sym, n, means, labels, counts, acc)
+        torch.cuda.synchronize()
+        print(f"k={k} fused={fused}: {(time.perf_counter()-t)/3*1e3:.2f} ms per iteration")
+PY
