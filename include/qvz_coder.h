@@ -95,7 +95,7 @@ int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint6
  * allocated for the call. With room for two segments the model kernel of one runs beside the coder kernel of the other. Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel
  * with one lane per (stream, column) and the tables in HBM.
  * d_labels must be readable up to n rounded up to a multiple of 4. The emitter checks its room once per 16 symbols:
- * a stream that comes within 128 bytes of cap_per_shard is reported as overflowed (QVZ_E_NOMEM). */
+ * a stream that comes within 256 bytes of cap_per_shard is reported as overflowed (QVZ_E_NOMEM). */
 int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                           uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                           uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes,

@@ -1238,10 +1238,10 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     // that have four complete words move them out as one 16-byte store (about five lanes per block at 1.4 bits per
     // symbol). A block adds at most four complete words, so at most seven are ever waiting.
     // A pair with a long symbol in some lane goes through a wave-uniform branch to the code with exact bounds (the
-    // ring is emptied first). Room is checked once per block, which makes a stream that comes within 128 bytes of
+    // ring is emptied first). Room is checked every fourth block, which makes a stream that comes within 256 bytes of
     // cap_per_shard count as overflowed. Lanes past the last stream produce zero bits and never store.
     uint8_t *const base = live ? out + (uint64_t)g * cap : out + (uint64_t)shards * cap - 4;
-    uint8_t *const end = live ? base + cap : base + 4 + 128;
+    uint8_t *const end = live ? base + cap : base + 4 + 256;
     uint8_t *rb = base;                                          // where word 0 of the ring numbering lies
     uint32_t wi = 0, fi = 0;                                     // words completed / moved out since rb (fi a multiple of 4)
     uint32_t nbits = 0;
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         rb = base + c.pos;
     };
     auto room = [&]() {                                          // out of room: keep the stores inside the stream's area
-        const bool tight = rb + (uint64_t)wi * 4 + 128 > end;
+        const bool tight = rb + (uint64_t)wi * 4 + 256 > end;    // (looked at every fourth block: 4 x 8 symbols x 16 bits = 64 bytes + the ring)
         ovf = ovf || tight;
         rb = tight ? base : rb;
         wi = tight ? 0u : wi;
@@ -1289,22 +1289,34 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
         uint32_t e[CR_B];
 #pragma unroll
         for (int jx = 0; jx < CR_B; ++jx) e[jx] = ebits[slot][jx][lane];
-        room();
-#pragma unroll
-        for (int jx = 0; jx < CR_B; jx += 2) {
-            if (__ballot((e[jx] | e[jx + 1]) & CR_RARE)) {       // wave-uniform, rare
-                drain();
-                piecewise(e[jx], words[wslot][jx][lane]);
-                piecewise(e[jx + 1], words[wslot][jx + 1][lane]);
-                room();
-                continue;
-            }
-            acc = (acc << (e[jx] >> 16)) | (uint64_t)(e[jx] & 0xFFFF);
-            acc = (acc << (e[jx + 1] >> 16)) | (uint64_t)(e[jx + 1] & 0xFFFF);
-            nbits += (e[jx] >> 16) + (e[jx + 1] >> 16);          // < 32 + 32
+        if ((b & 3) == 2) room();                                // (b starts at 2; the exact-bounds path below looks again itself)
+        auto pair = [&](uint32_t e0, uint32_t e1) {
+            // the pair first, in 32 bits (at most 16 + 16), then one 64-bit shift for both
+            const uint32_t n2 = e1 >> 16, pn = (e0 >> 16) + n2;
+            const uint32_t pv = ((e0 & 0xFFFF) << n2) | (e1 & 0xFFFF);
+            acc = (acc << pn) | (uint64_t)pv;
+            nbits += pn;                                         // < 32 + 32
             myring[wi & 15] = __builtin_bswap32((uint32_t)(acc >> ((nbits - 32) & 63)));
             wi += nbits >> 5;                                    // keep the word only if it was complete
             nbits &= 31;
+        };
+        // one wave-uniform test per block (a scalar branch on a vector compare stalls a lone wave for tens of cycles; per
+        // pair it was four of them): a block with a long symbol in some lane - about one in 2^13 - goes pair by pair
+        if (__ballot((e[0] | e[1] | e[2] | e[3] | e[4] | e[5] | e[6] | e[7]) & CR_RARE)) {
+#pragma unroll
+            for (int jx = 0; jx < CR_B; jx += 2) {
+                if (__ballot((e[jx] | e[jx + 1]) & CR_RARE)) {
+                    drain();
+                    piecewise(e[jx], words[wslot][jx][lane]);
+                    piecewise(e[jx + 1], words[wslot][jx + 1][lane]);
+                    room();
+                } else {
+                    pair(e[jx], e[jx + 1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jx = 0; jx < CR_B; jx += 2) pair(e[jx], e[jx + 1]);
         }
         if (__ballot(wi - fi >= 4)) {                            // wave-uniform; then only the lanes with four words store
             if (wi - fi >= 4) {

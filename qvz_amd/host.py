@@ -247,7 +247,7 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     ld = qi.shape[1]
     if cap_per_shard is None:
         per = (n + shards - 1) // shards + 4
-        cap_per_shard = (per * columns * 3) // 4 + 512          # 6 bits/symbol + the 128-byte margin the emitter wants
+        cap_per_shard = (per * columns * 3) // 4 + 512          # 6 bits/symbol + the 256-byte margin the emitter wants
     cap_per_shard = (cap_per_shard + 3) & ~3
     per_read = planes_bytes_per_read(shards, columns, k)
     longest = ((n + shards - 1) // shards + 7) & ~3

@@ -10,7 +10,7 @@ run() {
   local label=$1 cfg=$2; shift 2
   echo "== $label"
   env "$@" QVZ_CODER_DEBUG=1 timeout -k 10 300 python3 bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-u 2> /tmp/err.txt | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], {k:round(v*1e3,1) for k,v in d['phase_seconds'].items() if 'coder' in k})"; local rc=$?
-  grep -E "k_code_records cycles|k_model_ranks cycles" /tmp/err.txt | tail -2
+  grep -E "k_code_records cycles|k_model_ranks cycles|segment|streams made" /tmp/err.txt | tail -12
   [ $rc -ne 0 ] && tail -3 /tmp/err.txt
   return $rc
 }
