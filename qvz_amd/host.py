@@ -228,6 +228,30 @@ def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_pe
     return sizes, streams, out
 
 
+_KEPT_WORK = {}
+
+
+def kept_workspace(device, nbytes):
+    """The record workspace of the GPU coder (~100 GB at the BASELINE shapes), allocated once per device and kept. Taken
+    afresh from torch's caching allocator for every encode it was usually the cached block again - but the allocator splits
+    large free blocks for smaller requests (the 15 GB draw matrix of the next encode), and an encode that then found no
+    block of 100 GB cost a 100 ms allocation, sometimes after the cache had been emptied to make room (seen as one step in
+    twenty taking 315 instead of 216 ms). release_workspace() gives it back."""
+    import torch
+    key = str(device)
+    w = _KEPT_WORK.get(key)
+    if w is None or w.numel() < nbytes:
+        _KEPT_WORK.pop(key, None)
+        w = None
+        w = _KEPT_WORK[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return w
+
+
+def release_workspace(device=None):
+    for key in [k for k in _KEPT_WORK if device is None or k == str(device)]:
+        del _KEPT_WORK[key]
+
+
 def planes_bytes_per_read(shards, columns, k):
     """Record-workspace bytes that one read of every stream takes in qvz_hip_encode_planes: 16 bytes per record, streams
     padded to a multiple of 64, records per read (columns, behind 8 reserved positions - the cluster id and seven zero
@@ -257,7 +281,7 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
         import os
         work_bytes = min(per_read * longest, int(os.environ.get("QVZ_WORK_GIB", "96")) << 30)
     work_bytes = max(work_bytes, per_read * 4)
-    work = torch.empty(work_bytes, dtype=torch.uint8, device=qi.device)
+    work = kept_workspace(qi.device, work_bytes)
     out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=qi.device)
     sizes = (C.c_uint64 * shards)()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

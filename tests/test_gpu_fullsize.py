@@ -30,6 +30,7 @@ def test_full_size_encode_round_trip_and_oracle_parity(name):
     from qvz_amd import host, kernels as K, pipeline as P
     cfg = CONFIGS[name]
     import gc
+    host.release_workspace()                 # the coder's kept record workspace of an earlier test
     gc.collect()
     torch.cuda.empty_cache()                 # blocks an earlier test left in torch's caching allocator count as used otherwise
     free, _ = torch.cuda.mem_get_info()
@@ -83,5 +84,6 @@ def test_full_size_encode_round_trip_and_oracle_parity(name):
         stream = coded[g * cap: g * cap + sizes[g]].cpu().numpy().tobytes()
         assert stream == enc["stream"], f"shard {g}: GPU-coded stream differs from the oracle's"
     del r, sym, coded, cnt, labels
+    host.release_workspace()
     gc.collect()
     torch.cuda.empty_cache()
