@@ -346,6 +346,11 @@ def main():
     for _ in range(args.warmup):
         step()
     timer = P.Timer(True)
+    # Python's cyclic garbage collector stays out of the timed region: a full collection (deterministically around the 33rd
+    # encode of a process, 30 - 50 ms with torch and numpy loaded) landed in whatever phase was allocating Python objects
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     results = []
@@ -354,8 +359,14 @@ def main():
             for key in ("coded", "qv", "labels"):
                 results[-1].pop(key, None)
         results.append(step(timer))
+        if os.environ.get("QVZ_BENCH_MEM"):                  # development: HBM head-room after every step
+            free_b, total_b = torch.cuda.mem_get_info()
+            print(f"step {len(results)}: torch allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved "
+                  f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB (peak {torch.cuda.max_memory_reserved() / 2**30:.1f}), device free "
+                  f"{free_b / 2**30:.1f} of {total_b / 2**30:.1f} GiB", file=sys.stderr, flush=True)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

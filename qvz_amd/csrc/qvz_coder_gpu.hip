@@ -1445,6 +1445,9 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     }
     if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
     if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
+    auto wall_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_entry = wall_ms();
+    double t_first_launch = 0.0, t_enqueued = 0.0, t_synced = 0.0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);   // record positions per read (k_model_ranks)
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
@@ -1700,6 +1703,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     }
     if (getenv("QVZ_CODER_LDS_PAD")) cr_pad = (size_t)atoi(getenv("QVZ_CODER_LDS_PAD"));   // development knob
     if (cr_pad) TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_code_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
+    t_first_launch = wall_ms();
     for (uint32_t i = 0; i < nseg; ++i) {
         seg_lo = segs[i].first;
         const uint32_t seg_len = (uint32_t)segs[i].second;       // both kernels lay the segment's records out for this many reads
@@ -1737,10 +1741,32 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         TRY(hipEventRecord(e[3], s_coder));
     }
     TRY(hipGetLastError());
+    t_enqueued = wall_ms();
     if (overlap) TRY(hipStreamWaitEvent(st, evs[(size_t)(nseg - 1) * 4 + 3], 0));   // the last coder kernel ends after everything else
     TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TRY(hipStreamSynchronize(st));
+    // The wait for a whole encode (0.15 - 0.25 s) is done by polling an event, not by hipStreamSynchronize: the runtime
+    // blocks long waits on an interrupt, and on the (virtualised) boxes this was measured on a call now and then came back
+    // 0.1 s - once 2.1 s - after its last kernel had ended (kernel times and the time line as always, the phase that much
+    // longer). An event query is a load of the completion signal.
+    {
+        hipEvent_t ev_done = nullptr;
+        TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        hipError_t qe = hipEventRecord(ev_done, st);
+        const char *wk = getenv("QVZ_CODER_WAIT");               // development knob: "block" = hipStreamSynchronize as before
+        if (wk && strcmp(wk, "block") == 0 && qe == hipSuccess) qe = hipStreamSynchronize(st);
+        while (qe == hipSuccess) {
+            qe = hipEventQuery(ev_done);
+            if (qe != hipErrorNotReady) break;
+            struct timespec nap = {0, 20000};                     // 20 us
+            nanosleep(&nap, nullptr);
+            qe = hipSuccess;
+        }
+        (void)hipEventDestroy(ev_done);
+        if (qe != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "waiting for the coder kernels -> %s", hipGetErrorString(qe)); goto done; }
+    }
+    TRY(hipStreamSynchronize(st));                               // (returns at once: everything on st has completed)
+    t_synced = wall_ms();
     for (uint32_t i = 0; i < nseg; ++i) {                        // busy time of either kernel family (they overlap in time)
         float ta = 0.f, tb = 0.f;
         TRY(hipEventElapsedTime(&ta, evs[(size_t)i * 4], evs[(size_t)i * 4 + 1]));
@@ -1779,6 +1805,9 @@ done:
     if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); if (own_streams) (void)hipStreamDestroy(s_coder); }
     (void)hipFree(d_cs); (void)hipFree(own_work); (void)hipFree(d_slices); (void)hipFree(d_colbase); (void)hipFree(d_coff); (void)hipFree(d_save);
     (void)hipFree(d_clist); (void)hipFree(d_cstart); (void)hipFree(d_segpos); (void)hipFree(d_bounds);
+    if (getenv("QVZ_CODER_DEBUG") && t_synced > 0.0)
+        fprintf(stderr, "  host side of the call: set-up %.2f ms, launches enqueued in %.2f ms, waited %.2f ms, tear-down %.2f ms\n",
+                t_first_launch - t_entry, t_enqueued - t_first_launch, t_synced - t_enqueued, wall_ms() - t_synced);
     free(h_arena); free(h_off); free(h_first);
     return rc;
 }
