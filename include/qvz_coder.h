@@ -127,6 +127,9 @@ int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const
 /* GPU time of the last qvz_hip_encode_planes call, split into its model kernels and its coder kernels (HIP events on
  * the call's stream, summed over the segments). Either pointer may be NULL. */
 void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);
+/* qvz_hip_encode_planes keeps its internal device buffers (table images, per-stream table saves, read lists: a few GB at
+ * 100M x 150) and its two streams per device between calls; this gives the buffers of the current device back. */
+void qvz_hip_encode_planes_release(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Strict single-stream mode with the model on the GPU. The reference's file has ONE serial arithmetic stream

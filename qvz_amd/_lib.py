@@ -25,6 +25,7 @@ SIGNATURES = {
                                         C.c_void_p]),
     "qvz_hip_kmeans_accumulate": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u64p,
                                             C.c_void_p]),
+    "qvz_hip_encode_planes_release": (None, []),
     "qvz_hip_streams_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "qvz_hip_kmeans_step": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u8p, u8p, u32p, u64p, C.c_void_p]),
     "qvz_hip_kmeans_update": (C.c_int, [u64p, u32p, C.c_uint32, C.c_uint32, u8p, f64p, C.c_void_p, C.c_void_p]),

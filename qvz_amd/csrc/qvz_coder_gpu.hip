@@ -1039,6 +1039,11 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
 // One raw s_barrier per block of CR_B symbols (no fence, nobody but the loader waits on vmcnt): before barrier b the
 // loader has parked records b; after it the interval wave codes block b, the bits wave block b-1, the bytes wave
 // block b-2. (Measured with a single emitter wave: emitter busy 1440 cycles per 8 symbols, loader 1190, chain 1070.)
+__global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see the segment loop of qvz_hip_encode_planes
+    const uint64_t t0 = wall_clock64();                           // 100 MHz
+    while (wall_clock64() - t0 < (uint64_t)us * 100) __builtin_amdgcn_s_sleep(8);
+}
+
 #define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps 31.5 KB of LDS so that it fits beside the model kernel's workgroups: 3 x 42.5 KB + 32.5 KB is exactly a CU's 160 KB at 100M x 150, -f 0.5)
 static_assert(CR_B == 8, "the record layout (rec_index) has 8 records per lane and block");
 #define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
@@ -1418,6 +1423,48 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
                                             uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                             const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
                                             void *d_work, uint64_t work_bytes, void *stream);
+// The buffers a call needs beside the caller's (table images, the per-stream table saves between segments - gigabytes -,
+// read lists, coder states) are carved out of ONE allocation per device that is kept between calls: a dozen hipMalloc /
+// hipFree pairs per encode were, once in several hundred encodes, 2.6 - 4.8 SECONDS of it (measured: the whole stall inside
+// the set-up part of the call, kernels and everything else as always). A call that needs more than the area holds takes the
+// excess from hipMalloc and leaves a larger area behind. qvz_hip_encode_planes_release() gives the memory back.
+struct KeptArea {
+    std::mutex mu;
+    char *base = nullptr;
+    size_t cap = 0, used = 0, want = 0;
+    std::vector<void *> extra;
+    void begin() { used = 0; want = 0; }
+    hipError_t get(void **p, size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        want += bytes;
+        if (base && used + bytes <= cap) { *p = base + used; used += bytes; return hipSuccess; }
+        const hipError_t e = hipMalloc(p, bytes ? bytes : 256);
+        if (e == hipSuccess) extra.push_back(*p);
+        return e;
+    }
+    void finish() {
+        const bool grow = !extra.empty();
+        for (void *p : extra) (void)hipFree(p);
+        extra.clear();
+        if (grow) {
+            if (base) (void)hipFree(base);
+            base = nullptr; cap = 0;
+            const size_t room = want + want / 8;
+            if (hipMalloc((void **)&base, room) == hipSuccess) cap = room; else base = nullptr;
+        }
+        used = want = 0;
+    }
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = used = want = 0; }
+};
+static KeptArea g_coder_area[64];
+
+extern "C" void qvz_hip_encode_planes_release(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lk(g_coder_area[dev].mu);
+    g_coder_area[dev].release();
+}
+
 static thread_local double g_planes_ms[2] = {0.0, 0.0};   // model kernels, coder kernels of the calling thread's last qvz_hip_encode_planes call
 extern "C" void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms) {
     if (model_ms) *model_ms = g_planes_ms[0];
@@ -1447,7 +1494,14 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
     auto wall_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_entry = wall_ms();
+    int area_dev = 0;
+    if (hipGetDevice(&area_dev) != hipSuccess || area_dev < 0 || area_dev >= 64) area_dev = 0;
+    KeptArea &area = g_coder_area[area_dev];
+    std::unique_lock<std::mutex> area_lock(area.mu);             // one call per device at a time uses the kept buffers
+    area.begin();
     double t_first_launch = 0.0, t_enqueued = 0.0, t_synced = 0.0;
+    uint32_t spin_us = 0;
+    bool odd_call = false;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);   // record positions per read (k_model_ranks)
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
@@ -1584,26 +1638,26 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     if (getenv("QVZ_CODER_DEBUG"))
         fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu\n",
                 shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size());
-    TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
-    TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
-    TRY(hipMalloc(&d_status, sizeof(int32_t)));
-    TRY(hipMalloc(&d_cs, shards * sizeof(CoderState)));
+    TRY(area.get((void **)&d_first, (shards + 1) * sizeof(uint64_t)));
+    TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
+    TRY(area.get((void **)&d_status, sizeof(int32_t)));
+    TRY(area.get((void **)&d_cs, shards * sizeof(CoderState)));
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     if (rk_waves) {
-        TRY(hipMalloc(&d_slices, h_slices.size() * 4));
-        TRY(hipMalloc(&d_colbase, h_colbase.size() * 4));
-        TRY(hipMalloc(&d_coff, h_coff.size() * 4));
-        if (seg_reads < longest) TRY(hipMalloc(&d_save, h_slices.size() * 4 * (size_t)shards));   // table state between segments
+        TRY(area.get((void **)&d_slices, h_slices.size() * 4));
+        TRY(area.get((void **)&d_colbase, h_colbase.size() * 4));
+        TRY(area.get((void **)&d_coff, h_coff.size() * 4));
+        if (seg_reads < longest) TRY(area.get((void **)&d_save, h_slices.size() * 4 * (size_t)shards));   // table state between segments
         TRY(hipMemcpyAsync(d_slices, h_slices.data(), h_slices.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_colbase, h_colbase.data(), h_colbase.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_coff, h_coff.data(), h_coff.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     } else {                                                     // lane-per-column kernel with per-stream arenas in HBM
-        TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
-        TRY(hipMalloc(&d_off, offn * 4));
-        TRY(hipMalloc(&d_arena, ((size_t)words * shards + 8) * 4));   // + slack: a header read covers 32 bytes
+        TRY(area.get((void **)&d_tmpl, (size_t)words * 4));
+        TRY(area.get((void **)&d_off, offn * 4));
+        TRY(area.get((void **)&d_arena, ((size_t)words * shards + 8) * 4));   // + slack: a header read covers 32 bytes
         TRY(hipMemcpyAsync(d_tmpl, h_arena, (size_t)words * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
@@ -1632,10 +1686,10 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         for (uint32_t i = 0; i < nseg; ++i) h_bounds[i] = (uint32_t)segs[i].first;
         h_bounds[nseg] = 0xFFFFFFFFu;
         const size_t SK = (size_t)shards * clusters;
-        TRY(hipMalloc(&d_clist, (size_t)n * sizeof(uint32_t)));
-        TRY(hipMalloc(&d_cstart, SK * sizeof(uint64_t)));
-        TRY(hipMalloc(&d_segpos, SK * (nseg + 1) * sizeof(uint32_t)));
-        TRY(hipMalloc(&d_bounds, (nseg + 1) * sizeof(uint32_t)));
+        TRY(area.get((void **)&d_clist, (size_t)n * sizeof(uint32_t)));
+        TRY(area.get((void **)&d_cstart, SK * sizeof(uint64_t)));
+        TRY(area.get((void **)&d_segpos, SK * (nseg + 1) * sizeof(uint32_t)));
+        TRY(area.get((void **)&d_bounds, (nseg + 1) * sizeof(uint32_t)));
         TRY(hipMemcpyAsync(d_bounds, h_bounds.data(), (nseg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_cluster_lists, dim3(shards), dim3(256), 0, st, d_labels, (const uint64_t *)d_first, clusters, d_clist, d_cstart, d_status);
         hipLaunchKernelGGL(k_cluster_segpos, dim3((unsigned)((SK * (nseg + 1) + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_clist,
@@ -1704,6 +1758,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     if (getenv("QVZ_CODER_LDS_PAD")) cr_pad = (size_t)atoi(getenv("QVZ_CODER_LDS_PAD"));   // development knob
     if (cr_pad) TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_code_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
     t_first_launch = wall_ms();
+    spin_us = getenv("QVZ_CODER_HEADSTART_US") ? (uint32_t)atoi(getenv("QVZ_CODER_HEADSTART_US")) : 40u;   // development knob
     for (uint32_t i = 0; i < nseg; ++i) {
         seg_lo = segs[i].first;
         const uint32_t seg_len = (uint32_t)segs[i].second;       // both kernels lay the segment's records out for this many reads
@@ -1711,6 +1766,13 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         const int is_first = i == 0, is_last = i + 1 == nseg;
         Record *buf = (Record *)((char *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * per_read : 0));
         hipEvent_t *e = &evs[(size_t)i * 4];
+        // Head start for the coder kernel of the segment before: it is released by an event of the model kernel that has
+        // just ended, across queues, while the next model kernel follows that one in its own queue at once - and a model
+        // kernel that has filled the CUs first leaves a coder workgroup (32 KB of LDS) no room wherever three model
+        // workgroups take a CU's LDS between them (three clusters at 100M x 150: the coder kernel of a segment then took
+        // 44 ms instead of 25, ending with the model kernel beside it). A one-wave kernel that spins for a few tens of
+        // microseconds in front of the model kernel lets the 128 coder workgroups onto the idle CUs first.
+        if (overlap && i >= 1 && spin_us) hipLaunchKernelGGL(k_coder_spin_us, dim3(1), dim3(64), 0, s_model, spin_us);
         if (overlap && i >= 2) TRY(hipStreamWaitEvent(s_model, evs[(size_t)(i - 2) * 4 + 3], 0));   // the coder has drained this buffer
         TRY(hipEventRecord(e[0], s_model));
         if (rk_waves) {
@@ -1767,12 +1829,29 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     }
     TRY(hipStreamSynchronize(st));                               // (returns at once: everything on st has completed)
     t_synced = wall_ms();
+    {
+        // A call that took much longer than its kernels (seen a few times in a thousand: 0.1 - 3.9 s, kernel times as always)
+        // prints its time line whether asked to or not, so that the gap can be placed
+        float span = 0.f, busy_m = 0.f, busy_c = 0.f;
+        TRY(hipEventElapsedTime(&span, evs[0], evs[(size_t)(nseg - 1) * 4 + 3]));
+        for (uint32_t i = 0; i < nseg; ++i) {
+            float ta = 0.f, tb = 0.f;
+            TRY(hipEventElapsedTime(&ta, evs[(size_t)i * 4], evs[(size_t)i * 4 + 1]));
+            TRY(hipEventElapsedTime(&tb, evs[(size_t)i * 4 + 2], evs[(size_t)i * 4 + 3]));
+            busy_m += ta; busy_c += tb;
+        }
+        const double host_span = t_synced - t_first_launch;
+        odd_call = host_span > 1.25 * (busy_m + busy_c) + 30.0;
+        if (odd_call)
+            fprintf(stderr, "qvz_hip_encode_planes: this call took %.1f ms on the host (%.1f ms from the first kernel's start to the last one's end) for %.1f + %.1f ms of model and coder kernels; its time line:\n",
+                    host_span, span, busy_m, busy_c);
+    }
     for (uint32_t i = 0; i < nseg; ++i) {                        // busy time of either kernel family (they overlap in time)
         float ta = 0.f, tb = 0.f;
         TRY(hipEventElapsedTime(&ta, evs[(size_t)i * 4], evs[(size_t)i * 4 + 1]));
         TRY(hipEventElapsedTime(&tb, evs[(size_t)i * 4 + 2], evs[(size_t)i * 4 + 3]));
         g_planes_ms[0] += ta; g_planes_ms[1] += tb;
-        if (getenv("QVZ_CODER_DEBUG")) {                         // the segment's kernels on the time line of the call
+        if (odd_call || getenv("QVZ_CODER_DEBUG")) {             // the segment's kernels on the time line of the call
             float m0 = 0.f, c0 = 0.f;
             TRY(hipEventElapsedTime(&m0, evs[0], evs[(size_t)i * 4]));
             TRY(hipEventElapsedTime(&c0, evs[0], evs[(size_t)i * 4 + 2]));
@@ -1798,14 +1877,14 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     else if (status & 2) rc = qvz_set_error(QVZ_E_NOMEM, "a shard's stream exceeded cap_per_shard=%llu bytes", (unsigned long long)cap_per_shard);
 done:
 #undef TRY
-    (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
     for (size_t i = 0; i < evs.size(); ++i) if (evs[i]) (void)hipEventDestroy(evs[i]);
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (s_model && s_model != st) { (void)hipStreamSynchronize(s_model); if (own_streams) (void)hipStreamDestroy(s_model); }
     if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); if (own_streams) (void)hipStreamDestroy(s_coder); }
-    (void)hipFree(d_cs); (void)hipFree(own_work); (void)hipFree(d_slices); (void)hipFree(d_colbase); (void)hipFree(d_coff); (void)hipFree(d_save);
-    (void)hipFree(d_clist); (void)hipFree(d_cstart); (void)hipFree(d_segpos); (void)hipFree(d_bounds);
-    if (getenv("QVZ_CODER_DEBUG") && t_synced > 0.0)
+    (void)hipFree(own_work);
+    area.finish();                                               // (the buffers of this call stay allocated for the next one)
+    area_lock.unlock();
+    if (t_synced > 0.0 && (getenv("QVZ_CODER_DEBUG") || wall_ms() - t_entry > 1.25 * (g_planes_ms[0] + g_planes_ms[1]) + 30.0))
         fprintf(stderr, "  host side of the call: set-up %.2f ms, launches enqueued in %.2f ms, waited %.2f ms, tear-down %.2f ms\n",
                 t_first_launch - t_entry, t_enqueued - t_first_launch, t_synced - t_enqueued, wall_ms() - t_synced);
     free(h_arena); free(h_off); free(h_first);

@@ -248,8 +248,10 @@ def kept_workspace(device, nbytes):
 
 
 def release_workspace(device=None):
+    """Gives back the kept record workspace (and the coder's kept internal buffers of the current device)."""
     for key in [k for k in _KEPT_WORK if device is None or k == str(device)]:
         del _KEPT_WORK[key]
+    lib().qvz_hip_encode_planes_release()
 
 
 def planes_bytes_per_read(shards, columns, k):
