@@ -1807,10 +1807,9 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     if (overlap) TRY(hipStreamWaitEvent(st, evs[(size_t)(nseg - 1) * 4 + 3], 0));   // the last coder kernel ends after everything else
     TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    // The wait for a whole encode (0.15 - 0.25 s) is done by polling an event, not by hipStreamSynchronize: the runtime
-    // blocks long waits on an interrupt, and on the (virtualised) boxes this was measured on a call now and then came back
-    // 0.1 s - once 2.1 s - after its last kernel had ended (kernel times and the time line as always, the phase that much
-    // longer). An event query is a load of the completion signal.
+    // The wait for a whole encode (0.15 - 0.25 s) polls an event (a load of the completion signal every 20 us) instead of
+    // blocking in hipStreamSynchronize; it made no measurable difference (the seconds-long calls that prompted it turned out
+    // to sit in hipMalloc, see KeptArea) and is kept because it does not depend on interrupt delivery.
     {
         hipEvent_t ev_done = nullptr;
         TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
