@@ -1050,7 +1050,7 @@ static_assert(CR_B == 8, "the record layout (rec_index) has 8 records per lane a
 __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
-                                                      uint64_t *__restrict__ sizes, int32_t *__restrict__ status) {
+                                                      uint64_t *__restrict__ sizes, int32_t *__restrict__ status, int high_prio) {
     __shared__ Record ring[2][CR_B][64];
     __shared__ uint32_t words[3][CR_B][64];                      // three slots: the bytes wave re-reads a rare symbol's word two blocks later
     __shared__ uint32_t ebits[2][CR_B][64];                      // value (16 bits) | bit count << 16, or CR_RARE | pending run
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read (rec_index)
-    asm volatile("s_setprio 3");                                 // all four waves of the latency chain issue ahead of the throughput kernels sharing the CU
+    if (high_prio) asm volatile("s_setprio 3");                  // all four waves of the latency chain issue ahead of the throughput kernels sharing the CU
     uint64_t T = 0;
     if (live) {
         const uint64_t rend = first[g + 1], a = first[g] + seg_lo, b = a + seg_reads;
@@ -1502,6 +1502,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     double t_first_launch = 0.0, t_enqueued = 0.0, t_synced = 0.0;
     uint32_t spin_us = 0;
     bool odd_call = false;
+    const int coder_prio = getenv("QVZ_CODER_PRIO") ? atoi(getenv("QVZ_CODER_PRIO")) : 1;   // development knob: 0 = the coder waves issue at normal priority
     hipStream_t st = (hipStream_t)stream;
     const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);   // record positions per read (k_model_ranks)
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
@@ -1799,7 +1800,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
         hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, (const Record *)buf, Cx, d_first, shards,
-                           seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status);
+                           seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio);
         TRY(hipEventRecord(e[3], s_coder));
     }
     TRY(hipGetLastError());
