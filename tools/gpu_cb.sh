@@ -1,4 +1,5 @@
 #!/bin/bash
+# codebook phase split (QVZ_CB_DEBUG) of the three BASELINE configurations
 out=gpurun_out/$1
 mkdir -p $out
 export TMPDIR=/tmp

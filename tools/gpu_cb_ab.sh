@@ -1,4 +1,5 @@
 #!/bin/bash
+# codebook hand-over variants (QVZ_CB_SYNC / QVZ_CB_STAGE) side by side
 out=gpurun_out/$1
 mkdir -p $out
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# coder waves at raised (default) against normal issue priority (QVZ_CODER_PRIO)
 export TMPDIR=/tmp
 run() {
   echo "== config $1: $2"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# head start of the coder kernel over the next model kernel (QVZ_CODER_HEADSTART_US): 0 / 40 / 100 us
 export TMPDIR=/tmp
 run() {
   echo "== config $1: $2"

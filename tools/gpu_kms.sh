@@ -1,4 +1,5 @@
 #!/bin/bash
+# k-means parity tests, then the one-pass kernel against the two-pass kernels at 100M x 150 for k = 3, 5, 8
 export TMPDIR=/tmp
 timeout -k 10 400 python3 -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "kmeans" 2>&1 | tail -6 || exit 1
 timeout -k 10 200 python3 - <<'PY'

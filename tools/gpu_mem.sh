@@ -1,4 +1,5 @@
 #!/bin/bash
+# HBM head-room after every step (QVZ_BENCH_MEM=1)
 export TMPDIR=/tmp
 for cfg in 3 2; do
 echo "== config $cfg"

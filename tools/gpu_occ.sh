@@ -1,4 +1,5 @@
 #!/bin/bash
+# model kernel time against workgroups per CU (QVZ_MODEL_LDS_PAD)
 export TMPDIR=/tmp
 run() {
   local label=$1 cfg=$2; shift 2

@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU_MAX_HW_QUEUES = 4 / 8 / 16 for the three configurations
 export TMPDIR=/tmp
 run() {
   echo "== config $1: $2"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# quantizer variants with three clusters (QVZ_QUANTIZE_T, QVZ_QUANTIZE_RW)
 export TMPDIR=/tmp
 timeout -k 10 300 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py -m gpu -q -k "quant or shard or stream" 2>&1 | tail -2
 for v in "QVZ_QUANTIZE_T=512" "" "QVZ_QUANTIZE_RW=2"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# WELL generator pass size (QVZ_WELL_PASS_LOG2)
 export TMPDIR=/tmp
 for p in 22 24 26; do
   echo "== pass 2^$p"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# record workspace size (QVZ_WORK_GIB) for configs[2] and configs[3]
 export TMPDIR=/tmp
 for cfg in 2 3; do
 for w in 96 124; do
