@@ -1433,7 +1433,11 @@ struct KeptArea {
     char *base = nullptr;
     size_t cap = 0, used = 0, want = 0;
     std::vector<void *> extra;
-    void begin() { used = 0; want = 0; }
+    void begin() {
+        used = 0; want = 0;
+        // development knob: the area holds the previous call's bytes; a call must not depend on finding zeros there
+        if (base && getenv("QVZ_CODER_POISON")) { (void)hipMemset(base, 0xA5, cap); (void)hipDeviceSynchronize(); }
+    }
     hipError_t get(void **p, size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         want += bytes;
