@@ -47,6 +47,9 @@ extern "C" {
 #define QVZ_DIST_CUSTOM 4    /* -D FILE, reference include/distortion.h:10 */
 
 const char *qvz_hip_last_error(void);
+/* Records `msg` as the text qvz_hip_last_error() returns and hands `code` back: how the host C layer of the library
+ * (qvz_amd/csrc/host, no HIP headers) reports through the same channel as the kernels' launchers. */
+int qvz_hip_set_error(int code, const char *msg);
 uint64_t qvz_hip_ld(uint64_t n);
 int qvz_hip_device_count(void);
 

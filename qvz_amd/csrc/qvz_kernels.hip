@@ -34,6 +34,8 @@ int qvz_set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+extern "C" int qvz_hip_set_error(int code, const char *msg) { return qvz_set_error(code, "%s", msg ? msg : ""); }
+
 extern "C" uint64_t qvz_hip_ld(uint64_t n) { return (n + 255) & ~(uint64_t)255; }
 
 extern "C" int qvz_hip_device_count(void) {
