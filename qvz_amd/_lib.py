@@ -16,6 +16,7 @@ f64p = C.c_void_p
 # name -> (restype, argtypes); kept in one table so tests can check it against include/qvz_hip.h
 SIGNATURES = {
     "qvz_hip_last_error": (C.c_char_p, []),
+    "qvz_hip_set_error": (C.c_int, [C.c_int, C.c_char_p]),
     "qvz_hip_ld": (C.c_uint64, [C.c_uint64]),
     "qvz_hip_device_count": (C.c_int, []),
     "qvz_hip_transpose_text": (C.c_int, [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, u32p, C.c_void_p]),
