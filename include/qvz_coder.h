@@ -118,6 +118,14 @@ int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint6
 int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n,
                           uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                           const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels, void *stream);
+/* The same with the cut given (as qvz_hip_encode_planes_bounds on the encode side): stream g holds the reads
+ * [h_bounds[g], h_bounds[g+1]), h_bounds[0] = 0, h_bounds[shards] = n, every start a multiple of 4 reads (a WELL word
+ * boundary for any column count). NULL = qvz_shard_bounds(n, shards). This is what lets shard FILES, whose headers carry
+ * their own line counts, decode whatever formula cut them. */
+int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n,
+                                 uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                                 const uint64_t *h_bounds, const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels,
+                                 void *stream);
 
 /* The streams of a GPU coder call (stream g at d_coded + g * cap_per_shard, h_sizes[g] bytes) packed back to back into
  * d_packed (sum of the sizes): what travels to the host and into a shard set, instead of the whole fixed-stride area. */

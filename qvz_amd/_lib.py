@@ -97,6 +97,9 @@ SIGNATURES = {
     "qvz_hip_decode_shards": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "qvz_hip_decode_shards_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
+                                               C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "qvz_hip_encode_planes_last_ms": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "qvz_model_build": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),

@@ -315,13 +315,17 @@ int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_r
 /* S streams of one file (stream g = reads [first[g], first[g+1]) with qvz_shard_bounds(N, S)) decoded at once by the GPU
  * decoder and written as text. streams[g] points at sizes[g] bytes. */
 int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codebook_t *const *cbs, const uint32_t *well,
-                           uint32_t shards, const uint8_t *const *streams, const uint64_t *sizes, const char *out_path, int device) {
+                           uint32_t shards, const uint64_t *bounds, const uint8_t *const *streams, const uint64_t *sizes,
+                           const char *out_path, int device) {
     int rc = QVZ_OK;
     uint8_t *h_in = NULL, *d_in = NULL, *d_draws = NULL, *d_qv = NULL, *d_labels = NULL, *d_text = NULL, *h_text = NULL;
     FILE *fo = NULL;
     uint64_t cap = 0;
     for (uint32_t g = 0; g < shards; ++g) if (sizes[g] > cap) cap = sizes[g];
     cap = (cap + 7) & ~3ull;
+    /* N and C come from a file somebody else wrote: every product below must be the number it looks like */
+    if (!qvz_plausible_matrix(N, C) || shards == 0 || cap > (UINT64_MAX >> 1) / shards)
+        return qvz_job_fail(QVZ_E_DATA, "implausible size: %llu lines of %u columns in %u streams", (unsigned long long)N, C, shards);
     const uint64_t ld = qvz_hip_ld(N), stride = (uint64_t)C + 1;
     if (qvz_hip_set_device(device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
     h_in = (uint8_t *)calloc((size_t)shards, cap);
@@ -336,7 +340,7 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
     HIPC(qvz_hip_malloc((void **)&d_text, N * stride));
     HIPC(qvz_hip_copy_h2d(d_in, h_in, (size_t)shards * cap, NULL));
     HIPC(qvz_hip_well_draws(well, 0, N, C, d_draws, ld, NULL));
-    if (qvz_hip_decode_shards(d_in, cap, sizes, N, C, K, cbs, shards, d_draws, ld, d_qv, d_labels, NULL)) {
+    if (qvz_hip_decode_shards_bounds(d_in, cap, sizes, N, C, K, cbs, shards, bounds, d_draws, ld, d_qv, d_labels, NULL)) {
         rc = qvz_job_fail(QVZ_E_DATA, "%s", qvz_hip_last_error());
         goto done;
     }
@@ -389,16 +393,11 @@ int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_
         streams[g] = files[g] + head;
     }
     first[shards] = N;
-    {   /* the shard boundaries must be the ones qvz_shard_bounds gives for N reads: the decoder derives them itself */
-        uint64_t *chk = (uint64_t *)calloc((size_t)shards + 1, sizeof(*chk));
-        if (!chk) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        qvz_shard_bounds(N, shards, chk);
-        const int same = memcmp(chk, first, ((size_t)shards + 1) * sizeof(*chk)) == 0;
-        free(chk);
-        if (!same) { rc = qvz_job_fail(QVZ_E_DATA, "line counts of the shard files are not those of %u equal shards", shards); goto done; }
-    }
+    /* The cut is the one the files' headers state (whatever formula made it: an earlier revision dealt ceil(N / S) reads
+     * rounded up to 4, qvz_shard_bounds deals groups of 4); what the decoder needs is that every shard but the last holds
+     * whole WELL words, i.e. starts on a multiple of 4 reads - qvz_hip_decode_shards_bounds checks that. */
     /* shard 0 carries the file's WELL state */
-    rc = qvz_decode_streams_gpu(q0.K, q0.C, N, (const qvz_codebook_t *const *)q0.cbs, q0.well, shards, streams, sizes, out_path, device);
+    rc = qvz_decode_streams_gpu(q0.K, q0.C, N, (const qvz_codebook_t *const *)q0.cbs, q0.well, shards, first, streams, sizes, out_path, device);
     if (!rc && res) { memset(res, 0, sizeof(*res)); res->lines = N; res->columns = q0.C; for (uint32_t g = 0; g < shards; ++g) { res->stream_bytes += sizes[g]; res->file_bytes += fsize[g]; } }
 done:
     if (files) for (uint32_t g = 0; g < shards; ++g) free(files[g]);

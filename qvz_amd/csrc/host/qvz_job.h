@@ -92,9 +92,16 @@ int qvz_read_whole_file(const char *path, uint8_t **buf, size_t *size);
 /* start_qv_decompression (qv_compressor.c:145-231) over memory: the serial chain and the WELL draws on one host core */
 int qvz_decode_stream_host(uint32_t K, uint32_t C, uint64_t lines, const qvz_codebook_t *const *cbs, const uint32_t *well,
                            const uint8_t *stream, size_t size, FILE *fo, int verbose);
-/* S streams of one file (qvz_shard_bounds(N, S)) decoded at once on the GPU, written as text to out_path */
+/* S streams of one file decoded at once on the GPU, written as text to out_path; stream g holds the reads
+ * [bounds[g], bounds[g+1]) (NULL: qvz_shard_bounds(N, S)) */
 int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codebook_t *const *cbs, const uint32_t *well,
-                           uint32_t shards, const uint8_t *const *streams, const uint64_t *sizes, const char *out_path, int device);
+                           uint32_t shards, const uint64_t *bounds, const uint8_t *const *streams, const uint64_t *sizes,
+                           const char *out_path, int device);
+/* Sizes taken from a file somebody else wrote: 1 when N lines of C columns give products - N * (C + 1), C * ld(N),
+ * first_read * C - that fit 2^48 (256 TB of text: beyond any device or host this runs on, far below a 64-bit wrap) */
+static inline int qvz_plausible_matrix(uint64_t N, uint32_t C) {
+    return N != 0 && C != 0 && C <= (1u << 20) && N <= (1ull << 48) / ((uint64_t)C + 1);
+}
 
 int qvz_job_fail(int code, const char *fmt, ...);
 

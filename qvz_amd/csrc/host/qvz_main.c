@@ -151,6 +151,11 @@ int main(int argc, char **argv) {
             p = *end == ',' ? end + 1 : end;
         }
     }
+    if (ndev == 1) opts.device = devices[0];                      /* one ordinal named: that GPU, through the single-device driver */
+    if (ndev > 1 && files) {                                      /* options that cannot be honoured together are refused, not ignored */
+        printf("QVZ_SHARD_FILES=1 is not available with several QVZ_DEVICES: write the shard set and split it (qvz-shardset split)\n");
+        exit(1);
+    }
     const int rc = ndev > 1 ? qvz_encode_file_devices(input_name, output_name, &opts, devices, ndev, shards ? shards : 8192u * ndev, &res)
                    : !shards ? qvz_encode_file(input_name, output_name, &opts, &res)
                    : files ? qvz_encode_file_sharded(input_name, output_name, &opts, shards, &res)

@@ -78,7 +78,8 @@ typedef struct {
     uint32_t arrived, generation;
     int use_rccl;
     rccl_t rccl;
-    ncclComm_t *comms;            /* [parts] */
+    ncclComm_t *comms;            /* [parts]; an entry is NULL once its communicator has been aborted (ncclCommAbort frees it) */
+    uint8_t busy[64];             /* part d is inside a host call on comms[d]: nobody else may abort it meanwhile */
     /* host-staged reduction: every part copies its buffer here, part 0 adds them up */
     uint8_t *stage;               /* [parts][stage_bytes] */
     size_t stage_bytes;
@@ -120,13 +121,22 @@ static int bar_wait(shared_t *sh) {
     return failed;
 }
 
+/* Marks the encode as failed and releases everybody: the host barrier at once, and - with RCCL - the ranks parked in a
+ * collective on the device, by aborting the communicators. ncclCommAbort frees its communicator, so each one is aborted
+ * AT MOST ONCE: it is taken out of sh->comms under the lock before the call (several parts may fail at the same time), a
+ * communicator whose owner is inside ncclAllReduce right now is left to that owner (part_allreduce aborts it when the call
+ * returns), and whatever is NULL here is neither aborted again nor destroyed by qvz_encode_file_devices. */
 static void bar_abort(shared_t *sh) {
+    ncclComm_t mine[64];
+    uint32_t n = 0;
     pthread_mutex_lock(&sh->mu);
     sh->failed = 1;
     pthread_cond_broadcast(&sh->cv);
+    if (sh->use_rccl && sh->comms && sh->rccl.comm_abort)
+        for (uint32_t d = 0; d < sh->parts && d < 64; ++d)
+            if (sh->comms[d] && !sh->busy[d]) { mine[n++] = sh->comms[d]; sh->comms[d] = NULL; }
     pthread_mutex_unlock(&sh->mu);
-    if (sh->use_rccl && sh->comms && sh->rccl.comm_abort)        /* ranks parked in a collective on the device must not wait for this one */
-        for (uint32_t d = 0; d < sh->parts; ++d) if (sh->comms[d]) sh->rccl.comm_abort(sh->comms[d]);
+    for (uint32_t i = 0; i < n; ++i) sh->rccl.comm_abort(mine[i]);
 }
 
 static int part_fail(part_t *p, int rc) {
@@ -141,8 +151,20 @@ static int part_allreduce(void *ctx, void *d_buf, uint64_t count, int width, voi
     part_t *p = (part_t *)ctx;
     shared_t *sh = p->sh;
     if (sh->use_rccl) {
-        const int e = sh->rccl.all_reduce(d_buf, d_buf, (size_t)count, width == 8 ? NCCL_UINT64 : NCCL_UINT32, NCCL_SUM, sh->comms[p->part], stream);
+        ncclComm_t comm, late = NULL;
+        pthread_mutex_lock(&sh->mu);
+        comm = sh->failed ? NULL : sh->comms[p->part];
+        if (comm) sh->busy[p->part] = 1;
+        pthread_mutex_unlock(&sh->mu);
+        if (!comm) { qvz_job_fail(QVZ_E_HIP, "ncclAllReduce: another part failed, communicator aborted"); return QVZ_E_HIP; }
+        const int e = sh->rccl.all_reduce(d_buf, d_buf, (size_t)count, width == 8 ? NCCL_UINT64 : NCCL_UINT32, NCCL_SUM, comm, stream);
+        pthread_mutex_lock(&sh->mu);
+        sh->busy[p->part] = 0;
+        if (sh->failed && sh->comms[p->part] && sh->rccl.comm_abort) { late = sh->comms[p->part]; sh->comms[p->part] = NULL; }   /* bar_abort left it to us */
+        pthread_mutex_unlock(&sh->mu);
+        if (late) sh->rccl.comm_abort(late);
         if (e) { qvz_job_fail(QVZ_E_HIP, "ncclAllReduce: %s", sh->rccl.error_string ? sh->rccl.error_string(e) : "error"); return QVZ_E_HIP; }
+        if (late) { qvz_job_fail(QVZ_E_HIP, "ncclAllReduce: another part failed, communicator aborted"); return QVZ_E_HIP; }
         return QVZ_OK;
     }
     const size_t bytes = (size_t)count * (size_t)width;
@@ -385,6 +407,7 @@ done:
             parts[d].job.out_streams = NULL; parts[d].job.out_sizes = NULL; parts[d].job.out_err = NULL;
             if (parts[d].job.C) { qvz_hip_set_device(parts[d].device); qvz_job_release(&parts[d].job); }
         }
+    /* all threads are joined: what is still in sh.comms was never aborted (an aborted communicator is already freed) */
     if (sh.comms) { for (uint32_t d = 0; d < ndev; ++d) if (sh.comms[d]) sh.rccl.comm_destroy(sh.comms[d]); free(sh.comms); }
     if (sh.rccl.lib) dlclose(sh.rccl.lib);
     pthread_mutex_destroy(&sh.mu);

@@ -86,6 +86,9 @@ static int sset_parse(const uint8_t *f, size_t size, sset_t *t) {
     t->K = get_u32(f + 8); t->C = get_u32(f + 12); t->N = get_u64(f + 16); t->S = get_u32(f + 24);
     if (t->K < 1 || t->K > 255 || t->C < 1 || t->C > (1u << 20) || t->S < 1 || t->S > qvz_shard_limit(t->N) || t->N == 0)
         return qvz_job_fail(QVZ_E_DATA, "implausible shard-set header (%u clusters, %u columns, %llu lines, %u shards)", t->K, t->C, (unsigned long long)t->N, t->S);
+    /* the line count is 64 bits of somebody else's file: N * (C + 1), C * ld and first_read * C are computed from it later */
+    if (!qvz_plausible_matrix(t->N, t->C))
+        return qvz_job_fail(QVZ_E_DATA, "implausible shard-set header: %llu lines of %u columns", (unsigned long long)t->N, t->C);
     if ((uint64_t)size < QVZ_SHARDSET_FIXED + (uint64_t)t->S * 8) return qvz_job_fail(QVZ_E_DATA, "shard set ends inside its size table");
     memcpy(t->well, f + 32, 128);
     t->sizes = (uint64_t *)calloc(t->S, sizeof(uint64_t));
@@ -183,7 +186,7 @@ int qvz_shardset_decode(const char *path, const char *out_path, int device, qvz_
     streams = (const uint8_t **)calloc(t.S, sizeof(*streams));
     if (!streams) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
     for (uint32_t g = 0; g < t.S; ++g) streams[g] = f + t.at[g];
-    rc = qvz_decode_streams_gpu(t.K, t.C, t.N, (const qvz_codebook_t *const *)t.cbs, t.well, t.S, streams, t.sizes, out_path, device);
+    rc = qvz_decode_streams_gpu(t.K, t.C, t.N, (const qvz_codebook_t *const *)t.cbs, t.well, t.S, NULL, streams, t.sizes, out_path, device);
     if (!rc && res) {
         memset(res, 0, sizeof(*res));
         res->lines = t.N; res->columns = t.C; res->file_bytes = size;

@@ -228,6 +228,18 @@ __global__ __launch_bounds__(256) void k_dec_arena_fill(const uint32_t *__restri
 extern "C" int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n,
                                      uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                      const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels, void *stream) {
+    return qvz_hip_decode_shards_bounds(d_in, cap_per_shard, h_sizes, n, columns, clusters, cbs, shards, nullptr, d_draws, ld, d_qv, d_labels, stream);
+}
+
+extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n,
+                                            uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                                            const uint64_t *h_bounds, const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv,
+                                            uint8_t *d_labels, void *stream) {
+    if (h_bounds) {                                              // a cut somebody else made: whole WELL words, in order, all of the reads
+        if (h_bounds[0] != 0 || h_bounds[shards ? shards : 0] != n) return qvz_set_error(QVZ_E_ARG, "shard bounds do not cover the %llu reads", (unsigned long long)n);
+        for (uint32_t g = 0; g < shards; ++g)
+            if (h_bounds[g] > h_bounds[g + 1] || (h_bounds[g] & 3)) return qvz_set_error(QVZ_E_ARG, "shard %u does not start on a multiple of 4 reads or runs backwards", g);
+    }
     if (!d_in || !h_sizes || !n || !columns || !clusters || !cbs || !shards || !d_draws || !d_qv || ld < n || (ld & 3) || (cap_per_shard & 3))
         return qvz_set_error(QVZ_E_ARG, "bad shard-decoder arguments");
     if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "a label buffer is required for clusters > 1");
@@ -296,7 +308,8 @@ extern "C" int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard
                     h_ctx[((size_t)c * columns + s) * A + pv] = e;
                 }
     }
-    qvz_shard_bounds(n, shards, h_first);
+    if (h_bounds) memcpy(h_first, h_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
+    else qvz_shard_bounds(n, shards, h_first);
     TRY(hipMalloc(&d_tmpl, (size_t)dwords * 4));
     TRY(hipMalloc(&d_arena, ((size_t)dwords * shards + 16) * 4));   // + slack: a header read covers 64 bytes
     TRY(hipMalloc(&d_ctx, ctxn * sizeof(uint2)));

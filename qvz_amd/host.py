@@ -262,21 +262,28 @@ def planes_bytes_per_read(shards, columns, k):
 
 
 def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True,
-                      work_bytes=None):
+                      work_bytes=None, bounds=None):
     """GPU sharded coder fed from the quantizer's planes (qvz_hip_encode_planes): the model runs with a lane per
     (stream, column), the interval arithmetic with a lane per stream. qi/st: (columns, ld) uint8 device tensors.
     work_bytes: size of the record workspace (default: everything at once, capped at 96 GiB).
+    bounds: the cut into shards (shards + 1 read numbers, every start a multiple of 4; default qvz_shard_bounds).
     Returns (sizes, streams|None, out_tensor)."""
     import torch
     k = len(codebook_handles)
     arr = (C.c_void_p * k)(*codebook_handles)
     ld = qi.shape[1]
+    cap_given = cap_per_shard
     if cap_per_shard is None:
         per = (n + shards - 1) // shards + 4
         cap_per_shard = (per * columns * 3) // 4 + 512          # 6 bits/symbol + the 256-byte margin the emitter wants
     cap_per_shard = (cap_per_shard + 3) & ~3
     per_read = planes_bytes_per_read(shards, columns, k)
     longest = ((n + shards - 1) // shards + 7) & ~3
+    if bounds is not None:
+        per = max(b - a for a, b in zip(bounds, bounds[1:]))
+        longest = (per + 7) & ~3
+        if cap_given is None:
+            cap_per_shard = (((per + 4) * columns * 3) // 4 + 512 + 3) & ~3
     if work_bytes is None:
         # default: everything at once, capped (QVZ_WORK_GIB, 96 GiB of the 288 unless set); fewer, longer segments mean
         # fewer save/restore round trips of the model tables between segments
@@ -287,10 +294,16 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=qi.device)
     sizes = (C.c_uint64 * shards)()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = lib().qvz_hip_encode_planes(C.c_void_p(qi.data_ptr()), C.c_void_p(st.data_ptr()), ld,
-                                     C.c_void_p(labels.data_ptr()) if labels is not None else None, n, columns, k, arr, shards,
-                                     C.c_void_p(out.data_ptr()), cap_per_shard, sizes, C.c_void_p(work.data_ptr()), work_bytes,
-                                     stream)
+    lab = C.c_void_p(labels.data_ptr()) if labels is not None else None
+    if bounds is None:
+        rc = lib().qvz_hip_encode_planes(C.c_void_p(qi.data_ptr()), C.c_void_p(st.data_ptr()), ld, lab, n, columns, k, arr, shards,
+                                         C.c_void_p(out.data_ptr()), cap_per_shard, sizes, C.c_void_p(work.data_ptr()), work_bytes,
+                                         stream)
+    else:
+        hb = (C.c_uint64 * (shards + 1))(*[int(b) for b in bounds])
+        rc = lib().qvz_hip_encode_planes_bounds(C.c_void_p(qi.data_ptr()), C.c_void_p(st.data_ptr()), ld, lab, n, columns, k, arr,
+                                                shards, hb, C.c_void_p(out.data_ptr()), cap_per_shard, sizes,
+                                                C.c_void_p(work.data_ptr()), work_bytes, stream)
     if rc:
         raise QvzHipError(f"qvz_hip_encode_planes failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
     a, b = C.c_double(), C.c_double()
@@ -304,9 +317,10 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     return sizes, streams, out
 
 
-def decode_shards_gpu(coded, cap_per_shard, sizes, n, columns, codebook_handles, shards, draws, want_labels=False):
-    """GPU decoder of sharded streams (qvz_hip_decode_shards). coded: uint8 device tensor with stream g at
-    g * cap_per_shard; draws: (columns, ld) draw matrix of the same reads. Returns (qv plane (columns, ld), labels|None)."""
+def decode_shards_gpu(coded, cap_per_shard, sizes, n, columns, codebook_handles, shards, draws, want_labels=False, bounds=None):
+    """GPU decoder of sharded streams (qvz_hip_decode_shards_bounds). coded: uint8 device tensor with stream g at
+    g * cap_per_shard; draws: (columns, ld) draw matrix of the same reads; bounds: the cut (default qvz_shard_bounds).
+    Returns (qv plane (columns, ld), labels|None)."""
     import torch
     k = len(codebook_handles)
     arr = (C.c_void_p * k)(*codebook_handles)
@@ -315,9 +329,10 @@ def decode_shards_gpu(coded, cap_per_shard, sizes, n, columns, codebook_handles,
     labels = torch.zeros(ld, dtype=torch.uint8, device=draws.device) if (k > 1 or want_labels) else None
     sz = (C.c_uint64 * shards)(*[int(x) for x in sizes])
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = lib().qvz_hip_decode_shards(C.c_void_p(coded.data_ptr()), cap_per_shard, sz, n, columns, k, arr, shards,
-                                     C.c_void_p(draws.data_ptr()), ld, C.c_void_p(qv.data_ptr()),
-                                     C.c_void_p(labels.data_ptr()) if labels is not None else None, stream)
+    hb = (C.c_uint64 * (shards + 1))(*[int(b) for b in bounds]) if bounds is not None else None
+    rc = lib().qvz_hip_decode_shards_bounds(C.c_void_p(coded.data_ptr()), cap_per_shard, sz, n, columns, k, arr, shards, hb,
+                                            C.c_void_p(draws.data_ptr()), ld, C.c_void_p(qv.data_ptr()),
+                                            C.c_void_p(labels.data_ptr()) if labels is not None else None, stream)
     if rc:
         raise QvzHipError(f"qvz_hip_decode_shards failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
     return qv, labels

@@ -22,7 +22,7 @@ static int nodev(void) { return qvz_hip_set_error(QVZ_E_HIP, "fuzz build: no dev
 uint64_t qvz_hip_codebook_deferred_decisions(void) { return 0; }
 int qvz_hip_copy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) { U(h_dst); U(d_src); U(bytes); U(stream); return nodev(); }
 int qvz_hip_copy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) { U(d_dst); U(h_src); U(bytes); U(stream); return nodev(); }
-int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels, void *stream) { U(d_in); U(cap_per_shard); U(h_sizes); U(n); U(columns); U(clusters); U(cbs); U(shards); U(d_draws); U(ld); U(d_qv); U(d_labels); U(stream); return nodev(); }
+int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, const uint64_t *h_bounds, const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels, void *stream) { U(d_in); U(cap_per_shard); U(h_sizes); U(n); U(columns); U(clusters); U(cbs); U(shards); U(h_bounds); U(d_draws); U(ld); U(d_qv); U(d_labels); U(stream); return nodev(); }
 int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work, uint64_t work_bytes, void *stream) { U(d_qi); U(d_st); U(ld); U(d_labels); U(n); U(columns); U(clusters); U(cbs); U(shards); U(h_bounds); U(d_out); U(cap_per_shard); U(h_sizes); U(d_work); U(work_bytes); U(stream); return nodev(); }
 int qvz_hip_free(void *d_ptr) { U(d_ptr); return nodev(); }
 int qvz_hip_free_host(void *h_ptr) { U(h_ptr); return nodev(); }

@@ -168,6 +168,22 @@ def test_shardset_file_layout(tmp_path):
     assert (st.clusters, st.columns, st.shards, st.lines) == (k, c, shards, n)
     assert (st.header_bytes, st.codebook_bytes, st.stream_bytes, st.file_bytes) == (at, len(cb_bytes), len(body), len(data))
     assert (si.file_bytes, si.codebook_bytes) == (len(data), len(cb_bytes))
+    # A line count that makes N * (C + 1), C * ld or first_read * C wrap 64 bits (2^62 lines of c columns) must be
+    # refused by everything that parses the header - stat, decode and split - before any size is computed from it.
+    for lines in (1 << 62, (1 << 64) - 4, ((1 << 48) // (c + 1)) + 1):
+        bad = bytearray(data)
+        bad[16:24] = lines.to_bytes(8, "little")
+        bp = str(tmp_path / "bad.qs")
+        open(bp, "wb").write(bytes(bad))
+        info = host.ShardsetInfo()
+        assert L.qvz_shardset_stat(bp.encode(), C.byref(info)) != 0
+        assert b"implausible" in L.qvz_encode_last_error()
+        assert L.qvz_shardset_decode(bp.encode(), str(tmp_path / "bad.txt").encode(), 0, None) != 0
+        assert L.qvz_shardset_split(bp.encode(), str(tmp_path / "piece").encode(), 0, 0, 0) != 0
+    ok = bytearray(data)                                                           # the largest count that is accepted parses
+    ok[16:24] = ((1 << 48) // (c + 1)).to_bytes(8, "little")
+    open(bp, "wb").write(bytes(ok))
+    assert L.qvz_shardset_stat(bp.encode(), C.byref(info)) == 0
     for h in cbs:
         L.qvz_codebook_free(h)
 

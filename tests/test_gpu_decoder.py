@@ -85,3 +85,38 @@ def test_round_trip_at_bench_stream_length():
     draws = K.well_draws(np.full(32, 0x55555555, dtype=np.uint32), 0, n, c)
     qv, _ = host.decode_shards_gpu(coded.view(-1), cap, r["stream_bytes"], n, c, [cb.handle for cb in r["codebooks"]], shards, draws)
     assert torch.equal(qv[:, :n], r["qv"][:, :n])
+
+
+@pytest.mark.parametrize("name,shards", [("t2k_r10_M", 3), ("t2k_c3_f05_M", 7)])
+def test_shard_files_cut_by_another_formula_decode(tmp_path, name, shards):
+    """Shard FILES carry their own line counts, so `qvz -x` must decode them however they were cut - an earlier revision
+    dealt ceil(N / S) reads rounded up to 4 per shard, qvz_shard_bounds deals groups of 4 evenly. Streams coded over the old
+    cut (qvz_hip_encode_planes_bounds): the GPU decoder inverts them given the same cut, the files decode through the
+    command line, and each file is what the oracle's (= the reference's) decoder reads."""
+    import os
+    import subprocess
+    from qvz_amd import host, kernels as K
+    from test_gpu_encode import QVZ_BIN
+    rows, opts, n, c, r = encode(name, 1, coder="gpu")
+    per = ((n + shards - 1) // shards + 3) & ~3
+    bounds = [min(g * per, n) for g in range(shards)] + [n]
+    assert bounds != host.shard_bounds(n, shards)
+    handles = [cb.handle for cb in r["codebooks"]]
+    sizes, streams, coded = host.encode_planes_gpu(r["qi"], r["st"], r["labels"] if opts["k"] > 1 else None, n, c, handles, shards,
+                                                   bounds=bounds)
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    qv, labels = host.decode_shards_gpu(coded, coded.numel() // shards, sizes, n, c, handles, shards, draws, bounds=bounds)
+    assert torch.equal(qv[:, :n], r["qv"][:, :n])
+    with pytest.raises(Exception):                                              # a cut that is not on WELL word boundaries is refused
+        host.decode_shards_gpu(coded, coded.numel() // shards, sizes, n, c, handles, shards, draws, bounds=[0, 2] + bounds[2:])
+    u = K.untranspose_text(r["qv"], n).cpu().numpy().tobytes()
+    prefix = str(tmp_path / "old.q")
+    for g in range(shards):
+        state = K.well_jump(O.WELL_DEBUG_STATE, bounds[g] * c // 4)
+        image = host.shard_file_image(c, bounds[g + 1] - bounds[g], handles, state, streams[g])
+        open(f"{prefix}.{g:04d}", "wb").write(image)
+        assert O.decode(image) == u[bounds[g] * (c + 1):bounds[g + 1] * (c + 1)]
+    dec = str(tmp_path / "old.dec")
+    subprocess.run([QVZ_BIN, "-x", prefix, dec], env=dict(os.environ, QVZ_SHARDS=str(shards), QVZ_SHARD_FILES="1"), check=True,
+                   capture_output=True)
+    assert open(dec, "rb").read() == u

@@ -471,3 +471,21 @@ def test_one_rank_rccl_communicator_in_the_c_driver(tmp_path, monkeypatch):
     fresh_process_rand()
     host.encode_file_devices(inp, rc, [0], 4, **kw)
     assert open(rc, "rb").read() == open(one, "rb").read()
+
+
+def test_cli_one_named_device_is_honoured(tmp_path):
+    """QVZ_DEVICES with a single ordinal selects that GPU (it used to be ignored silently): ordinal 0 gives the usual file,
+    an ordinal the box does not have fails instead of running on device 0; QVZ_SHARD_FILES with several devices is refused."""
+    name = "t2k_r10_M"
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    env = dict(os.environ, QVZ_WELL_SEED="debug", QVZ_SHARDS="4")
+    a, b = str(tmp_path / "a.qset"), str(tmp_path / "b.qset")
+    subprocess.run([QVZ_BIN] + e["flags"].split() + [inp, a], env=env, capture_output=True, check=True)
+    subprocess.run([QVZ_BIN] + e["flags"].split() + [inp, b], env=dict(env, QVZ_DEVICES="0"), capture_output=True, check=True)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    r = subprocess.run([QVZ_BIN] + e["flags"].split() + [inp, b], env=dict(env, QVZ_DEVICES="63"), capture_output=True, text=True)
+    assert r.returncode != 0
+    r = subprocess.run([QVZ_BIN] + e["flags"].split() + [inp, b], env=dict(env, QVZ_DEVICES="0,0", QVZ_SHARD_FILES="1"),
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "QVZ_SHARD_FILES" in r.stdout
