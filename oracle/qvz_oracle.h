@@ -83,6 +83,8 @@ size_t orc_write_codebook(uint8_t *buf, const orc_codebook_t *cb);
 typedef struct { uint32_t state[32]; uint32_t n, bit_output, bits_left; } orc_well_t;
 uint32_t orc_well_word(orc_well_t *w);
 uint32_t orc_well_bits(orc_well_t *w, uint32_t bits);
+/* states after words[i] (ascending) calls from state0 (n = 0), each rotated to n = 0; by stepping only */
+void orc_well_states_at(const uint32_t *state0, const uint64_t *words, uint64_t count, uint32_t *out /*[count][32]*/);
 
 /* qv_compressor.c:48-143 + qv_stream.c + arith.c + os_stream.c.
  * cbs: k codebooks. well_state: the 32 words written to the file before the stream.

@@ -14,6 +14,18 @@ CUSTOM_DIST_CASES = {n: e for n, e in MANIFEST["cases"].items() if e.get("custom
 CASES = {n: e for n, e in MANIFEST["cases"].items() if not e.get("custom_dist")}
 
 
+def well_far():
+    """WELL-1024a states far into the stream (tests/golden/well_far.json: the reference's own well_1024a stepped from
+    32 x 0x55555555 by oracle/well_far.c). Returns [(words, state in the n = 0 form a file stores, next four words)]."""
+    doc = json.load(open(os.path.join(GOLD, "well_far.json")))
+    out = []
+    for v in doc["vectors"]:
+        st = np.array(v["state"], dtype=np.uint32)
+        rot = np.array([st[(v["n"] + i) & 31] for i in range(32)], dtype=np.uint32)
+        out.append((int(v["words"]), rot, [int(x) for x in v["next"]]))
+    return out
+
+
 def cli_flags(entry):
     """The reference CLI flags of a fixture as an argv list ("@name" = a file in tests/golden/)."""
     return [os.path.join(GOLD, f[1:]) if f.startswith("@") else f for f in entry["flags"].split()]

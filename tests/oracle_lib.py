@@ -75,6 +75,8 @@ def lib():
         L.orc_decode.restype = C.c_uint64
         L.orc_decode.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
         L.orc_qgen1_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, u8p]
+        L.orc_well_states_at.argtypes = [u32p, u64p, C.c_uint64, u32p]
+        L.orc_well_states_at.restype = None
         _lib = L
     return _lib
 
@@ -84,6 +86,21 @@ def _p(a, ty):
 
 
 WELL_DEBUG_STATE = np.full(32, 0x55555555, dtype=np.uint32)  # reference -DDEBUG seed, qv_stream.c:79-83
+
+
+def well_states_at(words, state0=WELL_DEBUG_STATE):
+    """WELL-1024a states (n = 0 form, as a file stores them) after words[i] generator calls from state0, by STEPPING the
+    oracle's generator (well.c:8-24 restated): the reference-derived WELL state of a shard in the middle of a file.
+    Any order of words; ~1.5 ns per word of the largest."""
+    words = np.asarray(words, dtype=np.uint64)
+    order = np.argsort(words, kind="stable")
+    srt = np.ascontiguousarray(words[order])
+    out = np.zeros((len(srt), 32), dtype=np.uint32)
+    s0 = np.ascontiguousarray(state0, dtype=np.uint32)
+    lib().orc_well_states_at(_p(s0, C.c_uint32), _p(srt, C.c_uint64), len(srt), _p(out, C.c_uint32))
+    res = np.zeros_like(out)
+    res[order] = out
+    return res
 
 
 def qgen1_rows(seed, n, c, first=0):

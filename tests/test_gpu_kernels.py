@@ -278,6 +278,31 @@ def test_well_random_state_and_jump(K):
     np.testing.assert_array_equal(a, b)
 
 
+def test_well_jump_ahead_matches_the_reference_generator_beyond_2_to_the_32(K):
+    """BASELINE configs[4] draws 3.75e10 words; rank 7 of 8 starts 32 812 500 000 words in. The GF(2) jump-ahead
+    (qvz_hip_well_jump, qvz_hip_well_jump_many) against states of the reference's own generator stepped that far
+    (tests/golden/well_far.json): bits 32-35 of the word offset are pinned by a reference-derived vector, not by a second
+    route through the same code."""
+    import ctypes as C
+    from qvz_amd._lib import lib
+    far = G.well_far()
+    for words, state, nxt in far:
+        got = K.well_jump(O.WELL_DEBUG_STATE, words)
+        np.testing.assert_array_equal(got, state, err_msg=f"jump by {words} words")
+        assert K.well_words(got, 0, 4).cpu().numpy().view(np.uint32).tolist() == nxt
+    # all of them in one batched call, and a relative jump from one golden state to the next
+    w = (C.c_uint64 * len(far))(*[f[0] for f in far])
+    out = np.zeros((len(far), 32), dtype=np.uint32)
+    st = np.ascontiguousarray(O.WELL_DEBUG_STATE)
+    assert lib().qvz_hip_well_jump_many(st.ctypes.data_as(C.POINTER(C.c_uint32)), w, len(far), out.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+    np.testing.assert_array_equal(out, np.stack([f[1] for f in far]))
+    np.testing.assert_array_equal(K.well_jump(far[3][1], far[4][0] - far[3][0]), far[4][1])
+    # draws of reads far into a 1B-read file: the word stream behind first_read * C draws
+    first_read, c, n = 875_000_000, 150, 64
+    draws = K.well_draws(O.WELL_DEBUG_STATE, first_read, n, c)
+    np.testing.assert_array_equal(draws[:, :n].cpu().numpy(), cpu_draws(far[4][1], 0, n, c))
+
+
 def cpu_draws(state, first_read, n, c):
     """(c, n) matrix of 7-bit draws as the reference consumes them: draw g = read*c + column (well.c:33-46)."""
     g0 = first_read * c

@@ -68,3 +68,18 @@ def test_well_known_answer():
         w.state[i] = 0x55555555
     draws = [lib.orc_well_bits(C.byref(w), 7) for _ in range(12)]
     assert draws == kat["first_draws"]
+
+
+def test_well_states_beyond_two_to_the_32_words():
+    """tests/golden/well_far.json holds states of the REFERENCE's generator after up to 3.75e10 words (stepped once in the
+    build container). The oracle's generator continues each of them correctly: its next words are the recorded ones, and
+    stepping it from the vector at 2^32 - 1 words for 8 words lands on the vector at 2^32 + 7. (The jump-ahead of the product
+    is tested against the same vectors in test_gpu_kernels.py.)"""
+    far = G.well_far()
+    assert [w for w, _, _ in far][:4] == [1000, (1 << 32) - 1, (1 << 32) + 7, (1 << 33) + 5] and far[-1][0] > 3.7e10
+    assert np.array_equal(O.well_states_at([1000])[0], far[0][1])               # from the seed by stepping
+    for words, state, nxt in far:
+        after = O.well_states_at([1, 2, 3, 4], state0=state)
+        # the word a call returns is the state word the new n points at = element 0 of the n = 0 form
+        assert [int(a[0]) for a in after] == nxt, words
+    assert np.array_equal(O.well_states_at([8], state0=far[1][1])[0], far[2][1])
