@@ -131,6 +131,10 @@ int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_per_shard, co
  * d_packed (sum of the sizes): what travels to the host and into a shard set, instead of the whole fixed-stride area. */
 int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const uint64_t *h_sizes, uint32_t shards,
                            uint8_t *d_packed, void *stream);
+/* The inverse, for a decoder fed from a shard set: packed streams -> stream g at d_coded + g * cap_per_shard, the rest of
+ * the area zeroed. */
+int qvz_hip_scatter_streams(const uint8_t *d_packed, const uint64_t *h_sizes, uint32_t shards, uint8_t *d_coded,
+                            uint64_t cap_per_shard, void *stream);
 
 /* GPU time of the last qvz_hip_encode_planes call, split into its model kernels and its coder kernels (HIP events on
  * the call's stream, summed over the segments). Either pointer may be NULL. */

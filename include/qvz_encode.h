@@ -54,6 +54,9 @@ typedef struct qvz_result {
     uint32_t kmeans_iterations;
     uint64_t deferred_decisions; /* codebook search decisions taken by host libm inside the guard band */
     double t_upload, t_cluster, t_stats, t_codebook, t_encode, t_total;   /* seconds */
+    /* sharded encodes: what t_encode consists of - waiting for the WELL draws + the quantizer, the coder kernels, and
+     * everything that leaves the device afterwards (-u text, per-read errors, streams: PCIe + file writes) */
+    double t_quantize, t_coder, t_egress;
 } qvz_result_t;
 
 void qvz_options_default(qvz_options_t *o);   /* reference defaults, main.c:198-204 (+ mode = RATIO) */

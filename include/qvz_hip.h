@@ -70,6 +70,8 @@ int qvz_hip_stream_create(void **stream);
 int qvz_hip_streams_overlap(void *stream_a, void *stream_b, int *overlap);
 int qvz_hip_stream_destroy(void *stream);
 int qvz_hip_stream_sync(void *stream);
+/* work submitted to `stream` from now on starts after everything submitted to `other` so far has finished (no host wait) */
+int qvz_hip_stream_wait(void *stream, void *other);
 
 /* ---------------------------------------------------------------------------------------------
  * Input staging. Replaces the row-major pointer view built by load_file (reference
@@ -81,6 +83,10 @@ int qvz_hip_transpose_text(const uint8_t *d_text, uint64_t n, uint32_t c, uint8_
                            uint32_t *d_bad, void *stream);
 /* Inverse, for the "-u" dump (reference src/qv_compressor.c:100-125): quantized symbols -> text rows. */
 int qvz_hip_untranspose_text(const uint8_t *d_qv, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text,
+                             void *stream);
+/* The same for the reads [first, first + n) of the matrix only (first a multiple of 4), written as rows 0 .. n-1 of
+ * d_text: how a whole-file -u text leaves the device slab by slab instead of as one N * (c + 1)-byte buffer. */
+int qvz_hip_untranspose_rows(const uint8_t *d_qv, uint64_t first, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text,
                              void *stream);
 /* QGEN-1 synthetic reads [first, first+n) generated directly in d_sym layout. */
 int qvz_hip_qgen1(uint64_t seed, uint64_t first, uint64_t n, uint32_t c, uint8_t *d_sym, uint64_t ld,

@@ -57,6 +57,13 @@ int qvz_shardset_write(FILE *f, uint32_t clusters, uint32_t columns, uint64_t li
                        const uint32_t *well_state, const qvz_codebook_t *const *cbs, const uint8_t *streams,
                        uint64_t stride, const uint64_t *sizes, qvz_shardset_info_t *info);
 
+/* Everything of a shard set that comes before the streams - fixed part, size table, the codebooks - for a writer that
+ * sends the streams after it piece by piece (the whole-file driver streams them out of the device through pinned slabs).
+ * info->stream_bytes / file_bytes count the streams the size table promises. */
+int qvz_shardset_write_head(FILE *f, uint32_t clusters, uint32_t columns, uint64_t lines, uint32_t shards,
+                            const uint32_t *well_state, const qvz_codebook_t *const *cbs, const uint64_t *sizes,
+                            qvz_shardset_info_t *info);
+
 /* header fields and byte counts of the shard set at `path` */
 int qvz_shardset_stat(const char *path, qvz_shardset_info_t *info);
 

@@ -21,6 +21,7 @@ SIGNATURES = {
     "qvz_hip_device_count": (C.c_int, []),
     "qvz_hip_transpose_text": (C.c_int, [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, u32p, C.c_void_p]),
     "qvz_hip_untranspose_text": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u8p, C.c_void_p]),
+    "qvz_hip_untranspose_rows": (C.c_int, [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, u8p, C.c_void_p]),
     "qvz_hip_qgen1": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.c_void_p]),
     "qvz_hip_kmeans_assign": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u8p, u8p, u32p,
                                         C.c_void_p]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     "qvz_hip_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "qvz_hip_stream_destroy": (C.c_int, [C.c_void_p]),
     "qvz_hip_stream_sync": (C.c_int, [C.c_void_p]),
+    "qvz_hip_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     # include/qvz_codebook.h
     "qvz_codebook_alloc": (C.c_void_p, [C.c_uint32]),
     "qvz_codebook_free": (None, [C.c_void_p]),
@@ -116,11 +118,14 @@ SIGNATURES = {
     "qvz_encode_last_error": (C.c_char_p, []),
     "qvz_encode_file_devices": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_void_p]),
     "qvz_ingest_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "qvz_hip_scatter_streams": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "qvz_hip_gather_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_void_p]),
     "qvz_hip_well_jump_many": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_shard_limit": (C.c_uint32, [C.c_uint64]),
     # include/qvz_shardset.h (host C)
     "qvz_shardset_is": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "qvz_shardset_write_head": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]),
     "qvz_shardset_write": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
     "qvz_shardset_stat": (C.c_int, [C.c_char_p, C.c_void_p]),

@@ -318,43 +318,53 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
                            uint32_t shards, const uint64_t *bounds, const uint8_t *const *streams, const uint64_t *sizes,
                            const char *out_path, int device) {
     int rc = QVZ_OK;
-    uint8_t *h_in = NULL, *d_in = NULL, *d_draws = NULL, *d_qv = NULL, *d_labels = NULL, *d_text = NULL, *h_text = NULL;
+    uint8_t *h_packed = NULL, *d_packed = NULL, *d_in = NULL, *d_draws = NULL, *d_qv = NULL, *d_labels = NULL;
     FILE *fo = NULL;
-    uint64_t cap = 0;
-    for (uint32_t g = 0; g < shards; ++g) if (sizes[g] > cap) cap = sizes[g];
+    uint64_t cap = 0, total = 0;
+    int contiguous = 1;
+    for (uint32_t g = 0; g < shards; ++g) {
+        if (sizes[g] > cap) cap = sizes[g];
+        if (g + 1 < shards && streams[g + 1] != streams[g] + sizes[g]) contiguous = 0;
+        total += sizes[g];
+    }
     cap = (cap + 7) & ~3ull;
     /* N and C come from a file somebody else wrote: every product below must be the number it looks like */
     if (!qvz_plausible_matrix(N, C) || shards == 0 || cap > (UINT64_MAX >> 1) / shards)
         return qvz_job_fail(QVZ_E_DATA, "implausible size: %llu lines of %u columns in %u streams", (unsigned long long)N, C, shards);
-    const uint64_t ld = qvz_hip_ld(N), stride = (uint64_t)C + 1;
+    const uint64_t ld = qvz_hip_ld(N);
     if (qvz_hip_set_device(device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
-    h_in = (uint8_t *)calloc((size_t)shards, cap);
-    h_text = (uint8_t *)malloc(N * stride);
-    if (!h_in || !h_text) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-    for (uint32_t g = 0; g < shards; ++g) memcpy(h_in + (size_t)g * cap, streams[g], sizes[g]);
 #define HIPC(call) do { if ((call) != QVZ_OK) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; } } while (0)
+    /* the streams go up packed (they lie back to back in a shard set; the pieces of shard FILES are packed first) through
+     * pinned slabs and are spread to the decoder's fixed-stride layout on the device */
+    if (!contiguous) {
+        h_packed = (uint8_t *)malloc(total ? total : 1);
+        if (!h_packed) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        for (uint64_t g = 0, at = 0; g < shards; at += sizes[g], ++g) memcpy(h_packed + at, streams[g], sizes[g]);
+    }
+    HIPC(qvz_hip_malloc((void **)&d_packed, total ? total : 1));
     HIPC(qvz_hip_malloc((void **)&d_in, (size_t)shards * cap));
     HIPC(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
+    HIPC(qvz_hip_well_draws(well, 0, N, C, d_draws, ld, NULL));                /* beside the upload */
+    if ((rc = qvz_ingress_bytes(d_packed, contiguous ? streams[0] : h_packed, total))) goto done;
+    HIPC(qvz_hip_scatter_streams(d_packed, sizes, shards, d_in, cap, NULL));
+    qvz_hip_free(d_packed); d_packed = NULL;
     HIPC(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
     HIPC(qvz_hip_malloc((void **)&d_labels, ld));
-    HIPC(qvz_hip_malloc((void **)&d_text, N * stride));
-    HIPC(qvz_hip_copy_h2d(d_in, h_in, (size_t)shards * cap, NULL));
-    HIPC(qvz_hip_well_draws(well, 0, N, C, d_draws, ld, NULL));
     if (qvz_hip_decode_shards_bounds(d_in, cap, sizes, N, C, K, cbs, shards, bounds, d_draws, ld, d_qv, d_labels, NULL)) {
         rc = qvz_job_fail(QVZ_E_DATA, "%s", qvz_hip_last_error());
         goto done;
     }
-    HIPC(qvz_hip_untranspose_text(d_qv, N, C, ld, d_text, NULL));
-    HIPC(qvz_hip_copy_d2h(h_text, d_text, N * stride, NULL));
     HIPC(qvz_hip_stream_sync(NULL));
 #undef HIPC
+    qvz_hip_free(d_draws); d_draws = NULL;
+    qvz_hip_free(d_in); d_in = NULL;
     fo = fopen(out_path, "w");
     if (!fo) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
-    if (fwrite(h_text, 1, N * stride, fo) != N * stride) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
+    rc = qvz_egress_text(fo, d_qv, N, C, ld, NULL);                            /* the text leaves in slabs: no N-sized host buffer */
 done:
     if (fo) fclose(fo);
-    qvz_hip_free(d_in); qvz_hip_free(d_draws); qvz_hip_free(d_qv); qvz_hip_free(d_labels); qvz_hip_free(d_text);
-    free(h_in); free(h_text);
+    qvz_hip_free(d_packed); qvz_hip_free(d_in); qvz_hip_free(d_draws); qvz_hip_free(d_qv); qvz_hip_free(d_labels);
+    free(h_packed);
     return rc;
 }
 

@@ -117,36 +117,6 @@ static int job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_
     return 0;
 }
 
-/* page cache -> pinned staging with a few threads: one core copies ~4 GB/s, PCIe takes several times that */
-typedef struct { uint8_t *dst; const uint8_t *src; size_t n; } copy_part_t;
-static void *copy_part(void *arg) {
-    const copy_part_t *p = (const copy_part_t *)arg;
-    memcpy(p->dst, p->src, p->n);
-    return NULL;
-}
-static void parallel_memcpy(uint8_t *dst, const uint8_t *src, size_t n) {
-    enum { TMAX = 16 };
-    pthread_t th[TMAX];
-    copy_part_t part[TMAX];
-    int started[TMAX] = {0};
-    if (n < (8u << 20)) { memcpy(dst, src, n); return; }
-    /* page cache -> pinned memory at one core's speed (~2 GB/s) would hold the PCIe link back: up to 16 threads, as
-     * many as the machine has, QVZ_COPY_THREADS to override */
-    long cores = sysconf(_SC_NPROCESSORS_ONLN);
-    int T = getenv("QVZ_COPY_THREADS") ? atoi(getenv("QVZ_COPY_THREADS")) : 4;   /* 4 reach the PCIe rate (17 GB/s measured); more add nothing */
-    if (cores > 0 && T > cores) T = (int)cores;
-    if (T < 1) T = 1;
-    if (T > TMAX) T = TMAX;
-    const size_t each = (n / (size_t)T + 4095) & ~(size_t)4095;
-    for (int i = 0; i < T; ++i) {
-        const size_t a = (size_t)i * each, b = a + each < n ? a + each : n;
-        part[i].dst = dst + a; part[i].src = src + a; part[i].n = a < n ? b - a : 0;
-        if (i + 1 < T && part[i].n) started[i] = pthread_create(&th[i], NULL, copy_part, &part[i]) == 0;
-        if (!started[i] && part[i].n) memcpy(part[i].dst, part[i].src, part[i].n);   /* the last part, or no thread */
-    }
-    for (int i = 0; i < T; ++i) if (started[i]) pthread_join(th[i], NULL);
-}
-
 /* Streaming, transposing ingest (replaces load_file's row-pointer table, lines.c:27-82): the text goes through two
  * pinned staging buffers so that the host copy of chunk k+1 (page cache -> pinned), the PCIe transfer of chunk k and its
  * transposition into the column-major matrix overlap. */
@@ -172,7 +142,7 @@ int qvz_ingest_rows(const uint8_t *text, uint64_t N, uint32_t C, uint8_t *d_sym,
         for (uint64_t r0 = 0; r0 < N; r0 += up_reads, b ^= 1) {
             const uint64_t n = N - r0 < up_reads ? N - r0 : up_reads;
             HIP(qvz_hip_stream_sync(st[b]));                       /* this staging pair was used two chunks ago */
-            parallel_memcpy(h_up[b], text + r0 * stride, n * stride);
+            qvz_parallel_memcpy(h_up[b], text + r0 * stride, n * stride);
             HIP(qvz_hip_copy_h2d(d_up[b], h_up[b], n * stride, st[b]));
             HIP(qvz_hip_transpose_text(d_up[b], n, C, d_sym + r0, ld, d_bad, st[b]));
         }
@@ -239,6 +209,50 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
     HIP(qvz_hip_memset(job->d_kstat, 0, sizeof(int32_t), NULL));
     uint32_t iter = 0;
     int loop = 1;
+    if (K == 1) {
+        /* One cluster: every read is in it whatever the centroid is (cluster.c:75-98 finds the nearest of one), so there is
+         * no assignment pass, and the column sums the reference's loop accumulates (cluster.c:100-131) are read off the PMF
+         * counters - sum over reads of X_s = sum over x of x * #(X_s = x), exact integers - instead of costing passes over
+         * the matrix of their own. The second iteration the reference runs when the first moved the centroid by more than
+         * the threshold recomputes the same sums: it moves by 0. */
+        const size_t words = (size_t)C * A * A;
+        uint64_t *h_col = NULL;
+        if (!job->counted && (rc = qvz_job_stats(job))) goto done;
+        h_col = (uint64_t *)malloc(words * sizeof(uint64_t));
+        if (!h_col) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        if (job->d_cnt64) {
+            if (qvz_hip_copy_d2h(h_col, job->d_cnt64, words * sizeof(uint64_t), NULL) || qvz_hip_stream_sync(NULL)) { free(h_col); rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+        } else {
+            uint32_t *h32 = (uint32_t *)h_col;                                   /* widened in place, from the top down */
+            if (qvz_hip_copy_d2h(h32, job->d_cnt, words * sizeof(uint32_t), NULL) || qvz_hip_stream_sync(NULL)) { free(h_col); rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; }
+            for (size_t i = words; i-- > 0;) h_col[i] = h32[i];
+        }
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < C; ++s) {
+            uint64_t sum = 0;
+            for (uint32_t p = 0; p < A; ++p)
+                for (uint32_t x = 0; x < A; ++x) sum += (uint64_t)x * h_col[((size_t)s * A + p) * A + x];
+            job->h_acc[s] = sum;
+        }
+        for (size_t i = 0; i < (size_t)A * A; ++i) total += h_col[i];           /* column 0's tile: one count per read */
+        free(h_col);
+        job->h_counts[0] = (uint32_t)N;
+        HIP(qvz_hip_copy_h2d(job->d_acc, job->h_acc, (size_t)C * sizeof(uint64_t), NULL));
+        HIP(qvz_hip_copy_h2d(job->d_counts, job->h_counts, sizeof(uint32_t), NULL));
+        if (job->allreduce) {
+            HIP(qvz_hip_copy_h2d(job->d_counts64, &total, sizeof(uint64_t), NULL));
+            HIP(qvz_hip_kmeans_update64(job->d_acc, job->d_counts64, K, C, job->d_means, job->d_moved, job->d_kstat, NULL));
+        } else
+        HIP(qvz_hip_kmeans_update(job->d_acc, job->d_counts, K, C, job->d_means, job->d_moved, job->d_kstat, NULL));
+        HIP(qvz_hip_copy_d2h(h_moved, job->d_moved, (K + 1) * sizeof(double), NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+        iter = h_moved[0] > job->opts.cluster_threshold ? 2 : 1;                /* cluster.c:230-233 */
+        if (job->opts.verbose) {
+            printf("Cluster 0 moved %f.\n\n", h_moved[1]);                      /* cluster.c:126-127, :236-238 */
+            if (iter == 2) printf("Cluster 0 moved %f.\n\n", 0.0);
+        }
+        loop = 0;
+    }
     while (iter < 1000 && loop) {                                               /* cluster.c:221, cluster.h:9 */
         int32_t kstat = 0;
         HIP(qvz_hip_memset(job->d_counts, 0, K * sizeof(uint32_t), NULL));
@@ -265,8 +279,10 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
     if (job->opts.verbose) printf("\nTotal number of iterations: %d.\n", iter); /* cluster.c:241-243 */
     job->kmeans_iterations = iter;
     HIP(qvz_hip_copy_d2h(job->h_means, job->d_means, (size_t)K * C, NULL));
-    HIP(qvz_hip_copy_d2h(job->h_counts, job->d_counts, K * sizeof(uint32_t), NULL));
-    HIP(qvz_hip_copy_d2h(job->h_acc, job->d_acc, (size_t)K * C * sizeof(uint64_t), NULL));
+    if (K > 1) {
+        HIP(qvz_hip_copy_d2h(job->h_counts, job->d_counts, K * sizeof(uint32_t), NULL));
+        HIP(qvz_hip_copy_d2h(job->h_acc, job->d_acc, (size_t)K * C * sizeof(uint64_t), NULL));
+    }
     if (want_host_labels) {
         job->h_labels = (uint8_t *)malloc(N);
         if (!job->h_labels) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
@@ -284,6 +300,7 @@ int qvz_job_stats(qvz_job_t *job) {
     int rc = 0;
     const double t0 = now();
     const size_t words = (size_t)job->K * job->C * A * A;
+    if (job->counted) return 0;
     if ((rc = qvz_job_upload(job))) return rc;
     HIP(qvz_hip_malloc((void **)&job->d_cnt, words * sizeof(uint32_t)));
     HIP(qvz_hip_memset(job->d_cnt, 0, words * sizeof(uint32_t), NULL));
@@ -300,25 +317,65 @@ done:
     return rc;
 }
 
+/* One cluster's generation: a chain of small kernels and host round trips (qvz_codebook.hip). The clusters' codebooks are
+ * independent, so with several clusters each gets a host thread and a stream of its own. */
+typedef struct {
+    qvz_job_t *job;
+    uint32_t j;
+    void *stream;
+    int rc;
+    uint64_t deferred;
+    char err[256];
+} cb_task_t;
+
+static void *cb_task(void *arg) {
+    cb_task_t *t = (cb_task_t *)arg;
+    qvz_job_t *job = t->job;
+    const size_t tile = (size_t)job->C * A * A;
+    int rc = qvz_hip_set_device(job->opts.device);                              /* the device is a per-thread setting */
+    if (!rc)
+        rc = job->d_cnt64 ? qvz_hip_generate_codebook64(job->d_cnt64 + t->j * tile, job->C, job->h_dist, job->opts.mode, job->opts.ratio, 0.0,
+                                                        job->cbs[t->j], t->stream)
+                          : qvz_hip_generate_codebook(job->d_cnt + t->j * tile, job->C, job->h_dist, job->opts.mode, job->opts.ratio, 0.0,
+                                                      job->cbs[t->j], t->stream);
+    t->rc = rc;
+    if (rc) snprintf(t->err, sizeof(t->err), "codebook of cluster %u: %s", t->j, qvz_hip_last_error());
+    t->deferred = qvz_hip_codebook_deferred_decisions();
+    return NULL;
+}
+
 int qvz_job_codebooks(qvz_job_t *job) {
     int rc = 0;
     const double t0 = now();
+    const uint32_t K = job->K;
+    cb_task_t *task = NULL;
+    pthread_t *th = NULL;
     if (!job->counted && (rc = qvz_job_stats(job))) return rc;
-    job->cbs = (qvz_codebook_t **)calloc(job->K, sizeof(*job->cbs));
-    if (!job->cbs) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
-    for (uint32_t j = 0; j < job->K; ++j) {
+    job->cbs = (qvz_codebook_t **)calloc(K, sizeof(*job->cbs));
+    task = (cb_task_t *)calloc(K, sizeof(*task));
+    th = (pthread_t *)calloc(K, sizeof(*th));
+    if (!job->cbs || !task || !th) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+    for (uint32_t j = 0; j < K; ++j) {
         job->cbs[j] = qvz_codebook_alloc(job->C);
         if (!job->cbs[j]) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        if (job->d_cnt64)
-            HIP(qvz_hip_generate_codebook64(job->d_cnt64 + (size_t)j * job->C * A * A, job->C, job->h_dist, job->opts.mode,
-                                            job->opts.ratio, 0.0, job->cbs[j], NULL));
-        else
-        HIP(qvz_hip_generate_codebook(job->d_cnt + (size_t)j * job->C * A * A, job->C, job->h_dist, job->opts.mode,
-                                      job->opts.ratio, 0.0, job->cbs[j], NULL));
-        job->deferred_decisions += qvz_hip_codebook_deferred_decisions();
+        task[j].job = job; task[j].j = j;
+    }
+    HIP(qvz_hip_stream_sync(NULL));                                            /* the counters are complete */
+    /* cluster 0 on the calling thread and the default stream, the others on threads and streams of their own */
+    for (uint32_t j = 1; j < K; ++j) {
+        if (qvz_hip_stream_create(&task[j].stream)) task[j].stream = NULL;     /* no stream: the default one, in turn */
+        if (pthread_create(&th[j], NULL, cb_task, &task[j])) { th[j] = 0; cb_task(&task[j]); }
+    }
+    cb_task(&task[0]);
+    for (uint32_t j = 1; j < K; ++j) if (th[j]) pthread_join(th[j], NULL);
+    for (uint32_t j = 0; j < K; ++j) {
+        if (task[j].stream) qvz_hip_stream_destroy(task[j].stream);
+        if (task[j].rc && !rc) rc = qvz_job_fail(task[j].rc, "%s", task[j].err);
+        job->deferred_decisions += task[j].deferred;
     }
     job->t_codebook = now() - t0;
 done:
+    free(task); free(th);
     return rc;
 }
 
@@ -527,31 +584,106 @@ done:
     return rc;
 }
 
+/* The WELL state of the file (qv_stream.c:70-89) and its draw matrix. The draws depend on the seed only, so they are
+ * generated on a side stream beside the codebook generation (small latency-bound kernels and host round trips): 25 ms of
+ * generator and transposition kernels at 100M x 150 that the quantizer would otherwise wait for. */
+int qvz_job_start_draws(qvz_job_t *job) {
+    int rc = 0;
+    if (job->d_draws) return 0;
+    if (!job->well_chosen) {
+        if (job->opts.seed_mode == QVZ_SEED_EXPLICIT) {
+            memcpy(job->well_state, job->opts.well_state, sizeof(job->well_state));
+        } else {
+            srand((uint32_t)time(0));                                          /* qv_stream.c:77 (also in -DDEBUG builds) */
+            for (int i = 0; i < 32; ++i) job->well_state[i] = job->opts.seed_mode == QVZ_SEED_DEBUG ? 0x55555555u : (uint32_t)rand();
+        }
+        job->well_chosen = 1;
+    }
+    HIP(qvz_hip_set_device(job->opts.device));
+    HIP(qvz_hip_malloc((void **)&job->d_draws, (size_t)job->C * job->ld));
+    /* The runtime spreads streams over a few hardware queues and a queue runs its kernels in order: a side stream that
+     * shares the default stream's queue would put the generator IN FRONT of the codebook kernels instead of beside them
+     * (DESIGN.md section 8). A candidate is probed (~1 ms) and dropped for the next one if it does not overlap. */
+    {
+        void *cand[8] = {NULL};
+        int n = 0, good = -1;
+        while (n < 8 && good < 0) {
+            int overlap = 0;
+            if (qvz_hip_stream_create(&cand[n])) break;
+            if (qvz_hip_streams_overlap(cand[n], NULL, &overlap) == QVZ_OK && overlap) good = n;
+            ++n;
+        }
+        if (good < 0 && n > 0) good = n - 1;
+        for (int i = 0; i < n; ++i) if (i != good) qvz_hip_stream_destroy(cand[i]);
+        if (good < 0) { rc = qvz_job_fail(QVZ_E_HIP, "no stream for the WELL draws: %s", qvz_hip_last_error()); goto done; }
+        job->well_stream = cand[good];
+    }
+    HIP(qvz_hip_stream_wait(job->well_stream, NULL));
+    HIP(qvz_hip_well_draws(job->well_state, job->first_read, job->N, job->C, job->d_draws, job->ld, job->well_stream));
+done:
+    return rc;
+}
+
+/* what runs beside the coder kernels, each on a host thread of its own */
+typedef struct {
+    int device, rc;
+    FILE *fu;
+    const uint8_t *d_qv;
+    const double *d_err;
+    uint64_t N, ld;
+    uint32_t C;
+    double sum, *keep;
+    char err[256];
+} side_task_t;
+
+static void *side_text(void *arg) {
+    side_task_t *t = (side_task_t *)arg;
+    t->rc = qvz_hip_set_device(t->device);
+    if (!t->rc) t->rc = qvz_egress_text(t->fu, t->d_qv, t->N, t->C, t->ld, NULL);
+    if (t->rc) snprintf(t->err, sizeof(t->err), "-u text: %s", qvz_encode_last_error());
+    return NULL;
+}
+
+static void *side_errors(void *arg) {
+    side_task_t *t = (side_task_t *)arg;
+    t->rc = qvz_hip_set_device(t->device);
+    if (!t->rc) t->rc = qvz_sum_errors(t->d_err, t->N, t->C, &t->sum, t->keep, NULL);
+    if (t->rc) snprintf(t->err, sizeof(t->err), "per-read errors: %s", qvz_encode_last_error());
+    return NULL;
+}
+
 /* start_qv_compression for sharded output (option B): the whole matrix is quantized on the GPU,
- * `shards` contiguous read ranges are coded as independent streams by the GPU coder (qvz_hip_encode_planes), and every
- * stream is written as a complete reference-format file "<prefix>.<g>" (header with the shard's line count, the whole
- * file's codebooks, the WELL state advanced to the shard's first draw, the stream): the unmodified reference decoder
- * decodes each, and the decodes concatenate to the -u text. The distortion is the reference's sequential sum. */
+ * `shards` contiguous read ranges are coded as independent streams by the GPU coder (qvz_hip_encode_planes), and the
+ * streams are written as one shard set, or every stream as a complete reference-format file "<prefix>.<g>" (header with
+ * the shard's line count, the whole file's codebooks, the WELL state advanced to the shard's first draw, the stream): the
+ * unmodified reference decoder decodes each, and the decodes concatenate to the -u text.
+ *
+ * Schedule (the one qvz_amd/pipeline.py measures, plus the products' way out): the WELL draws were started beside the
+ * codebooks (qvz_job_start_draws); quantizer; then, side by side, the coder kernels (two streams of their own inside
+ * qvz_hip_encode_planes), the -u text leaving through pinned slabs into the file (qvz_egress_text) and the per-read
+ * errors summed in file order on one host core (qvz_sum_errors: the reference's sequential sum, qv_compressor.c:127,
+ * 139-140); at the end the streams, packed back to back, through pinned slabs into the output. No N-sized host buffer. */
 static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
                                  uint64_t *file_bytes, double *distortion_out) {
     int rc = 0;
     const double t0 = now();
+    double t1, t2;
     const uint32_t C = job->C, K = job->K;
-    const uint64_t N = job->N, ld = job->ld, stride = (uint64_t)C + 1;
+    const uint64_t N = job->N, ld = job->ld;
     uint16_t *d_ct = NULL, *d_qs = NULL, *h_ct = NULL, *h_qs = NULL;
-    double *d_dist = NULL, *d_err = NULL, *h_err = NULL;
-    uint8_t *d_draws = NULL, *d_qv = NULL, *d_qi = NULL, *d_st = NULL, *d_out = NULL, *d_text = NULL, *h_buf = NULL, *image = NULL;
+    double *d_dist = NULL, *d_err = NULL;
+    uint8_t *d_qv = NULL, *d_qi = NULL, *d_st = NULL, *d_out = NULL, *d_packed = NULL, *h_buf = NULL, *image = NULL;
     int32_t *d_status = NULL, status = 0;
     uint64_t *sizes = NULL, *first = NULL;
     uint32_t *wstates = NULL;
+    pthread_t th_text, th_err;
+    int text_running = 0, err_running = 0;
+    side_task_t task_text, task_err;
+    memset(&task_text, 0, sizeof(task_text));
+    memset(&task_err, 0, sizeof(task_err));
     if (!shards || (!job->shard_bounds && shards > qvz_shard_limit(N))) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads: a shard needs at least 4 reads", shards, (unsigned long long)N);
 
-    if (job->opts.seed_mode == QVZ_SEED_EXPLICIT) {                             /* qv_stream.c:70-89 */
-        memcpy(job->well_state, job->opts.well_state, sizeof(job->well_state));
-    } else {
-        srand((uint32_t)time(0));
-        for (int i = 0; i < 32; ++i) job->well_state[i] = job->opts.seed_mode == QVZ_SEED_DEBUG ? 0x55555555u : (uint32_t)rand();
-    }
+    if ((rc = qvz_job_start_draws(job))) goto done;                            /* already running when the caller started them */
     {
         const size_t ctn = (size_t)K * C * QVZ_CT_STRIDE, qsn = (size_t)K * C * QVZ_QS_STRIDE;
         h_ct = (uint16_t *)malloc(ctn * sizeof(uint16_t));
@@ -570,50 +702,42 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     }
     if (job->shard_bounds) memcpy(first, job->shard_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
     else qvz_shard_bounds(N, shards, first);
-    /* WELL draws (this part's first draw is first_read * C draws into the file's stream), quantizer */
-    HIP(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
-    HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
+    /* quantizer: the qv plane (the -u product) only for a caller that wants the text */
+    if (fu) HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
     HIP(qvz_hip_malloc((void **)&d_qi, (size_t)C * ld));
     HIP(qvz_hip_malloc((void **)&d_st, (size_t)C * ld));
     HIP(qvz_hip_malloc((void **)&d_err, N * sizeof(double)));
     HIP(qvz_hip_malloc((void **)&d_status, sizeof(int32_t)));
     HIP(qvz_hip_memset(d_status, 0, sizeof(int32_t), NULL));
-    HIP(qvz_hip_well_draws(job->well_state, job->first_read, N, C, d_draws, ld, NULL));
-    HIP(qvz_hip_quantize(job->d_sym, K > 1 ? job->d_labels : NULL, N, C, ld, K, d_ct, d_qs, d_draws, ld, d_dist, d_qv, d_qi, d_st,
+    HIP(qvz_hip_stream_wait(NULL, job->well_stream));                          /* the draws, on the device's side */
+    HIP(qvz_hip_quantize(job->d_sym, K > 1 ? job->d_labels : NULL, N, C, ld, K, d_ct, d_qs, job->d_draws, ld, d_dist, d_qv, d_qi, d_st,
                          ld, d_err, d_status, NULL));
     HIP(qvz_hip_copy_d2h(&status, d_status, sizeof(status), NULL));
     HIP(qvz_hip_stream_sync(NULL));
     if (status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
-    qvz_hip_free(d_draws); d_draws = NULL;
-    {   /* distortion: the reference's sequential sum over reads (qv_compressor.c:127,139-140) */
-        double distortion = 0.0;
-        h_err = (double *)malloc(N * sizeof(double));
-        if (!h_err) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        HIP(qvz_hip_copy_d2h(h_err, d_err, N * sizeof(double), NULL));
-        HIP(qvz_hip_stream_sync(NULL));
-        for (uint64_t i = 0; i < N; ++i) distortion += h_err[i] / ((double)C);
-        if (distortion_out) *distortion_out = distortion / ((double)N);
-        if (job->collect) { job->out_err = h_err; h_err = NULL; }               /* the caller sums all parts in file order */
-        free(h_err); h_err = NULL;
-        qvz_hip_free(d_err); d_err = NULL;
+    qvz_hip_free(job->d_draws); job->d_draws = NULL;
+    t1 = now();
+    job->t_quantize = t1 - t0;
+
+    /* beside the coder: per-read errors (file-order sum on one host core) and the -u text (pinned slabs -> file) */
+    task_err.device = task_text.device = job->opts.device;
+    task_err.d_err = d_err; task_err.N = N; task_err.C = C;
+    if (job->collect) {
+        job->out_err = (double *)malloc(N * sizeof(double));                    /* the caller sums all parts in file order */
+        if (!job->out_err) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        task_err.keep = job->out_err;
     }
-    if (fu) {                                                                   /* -u text (qv_compressor.c:100-125) */
-        h_buf = (uint8_t *)malloc(N * stride);
-        if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        HIP(qvz_hip_malloc((void **)&d_text, N * stride));
-        HIP(qvz_hip_untranspose_text(d_qv, N, C, ld, d_text, NULL));
-        HIP(qvz_hip_copy_d2h(h_buf, d_text, N * stride, NULL));
-        HIP(qvz_hip_stream_sync(NULL));
-        if (fwrite(h_buf, 1, N * stride, fu) != N * stride) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
-        free(h_buf); h_buf = NULL;
-        qvz_hip_free(d_text); d_text = NULL;
+    err_running = pthread_create(&th_err, NULL, side_errors, &task_err) == 0;
+    if (fu) {
+        task_text.fu = fu; task_text.d_qv = d_qv; task_text.N = N; task_text.C = C; task_text.ld = ld;
+        text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
     }
-    qvz_hip_free(d_qv); d_qv = NULL;
     {   /* coding. Room per stream: 6 bits per symbol to begin with (real data needs 1-2); a stream that outgrows it
          * (-r above 6, near-uniform input) makes the coder report QVZ_E_NOMEM and the call is repeated with twice the room,
          * up to the 22 bits per symbol no symbol can exceed (counts >= 1 of n <= 2^19 + 8, plus the flush) */
-        const uint64_t per = (N + shards - 1) / shards + 4;
-        uint64_t cap = 0, total = 0, ftotal = 0;
+        uint64_t per = 0, cap = 0, total = 0, ftotal = 0;
+        for (uint32_t g = 0; g < shards; ++g) if (first[g + 1] - first[g] > per) per = first[g + 1] - first[g];
+        per += 4;
         for (uint32_t bits = 6; ; bits *= 2) {
             cap = ((per * C * bits) / 8 + 512 + 3) & ~3ull;
             qvz_hip_free(d_out); d_out = NULL;
@@ -623,32 +747,45 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
             if (crc == QVZ_OK) break;
             if (crc != QVZ_E_NOMEM || bits >= 24) { rc = qvz_job_fail(crc, "%s", qvz_hip_last_error()); goto done; }
         }
+        t2 = now();
+        job->t_coder = t2 - t1;
         for (uint32_t g = 0; g < shards; ++g) total += sizes[g];
         /* the streams leave the device packed back to back: 1-2 bits per symbol instead of the 6 the area was sized for */
         qvz_hip_free(d_qi); d_qi = NULL;
         qvz_hip_free(d_st); d_st = NULL;
-        HIP(qvz_hip_malloc((void **)&d_text, total ? total : 1));
-        HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_text, NULL));
-        h_buf = (uint8_t *)malloc(total ? total : 1);
-        if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        HIP(qvz_hip_copy_d2h(h_buf, d_text, total, NULL));
-        HIP(qvz_hip_stream_sync(NULL));
+        HIP(qvz_hip_malloc((void **)&d_packed, total ? total : 1));
+        HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_packed, NULL));
+        if (err_running) { pthread_join(th_err, NULL); err_running = 0; } else side_errors(&task_err);
+        if (task_err.rc) { rc = qvz_job_fail(task_err.rc, "%s", task_err.err); goto done; }
+        if (distortion_out) *distortion_out = task_err.sum / ((double)N);      /* qv_compressor.c:139-140 */
+        if (fu) {
+            if (text_running) { pthread_join(th_text, NULL); text_running = 0; } else side_text(&task_text);
+            if (task_text.rc) { rc = qvz_job_fail(task_text.rc, "%s", task_text.err); goto done; }
+        }
         if (job->collect) {                                                     /* a part of a file: the caller assembles the whole */
+            h_buf = (uint8_t *)malloc(total ? total : 1);
+            if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+            HIP(qvz_hip_copy_d2h(h_buf, d_packed, total, NULL));
+            HIP(qvz_hip_stream_sync(NULL));
             job->out_streams = h_buf; h_buf = NULL;
             job->out_sizes = sizes; sizes = NULL;
         } else if (fset) {                                                      /* one shard set: codebooks once (qvz_shardset.h) */
             qvz_shardset_info_t si;
-            if ((rc = qvz_shardset_write(fset, K, C, N, shards, job->well_state, (const qvz_codebook_t *const *)job->cbs, h_buf, 0, sizes, &si))) goto done;
+            if ((rc = qvz_shardset_write_head(fset, K, C, N, shards, job->well_state, (const qvz_codebook_t *const *)job->cbs, sizes, &si))) goto done;
+            if ((rc = qvz_egress_bytes(fset, d_packed, total, NULL))) goto done;
             ftotal = si.file_bytes;
         } else {                                                                /* one reference-format file per shard */
             uint64_t img_cap = 0;
             uint64_t *jump = (uint64_t *)malloc((size_t)shards * sizeof(uint64_t));
             wstates = (uint32_t *)malloc((size_t)shards * 128);
-            if (!jump || !wstates) { free(jump); rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-            for (uint32_t g = 0; g < shards; ++g) jump[g] = first[g] * C / 4;   /* generator at the shard's first draw, n = 0 */
+            h_buf = (uint8_t *)malloc(total ? total : 1);
+            if (!jump || !wstates || !h_buf) { free(jump); rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+            for (uint32_t g = 0; g < shards; ++g) jump[g] = (job->first_read + first[g]) * C / 4;   /* generator at the shard's first draw, n = 0 */
             const int jrc = qvz_hip_well_jump_many(job->well_state, jump, shards, wstates);
             free(jump);
             if (jrc) { rc = qvz_job_fail(jrc, "%s", qvz_hip_last_error()); goto done; }
+            HIP(qvz_hip_copy_d2h(h_buf, d_packed, total, NULL));
+            HIP(qvz_hip_stream_sync(NULL));
             uint64_t at = 0;
             for (uint32_t g = 0; g < shards; at += sizes[g], ++g) {
                 char name[4096];
@@ -673,12 +810,17 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         }
         if (stream_bytes) *stream_bytes = total;
         if (file_bytes) *file_bytes = ftotal;
+        job->t_egress = now() - t2;
     }
     job->t_encode = now() - t0;
 done:
-    free(h_ct); free(h_qs); free(sizes); free(first); free(h_err); free(h_buf); free(image); free(wstates);
-    qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist); qvz_hip_free(d_err); qvz_hip_free(d_draws); qvz_hip_free(d_qv);
-    qvz_hip_free(d_qi); qvz_hip_free(d_st); qvz_hip_free(d_out); qvz_hip_free(d_text); qvz_hip_free(d_status);
+    if (err_running) pthread_join(th_err, NULL);                                /* they read device buffers freed below */
+    if (text_running) pthread_join(th_text, NULL);
+    free(h_ct); free(h_qs); free(sizes); free(first); free(h_buf); free(image); free(wstates);
+    qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist); qvz_hip_free(d_err); qvz_hip_free(d_qv);
+    qvz_hip_free(d_qi); qvz_hip_free(d_st); qvz_hip_free(d_out); qvz_hip_free(d_packed); qvz_hip_free(d_status);
+    if (job->d_draws) { qvz_hip_free(job->d_draws); job->d_draws = NULL; }
+    if (job->well_stream) { qvz_hip_stream_destroy(job->well_stream); job->well_stream = NULL; }
     return rc;
 }
 
@@ -698,6 +840,8 @@ void qvz_job_release(qvz_job_t *job) {
     qvz_hip_free(job->d_sym); qvz_hip_free(job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
     qvz_hip_free(job->d_counts); qvz_hip_free(job->d_acc); qvz_hip_free(job->d_moved); qvz_hip_free(job->d_kstat);
     qvz_hip_free(job->d_cnt64); qvz_hip_free(job->d_counts64);
+    qvz_hip_free(job->d_draws);
+    if (job->well_stream) qvz_hip_stream_destroy(job->well_stream);
     memset(job, 0, sizeof(*job));
 }
 
@@ -733,6 +877,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     if ((rc = qvz_job_kmeans(&job, 0))) goto done;
     if (opts->verbose) printf("Clustering took %.4f seconds\n", job.t_cluster);                      /* main.c:56-58 */
     if ((rc = qvz_job_stats(&job))) goto done;
+    if (shards && (rc = qvz_job_start_draws(&job))) goto done;                  /* the WELL generator runs beside the codebooks */
     if ((rc = qvz_job_codebooks(&job))) goto done;
     if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", job.t_stats + job.t_codebook);   /* main.c:66-67 */
     if (shards && !shard_prefix) {                                              /* one shard-set file */
@@ -752,6 +897,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     R.deferred_decisions = job.deferred_decisions;
     R.t_upload = job.t_upload; R.t_cluster = job.t_cluster; R.t_stats = job.t_stats; R.t_codebook = job.t_codebook;
     R.t_encode = job.t_encode;
+    R.t_quantize = job.t_quantize; R.t_coder = job.t_coder; R.t_egress = job.t_egress;
     R.t_total = now() - t_start;
     if (opts->verbose) {                                                       /* main.c:96-121 */
         switch (opts->distortion) {

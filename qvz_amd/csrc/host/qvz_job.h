@@ -39,6 +39,12 @@ typedef struct qvz_job {
     int32_t *d_kstat;
     int uploaded, clustered, counted;
     double t_upload, t_cluster, t_stats, t_codebook, t_encode;
+    double t_quantize, t_coder, t_egress;   /* inside t_encode of a sharded encode: WELL wait + quantizer, coder kernels, what leaves the device afterwards */
+    /* WELL draws of the whole part, started on a side stream before the codebooks are generated (they depend on the seed
+     * only; qvz_job_start_draws), waited for by the quantizer */
+    uint8_t *d_draws;
+    void *well_stream;
+    int well_chosen;
     /* ---- a job that holds PART of a file (one device of a multi-device encode, qvz_multi.c); all zero otherwise ---- */
     uint64_t first_read;        /* global number of this job's first read: WELL offset of its draws (a multiple of 4)         */
     const uint8_t *centroid_rows;  /* [K][C+1] text rows of the k centroid reads, wherever in the file they lie (cluster.c:198-201) */
@@ -75,7 +81,20 @@ int qvz_job_compress_sharded(qvz_job_t *job, const char *prefix, FILE *fu, uint3
 /* the same streams as ONE shard-set file (include/qvz_shardset.h): codebooks stored once */
 int qvz_job_compress_shardset(qvz_job_t *job, FILE *fout, FILE *fu, uint32_t shards, uint64_t *stream_bytes,
                               uint64_t *file_bytes, double *distortion);
+/* Chooses the WELL state (qv_stream.c:70-89) and starts generating the part's draw matrix on a side stream; called before
+ * qvz_job_codebooks so that the generator runs beside it (the sharded compress calls it itself otherwise). */
+int qvz_job_start_draws(qvz_job_t *job);
 void qvz_job_release(qvz_job_t *job);
+
+/* ---- qvz_egress.c: products leaving the device in slabs (pinned double buffers, threaded file writes) ---- */
+/* `after`: a stream whose work so far must be finished before the device data is read - waited for on the device,
+ * not by the host; NULL: the data is complete already */
+int qvz_egress_text(FILE *fu, const uint8_t *d_qv, uint64_t N, uint32_t C, uint64_t ld, void *after);   /* -u rows at fu's position */
+int qvz_egress_bytes(FILE *f, const uint8_t *d_src, uint64_t bytes, void *after);
+int qvz_sum_errors(const double *d_err, uint64_t N, uint32_t C, double *sum_out, double *keep, void *after);
+int qvz_parallel_pwrite(int fd, const uint8_t *buf, size_t n, int64_t off);
+void qvz_parallel_memcpy(uint8_t *dst, const uint8_t *src, size_t n);
+int qvz_ingress_bytes(uint8_t *d_dst, const uint8_t *h_src, uint64_t bytes);
 
 /* ---- decode side, shared by qvz_decode.c, qvz_shardset.c and qvz_compat.c ---- */
 typedef struct qvz_qfile {

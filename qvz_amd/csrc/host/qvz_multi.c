@@ -220,6 +220,7 @@ static void *part_main(void *arg) {
     STAGE(qvz_job_upload(&p->job));
     STAGE(qvz_job_kmeans(&p->job, 0));
     STAGE(qvz_job_stats(&p->job));
+    if (!p->rc && (rc = qvz_job_start_draws(&p->job))) part_fail(p, rc);        /* this part's WELL draws, beside the codebooks */
     if (p->part == 0) {                                          /* identical on every device: generated once */
         if (!p->rc && (rc = qvz_job_codebooks(&p->job))) part_fail(p, rc);
         *p->cbs_slot = p->job.cbs;

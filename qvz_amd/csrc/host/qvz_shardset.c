@@ -18,10 +18,10 @@ int qvz_shardset_is(const uint8_t *buf, size_t size) {
     return buf && size >= QVZ_SHARDSET_FIXED && memcmp(buf, QVZ_SHARDSET_MAGIC, 8) == 0;
 }
 
-int qvz_shardset_write(FILE *f, uint32_t clusters, uint32_t columns, uint64_t lines, uint32_t shards,
-                       const uint32_t *well_state, const qvz_codebook_t *const *cbs, const uint8_t *streams,
-                       uint64_t stride, const uint64_t *sizes, qvz_shardset_info_t *info) {
-    if (!f || !clusters || !columns || !shards || !well_state || !cbs || !streams || !sizes) return qvz_job_fail(QVZ_E_ARG, "bad shard-set arguments");
+int qvz_shardset_write_head(FILE *f, uint32_t clusters, uint32_t columns, uint64_t lines, uint32_t shards,
+                            const uint32_t *well_state, const qvz_codebook_t *const *cbs, const uint64_t *sizes,
+                            qvz_shardset_info_t *info) {
+    if (!f || !clusters || !columns || !shards || !well_state || !cbs || !sizes) return qvz_job_fail(QVZ_E_ARG, "bad shard-set arguments");
     const size_t hbytes = QVZ_SHARDSET_FIXED + (size_t)shards * 8;
     uint8_t *head = (uint8_t *)calloc(1, hbytes);
     uint8_t *cbuf = NULL;
@@ -47,12 +47,6 @@ int qvz_shardset_write(FILE *f, uint32_t clusters, uint32_t columns, uint64_t li
         cb_total += sz;
     }
     for (uint32_t g = 0; g < shards; ++g) st_total += sizes[g];
-    if (stride == 0) {                                                          /* packed: one write */
-        if (st_total && fwrite(streams, 1, st_total, f) != st_total) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
-    } else {
-        for (uint32_t g = 0; g < shards; ++g)
-            if (sizes[g] && fwrite(streams + (size_t)g * stride, 1, sizes[g], f) != sizes[g]) { rc = qvz_job_fail(QVZ_E_ARG, "write failed"); goto done; }
-    }
     if (info) {
         memset(info, 0, sizeof(*info));
         info->clusters = clusters; info->columns = columns; info->shards = shards; info->lines = lines;
@@ -62,6 +56,23 @@ int qvz_shardset_write(FILE *f, uint32_t clusters, uint32_t columns, uint64_t li
 done:
     free(head);
     return rc;
+}
+
+int qvz_shardset_write(FILE *f, uint32_t clusters, uint32_t columns, uint64_t lines, uint32_t shards,
+                       const uint32_t *well_state, const qvz_codebook_t *const *cbs, const uint8_t *streams,
+                       uint64_t stride, const uint64_t *sizes, qvz_shardset_info_t *info) {
+    qvz_shardset_info_t si;
+    if (!streams) return qvz_job_fail(QVZ_E_ARG, "bad shard-set arguments");
+    const int rc = qvz_shardset_write_head(f, clusters, columns, lines, shards, well_state, cbs, sizes, &si);
+    if (rc) return rc;
+    if (stride == 0) {                                                          /* packed: one write */
+        if (si.stream_bytes && fwrite(streams, 1, si.stream_bytes, f) != si.stream_bytes) return qvz_job_fail(QVZ_E_ARG, "write failed");
+    } else {
+        for (uint32_t g = 0; g < shards; ++g)
+            if (sizes[g] && fwrite(streams + (size_t)g * stride, 1, sizes[g], f) != sizes[g]) return qvz_job_fail(QVZ_E_ARG, "write failed");
+    }
+    if (info) *info = si;
+    return QVZ_OK;
 }
 
 /* a shard set in memory: header fields, parsed codebooks, where the streams lie */

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_transpose_text(const uint8_t *__restric
     if (nbad) atomicAdd(bad, nbad);
 }
 
-__global__ __launch_bounds__(256) void k_untranspose_text(const uint8_t *__restrict__ Q, uint64_t n, uint32_t C,
+// rows [first, first + n) of the matrix Q (ld reads per column) as text rows 0 .. n-1 (first must be a multiple of 4)
+__global__ __launch_bounds__(256) void k_untranspose_text(const uint8_t *__restrict__ Q, uint64_t first, uint64_t n, uint32_t C,
                                                           uint64_t ld, uint8_t *__restrict__ text) {
     __shared__ uint8_t tile[TT_COLS * TT_PITCH];
     const uint64_t row0 = (uint64_t)blockIdx.x * TT_ROWS;
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) void k_untranspose_text(const uint8_t *__restr
     for (uint32_t i = threadIdx.x; i < TT_COLS * (TT_ROWS / 4); i += 256) {
         uint32_t cc = i >> 6, dw = i & 63;
         uint32_t v = 0;
-        if (col0 + cc < C && row0 + 4 * dw < ld)
-            v = *reinterpret_cast<const uint32_t *>(Q + (uint64_t)(col0 + cc) * ld + row0 + 4 * dw);
+        if (col0 + cc < C && first + row0 + 4 * dw < ld)
+            v = *reinterpret_cast<const uint32_t *>(Q + (uint64_t)(col0 + cc) * ld + first + row0 + 4 * dw);
         *reinterpret_cast<uint32_t *>(&tile[cc * TT_PITCH + 4 * dw]) = v;
     }
     __syncthreads();
@@ -188,15 +189,22 @@ extern "C" int qvz_hip_transpose_text(const uint8_t *d_text, uint64_t n, uint32_
     return QVZ_OK;
 }
 
-extern "C" int qvz_hip_untranspose_text(const uint8_t *d_qv, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text,
-                                        void *stream) {
+extern "C" int qvz_hip_untranspose_rows(const uint8_t *d_qv, uint64_t first, uint64_t n, uint32_t c, uint64_t ld,
+                                        uint8_t *d_text, void *stream) {
     int rc = check_matrix(n, c, ld);
     if (rc) return rc;
+    if ((first & 3) || first + n > ld) return qvz_set_error(QVZ_E_ARG, "rows [%llu, +%llu) of a matrix with ld=%llu (the first row must be a multiple of 4)",
+                                                            (unsigned long long)first, (unsigned long long)n, (unsigned long long)ld);
     // one extra column slot so that some lane owns column index C (the '\n')
     dim3 grid((unsigned)((n + TT_ROWS - 1) / TT_ROWS), (c + 1 + TT_COLS - 1) / TT_COLS);
-    hipLaunchKernelGGL(k_untranspose_text, grid, dim3(256), 0, (hipStream_t)stream, d_qv, n, c, ld, d_text);
+    hipLaunchKernelGGL(k_untranspose_text, grid, dim3(256), 0, (hipStream_t)stream, d_qv, first, n, c, ld, d_text);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
+}
+
+extern "C" int qvz_hip_untranspose_text(const uint8_t *d_qv, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text,
+                                        void *stream) {
+    return qvz_hip_untranspose_rows(d_qv, 0, n, c, ld, d_text, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1918,18 +1926,20 @@ extern "C" int qvz_hip_pack_feed(const uint8_t *d_qi, const uint8_t *d_st, uint6
 // memory / stream plumbing for host C callers
 // ------------------------------------------------------------------------------------------------
 // ---- streams out of the coder's fixed-stride area into one packed run (what goes to the host / into a shard set) ----
+// SCATTER: the inverse (packed run -> fixed-stride area), for the decoder
+template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_gather_streams(const uint8_t *__restrict__ in, uint64_t cap, const uint64_t *__restrict__ sizes,
                                                         const uint64_t *__restrict__ at, uint8_t *__restrict__ out) {
     const uint32_t g = blockIdx.x;
     const uint64_t sz = sizes[g];
-    const uint8_t *src = in + (uint64_t)g * cap;                 // 4-byte aligned (cap is a multiple of 4)
-    uint8_t *dst = out + at[g];                                  // any alignment
+    const uint8_t *src = SCATTER ? in + at[g] : in + (uint64_t)g * cap;     // the fixed-stride side is 4-byte aligned (cap is a multiple of 4)
+    uint8_t *dst = SCATTER ? out + (uint64_t)g * cap : out + at[g];         // the packed side has any alignment
     for (uint64_t i = (uint64_t)blockIdx.y * 256 + threadIdx.x; i < sz; i += (uint64_t)gridDim.y * 256) dst[i] = src[i];
 }
 
-extern "C" int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const uint64_t *h_sizes, uint32_t shards,
-                                      uint8_t *d_packed, void *stream) {
-    if (!d_coded || !h_sizes || !shards || !d_packed) return qvz_set_error(QVZ_E_ARG, "bad gather arguments");
+static int move_streams(bool scatter, const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint32_t shards,
+                        uint8_t *d_out, void *stream) {
+    if (!d_in || !h_sizes || !shards || !d_out) return qvz_set_error(QVZ_E_ARG, "bad gather / scatter arguments");
     hipStream_t st = (hipStream_t)stream;
     uint64_t *h = (uint64_t *)malloc((size_t)shards * 2 * sizeof(uint64_t)), *d = nullptr;
     if (!h) return qvz_set_error(QVZ_E_NOMEM, "host alloc");
@@ -1941,16 +1951,28 @@ extern "C" int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_s
     }
     hipError_t e = hipMalloc(&d, (size_t)shards * 2 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d, h, (size_t)shards * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && scatter) e = hipMemsetAsync(d_out, 0, (size_t)shards * cap_per_shard, st);   // a decoder looks a few bytes past a stream's end
     if (e == hipSuccess) {
         const unsigned ny = (unsigned)((longest + 16383) / 16384);       // 64 bytes per thread at most
-        hipLaunchKernelGGL(k_gather_streams, dim3(shards, ny ? ny : 1), dim3(256), 0, st, d_coded, cap_per_shard, d, d + shards, d_packed);
+        if (scatter) hipLaunchKernelGGL(k_gather_streams<true>, dim3(shards, ny ? ny : 1), dim3(256), 0, st, d_in, cap_per_shard, d, d + shards, d_out);
+        else hipLaunchKernelGGL(k_gather_streams<false>, dim3(shards, ny ? ny : 1), dim3(256), 0, st, d_in, cap_per_shard, d, d + shards, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);            // h and d go away below
     free(h);
     (void)hipFree(d);
-    if (e != hipSuccess) return qvz_set_error(QVZ_E_HIP, "qvz_hip_gather_streams: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return qvz_set_error(QVZ_E_HIP, "gather / scatter of streams: %s", hipGetErrorString(e));
     return QVZ_OK;
+}
+
+extern "C" int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const uint64_t *h_sizes, uint32_t shards,
+                                      uint8_t *d_packed, void *stream) {
+    return move_streams(false, d_coded, cap_per_shard, h_sizes, shards, d_packed, stream);
+}
+
+extern "C" int qvz_hip_scatter_streams(const uint8_t *d_packed, const uint64_t *h_sizes, uint32_t shards, uint8_t *d_coded,
+                                       uint64_t cap_per_shard, void *stream) {
+    return move_streams(true, d_packed, cap_per_shard, h_sizes, shards, d_coded, stream);
 }
 
 extern "C" int qvz_hip_set_device(int device) { QVZ_HIP_CHECK(hipSetDevice(device)); return QVZ_OK; }
@@ -2016,3 +2038,13 @@ extern "C" int qvz_hip_streams_overlap(void *stream_a, void *stream_b, int *over
 
 extern "C" int qvz_hip_stream_destroy(void *stream) { QVZ_HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); return QVZ_OK; }
 extern "C" int qvz_hip_stream_sync(void *stream) { QVZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); return QVZ_OK; }
+
+extern "C" int qvz_hip_stream_wait(void *stream, void *other) {
+    hipEvent_t ev;
+    QVZ_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)other);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+    (void)hipEventDestroy(ev);                                   // released once the recorded work has completed
+    QVZ_HIP_CHECK(e);
+    return QVZ_OK;
+}

@@ -24,7 +24,8 @@ class Result(C.Structure):
     _fields_ = [("lines", C.c_uint64), ("columns", C.c_uint32), ("stream_bytes", C.c_uint64),
                 ("file_bytes", C.c_uint64), ("distortion", C.c_double), ("kmeans_iterations", C.c_uint32),
                 ("deferred_decisions", C.c_uint64), ("t_upload", C.c_double), ("t_cluster", C.c_double),
-                ("t_stats", C.c_double), ("t_codebook", C.c_double), ("t_encode", C.c_double), ("t_total", C.c_double)]
+                ("t_stats", C.c_double), ("t_codebook", C.c_double), ("t_encode", C.c_double), ("t_total", C.c_double),
+                ("t_quantize", C.c_double), ("t_coder", C.c_double), ("t_egress", C.c_double)]
 
 
 def default_options():

@@ -52,3 +52,7 @@ int qvz_hip_untranspose_text(const uint8_t *d_qv, uint64_t n, uint32_t c, uint64
 int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, uint64_t n, uint32_t c, uint8_t *d_draws, uint64_t ld, void *stream) { U(h_state); U(first_read); U(n); U(c); U(d_draws); U(ld); U(stream); return nodev(); }
 int qvz_hip_well_jump_many(const uint32_t *h_state, const uint64_t *h_words, uint64_t count, uint32_t *h_states_out) { U(h_state); U(h_words); U(count); U(h_states_out); return nodev(); }
 int qvz_hip_widen_u32(const uint32_t *d_src, uint64_t *d_dst, uint64_t count, void *stream) { U(d_src); U(d_dst); U(count); U(stream); return nodev(); }
+int qvz_hip_stream_wait(void *stream, void *other) { U(stream); U(other); return nodev(); }
+int qvz_hip_streams_overlap(void *stream_a, void *stream_b, int *overlap) { U(stream_a); U(stream_b); U(overlap); return nodev(); }
+int qvz_hip_untranspose_rows(const uint8_t *d_qv, uint64_t first, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text, void *stream) { U(d_qv); U(first); U(n); U(c); U(ld); U(d_text); U(stream); return nodev(); }
+int qvz_hip_scatter_streams(const uint8_t *d_packed, const uint64_t *h_sizes, uint32_t shards, uint8_t *d_coded, uint64_t cap_per_shard, void *stream) { U(d_packed); U(h_sizes); U(shards); U(d_coded); U(cap_per_shard); U(stream); return nodev(); }

@@ -18,7 +18,7 @@ import golden_util as G
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
-HOST = ["qvz_coder", "qvz_decode", "qvz_fastq", "qvz_shardset", "qvz_shard", "qvz_encode", "qvz_multi", "qvz_codebook_host"]
+HOST = ["qvz_coder", "qvz_decode", "qvz_fastq", "qvz_shardset", "qvz_shard", "qvz_encode", "qvz_multi", "qvz_codebook_host", "qvz_egress"]
 SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
 # the harness must not see a GPU even where one exists (it links no HIP runtime; this is belt and braces)
 CPU_ONLY = {"HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "-1"}
