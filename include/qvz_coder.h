@@ -103,6 +103,14 @@ int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld,
 /* The same with the caller's cut of the n reads into `shards` ranges: h_bounds[0] = 0 < ... < h_bounds[shards] = n, every
  * bound but the last a multiple of 4 reads (NULL: qvz_shard_bounds(n, shards)). A device that holds reads
  * [first[a], first[b]) of a file cut by qvz_shard_bounds(N, S) codes its shards a .. b-1 with h_bounds[g] = first[a+g] - first[a]. */
+/* What a process's FIRST qvz_hip_encode_planes(_bounds) call does before its first kernel (code object load, the kept
+ * buffers sized and allocated, the model / coder stream pair made and probed: 40-50 ms), without coding anything, so that
+ * a one-shot process can do it on a host thread beside the quantizer. Same arguments as the call that follows. */
+int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs,
+                                  uint32_t shards, const uint64_t *h_bounds, uint64_t work_bytes);
+/* Record workspace (bytes) with which streams of up to longest_reads reads are coded in one segment; less means more
+ * segments (each costs the model kernel a table save and load). For callers that allocate d_work themselves. */
+uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards);
 int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                  uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                  const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work,

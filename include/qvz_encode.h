@@ -72,6 +72,10 @@ int qvz_fastq_qualities(const uint8_t *text, uint64_t bytes, uint8_t **rows_out,
  * column-major symbol matrix d_sym (c x ld, include/qvz_hip.h) through two pinned staging buffers: host copy, PCIe transfer
  * and the transposing kernel of consecutive chunks overlap. *bad_out: bytes outside '!'..'h' or rows without '\n'. */
 int qvz_ingest_rows(const uint8_t *text, uint64_t n, uint32_t c, uint8_t *d_sym, uint64_t ld, uint32_t *bad_out);
+/* The inverse: the reads of a column-major matrix in HBM (c x ld symbols, include/qvz_hip.h) written to `path` as text
+ * rows - how a -u text or a decoded file leaves the device: slab by slab through two pinned buffers, the file written by
+ * a few threads; no n * (c + 1)-byte buffer on either side. */
+int qvz_egress_rows(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, const char *path);
 
 /* text: the whole input file image (rows of c+1 bytes, or FASTQ: see input_format). fout receives the .q file, fu (may be
  * NULL) the -u text. */

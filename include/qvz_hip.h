@@ -56,6 +56,7 @@ int qvz_hip_device_count(void);
 /* Device memory / stream plumbing so that host C code (qvz_amd/csrc/host) needs no HIP headers.
  * The reference has no counterpart: it mmaps the input and callocs everything (src/lines.c:64,116). */
 int qvz_hip_set_device(int device);
+int qvz_hip_mem_info(uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the current device */
 int qvz_hip_malloc(void **d_ptr, size_t bytes);
 int qvz_hip_free(void *d_ptr);
 int qvz_hip_malloc_host(void **h_ptr, size_t bytes);   /* pinned host memory for async copies */

@@ -44,6 +44,7 @@ SIGNATURES = {
                                    C.c_uint64, f64p, u8p, u8p, u8p, C.c_uint64, f64p, C.c_void_p, C.c_void_p]),
     "qvz_hip_pack_feed": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, u16p, C.c_void_p]),
     "qvz_hip_set_device": (C.c_int, [C.c_int]),
+    "qvz_hip_mem_info": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "qvz_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "qvz_hip_free": (C.c_int, [C.c_void_p]),
     "qvz_hip_malloc_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
@@ -102,6 +103,8 @@ SIGNATURES = {
     "qvz_hip_decode_shards_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
                                                C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qvz_hip_encode_planes_prepare": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64]),
+    "qvz_hip_encode_planes_work_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "qvz_hip_encode_planes_last_ms": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "qvz_model_build": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
@@ -117,6 +120,7 @@ SIGNATURES = {
     "qvz_encode_file_sharded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qvz_encode_last_error": (C.c_char_p, []),
     "qvz_encode_file_devices": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_void_p]),
+    "qvz_egress_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p]),
     "qvz_ingest_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_hip_scatter_streams": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "qvz_hip_gather_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_void_p]),

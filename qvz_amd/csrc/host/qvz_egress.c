@@ -228,3 +228,12 @@ done:
     stage_free(&s);
     return rc;
 }
+
+int qvz_egress_rows(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, const char *path) {
+    if (!d_sym || !n || !c || ld < n || !path) return qvz_job_fail(QVZ_E_ARG, "bad egress arguments");
+    FILE *f = fopen(path, "w");
+    if (!f) return qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
+    const int rc = qvz_egress_text(f, d_sym, n, c, ld, NULL);
+    if (fclose(f) && !rc) return qvz_job_fail(QVZ_E_ARG, "write failed");
+    return rc;
+}

@@ -624,6 +624,56 @@ done:
     return rc;
 }
 
+static void *workspace_main(void *arg) {
+    qvz_job_t *job = (qvz_job_t *)arg;
+    uint64_t free_b = 0, per = 0;
+    job->work_rc = qvz_hip_set_device(job->opts.device);
+    if (job->work_rc) return NULL;
+    if (job->shard_bounds) { for (uint32_t g = 0; g < job->work_shards; ++g) if (job->shard_bounds[g + 1] - job->shard_bounds[g] > per) per = job->shard_bounds[g + 1] - job->shard_bounds[g]; }
+    else per = (job->N + job->work_shards - 1) / job->work_shards + 4;
+    uint64_t want = qvz_hip_encode_planes_work_bytes(per, job->C, job->K, job->work_shards);
+    /* everything at once if it fits: 96 GiB at most, and never more than a third of what is free now - the matrix, the
+     * draws and the quantizer's planes (5 x C x ld bytes) are still to come */
+    const uint64_t planes = 5 * (uint64_t)job->C * job->ld + job->N * 8;
+    if (want > (96ull << 30)) want = 96ull << 30;
+    if (qvz_hip_mem_info(&free_b, NULL) == QVZ_OK) {
+        const uint64_t room = free_b > planes + (24ull << 30) ? free_b - planes - (24ull << 30) : 0;
+        if (want > room) want = room;
+    }
+    if (want < (1ull << 30)) return NULL;                                       /* little room: the coder sizes its own later */
+    const double t0 = now();
+    if (qvz_hip_malloc(&job->d_work, (size_t)want) == QVZ_OK) job->work_bytes = want; else job->d_work = NULL;
+    if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: workspace of %.1f GiB allocated in %.4f s\n", want / 1073741824.0, now() - t0);
+    return NULL;
+}
+
+int qvz_job_start_workspace(qvz_job_t *job, uint32_t shards) {
+    pthread_t th;
+    if (job->d_work || job->work_running || !shards) return 0;
+    job->work_shards = shards;
+    const char *how = getenv("QVZ_WORK_EARLY");                                /* development knob: thread (default) | sync | off */
+    if (how && strcmp(how, "off") == 0) return 0;
+    if (how && strcmp(how, "sync") == 0) { workspace_main(job); return 0; }
+    if (pthread_create(&th, NULL, workspace_main, job) == 0) { job->work_thread = (unsigned long)th; job->work_running = 1; }
+    return 0;
+}
+
+static void workspace_join(qvz_job_t *job) {
+    if (job->work_running) { pthread_join((pthread_t)job->work_thread, NULL); job->work_running = 0; }
+}
+
+/* The first coder call of a process loads its code object, sizes and allocates its kept buffers and makes its stream pair:
+ * 40-50 ms before the first kernel. A one-shot process does that here, on a thread beside the quantizer. */
+typedef struct { qvz_job_t *job; uint32_t shards; } prepare_task_t;
+static void *prepare_main(void *arg) {
+    prepare_task_t *t = (prepare_task_t *)arg;
+    qvz_job_t *job = t->job;
+    workspace_join(job);
+    if (job->d_work && job->work_shards == t->shards && qvz_hip_set_device(job->opts.device) == QVZ_OK)
+        (void)qvz_hip_encode_planes_prepare(job->N, job->C, job->K, (const qvz_codebook_t *const *)job->cbs, t->shards, job->shard_bounds, job->work_bytes);
+    return NULL;                                                                /* a failure here shows again, with its message, in the call that codes */
+}
+
 /* what runs beside the coder kernels, each on a host thread of its own */
 typedef struct {
     int device, rc;
@@ -676,14 +726,17 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     int32_t *d_status = NULL, status = 0;
     uint64_t *sizes = NULL, *first = NULL;
     uint32_t *wstates = NULL;
-    pthread_t th_text, th_err;
-    int text_running = 0, err_running = 0;
+    pthread_t th_text, th_err, th_prep;
+    int text_running = 0, err_running = 0, prep_running = 0;
     side_task_t task_text, task_err;
+    prepare_task_t task_prep = {job, shards};
     memset(&task_text, 0, sizeof(task_text));
     memset(&task_err, 0, sizeof(task_err));
     if (!shards || (!job->shard_bounds && shards > qvz_shard_limit(N))) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads: a shard needs at least 4 reads", shards, (unsigned long long)N);
 
     if ((rc = qvz_job_start_draws(job))) goto done;                            /* already running when the caller started them */
+    if (!(getenv("QVZ_CODER_PREPARE") && atoi(getenv("QVZ_CODER_PREPARE")) == 0))   /* development knob: 0 = the coder call sets itself up */
+        prep_running = pthread_create(&th_prep, NULL, prepare_main, &task_prep) == 0;
     {
         const size_t ctn = (size_t)K * C * QVZ_CT_STRIDE, qsn = (size_t)K * C * QVZ_QS_STRIDE;
         h_ct = (uint16_t *)malloc(ctn * sizeof(uint16_t));
@@ -719,7 +772,11 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     t1 = now();
     job->t_quantize = t1 - t0;
 
-    /* beside the coder: per-read errors (file-order sum on one host core) and the -u text (pinned slabs -> file) */
+    /* beside the coder kernels: the per-read errors (0.8 GB over PCIe, then the file-order sum on one host core). The -u text
+     * starts when the coder has finished - its slabs keep two more streams and the copy engines busy for seconds, and beside
+     * them the coder phase took 1 - 3 s instead of 0.16 (QVZ_EGRESS_OVERLAP=1 brings that schedule back for measurements) -
+     * and runs beside the way out of the streams. */
+    const int overlap_text = getenv("QVZ_EGRESS_OVERLAP") && atoi(getenv("QVZ_EGRESS_OVERLAP"));
     task_err.device = task_text.device = job->opts.device;
     task_err.d_err = d_err; task_err.N = N; task_err.C = C;
     if (job->collect) {
@@ -730,7 +787,7 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     err_running = pthread_create(&th_err, NULL, side_errors, &task_err) == 0;
     if (fu) {
         task_text.fu = fu; task_text.d_qv = d_qv; task_text.N = N; task_text.C = C; task_text.ld = ld;
-        text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
+        if (overlap_text) text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
     }
     {   /* coding. Room per stream: 6 bits per symbol to begin with (real data needs 1-2); a stream that outgrows it
          * (-r above 6, near-uniform input) makes the coder report QVZ_E_NOMEM and the call is repeated with twice the room,
@@ -742,8 +799,11 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
             cap = ((per * C * bits) / 8 + 512 + 3) & ~3ull;
             qvz_hip_free(d_out); d_out = NULL;
             HIP(qvz_hip_malloc((void **)&d_out, (size_t)shards * cap));
+            if (prep_running) { pthread_join(th_prep, NULL); prep_running = 0; }
+            workspace_join(job);
+            const int mine = job->d_work && job->work_shards == shards;        /* allocated ahead of time for this very cut */
             const int crc = qvz_hip_encode_planes_bounds(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
-                                                         shards, job->shard_bounds, d_out, cap, sizes, NULL, 0, NULL);
+                                                         shards, job->shard_bounds, d_out, cap, sizes, mine ? job->d_work : NULL, mine ? job->work_bytes : 0, NULL);
             if (crc == QVZ_OK) break;
             if (crc != QVZ_E_NOMEM || bits >= 24) { rc = qvz_job_fail(crc, "%s", qvz_hip_last_error()); goto done; }
         }
@@ -751,17 +811,12 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         job->t_coder = t2 - t1;
         for (uint32_t g = 0; g < shards; ++g) total += sizes[g];
         /* the streams leave the device packed back to back: 1-2 bits per symbol instead of the 6 the area was sized for */
-        qvz_hip_free(d_qi); d_qi = NULL;
-        qvz_hip_free(d_st); d_st = NULL;
         HIP(qvz_hip_malloc((void **)&d_packed, total ? total : 1));
         HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_packed, NULL));
         if (err_running) { pthread_join(th_err, NULL); err_running = 0; } else side_errors(&task_err);
         if (task_err.rc) { rc = qvz_job_fail(task_err.rc, "%s", task_err.err); goto done; }
         if (distortion_out) *distortion_out = task_err.sum / ((double)N);      /* qv_compressor.c:139-140 */
-        if (fu) {
-            if (text_running) { pthread_join(th_text, NULL); text_running = 0; } else side_text(&task_text);
-            if (task_text.rc) { rc = qvz_job_fail(task_text.rc, "%s", task_text.err); goto done; }
-        }
+        if (fu && !text_running) text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
         if (job->collect) {                                                     /* a part of a file: the caller assembles the whole */
             h_buf = (uint8_t *)malloc(total ? total : 1);
             if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
@@ -808,12 +863,17 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
                 ftotal += need;
             }
         }
+        if (fu) {                                                               /* the -u text: wait for it (or write it now) */
+            if (text_running) { pthread_join(th_text, NULL); text_running = 0; } else side_text(&task_text);
+            if (task_text.rc) { rc = qvz_job_fail(task_text.rc, "%s", task_text.err); goto done; }
+        }
         if (stream_bytes) *stream_bytes = total;
         if (file_bytes) *file_bytes = ftotal;
         job->t_egress = now() - t2;
     }
     job->t_encode = now() - t0;
 done:
+    if (prep_running) pthread_join(th_prep, NULL);
     if (err_running) pthread_join(th_err, NULL);                                /* they read device buffers freed below */
     if (text_running) pthread_join(th_text, NULL);
     free(h_ct); free(h_qs); free(sizes); free(first); free(h_buf); free(image); free(wstates);
@@ -842,6 +902,8 @@ void qvz_job_release(qvz_job_t *job) {
     qvz_hip_free(job->d_cnt64); qvz_hip_free(job->d_counts64);
     qvz_hip_free(job->d_draws);
     if (job->well_stream) qvz_hip_stream_destroy(job->well_stream);
+    workspace_join(job);
+    qvz_hip_free(job->d_work);
     memset(job, 0, sizeof(*job));
 }
 
@@ -873,6 +935,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     int rc = qvz_job_init(&job, text, bytes, 0, 0, opts);
     if (rc) { free(fq_rows); return rc; }
     uint64_t head_bytes = 0;
+    if (shards) qvz_job_start_workspace(&job, shards);                         /* the coder's record workspace, beside the upload */
     if ((rc = qvz_job_upload(&job))) goto done;
     if ((rc = qvz_job_kmeans(&job, 0))) goto done;
     if (opts->verbose) printf("Clustering took %.4f seconds\n", job.t_cluster);                      /* main.c:56-58 */

@@ -45,6 +45,14 @@ typedef struct qvz_job {
     uint8_t *d_draws;
     void *well_stream;
     int well_chosen;
+    /* record workspace of the GPU coder, allocated ahead of time by a host thread of its own while the text is still
+     * being uploaded (qvz_job_start_workspace): a one-shot process cannot keep it between encodes as bench.py does, and a
+     * 96 GiB hipMalloc in front of the coder kernels is time on the critical path */
+    void *d_work;
+    uint64_t work_bytes;
+    uint32_t work_shards;
+    int work_running, work_rc;
+    unsigned long work_thread;        /* pthread_t */
     /* ---- a job that holds PART of a file (one device of a multi-device encode, qvz_multi.c); all zero otherwise ---- */
     uint64_t first_read;        /* global number of this job's first read: WELL offset of its draws (a multiple of 4)         */
     const uint8_t *centroid_rows;  /* [K][C+1] text rows of the k centroid reads, wherever in the file they lie (cluster.c:198-201) */
@@ -84,6 +92,8 @@ int qvz_job_compress_shardset(qvz_job_t *job, FILE *fout, FILE *fu, uint32_t sha
 /* Chooses the WELL state (qv_stream.c:70-89) and starts generating the part's draw matrix on a side stream; called before
  * qvz_job_codebooks so that the generator runs beside it (the sharded compress calls it itself otherwise). */
 int qvz_job_start_draws(qvz_job_t *job);
+/* starts allocating the coder's record workspace for `shards` streams on a thread of its own; the sharded compress waits for it */
+int qvz_job_start_workspace(qvz_job_t *job, uint32_t shards);
 void qvz_job_release(qvz_job_t *job);
 
 /* ---- qvz_egress.c: products leaving the device in slabs (pinned double buffers, threaded file writes) ---- */

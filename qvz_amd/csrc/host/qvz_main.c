@@ -4,7 +4,7 @@
  * on the MI355X through libqvzhip.
  * Environment (additions): QVZ_WELL_SEED=debug|time (default time), QVZ_DEVICE=<ordinal>,
  * QVZ_CHUNK_READS=<n>, QVZ_SHARDS=<n> (sharded output: one shard-set file, include/qvz_shardset.h; with
- * QVZ_SHARD_FILES=1 one reference-format file per shard instead), QVZ_INPUT=fastq|qual. */
+ * QVZ_SHARD_FILES=1 one reference-format file per shard instead), QVZ_INPUT=fastq|qual, QVZ_TIMING=1 (phase seconds on stderr). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -164,5 +164,11 @@ int main(int argc, char **argv) {
         printf("%s\n", qvz_encode_last_error());                  /* reference: printf + exit(1), main.c:43-46 */
         exit(1);
     }
+    if (getenv("QVZ_TIMING"))                                     /* where the wall time went, one line on stderr (bench.py reads it) */
+        fprintf(stderr, "qvz_timing: upload=%.4f cluster=%.4f stats=%.4f codebook=%.4f quantize=%.4f coder=%.4f egress=%.4f encode=%.4f total=%.4f "
+                        "lines=%llu columns=%u stream_bytes=%llu file_bytes=%llu distortion=%.17g kmeans_iterations=%u\n",
+                res.t_upload, res.t_cluster, res.t_stats, res.t_codebook, res.t_quantize, res.t_coder, res.t_egress, res.t_encode, res.t_total,
+                (unsigned long long)res.lines, res.columns, (unsigned long long)res.stream_bytes, (unsigned long long)res.file_bytes,
+                res.distortion, res.kmeans_iterations);
     return 0;
 }

@@ -1469,6 +1469,15 @@ extern "C" void qvz_hip_encode_planes_release(void) {
     g_coder_area[dev].release();
 }
 
+// Bytes of record workspace that let qvz_hip_encode_planes code streams of up to `longest_reads` reads in one segment
+// (16 bytes per record, streams padded to 64, record positions per read padded to 8). A caller that
+// allocates the workspace itself - early, beside other work - asks this, caps it (96 GiB, what is free) and passes it in.
+extern "C" uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards) {
+    const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);
+    const uint32_t Cp = (Cx + 7) & ~7u;
+    return (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(Record) * ((longest_reads + 3) & ~(uint64_t)3);
+}
+
 static thread_local double g_planes_ms[2] = {0.0, 0.0};   // model kernels, coder kernels of the calling thread's last qvz_hip_encode_planes call
 extern "C" void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms) {
     if (model_ms) *model_ms = g_planes_ms[0];
@@ -1483,18 +1492,43 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
                                         h_sizes, d_work, work_bytes, stream);
 }
 
+static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
+                              uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                              const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
+                              void *d_work, uint64_t work_bytes, void *stream);
+
 extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                             uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                             const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
                                             void *d_work, uint64_t work_bytes, void *stream) {
-    if (!d_qi || !d_st || !n || !columns || !clusters || !shards || !d_out || !h_sizes || ld < n || (ld & 3))
+    return encode_planes_impl(false, d_qi, d_st, ld, d_labels, n, columns, clusters, cbs, shards, h_bounds, d_out, cap_per_shard, h_sizes,
+                              d_work, work_bytes, stream);
+}
+
+// Everything a first qvz_hip_encode_planes(_bounds) call of a process does before its first kernel - the code object of
+// this file loaded, the kept buffers sized and allocated, the model / coder stream pair made and probed - without coding
+// anything: a one-shot process (the qvz binary) runs this on a host thread beside the quantizer, where a resident process
+// simply keeps what its previous encode left. Same n, columns, clusters, codebooks, shards, bounds and workspace size as
+// the call that follows.
+extern "C" int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs,
+                                             uint32_t shards, const uint64_t *h_bounds, uint64_t work_bytes) {
+    uint64_t sizes_dummy = 0;
+    return encode_planes_impl(true, nullptr, nullptr, qvz_hip_ld(n), nullptr, n, columns, clusters, cbs, shards, h_bounds, nullptr, 8, &sizes_dummy,
+                              work_bytes ? (void *)(uintptr_t)256 : nullptr, work_bytes, nullptr);
+}
+
+static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
+                              uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
+                              const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
+                              void *d_work, uint64_t work_bytes, void *stream) {
+    if (((!d_qi || !d_st || !d_out) && !dry) || !n || !columns || !clusters || !shards || !h_sizes || ld < n || (ld & 3))
         return qvz_set_error(QVZ_E_ARG, "bad plane-coder arguments");
     if (h_bounds) {                                              // the caller's cut of these n reads (a device's part of a larger file)
         if (h_bounds[0] != 0 || h_bounds[shards] != n) return qvz_set_error(QVZ_E_ARG, "shard bounds must run from 0 to n");
         for (uint32_t g = 0; g < shards; ++g)
             if ((h_bounds[g] & 3) || h_bounds[g + 1] <= h_bounds[g]) return qvz_set_error(QVZ_E_ARG, "shard %u: bounds must ascend in multiples of 4 reads", g);
     }
-    if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
+    if (clusters > 1 && !d_labels && !dry) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
     if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
     auto wall_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_entry = wall_ms();
@@ -1503,7 +1537,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     KeptArea &area = g_coder_area[area_dev];
     std::unique_lock<std::mutex> area_lock(area.mu);             // one call per device at a time uses the kept buffers
     area.begin();
-    double t_first_launch = 0.0, t_enqueued = 0.0, t_synced = 0.0;
+    double t_first_launch = 0.0, t_enqueued = 0.0, t_synced = 0.0, t_tables = 0.0, t_work = 0.0, t_area = 0.0;
     uint32_t spin_us = 0;
     bool odd_call = false;
     const int coder_prio = getenv("QVZ_CODER_PRIO") ? atoi(getenv("QVZ_CODER_PRIO")) : 1;   // development knob: 0 = the coder waves issue at normal priority
@@ -1603,6 +1637,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         hipError_t e_ = (expr);                                                                                      \
         if (e_ != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); goto done; } \
     } while (0)
+    t_tables = wall_ms();
     if (!d_work) {                                               // no workspace given: our own, up to 96 GiB of what is free
         work_bytes = per_read * longest;
         size_t mem_free = 0, mem_total = 0;
@@ -1614,6 +1649,7 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         TRY(hipMalloc(&own_work, work_bytes));
         d_work = own_work;
     }
+    t_work = wall_ms();
     // Segments. With room for two record buffers the model kernel of segment i+1 runs beside the coder kernel of
     // segment i on a second HIP stream (the coder keeps three waves on half of the CUs busy with a latency chain; the
     // model kernel is throughput work that fills the rest); segments are then at most a quarter of a stream (every segment
@@ -1696,12 +1732,15 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
         TRY(area.get((void **)&d_segpos, SK * (nseg + 1) * sizeof(uint32_t)));
         TRY(area.get((void **)&d_bounds, (nseg + 1) * sizeof(uint32_t)));
         TRY(hipMemcpyAsync(d_bounds, h_bounds.data(), (nseg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_cluster_lists, dim3(shards), dim3(256), 0, st, d_labels, (const uint64_t *)d_first, clusters, d_clist, d_cstart, d_status);
-        hipLaunchKernelGGL(k_cluster_segpos, dim3((unsigned)((SK * (nseg + 1) + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_clist,
-                           (const uint64_t *)d_cstart, (const uint64_t *)d_first, shards, clusters, (const uint32_t *)d_bounds, nseg + 1, d_segpos);
+        if (!dry) {
+            hipLaunchKernelGGL(k_cluster_lists, dim3(shards), dim3(256), 0, st, d_labels, (const uint64_t *)d_first, clusters, d_clist, d_cstart, d_status);
+            hipLaunchKernelGGL(k_cluster_segpos, dim3((unsigned)((SK * (nseg + 1) + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_clist,
+                               (const uint64_t *)d_cstart, (const uint64_t *)d_first, shards, clusters, (const uint32_t *)d_bounds, nseg + 1, d_segpos);
+        }
         TRY(hipGetLastError());
         TRY(hipStreamSynchronize(st));                           // h_bounds goes out of scope; the lists are ready for both streams
     }
+    t_area = wall_ms();
     evs.assign((size_t)nseg * 4, nullptr);
     for (size_t i = 0; i < evs.size(); ++i) TRY(hipEventCreate(&evs[i]));
     g_planes_ms[0] = g_planes_ms[1] = 0.0;
@@ -1762,6 +1801,10 @@ extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *
     }
     if (getenv("QVZ_CODER_LDS_PAD")) cr_pad = (size_t)atoi(getenv("QVZ_CODER_LDS_PAD"));   // development knob
     if (cr_pad) TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_code_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
+    if (dry) {                                                   // qvz_hip_encode_planes_prepare: everything is in place for the call that codes
+        TRY(hipStreamSynchronize(st));
+        goto done;
+    }
     t_first_launch = wall_ms();
     spin_us = getenv("QVZ_CODER_HEADSTART_US") ? (uint32_t)atoi(getenv("QVZ_CODER_HEADSTART_US")) : 40u;   // development knob
     for (uint32_t i = 0; i < nseg; ++i) {
@@ -1889,8 +1932,9 @@ done:
     area.finish();                                               // (the buffers of this call stay allocated for the next one)
     area_lock.unlock();
     if (t_synced > 0.0 && (getenv("QVZ_CODER_DEBUG") || wall_ms() - t_entry > 1.25 * (g_planes_ms[0] + g_planes_ms[1]) + 30.0))
-        fprintf(stderr, "  host side of the call: set-up %.2f ms, launches enqueued in %.2f ms, waited %.2f ms, tear-down %.2f ms\n",
-                t_first_launch - t_entry, t_enqueued - t_first_launch, t_synced - t_enqueued, wall_ms() - t_synced);
+        fprintf(stderr, "  host side of the call: set-up %.2f ms (model tables on the host %.2f, workspace %.2f, buffers + uploads %.2f, events + streams %.2f), launches enqueued in %.2f ms, waited %.2f ms, tear-down %.2f ms\n",
+                t_first_launch - t_entry, t_tables - t_entry, t_work - t_tables, t_area - t_work, t_first_launch - t_area,
+                t_enqueued - t_first_launch, t_synced - t_enqueued, wall_ms() - t_synced);
     free(h_arena); free(h_off); free(h_first);
     return rc;
 }

@@ -2039,6 +2039,14 @@ extern "C" int qvz_hip_streams_overlap(void *stream_a, void *stream_b, int *over
 extern "C" int qvz_hip_stream_destroy(void *stream) { QVZ_HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); return QVZ_OK; }
 extern "C" int qvz_hip_stream_sync(void *stream) { QVZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); return QVZ_OK; }
 
+extern "C" int qvz_hip_mem_info(uint64_t *free_bytes, uint64_t *total_bytes) {
+    size_t f = 0, t = 0;
+    QVZ_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return QVZ_OK;
+}
+
 extern "C" int qvz_hip_stream_wait(void *stream, void *other) {
     hipEvent_t ev;
     QVZ_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

@@ -178,6 +178,16 @@ def ingest_rows(text_host, n, columns, sym):
     return int(bad.value)
 
 
+def egress_rows(sym, n, path):
+    """A (columns, ld) uint8 device matrix written to `path` as text rows (qvz_egress_rows: pinned slabs, threaded writes)."""
+    import torch
+    torch.cuda.synchronize()
+    c, ld = sym.shape
+    rc = lib().qvz_egress_rows(C.c_void_p(sym.data_ptr()), n, c, ld, path.encode())
+    if rc:
+        raise QvzHipError(f"qvz_egress_rows failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+
+
 def shard_bounds(n, shards):
     """first[g] for g = 0..shards; every shard starts at a multiple of 4 reads (a WELL word boundary)."""
     first = (C.c_uint64 * (shards + 1))()
