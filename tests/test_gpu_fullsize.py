@@ -107,3 +107,77 @@ def test_full_size_encode_round_trip_and_oracle_parity(name):
     host.release_workspace()
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def test_configs4_rank_7_of_8_on_one_gpu():
+    """BASELINE configs[4] (1B reads x 150 columns, -c 3 -d M -r 1.0 over 8 GPUs) cannot run here; what one GPU can prove of it:
+    rank 7's share - reads [875M, 1B), 125M x 150 - goes through the product's N > 1 code path (pipeline.encode_pass with a
+    one-rank RCCL group: all-reduces of the k-means sums, the PMF counters and the distortion), fits the 288 GB, and draws from
+    the WELL stream 3.28e10 words in (first_read * C / 4 > 2^32) exactly: the first and the last of its shards are re-encoded
+    by the oracle with WELL states that come from the REFERENCE's generator stepped that far (tests/golden/well_far.json)
+    and on from there by the oracle's. Centroids: the three reads libc rand() picks among the 1B are generated by the oracle
+    (QGEN-1 is counter based), as the ranks that own them would contribute them."""
+    import gc
+    import os
+    import socket
+    import torch.distributed as dist
+    import golden_util as G
+    from qvz_amd import host, kernels as K, pipeline as P
+    host.release_workspace()
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 262 * 2 ** 30:
+        pytest.skip(f"needs ~262 GB of HBM, {free >> 30} GiB free")
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    n_total, world, rank, k, seed = 1_000_000_000, 8, 7, 3, 4
+    first_read, last = P.rank_read_range(n_total, world, rank)
+    n = last - first_read
+    assert (first_read, n) == (875_000_000, 125_000_000)
+    far = {w: st for w, st, _ in G.well_far()}
+    word0 = first_read * C // 4
+    assert word0 in far and word0 > 2 ** 32
+    lines = P.reference_centroid_lines(n_total, k)
+    means0 = torch.from_numpy(np.stack([O.qgen1_rows(seed, 1, C, first=ln)[0, :C] - 33 for ln in lines]).astype(np.uint8)).cuda()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sym = K.qgen1(seed, n, C, first=first_read)
+        r = P.encode_pass(sym, n, first_read, n_total, means0, clusters=k, mode=host.MODE_FIXED, ratio=1.0, dist="M", shards=SHARDS,
+                          coder="gpu", keep_device=True, want_reuse=True, group=dist.group.WORLD)
+    finally:
+        dist.destroy_process_group()
+    sizes = r["stream_bytes"]
+    assert len(sizes) == SHARDS and min(sizes) > 0
+    labels, cnt = r["labels"], r["reuse"]["cnt"]
+    # every stream decodes to the quantizer's plane (the draws are the ones of reads 875M.. of the 1B-read file)
+    qv, lab = host.decode_shards_gpu(r["coded"], r["cap_per_shard"], sizes, n, C, [cb.handle for cb in r["codebooks"]], SHARDS,
+                                     r["reuse"]["draws"])
+    assert torch.equal(qv[:, :n], r["qv"][:, :n]) and torch.equal(lab[:n], labels[:n])
+    del qv, lab
+    # the oracle's leg: codebooks from this rank's counters, two shards from reads and WELL states it makes itself
+    dmat = O.distortion("M")
+    cnt_h = cnt.cpu().numpy().astype(np.uint32)
+    ocbs = [O.generate_codebook(cnt_h[j], dmat, O.MODE_FIXED, 1.0) for j in range(k)]
+    for j in range(k):
+        assert ocbs[j].serialize() == r["codebooks"][j].serialize()
+    first = host.shard_bounds(n, SHARDS)
+    picks = [0, SHARDS - 1]
+    states = O.well_states_at([first[g] * C // 4 for g in picks], state0=far[word0])
+    coded, cap = r["coded"], r["cap_per_shard"]
+    for g, state in zip(picks, states):
+        a, b = first[g], first[g + 1]
+        rows = O.qgen1_rows(seed, b - a, C, first=first_read + a)
+        assert np.array_equal(sym[:, a:b].cpu().numpy(), (rows[:, :C].T - 33).astype(np.uint8))
+        enc = O.encode_stream(rows, np.ascontiguousarray(labels[a:b].cpu().numpy()), ocbs, dmat, well_state=state)
+        assert np.array_equal((r["qv"][:, a:b].cpu().numpy().T + 33).astype(np.uint8), enc["u"][:, :C]), f"shard {g}: quantized rows differ"
+        assert coded[g * cap: g * cap + sizes[g]].cpu().numpy().tobytes() == enc["stream"], f"shard {g}: stream differs from the oracle's"
+        np.testing.assert_array_equal(K.well_jump(O.WELL_DEBUG_STATE, (first_read + a) * C // 4), state)
+    del r, sym, coded, cnt, labels
+    host.release_workspace()
+    gc.collect()
+    torch.cuda.empty_cache()
