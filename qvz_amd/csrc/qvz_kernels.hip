@@ -927,7 +927,13 @@ __device__ __noinline__ void pmf_count_slow(uint32_t x, uint32_t p, uint32_t lra
 
 // Inner loop budget (k = 1): per 4-symbol word one packed range check (7 VALU) and per symbol v_perm_b32 +
 // v_dot2_u32_u16 + ds_add_u32. The kernel is issue-bound, not bandwidth-bound, so instruction count is what matters.
-template <bool HAVE_LABELS, int Q>
+// LMODE: 0 no labels (one cluster); 1 a label byte per read, asked for again in every column when more than two groups per
+// thread are in flight (any number of clusters, PMF_KT of them per pass); 2 at most four clusters, all in one pass: a
+// thread packs the labels of its groups to 2 bits each ONCE, before the first column - one dword per 16 reads - so that
+// they stay in registers over all columns beside prv / cur / nxt (six groups per thread as with one cluster), no label is
+// loaded twice, and a symbol's tile is one v_bfe + one v_mad away. A group that holds a label outside the pass's clusters
+// (never, for labels that come from the k-means kernels) takes the per-symbol path with its label bytes read again.
+template <int LMODE, int Q>
 __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                           uint64_t n, uint32_t C, uint64_t ld, uint32_t kb, uint32_t kt,
                                                           uint32_t R, uint32_t AA, uint32_t G, uint32_t *__restrict__ cnt) {
@@ -937,17 +943,48 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
     const uint32_t rs = G * cs + 1;                              // replica stride
     uint32_t *mine = tile + (threadIdx.x % R) * rs;
     const uint64_t slab0 = (uint64_t)blockIdx.x * T * 16 * Q;
-    uint64_t row[Q];
-    uint4 prv[Q], cur[Q], lab[Q];
+    // group q of this thread = the 16 reads from ROW(q); which groups lie wholly / partly inside the matrix is kept as two
+    // bit masks instead of Q 64-bit row numbers (registers are what limits the groups per thread)
+    const uint64_t base_row = slab0 + (uint64_t)threadIdx.x * 16;
+#define ROW(q) (base_row + (uint64_t)(q) * T * 16)
+#define LIVE(q) (((full | part) >> (q)) & 1u)
+#define FULL(q) ((full >> (q)) & 1u)
+    uint32_t full = 0, part = 0;
+    constexpr bool HAVE_LABELS = LMODE != 0;
+    constexpr bool PACKED = LMODE == 2;
+    uint4 prv[Q], cur[Q], lab[PACKED ? 1 : Q];
+    uint32_t lab2[PACKED ? Q : 1];                               // PACKED: 16 labels x 2 bits
+    uint32_t lbad = 0;                                           // PACKED: bit q = group q holds a label outside [kb, kb + kt)
     uint32_t pbad[Q];                                            // range check of prv[q], made when it was cur[q]
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        row[q] = slab0 + ((uint64_t)q * T + threadIdx.x) * 16;
+        if (ROW(q) + 16 <= n) full |= 1u << q; else if (ROW(q) < n) part |= 1u << q;
         prv[q] = make_uint4(0, 0, 0, 0);                         // column 0 counts under prev = 0 (codebook.c:200)
         pbad[q] = 0;
-        lab[q] = make_uint4(0, 0, 0, 0);
-        if (HAVE_LABELS && Q <= 2 && row[q] < n) lab[q] = *reinterpret_cast<const uint4 *>(labels + row[q]);
-        cur[q] = row[q] < n ? *reinterpret_cast<const uint4 *>(D + row[q]) : make_uint4(0, 0, 0, 0);
+        if (!PACKED) {
+            lab[q] = make_uint4(0, 0, 0, 0);
+            if (HAVE_LABELS && Q <= 2 && LIVE(q)) lab[q] = *reinterpret_cast<const uint4 *>(labels + ROW(q));
+        } else {
+            const uint4 lv = LIVE(q) ? *reinterpret_cast<const uint4 *>(labels + ROW(q)) : make_uint4(0, 0, 0, 0);
+            const uint32_t lw4[4] = {lv.x - 0x01010101u * kb, lv.y - 0x01010101u * kb, lv.z - 0x01010101u * kb, lv.w - 0x01010101u * kb};   // kb = 0 in this mode
+            const uint32_t kk = 0x01010101u * (0x80u - kt);      // byte + (128 - kt) sets bit 7 iff byte >= kt
+            uint32_t packed = 0, bad = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                bad |= ((lw4[w] + kk) | lw4[w]) & 0x80808080u;
+                uint32_t x = lw4[w] & 0x03030303u;               // four labels of 2 bits, one per byte -> 8 bits
+                x = (x | (x >> 6)) & 0x000F000Fu;
+                x = (x | (x >> 12)) & 0xFFu;
+                packed |= x << (8 * w);
+            }
+            lab2[q] = packed;
+            if (bad) {                                           // cold: this group is counted after the column walk, symbol by symbol
+                lbad |= 1u << q;
+                full &= ~(1u << q);                              // the walk skips it
+                part &= ~(1u << q);
+            }
+        }
+        cur[q] = LIVE(q) ? *reinterpret_cast<const uint4 *>(D + ROW(q)) : make_uint4(0, 0, 0, 0);
     }
     const uint32_t k80 = 0x01010101u * (0x80u - AA);             // byte + (128 - AA) sets bit 7 iff byte >= AA
     const uint32_t dump = (uint32_t)(uintptr_t)(pmf_lds_u32 *)tile + (uint32_t)(((mine - tile) + rs - 1) * 4);   // the replica's skew dword
@@ -962,15 +999,15 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
             uint4 nxt[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q)                          // prefetch column s+1 while column s is counted
-                nxt[q] = (s + 1 < C && row[q] < n) ? *reinterpret_cast<const uint4 *>(D + (uint64_t)(s + 1) * ld + row[q])
+                nxt[q] = (s + 1 < C && LIVE(q)) ? *reinterpret_cast<const uint4 *>(D + (uint64_t)(s + 1) * ld + ROW(q))
                                                    : make_uint4(0, 0, 0, 0);
             // With more than two groups per thread the labels do not stay in registers beside prv / cur / nxt (four groups
             // spilled: 16.6 ms instead of 7.1 at 100M x 150, k = 3): they are asked for again in every column - 1 byte per read
             // and column out of L2 / the Infinity Cache (the label vector is 100 MB) - and bigger slabs mean fewer flushes.
-            if (HAVE_LABELS && Q > 2) {
+            if (HAVE_LABELS && !PACKED && Q > 2) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q)
-                    lab[q] = row[q] < n ? *reinterpret_cast<const uint4 *>(labels + row[q]) : make_uint4(0, 0, 0, 0);
+                    lab[q] = LIVE(q) ? *reinterpret_cast<const uint4 *>(labels + ROW(q)) : make_uint4(0, 0, 0, 0);
             }
             uint32_t *col_tile = mine + (s - g0) * cs;
             uint32_t *gcol = cnt + ((uint64_t)kb * C + s) * PMF_TILE;
@@ -979,7 +1016,11 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
             for (int q = 0; q < Q; ++q) {
                 const uint32_t cw[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
                 const uint32_t pw[4] = {prv[q].x, prv[q].y, prv[q].z, prv[q].w};
-                const uint32_t lw[4] = {lab[q].x, lab[q].y, lab[q].z, lab[q].w};
+                const uint32_t lw[4] = {lab[PACKED ? 0 : q].x, lab[PACKED ? 0 : q].y, lab[PACKED ? 0 : q].z, lab[PACKED ? 0 : q].w};
+                uint32_t l2 = lab2[PACKED ? q : 0];
+                // the packed labels do not change from column to column: without this the compiler computes the sixteen tile
+                // offsets of every group once, in front of the column loop, and spills them (380 VGPRs' worth at six groups)
+                asm volatile("" : "+v"(l2));
                 // one range check per 16-byte group and column: bit 7 of a byte of cbad is set iff that symbol is outside
                 // the tile; the group's check as `prev` is the one it got as `cur` a column earlier
                 const uint32_t cbad = (((cw[0] + k80) | cw[0]) | ((cw[1] + k80) | cw[1]) | ((cw[2] + k80) | cw[2]) |
@@ -1000,7 +1041,9 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                     }
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        if (HAVE_LABELS) {
+                        if (PACKED) {
+                            addr[b] = __umul24(__builtin_amdgcn_ubfe(l2, 8 * w + 2 * b, 2), ts * 4) + addr[b];
+                        } else if (HAVE_LABELS) {
                             const uint32_t l = ((lw[w] >> (8 * b)) & 0xFF) - kb;
                             // a read of a cluster outside this pass's tiles (or of no cluster at all) counts into the
                             // replica's skew dword, which nobody reads: a select instead of an exec-mask region per symbol
@@ -1011,10 +1054,10 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 };
-                if (row[q] + 16 <= n && gbad == 0) {             // the usual case: sixteen pairs inside the tile
+                if (FULL(q) && gbad == 0) {                      // the usual case: sixteen pairs inside the tile
 #pragma unroll
                     for (int w = 0; w < 4; ++w) fast_word(w);
-                } else if (row[q] + 16 <= n) {
+                } else if (FULL(q)) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const uint32_t bad = ((cw[w] + k80) | (pw[w] + k80) | cw[w] | pw[w]) & 0x80808080u;
@@ -1024,13 +1067,15 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
 #pragma unroll
                             for (int b = 0; b < 4; ++b)
                                 pmf_count_slow<HAVE_LABELS>((cw[w] >> (8 * b)) & 0xFF, (pw[w] >> (8 * b)) & 0xFF,
-                                                            (lw[w] >> (8 * b)) & 0xFF, kb, kt, AA, col_tile, gcol, C);
+                                                            PACKED ? kb + ((l2 >> (8 * w + 2 * b)) & 3u) : (lw[w] >> (8 * b)) & 0xFF,
+                                                            kb, kt, AA, col_tile, gcol, C);
                         }
                     }
-                } else if (row[q] < n) {                         // the last, partial group of the matrix
-                    for (uint32_t r = 0; r < 16 && row[q] + r < n; ++r)
+                } else if (LIVE(q)) {                            // the last, partial group of the matrix
+                    for (uint32_t r = 0; r < 16 && ROW(q) + r < n; ++r)
                         pmf_count_slow<HAVE_LABELS>((cw[r >> 2] >> (8 * (r & 3))) & 0xFF, (pw[r >> 2] >> (8 * (r & 3))) & 0xFF,
-                                                    (lw[r >> 2] >> (8 * (r & 3))) & 0xFF, kb, kt, AA, col_tile, gcol, C);
+                                                    PACKED ? kb + ((l2 >> (2 * r)) & 3u) : (lw[r >> 2] >> (8 * (r & 3))) & 0xFF,
+                                                    kb, kt, AA, col_tile, gcol, C);
                 }
                 prv[q] = cur[q];
                 cur[q] = nxt[q];
@@ -1052,7 +1097,25 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
         }
         __syncthreads();
     }
+    if (PACKED && lbad) {
+        // Groups that hold a label outside this pass's clusters (a caller's own label vector; the k-means kernels never write
+        // one): counted here, symbol by symbol, straight into the global counters.
+        for (int q = 0; q < Q; ++q) {
+            if (!((lbad >> q) & 1u)) continue;
+            const uint64_t r0 = ROW(q);
+            for (uint32_t s = 0; s < C; ++s)
+                for (uint32_t r = 0; r < 16 && r0 + r < n; ++r) {
+                    const uint32_t x = D[(uint64_t)s * ld + r0 + r], p = s ? D[(uint64_t)(s - 1) * ld + r0 + r] : 0u;
+                    const uint32_t l = (uint32_t)labels[r0 + r] - kb;
+                    if (x >= QVZ_A || p >= QVZ_A || l >= kt) continue;
+                    atomicAdd(&cnt[((uint64_t)(kb + l) * C + s) * PMF_TILE + p * QVZ_A + x], 1u);
+                }
+        }
+    }
 }
+#undef ROW
+#undef LIVE
+#undef FULL
 
 // largest symbol in an evenly spread sample of every column (64 x 1024 rows per column)
 __global__ __launch_bounds__(256) void k_sym_max(const uint8_t *__restrict__ D, uint64_t n, uint64_t ld,
@@ -1176,7 +1239,9 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
             // bigger slabs = fewer blocks = fewer flush atomics; six groups per thread is what 128 VGPRs hold (k = 1)
             // with labels (k > 1) kept in registers two groups are the limit: four spill (100M x 150, k = 3: 16.9 ms against 7.2)
             // (k > 1, labels re-read per column: four groups 6.4 ms, two 7.1, six 9.0 at 100M x 150, k = 3)
-            if (Q == 0) Q = (k == 1 && n >= 768ull * 98304) ? 6 : (n >= 768ull * 65536) ? 4 : (n >= 768ull * 32768 ? 2 : 1);
+            // (k = 2 .. 4 with the labels packed to 2 bits in registers - QVZ_PMF_LABELS=bytes keeps the byte path -: six groups again)
+            const bool packed = k > 1 && k <= 4 && !(getenv("QVZ_PMF_LABELS") && strcmp(getenv("QVZ_PMF_LABELS"), "bytes") == 0);
+            if (Q == 0) Q = ((k == 1 || packed) && n >= 768ull * 98304) ? 6 : (n >= 768ull * 65536) ? 4 : (n >= 768ull * 32768 ? 2 : 1);
             if (Q != 1 && Q != 2 && Q != 4 && Q != 6) Q = 4;
             const uint64_t slab = (uint64_t)PMF_WALK_T * 16 * Q;
             dim3 grid((unsigned)((n + slab - 1) / slab));
@@ -1189,9 +1254,11 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
                            R, AA, G, d_cnt);                                                                           \
     } while (0)
             if (k == 1) {
-                if (Q == 6) LAUNCH_WALK(false, 6); else if (Q >= 4) LAUNCH_WALK(false, 4); else if (Q == 2) LAUNCH_WALK(false, 2); else LAUNCH_WALK(false, 1);
+                if (Q == 6) LAUNCH_WALK(0, 6); else if (Q >= 4) LAUNCH_WALK(0, 4); else if (Q == 2) LAUNCH_WALK(0, 2); else LAUNCH_WALK(0, 1);
+            } else if (packed) {
+                if (Q == 6) LAUNCH_WALK(2, 6); else if (Q >= 4) LAUNCH_WALK(2, 4); else if (Q == 2) LAUNCH_WALK(2, 2); else LAUNCH_WALK(2, 1);
             } else {
-                if (Q == 6) LAUNCH_WALK(true, 6); else if (Q >= 4) LAUNCH_WALK(true, 4); else if (Q == 2) LAUNCH_WALK(true, 2); else LAUNCH_WALK(true, 1);
+                if (Q == 6) LAUNCH_WALK(1, 6); else if (Q >= 4) LAUNCH_WALK(1, 4); else if (Q == 2) LAUNCH_WALK(1, 2); else LAUNCH_WALK(1, 1);
             }
 #undef LAUNCH_WALK
             QVZ_HIP_CHECK(hipGetLastError());

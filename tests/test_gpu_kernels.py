@@ -226,6 +226,40 @@ def test_pmf_kernel_variants_agree(K, aa, monkeypatch):
         np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ref, err_msg=f"algo={algo} Q={q}")
 
 
+@pytest.mark.parametrize("k,aa,q", [(2, 0, 0), (3, 0, 4), (3, 30, 6), (4, 0, 6), (4, 72, 2)])
+def test_pmf_labels_packed_to_two_bits_count_like_label_bytes(K, k, aa, q, monkeypatch):
+    """Up to four clusters: the walking kernel packs a thread's labels to 2 bits each and keeps them in registers over all
+    columns (QVZ_PMF_LABELS=bytes: the label bytes, asked for again in every column). Same counters as the oracle's
+    calculate_statistics restatement (codebook.c:193-205), with a ragged last group, a tile hint below the alphabet, and a
+    caller's label vector that holds values outside the clusters (those reads count nowhere, on either path)."""
+    n, c = 70001, 14
+    rows = O.qgen1_rows(21, n, c)
+    rng = np.random.default_rng(k * 1000 + aa)
+    labels_np = rng.integers(0, k, size=n).astype(np.uint8)
+    sym = upload_sym(K, rows)
+    lab = torch.zeros(sym.shape[1], dtype=torch.uint8, device="cuda")
+    lab[:n] = torch.from_numpy(labels_np).cuda()
+    ref = O.stats(rows, labels_np, k)
+    monkeypatch.setenv("QVZ_PMF_ALGO", "1")
+    monkeypatch.setenv("QVZ_PMF_AA", str(aa))
+    monkeypatch.setenv("QVZ_PMF_Q", str(q))
+    packed = K.pmf_hist(sym, n, labels=lab, k=k)
+    np.testing.assert_array_equal(packed.cpu().numpy().astype(np.uint32), ref)
+    # a label vector with strangers in it: cluster ids k .. 255 in 1 % of the reads (also 3 -> the 2-bit field's own value when k = 3)
+    odd = labels_np.copy()
+    where = rng.choice(n, size=n // 100, replace=False)
+    odd[where] = rng.integers(k, 256, size=where.size).astype(np.uint8)
+    odd[where[:50]] = k
+    lab[:n] = torch.from_numpy(odd).cuda()
+    packed = K.pmf_hist(sym, n, labels=lab, k=k)
+    monkeypatch.setenv("QVZ_PMF_LABELS", "bytes")
+    by_bytes = K.pmf_hist(sym, n, labels=lab, k=k)
+    assert torch.equal(packed, by_bytes)
+    keep = odd < k
+    ref_odd = O.stats(np.ascontiguousarray(rows[keep]), np.ascontiguousarray(odd[keep]), k)
+    np.testing.assert_array_equal(packed.cpu().numpy().astype(np.uint32), ref_odd)
+
+
 def test_pmf_accumulates_across_calls(K):
     """Counters are += : two shards of reads give the single-pass counts (the multi-GPU reduction relies on it)."""
     rows = O.qgen1_rows(8, 9000, 25)
