@@ -70,6 +70,15 @@ int qvz_hip_generate_codebook64(const uint64_t *d_cnt, uint32_t C, const double 
  * (reference src/codebook.c:208-219, combine_pmfs src/pmf.c:189-205), bit-identical to the reference's values. */
 int qvz_hip_marginals(const uint32_t *d_cnt, uint32_t C, double *h_marg, void *stream);
 
+/* Starts, on a host thread of its own, the one-time check that lets the device's entropies decide: glibc's log2 as restated
+ * for the device (qvz_amd/csrc/qvz_log2_glibc.h) against this host's log2 on 2^20 arguments, bit for bit. Optional: the
+ * first qvz_hip_generate_codebook of a process runs (and waits for) the check itself; a caller that knows a generation
+ * is coming calls this early. QVZ_CB_LOG2=host: no check, the host's libm takes every decision as before round 3. */
+int qvz_hip_codebook_warmup(void);
+/* 1 if the check has passed on the current device (runs / waits for it): the device's entropies take the decisions;
+ * 0: they only steer and the host's libm decides (the check failed, or QVZ_CB_LOG2=host) */
+int qvz_hip_codebook_exact_entropies(void);
+
 /* Number of host-side decisions the last qvz_hip_generate_codebook call OF THE CALLING THREAD had to take inside the
  * guard band. (qvz_hip_generate_codebook may run concurrently on several host threads, one cluster and one stream each:
  * the clusters' codebooks are independent, and a generation is a chain of small kernels and host round trips.) */

@@ -172,6 +172,7 @@ int qvz_job_upload(qvz_job_t *job) {
     uint32_t bad = 0;
     if (job->uploaded) return 0;
     HIP(qvz_hip_set_device(job->opts.device));
+    (void)qvz_hip_codebook_warmup();                               /* the one-time log2 check of the codebook generation, beside the upload */
     HIP(qvz_hip_malloc((void **)&job->d_sym, (size_t)job->C * ld));
     HIP(qvz_hip_malloc((void **)&job->d_labels, ld));
     HIP(qvz_hip_memset(job->d_labels, 0, ld, NULL));               /* calloc'd line_t.cluster, lines.c:116 */

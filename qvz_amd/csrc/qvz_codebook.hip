@@ -32,11 +32,14 @@
 #include <time.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "qvz_codebook.h"
 #include "qvz_internal.h"
+#include "qvz_log2_glibc.h"
 
 #define A QVZ_A
 
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
 // which designs give up early, by more than the guard band; every decision is the host's, from libm values.
 __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
                                                   const double *__restrict__ qpmf, double *__restrict__ xpmf, double *__restrict__ xpmf_host,
-                                                  LmIn *__restrict__ lin, int ratio_mode, double opt_ratio) {
+                                                  LmIn *__restrict__ lin, int ratio_mode, double opt_ratio, int exact,
+                                                  LmIn *__restrict__ lin_host) {
     __shared__ double row[A], nrow[A], ent[A];
     const uint32_t idx = blockIdx.x, k = threadIdx.x;
     const double *Ps = P + (uint64_t)s * A * A;
@@ -196,7 +200,10 @@ __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, 
         xpmf[idx * A + k] = nv;
         xpmf_host[idx * A + k] = nv;                              // the host's copy (mapped memory): its libm entropy is the target
         nrow[k] = nv;
-        ent[k] = lin && nv > 0.0 ? nv * log2(nv) : 0.0;          // every thread its own term
+        // every thread its own term; `exact`: with glibc's log2 restated (qvz_log2_glibc.h) the sum below IS the reference's
+        // get_entropy of this row (pmf.c:141-155: the same terms, subtracted in index order), and its product with the -f
+        // ratio is the target the host would compute - the host then takes it from here instead of calling libm 72 x 72 times
+        ent[k] = lin && nv > 0.0 ? nv * (exact ? qvz_log2_glibc(nv) : log2(nv)) : 0.0;
     }
     __syncthreads();
     if (k == 0 && lin) {
@@ -215,6 +222,7 @@ __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, 
         I.startS = 1;
         for (int i = 0; i < 6; ++i) I.pad[i] = 0;
         lin[idx] = I;
+        if (exact && lin_host) lin_host[idx] = I;                  // mapped host memory: the host's copy of the plan and the exact target
     }
 }
 
@@ -510,6 +518,21 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
     return true;
 }
 
+// get_entropy (pmf.c:141-155) of a design's output pmf, bit for bit: the 72 terms p * log2(p) by the lanes (glibc's log2
+// restated, one IEEE multiply), then ONE lane subtracts them in index order as the reference's loop does. `term` is LDS.
+__device__ double lm_entropy_exact(const double *o, double *term) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t v = lane; v < A; v += 64) {
+        const double x = o[v];
+        term[v] = x > 0.0 ? x * qvz_log2_glibc(x) : 0.0;         // e - 0.0 == e: a skipped term changes nothing
+    }
+    __syncthreads();
+    double e = 0.0;
+    if (lane == 0)
+        for (uint32_t v = 0; v < A; ++v) e -= term[v];
+    return __shfl(e, 0, 64);
+}
+
 __device__ double lm_entropy_dev(const double *o) {   // steering value only (device log2, tree order)
     const uint32_t lane = threadIdx.x;
     double t = 0.0;
@@ -526,7 +549,7 @@ __device__ double lm_entropy_dev(const double *o) {   // steering value only (de
 template <bool TOEP, bool MONO>
 __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm, const double *__restrict__ distT,
                                                   const LmIn *__restrict__ in, LmDesign *__restrict__ out,
-                                                  uint32_t *__restrict__ stop, double guard) {
+                                                  uint32_t *__restrict__ stop, double guard, int exact) {
     extern __shared__ double sm[];
     double *dl = sm;
     double *p = sm + (TOEP ? A : A * A);
@@ -552,7 +575,9 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
         if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
         return;
     }
-    const double H = lm_entropy_dev(o);
+    // exact: hdev IS the libm entropy of o and every decision of the walk can be taken from it (no guard band);
+    // L->mv (72 doubles of LDS) is free once the design is done
+    const double H = exact ? lm_entropy_exact(o, L->mv) : lm_entropy_dev(o);
     for (uint32_t e = lane; e < A; e += 64) {
         O->o[e] = o[e];
         O->q[e] = L->q[0][e];
@@ -564,7 +589,8 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
         const unsigned long long dt = (__builtin_readcyclecounter() - t_begin) >> 8;   // shader cycles / 256
         O->pad[1] = (uint8_t)(dt > 65535 ? 255 : dt >> 8);
         O->pad[2] = (uint8_t)dt;
-        if (I.mode == 1 && S > 1 && H - I.target > guard) atomicMin(stop + ctx, S);   // surely >= target: the walk ends here or earlier
+        // surely >= target (exact: simply not below it, codebook.c:249-258): the walk ends here or earlier
+        if (I.mode == 1 && S > 1 && (exact ? !(H < I.target) : H - I.target > guard)) atomicMin(stop + ctx, S);
     }
 }
 
@@ -680,6 +706,112 @@ static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts)
 static thread_local unsigned long long cb_stat[6];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns
 static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 static std::atomic<int> g_cb_active{0};   // qvz_hip_generate_codebook calls in flight (one per cluster when a caller runs them concurrently)
+// ---- is the device's restatement of glibc's log2 THIS host's log2? ---------------------------------------------------------
+// The exact path (device entropies decide, the host calls libm no more) is taken only after the device function has agreed
+// with the host's log2, bit for bit, on 2^20 arguments of the kinds the pmfs hold (count / total, products, values next to
+// 1, powers of two, arbitrary mantissas): once per process and device, on a host thread of its own when the caller says so
+// early (qvz_hip_codebook_warmup), ~15 ms of libm calls. One differing bit - another libm, another glibc, a compiler that
+// contracts - and the generation falls back to the hand-over in which the host's libm takes every decision.
+// QVZ_CB_LOG2=host forces that path (the tests run both and compare codebook bytes).
+__global__ __launch_bounds__(256) void k_log2_selftest(const double *__restrict__ x, double *__restrict__ y, uint32_t count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = qvz_log2_glibc(x[i]);
+}
+
+struct Log2Check {
+    std::mutex mu;
+    std::condition_variable cv;
+    int state = 0;          // 0 not started, 1 running, 2 verified, 3 differs / could not run
+};
+// one per device ordinal, made on first use and never destroyed: the checking thread is detached (a process may end, or
+// never generate a codebook, while it runs) and must not find its mutex gone
+static std::mutex g_log2_mu;
+static Log2Check *g_log2[64];
+
+static void log2_selftest_run(int dev, Log2Check *L) {
+    const uint32_t M = 1u << 20;
+    int verdict = 3;
+    std::vector<double> hx(M), hy(M);
+    uint64_t st = 0x243F6A8885A308D3ull;
+    auto rnd = [&]() { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    for (uint32_t i = 0; i < M; ++i) {
+        const uint64_t r = rnd();
+        double x;
+        switch (i & 7) {
+            case 0: case 1: case 2: { const uint64_t t = 1 + (rnd() >> (rnd() % 40 + 24)), c = 1 + r % t; x = (double)c / (double)t; break; }   // count / total
+            case 3: x = qvz_log2_from_bits((r >> 12) | ((uint64_t)(1023 - (rnd() % 64)) << 52)); break;                                          // any mantissa, exponent 0 .. -63
+            case 4: x = 1.0 - ldexp((double)(r >> 11), -53 - (int)(rnd() % 30)); break;                                                         // just below 1
+            case 5: x = qvz_log2_from_bits(0x3FEEA4AF00000000ull + r % 0x210AA00000000ull + (rnd() % 5) - 2); break;                             // the close-to-1 branch and its edges
+            case 6: x = ldexp(1.0, -(int)(r % 64)) * (1.0 + (double)(rnd() % 3) * 0x1p-52); break;                                              // powers of two and neighbours
+            default: x = (double)(1 + r % 1000000) * (double)(1 + rnd() % 1000000) * 0x1p-60; break;                                            // products
+        }
+        if (!(x > 0x1p-1000) || !(x < 0x1p+1000)) x = 0.5;
+        hx[i] = x;
+    }
+    double *dx = nullptr, *dy = nullptr;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+        hipMalloc(&dx, M * sizeof(double)) == hipSuccess && hipMalloc(&dy, M * sizeof(double)) == hipSuccess &&
+        hipMemcpyAsync(dx, hx.data(), M * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess) {
+        hipLaunchKernelGGL(k_log2_selftest, dim3(M / 256), dim3(256), 0, s, (const double *)dx, dy, M);
+        if (hipMemcpyAsync(hy.data(), dy, M * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+            verdict = 2;
+            for (uint32_t i = 0; i < M; ++i) {
+                const double ref = log2(hx[i]);                  // this host's libm: what the reference would call here
+                if (memcmp(&ref, &hy[i], sizeof(double)) != 0) {
+                    verdict = 3;
+                    if (getenv("QVZ_CB_DEBUG")) fprintf(stderr, "qvz: device log2 differs from this host's: x=%a libm=%a device=%a -> host hand-over\n", hx[i], ref, hy[i]);
+                    break;
+                }
+            }
+        }
+    }
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (s) (void)hipStreamDestroy(s);
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        L->state = verdict;
+    }
+    L->cv.notify_all();
+}
+
+static Log2Check *log2_check_start() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    Log2Check *L;
+    {
+        std::lock_guard<std::mutex> g(g_log2_mu);
+        if (!g_log2[dev]) g_log2[dev] = new Log2Check();
+        L = g_log2[dev];
+    }
+    std::lock_guard<std::mutex> lk(L->mu);
+    if (L->state == 0) {
+        L->state = 1;
+        std::thread(log2_selftest_run, dev, L).detach();
+    }
+    return L;
+}
+
+extern "C" int qvz_hip_codebook_warmup(void) {                   // starts the check on a thread of its own; returns at once
+    const char *e = getenv("QVZ_CB_LOG2");
+    if (e && strcmp(e, "host") == 0) return QVZ_OK;
+    return log2_check_start() ? QVZ_OK : qvz_set_error(QVZ_E_HIP, "no current device");
+}
+
+static bool log2_exact_on_this_device();
+extern "C" int qvz_hip_codebook_exact_entropies(void) { return log2_exact_on_this_device() ? 1 : 0; }
+
+static bool log2_exact_on_this_device() {
+    const char *e = getenv("QVZ_CB_LOG2");
+    if (e && strcmp(e, "host") == 0) return false;
+    Log2Check *L = log2_check_start();
+    if (!L) return false;
+    std::unique_lock<std::mutex> lk(L->mu);
+    L->cv.wait(lk, [&] { return L->state >= 2; });
+    return L->state == 2;
+}
+
 static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
                     qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
     const size_t tile = (size_t)A * A;
@@ -701,7 +833,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
         QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocMapped));
         QVZ_HIP_CHECK(hipMalloc(&W.stop, A * sizeof(uint32_t)));
-        QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A), hipHostMallocMapped));
+        QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A) + A * sizeof(LmIn), hipHostMallocMapped));
         QVZ_HIP_CHECK(hipHostMalloc(&W.flag, 64, hipHostMallocMapped));
         *W.flag = 0;
         W.seq = 0;
@@ -737,6 +869,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     double *hr2 = reinterpret_cast<double *>(hin + A);                  // [2][A]
     uint8_t *hq2 = reinterpret_cast<uint8_t *>(hr2 + 2 * A);            // [2][2 * tile]
     uint8_t *hu2 = hq2 + 2 * 2 * tile;                                  // [2][4 * A]
+    LmIn *hplan = reinterpret_cast<LmIn *>(hu2 + 2 * 4 * A);            // [A] exact mode: the device's plan of a column with its exact targets
     LmDesign *hout = W.hout;
     uint8_t *pin_d = nullptr;                                           // the same areas as the device sees them
     LmDesign *hout_d = nullptr;
@@ -749,6 +882,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     double *hr2_d = reinterpret_cast<double *>(hin_d + A);
     uint8_t *hq2_d = reinterpret_cast<uint8_t *>(hr2_d + 2 * A);
     uint8_t *hu2_d = hq2_d + 2 * 2 * tile;
+    LmIn *hplan_d = reinterpret_cast<LmIn *>(hu2_d + 2 * 4 * A);
+    // Entropies: the device's own (glibc's log2 restated, qvz_log2_glibc.h) once they have been checked against this host's
+    // libm; then the targets and every `entropy < target` come from the device and the host calls libm no more. Otherwise
+    // the device values only steer and the host's libm decides inside the guard band, as before.
+    const bool exact = log2_exact_on_this_device();
     const bool cb_debug = getenv("QVZ_CB_DEBUG") != nullptr;
     const bool spin = !getenv("QVZ_CB_SYNC");                           // development knob: wait with hipStreamSynchronize instead
     // Waits for hand-over number `seq`, raised by a k_cb_flag (flag_after): everything enqueued before it has run and its
@@ -777,9 +915,9 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     };
     const bool stage_kernel = getenv("QVZ_CB_STAGE") != nullptr;        // development knob: copy the host's tables to the device first
     auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win) -> uint32_t {
-        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard);
-        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard);
-        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard);
+        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0);
+        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0);
+        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0);
         return flag_after();
     };
     LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
@@ -832,7 +970,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             // k_ctx_xpmf plans the first design window on the device (all-zero rows and zero targets are exact on both
             // sides; its log2-based target only steers which designs give up early), so the window follows at once
             hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf, hx_d,
-                               W.lin, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio);
+                               W.lin, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio, exact ? 1 : 0, hplan_d);
             pq ^= 1;
             d_rows = W.xpmf;
             win0 = window0;
@@ -864,6 +1002,14 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         memset(hin, 0, A * sizeof(LmIn));
         const double t_tg = cb_now();
         for (uint32_t j = 0; j < nu; ++j) {
+            if (exact && s > 0) {
+                // the device's plan of this column: all-zero row (mode 0), target exactly 0 (mode 2), else the exact target -
+                // get_entropy of the row times the -f ratio, or the -r rate (codebook.c:444-447) - computed beside the row
+                zero[j] = hplan[j].mode == 0;
+                target[j] = hplan[j].target;
+                if (!zero[j]) { hin[j] = hplan[j]; any_gpu = true; }
+                continue;
+            }
             const double *pj = hx + (size_t)j * A;
             zero[j] = true;
             for (int i = 0; i < A; ++i) if (pj[i] != 0.0) { zero[j] = false; break; }
@@ -909,7 +1055,8 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                         return qvz_set_error(QVZ_E_HIP, "column %u context %u: design %u missing", s, j, hin[j].startS + w);
                     const double diff = d[w].hdev - target[j];
                     bool below;
-                    if (fabs(diff) <= guard) { g_deferred += 1; below = entropy_libm(d[w].o) < target[j]; }
+                    if (exact) below = d[w].hdev < target[j];                       // hdev is get_entropy(d[w].o): codebook.c:249-258 as it stands
+                    else if (fabs(diff) <= guard) { g_deferred += 1; below = entropy_libm(d[w].o) < target[j]; }
                     else below = diff < 0.0;
                     if (!below || d[w].S >= A) { done = true; break; }
                 }
@@ -950,7 +1097,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                 if (target[j] == 0.0) {
                     ratio = 1.0;
                 } else {
-                    const double lo_entropy = entropy_libm(lo_d[j].o), hi_entropy = entropy_libm(hi_d[j].o);
+                    const double lo_entropy = exact ? lo_d[j].hdev : entropy_libm(lo_d[j].o), hi_entropy = exact ? hi_d[j].hdev : entropy_libm(hi_d[j].o);
                     if (hi_entropy < target[j]) ratio = 0.0;
                     else if (lo_entropy >= target[j] || hi_entropy == lo_entropy) ratio = 1.0;
                     else ratio = (target[j] - hi_entropy) / (lo_entropy - hi_entropy);

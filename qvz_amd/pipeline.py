@@ -125,6 +125,8 @@ class HipBackend:
         self.device_index = device_index
         self.timer = timer or Timer(False)
         self._side = None
+        from ._lib import lib
+        lib().qvz_hip_codebook_warmup()     # once per process: glibc's log2 as restated for the device against this host's (include/qvz_codebook.h)
 
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)

@@ -59,3 +59,5 @@ int qvz_hip_scatter_streams(const uint8_t *d_packed, const uint64_t *h_sizes, ui
 int qvz_hip_mem_info(uint64_t *free_bytes, uint64_t *total_bytes) { U(free_bytes); U(total_bytes); return nodev(); }
 uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards) { U(longest_reads); U(columns); U(clusters); U(shards); return 0; }
 int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, const uint64_t *h_bounds, uint64_t work_bytes) { U(n); U(columns); U(clusters); U(cbs); U(shards); U(h_bounds); U(work_bytes); return nodev(); }
+int qvz_hip_codebook_warmup(void) { return nodev(); }
+int qvz_hip_codebook_exact_entropies(void) { return 0; }

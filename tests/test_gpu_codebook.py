@@ -59,9 +59,11 @@ def test_codebook_matches_oracle_and_reference_bytes(K, name):
 
 
 @pytest.mark.parametrize("name", ["t2k_r10_M", "t2k_f05_L", "uniform72_f09_M", "r35_high_rate"])
-def test_host_decides_everything_with_infinite_guard(K, name):
+def test_host_decides_everything_with_infinite_guard(K, name, monkeypatch):
     """Rare-branch test: with a huge guard band every search decision is deferred to host libm and the search is
-    resumed state by state; the codebook must not change."""
+    resumed state by state; the codebook must not change. (QVZ_CB_LOG2=host: the hand-over in which the device's entropies
+    only steer - what runs when the device's log2 has not been verified against this host's.)"""
+    monkeypatch.setenv("QVZ_CB_LOG2", "host")
     rows, opts, cnt, d, refs = oracle_codebooks(name)
     cb, deferred = K.generate_codebook(torch.from_numpy(cnt[0].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"],
                                        guard=1e30)
@@ -70,6 +72,27 @@ def test_host_decides_everything_with_infinite_guard(K, name):
     cb2, deferred2 = K.generate_codebook(torch.from_numpy(cnt[0].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"])
     assert deferred2 <= deferred
     assert_same_codebook(cb2, refs[0])
+
+
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_device_entropies_decide_like_the_hosts_libm(K, name, monkeypatch):
+    """The device evaluates the reference's entropies itself - glibc's log2 restated (qvz_amd/csrc/qvz_log2_glibc.h), checked
+    against this host's log2 on 2^20 arguments when the process first generates a codebook - and takes every
+    `entropy < target` decision and every ratio from them; with QVZ_CB_LOG2=host the host's libm does, as before. Same
+    codebooks either way, equal to the oracle's, and the check must have PASSED on this box (otherwise the fast path would
+    silently be off)."""
+    from qvz_amd._lib import lib
+    assert lib().qvz_hip_codebook_exact_entropies() == 1, "the device's log2 does not reproduce this host's libm"
+    rows, opts, cnt, d, refs = oracle_codebooks(name)
+    for j in range(opts["k"]):
+        dev_cnt = torch.from_numpy(cnt[j].view(np.int32)).cuda()
+        a, deferred = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
+        assert deferred == 0                                      # nothing is deferred to the host when the device's values are exact
+        assert_same_codebook(a, refs[j])
+        monkeypatch.setenv("QVZ_CB_LOG2", "host")
+        b, _ = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
+        monkeypatch.delenv("QVZ_CB_LOG2")
+        assert_same_codebook(b, a)                                # ratio bits included
 
 
 def test_device_tables_match_python_builder(K):

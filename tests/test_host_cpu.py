@@ -303,3 +303,18 @@ def test_distortion_matrix_host():
     from qvz_amd import kernels as K
     for kind in "MLA":
         assert K.distortion_matrix(kind).tobytes() == O.distortion(kind).tobytes()
+
+
+def test_glibc_log2_restatement_equals_this_hosts_log2(tmp_path):
+    """qvz_amd/csrc/qvz_log2_glibc.h (what the GPU evaluates entropies with) built for the host: bit-identical to libm's
+    log2 on 2e7 arguments of the kinds the pmfs hold - count / total quotients, products, the close-to-1 branch and its
+    edges, powers of two, arbitrary mantissas (1e8 when it was written). The constants are the library's own
+    (tools/extract_glibc_log2.py); the product repeats this check on the device before it lets device entropies decide."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "log2_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-std=gnu11", "-I", os.path.join(root, "qvz_amd", "csrc"), "-o", exe,
+                    os.path.join(root, "tests", "log2_check.c"), "-lm"], check=True)
+    for seed in (1, 2026):
+        r = subprocess.run([exe, "10000000", str(seed)], capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
