@@ -77,31 +77,38 @@ __device__ __forceinline__ uint32_t ld_take(LaneDecoder &d, uint32_t nb) {   // 
     return v;
 }
 
-// One symbol with table t ([n][card][counts...]); returns the state, or card on a corrupt stream.
-__device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restrict__ t, bool last) {
-    // The first 14 counts come in with the header in four independent 16-byte loads (tables are 16-byte aligned and
-    // the arena has slack behind it), so the cumulative search runs in registers: walking the counts one dependent
-    // load at a time cost several cache round trips per symbol.
+// One symbol with table t; returns the state, or 0xFFFFFFFF on a corrupt stream. Decoder tables are laid out
+//   [n][card][recon 0..7, a byte each][counts 0 .. card-1][recon 8 .. card-1]
+// so that the 64 bytes the decode needs anyway - four independent 16-byte loads, ONE memory round trip for a lane whose
+// table lies in HBM or the Infinity Cache - also hold the quality values of the first eight states: with the output
+// alphabet behind the counts, in another cache line, mapping the state back to a value was a second dependent round trip
+// for every symbol (4.2 s for 100M x 150 reads). *val: the value of the state (x < card).
+__device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restrict__ t, bool last, uint32_t *val) {
+    // The first 12 counts come in with the header, so the cumulative search runs in registers: walking the counts one
+    // dependent load at a time cost several cache round trips per symbol.
     const uint4 h0 = reinterpret_cast<const uint4 *>(t)[0], h1 = reinterpret_cast<const uint4 *>(t)[1],
                 h2 = reinterpret_cast<const uint4 *>(t)[2], h3 = reinterpret_cast<const uint4 *>(t)[3];
     const uint32_t n = h0.x, card = h0.y;
-    const uint32_t cn[14] = {h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+    const uint32_t cn[12] = {h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
     const uint32_t range = d.u - d.l + 1;
     const uint64_t gap = (uint64_t)(d.t - d.l) + 1;
     const uint32_t sub = dec_div(gap * n - 1, range);           // arith.c:134 / :199 (below n, so 32 bits hold it either way)
     uint32_t cum = 0, k = 0, fxr = 0;                            // arith.c:136-139: first k with c_0 + .. + c_k > sub
     bool found = false;
 #pragma unroll
-    for (int i = 0; i < 14; ++i) {
+    for (int i = 0; i < 12; ++i) {
         const bool take = !found && (uint32_t)i < card && sub >= cum;
         cum += take ? cn[i] : 0u;
         fxr = take ? cn[i] : fxr;
         k += take ? 1u : 0u;
         found = found || !take;
     }
-    while (k >= 14 && k < card && sub >= cum) { fxr = t[2 + k++]; cum += fxr; }   // long tables: the rest from memory
-    if (sub >= cum) return card;                                 // ran off the table: not a stream of this model
+    while (k >= 12 && k < card && sub >= cum) { fxr = t[4 + k++]; cum += fxr; }   // long tables: the rest from memory
+    if (sub >= cum) return 0xFFFFFFFFu;                          // ran off the table: not a stream of this model
     const uint32_t x = k - 1;
+    // the state's value: one of the eight bytes that came with the header, or - long tables, rare states - behind the counts
+    *val = x < 8 ? ((x < 4 ? h0.z : h0.w) >> (8 * (x & 3))) & 0xFF
+                 : (t[4 + card + ((x - 8) >> 2)] >> (8 * (x & 3))) & 0xFF;
     if (last) return x;                                          // decoder_last_step: nothing else changes
     const uint32_t fx = fxr, cum_lo = cum - fx;
     uint32_t u = d.l + dec_div((uint64_t)range * cum, n) - 1;    // arith.c:146-147
@@ -122,13 +129,13 @@ __device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restri
     tg = (((tg << j) & MASK_M) | ld_take(d, j)) ^ (j ? MSB : 0u);
     ld_refill(d);
     d.l = l; d.u = u; d.t = tg;
-    t[2 + x] = fx + STEP;                                        // update_stats, qv_stream.c:12-24
+    t[4 + x] = fx + STEP;                                        // update_stats, qv_stream.c:12-24
     uint32_t nn = n + STEP;
     if (nn > RESCALE) {
         nn = 0;
         for (uint32_t i = 0; i < card; ++i) {
-            const uint32_t v = t[2 + i];
-            if (v) { const uint32_t hv = (v >> 1) + 1; t[2 + i] = hv; nn += hv; }
+            const uint32_t v = t[4 + i];
+            if (v) { const uint32_t hv = (v >> 1) + 1; t[4 + i] = hv; nn += hv; }
         }
     }
     t[0] = nn;
@@ -183,8 +190,9 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
         if (on) {
             uint32_t cl = 0;
             if (HAVE_LABELS) {                                   // qv_read_cluster, qv_compressor.c:36-43
-                cl = ld_decode(d, ar, false);
-                if (cl >= K) { bad = true; cl = 0; }
+                uint32_t unused;
+                cl = ld_decode(d, ar, false, &unused);
+                if (cl >= K) { bad = true; cl = 0; }                                 // (0xFFFFFFFF, ran off the table, included)
                 labels[r0 + i] = (uint8_t)cl;
             }
             uint32_t prev = 0;
@@ -195,10 +203,10 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
                 const uint32_t o = draw >= (cv.x >> 24) ? cv.y : (cv.x & 0xFFFFFFu); // hi : lo quantizer, codebook.c:165-170
                 if (o == 0xFFFFFFu) { bad = true; break; }                           // dead context: no table
                 const bool last = i + 1 == nreads && s + 1 == C;                     // qv_compressor.c:222-225
-                const uint32_t x = ld_decode(d, ar + o, last);
-                const uint32_t card = ar[o + 1];
-                if (x >= card) { bad = true; break; }
-                prev = (ar[o + 2 + card + (x >> 2)] >> (8 * (x & 3))) & 0xFF;        // the quantizer's output alphabet
+                uint32_t value = 0;
+                const uint32_t x = ld_decode(d, ar + o, last, &value);
+                if (x == 0xFFFFFFFFu) { bad = true; break; }                         // ran off the table
+                prev = value;                                                        // the quantizer's output alphabet
                 sb[(s * 64 + lane) * 4 + (uint32_t)(i & 3)] = (uint8_t)prev;
             }
         }
@@ -273,24 +281,32 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     } while (0)
     if (!h_first) { rc = qvz_set_error(QVZ_E_NOMEM, "host alloc"); goto done; }
     {
-        const uint32_t head = 2 + clusters;                      // the cluster-id table stays first
-        for (uint32_t i = 0; i < head; ++i) h_dar.push_back(h_arena[i]);
-        while (h_dar.size() & 3) h_dar.push_back(0);
+        // every table of qvz_model_build ([n][card][counts]) re-laid as [n][card][recon 0..7][counts][recon 8..], 16-byte aligned;
+        // the cluster-id table first (its "values" are the ids themselves and are not used)
+        auto put_table = [&](const uint32_t *tb, const uint8_t *rc8) {
+            const uint32_t card = tb[1];
+            h_dar.push_back(tb[0]); h_dar.push_back(card);
+            for (uint32_t w0 = 0; w0 < 8; w0 += 4) {
+                uint32_t w = 0;
+                for (uint32_t b = 0; b < 4 && w0 + b < card; ++b) w |= (uint32_t)(rc8 ? rc8[w0 + b] : w0 + b) << (8 * b);
+                h_dar.push_back(w);
+            }
+            for (uint32_t i = 0; i < card; ++i) h_dar.push_back(tb[2 + i]);
+            for (uint32_t i = 8; i < card; i += 4) {
+                uint32_t w = 0;
+                for (uint32_t b = 0; b < 4 && i + b < card; ++b) w |= (uint32_t)(rc8 ? rc8[i + b] : i + b) << (8 * b);
+                h_dar.push_back(w);
+            }
+            while (h_dar.size() & 3) h_dar.push_back(0);
+        };
+        put_table(h_arena, nullptr);                             // offset 0: [n][clusters][counts of the cluster ids]
         for (uint32_t c = 0; c < clusters; ++c)
             for (uint32_t s = 0; s < columns; ++s)
                 for (uint32_t j = 0; j < 2 * A; ++j) {
                     const uint32_t o = h_off[((size_t)c * columns + s) * 2 * A + j];
                     if (o == NO_TABLE) continue;
-                    const uint32_t card = h_arena[o + 1];
                     h_doff[((size_t)c * columns + s) * 2 * A + j] = (uint32_t)h_dar.size();
-                    for (uint32_t i = 0; i < 2 + card; ++i) h_dar.push_back(h_arena[o + i]);
-                    const uint8_t *rc8 = cbs[c]->recon + (((size_t)s * 2 * A) + j) * A;
-                    for (uint32_t i = 0; i < card; i += 4) {
-                        uint32_t w = 0;
-                        for (uint32_t b = 0; b < 4 && i + b < card; ++b) w |= (uint32_t)rc8[i + b] << (8 * b);
-                        h_dar.push_back(w);
-                    }
-                    while (h_dar.size() & 3) h_dar.push_back(0);
+                    put_table(h_arena + o, cbs[c]->recon + (((size_t)s * 2 * A) + j) * A);
                 }
         if (h_dar.size() >= 0xFFFFFFu) { rc = qvz_set_error(QVZ_E_ARG, "model too large for the decoder's 24-bit table offsets"); goto done; }
         dwords = (uint32_t)h_dar.size();
