@@ -86,13 +86,32 @@ def test_device_entropies_decide_like_the_hosts_libm(K, name, monkeypatch):
     rows, opts, cnt, d, refs = oracle_codebooks(name)
     for j in range(opts["k"]):
         dev_cnt = torch.from_numpy(cnt[j].view(np.int32)).cuda()
+        # (1) the default: the host's column-by-column loop over the device's exact entropies
         a, deferred = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
         assert deferred == 0                                      # nothing is deferred to the host when the device's values are exact
         assert_same_codebook(a, refs[j])
-        monkeypatch.setenv("QVZ_CB_LOG2", "host")
-        b, _ = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
-        monkeypatch.delenv("QVZ_CB_LOG2")
+        # (2) all columns driven from the device (QVZ_CB_FLOW=device, k_cb_decide): nothing crosses to the host until the book is complete
+        monkeypatch.setenv("QVZ_CB_FLOW", "device")
+        b, deferred = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
+        monkeypatch.delenv("QVZ_CB_FLOW")
+        assert deferred == 0
         assert_same_codebook(b, a)                                # ratio bits included
+        # (3) ... and with the host's libm taking every decision (what runs when the check fails)
+        monkeypatch.setenv("QVZ_CB_LOG2", "host")
+        c_, _ = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
+        monkeypatch.delenv("QVZ_CB_LOG2")
+        assert_same_codebook(c_, a)
+
+
+@pytest.mark.parametrize("name", ["t2k_r10_M", "r35_high_rate", "uniform72_f09_M"])
+def test_device_driven_generation_with_a_window_that_is_too_short(K, name, monkeypatch):
+    """The design window of a column follows the previous column's largest state count + 3; a walk that runs off it gets the
+    second, full-width round (k_cb_decide, round 2). Forced here for every column by a first window of two designs."""
+    rows, opts, cnt, d, refs = oracle_codebooks(name)
+    monkeypatch.setenv("QVZ_CB_FLOW", "device")
+    monkeypatch.setenv("QVZ_CB_FIRST_WINDOW", "2")
+    cb, _ = K.generate_codebook(torch.from_numpy(cnt[0].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"])
+    assert_same_codebook(cb, refs[0])
 
 
 def test_device_tables_match_python_builder(K):

@@ -6,9 +6,11 @@ export TMPDIR=/tmp
 timeout -k 10 900 python3 -m pytest tests/test_gpu_codebook.py tests/test_gpu_encode.py tests/test_gpu_dropin.py -x -q > $out/pytest.log 2>&1
 echo "pytest rc=$?"; tail -4 $out/pytest.log
 for cfg in 2 1 3; do
-  for how in device host; do
-    echo "== config $cfg, entropies decided by: $how"
-    if [ $how = host ]; then export QVZ_CB_LOG2=host; else unset QVZ_CB_LOG2; fi
+  for how in default device-flow host-libm; do
+    echo "== config $cfg, $how"
+    unset QVZ_CB_LOG2 QVZ_CB_FLOW
+    if [ $how = host-libm ]; then export QVZ_CB_LOG2=host; fi
+    if [ $how = device-flow ]; then export QVZ_CB_FLOW=device; fi
     QVZ_CB_DEBUG=1 timeout -k 10 300 python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline --no-extras 2> $out/err_${cfg}_$how.txt | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('ms_per_step', d['ms_per_step'], 'codebook phase ms', d['step_phase_ms']['codebook'], 'bits/sym', d['bits_per_symbol'])"
