@@ -547,13 +547,34 @@ __device__ double lm_entropy_dev(const double *o) {   // steering value only (de
     return -t;
 }
 
+struct LmRider {           // k_ctx_ptemp of the next column riding on a window launch (rows == 0: none)
+    const double *P, *marg, *qpmf;
+    double *ptemp;
+    uint32_t s, nprev, rows;
+};
+
 // grid (contexts, window); block (ctx, w) designs S = startS + w. distT[i*72 + r] = d(i, r) (lanes walk r: no LDS
 // bank conflicts). blockIdx.x runs fastest, so the small S of every context are dispatched first.
 template <bool TOEP, bool MONO>
 __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm, const double *__restrict__ distT,
                                                   const LmIn *__restrict__ in, LmDesign *__restrict__ out,
                                                   uint32_t *__restrict__ stop, double guard, int exact,
-                                                  const uint32_t *__restrict__ limits) {
+                                                  const uint32_t *__restrict__ limits, LmRider rider) {
+    // Rows of the grid beyond the window (blockIdx.y >= rider.rows) carry k_ctx_ptemp of the NEXT column: it needs this
+    // column's qpmf only, and as blocks of this launch it runs on CUs the designs leave idle instead of being one more
+    // dependent launch in the stream (a dependent launch costs ~11 us on this runtime, the kernel itself 15-23 us).
+    if (rider.rows && blockIdx.y >= rider.rows) {
+        const uint32_t e = ((blockIdx.y - rider.rows) * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
+        if (e >= A * rider.nprev) return;
+        const double *Pc = rider.P + (uint64_t)(rider.s - 1) * A * A;
+        const double *mm = rider.marg + (uint64_t)(rider.s - 2) * A;
+        const uint32_t k = e / rider.nprev, j = e % rider.nprev;
+        double pt = 0;
+#pragma unroll 8
+        for (int x = 0; x < A; ++x) pt += rider.qpmf[x * A + j] * Pc[x * A + k] * mm[x];   // k_ctx_ptemp's sum, term for term
+        rider.ptemp[k * A + j] = pt;
+        return;
+    }
     // limits (device-driven flow, k_cb_decide): {contexts of this column, window width, run this round at all}. The grid is
     // the largest a column can need (72 x 72); what lies outside the column's own numbers returns at once.
     if (limits && (blockIdx.x >= limits[0] || blockIdx.y >= limits[1] || !limits[2])) return;
@@ -564,7 +585,7 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     LmLds *L = reinterpret_cast<LmLds *>(o + A);
     const uint32_t ctx = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
     const LmIn I = in[ctx];
-    LmDesign *O = out + (size_t)ctx * gridDim.y + w;
+    LmDesign *O = out + (size_t)ctx * (rider.rows ? rider.rows : gridDim.y) + w;
     const uint32_t S = (uint32_t)I.startS + w;
     // (`out` is mapped host memory: the results need no copy; the k_cb_flag launched behind this kernel tells the host.
     // Letting the last block raise the flag instead needs a system-scope fence in every block: measured, with the 72 x 72
@@ -1056,9 +1077,9 @@ static int generate_on_device(const void *d_cnt, bool wide, uint32_t C, const do
     else hipLaunchKernelGGL(k_cond_pmf<uint32_t>, dim3(C * A), dim3(64), 0, st, (const uint32_t *)d_cnt, W.P);
     hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
     auto window = [&](const double *rows, const LmIn *in, LmDesign *out, dim3 grid, const uint32_t *limits) {
-        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), grid, dim3(64), LM_LDS_BYTES(true), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits);
-        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), grid, dim3(64), LM_LDS_BYTES(true), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits);
-        else hipLaunchKernelGGL((k_lm_window<false, false>), grid, dim3(64), LM_LDS_BYTES(false), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits);
+        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), grid, dim3(64), LM_LDS_BYTES(true), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits, LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0});
+        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), grid, dim3(64), LM_LDS_BYTES(true), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits, LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0});
+        else hipLaunchKernelGGL((k_lm_window<false, false>), grid, dim3(64), LM_LDS_BYTES(false), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits, LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0});
     };
     // designs for the all-zero pmf depend only on (distortion, S): one launch, 72 waves; dzero[S - 1]
     {
@@ -1257,10 +1278,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         return seq;
     };
     const bool stage_kernel = getenv("QVZ_CB_STAGE") != nullptr;        // development knob: copy the host's tables to the device first
-    auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win) -> uint32_t {
-        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr);
-        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr);
-        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr);
+    auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win, LmRider rider = LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0}) -> uint32_t {
+        const uint32_t extra = rider.rows ? (A * rider.nprev + 64 * nu - 1) / (64 * nu) : 0;     // rows of nu blocks x 64 threads for A * nprev sums
+        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr, rider);
+        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr, rider);
+        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr, rider);
         return flag_after();
     };
     LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
@@ -1317,8 +1339,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             pq ^= 1;
             d_rows = W.xpmf;
             win0 = window0;
-            seq0 = launch_window(d_rows, W.lin, nu, win0);
-            if (s + 1 < C)      // p_temp of column s + 1 needs this column's qpmf only: off the critical path, behind the window
+            // p_temp of column s + 1 needs this column's qpmf only: it rides on the window launch (QVZ_CB_PTEMP=own: a launch of its own behind it)
+            const bool ride = s + 1 < C && !(getenv("QVZ_CB_PTEMP") && strcmp(getenv("QVZ_CB_PTEMP"), "own") == 0);
+            seq0 = ride ? launch_window(d_rows, W.lin, nu, win0, LmRider{W.P, W.marg, W.qpmf[pq], W.ptemp, s + 1, nu, win0})
+                        : launch_window(d_rows, W.lin, nu, win0);
+            if (s + 1 < C && !ride)
                 hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nu + 255) / 256), dim3(256), 0, st, W.P, W.marg, s + 1, nu, W.qpmf[pq], W.ptemp);
         }
         QVZ_HIP_CHECK(hipGetLastError());
