@@ -62,11 +62,11 @@ CHAIN_KERNELS = ("code_records", "arith_shards")
 
 
 def measured_traffic(kernel, args, cfg, shards, world):
-    """HBM bytes per step of `kernel` from the committed PMC passes of this round (profiles/r02_pmc_traffic_cfgN.json), if
+    """HBM bytes per step of `kernel` from the committed PMC passes of this round (profiles/r03_pmc_traffic_cfgN.json), if
     they were taken on this very workload; None otherwise. (The counters need rocprofv3 around the process: tools/
     collect_profiles.sh runs this very script under it; bench.py itself cannot read them.)"""
     try:
-        with open(os.path.join(ROOT, "profiles", f"r02_pmc_traffic_cfg{args.config}.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r03_pmc_traffic_cfg{args.config}.json")) as f:
             t = json.load(f)
         w = t["workload"]
         same = (w["config"] == args.config and w["reads"] == cfg["reads"] and w["columns"] == cfg["cols"] and
@@ -89,7 +89,10 @@ def cpu_baseline(cfg, cores_note):
     times = []
     kind = "reference" if os.path.exists(ref_bin) else "port"
     with tempfile.TemporaryDirectory() as td:
-        for n in samples:
+        for n in list(samples):
+            if times and times[0] > 30.0 and n == samples[-1] and len(samples) == 3:
+                samples = samples[:2]          # the N-independent part alone takes a minute (three clusters' codebooks): two samples bound the run
+                break
             rows = O.qgen1_rows(cfg["seed"], n, c)
             if kind == "reference":
                 inp = os.path.join(td, f"s{n}.txt")
@@ -109,10 +112,11 @@ def cpu_baseline(cfg, cores_note):
     fixed = max(float(fixed), 0.0)
     full = cfg["reads"] * c
     n3, t3 = samples[-1], times[-1]
+    others = "; ".join(f"{n_} reads {t_:.2f} s" for n_, t_ in zip(samples[:-1], times[:-1]))
     return dict(value=round(n3 * c / t3, 1), unit="quality-symbols/s", cores=1, kind=kind,
                 sample=f"QGEN-1 seed {cfg['seed']}, {n3} reads x {c} cols, flags {' '.join(flags)}, whole encode() incl. codebook "
-                       f"generation, {t3:.2f} s (`value`); also {samples[0]} reads {times[0]:.2f} s and {samples[1]} reads {times[1]:.2f} s; "
-                       "the full workload's figure below is a three-point extrapolation, not a run",
+                       f"generation, {t3:.2f} s (`value`); also {others}; "
+                       f"the full workload's figure below is a {len(samples)}-point extrapolation, not a run",
                 sample_seconds={str(n_): round(t_, 3) for n_, t_ in zip(samples, times)},
                 seconds_per_symbol=float(slope), fixed_seconds=round(fixed, 3),
                 extrapolated_full_workload_value=round(full / (fixed + slope * full), 1),
@@ -513,7 +517,7 @@ def main():
         roof = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(dom, args, cfg, shards, world),
                     ms_per_launch=round(per_launch[dom], 4), algorithmic_bytes_per_launch=int(alg_bytes),
-                    bytes_per_symbol=bps, traffic_source=f"profiles/r02_pmc_traffic_cfg{args.config}.json (rocprofv3 --pmc FETCH_SIZE / "
+                    bytes_per_symbol=bps, traffic_source=f"profiles/r03_pmc_traffic_cfg{args.config}.json (rocprofv3 --pmc FETCH_SIZE / "
                     "WRITE_SIZE passes of this workload, FETCH_SIZE x2 per the gfx950 correction); null if the workload differs")
         pmf_ach = (n * c + (n if k > 1 else 0)) / (per_launch["pmf_hist"] * 1e-3) / 1e9
         wall = {ph: round(float(np.mean([r["wall"][ph] for r in results])), 4) for ph in results[-1]["wall"]}
