@@ -551,6 +551,17 @@ def main():
                                 ns_per_symbol_per_stream=round(per_step.get("code_records", per_step.get("arith_shards", 0.0))
                                                                * 1e6 * shards / (n * c), 2)) if args.coder != "host" else None,
         }
+        if args.coder == "gpu":
+            # the coder phase against what SURVEY section 8(d) prices it at: 2 B per symbol in (quantizer index, state) + the streams out;
+            # everything beyond that is the builder's own intermediate record (16 B per symbol written by the model kernel, read by the chain)
+            tm, tc = measured_traffic("model_records", args, cfg, shards, world), measured_traffic("code_records", args, cfg, shards, world)
+            survey = 2.0 * n * c + results[-1]["total_stream_bytes"]
+            line["coder_phase_traffic"] = dict(hbm_bytes=(tm + tc) if tm and tc else None, survey_8d_bytes=int(survey),
+                                               ratio=round((tm + tc) / survey, 2) if tm and tc else None,
+                                               phase_ms=round(wall["coder"] * 1e3, 2),
+                                               survey_bytes_over_phase_GBps=round(survey / wall["coder"] / 1e9, 1),
+                                               note="model + chain kernels' HBM bytes (PMC, profiles/) over SURVEY 8(d)'s bytes for the phase: the records' "
+                                                    "round trip through HBM is the price of splitting the adaptive model from the serial chain (DESIGN.md section 6.7)")
         if args.roundtrip and args.coder != "host":
             line["roundtrip"] = roundtrip
         line["qv_plane_written_in_step"] = not args.no_u and args.coder != "host"
