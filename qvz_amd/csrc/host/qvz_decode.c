@@ -10,6 +10,10 @@
  *   qvz_decode_shard_files the files written by qvz_encode_file_sharded ("<prefix>.0000" ...): every shard is one lane of
  *                          the GPU decoder (qvz_hip_decode_shards); output = the decodes in order
  */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -227,6 +231,22 @@ int qvz_qfile_parse(const uint8_t *f, size_t size, qvz_qfile_t *q) {
     return QVZ_OK;
 }
 
+/* A file somebody wrote, mapped read-only (no copy: a shard set of 100M x 150 reads is 2.6 GB, and its streams go from the page
+ * cache through pinned slabs to the device). qvz_unmap_file releases it. */
+int qvz_map_file(const char *path, const uint8_t **buf, size_t *size) {
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0) return qvz_job_fail(QVZ_E_ARG, "Unable to open input file %s", path);
+    if (fstat(fd, &st) || st.st_size <= 0) { close(fd); return qvz_job_fail(QVZ_E_ARG, "cannot read %s", path); }
+    void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return qvz_job_fail(QVZ_E_NOMEM, "cannot map %s", path);
+    *buf = (const uint8_t *)m;
+    *size = (size_t)st.st_size;
+    return QVZ_OK;
+}
+void qvz_unmap_file(const uint8_t *buf, size_t size) { if (buf) munmap((void *)buf, size); }
+
 int qvz_read_whole_file(const char *path, uint8_t **buf, size_t *size) {
     FILE *f = fopen(path, "rb");
     if (!f) return qvz_job_fail(QVZ_E_ARG, "Unable to open input file %s", path);
@@ -289,17 +309,17 @@ done:
 }
 
 int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_result_t *res) {
-    uint8_t *f = NULL;
+    const uint8_t *f = NULL;
     size_t size = 0;
     qvz_qfile_t q;
     int rc;
     memset(&q, 0, sizeof(q));
-    if ((rc = qvz_read_whole_file(in_path, &f, &size))) return rc;
+    if ((rc = qvz_map_file(in_path, &f, &size))) return rc;
     if (qvz_shardset_is(f, size)) {                                             /* a shard set (include/qvz_shardset.h): all streams at once on the GPU */
-        free(f);
+        qvz_unmap_file(f, size);
         return qvz_shardset_decode(in_path, out_path, device, res);
     }
-    if ((rc = qvz_qfile_parse(f, size, &q))) { free(f); return rc; }
+    if ((rc = qvz_qfile_parse(f, size, &q))) { qvz_unmap_file(f, size); return rc; }
     FILE *fo = fopen(out_path, "w");
     if (!fo) rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
     else {
@@ -307,7 +327,7 @@ int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_r
         fclose(fo);
     }
     if (!rc && res) { memset(res, 0, sizeof(*res)); res->lines = q.lines; res->columns = q.C; res->stream_bytes = size - q.stream_at; res->file_bytes = size; }
-    free(f);
+    qvz_unmap_file(f, size);
     qvz_qfile_release(&q);
     return rc;
 }

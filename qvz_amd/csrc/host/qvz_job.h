@@ -118,6 +118,8 @@ int qvz_qfile_parse(const uint8_t *f, size_t size, qvz_qfile_t *q);       /* hea
 void qvz_qfile_release(qvz_qfile_t *q);
 int qvz_codebooks_parse(const uint8_t *f, size_t size, size_t *pos, uint32_t K, uint32_t C, qvz_codebook_t ***out);
 int qvz_read_whole_file(const char *path, uint8_t **buf, size_t *size);
+int qvz_map_file(const char *path, const uint8_t **buf, size_t *size);      /* read-only mapping of a whole file */
+void qvz_unmap_file(const uint8_t *buf, size_t size);
 /* start_qv_decompression (qv_compressor.c:145-231) over memory: the serial chain and the WELL draws on one host core */
 int qvz_decode_stream_host(uint32_t K, uint32_t C, uint64_t lines, const qvz_codebook_t *const *cbs, const uint32_t *well,
                            const uint8_t *stream, size_t size, FILE *fo, int verbose);

@@ -187,13 +187,13 @@ done:
 }
 
 int qvz_shardset_decode(const char *path, const char *out_path, int device, qvz_result_t *res) {
-    uint8_t *f = NULL;
+    const uint8_t *f = NULL;
     size_t size = 0;
     sset_t t;
     const uint8_t **streams = NULL;
-    int rc = qvz_read_whole_file(path, &f, &size);
+    int rc = qvz_map_file(path, &f, &size);                                     /* mapped, not copied: the streams go page cache -> pinned slabs -> device */
     if (rc) return rc;
-    if ((rc = sset_parse(f, size, &t))) { free(f); return rc; }
+    if ((rc = sset_parse(f, size, &t))) { qvz_unmap_file(f, size); return rc; }
     streams = (const uint8_t **)calloc(t.S, sizeof(*streams));
     if (!streams) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
     for (uint32_t g = 0; g < t.S; ++g) streams[g] = f + t.at[g];
@@ -206,6 +206,6 @@ int qvz_shardset_decode(const char *path, const char *out_path, int device, qvz_
 done:
     free(streams);
     sset_release(&t);
-    free(f);
+    qvz_unmap_file(f, size);
     return rc;
 }
