@@ -6,11 +6,13 @@
  * generate_quantizer / apply_quantizer (src/quantizer.c:34-161).
  *
  * Where the arithmetic runs: every probability table, every Lloyd-Max design and every output pmf is computed
- * by HIP kernels in the reference's summation order (FP64, no FMA contraction). Two things stay on the host by
- * design, because they are decision-bearing libm values that must be bit-identical to the reference's:
- * log2() for entropies (src/pmf.c:150) and the few scalar operations that turn two entropies into `ratio`
- * (src/codebook.c:263-268). The device uses its own log2 only to steer the search, inside a guard band; any
- * decision that falls inside the band is re-taken by the host from the libm value.
+ * by HIP kernels in the reference's summation order (FP64, no FMA contraction). The entropies that decide codebook
+ * bytes (src/pmf.c:141-155, src/codebook.c:244-268) are libm log2 values in the reference; since round 3 the device
+ * evaluates glibc's own log2 (qvz_amd/csrc/qvz_log2_glibc.h: the routine restated operation by operation, its
+ * constants read out of libm.so.6) once a run-time check has found it bit-identical to this host's log2
+ * (qvz_hip_codebook_warmup / qvz_hip_codebook_exact_entropies). Until then - or with QVZ_CB_LOG2=host - the device's
+ * own log2 only steers the search, inside a guard band, and the host's libm takes every decision that falls inside
+ * the band and computes the entropies that become `ratio`.
  */
 #ifndef QVZ_CODEBOOK_H
 #define QVZ_CODEBOOK_H
