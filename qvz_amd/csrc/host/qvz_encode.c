@@ -774,9 +774,10 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     job->t_quantize = t1 - t0;
 
     /* beside the coder kernels: the per-read errors (0.8 GB over PCIe, then the file-order sum on one host core). The -u text
-     * starts when the coder has finished - its slabs keep two more streams and the copy engines busy for seconds, and beside
-     * them the coder phase took 1 - 3 s instead of 0.16 (QVZ_EGRESS_OVERLAP=1 brings that schedule back for measurements) -
-     * and runs beside the way out of the streams. */
+     * starts when the coder has finished and runs beside the way out of the streams; QVZ_EGRESS_OVERLAP=1 starts it beside the
+     * coder kernels instead. Measured on a settled GPU the two schedules do not differ beyond the noise of the file writes
+     * (coder phase 0.16-0.17 s either way, the whole encode 3.4-4.8 s: profiles/r03_e2e_cli.txt); the 1-3 s coder phases first
+     * blamed on the overlap were the allocation stall of a process that starts right after another has freed its HBM. */
     const int overlap_text = getenv("QVZ_EGRESS_OVERLAP") && atoi(getenv("QVZ_EGRESS_OVERLAP"));
     task_err.device = task_text.device = job->opts.device;
     task_err.d_err = d_err; task_err.N = N; task_err.C = C;
