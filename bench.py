@@ -99,7 +99,7 @@ def cpu_baseline(cfg, cores_note):
                 open(inp, "wb").write(rows.tobytes())
                 del rows
                 t = time.perf_counter()
-                subprocess.run([ref_bin] + flags + [inp, os.path.join(td, "s.q")], check=True, capture_output=True)
+                subprocess.run([ref_bin] + flags + [inp, os.path.join(td, "s.q")], check=True, capture_output=True, timeout=600)
                 times.append(time.perf_counter() - t)
                 os.remove(inp)
             else:
@@ -294,7 +294,7 @@ def e2e_cli_report(cfg, sym, n, c, shards):
         def timed(cmd, **kw):
             time.sleep(settle)
             t = time.perf_counter()
-            res = subprocess.run(cmd, capture_output=True, text=True, **kw)
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, **kw)
             return res, time.perf_counter() - t
 
         def phases_of(res):
@@ -565,25 +565,33 @@ def main():
         if args.roundtrip and args.coder != "host":
             line["roundtrip"] = roundtrip
         line["qv_plane_written_in_step"] = not args.no_u and args.coder != "host"
+        def guarded(name, fn, *a):
+            # what comes after the timed steps must not be able to take the headline with it: an exception (or a child process
+            # that does not come back) becomes an entry that says so
+            try:
+                line[name] = fn(*a)
+            except Exception as exc:       # noqa: BLE001 - reported, not swallowed
+                line[name] = dict(failed=f"{type(exc).__name__}: {exc}"[:600])
+
         if not args.no_extras and world == 1 and args.coder == "gpu" and "coded" in results[-1]:
-            line["product"] = product_report(results[-1], n, c, k, shards, args.steps, elapsed)
+            guarded("product", product_report, results[-1], n, c, k, shards, args.steps, elapsed)
             for key in ("coded", "qv", "labels"):
                 results[-1].pop(key, None)
-            line["ingest"] = ingest_report(cfg, n, c)
-            line["roofline_pmf_hist_72_symbols"] = pmf72_report(n, c)
-            line["strict"] = strict_report(cfg, c)
-            line["other_configs"] = other_configs_report(args, cfg, sym, threads)
-            line["e2e_cli"] = e2e_cli_report(cfg, sym, n, c, shards)
+            guarded("ingest", ingest_report, cfg, n, c)
+            guarded("roofline_pmf_hist_72_symbols", pmf72_report, n, c)
+            guarded("strict", strict_report, cfg, c)
+            guarded("other_configs", other_configs_report, args, cfg, sym, threads)
+            guarded("e2e_cli", e2e_cli_report, cfg, sym, n, c, shards)
         if not args.no_cpu_baseline and world == 1:               # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            line["cpu_baseline"] = cpu_baseline(CONFIGS[args.config], f"{cores} host cores visible, 1 used")
-            if "strict" in line:                                  # the byte-identical single-stream file against the reference ON THIS HOST
+            guarded("cpu_baseline", cpu_baseline, CONFIGS[args.config], f"{cores} host cores visible, 1 used")
+            if "gpu_model" in line.get("strict", {}) and "seconds_per_symbol" in line.get("cpu_baseline", {}):   # the byte-identical single-stream file against the reference ON THIS HOST
                 ref_ns = line["cpu_baseline"]["seconds_per_symbol"] * 1e9
                 gpu_ns = line["strict"]["gpu_model"]["ns_per_symbol"]
                 line["strict"]["reference_ns_per_symbol_same_host"] = round(ref_ns, 2)
                 line["strict"]["speedup_vs_same_host_reference"] = round(ref_ns / gpu_ns, 2) if gpu_ns else None
                 line["strict"]["speedup_note"] = ("per-symbol slope of the reference's encode (all N-dependent phases) over the strict path's "
                                                   "start_qv_compression phase, both on this host's cores; the format's one serial stream caps it")
-        if "strict" in line:
+        if "gpu_model" in line.get("strict", {}):
             # what sharding costs in bits: the same quantized symbols as ONE stream (the strict sample, 2M reads) and as the
             # sharded product's share of streams for that many reads would be unfair to compare; the full-size figures with fewer
             # streams are measurements of earlier rounds' sweeps (profiles/r01_a_bench_cfg2.jsonl, r02_stream_sweep_cfg2.jsonl)
