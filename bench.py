@@ -400,6 +400,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # Rehearsal aid for a box with ONE GPU (the N > 1 launch line cannot be tried there otherwise): QVZ_BENCH_ONE_DEVICE=1 puts
+    # every rank on cuda:0 and QVZ_BENCH_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device). Never set
+    # by the driver: on a multi-GPU node it is one rank per GPU over RCCL ("nccl").
+    if os.environ.get("QVZ_BENCH_ONE_DEVICE"):
+        local = 0
+    backend = os.environ.get("QVZ_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     group = None
     if world > 1 or os.environ.get("QVZ_BENCH_FORCE_DIST"):   # (the variable: a one-rank RCCL group, to rehearse the N > 1 code path on one GPU)
@@ -407,7 +413,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     cfg = dict(CONFIGS[args.config])

@@ -87,3 +87,31 @@ def test_two_ranks_on_one_gpu_with_the_hip_backend(k, mode, ratio, dist_kind):
             image = O.write_header(k, COLS, e - a) + blob + states[g] + streams[g]
             assert O.decode(image) == ushard[a:e].tobytes(), f"rank {rank} shard {g}"
     assert u == single["u"].tobytes(), "the ranks' quantized values, concatenated, are the single-process -u output"
+
+
+def test_bench_launch_line_with_two_ranks(tmp_path):
+    """The driver's N > 1 command for bench.py, word for word (python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...), on the one GPU of a test box: QVZ_BENCH_ONE_DEVICE puts both
+    ranks on cuda:0 and QVZ_BENCH_BACKEND=gloo carries the collectives. Rank 0 alone prints, one JSON line, with the whole-job
+    value (both ranks' symbols over the max-over-ranks time) and the keys the contract names."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    reads, steps = 2_000_000, 2
+    env = dict(os.environ, QVZ_BENCH_ONE_DEVICE="1", QVZ_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--reads", str(reads), "--steps", str(steps),
+                        "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["metric"] == "quality-symbols/s (encode)" and d["unit"] == "quality-symbols/s" and d["dtype"] == "u8" and d["vs_baseline"] is None
+    assert d["config"]["reads_per_gpu"] == reads and d["config"]["parallelism"] == "read-sharded x2"
+    assert d["value"] == pytest.approx(2 * reads * 150 / (d["ms_per_step"] * 1e-3), rel=1e-3)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None            # rank 0 at N = 1 only
+    assert 0.5 < d["bits_per_symbol"] < 3.0

@@ -18,6 +18,7 @@
 #   pmf                          PMF pass with three clusters: label bytes against 2-bit labels, groups per thread
 #   codebook                     codebook parity tests, then the phase three ways (host loop / device flow / host libm)
 #   decoder                      decoder parity tests, then the full-size round trip
+#   n2 [reads]                   the driver's N = 2 launch line of bench.py with both ranks on this box's one GPU (gloo), then N = 1 beside it
 #   host                         cores, memory, tmpfs and I/O rates of the box (tools/io_bench.c)
 tag=${1:?tag}; action=${2:?action}; shift 2
 root=$(pwd)
@@ -134,6 +135,12 @@ decoder)
     timeout -k 10 400 python3 bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-extras --roundtrip 2> $out/err$cfg.txt | python3 -c "
 import json,sys; print('config $cfg', json.loads(sys.stdin.readline())['roundtrip'])"
   done ;;
+n2)
+  reads=${1:-20000000}
+  QVZ_BENCH_ONE_DEVICE=1 QVZ_BENCH_BACKEND=gloo timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+    --master-port 29617 bench.py --gpus 2 --reads $reads --steps 2 --warmup 1 > $out/n2.jsonl 2> $out/n2.err; echo "rc=$?"
+  line < $out/n2.jsonl
+  timeout -k 10 300 python3 bench.py --reads $reads --steps 2 --warmup 1 --no-cpu-baseline --no-extras 2> $out/n1.err | tee $out/n1.jsonl | line ;;
 host)
   { nproc; free -g; df -h /dev/shm /tmp .; grep -m1 "model name" /proc/cpuinfo; } 2>&1 | tee $out/host.txt
   gcc -O2 -o /tmp/io_bench tools/io_bench.c -lpthread && /tmp/io_bench /dev/shm/iob 16 4 8 16 2>&1 | tee $out/io_bench.txt ;;
