@@ -42,6 +42,10 @@
 #include "qvz_log2_glibc.h"
 
 #define A QVZ_A
+// The kernels of the column loop are short dependent chains, a wave or two per design: on a SIMD they share with the waves of
+// a throughput kernel on another stream (the WELL draws run beside the codebooks) they would get every n-th issue slot; raised
+// priority lets them issue whenever they can.
+#define CB_PRIO() asm volatile("s_setprio 3")
 
 // (the host-side codebook container, the distortion matrices and the serialisation live in host/qvz_codebook_host.c)
 
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
                                                        const uint8_t *__restrict__ nctx) {    // device-driven flow: contexts per column
     __shared__ double pt[A], raw[A], sr[A];
     __shared__ uint8_t slo[A], shi[A];
+    CB_PRIO();
     const uint32_t k = blockIdx.x, idx = threadIdx.x;
     if (nctx) { nprev = nctx[s - 1]; nu = nctx[s]; }
     if (k == 0 && idx < A) stop[idx] = 0xFFFFFFFFu;              // the design window that follows starts with no stop marks
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, 
                                                   LmIn *__restrict__ lin, int ratio_mode, double opt_ratio, int exact,
                                                   LmIn *__restrict__ lin_host, const uint8_t *__restrict__ nctx) {
     __shared__ double row[A], nrow[A], ent[A];
+    CB_PRIO();
     const uint32_t idx = blockIdx.x, k = threadIdx.x;
     if (nctx && idx >= nctx[s]) return;                           // device-driven flow: the grid is sized for 72 contexts
     const double *Ps = P + (uint64_t)s * A * A;
@@ -578,6 +584,7 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
                                                   const LmIn *__restrict__ in, LmDesign *__restrict__ out,
                                                   uint32_t *__restrict__ stop, double guard, int exact,
                                                   const uint32_t *__restrict__ limits, LmRider rider) {
+    CB_PRIO();
     // Rows of the grid beyond the window (blockIdx.y >= rider.rows) carry k_ctx_ptemp of the NEXT column: it needs this
     // column's qpmf only, and as blocks of this launch it runs on CUs the designs leave idle instead of being one more
     // dependent launch in the stream (a dependent launch costs ~11 us on this runtime, the kernel itself 15-23 us).

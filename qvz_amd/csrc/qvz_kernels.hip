@@ -1392,9 +1392,15 @@ __global__ __launch_bounds__(1024) void k_gf2_apply(const uint32_t *__restrict__
     }
 }
 
-// one thread = one chunk of WELL_CHUNK words, reference recurrence with n = 0,31,30,...,1 unrolled
+// one thread = one chunk of WELL_CHUNK words, reference recurrence with n = 0,31,30,...,1 unrolled.
+// `pad` words are left free behind every chunk of the output. With pad = 0 (the linear word stream of qvz_hip_well_words) the 64
+// lanes of a store write 64 lines that lie 32 KB apart - one memory channel - and every wave of the launch is at about the same
+// place in its chunk: measured 1.06 TB/s of stores. The draw generator, whose word buffer is its own, asks for WELL_PAD = 32
+// words (chunks 257 lines apart: consecutive lanes, consecutive channels): 2.09 TB/s (k_draws_transpose reads through well_phys).
+#define WELL_PAD 32u
+__device__ __host__ __forceinline__ uint64_t well_phys(uint64_t rel, uint32_t pad) { return rel + (rel >> WELL_CHUNK_LOG2) * pad; }
 __global__ __launch_bounds__(64) void k_well_gen(const uint32_t *__restrict__ states, uint64_t nchunks, uint64_t nwords,
-                                                 uint32_t *__restrict__ words) {
+                                                 uint32_t *__restrict__ words, uint32_t pad) {
     const uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= nchunks) return;
     uint32_t s[32];
@@ -1421,7 +1427,7 @@ __global__ __launch_bounds__(64) void k_well_gen(const uint32_t *__restrict__ st
             s[nn] = (z0 ^ (z0 << 11)) ^ (z1 ^ (z1 << 7)) ^ (z2 ^ (z2 << 13));
             out[i] = s[nn];
         }
-        uint32_t *dstw = words + w0 + base;
+        uint32_t *dstw = words + w0 + t * pad + base;
         if (base + 32 <= todo) {
             uint4 *d4 = reinterpret_cast<uint4 *>(dstw);       // w0+base is a multiple of 32 words = 128 B
 #pragma unroll
@@ -1555,17 +1561,15 @@ extern "C" int qvz_hip_well_jump_many(const uint32_t *h_state, const uint64_t *h
     return QVZ_OK;
 }
 
-static int well_words_locked(DevScratch &W, const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
-                             hipStream_t st) {
-    if (nwords == 0) return QVZ_OK;
-    if ((uintptr_t)d_words & 15) return qvz_set_error(QVZ_E_ARG, "d_words must be 16-byte aligned");
+// W.d_states[i] = generator state (n = 0) after first_word + i * WELL_CHUNK words, i < nchunks
+static int well_states_locked(DevScratch &W, const uint32_t *h_state, uint64_t first_word, uint64_t nchunks, hipStream_t st) {
     int rc = well_init(W, st);
     if (rc) return rc;
-    const uint64_t nchunks = (nwords + WELL_CHUNK - 1) / WELL_CHUNK;
     if (nchunks > W.states_cap) {
-        if (W.d_states) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(W.d_states); }
-        W.states_cap = nchunks + nchunks / 4 + 64;
-        QVZ_HIP_CHECK(hipMalloc(&W.d_states, W.states_cap * 128));
+        if (W.d_states) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(W.d_states); W.d_states = nullptr; W.states_cap = 0; }
+        const uint64_t cap = nchunks + nchunks / 4 + 64;
+        QVZ_HIP_CHECK(hipMalloc(&W.d_states, cap * 128));
+        W.states_cap = cap;
     }
     rc = well_jump_device(W, h_state, first_word, W.d_states, st);
     if (rc) return rc;
@@ -1578,10 +1582,26 @@ static int well_words_locked(DevScratch &W, const uint32_t *h_state, uint64_t fi
         hipLaunchKernelGGL(k_gf2_apply, dim3((unsigned)((make + WELL_SPB - 1) / WELL_SPB)), dim3(1024), 0, st,
                            W.d_pow + (size_t)j * 1024 * 32, W.d_states, W.d_states + have * 32, make);
     }
-    hipLaunchKernelGGL(k_well_gen, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, W.d_states, nchunks,
-                       nwords, d_words);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
+}
+
+// nwords words from chunk `chunk0` of the states above on (d_words[0] = the first word of that chunk)
+static int well_gen_locked(DevScratch &W, uint64_t chunk0, uint64_t nwords, uint32_t *d_words, hipStream_t st, uint32_t pad) {
+    if (nwords == 0) return QVZ_OK;
+    const uint64_t nchunks = (nwords + WELL_CHUNK - 1) / WELL_CHUNK;
+    hipLaunchKernelGGL(k_well_gen, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, W.d_states + chunk0 * 32, nchunks,
+                       nwords, d_words, pad);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+static int well_words_locked(DevScratch &W, const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
+                             hipStream_t st) {
+    if (nwords == 0) return QVZ_OK;
+    if ((uintptr_t)d_words & 15) return qvz_set_error(QVZ_E_ARG, "d_words must be 16-byte aligned");
+    const int rc = well_states_locked(W, h_state, first_word, (nwords + WELL_CHUNK - 1) / WELL_CHUNK, st);
+    return rc ? rc : well_gen_locked(W, 0, nwords, d_words, st, 0);
 }
 
 extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, uint64_t nwords, uint32_t *d_words,
@@ -1600,32 +1620,31 @@ extern "C" int qvz_hip_well_words(const uint32_t *h_state, uint64_t first_word, 
 // ------------------------------------------------------------------------------------------------
 #define DT_MAX_WORDS 15360   // 60 KB of LDS per block
 
-__global__ __launch_bounds__(256) void k_draws_transpose(const uint32_t *__restrict__ words, uint64_t word0, uint64_t draw0,
+__global__ __launch_bounds__(256) void k_draws_transpose(const uint32_t *__restrict__ words, uint64_t word0, uint32_t pad, uint64_t draw0,
                                                          uint64_t n, uint32_t C, uint32_t TR, uint8_t *__restrict__ draws,
                                                          uint64_t ld) {
-    __shared__ uint32_t w[DT_MAX_WORDS + 4];
+    extern __shared__ uint32_t w[];                              // the tile's words: TR * C / 4 + 2 (the launcher sizes it)
     const uint64_t i0 = (uint64_t)blockIdx.x * TR;               // first read of this tile (multiple of 4)
     const uint32_t reads = (uint32_t)(n - i0 < TR ? n - i0 : TR);
     const uint64_t g0 = draw0 + i0 * C, g1 = g0 + (uint64_t)reads * C;     // draws [g0, g1) of the stream
     const uint64_t wa = g0 >> 2, wb = (g1 + 3) >> 2;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(wb - wa); i += 256) w[i] = words[wa - word0 + i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(wb - wa); i += 256) w[i] = words[well_phys(wa - word0 + i, pad)];   // the generator's chunks are `pad` words apart
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t quads = (reads + 3) / 4;
+    const uint32_t quads = (reads + 3) / 4;                      // a column of the tile = `quads` dwords (TR / 4: a power of two or not)
     const uint32_t base = (uint32_t)(g0 - (wa << 2));             // offset of the tile's first draw inside w[]
-    for (uint32_t s = wave; s < C; s += 4)                       // waves take columns in turn, lanes take read quads
-        for (uint32_t q = lane; q < quads; q += 64) {
-            uint32_t packed = 0;
+    for (uint32_t e = threadIdx.x; e < C * quads; e += 256) {    // consecutive threads: consecutive read quads of a column
+        const uint32_t s = e / quads, q = e - s * quads;
+        uint32_t packed = 0;
 #pragma unroll
-            for (uint32_t r = 0; r < 4; ++r) {
-                const uint32_t rd = 4 * q + r;
-                if (rd < reads) {
-                    const uint32_t d = base + rd * C + s;
-                    packed |= ((w[d >> 2] >> (7 * (d & 3))) & 127u) << (8 * r);   // well_1024a_bits, well.c:33-46
-                }
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t rd = 4 * q + r;
+            if (rd < reads) {
+                const uint32_t d = base + rd * C + s;
+                packed |= ((w[d >> 2] >> (7 * (d & 3))) & 127u) << (8 * r);   // well_1024a_bits, well.c:33-46
             }
-            *reinterpret_cast<uint32_t *>(draws + (uint64_t)s * ld + i0 + 4 * q) = packed;
         }
+        *reinterpret_cast<uint32_t *>(draws + (uint64_t)s * ld + i0 + 4 * q) = packed;
+    }
 }
 
 // Generates the draws of reads [first_read, first_read + n) in chunks: words into a reusable workspace
@@ -1642,26 +1661,41 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
     uint32_t TR = (DT_MAX_WORDS * 4 - 8) / c;                    // reads per tile: TR*c draws fit the LDS buffer
     TR &= ~3u;
     if (TR > 256) TR = 256;
+    if (getenv("QVZ_DRAWS_TR") && (uint32_t)atoi(getenv("QVZ_DRAWS_TR")) >= 4 && (uint32_t)atoi(getenv("QVZ_DRAWS_TR")) < TR)   // development knob
+        TR = (uint32_t)atoi(getenv("QVZ_DRAWS_TR")) & ~3u;
     if (TR < 4) return qvz_set_error(QVZ_E_ARG, "c=%u too wide for the draw transposer", c);
+    const size_t tile_lds = ((size_t)TR * c / 4 + 4) * sizeof(uint32_t);   // what a tile needs, not the 60 KB the widest may: more tiles per CU
     // Reads per generator pass. A generator thread runs 8192 words (218 reads at C = 150) serially, so a pass of 2^22 reads
     // is only ~300 waves - fewer than the chip has SIMDs - and each of them a dependent chain: the passes took 0.5 ms each
-    // for 0.6 GB of words. 2^24 reads per pass (2.5 GB of words at C = 150) fill every SIMD.
+    // for 0.6 GB of words. 2^24 reads per pass (2.5 GB of words at C = 150) fill every SIMD (2^25 .. 2^27: the same 15.3 ms per
+    // 100M x 150 draws, for 5 .. 15 GB of buffer).
+    // A pass begins on a chunk boundary of the generator (its reads x C draws are a multiple of 4 * WELL_CHUNK) and on a tile
+    // boundary of the transposer, so the chunk states of the WHOLE call are made once (one doubling ladder of ~19 launches
+    // instead of one of ~17 per pass) and every pass starts from its own.
+    uint64_t per_chunk = 4ull * WELL_CHUNK;                          // reads between two chunk boundaries that are read boundaries
+    { uint64_t a = c, b = per_chunk; while (b) { const uint64_t t = a % b; a = b; b = t; } per_chunk /= a; }
+    uint64_t unit = per_chunk;                                       // lcm(TR, per_chunk)
+    { uint64_t a = TR, b = per_chunk; while (b) { const uint64_t t = a % b; a = b; b = t; } unit = TR / a * per_chunk; }
     const uint64_t chunk = 1ull << (getenv("QVZ_WELL_PASS_LOG2") ? atoi(getenv("QVZ_WELL_PASS_LOG2")) : 24);
-    const uint64_t chunk_reads = (chunk / TR) * TR;
-    const uint64_t need = (n < chunk_reads ? ((n + TR - 1) / TR) * TR : chunk_reads) * c / 4 + 8;
+    const uint64_t chunk_reads = chunk / unit ? (chunk / unit) * unit : unit;
+    const uint64_t need_lin = (n < chunk_reads ? ((n + TR - 1) / TR) * TR : chunk_reads) * c / 4 + 8;
+    const uint64_t need = well_phys(need_lin, WELL_PAD) + WELL_PAD + 8;                        // the chunks lie WELL_PAD words apart
     if (need > ws_words) {
-        if (d_ws) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(d_ws); d_ws = nullptr; }
+        if (d_ws) { QVZ_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(d_ws); d_ws = nullptr; ws_words = 0; }
         QVZ_HIP_CHECK(hipMalloc(&d_ws, need * sizeof(uint32_t)));
         ws_words = need;
     }
+    const uint64_t W0 = (first_read * c) >> 2, W1 = ((first_read + n) * c + 3) >> 2;
+    rc = well_states_locked(*lk.d, h_state, W0, (W1 - W0 + WELL_CHUNK - 1) / WELL_CHUNK, st);
+    if (rc) return rc;
     for (uint64_t r0 = 0; r0 < n; r0 += chunk_reads) {
         const uint64_t m = n - r0 < chunk_reads ? n - r0 : chunk_reads;
         const uint64_t g0 = (first_read + r0) * c, g1 = g0 + m * c;
-        const uint64_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;
-        rc = well_words_locked(*lk.d, h_state, w0, w1 - w0, d_ws, st);
+        const uint64_t w0 = g0 >> 2, w1 = (g1 + 3) >> 2;             // w0 - W0 = r0 * c / 4: a multiple of WELL_CHUNK
+        rc = well_gen_locked(*lk.d, (w0 - W0) >> WELL_CHUNK_LOG2, w1 - w0, d_ws, st, WELL_PAD);
         if (rc) return rc;
         dim3 grid((unsigned)((m + TR - 1) / TR));
-        hipLaunchKernelGGL(k_draws_transpose, grid, dim3(256), 0, st, d_ws, w0, g0, m, c, TR, d_draws + r0, ld);
+        hipLaunchKernelGGL(k_draws_transpose, grid, dim3(256), tile_lds, st, d_ws, w0, WELL_PAD, g0, m, c, TR, d_draws + r0, ld);
         QVZ_HIP_CHECK(hipGetLastError());
     }
     return QVZ_OK;
