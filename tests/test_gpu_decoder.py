@@ -71,6 +71,69 @@ def test_decoder_rejects_a_foreign_stream():
         host.decode_shards_gpu(coded, cap, [len(s) for s in junk], n, c, [cb.handle for cb in r["codebooks"]], 2, draws)
 
 
+@pytest.mark.parametrize("name,shards", [("t2k_c3_f05_M", 5), ("t2k_r10_M", 3)])
+def test_decoder_survives_mutated_streams(name, shards):
+    """Streams somebody damaged: bit flips, zeroed and random runs, truncated and over-stated lengths, streams swapped
+    between shards. A decode either fails with the library's data error or returns values of the alphabet - it never reads
+    outside its tables or its stream (the kernel takes every table offset from the validated codebooks, checks every state
+    against the table's size and reads zeros behind a stream's stated end, as the reference's stream reader does,
+    os_stream.c:36-52). The untouched streams decode to the quantizer's output before and after."""
+    from qvz_amd import host, kernels as K
+    rows, opts, n, c, r = encode(name, shards)
+    handles = [cb.handle for cb in r["codebooks"]]
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    rng = np.random.default_rng(20260403)
+    good = [bytes(s) for s in r["streams"]]
+    outcomes = {"rejected": 0, "decoded": 0}
+
+    def run(streams, sizes=None):
+        coded, cap = upload_streams(streams)
+        try:
+            qv, labels = host.decode_shards_gpu(coded, cap, sizes or [len(x) for x in streams], n, c, handles, shards, draws)
+        except Exception as e:                                   # noqa: BLE001
+            assert "does not decode" in str(e) or "longer than cap" in str(e), e
+            outcomes["rejected"] += 1
+            return None
+        torch.cuda.synchronize()
+        assert int(qv[:, :n].max()) < 72
+        outcomes["decoded"] += 1
+        return qv
+
+    assert torch.equal(run(good)[:, :n], r["qv"][:, :n])
+    for trial in range(40):
+        streams = [bytearray(x) for x in good]
+        g = int(rng.integers(shards))
+        kind = trial % 8
+        sizes = None
+        if kind == 0:                                            # single bit flips, early in the stream (everything after depends on them)
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(min(64, len(streams[g]))))
+                streams[g][pos] ^= 1 << int(rng.integers(8))
+        elif kind == 1:                                          # ... anywhere
+            pos = int(rng.integers(len(streams[g])))
+            streams[g][pos] ^= 1 << int(rng.integers(8))
+        elif kind == 2:                                          # a zeroed run
+            a = int(rng.integers(len(streams[g])))
+            streams[g][a:a + 37] = bytes(len(streams[g][a:a + 37]))
+        elif kind == 3:                                          # random bytes from some point to the end
+            a = int(rng.integers(len(streams[g])))
+            streams[g][a:] = rng.integers(0, 256, len(streams[g]) - a, dtype=np.uint8).tobytes()
+        elif kind == 4:                                          # truncated: the stated size ends early (zeros are read behind it)
+            sizes = [len(x) for x in streams]
+            sizes[g] = int(rng.integers(0, len(streams[g])))
+        elif kind == 5:                                          # over-stated size: up to the slot's capacity
+            sizes = [len(x) for x in streams]
+            sizes[g] = (max(sizes) + 7) & ~3
+        elif kind == 6:                                          # two shards' streams swapped
+            h = (g + 1) % shards
+            streams[g], streams[h] = streams[h], streams[g]
+        else:                                                    # all ones / all zeros
+            streams[g] = bytearray([0xFF if trial & 8 else 0x00]) * len(streams[g])
+        run([bytes(x) for x in streams], sizes)
+    assert outcomes["rejected"] > 0 and outcomes["decoded"] > 1, outcomes
+    assert torch.equal(run(good)[:, :n], r["qv"][:, :n])
+
+
 def test_round_trip_at_bench_stream_length():
     """12 208 reads per stream x 150 columns (the per-stream shape of BASELINE configs[1] at 8192 streams), 256 streams."""
     from qvz_amd import host, kernels as K, pipeline as P
