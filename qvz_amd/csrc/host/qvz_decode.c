@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "qvz_codebook.h"
 #include "qvz_coder.h"
@@ -334,6 +335,8 @@ int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_r
 
 /* S streams of one file (stream g = reads [first[g], first[g+1]) with qvz_shard_bounds(N, S)) decoded at once by the GPU
  * decoder and written as text. streams[g] points at sizes[g] bytes. */
+static double dec_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
 int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codebook_t *const *cbs, const uint32_t *well,
                            uint32_t shards, const uint64_t *bounds, const uint8_t *const *streams, const uint64_t *sizes,
                            const char *out_path, int device) {
@@ -353,6 +356,11 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
         return qvz_job_fail(QVZ_E_DATA, "implausible size: %llu lines of %u columns in %u streams", (unsigned long long)N, C, shards);
     const uint64_t ld = qvz_hip_ld(N);
     if (qvz_hip_set_device(device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
+    fo = fopen(out_path, "w");
+    if (!fo) return qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
+    qvz_prealloc_start(fo, N * ((uint64_t)C + 1));                             /* the text's pages are made while the GPU decodes */
+    const double t_0 = dec_now();
+    double t_up = t_0, t_dec = t_0;
 #define HIPC(call) do { if ((call) != QVZ_OK) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; } } while (0)
     /* the streams go up packed (they lie back to back in a shard set; the pieces of shard FILES are packed first) through
      * pinned slabs and are spread to the decoder's fixed-stride layout on the device */
@@ -368,6 +376,7 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
     if ((rc = qvz_ingress_bytes(d_packed, contiguous ? streams[0] : h_packed, total))) goto done;
     HIPC(qvz_hip_scatter_streams(d_packed, sizes, shards, d_in, cap, NULL));
     qvz_hip_free(d_packed); d_packed = NULL;
+    t_up = dec_now();
     HIPC(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
     HIPC(qvz_hip_malloc((void **)&d_labels, ld));
     if (qvz_hip_decode_shards_bounds(d_in, cap, sizes, N, C, K, cbs, shards, bounds, d_draws, ld, d_qv, d_labels, NULL)) {
@@ -376,12 +385,15 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
     }
     HIPC(qvz_hip_stream_sync(NULL));
 #undef HIPC
+    t_dec = dec_now();
     qvz_hip_free(d_draws); d_draws = NULL;
     qvz_hip_free(d_in); d_in = NULL;
-    fo = fopen(out_path, "w");
-    if (!fo) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
     rc = qvz_egress_text(fo, d_qv, N, C, ld, NULL);                            /* the text leaves in slabs: no N-sized host buffer */
+    if (getenv("QVZ_TIMING"))                                                  /* where the wall time went, one line on stderr */
+        fprintf(stderr, "qvz_timing: decode upload=%.4f decode=%.4f egress=%.4f lines=%llu columns=%u streams=%u\n", t_up - t_0, t_dec - t_up,
+                dec_now() - t_dec, (unsigned long long)N, C, shards);
 done:
+    qvz_prealloc_finish(fo);
     if (fo) fclose(fo);
     qvz_hip_free(d_packed); qvz_hip_free(d_in); qvz_hip_free(d_draws); qvz_hip_free(d_qv); qvz_hip_free(d_labels);
     free(h_packed);

@@ -5,9 +5,12 @@
  * reads), and no N-sized host buffer, pageable copy or second N-sized device buffer is made for either.
  * Every function may be called from a host thread of its own (it makes its own streams); the caller has selected the device. */
 #define _GNU_SOURCE
+#include <fcntl.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "qvz_job.h"
@@ -82,6 +85,105 @@ int qvz_parallel_pwrite(int fd, const uint8_t *buf, size_t n, int64_t off) {
     return failed ? qvz_job_fail(QVZ_E_ARG, "write failed") : QVZ_OK;
 }
 
+/* ---- pages ahead of the writer -------------------------------------------------------------------------------------
+ * A big output whose size is known early (the -u text: N (C + 1) bytes once the first line has been seen; the text of a
+ * decode: from the header) is mostly the cost of MAKING its pages in the page cache: measured on the MI355X host's tmpfs,
+ * pwrite into new pages 4-5 GB/s whatever the thread count (writers of one file take turns on its inode lock), page
+ * faults on a fresh mapping 4 GB/s, fallocate 7 GB/s, and any two of these at once less than either alone (2.6-3.8 GB/s) -
+ * while copying into pages that EXIST through a mapping runs at 14-17 GB/s (tools/io_bench.c, profiles/r03_host_io.txt).
+ * So one thread makes the pages with fallocate from the moment the size is known - beside the upload and the kernels,
+ * when nothing else wants the file - and the writer (put, below) copies through a mapping and never gets ahead of it.
+ * Anything that does not work out (no O_RDWR twin of the descriptor, fallocate or mmap refused) falls back to pwrite. */
+typedef struct {
+    int fd, fd2;                         /* the FILE's descriptor (the key) and an O_RDWR twin of it */
+    int64_t base;                        /* file offset the output starts at */
+    uint64_t bytes;
+    uint8_t *map;                        /* mapping of [base_page, base + bytes) */
+    size_t map_len;
+    int64_t base_page;
+    volatile uint64_t done;              /* bytes from base whose pages exist */
+    volatile int stop, failed;
+    pthread_t th;
+} prealloc_t;
+static prealloc_t *g_pre[8];
+static pthread_mutex_t g_pre_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void *prealloc_main(void *arg) {
+    prealloc_t *p = (prealloc_t *)arg;
+    const uint64_t slab = 32ull << 20;
+    for (uint64_t at = 0; at < p->bytes && !p->stop; at += slab) {
+        const uint64_t m = p->bytes - at < slab ? p->bytes - at : slab;
+        if (fallocate(p->fd2, 0, (off_t)(p->base + (int64_t)at), (off_t)m)) { p->failed = 1; break; }
+        __atomic_store_n(&p->done, at + m, __ATOMIC_RELEASE);
+    }
+    return NULL;
+}
+
+int qvz_prealloc_start(FILE *f, uint64_t bytes) {
+    const uint64_t least = getenv("QVZ_PREALLOC_MIN") ? strtoull(getenv("QVZ_PREALLOC_MIN"), NULL, 10) : 256ull << 20;   /* (the variable: tests) */
+    if (!f || bytes < least || (getenv("QVZ_PREALLOC") && atoi(getenv("QVZ_PREALLOC")) == 0)) return 0;
+    fflush(f);
+    const int64_t base = (int64_t)ftello(f);
+    const int fd = fileno(f);
+    struct stat st;
+    if (base < 0 || fd < 0 || fstat(fd, &st) || !S_ISREG(st.st_mode)) return 0;
+    char link[64];
+    snprintf(link, sizeof(link), "/proc/self/fd/%d", fd);
+    const int fd2 = open(link, O_RDWR);                                        /* fopen(.., "w") is write-only: no shared mapping of it */
+    if (fd2 < 0) return 0;
+    prealloc_t *p = (prealloc_t *)calloc(1, sizeof(*p));
+    const long page = sysconf(_SC_PAGESIZE);
+    if (!p || page <= 0 || ((uint64_t)st.st_size < (uint64_t)base + bytes && ftruncate(fd2, (off_t)((uint64_t)base + bytes)))) { free(p); close(fd2); return 0; }
+    p->fd = fd; p->fd2 = fd2; p->base = base; p->bytes = bytes;
+    p->base_page = base - base % page;
+    p->map_len = (size_t)((uint64_t)(base - p->base_page) + bytes);
+    p->map = (uint8_t *)mmap(NULL, p->map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd2, (off_t)p->base_page);
+    if (p->map == MAP_FAILED) { free(p); close(fd2); return 0; }
+    int slot = -1;
+    pthread_mutex_lock(&g_pre_mu);
+    for (int i = 0; i < 8 && slot < 0; ++i) if (!g_pre[i]) slot = i;
+    if (slot >= 0 && pthread_create(&p->th, NULL, prealloc_main, p) == 0) g_pre[slot] = p; else slot = -1;
+    pthread_mutex_unlock(&g_pre_mu);
+    if (slot < 0) { munmap(p->map, p->map_len); close(fd2); free(p); return 0; }
+    return 1;
+}
+
+static prealloc_t *prealloc_of(int fd) {
+    prealloc_t *p = NULL;
+    pthread_mutex_lock(&g_pre_mu);
+    for (int i = 0; i < 8; ++i) if (g_pre[i] && g_pre[i]->fd == fd) p = g_pre[i];
+    pthread_mutex_unlock(&g_pre_mu);
+    return p;
+}
+
+void qvz_prealloc_finish(FILE *f) {
+    if (!f) return;
+    const int fd = fileno(f);
+    prealloc_t *p = NULL;
+    pthread_mutex_lock(&g_pre_mu);
+    for (int i = 0; i < 8; ++i) if (g_pre[i] && g_pre[i]->fd == fd) { p = g_pre[i]; g_pre[i] = NULL; }
+    pthread_mutex_unlock(&g_pre_mu);
+    if (!p) return;
+    p->stop = 1;
+    pthread_join(p->th, NULL);
+    munmap(p->map, p->map_len);
+    close(p->fd2);
+    free(p);
+}
+
+/* n bytes at file offset off through the mapping once their pages exist; 0: not this file's business (use pwrite) */
+static int prealloc_put(int fd, const uint8_t *buf, size_t n, int64_t off) {
+    prealloc_t *p = prealloc_of(fd);
+    if (!p || off < p->base || (uint64_t)(off - p->base) + n > p->bytes) return 0;
+    const uint64_t need = (uint64_t)(off - p->base) + n;
+    while (__atomic_load_n(&p->done, __ATOMIC_ACQUIRE) < need) {
+        if (p->failed) return 0;
+        usleep(100);
+    }
+    qvz_parallel_memcpy(p->map + (off - p->base_page), buf, n);
+    return 1;
+}
+
 /* where a FILE's next byte goes, as (descriptor, offset), with its buffer flushed; *off < 0: not seekable, use fwrite */
 static int file_cursor(FILE *f, int64_t *off) {
     fflush(f);
@@ -91,7 +193,7 @@ static int file_cursor(FILE *f, int64_t *off) {
 
 static int put(FILE *f, int fd, int64_t *off, const uint8_t *buf, size_t n) {
     if (*off < 0) return fwrite(buf, 1, n, f) == n ? QVZ_OK : qvz_job_fail(QVZ_E_ARG, "write failed");
-    const int rc = qvz_parallel_pwrite(fd, buf, n, *off);
+    const int rc = prealloc_put(fd, buf, n, *off) ? QVZ_OK : qvz_parallel_pwrite(fd, buf, n, *off);
     *off += (int64_t)n;
     return rc;
 }
@@ -233,7 +335,9 @@ int qvz_egress_rows(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, c
     if (!d_sym || !n || !c || ld < n || !path) return qvz_job_fail(QVZ_E_ARG, "bad egress arguments");
     FILE *f = fopen(path, "w");
     if (!f) return qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
+    qvz_prealloc_start(f, n * ((uint64_t)c + 1));                              /* pages made ahead of the writer */
     const int rc = qvz_egress_text(f, d_sym, n, c, ld, NULL);
+    qvz_prealloc_finish(f);
     if (fclose(f) && !rc) return qvz_job_fail(QVZ_E_ARG, "write failed");
     return rc;
 }

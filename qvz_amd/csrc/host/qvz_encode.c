@@ -937,6 +937,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     int rc = qvz_job_init(&job, text, bytes, 0, 0, opts);
     if (rc) { free(fq_rows); return rc; }
     uint64_t head_bytes = 0;
+    if (shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));   /* the -u text's pages, made beside everything up to its egress */
     if (shards) qvz_job_start_workspace(&job, shards);                         /* the coder's record workspace, beside the upload */
     if ((rc = qvz_job_upload(&job))) goto done;
     if ((rc = qvz_job_kmeans(&job, 0))) goto done;
@@ -982,6 +983,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
         printf("rate, %.4f, distortion, %.4f, time, %.4f, size, %llu \n", (R.stream_bytes * 8.) / ((double)R.lines * R.columns),
                R.distortion, R.t_total, (unsigned long long)R.stream_bytes);
 done:
+    qvz_prealloc_finish(fu);
     qvz_job_release(&job);
     free(fq_rows);
     if (res) *res = R;

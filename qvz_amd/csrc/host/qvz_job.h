@@ -100,6 +100,8 @@ void qvz_job_release(qvz_job_t *job);
 /* `after`: a stream whose work so far must be finished before the device data is read - waited for on the device,
  * not by the host; NULL: the data is complete already */
 int qvz_egress_text(FILE *fu, const uint8_t *d_qv, uint64_t N, uint32_t C, uint64_t ld, void *after);   /* -u rows at fu's position */
+int qvz_prealloc_start(FILE *f, uint64_t bytes);    /* a thread makes the pages of the next `bytes` of f ahead of qvz_egress_*; 1 if started */
+void qvz_prealloc_finish(FILE *f);                  /* ... and must be ended before f is closed (no-op if none was started) */
 int qvz_egress_bytes(FILE *f, const uint8_t *d_src, uint64_t bytes, void *after);
 int qvz_sum_errors(const double *d_err, uint64_t N, uint32_t C, double *sum_out, double *keep, void *after);
 int qvz_parallel_pwrite(int fd, const uint8_t *buf, size_t n, int64_t off);

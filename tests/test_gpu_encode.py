@@ -207,6 +207,24 @@ def test_sharded_files_decode_with_the_reference_decoder(tmp_path, name, shards)
     assert r.stream_bytes >= e["size"] * 0.98
 
 
+@pytest.mark.parametrize("name", ["t2k_c3_f05_M", "wide_c151"])
+def test_cli_text_written_through_preallocated_pages(tmp_path, name):
+    """Big -u / decode outputs are written through a mapping into pages that a helper thread makes ahead of the writer
+    (host/qvz_egress.c: qvz_prealloc_start; by default for outputs of 256 MB and more - the full-size CLI tests). Here the
+    threshold is lowered so that small fixtures take that path: the same bytes as through pwrite, file length included."""
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    outs = {}
+    for tag, extra in (("pwrite", {"QVZ_PREALLOC": "0"}), ("mapped", {"QVZ_PREALLOC_MIN": "1"})):
+        q, u, d = (str(tmp_path / f"{tag}.{x}") for x in ("qset", "u", "dec"))
+        env = dict(os.environ, QVZ_WELL_SEED="debug", QVZ_SHARDS="5", **extra)
+        subprocess.run([QVZ_BIN] + e["flags"].split() + ["-u", u, inp, q], env=env, check=True, capture_output=True)
+        subprocess.run([QVZ_BIN, "-x", q, d], env=dict(os.environ, **extra), check=True, capture_output=True)
+        outs[tag] = (open(q, "rb").read(), open(u, "rb").read(), open(d, "rb").read())
+    assert outs["pwrite"] == outs["mapped"]
+    assert G.md5(outs["mapped"][1]) == e["u_md5"] and outs["mapped"][2] == outs["mapped"][1]
+
+
 def test_cli_qvz_shards_env(tmp_path):
     """QVZ_SHARDS=N: the default product is ONE shard-set file (codebooks once, include/qvz_shardset.h); `qvz -x` decodes
     it, qvz-shardset splits it into reference-format files the unmodified reference decoder reads; QVZ_SHARD_FILES=1 writes
