@@ -101,6 +101,7 @@ typedef struct {
     uint8_t *map;                        /* mapping of [base_page, base + bytes) */
     size_t map_len;
     int64_t base_page;
+    int64_t sized_at;                    /* the length the file was given for the mapping */
     volatile uint64_t done;              /* bytes from base whose pages exist */
     volatile int stop, failed;
     pthread_t th;
@@ -108,14 +109,21 @@ typedef struct {
 static prealloc_t *g_pre[8];
 static pthread_mutex_t g_pre_mu = PTHREAD_MUTEX_INITIALIZER;
 
+static pthread_mutex_t g_alloc_mu = PTHREAD_MUTEX_INITIALIZER;   /* one file's pages at a time (two allocators are slower than one): first come, first served */
+
 static void *prealloc_main(void *arg) {
     prealloc_t *p = (prealloc_t *)arg;
     const uint64_t slab = 32ull << 20;
+    while (pthread_mutex_trylock(&g_alloc_mu)) {
+        if (p->stop) return NULL;
+        usleep(500);
+    }
     for (uint64_t at = 0; at < p->bytes && !p->stop; at += slab) {
         const uint64_t m = p->bytes - at < slab ? p->bytes - at : slab;
         if (fallocate(p->fd2, 0, (off_t)(p->base + (int64_t)at), (off_t)m)) { p->failed = 1; break; }
         __atomic_store_n(&p->done, at + m, __ATOMIC_RELEASE);
     }
+    pthread_mutex_unlock(&g_alloc_mu);
     return NULL;
 }
 
@@ -135,6 +143,7 @@ int qvz_prealloc_start(FILE *f, uint64_t bytes) {
     const long page = sysconf(_SC_PAGESIZE);
     if (!p || page <= 0 || ((uint64_t)st.st_size < (uint64_t)base + bytes && ftruncate(fd2, (off_t)((uint64_t)base + bytes)))) { free(p); close(fd2); return 0; }
     p->fd = fd; p->fd2 = fd2; p->base = base; p->bytes = bytes;
+    p->sized_at = (uint64_t)st.st_size < (uint64_t)base + bytes ? (int64_t)((uint64_t)base + bytes) : -1;
     p->base_page = base - base % page;
     p->map_len = (size_t)((uint64_t)(base - p->base_page) + bytes);
     p->map = (uint8_t *)mmap(NULL, p->map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd2, (off_t)p->base_page);
@@ -167,6 +176,14 @@ void qvz_prealloc_finish(FILE *f) {
     p->stop = 1;
     pthread_join(p->th, NULL);
     munmap(p->map, p->map_len);
+    /* the file was sized for the mapping (bytes may have been an estimate: the shard set's streams); it ends where the FILE's
+     * position is - everything written so far - and pages made beyond that go back */
+    fflush(f);
+    const int64_t end = (int64_t)ftello(f);
+    struct stat st;
+    if (end >= 0 && fstat(p->fd2, &st) == 0 && (int64_t)st.st_size > end && p->sized_at == (int64_t)st.st_size) {
+        if (ftruncate(p->fd2, (off_t)end)) { /* best effort: the caller's own writes define the file */ }
+    }
     close(p->fd2);
     free(p);
 }

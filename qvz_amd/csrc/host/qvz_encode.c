@@ -937,7 +937,11 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     int rc = qvz_job_init(&job, text, bytes, 0, 0, opts);
     if (rc) { free(fq_rows); return rc; }
     uint64_t head_bytes = 0;
-    if (shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));   /* the -u text's pages, made beside everything up to its egress */
+    /* pages of the big outputs, made by a helper thread beside everything up to their egress (host/qvz_egress.c): the shard
+     * set first - its size is not known yet: 2 bits per symbol are assumed, what is written beyond goes through pwrite and
+     * what is not needed is given back - then the -u text, N (C + 1) bytes */
+    if (shards && fout && !shard_prefix) qvz_prealloc_start(fout, job.N * (uint64_t)job.C / 4);
+    if (shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));
     if (shards) qvz_job_start_workspace(&job, shards);                         /* the coder's record workspace, beside the upload */
     if ((rc = qvz_job_upload(&job))) goto done;
     if ((rc = qvz_job_kmeans(&job, 0))) goto done;
@@ -984,6 +988,7 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
                R.distortion, R.t_total, (unsigned long long)R.stream_bytes);
 done:
     qvz_prealloc_finish(fu);
+    if (shards && !shard_prefix) qvz_prealloc_finish(fout);
     qvz_job_release(&job);
     free(fq_rows);
     if (res) *res = R;
