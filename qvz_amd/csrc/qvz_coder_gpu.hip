@@ -904,10 +904,17 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         if (rb + 64 < nr) lookup(rb + 64, chunk + 1);
         RK_T(0);
         if (active) {
-            // every lane marks its table and its (table, state) entry (lanes without a symbol OR in nothing)
-            const unsigned long long bit = ok ? 1ull << lane : 0ull;
-            __hip_atomic_fetch_or(&msk[tb], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_or(&msk[tb + 2 + x], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // every lane marks its table and its (table, state) entry (lanes without a symbol OR in nothing). An LDS atomic costs
+            // two cycles for every lane of the instruction that hits the SAME address (tools/lds_bench.hip: 9 cycles for 64
+            // different addresses, 129 for one), and most lanes of a chunk share one or two tables - but the masks need the OR.
+            // (Tried: the table mask as four 16-bit pieces in the dwords of msk[tb], msk[tb + 1], one per quarter of the wave,
+            // and the (table, state) mask ORed into by halves - a quarter and a half of the lanes per address: the ten extra
+            // instructions cost more than the LDS cycles gave back, model kernels 130.8 -> 136 ms at 100M x 150 -f 0.5.)
+            {
+                const unsigned long long bit = ok ? 1ull << lane : 0ull;
+                __hip_atomic_fetch_or(&msk[tb], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&msk[tb + 2 + x], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             // counts before this chunk, and ranks inside it: earlier lanes with the same table (e), the same table and
             // state (E), a smaller state (L). cum_lo and L come from whichever end of the table is nearer
             // (sum over y < x directly, or n - c_x - sum over y > x).
@@ -917,8 +924,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             };
             const uint32_t n_b = tab[tb], c_x = tab[tb + 2 + x];
             const unsigned long long mt = msk[tb];
+            const unsigned long long mx = msk[tb + 2 + x];
             const uint32_t e = earlier(mt, 0u), hits = (uint32_t)__builtin_popcountll(mt);
-            const uint32_t E = earlier(msk[tb + 2 + x], 0u);
+            const uint32_t E = earlier(mx, 0u), same = (uint32_t)__builtin_popcountll(mx);
             {
                 const bool up = 2 * x < card;
                 uint32_t y = up ? 0u : x + 1, yend = up ? x : card, acc = 0, accm = 0;
@@ -951,13 +959,15 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             msk[tb] = 0ull;                                      // leave the masks clean for the next chunk
             msk[tb + 2 + x] = 0ull;
             if (!rescale) {
-                // update_stats for the whole chunk (order-free sums). (One plain store per table and per (table, state)
-                // by the first lane that holds it avoids the same-address atomics but needs two exec-mask regions:
-                // measured 4 % slower.)
-                const uint32_t step = ok ? STEP : 0u;
+                // update_stats for the whole chunk: every lane knows what its table's total and its state's count become
+                // (before + 8 x the lanes of the chunk that share them) and stores it - the lanes that share an entry store
+                // the same value, and plain stores to one address do not take turns as atomic adds do (model kernels 132.6 ->
+                // 130.8 ms at 100M x 150 with one cluster, 234.8 -> 228.5 with three). Lanes without a symbol sit on table 0,
+                // state 0 and store what the lanes that do have them store. (One store per entry by the first lane that holds it
+                // needs two exec-mask regions: measured 4 % slower than the atomics had been.)
                 RK_EXP(8) {
-                atomicAdd(&tab[tb + 2 + x], step);
-                atomicAdd(&tab[tb], step);
+                tab[tb + 2 + x] = c_x + STEP * same;
+                tab[tb] = n_b + STEP * hits;
                 }
             }
             if (rescale) {

@@ -1835,26 +1835,40 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
         prev[r] = 0;
         err[r] = 0.0;
     }
-    uint4 stg[NQ];
-    auto fetch = [&](uint32_t s) {                               // column s's tables -> registers
+    // Column s's tables -> registers -> LDS. The loads are issued by hand (one unconditional 16-byte load per stage register,
+    // its address picked by selects) and waited for by hand in park(), a whole column of work later. Left to the compiler the
+    // copy was `if (ct part) load .. else if (qs part) load ..`: two exec-mask regions writing the same registers with an
+    // s_waitcnt vmcnt(0) between them, so every column paid NQ L2 round trips one after the other (and the wait drained the
+    // symbol and draw loads of the next column that had just been issued); as plain C++ loads without the branches it
+    // reused the address registers as destinations and waited after each load again. Three clusters (63 KB of tables per
+    // column, one workgroup per CU): 26.9 -> 24.7 ms at 100M x 150; one cluster: unchanged (20.0 ms; there the kernel is 70 %
+    // VALU-bound: SQ counters in profiles/r03_sq_counters_cfg2.txt).
+    typedef uint32_t qz_u32x4 __attribute__((ext_vector_type(4)));
+    qz_u32x4 stg[NQ];
+    auto fetch = [&](uint32_t s) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint32_t i = threadIdx.x + q * T;
-            if (i < per_col4) {
-                const uint32_t l = i / QZ_CLUSTER4, j = i % QZ_CLUSTER4;
-                const uint64_t cs = (uint64_t)l * C + s;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (j < 9) v = reinterpret_cast<const uint4 *>(ct + cs * QVZ_CT_STRIDE)[j];
-                else if (j >= 10) v = reinterpret_cast<const uint4 *>(qs + cs * QVZ_QS_STRIDE)[j - 10];
-                stg[q] = v;
-            }
+            const uint32_t ii = i < per_col4 ? i : 0u;          // threads past the column's tables load entry 0 and park nothing
+            const uint32_t l = ii / QZ_CLUSTER4, j = ii % QZ_CLUSTER4;
+            const uint64_t cs = (uint64_t)l * C + s;
+            const uint4 *pct = reinterpret_cast<const uint4 *>(ct + cs * QVZ_CT_STRIDE);
+            const uint4 *pqs = reinterpret_cast<const uint4 *>(qs + cs * QVZ_QS_STRIDE);
+            const uint4 *src = j < 10 ? pct + (j < 9 ? j : 0u) : pqs + (j - 10);   // (j == 9, the pad between the two tables, gets a copy of entry 0: nobody reads it)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stg[q]) : "v"(src) : "memory");
         }
     };
     auto park = [&](uint4 *dst) {
+        // every load issued so far has landed (the stage registers pass through the wait, so nothing that reads them moves above it)
+        if constexpr (NQ == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]) : : "memory");
+        else if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]) : : "memory");
+        else if constexpr (NQ == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]) : : "memory");
+        static_assert(NQ == 3 || NQ == 4 || NQ == 6 || NQ == 8, "stage registers");
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint32_t i = threadIdx.x + q * T;
-            if (i < per_col4) dst[i] = stg[q];
+            if (i < per_col4) dst[i] = make_uint4(stg[q].x, stg[q].y, stg[q].z, stg[q].w);
         }
     };
     fetch(0);
