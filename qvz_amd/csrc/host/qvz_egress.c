@@ -352,9 +352,9 @@ int qvz_egress_rows(const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, c
     if (!d_sym || !n || !c || ld < n || !path) return qvz_job_fail(QVZ_E_ARG, "bad egress arguments");
     FILE *f = fopen(path, "w");
     if (!f) return qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
-    qvz_prealloc_start(f, n * ((uint64_t)c + 1));                              /* pages made ahead of the writer */
+    /* (no pages made ahead here: without a head start the helper and the writer work on the same pages at the same time,
+     * which is slower than the writer alone - 4.6 s against 3.6 s for 15.1 GB) */
     const int rc = qvz_egress_text(f, d_sym, n, c, ld, NULL);
-    qvz_prealloc_finish(f);
     if (fclose(f) && !rc) return qvz_job_fail(QVZ_E_ARG, "write failed");
     return rc;
 }
