@@ -476,6 +476,13 @@ struct CoderState {
 #define QUOT_LO 5.9604644775390625e-08    /* 2^-24 */
 #define QUOT_HI 0.99999994039535522461    /* 1 - 2^-24 */
 typedef double2 Record;
+// A record is written once by the model kernel and read once by the coder kernel, a segment (~25 ms and gigabytes) later: the
+// stores carry the non-temporal hint, so the lines do not displace what the chip's caches hold for both kernels' other traffic.
+// Alternating builds on one box, 100M x 150: coder phase 154.5 -> 152.4 ms with one cluster (model kernels 127.9 -> 126.4, the
+// coder kernels beside them 136.0 -> 134.2), 227.7 -> 224.1 with three. The same hint on the coder kernel's LOADS of the
+// records makes it 45 % slower (137 -> 198 ms): its loader asks for half lines, and the other half then comes from HBM again.
+typedef double rk_d2 __attribute__((ext_vector_type(2)));
+#define RK_STORE(ptr, val) do { const Record v_ = (val); rk_d2 w_; w_.x = v_.x; w_.y = v_.y; __builtin_nontemporal_store(w_, reinterpret_cast<rk_d2 *>(ptr)); } while (0)
 // The two quotients need not be correctly rounded, only within 2^-47 of cum / n (see above: the budget is 2^-24 over
 // R <= 2^22): 1/n from v_rcp_f64 plus two Newton steps (relative error ~2^-52) times the numerator is far inside that,
 // and costs a dozen instructions instead of two IEEE divisions.
@@ -798,24 +805,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     if (active) {
         b0 = colbase[slice];
         sw = colbase[slice + 1] - b0;
-        // a workgroup lives for some twenty chunks, so what it does before the first one counts: the slice comes in as
-        // 16-byte loads issued back to back, the offset table is ready-made on the host (no dependent second load)
-        const uint4 *src = reinterpret_cast<const uint4 *>(is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0);
-        if (nr == 0) {                                           // no read of this cluster here: the state passes through
-            if (is_first && !is_last)
-                for (uint32_t i = lane; i < sw / 4; i += 64) reinterpret_cast<uint4 *>(save + (uint64_t)g * total_words + b0)[i] = src[i];
-        } else {
-            for (uint32_t i = lane; i < sw / 4; i += 64) {
-                reinterpret_cast<uint4 *>(tab)[i] = src[i];
-                reinterpret_cast<uint4 *>(msk)[2 * i] = make_uint4(0u, 0u, 0u, 0u);
-                reinterpret_cast<uint4 *>(msk)[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
-            }
-            if (!cluster_wave)
-                for (uint32_t i = lane; i < 2 * A; i += 64) cof[i] = coff[(uint64_t)slice * 2 * A + i];
-        }
     }
-    if (nr == 0) return;                                         // whole workgroup (lists only)
-    __syncthreads();
+    if (nr == 0) {                                               // whole workgroup (lists only): no read of this cluster here, the state passes through
+        if (active && is_first && !is_last) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(tmpl + b0);
+            for (uint32_t i = lane; i < sw / 4; i += 64) reinterpret_cast<uint4 *>(save + (uint64_t)g * total_words + b0)[i] = src[i];
+        }
+        return;
+    }
 
     Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index; g = 0 when unit_recs = 8)
     bool bad = false;
@@ -833,6 +830,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t e = ro + j * 64 + lane;
             r_nn[j] = lp[e < nr ? e : nr - 1];
+        }
+    };
+    uint32_t r_n2[4] = {0, 0, 0, 0};                             // the second batch of list entries of a workgroup's start (both are asked for at once)
+    auto fetch_list_second = [&](uint32_t ro) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t e = ro + j * 64 + lane;
+            r_n2[j] = lp[e < nr ? e : nr - 1];
         }
     };
     auto fetch = [&](uint32_t ro) {                              // ro = read (or list entry) offset in the segment
@@ -876,13 +881,68 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         }
         fetch(ro + 256);
     };
+    // Before the first chunk a workgroup needs its tables in LDS and the bytes of its first reads in registers: the list entries
+    // (several clusters) and the input bytes are asked for first, the tables next, and everything is in flight together - one
+    // memory round trip where the order tables, barrier, list entries, bytes made three or four. A workgroup lives for some twenty
+    // chunks, so what it does before the first one counts.
     if (lists) {
         fetch_list(0);
+        fetch_list_second(256);
+    } else {
+        fetch(0);
+    }
+    if (active) {
+        // the slice comes in as 16-byte loads issued back to back, the offset table is ready-made on the host (no dependent
+        // second load). (Written as `for (i ..) tab[i] = src[i]` the compiler made a loop of load, s_waitcnt vmcnt(0), store:
+        // one memory round trip per KB of tables and three more for the offsets, one after the other. Unconditional loads -
+        // the index clamped instead of the lane masked -, issued by hand in batches of four per lane, the offsets first:
+        // model kernels 130.7 -> 127.9 ms at 100M x 150 with one cluster, 228 -> 219 with three, 18.0 -> 16.2 at 10M x 150.)
+        const uint4 *src = reinterpret_cast<const uint4 *>(is_first ? tmpl + b0 : save + (uint64_t)g * total_words + b0);
+        const uint32_t n4 = sw / 4;
+        uint32_t cv[(2 * A + 63) / 64];
+        if (!cluster_wave) {
+#pragma unroll
+            for (uint32_t u = 0; u < (2 * A + 63) / 64; ++u) {
+                const uint32_t i = lane + 64 * u;
+                cv[u] = coff[(uint64_t)slice * 2 * A + (i < 2 * A ? i : 2 * A - 1)];
+            }
+        }
+        typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
+        for (uint32_t i0 = 0; i0 < n4; i0 += 256) {
+            rk_u32x4 v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {                 // issued by hand: the compiler sinks a plain load to its store and waits there
+                const uint32_t i = i0 + lane + 64 * u;
+                const uint4 *pa = src + (i < n4 ? i : n4 - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v[u]) : "v"(pa) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + lane + 64 * u;
+                if (i < n4) {
+                    reinterpret_cast<uint4 *>(tab)[i] = make_uint4(v[u].x, v[u].y, v[u].z, v[u].w);
+                    reinterpret_cast<uint4 *>(msk)[2 * i] = make_uint4(0u, 0u, 0u, 0u);
+                    reinterpret_cast<uint4 *>(msk)[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        }
+        if (!cluster_wave) {
+#pragma unroll
+            for (uint32_t u = 0; u < (2 * A + 63) / 64; ++u) {
+                const uint32_t i = lane + 64 * u;
+                if (i < 2 * A) cof[i] = cv[u];
+            }
+        }
+    }
+    if (lists) {                                                 // the list entries have landed (the tables' wait): now the bytes of those reads
 #pragma unroll
         for (int j = 0; j < 4; ++j) r_nx[j] = r_nn[j];
-        fetch_list(256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r_nn[j] = r_n2[j];
+        fetch(0);
     }
-    fetch(0);
+    __syncthreads();
     park(0);
     lookup(0, 0);
 #ifdef QVZ_PROFILE
@@ -1020,7 +1080,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             if (((chunk + 2) & 3) == 0) park(rb + 128);
             if (rb + rd < nr && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
                 RK_EXP(1)
-                rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 1) * 4 + (col & 3)] = buf[rd * rb_stride + cw];
+                RK_STORE(&rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 1) * 4 + (col & 3)], buf[rd * rb_stride + cw]);
         }
         RK_T(5);
     }
@@ -1816,7 +1876,11 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         goto done;
     }
     t_first_launch = wall_ms();
-    spin_us = getenv("QVZ_CODER_HEADSTART_US") ? (uint32_t)atoi(getenv("QVZ_CODER_HEADSTART_US")) : 40u;   // development knob
+    // the coder kernel's head start over the next model kernel (below). 40 us are enough where the model's workgroups take a CU's
+    // LDS between them slowly (three clusters); with one cluster the model kernel's workgroups - since they ask for their
+    // tables and their first bytes at once - fill the chip faster than 128 coder workgroups find their CUs: at 10M x 150 the coder
+    // kernels took 15 or 18-20 ms from step to step with 40 us, 15.5 with 200 (step 43-44 -> 41.7-42.1 ms; 100M x 150: no change)
+    spin_us = getenv("QVZ_CODER_HEADSTART_US") ? (uint32_t)atoi(getenv("QVZ_CODER_HEADSTART_US")) : (clusters > 1 ? 40u : 200u);   // (the variable: development knob)
     for (uint32_t i = 0; i < nseg; ++i) {
         seg_lo = segs[i].first;
         const uint32_t seg_len = (uint32_t)segs[i].second;       // both kernels lay the segment's records out for this many reads
