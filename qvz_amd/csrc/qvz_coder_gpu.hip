@@ -1722,16 +1722,21 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     t_work = wall_ms();
     // Segments. With room for two record buffers the model kernel of segment i+1 runs beside the coder kernel of
     // segment i on a second HIP stream (the coder keeps three waves on half of the CUs busy with a latency chain; the
-    // model kernel is throughput work that fills the rest); segments are then at most a quarter of a stream (every segment
-    // costs the model kernel a table load and save per workgroup: 104 ms + 5 ms per segment at 100M x 150), the first
-    // and the last a quarter of that.
+    // model kernel is throughput work that fills the rest); segments are then at most an eighth of a stream - a quarter with
+    // several clusters, where a segment costs three times the workgroup starts: 309 against 325 ms per step - (every segment
+    // costs the model kernel a table load and save per workgroup - 5 ms per segment at 100M x 150 in round 2, when a
+    // quarter was the best cut; less since a workgroup asks for its tables and its first bytes at once -, and the coder
+    // kernels idle for about (middle segment - first segment) reads' worth of time while the pipeline fills, whatever
+    // the ramp: a quarter 152.3 ms, a sixth 151.3, an eighth 149.8, a tenth 151.6 at 100M x 150 with one cluster; three
+    // clusters: the workspace bounds the segment), the first and the last a quarter of that.
     seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
     if (seg_reads > longest) seg_reads = longest;
     {
         const char *ov = getenv("QVZ_CODER_OVERLAP");            // development knob: "0" keeps everything on the caller's stream
         const uint64_t half = (work_bytes / 2 / per_read) & ~(uint64_t)63;
         if (!(ov && atoi(ov) == 0) && longest >= 1024 && half >= 64) {
-            uint64_t target = ((longest + 3) / 4 + 63) & ~(uint64_t)63;
+            const uint64_t div = getenv("QVZ_CODER_SEG_DIV") && atoi(getenv("QVZ_CODER_SEG_DIV")) > 0 ? (uint64_t)atoi(getenv("QVZ_CODER_SEG_DIV")) : (clusters > 1 ? 4 : 8);   // (the variable: development knob)
+            uint64_t target = ((longest + div - 1) / div + 63) & ~(uint64_t)63;
             seg_reads = half < target ? half : target;
             overlap = true;
         }
