@@ -215,6 +215,21 @@ static int put(FILE *f, int fd, int64_t *off, const uint8_t *buf, size_t n) {
     return rc;
 }
 
+/* A host buffer into a file at its position the way the slab pipelines below write theirs: with `estimate` > 0 the pages are
+ * made ahead (qvz_prealloc_start) and the slabs go through the mapping - beyond the estimate through pwrite -, and the file ends
+ * where the last byte was written. The pipelines' host half on its own: what the CPU tests (and the sanitizer build) exercise. */
+int qvz_host_write_slabs(FILE *f, const uint8_t *buf, uint64_t bytes, uint64_t estimate, uint64_t slab) {
+    if (!f || (!buf && bytes) || !slab) return qvz_job_fail(QVZ_E_ARG, "bad write arguments");
+    int rc = QVZ_OK;
+    if (estimate) qvz_prealloc_start(f, estimate);
+    int64_t off;
+    const int fd = file_cursor(f, &off);
+    for (uint64_t at = 0; at < bytes && !rc; at += slab) rc = put(f, fd, &off, buf + at, (size_t)(bytes - at < slab ? bytes - at : slab));
+    if (off >= 0) fseeko(f, (off_t)off, SEEK_SET);
+    qvz_prealloc_finish(f);
+    return rc;
+}
+
 /* ---- the pipeline: slab i+1 is produced (kernel + D2H on its own stream) while slab i is written ---- */
 typedef struct {
     void *st[2];

@@ -101,6 +101,7 @@ void qvz_job_release(qvz_job_t *job);
  * not by the host; NULL: the data is complete already */
 int qvz_egress_text(FILE *fu, const uint8_t *d_qv, uint64_t N, uint32_t C, uint64_t ld, void *after);   /* -u rows at fu's position */
 int qvz_prealloc_start(FILE *f, uint64_t bytes);    /* a thread makes the pages of the next `bytes` of f ahead of qvz_egress_*; 1 if started */
+int qvz_host_write_slabs(FILE *f, const uint8_t *buf, uint64_t bytes, uint64_t estimate, uint64_t slab);   /* a host buffer the way the slab pipelines write */
 void qvz_prealloc_finish(FILE *f);                  /* ... and must be ended before f is closed (no-op if none was started) */
 int qvz_egress_bytes(FILE *f, const uint8_t *d_src, uint64_t bytes, void *after);
 int qvz_sum_errors(const double *d_err, uint64_t N, uint32_t C, double *sum_out, double *keep, void *after);

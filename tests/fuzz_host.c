@@ -118,6 +118,23 @@ int main(int argc, char **argv) {
     snprintf(tmp, sizeof(tmp), "%s/mutant", work);
     snprintf(out, sizeof(out), "%s/out", work);
     FILE *sink = fopen("/dev/null", "w");
+    {   /* the output side once under the sanitizers: pages made ahead and the writer's mapping (host/qvz_egress.c), exact and wrong estimates */
+        setenv("QVZ_PREALLOC_MIN", "1", 1);
+        const size_t n = (3u << 20) + 77;
+        uint8_t *buf = (uint8_t *)malloc(n), *back = (uint8_t *)malloc(n + 64);
+        for (size_t i = 0; i < n; ++i) buf[i] = (uint8_t)(rnd() >> 7);
+        const uint64_t est[4] = {n, n + 100000, 4096 + 5, 0};
+        for (int e = 0; e < 4; ++e) {
+            FILE *f = fopen(out, "w");
+            if (!f || fwrite("head", 1, 4, f) != 4 || qvz_host_write_slabs(f, buf, n, est[e], 1u << 20)) { fprintf(stderr, "write through the mapping failed\n"); return 3; }
+            fclose(f);
+            f = fopen(out, "rb");
+            const size_t got = fread(back, 1, n + 64, f);
+            fclose(f);
+            if (got != n + 4 || memcmp(back, "head", 4) || memcmp(back + 4, buf, n)) { fprintf(stderr, "estimate %d: the file differs\n", e); return 3; }
+        }
+        free(buf); free(back);
+    }
     long parsed = 0, decoded = 0, rejected = 0, fq_ok = 0, set_ok = 0, dist_ok = 0;
     for (long it = 0; it < iters; ++it) {
         if (nq) {                                                             /* .q image: header + codebooks + stream */

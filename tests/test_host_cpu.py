@@ -349,3 +349,37 @@ def test_parallel_file_write_and_copy_helpers(tmp_path):
     finally:
         os.close(fd)
     assert open(path, "rb").read() == bytes(expect)
+
+
+@pytest.mark.parametrize("estimate_of", ["exact", "too_much", "too_little", "none"])
+def test_big_outputs_through_pages_made_ahead(tmp_path, estimate_of, monkeypatch):
+    """host/qvz_egress.c: a big output whose size is known (or estimated) early gets its pages from a helper thread's
+    fallocate and is written through a mapping, never ahead of the helper; what lies beyond an estimate goes through pwrite,
+    what an estimate allocated too much is given back, and the file ends where the last byte went. The same bytes and the same
+    length as a plain write, behind a header that stdio wrote first."""
+    from qvz_amd._lib import lib
+    L = lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fwrite.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    L.qvz_host_write_slabs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.qvz_host_write_slabs.restype = C.c_int
+    monkeypatch.setenv("QVZ_PREALLOC_MIN", "1")
+    rng = np.random.default_rng(11)
+    head = b"header written by stdio\n" * 3                     # not page aligned: the mapping starts inside a page
+    n = (21 << 20) + 4321
+    body = rng.integers(0, 256, size=n, dtype=np.uint8)
+    estimate = {"exact": n, "too_much": n + (9 << 20) + 17, "too_little": (5 << 20) + 3, "none": 0}[estimate_of]
+    path = str(tmp_path / "out.bin")
+    f = libc.fopen(path.encode(), b"w")
+    assert f
+    assert libc.fwrite(head, 1, len(head), f) == len(head)
+    assert L.qvz_host_write_slabs(f, body.ctypes.data, n, estimate, 3 << 20) == 0
+    tail = b"and a trailer through stdio"
+    assert libc.fwrite(tail, 1, len(tail), f) == len(tail)
+    libc.fclose(f)
+    got = open(path, "rb").read()
+    assert len(got) == len(head) + n + len(tail)
+    assert got[:len(head)] == head and got[len(head):len(head) + n] == body.tobytes() and got[len(head) + n:] == tail
