@@ -1784,10 +1784,20 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         const uint64_t q = (seg_reads / 4) & ~(uint64_t)63;
         const uint64_t tail_lo = (longest - q) & ~(uint64_t)63;                  // segment starts stay multiples of 64
         const uint64_t mid = tail_lo - q;
-        const uint64_t nm = (mid + seg_reads - 1) / seg_reads;
-        const uint64_t each = (((mid + nm - 1) / nm) + 63) & ~(uint64_t)63;      // <= seg_reads (a multiple of 64 itself)
+        // the middle in nm segments of whole 64-read chunks that differ by one chunk at most (cut as "each, each, .., the rest"
+        // the rest could be a fifth of a segment: a table save and load per workgroup for a handful of chunks)
+        const uint64_t units = mid / 64;                                          // q and tail_lo are multiples of 64
+        uint64_t nm = (mid + seg_reads - 1) / seg_reads;
+        if (nm == 0) nm = 1;
+        const uint64_t base = units / nm, extra = units % nm;                    // `extra` segments get one chunk more
         segs.push_back({0, q});
-        for (uint64_t lo = q; lo < tail_lo; lo += each) segs.push_back({lo, lo + each <= tail_lo ? each : tail_lo - lo});
+        uint64_t lo = q;
+        for (uint64_t i = 0; i < nm && lo < tail_lo; ++i) {
+            uint64_t len = (base + (i < extra ? 1 : 0)) * 64;
+            if (i + 1 == nm || lo + len > tail_lo) len = tail_lo - lo;            // (mid is a multiple of 64: the last one ends on tail_lo)
+            if (len) segs.push_back({lo, len});
+            lo += len;
+        }
         segs.push_back({tail_lo, longest - tail_lo});
         // (Halving the last full segment - and its second half again - so that less of the coder's work is left when the last
         // model kernel ends was tried: every extra segment costs the model kernel a table save and load per workgroup,
