@@ -1091,7 +1091,12 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
 #endif
     if (active && !is_last)
-        for (uint32_t i = lane; i < sw / 4; i += 64) reinterpret_cast<uint4 *>(save + (uint64_t)g * total_words + b0)[i] = reinterpret_cast<const uint4 *>(tab)[i];
+        for (uint32_t i = lane; i < sw / 4; i += 64) {           // (read again a segment later: the non-temporal hint, as for the records)
+            typedef uint32_t rk_u32x4s __attribute__((ext_vector_type(4)));
+            const uint4 v = reinterpret_cast<const uint4 *>(tab)[i];
+            rk_u32x4s w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+            __builtin_nontemporal_store(w, reinterpret_cast<rk_u32x4s *>(save + (uint64_t)g * total_words + b0) + i);
+        }
     if (bad) atomicOr(status, 1);
 }
 
