@@ -1150,16 +1150,24 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     const uint64_t nblk = (Tmax + CR_B - 1) / CR_B;              // the same in all four waves
     const bool fresh = is_first || !live;
 #ifdef QVZ_PROFILE          // busy / waiting cycles of each role between the block barriers
-    unsigned long long cr_busy = 0, cr_wait = 0, cr_t = __builtin_readcyclecounter();
-#define CR_BARRIER() do { const unsigned long long a_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-                          const unsigned long long b_ = __builtin_readcyclecounter(); cr_busy += a_ - cr_t; cr_wait += b_ - a_; cr_t = b_; } while (0)
+    unsigned long long cr_busy = 0, cr_wait = 0, cr_drain = 0, cr_t = __builtin_readcyclecounter();   // cr_drain: the part of cr_wait spent in s_waitcnt lgkmcnt(0)
+#define CR_BARRIER() do { const unsigned long long a_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                          const unsigned long long m_ = __builtin_readcyclecounter(); asm volatile("s_barrier" ::: "memory"); \
+                          const unsigned long long b_ = __builtin_readcyclecounter(); cr_busy += a_ - cr_t; cr_wait += b_ - a_; cr_drain += m_ - a_; cr_t = b_; } while (0)
 #define CR_REPORT() do { if (lane == 0 && (blockIdx.x & 15) == 3) { atomicAdd(&g_cr_prof[wave * 2], cr_busy); atomicAdd(&g_cr_prof[wave * 2 + 1], cr_wait); \
+                                                                    atomicAdd(&g_cr_prof[9 + wave], cr_drain); \
                                                                     if (wave == 0) atomicAdd(&g_cr_prof[8], (unsigned long long)nblk); } } while (0)
 #else
 #define CR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define CR_REPORT() do { } while (0)
 #endif
-    // barriers 0 .. nblk + 1 in every wave (+ one more on the last segment for the hand-over of l and scale3)
+    // barriers 0 .. nblk + 1 in every wave (+ one more on the last segment for the hand-over of l and scale3).
+    // (Beside the model kernel the interval wave is busy 1084 cycles of a block's 1370, 74 of the rest drain its LDS writes and
+    // 212 pass in the barrier - 57 with the CU to itself. Tried: no barrier, the waves handing blocks over through progress
+    // counters in LDS - a counter written after a block's data, read before it; a wave's LDS instructions are carried out in
+    // order -, only the wave that is behind waiting, polls bounded. Byte-identical streams and twice as slow, alone (210 against
+    // 110 ms) and beside the model kernel (223 against 139): a hand-over costs a write's and a read's LDS latency plus the
+    // poll's sleep where the barrier costs tens of cycles, and the polling waves take LDS slots from the one that works.)
 
     if (wave == 3) {
         // ------------------------------------ loader ------------------------------------
@@ -2010,6 +2018,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         const double nb = cr[8] ? (double)cr[8] : 1.0;
         fprintf(stderr, "k_code_records cycles per block of 8 symbols, busy/waiting: interval %.0f/%.0f  bits %.0f/%.0f  bytes %.0f/%.0f  loader %.0f/%.0f\n",
                 cr[0] / nb, cr[1] / nb, cr[2] / nb, cr[3] / nb, cr[4] / nb, cr[5] / nb, cr[6] / nb, cr[7] / nb);
+        fprintf(stderr, "  cycles of that waiting spent in s_waitcnt lgkmcnt(0) before the barrier: interval %.0f  bits %.0f  bytes %.0f  loader %.0f\n", cr[9] / nb, cr[10] / nb, cr[11] / nb, cr[12] / nb);
         fprintf(stderr, "k_model_ranks cycles per wave and chunk: lookup %.0f  ranks %.0f  update+record %.0f  barrier1 %.0f  park+barrier2 %.0f  drain %.0f  (%.3g wave-chunks)\n",
                 z[0] / ch, z[1] / ch, z[2] / ch, z[3] / ch, z[4] / ch, z[5] / ch, ch);
     }
