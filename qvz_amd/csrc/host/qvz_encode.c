@@ -770,6 +770,9 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     HIP(qvz_hip_stream_sync(NULL));
     if (status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
     qvz_hip_free(job->d_draws); job->d_draws = NULL;
+    /* the symbols are not needed again either (this stage ends a job; qvz_job_release frees what is left): 15 GB at 100M x 150
+     * that the coder's buffers and the -u staging can have - with -u the process is otherwise near what the card holds */
+    qvz_hip_free(job->d_sym); job->d_sym = NULL;
     t1 = now();
     job->t_quantize = t1 - t0;
 
@@ -799,10 +802,15 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         per += 4;
         for (uint32_t bits = 6; ; bits *= 2) {
             cap = ((per * C * bits) / 8 + 512 + 3) & ~3ull;
+            const double ta = now();
             qvz_hip_free(d_out); d_out = NULL;
             HIP(qvz_hip_malloc((void **)&d_out, (size_t)shards * cap));
+            const double tb = now();
             if (prep_running) { pthread_join(th_prep, NULL); prep_running = 0; }
+            const double tc = now();
             workspace_join(job);
+            if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: before the coder call: stream area of %.1f GB allocated in %.4f s, waited %.4f s for the coder's set-up thread, %.4f s for the workspace thread\n",
+                                              (double)shards * cap / 1e9, tb - ta, tc - tb, now() - tc);
             const int mine = job->d_work && job->work_shards == shards;        /* allocated ahead of time for this very cut */
             const int crc = qvz_hip_encode_planes_bounds(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
                                                          shards, job->shard_bounds, d_out, cap, sizes, mine ? job->d_work : NULL, mine ? job->work_bytes : 0, NULL);
