@@ -270,6 +270,7 @@ struct LmDesign {
 
 // Region index of two symbols under a partition: the number of interior bounds (t = 1 .. S-1) not above the symbol.
 // The bounds are read sixteen at a time (one LDS round trip) and compared from registers.
+template <bool BOTH = true>
 __device__ __forceinline__ void lm_region_of(const uint8_t *bounds, uint32_t S, uint32_t xa, uint32_t xb, uint32_t &ja,
                                              uint32_t &jb) {
     for (uint32_t t0 = 0; t0 < S; t0 += 16) {
@@ -284,7 +285,7 @@ __device__ __forceinline__ void lm_region_of(const uint8_t *bounds, uint32_t S, 
             // t = 0 never counts; bounds past S - 1 are made unreachable (a scalar select) instead of masking two vector results
             const uint32_t bt = (t >= 1 && t < S) ? (ww[u >> 2] >> (8 * (u & 3))) & 0xFFu : 0xFFFFu;
             ja += bt <= xa ? 1u : 0u;
-            jb += bt <= xb ? 1u : 0u;
+            if (BOTH) jb += bt <= xb ? 1u : 0u;
         }
     }
 }
@@ -360,28 +361,51 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 // leaves a sum of non-negative terms bit for bit what it was.
                 const uint32_t rrA = lane, rrB = lane + 64 < A ? lane + 64 : A - 1;
                 const bool hasB = lane + 64 < A;
+                // MONO and no mass from symbol 64 on (real quality values end near 41): a candidate r >= 64 costs more than
+                // r - 1 - every term p_i f(r - i) with i < 64 <= r grows with r, f strictly increasing - or, in a region without
+                // mass, as much as every other one, where the first candidate wins: it is never the first minimum of its region
+                // unless it is the region's first candidate, which the arg-min below starts from whatever its cost. So the
+                // eight second candidates are not summed (they doubled the loop for all 64 lanes) and their cost reads DBL_MAX.
+                const bool skipB = MONO && zhi <= 64;
                 uint32_t jA = 0, jB = 0;
-                lm_region_of(bounds, S, rrA, rrB, jA, jB);
-                uint32_t a0 = bounds[jA], a1 = bounds[jA + 1], c0 = bounds[jB], c1 = hasB ? bounds[jB + 1] : c0;
+                if (skipB) lm_region_of<false>(bounds, S, rrA, rrB, jA, jB); else lm_region_of<true>(bounds, S, rrA, rrB, jA, jB);
+                uint32_t a0 = bounds[jA], a1 = bounds[jA + 1];
                 a0 = a0 > zlo ? a0 : zlo; a1 = a1 < zhi ? a1 : zhi; a1 = a1 > a0 ? a1 : a0;   // the region's part with mass
-                c0 = c0 > zlo ? c0 : zlo; c1 = c1 < zhi ? c1 : zhi; c1 = c1 > c0 ? c1 : c0;
-                const uint32_t lenA = a1 - a0, lenB = c1 - c0;
-                LM_T(1);
-                // A design is one wave alone on its SIMD: every LDS access it waits for costs its full latency (~130
-                // cycles), so four terms are fetched and multiplied at a time and then added in index order.
-                double mA = 0.0, mB = 0.0;
-                for (uint32_t k = 0; __ballot(k < lenA || k < lenB); k += 4) {
-                    double vA[4], vB[4];
+                const uint32_t lenA = a1 - a0;
+                double mA = 0.0, mB = DBL_MAX;
+                if (skipB) {
+                    LM_T(1);
+                    for (uint32_t k = 0; __ballot(k < lenA); k += 4) {
+                        double vA[4];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t iA = k + u < lenA ? a0 + k + u : a0, iB = k + u < lenB ? c0 + k + u : c0;
-                        vA[u] = p[iA] * D(iA, rrA);
-                        vB[u] = p[iB] * D(iB, rrB);
+                        for (uint32_t u = 0; u < 4; ++u) {
+                            const uint32_t iA = k + u < lenA ? a0 + k + u : a0;
+                            vA[u] = p[iA] * D(iA, rrA);
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; ++u) mA += k + u < lenA ? vA[u] : 0.0;
                     }
+                } else {
+                    uint32_t c0 = bounds[jB], c1 = hasB ? bounds[jB + 1] : c0;
+                    c0 = c0 > zlo ? c0 : zlo; c1 = c1 < zhi ? c1 : zhi; c1 = c1 > c0 ? c1 : c0;
+                    const uint32_t lenB = c1 - c0;
+                    LM_T(1);
+                    // A design is one wave alone on its SIMD: every LDS access it waits for costs its full latency (~130
+                    // cycles), so four terms are fetched and multiplied at a time and then added in index order.
+                    mB = 0.0;
+                    for (uint32_t k = 0; __ballot(k < lenA || k < lenB); k += 4) {
+                        double vA[4], vB[4];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        mA += k + u < lenA ? vA[u] : 0.0;
-                        mB += k + u < lenB ? vB[u] : 0.0;
+                        for (uint32_t u = 0; u < 4; ++u) {
+                            const uint32_t iA = k + u < lenA ? a0 + k + u : a0, iB = k + u < lenB ? c0 + k + u : c0;
+                            vA[u] = p[iA] * D(iA, rrA);
+                            vB[u] = p[iB] * D(iB, rrB);
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; ++u) {
+                            mA += k + u < lenA ? vA[u] : 0.0;
+                            mB += k + u < lenB ? vB[u] : 0.0;
+                        }
                     }
                 }
                 L->mv[rrA] = mA;
