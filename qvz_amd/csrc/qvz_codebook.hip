@@ -418,13 +418,20 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                 const uint32_t b0 = bounds[j], b1 = bounds[j + 1];
                 double best_v = DBL_MAX;
                 uint32_t best_r = b0;                                                // min_r = bounds[j]
-                for (uint32_t r = b0; r < b1; r += 8) {              // eight candidates per LDS round trip, compared in order
+                // MONO: a candidate below the first symbol with mass costs more than its right neighbour, one from the last
+                // symbol with mass on more than its left neighbour (every term p_i f(|i - r|) moves the same way, f strictly
+                // increasing), so the first minimum of a region with mass lies in [zlo, zhi); a region without mass either lies
+                // outside that range (nothing is scanned, the first candidate stands) or begins inside it (the scan begins at its
+                // first candidate, all costs are 0, the first one stands). The widest region is the last one - it runs to
+                // symbol 71 whatever the data - and its scan ends at zhi (~41) now.
+                const uint32_t s0 = MONO ? (b0 > zlo ? b0 : zlo) : b0, s1 = MONO ? (b1 < zhi ? b1 : zhi) : b1;
+                for (uint32_t r = s0; r < s1; r += 8) {              // eight candidates per LDS round trip, compared in order
                     double v[8];
 #pragma unroll
-                    for (uint32_t u = 0; u < 8; ++u) v[u] = L->mv[r + u < b1 ? r + u : b0];
+                    for (uint32_t u = 0; u < 8; ++u) v[u] = L->mv[r + u < s1 ? r + u : s0];
 #pragma unroll
                     for (uint32_t u = 0; u < 8; ++u)
-                        if (r + u < b1 && v[u] < best_v) { best_v = v[u]; best_r = r + u; }
+                        if (r + u < s1 && v[u] < best_v) { best_v = v[u]; best_r = r + u; }
                 }
                 if (best_r != recon[j]) { chg = 1; recon[j] = (uint8_t)best_r; }
             }
