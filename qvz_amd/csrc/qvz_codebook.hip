@@ -476,6 +476,27 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
             // The reconstruction points are read eight at a time (recon[] is 8-byte aligned in both slots).
             // Every lane would compute the same walk: the eight reconstruction points of a step go to scalar registers and
             // the walk is scalar arithmetic with scalar branches (as vector code every `if` of it was an exec-mask region).
+            if (S <= 64) {
+                // ... and the walk itself is a scan: with c_t = (ra + rb) / 2 + 1 where rb > ra (0, which never binds, elsewhere),
+                // jn_t = max(c_t, jn_{t-1} + 1) from jn_{-1} = 0 is t + max(1, max_{s <= t} (c_s - s)): lane t takes boundary t, a
+                // prefix maximum over the lanes (six shuffles) replaces S - 1 dependent scalar steps of ten instructions each -
+                // a fifth of an iteration of this lone wave. The walk stops at the first t whose own test fails (the same tests on
+                // the same numbers: a lane's jn_t is exact whenever every earlier lane passed); the bounds beyond keep their values.
+                const uint32_t t = lane;
+                const bool in = t + 1 < S;
+                const uint32_t ra = recon[in ? t : 0], rb = recon[in ? t + 1 : 0];
+                int32_t m = in ? (rb > ra ? (int32_t)((ra + rb) / 2 + 1) - (int32_t)t : -(int32_t)t) : -(int32_t)(1 << 20);
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int32_t o = __shfl_up(m, off, 64);
+                    m = (int)lane >= off && o > m ? o : m;
+                }
+                const uint32_t jn = t + (uint32_t)(m > 1 ? m : 1);
+                const bool stop_here = in && ((rb <= ra && (rb == ra || 2 * jn >= ra + rb)) || jn > A - 2);
+                const unsigned long long stops = __ballot(stop_here);
+                const uint32_t first = stops ? (uint32_t)__builtin_ctzll(stops) : 64u;
+                if (in && t < first) bounds[t + 1] = (uint8_t)jn;
+            } else {
             uint32_t jprev = 0;
             bool walking = true;
             for (uint32_t t0 = 0; t0 + 1 < S && walking; t0 += 8) {
@@ -496,6 +517,7 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
                     if (lane == 0) bounds[t + 1] = (uint8_t)jn;
                     jprev = jn;
                 }
+            }
             }
         } else {
             uint32_t jprev = 0;
