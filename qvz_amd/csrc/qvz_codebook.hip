@@ -345,7 +345,9 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
         iter += 1;
         // `stop` lives in global memory: looking at it costs this lone wave ~1100 cycles, a tenth of an iteration (asking an
         // iteration ahead did not hide it). Every fourth iteration is enough: a design learns of a smaller S that reached
-        // the target at most three iterations late.
+        // the target at most three iterations late. (Also tried, end of round 3: the look as a hand-issued VECTOR load - the
+        // uniform address makes it a scalar one, which every lgkmcnt wait between an iteration's phases waits for - asked for
+        // at the top of every iteration and read at the top of the next: same bytes, the same 18 ms per codebook.)
         if (stop && (iter & 3) == 1 && __atomic_load_n(stop, __ATOMIC_RELAXED) < S) return false;   // wave-uniform
         LM_T(0);
         // New reconstruction points (:62-87). The regions of one iteration depend on the bounds only, which do not
