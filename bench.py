@@ -242,6 +242,7 @@ def other_configs_report(args, done_cfg, sym_done, threads):
             return P.encode_pass(sym, n, 0, n, None, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], shards=8192,
                                  threads=threads, coder="gpu", keep_device=not args.no_u)
 
+        torch.cuda.empty_cache()                                 # (what the extras before this one left in torch's cache has the wrong block sizes)
         r = step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
