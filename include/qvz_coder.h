@@ -111,6 +111,13 @@ int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint32_t cluster
 /* Record workspace (bytes) with which streams of up to longest_reads reads are coded in one segment; less means more
  * segments (each costs the model kernel a table save and load). For callers that allocate d_work themselves. */
 uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards);
+
+/* How qvz_hip_encode_planes cuts a stream of `longest_reads` reads into segments of at most `seg_reads` (what half the
+ * workspace holds, or an eighth / a quarter of a stream): `overlap` != 0 - the model kernel of a segment beside the coder kernel
+ * of the one before - makes the first and the last segment a quarter of the others. No device needed. Returns the number of
+ * segments; first[i], reads[i] of the first min(count, cap) are written. (No counterpart in the reference: its coder is one
+ * loop over the lines, src/qv_compressor.c:76-135.) */
+uint32_t qvz_coder_segment_list(uint64_t longest_reads, uint64_t seg_reads, int overlap, uint64_t *first, uint64_t *reads, uint32_t cap);
 int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                  uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                  const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work,

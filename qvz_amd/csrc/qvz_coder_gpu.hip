@@ -1575,6 +1575,50 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
                                         h_sizes, d_work, work_bytes, stream);
 }
 
+// Segment list of a call: (first read, reads) relative to a stream's start, for the longest stream. When the two kernels
+// overlap, the first model kernel and the last coder kernel still run alone: those two segments are a quarter of the others.
+static void coder_segments(uint64_t longest, uint64_t seg_reads, bool overlap, std::vector<std::pair<uint64_t, uint64_t>> &segs) {
+    if (overlap && seg_reads >= 256 && longest > seg_reads) {
+        const uint64_t q = (seg_reads / 4) & ~(uint64_t)63;
+        const uint64_t tail_lo = (longest - q) & ~(uint64_t)63;                  // segment starts stay multiples of 64
+        const uint64_t mid = tail_lo - q;
+        // the middle in nm segments of whole 64-read chunks that differ by one chunk at most (cut as "each, each, .., the rest"
+        // the rest could be a fifth of a segment: a table save and load per workgroup for a handful of chunks)
+        const uint64_t units = mid / 64;                                          // q and tail_lo are multiples of 64
+        uint64_t nm = (mid + seg_reads - 1) / seg_reads;
+        if (nm == 0) nm = 1;
+        const uint64_t base = units / nm, extra = units % nm;                    // `extra` segments get one chunk more
+        segs.push_back({0, q});
+        uint64_t lo = q;
+        for (uint64_t i = 0; i < nm && lo < tail_lo; ++i) {
+            uint64_t len = (base + (i < extra ? 1 : 0)) * 64;
+            if (i + 1 == nm || lo + len > tail_lo) len = tail_lo - lo;            // (mid is a multiple of 64: the last one ends on tail_lo)
+            if (len) segs.push_back({lo, len});
+            lo += len;
+        }
+        segs.push_back({tail_lo, longest - tail_lo});
+        // (Halving the last full segment - and its second half again - so that less of the coder's work is left when the last
+        // model kernel ends was tried: every extra segment costs the model kernel a table save and load per workgroup,
+        // 3 ms at 100M x 150 with one cluster and 8-10 ms with three, more than the shorter tail gives back:
+        // 220.7 -> 221.9 -> 224.3 ms and 349 -> 361 -> 363 ms per step.)
+    } else {
+        for (uint64_t lo = 0; lo < longest; lo += seg_reads) segs.push_back({lo, lo + seg_reads <= longest ? seg_reads : longest - lo});
+    }
+}
+
+// The rule above on its own (no device needed): tests and tools look at the cut a call would make. Returns the number of segments;
+// the first min(count, cap) are written.
+extern "C" uint32_t qvz_coder_segment_list(uint64_t longest, uint64_t seg_reads, int overlap, uint64_t *first, uint64_t *reads, uint32_t cap) {
+    std::vector<std::pair<uint64_t, uint64_t>> segs;
+    if (!longest || seg_reads < 4) return 0;
+    coder_segments(longest, seg_reads, overlap != 0, segs);
+    for (uint32_t i = 0; i < segs.size() && i < cap; ++i) {
+        if (first) first[i] = segs[i].first;
+        if (reads) reads[i] = segs[i].second;
+    }
+    return (uint32_t)segs.size();
+}
+
 static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                               uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                               const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
@@ -1791,34 +1835,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
     }
-    // Segment list. When the two kernels overlap, the first model kernel and the last coder kernel still run alone:
-    // those two segments are a quarter of the others.
-    if (overlap && seg_reads >= 256 && longest > seg_reads) {
-        const uint64_t q = (seg_reads / 4) & ~(uint64_t)63;
-        const uint64_t tail_lo = (longest - q) & ~(uint64_t)63;                  // segment starts stay multiples of 64
-        const uint64_t mid = tail_lo - q;
-        // the middle in nm segments of whole 64-read chunks that differ by one chunk at most (cut as "each, each, .., the rest"
-        // the rest could be a fifth of a segment: a table save and load per workgroup for a handful of chunks)
-        const uint64_t units = mid / 64;                                          // q and tail_lo are multiples of 64
-        uint64_t nm = (mid + seg_reads - 1) / seg_reads;
-        if (nm == 0) nm = 1;
-        const uint64_t base = units / nm, extra = units % nm;                    // `extra` segments get one chunk more
-        segs.push_back({0, q});
-        uint64_t lo = q;
-        for (uint64_t i = 0; i < nm && lo < tail_lo; ++i) {
-            uint64_t len = (base + (i < extra ? 1 : 0)) * 64;
-            if (i + 1 == nm || lo + len > tail_lo) len = tail_lo - lo;            // (mid is a multiple of 64: the last one ends on tail_lo)
-            if (len) segs.push_back({lo, len});
-            lo += len;
-        }
-        segs.push_back({tail_lo, longest - tail_lo});
-        // (Halving the last full segment - and its second half again - so that less of the coder's work is left when the last
-        // model kernel ends was tried: every extra segment costs the model kernel a table save and load per workgroup,
-        // 3 ms at 100M x 150 with one cluster and 8-10 ms with three, more than the shorter tail gives back:
-        // 220.7 -> 221.9 -> 224.3 ms and 349 -> 361 -> 363 ms per step.)
-    } else {
-        for (uint64_t lo = 0; lo < longest; lo += seg_reads) segs.push_back({lo, lo + seg_reads <= longest ? seg_reads : longest - lo});
-    }
+    coder_segments(longest, seg_reads, overlap, segs);
     nseg = (uint32_t)segs.size();
     if (rk_waves && clusters > 1) {                              // read lists per (stream, cluster) and where the segments cut them
         std::vector<uint32_t> h_bounds(nseg + 1);

@@ -383,3 +383,30 @@ def test_big_outputs_through_pages_made_ahead(tmp_path, estimate_of, monkeypatch
     got = open(path, "rb").read()
     assert len(got) == len(head) + n + len(tail)
     assert got[:len(head)] == head and got[len(head):len(head) + n] == body.tobytes() and got[len(head) + n:] == tail
+
+
+def test_coder_segment_cut():
+    """The cut of a stream into the coder's segments (qvz_coder_segment_list, the rule of qvz_hip_encode_planes): the segments
+    tile the stream in order, none is longer than the bound, every start is a whole 64-read chunk; with overlapping kernels the
+    first and the last are short (a quarter of the bound) and the middle ones differ by one chunk at most - no short left-over
+    segment, which would cost every model workgroup a table save and load for a handful of chunks."""
+    from qvz_amd._lib import lib
+    L = lib()
+    rng = np.random.default_rng(3)
+    cases = [(12208, 1536, 1), (12208, 2432, 1), (1224, 192, 1), (12208, 2560, 0), (100, 64, 1), (255, 256, 1), (70000, 2432, 1)]
+    cases += [(int(rng.integers(1, 200000)), int(rng.integers(1, 80)) * 64, int(rng.integers(0, 2))) for _ in range(300)]
+    for longest, seg, overlap in cases:
+        first = np.zeros(4096, dtype=np.uint64)
+        reads = np.zeros(4096, dtype=np.uint64)
+        n = L.qvz_coder_segment_list(longest, seg, overlap, first.ctypes.data, reads.ctypes.data, 4096)
+        assert 0 < n <= 4096, (longest, seg, overlap, n)
+        f, r = first[:n].astype(np.int64), reads[:n].astype(np.int64)
+        assert f[0] == 0 and (f[1:] == f[:-1] + r[:-1]).all() and f[-1] + r[-1] == longest, (longest, seg, overlap)
+        assert (r > 0).all() and (r <= seg).all() and (f % 64 == 0).all(), (longest, seg, overlap, r)
+        if overlap and seg >= 256 and longest > seg:
+            q = (seg // 4) // 64 * 64
+            assert r[0] == q and q <= r[-1] < q + 64, (longest, seg, r)
+            mid = r[1:-1]
+            assert len(mid) == 0 or (mid.max() - mid.min() <= 64 and (mid % 64 == 0).all()), (longest, seg, mid)
+        else:
+            assert (r[:-1] == seg).all(), (longest, seg, r)
