@@ -80,6 +80,12 @@ int qvz_hip_codebook_warmup(void);
 /* 1 if the check has passed on the current device (runs / waits for it): the device's entropies take the decisions;
  * 0: they only steer and the host's libm decides (the check failed, or QVZ_CB_LOG2=host) */
 int qvz_hip_codebook_exact_entropies(void);
+/* The run-time check is a sample (2^20 arguments): it catches another libm, it cannot prove equality on the arguments a given
+ * pmf produces - "the reference's bytes on this host" is a statistical claim as far as the ratios go. The DECISIONS are
+ * protected further: an `entropy < target` comparison whose two sides lie within 1e-12 of each other (a one-bit miss of the
+ * log2 restatement moves an entropy by ~1e-15) is taken again by the host's libm from the device-made pmfs, target included.
+ * Process-wide counts of such re-decisions and of those where the libm's numbers differed from the device's by a bit. */
+void qvz_hip_codebook_exact_recheck_counts(unsigned long long *rechecked, unsigned long long *mismatched);
 
 /* Number of host-side decisions the last qvz_hip_generate_codebook call OF THE CALLING THREAD had to take inside the
  * guard band. (qvz_hip_generate_codebook may run concurrently on several host threads, one cluster and one stream each:

@@ -67,6 +67,7 @@ SIGNATURES = {
                                             C.c_double, C.c_void_p, C.c_void_p]),
     "qvz_hip_codebook_warmup": (C.c_int, []),
     "qvz_hip_codebook_exact_entropies": (C.c_int, []),
+    "qvz_hip_codebook_exact_recheck_counts": (None, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "qvz_hip_codebook_deferred_decisions": (C.c_uint64, []),
     "qvz_hip_marginals": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.c_void_p]),
     "qvz_codebook_tables": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),

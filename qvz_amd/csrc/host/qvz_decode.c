@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/statvfs.h>
 #include <time.h>
 
 #include "qvz_codebook.h"
@@ -358,7 +359,22 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
     if (qvz_hip_set_device(device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
     fo = fopen(out_path, "w");
     if (!fo) return qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
-    qvz_prealloc_start(fo, N * ((uint64_t)C + 1));                             /* the text's pages are made while the GPU decodes */
+    {
+        /* The text's pages are made while the GPU decodes - but N and C are a header's claim until the streams have decoded, and
+         * a small crafted file may claim 1e9 x 150: pages are made ahead only for a text the output's file system has room for
+         * (on tmpfs that is RAM: a claim beyond it is refused here, where a true one would fail in the writes anyway). */
+        const uint64_t text = N * ((uint64_t)C + 1);
+        struct statvfs vfs;
+        struct stat ost;
+        if (fstat(fileno(fo), &ost) == 0 && S_ISREG(ost.st_mode) && fstatvfs(fileno(fo), &vfs) == 0) {
+            const uint64_t room = (uint64_t)vfs.f_bavail * (uint64_t)vfs.f_frsize;
+            if (text > room) {
+                rc = qvz_job_fail(QVZ_E_DATA, "the header claims %llu bytes of text, the output's file system has room for %llu", (unsigned long long)text, (unsigned long long)room);
+                goto done;
+            }
+            qvz_prealloc_start(fo, text);
+        }
+    }
     const double t_0 = dec_now();
     double t_up = t_0, t_dec = t_0;
 #define HIPC(call) do { if ((call) != QVZ_OK) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; } } while (0)

@@ -5,6 +5,7 @@
  * reads), and no N-sized host buffer, pageable copy or second N-sized device buffer is made for either.
  * Every function may be called from a host thread of its own (it makes its own streams); the caller has selected the device. */
 #define _GNU_SOURCE
+#include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -56,9 +57,11 @@ typedef struct { int fd; const uint8_t *buf; size_t n; off_t off; int failed; } 
 
 static void *write_part(void *arg) {
     wpart_t *p = (wpart_t *)arg;
+    int zero_writes = 0;
     while (p->n) {
         const ssize_t w = pwrite(p->fd, p->buf, p->n, p->off);
-        if (w <= 0) { p->failed = 1; return NULL; }
+        if (w < 0 && errno == EINTR) continue;                                  /* a signal (a profiler's timer) is not a failed write */
+        if (w < 0 || (w == 0 && ++zero_writes > 1)) { p->failed = 1; return NULL; }
         p->buf += w; p->off += w; p->n -= (size_t)w;
     }
     return NULL;
@@ -141,19 +144,31 @@ int qvz_prealloc_start(FILE *f, uint64_t bytes) {
     if (fd2 < 0) return 0;
     prealloc_t *p = (prealloc_t *)calloc(1, sizeof(*p));
     const long page = sysconf(_SC_PAGESIZE);
-    if (!p || page <= 0 || ((uint64_t)st.st_size < (uint64_t)base + bytes && ftruncate(fd2, (off_t)((uint64_t)base + bytes)))) { free(p); close(fd2); return 0; }
+    if (!p || page <= 0) { free(p); close(fd2); return 0; }
+    /* the file is made long enough for the mapping; whatever fails from here on gives it its old length back (`bytes` may be an
+     * estimate above the real size - the shard set's streams -, and nobody would shrink the file again: qvz_prealloc_finish
+     * finds no entry for it) */
+    const int grown = (uint64_t)st.st_size < (uint64_t)base + bytes;
+    if (grown && ftruncate(fd2, (off_t)((uint64_t)base + bytes))) { free(p); close(fd2); return 0; }
     p->fd = fd; p->fd2 = fd2; p->base = base; p->bytes = bytes;
-    p->sized_at = (uint64_t)st.st_size < (uint64_t)base + bytes ? (int64_t)((uint64_t)base + bytes) : -1;
+    p->sized_at = grown ? (int64_t)((uint64_t)base + bytes) : -1;
     p->base_page = base - base % page;
     p->map_len = (size_t)((uint64_t)(base - p->base_page) + bytes);
     p->map = (uint8_t *)mmap(NULL, p->map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd2, (off_t)p->base_page);
-    if (p->map == MAP_FAILED) { free(p); close(fd2); return 0; }
     int slot = -1;
-    pthread_mutex_lock(&g_pre_mu);
-    for (int i = 0; i < 8 && slot < 0; ++i) if (!g_pre[i]) slot = i;
-    if (slot >= 0 && pthread_create(&p->th, NULL, prealloc_main, p) == 0) g_pre[slot] = p; else slot = -1;
-    pthread_mutex_unlock(&g_pre_mu);
-    if (slot < 0) { munmap(p->map, p->map_len); close(fd2); free(p); return 0; }
+    if (p->map != MAP_FAILED) {
+        pthread_mutex_lock(&g_pre_mu);
+        for (int i = 0; i < 8 && slot < 0; ++i) if (!g_pre[i]) slot = i;
+        if (getenv("QVZ_PREALLOC_FAIL")) slot = -1;                            /* tests: the failure path behind the ftruncate */
+        if (slot >= 0 && pthread_create(&p->th, NULL, prealloc_main, p) == 0) g_pre[slot] = p; else slot = -1;
+        pthread_mutex_unlock(&g_pre_mu);
+    }
+    if (slot < 0) {
+        if (p->map != MAP_FAILED) munmap(p->map, p->map_len);
+        if (grown && ftruncate(fd2, st.st_size)) { /* best effort */ }
+        close(fd2); free(p);
+        return 0;
+    }
     return 1;
 }
 

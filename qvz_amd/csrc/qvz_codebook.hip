@@ -698,7 +698,10 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
         O->pad[1] = (uint8_t)(dt > 65535 ? 255 : dt >> 8);
         O->pad[2] = (uint8_t)dt;
         // surely >= target (exact: simply not below it, codebook.c:249-258): the walk ends here or earlier
-        if (I.mode == 1 && S > 1 && (exact ? !(H < I.target) : H - I.target > guard)) atomicMin(stop + ctx, S);
+        // (exact mode: the host asks its libm again when H lies within QVZ_EXACT_BAND of the target - see there -, so a design
+        // that close to it must not tell the larger ones to give up either)
+        // (`guard` is that band then)
+        if (I.mode == 1 && S > 1 && H - I.target > guard) atomicMin(stop + ctx, S);
     }
 }
 
@@ -1032,6 +1035,14 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static thread_local unsigned long long cb_stat[6];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns
 static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
+// exact mode: |entropy - target| at or below this is re-decided by the host's libm (a one-bit miss of the device's log2 restatement
+// moves an entropy of at most ~6.2 bits by a few ulps of 8.9e-16; the band is a thousand times that and is met about once in 1e12 decisions)
+#define QVZ_EXACT_BAND 1e-12   /* QVZ_CB_EXACT_BAND overrides it (tests: a huge band makes the libm re-decide everything) */
+static std::atomic<unsigned long long> g_exact_rechecked{0}, g_exact_mismatch{0};
+extern "C" void qvz_hip_codebook_exact_recheck_counts(unsigned long long *rechecked, unsigned long long *mismatched) {
+    if (rechecked) *rechecked = g_exact_rechecked.load();
+    if (mismatched) *mismatched = g_exact_mismatch.load();
+}
 static std::atomic<int> g_cb_active{0};   // qvz_hip_generate_codebook calls in flight (one per cluster when a caller runs them concurrently)
 // ---- is the device's restatement of glibc's log2 THIS host's log2? ---------------------------------------------------------
 // The exact path (device entropies decide, the host calls libm no more) is taken only after the device function has agreed
@@ -1049,11 +1060,31 @@ struct Log2Check {
     std::mutex mu;
     std::condition_variable cv;
     int state = 0;          // 0 not started, 1 running, 2 verified, 3 differs / could not run
+    std::thread th;         // the checking thread: joined before the process leaves (log2_join_all)
 };
-// one per device ordinal, made on first use and never destroyed: the checking thread is detached (a process may end, or
-// never generate a codebook, while it runs) and must not find its mutex gone
+// one per device ordinal, made on first use and never destroyed. A process may end, or never generate a codebook, while the
+// check runs (bad input refused during the upload, a Python process that only builds the backend): exit() must not reach the
+// HIP runtime's teardown with that thread still inside hipMalloc or a kernel launch, so the thread is joinable and an atexit
+// hook - registered after the runtime's own, hence run before it - and the library's destructor wait for it (~15 ms at worst).
 static std::mutex g_log2_mu;
 static Log2Check *g_log2[64];
+static void log2_join_all() {
+    for (int dev = 0; dev < 64; ++dev) {
+        Log2Check *L;
+        {
+            std::lock_guard<std::mutex> g(g_log2_mu);
+            L = g_log2[dev];
+        }
+        if (!L) continue;
+        std::thread t;
+        {
+            std::lock_guard<std::mutex> lk(L->mu);
+            t.swap(L->th);
+        }
+        if (t.joinable()) t.join();
+    }
+}
+__attribute__((destructor)) static void log2_join_at_unload() { log2_join_all(); }
 
 static void log2_selftest_run(int dev, Log2Check *L) {
     const uint32_t M = 1u << 20;
@@ -1114,8 +1145,10 @@ static Log2Check *log2_check_start() {
     }
     std::lock_guard<std::mutex> lk(L->mu);
     if (L->state == 0) {
+        static std::once_flag hook;
+        std::call_once(hook, [] { atexit(log2_join_all); });
         L->state = 1;
-        std::thread(log2_selftest_run, dev, L).detach();
+        L->th = std::thread(log2_selftest_run, dev, L);
     }
     return L;
 }
@@ -1331,6 +1364,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     // libm; then the targets and every `entropy < target` come from the device and the host calls libm no more. Otherwise
     // the device values only steer and the host's libm decides inside the guard band, as before.
     const bool exact = log2_exact_on_this_device();
+    if (exact) guard = getenv("QVZ_CB_EXACT_BAND") ? atof(getenv("QVZ_CB_EXACT_BAND")) : QVZ_EXACT_BAND;   // the band inside which the host's libm is asked again
     const bool cb_debug = getenv("QVZ_CB_DEBUG") != nullptr;
     const bool spin = !getenv("QVZ_CB_SYNC");                           // development knob: wait with hipStreamSynchronize instead
     // Waits for hand-over number `seq`, raised by a k_cb_flag (flag_after): everything enqueued before it has run and its
@@ -1503,7 +1537,18 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                         return qvz_set_error(QVZ_E_HIP, "column %u context %u: design %u missing", s, j, hin[j].startS + w);
                     const double diff = d[w].hdev - target[j];
                     bool below;
-                    if (exact) below = d[w].hdev < target[j];                       // hdev is get_entropy(d[w].o): codebook.c:249-258 as it stands
+                    if (exact && fabs(diff) <= guard) {
+                        // The run-time check of the device's log2 is a sample: it catches another libm, it cannot prove equality
+                        // on the arguments this very pmf produces. A single differing bit in one term moves an entropy by a few
+                        // ulps (~1e-15), so a decision this close to its target - one in ~1e12 - is taken by the host's libm,
+                        // target included, and a miss cannot flip it.
+                        g_exact_rechecked += 1;
+                        const double t_libm = mode == QVZ_MODE_RATIO && s > 0 ? entropy_libm(hx + (size_t)j * A) * opt_ratio : target[j];
+                        const double h_libm = entropy_libm(d[w].o);
+                        if (memcmp(&t_libm, &target[j], sizeof(double)) != 0 || memcmp(&h_libm, &d[w].hdev, sizeof(double)) != 0) g_exact_mismatch += 1;
+                        below = h_libm < t_libm;
+                    }
+                    else if (exact) below = d[w].hdev < target[j];                  // hdev is get_entropy(d[w].o): codebook.c:249-258 as it stands
                     else if (fabs(diff) <= guard) { g_deferred += 1; below = entropy_libm(d[w].o) < target[j]; }
                     else below = diff < 0.0;
                     if (!below || d[w].S >= A) { done = true; break; }

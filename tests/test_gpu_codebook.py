@@ -96,6 +96,19 @@ def test_device_entropies_decide_like_the_hosts_libm(K, name, monkeypatch):
         monkeypatch.delenv("QVZ_CB_FLOW")
         assert deferred == 0
         assert_same_codebook(b, a)                                # ratio bits included
+        # (2b) the band inside which the host's libm re-decides (1e-12 by default: about one decision in 1e12) made huge: every
+        # decision goes through the re-check, the libm's targets and entropies must equal the device's bit for bit, same book
+        import ctypes
+        r0, m0 = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        lib().qvz_hip_codebook_exact_recheck_counts(ctypes.byref(r0), ctypes.byref(m0))
+        monkeypatch.setenv("QVZ_CB_EXACT_BAND", "1e30")
+        e, deferred = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
+        monkeypatch.delenv("QVZ_CB_EXACT_BAND")
+        r1, m1 = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        lib().qvz_hip_codebook_exact_recheck_counts(ctypes.byref(r1), ctypes.byref(m1))
+        assert_same_codebook(e, a)
+        assert m1.value == m0.value, "the host's libm disagrees with the device's entropies by a bit"
+        assert r1.value >= r0.value                               # (a book whose every context is dead takes no decision at all)
         # (3) ... and with the host's libm taking every decision (what runs when the check fails)
         monkeypatch.setenv("QVZ_CB_LOG2", "host")
         c_, _ = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
