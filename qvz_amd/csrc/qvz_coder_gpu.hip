@@ -495,6 +495,42 @@ __device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint3
     return make_double2((double)cum_lo * rn, (double)(n - cum_lo - fx) * rn);
 }
 
+// ---- packed records (round 4): the integer triple in 8 bytes, the division on the coder's side ------------------------------
+// What the model knows about a symbol is three integers below 2^21 (n <= 2^19 + 8 * 64: a table passes the rescale threshold
+// inside a chunk at most; cum_lo < n; n - cum_hi <= n): cum_lo in bits [0, 21), n - cum_hi in [21, 42), n in [42, 63); the
+// all-zero word codes nothing. The model kernel then spends 7 integer instructions per symbol on its record instead of a
+// reciprocal, two Newton steps, three conversions and two products in FP64, its transposition buffer and its stores halve, and
+// so does the record traffic in both directions. The two quotients are made where they are
+// consumed: by the two loader waves of k_code_records<true>, which share a SIMD of their own - throughput work with eight
+// independent records per block - so that nothing is added to the interval wave's chain. Same quotients to within 2^-52
+// relative (v_rcp_f64 + two Newton steps on n * 2^10, which is exact in a double), the bound Record's proof needs is 2^-47.
+typedef unsigned long long PRec;
+__device__ __forceinline__ PRec pack_record(uint32_t n, uint32_t cum_lo, uint32_t fx) {
+    const uint32_t nc = n - cum_lo - fx;
+    const uint32_t lo = cum_lo | (nc << 21), hi = (nc >> 11) | (n << 10);
+    return ((PRec)hi << 32) | lo;
+}
+__device__ __forceinline__ Record unpack_record(uint32_t lo, uint32_t hi) {
+    const uint32_t cum = lo & 0x1FFFFFu;
+    const uint32_t nc = __builtin_amdgcn_alignbit(hi, lo, 21) & 0x1FFFFFu;
+    uint32_t n10 = hi & 0xFFFFFC00u;                             // n * 2^10 (bit 63 of a record is zero)
+    n10 = n10 ? n10 : 1u;                                        // the no-op record: 0 / 1 twice
+    const double nd = (double)n10;
+    double rn = __builtin_amdgcn_rcp(nd);
+    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
+    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
+    return make_double2((double)cum * rn, (double)nc * rn);
+}
+// Packed-record area of one segment: units of 4 reads x 4 columns (16 records, 128 bytes: [read & 3][column & 3]), the 64
+// streams' units of the same (read quad, column group) side by side - a model workgroup (4 adjacent columns, 64 consecutive
+// reads) still writes whole 128-byte lines, and a lane of the coder finds the 8 symbols of a block as two 32-byte pieces of
+// two neighbouring units. Record (row, col) of stream g is at
+//   (((g / 64) * nunit + (row / 4) * (Cp / 4) + col / 4) * 64 + g % 64) * 16 + (row % 4) * 4 + col % 4,  nunit = seg_reads * Cp / 16.
+__device__ __forceinline__ uint64_t rec8_index(uint32_t g, uint64_t row, uint32_t col, uint32_t Cp, uint64_t nunit) {
+    return (((uint64_t)(g >> 6) * nunit + (row >> 2) * (Cp >> 2) + (col >> 2)) * 64 + (g & 63)) * 16 + (row & 3) * 4 + (col & 3);
+}
+#define RK_STORE8(ptr, val) __builtin_nontemporal_store((PRec)(val), reinterpret_cast<PRec *>(ptr))
+
 // The record for the HOST's interval chain (strict single-stream mode, qvz_coder_encode_records): two 64-bit integers in
 // the record's 16 bytes, X(c) = floor(2^62 * c / n) + 1 for c = cum_lo and c = cum_hi. With rd = (u - l + 1) * 1024 <= 2^32
 //     floor((u - l + 1) * c / n) = (rd * X(c)) >> 72                                                  (arith.c:47-48)
@@ -528,7 +564,7 @@ __device__ __forceinline__ uint64_t rec_index(uint32_t g, uint64_t row, uint32_t
     return (((uint64_t)(g >> 6) * nblk8 + (row >> 1) * (Cp >> 2) + (col >> 2)) * 64 + (g & 63)) * 8 + (row & 1) * 4 + (col & 3);
 }
 
-template <bool HAVE_LABELS>
+template <bool HAVE_LABELS, bool REC8>
 __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                        const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
                                                        const uint64_t *__restrict__ first, uint32_t shards,
@@ -546,7 +582,8 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
     const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
     uint32_t *ar = arena + (uint64_t)g * arena_words;
     const uint32_t Cp = (Cx + 7) & ~7u;
-    const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;
+    const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8, nunit = (uint64_t)seg_reads * Cp / 16;
+    PRec *const rec8 = reinterpret_cast<PRec *>(rec);
     const bool cluster_lane = HAVE_LABELS && sx == 0;
     const uint32_t s = HAVE_LABELS ? sx - 1 : sx;
     bool bad = false;
@@ -573,6 +610,7 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                 o = q < 2 * A ? off[((uint64_t)cl * C + s) * 2 * A + q] : NO_TABLE;
             }
             Record w = make_double2(0.0, 0.0);                   // nothing to code (bad feed, reported below)
+            PRec w8 = 0;
             if (o == NO_TABLE) {
                 bad = true;
             } else {
@@ -607,8 +645,16 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                         }
                     }
                     t[0] = nn;
-                    w = make_record(n, cum_lo, fx);
+                    if (REC8) w8 = pack_record(n, cum_lo, fx); else w = make_record(n, cum_lo, fx);
                 }
+            }
+            if (REC8) {
+                rec8[rec8_index(g, r + j - r0, pos, Cp, nunit)] = w8;
+                if (cluster_lane)                                // the reserved positions behind the cluster id
+                    for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = 0;
+                if (sx + 1 == Cw)                                // the read's pad records
+                    for (uint32_t pc = Cx; pc < Cp; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = 0;
+                continue;
             }
             rec[rec_index(g, r + j - r0, pos, Cp, nblk8)] = w;
             if (cluster_lane)                                    // the reserved positions behind the cluster id
@@ -657,6 +703,7 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 #ifdef QVZ_PROFILE          // development build (make HIPFLAGS+=-DQVZ_PROFILE): shader-clock cycles per section of the chunk loop, summed over waves
 __device__ unsigned long long g_rk_prof[8];
 __device__ unsigned long long g_cr_prof[16];
+__device__ uint32_t g_cr_simd[8];   // SIMD of every wave of one k_code_records workgroup (HW_ID bits 5:4)
 __device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no record store, 2 no transposition/barriers, 4 no cumulative loop, 8 no table update, 16 no timers
 #define RK_T(i) do { if (!(exp_ & 16)) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
 #define RK_EXP(bit) if (!(exp_ & (bit)))
@@ -736,7 +783,7 @@ __global__ __launch_bounds__(256) void k_cluster_segpos(const uint32_t *__restri
 // number of waves a CU holds, is that of the one-cluster case - and every lane of a chunk has a symbol. The workgroups
 // of the reserved positions (cluster z = 0 only) take the reads in file order: the cluster id of every read is a symbol
 // of its own table (qv_compressor.c:86), the other reserved positions are zero records.
-template <bool HAVE_LABELS, bool DENSE>
+template <bool HAVE_LABELS, bool DENSE, bool REC8>
 __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                       const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
                                                       const uint64_t *__restrict__ first, const uint32_t *__restrict__ coff,
@@ -748,7 +795,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                                                       const uint32_t *__restrict__ segpos_lo, const uint32_t *__restrict__ segpos_hi) {
     // records between consecutive units of a stream: 512 = 8 records x 64 interleaved streams (rec_index, the coder
     // kernel's layout); DENSE: one stream alone, its units back to back (qvz_hip_model_session_records)
-    constexpr uint32_t unit_recs = DENSE ? 8u : 512u;
+    // REC8: packed 8-byte records, units of 16 (rec8_index): 1024 records between consecutive units of a stream
+    static_assert(!(DENSE && REC8), "the host's chain takes 16-byte fixed-point records");
+    constexpr uint32_t unit_recs = DENSE ? 8u : REC8 ? 1024u : 512u;
     extern __shared__ uint4 rk_smem[];
     // the wave index is wave-uniform, which the compiler cannot see: readfirstlane keeps everything derived from it
     // (column, table slice, activity) in scalar registers and its tests in scalar branches
@@ -772,7 +821,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     const bool lists = HAVE_LABELS && cg * W >= QVZ_CID_SLOTS;   // this workgroup walks cluster z's reads
     if (HAVE_LABELS && !lists && z) return;                      // the reserved positions belong to the z = 0 workgroups
     const uint32_t Cp = (Cx + 7) & ~7u;
-    const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;
+    const uint64_t nblk8 = REC8 ? (uint64_t)seg_reads * Cp / 16 : (uint64_t)seg_reads * Cp / 8;   // units of a stream in the segment
     auto uniform64 = [](uint64_t v) -> uint64_t {               // same value in every lane: keep it in scalar registers
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     };
@@ -788,13 +837,21 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
     const uint32_t rb_stride = W + 1;                            // +1: conflict-free transposition
     Record *recbuf = reinterpret_cast<Record *>(rk_smem);        // [64][W + 1]
+    // REC8: the transposition buffer holds packed records, [64][W + 1] of 8 bytes (the odd stride keeps the 8-byte accesses
+    // of 32 lanes on 64 different banks), and the list rows below have 1 KB of their own behind it - 2.5 + 1 KB where the
+    // 16-byte records take 5
+    PRec *recbuf8 = reinterpret_cast<PRec *>(rk_smem);
+    uint32_t *rows8 = reinterpret_cast<uint32_t *>(recbuf8 + 64 * rb_stride);   // [64][4], several clusters only
     // lists: the segment rows of the reads of a block of four chunks live in the padding record of the read's row of
     // recbuf (16 bytes = four row numbers per lane): no LDS of their own - with three clusters on 100M x 150 that is what
     // lets a third workgroup fit a CU
-    auto rowslot = [&](uint32_t rd, uint32_t j) -> uint32_t * { return reinterpret_cast<uint32_t *>(recbuf + rd * rb_stride + W) + j; };
+    auto rowslot = [&](uint32_t rd, uint32_t j) -> uint32_t * {
+        return REC8 ? rows8 + rd * 4 + j : reinterpret_cast<uint32_t *>(recbuf + rd * rb_stride + W) + j;
+    };
     // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, and per quantizer of the column its table's
     // offset in the slice | alphabet size << 16 (RK_NONE, size 0: no table), so that one LDS read resolves a symbol
-    unsigned long long *msk = reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride) + (size_t)wave * ((3 * slice_cap + 2 * A) / 2);
+    unsigned long long *msk = (REC8 ? reinterpret_cast<unsigned long long *>(rows8 + (HAVE_LABELS ? 256 : 0))
+                                    : reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride)) + (size_t)wave * ((3 * slice_cap + 2 * A) / 2);
     uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
     uint32_t *cof = tab + slice_cap;
     const bool cluster_wave = HAVE_LABELS && sx == 0;
@@ -815,6 +872,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
 
     Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index; g = 0 when unit_recs = 8)
+    PRec *const rec8_g = reinterpret_cast<PRec *>(rec) + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 16;   // REC8: the same by rec8_index
     bool bad = false;
     uint32_t chunk = 0;
     // Input: every lane loads the bytes of its own read for the next four chunks (a wave instruction = 64 contiguous bytes
@@ -951,6 +1009,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
 #endif
     for (uint32_t rb = 0; rb < nr; rb += 64, ++chunk) {       // rb = read offset in the segment
         Record outr = make_double2(0.0, 0.0);
+        PRec outp = 0;
         const uint32_t tb = tb_nx, x = x_lk, card = card_nx;
         const bool ok = ok_nx;
         // where in the segment the reads of this block of four chunks lie. Everybody has drained the chunk before the last
@@ -1056,7 +1115,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                     if (lane == 0) tab[t] = nn;
                 }
             }
-            {
+            if (REC8) {
+                outp = ok ? pack_record(n, cum_lo, fx) : 0ull;   // (ok: n >= the alphabet size >= 1)
+            } else {
                 const Record rr = DENSE ? make_record_fixed(n ? n : 1u, cum_lo, fx) : make_record(n ? n : 1u, cum_lo, fx);
                 outr = make_double2(ok ? rr.x : 0.0, ok ? rr.y : 0.0);
             }
@@ -1066,7 +1127,8 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         RK_EXP(2)
         __syncthreads();                                         // the previous chunk has been drained
         RK_T(3);
-        buf[lane * rb_stride + wave] = outr;
+        if (REC8) recbuf8[lane * rb_stride + wave] = outp;
+        else buf[lane * rb_stride + wave] = outr;
         if (new_rows) *rowslot(lane, 3) = r_cur[3] - (uint32_t)seg_lo;
         RK_EXP(2)
         __syncthreads();
@@ -1078,9 +1140,12 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             // The input bytes of chunks c+2 .. c+5 are taken over here (and the following four requested): the wait for
             // them also waits for every store issued so far, and at this point the latest one is a whole chunk old.
             if (((chunk + 2) & 3) == 0) park(rb + 128);
-            if (rb + rd < nr && col < Cp)                        // columns Cx .. Cp-1 belong to idle waves: zero records
-                RK_EXP(1)
-                RK_STORE(&rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 1) * 4 + (col & 3)], buf[rd * rb_stride + cw]);
+            if (rb + rd < nr && col < Cp) {                      // columns Cx .. Cp-1 belong to idle waves: zero records
+                RK_EXP(1) {
+                if (REC8) RK_STORE8(&rec8_g[((uint64_t)(row >> 2) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 3) * 4 + (col & 3)], recbuf8[rd * rb_stride + cw]);
+                else RK_STORE(&rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 1) * 4 + (col & 3)], buf[rd * rb_stride + cw]);
+                }
+            }
         }
         RK_T(5);
     }
@@ -1122,7 +1187,13 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
 #define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps 31.5 KB of LDS so that it fits beside the model kernel's workgroups: 3 x 42.5 KB + 32.5 KB is exactly a CU's 160 KB at 100M x 150, -f 0.5)
 static_assert(CR_B == 8, "the record layout (rec_index) has 8 records per lane and block");
 #define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
-__global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
+// REC8 (round 4): the records come packed (PRec, rec8_index) and a FIFTH wave joins: waves 0 and 4 - which a round-robin
+// placement of the workgroup's waves puts on one SIMD - are two loaders that each take half of every block (symbols 0-3 /
+// 4-7: the 32-byte piece of one unit per lane), turn the integer triples into the two quotients (unpack_record) and park them
+// in the ring; waves 1, 2, 3 are interval, bits, bytes as before. The loaders are throughput work (eight independent
+// records per block and lane); the three chain waves keep a SIMD each.
+template <bool REC8>
+__global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
                                                       uint64_t *__restrict__ sizes, int32_t *__restrict__ status, int high_prio) {
@@ -1131,11 +1202,17 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     __shared__ uint32_t ebits[2][CR_B][64];                      // value (16 bits) | bit count << 16, or CR_RARE | pending run
     __shared__ uint32_t final_l[64], final_s3[64];
     __shared__ uint4 oring[64 * 5];                              // the bytes wave's output ring: 16 words per lane, 80-byte stride
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t hw_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // role: 0 interval, 1 bits, 2 bytes, 3 loader (REC8: of symbols 0-3), 4 (REC8 only) loader of symbols 4-7
+    const uint32_t wave = !REC8 ? hw_wave : hw_wave == 0 ? 3u : hw_wave == 4 ? 4u : hw_wave - 1;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read (rec_index)
-    if (high_prio) asm volatile("s_setprio 3");                  // all four waves of the latency chain issue ahead of the throughput kernels sharing the CU
+    if (high_prio) {
+        // all waves of the latency chain issue ahead of the throughput kernels sharing the CU; REC8: the two loaders, which are
+        // throughput work themselves, one step below the three chain waves
+        if (REC8 && wave >= 3) asm volatile("s_setprio 2"); else asm volatile("s_setprio 3");
+    }
     uint64_t T = 0;
     if (live) {
         const uint64_t rend = first[g + 1], a = first[g] + seg_lo, b = a + seg_reads;
@@ -1154,9 +1231,11 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
 #define CR_BARRIER() do { const unsigned long long a_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                           const unsigned long long m_ = __builtin_readcyclecounter(); asm volatile("s_barrier" ::: "memory"); \
                           const unsigned long long b_ = __builtin_readcyclecounter(); cr_busy += a_ - cr_t; cr_wait += b_ - a_; cr_drain += m_ - a_; cr_t = b_; } while (0)
-#define CR_REPORT() do { if (lane == 0 && (blockIdx.x & 15) == 3) { atomicAdd(&g_cr_prof[wave * 2], cr_busy); atomicAdd(&g_cr_prof[wave * 2 + 1], cr_wait); \
+#define CR_REPORT() do { if (lane == 0 && (blockIdx.x & 15) == 3 && wave < 4) { atomicAdd(&g_cr_prof[wave * 2], cr_busy); atomicAdd(&g_cr_prof[wave * 2 + 1], cr_wait); \
                                                                     atomicAdd(&g_cr_prof[9 + wave], cr_drain); \
-                                                                    if (wave == 0) atomicAdd(&g_cr_prof[8], (unsigned long long)nblk); } } while (0)
+                                                                    if (wave == 0) atomicAdd(&g_cr_prof[8], (unsigned long long)nblk); } \
+                         if (lane == 0 && (blockIdx.x & 15) == 3 && wave == 4) { atomicAdd(&g_cr_prof[13], cr_busy); atomicAdd(&g_cr_prof[14], cr_wait); } \
+                         if (lane == 0 && (blockIdx.x & 15) == 3) { uint32_t hwid_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_)); g_cr_simd[hw_wave] = (hwid_ >> 4) & 3; } } while (0)
 #else
 #define CR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define CR_REPORT() do { } while (0)
@@ -1169,7 +1248,79 @@ __global__ __launch_bounds__(256) void k_code_records(const Record *__restrict__
     // 110 ms) and beside the model kernel (223 against 139): a hand-over costs a write's and a read's LDS latency plus the
     // poll's sleep where the barrier costs tens of cycles, and the polling waves take LDS slots from the one that works.)
 
-    if (wave == 3) {
+    if (REC8 && wave >= 3) {
+        // ------------------------------------ the two loaders of packed records ------------------------------------
+        const uint32_t half = wave - 3;                          // symbols 4 * half .. 4 * half + 3 of every block
+        const uint64_t nunit = (uint64_t)seg_reads * Cp / 16;    // units of 16 records in a stream's area
+        const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // blocks of the area (what a lane can load)
+        const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const PRec *>(rec) + ((uint64_t)blockIdx.x * nunit * 64 + lane) * 16);   // the lane's slot of unit 0 (rec8_index), 8 uint4 per unit
+        const uint64_t nfull = Tmin / CR_B;                      // blocks that are whole in every lane: no padding test
+        // block b of a lane = columns 8m .. 8m+7 of read `row` (b = row * Cp/8 + m): this wave's four are the quarter
+        // [row & 3] of unit (row / 4, 2m + half): 32 bytes. A register stage holds LD_B blocks' pieces; three stages in
+        // rotation keep two of them in flight. Past the last block the last one is loaded again (unconditional loads keep
+        // vmcnt countable).
+        constexpr int LD_B = 2;
+        uint64_t l_blk = 0;
+        uint32_t l_row = 0, l_m = 0;
+        auto load_stage = [&](uint4 *d) {
+#pragma unroll
+            for (int k = 0; k < LD_B; ++k) {
+                const uint64_t at = (((uint64_t)(l_row >> 2) * (Cp >> 2) + 2 * l_m + half) * 64 * 8) + (l_row & 3) * 2;   // in uint4: a unit is 8, the 64 streams' units lie side by side
+                d[k * 2] = p[at];
+                d[k * 2 + 1] = p[at + 1];
+                if (l_blk + 1 < nblk8) {
+                    ++l_blk;
+                    if (++l_m == (Cp >> 3)) { l_m = 0; ++l_row; }
+                }
+            }
+        };
+        auto park = [&](uint64_t b, const uint4 *d) {            // this wave's half of block b -> slot b & 1, then barrier b
+            const uint32_t slot = (uint32_t)(b & 1);
+            Record r4[4];
+            r4[0] = unpack_record(d[0].x, d[0].y);
+            r4[1] = unpack_record(d[0].z, d[0].w);
+            r4[2] = unpack_record(d[1].x, d[1].y);
+            r4[3] = unpack_record(d[1].z, d[1].w);
+            if (b < nfull) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ring[slot][half * 4 + i][lane] = r4[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool pad = b * CR_B + half * 4 + i >= T;   // beyond this lane's symbols: the no-op record
+                    ring[slot][half * 4 + i][lane] = make_double2(pad ? 0.0 : r4[i].x, pad ? 0.0 : r4[i].y);
+                }
+            }
+            CR_BARRIER();
+        };
+        auto park_stage = [&](uint64_t stg, const uint4 *d) -> bool {   // false: that was the last block
+#pragma unroll
+            for (int k = 0; k < LD_B; ++k) {
+                const uint64_t b = stg * LD_B + k;
+                if (b >= nblk) return false;
+                park(b, d + k * 2);
+            }
+            return (stg + 1) * LD_B < nblk;
+        };
+        uint4 s0[LD_B * 2], s1[LD_B * 2], s2[LD_B * 2];
+        load_stage(s0);
+        load_stage(s1);
+        for (uint64_t t = 0; t * LD_B < nblk; t += 3) {
+            load_stage(s2);
+            if (!park_stage(t, s0)) break;
+            load_stage(s0);
+            if (!park_stage(t + 1, s1)) break;
+            load_stage(s1);
+            if (!park_stage(t + 2, s2)) break;
+        }
+        CR_BARRIER();                                            // barriers nblk and nblk + 1: the other waves run behind
+        CR_BARRIER();
+        if (is_last) CR_BARRIER();
+        CR_REPORT();
+        return;
+    }
+
+    if (!REC8 && wave == 3) {
         // ------------------------------------ loader ------------------------------------
         const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // blocks of 8 records in a stream's area
         const Record *p = rec + ((uint64_t)blockIdx.x * nblk8 * 64 + lane) * 8;   // the lane's slot of unit 0 (rec_index)
@@ -1555,6 +1706,7 @@ extern "C" void qvz_hip_encode_planes_release(void) {
 // Bytes of record workspace that let qvz_hip_encode_planes code streams of up to `longest_reads` reads in one segment
 // (16 bytes per record, streams padded to 64, record positions per read padded to 8). A caller that
 // allocates the workspace itself - early, beside other work - asks this, caps it (96 GiB, what is free) and passes it in.
+// (Sized for 16-byte records whichever kind a call uses: packed ones need half.)
 extern "C" uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards) {
     const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);
     const uint32_t Cp = (Cx + 7) & ~7u;
@@ -1690,7 +1842,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     int32_t status = 0;
     const size_t offn = (size_t)clusters * columns * 2 * A;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read incl. pad, streams padded to 64 (rec_index)
-    const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(Record);  // record bytes for one read of every stream
+    // packed 8-byte records (the division on the coder's side) unless QVZ_CODER_RECORDS=16 asks for
+    // the pairs of doubles of rounds 1-3 (development knob: the tests run both, the streams are the same bytes)
+    const bool rec8 = !(getenv("QVZ_CODER_RECORDS") && atoi(getenv("QVZ_CODER_RECORDS")) == 16);
+    const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * (rec8 ? sizeof(PRec) : sizeof(Record));  // record bytes for one read of every stream
     uint64_t seg_reads = 0, seg_lo = 0;
 
     // Slices for k_model_ranks: the tables of one (column, cluster) packed back to back, coff[slice][quantizer] = word
@@ -1743,7 +1898,9 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
             // beside k_code_records' 32 KB of LDS (measured with three clusters, where LDS holds one such workgroup
             // per CU: W = 4 0.40 s, W = 2 0.42 s, W = 1 0.67 s for the model kernels; W = 8 never paid).
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
-            auto need_of = [&](uint32_t w) { return (size_t)64 * (w + 1) * sizeof(Record) + (size_t)w * (3 * slice_cap + 2 * A) * 4; };   // records (list rows in their padding), per wave masks + tables + offsets
+            auto need_of = [&](uint32_t w) {                     // records (16 bytes: list rows in their padding; packed: 1 KB of their own), per wave masks + tables + offsets
+                return (rec8 ? (size_t)64 * (w + 1) * sizeof(PRec) + (clusters > 1 ? 1024u : 0u) : (size_t)64 * (w + 1) * sizeof(Record)) + (size_t)w * (3 * slice_cap + 2 * A) * 4;
+            };
             const size_t budget = 160 * 1024 - 32 * 1024;
             const uint32_t order[3] = {4, 2, 1};
             for (uint32_t w : order) {
@@ -1752,6 +1909,12 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
                 rk_waves = w; rk_lds = need;
                 break;
             }
+            // Packed records shrank the transposition buffer, and at 100M x 150 -f 0.5 a FOURTH workgroup then fits a CU (4 x 40.4 KB):
+            // the model kernel gains (110 against 122 ms busy) but fills every CU to the brim the moment it starts, and the coder
+            // kernel of the segment before - released across queues at the same moment - finds room late or not at all from step
+            // to step (coder phase 138 .. 190 ms, steps of 185 .. 236 ms; a 1.5 ms head start for the coder cures it as well).
+            // Three to a CU is steady: 182.0-183.0 ms per step. So a fourth is kept out by asking for a little more than a quarter.
+            if (rk_waves && rk_lds * 4 <= (size_t)160 * 1024 && !getenv("QVZ_MODEL_LDS_PAD")) rk_lds = (size_t)160 * 1024 / 4 + 512;
             if (getenv("QVZ_MODEL_LDS_PAD")) rk_lds += (size_t)atoi(getenv("QVZ_MODEL_LDS_PAD"));   // development knob: occupancy experiments
             if (we) {
                 const uint32_t w = (uint32_t)atoi(we);
@@ -1809,8 +1972,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     }
 #endif
     if (getenv("QVZ_CODER_DEBUG"))
-        fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu\n",
-                shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size());
+        fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu, %d-byte records\n",
+                shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size(), rec8 ? 8 : 16);
     TRY(area.get((void **)&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
     TRY(area.get((void **)&d_status, sizeof(int32_t)));
@@ -1825,8 +1988,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipMemcpyAsync(d_slices, h_slices.data(), h_slices.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_colbase, h_colbase.data(), h_colbase.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_coff, h_coff.data(), h_coff.size() * 4, hipMemcpyHostToDevice, st));
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     } else {                                                     // lane-per-column kernel with per-stream arenas in HBM
         TRY(area.get((void **)&d_tmpl, (size_t)words * 4));
         TRY(area.get((void **)&d_off, offn * 4));
@@ -1910,12 +2075,12 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     // dispatch and costs 30 ms).
     if (overlap && rk_waves) {
         hipFuncAttributes fa;
-        TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_code_records)));
+        TRY(hipFuncGetAttributes(&fa, rec8 ? reinterpret_cast<const void *>(&k_code_records<true>) : reinterpret_cast<const void *>(&k_code_records<false>)));
         const size_t lds_cu = 160 * 1024, beside = (lds_cu - fa.sharedSizeBytes) / rk_lds;
         if (beside >= 3) cr_pad = ((lds_cu - fa.sharedSizeBytes - beside * rk_lds) + 1024) & ~(size_t)255;
     }
     if (getenv("QVZ_CODER_LDS_PAD")) cr_pad = (size_t)atoi(getenv("QVZ_CODER_LDS_PAD"));   // development knob
-    if (cr_pad) TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_code_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
+    if (cr_pad) TRY(hipFuncSetAttribute(rec8 ? reinterpret_cast<const void *>(&k_code_records<true>) : reinterpret_cast<const void *>(&k_code_records<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
     if (dry) {                                                   // qvz_hip_encode_planes_prepare: everything is in place for the call that codes
         TRY(hipStreamSynchronize(st));
         goto done;
@@ -1945,28 +2110,30 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (rk_waves) {
             const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves, clusters), block(64 * rk_waves);   // z: the cluster a workgroup of column positions serves
             const size_t SK = (size_t)shards * clusters;
-            if (clusters > 1)
-                hipLaunchKernelGGL((k_model_ranks<true, false>), grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
-                                   d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status,
-                                   (const uint32_t *)d_clist, (const uint64_t *)d_cstart, (const uint32_t *)(d_segpos + (size_t)i * SK),
-                                   (const uint32_t *)(d_segpos + (size_t)(i + 1) * SK));
-            else
-                hipLaunchKernelGGL((k_model_ranks<false, false>), grid, block, rk_lds, s_model, d_qi, d_st, ld, d_labels, columns, clusters, d_first,
-                                   d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo,
-                                   seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status,
-                                   (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-        } else if (clusters > 1)
-            hipLaunchKernelGGL(k_model_columns<true>, dim3(mblocks), dim3(256), 0, s_model, d_qi, d_st, ld, d_labels, columns, clusters,
-                               d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status);
-        else
-            hipLaunchKernelGGL(k_model_columns<false>, dim3(mblocks), dim3(256), 0, s_model, d_qi, d_st, ld, d_labels, columns, clusters,
-                               d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status);
+#define RK_ARGS(LISTS) d_qi, d_st, ld, d_labels, columns, clusters, d_first, d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo, \
+                       seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status, \
+                       (const uint32_t *)(LISTS ? d_clist : nullptr), (const uint64_t *)(LISTS ? d_cstart : nullptr), \
+                       (const uint32_t *)(LISTS ? d_segpos + (size_t)i * SK : nullptr), (const uint32_t *)(LISTS ? d_segpos + (size_t)(i + 1) * SK : nullptr)
+            if (clusters > 1 && rec8) hipLaunchKernelGGL((k_model_ranks<true, false, true>), grid, block, rk_lds, s_model, RK_ARGS(true));
+            else if (clusters > 1) hipLaunchKernelGGL((k_model_ranks<true, false, false>), grid, block, rk_lds, s_model, RK_ARGS(true));
+            else if (rec8) hipLaunchKernelGGL((k_model_ranks<false, false, true>), grid, block, rk_lds, s_model, RK_ARGS(false));
+            else hipLaunchKernelGGL((k_model_ranks<false, false, false>), grid, block, rk_lds, s_model, RK_ARGS(false));
+#undef RK_ARGS
+        } else {
+#define MC_ARGS d_qi, d_st, ld, d_labels, columns, clusters, d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status
+            if (clusters > 1 && rec8) hipLaunchKernelGGL((k_model_columns<true, true>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
+            else if (clusters > 1) hipLaunchKernelGGL((k_model_columns<true, false>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
+            else if (rec8) hipLaunchKernelGGL((k_model_columns<false, true>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
+            else hipLaunchKernelGGL((k_model_columns<false, false>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
+#undef MC_ARGS
+        }
         TRY(hipEventRecord(e[1], s_model));
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
-        hipLaunchKernelGGL(k_code_records, dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, (const Record *)buf, Cx, d_first, shards,
-                           seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio);
+        if (rec8) hipLaunchKernelGGL(k_code_records<true>, dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, (const Record *)buf, Cx, d_first, shards,
+                                     seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio);
+        else hipLaunchKernelGGL(k_code_records<false>, dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, (const Record *)buf, Cx, d_first, shards,
+                                seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio);
         TRY(hipEventRecord(e[3], s_coder));
     }
     TRY(hipGetLastError());
@@ -2036,6 +2203,12 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         fprintf(stderr, "k_code_records cycles per block of 8 symbols, busy/waiting: interval %.0f/%.0f  bits %.0f/%.0f  bytes %.0f/%.0f  loader %.0f/%.0f\n",
                 cr[0] / nb, cr[1] / nb, cr[2] / nb, cr[3] / nb, cr[4] / nb, cr[5] / nb, cr[6] / nb, cr[7] / nb);
         fprintf(stderr, "  cycles of that waiting spent in s_waitcnt lgkmcnt(0) before the barrier: interval %.0f  bits %.0f  bytes %.0f  loader %.0f\n", cr[9] / nb, cr[10] / nb, cr[11] / nb, cr[12] / nb);
+        if (rec8) {
+            uint32_t simd[8] = {0};
+            (void)hipMemcpyFromSymbol(simd, HIP_SYMBOL(g_cr_simd), sizeof(simd));
+            fprintf(stderr, "  second loader %.0f/%.0f; SIMD of the workgroup's waves 0..4 (loader, interval, bits, bytes, loader): %u %u %u %u %u\n", cr[13] / nb, cr[14] / nb,
+                    simd[0], simd[1], simd[2], simd[3], simd[4]);
+        }
         fprintf(stderr, "k_model_ranks cycles per wave and chunk: lookup %.0f  ranks %.0f  update+record %.0f  barrier1 %.0f  park+barrier2 %.0f  drain %.0f  (%.3g wave-chunks)\n",
                 z[0] / ch, z[1] / ch, z[2] / ch, z[3] / ch, z[4] / ch, z[5] / ch, ch);
     }
@@ -2155,8 +2328,8 @@ extern "C" int qvz_hip_model_session_open(uint32_t columns, uint32_t clusters, c
         TRY(hipMemset(s->d_status, 0, sizeof(int32_t)));
         TRY(hipMemset(s->d_first, 0, 2 * sizeof(uint64_t)));
         if (clusters > 1) TRY(hipMemcpy(s->d_bounds, bounds, sizeof(bounds), hipMemcpyHostToDevice));
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->rk_lds));
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->rk_lds));
+        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->rk_lds));
     }
 #undef TRY
     if (rc != QVZ_OK) { qvz_hip_model_session_close(s); return rc; }
@@ -2187,13 +2360,13 @@ extern "C" int qvz_hip_model_session_records(qvz_model_session *s, const uint8_t
         hipLaunchKernelGGL(k_cluster_lists, dim3(1), dim3(256), 0, st, d_labels, (const uint64_t *)s->d_first, s->clusters, s->d_clist, s->d_cstart, s->d_status);
         hipLaunchKernelGGL(k_cluster_segpos, dim3((s->clusters * 2 + 255) / 256), dim3(256), 0, st, (const uint32_t *)s->d_clist,
                            (const uint64_t *)s->d_cstart, (const uint64_t *)s->d_first, 1u, s->clusters, (const uint32_t *)s->d_bounds, 2u, s->d_segpos);
-        hipLaunchKernelGGL((k_model_ranks<true, true>), grid, block, s->rk_lds, st, d_qi, d_st, ld, d_labels, s->columns, s->clusters,
+        hipLaunchKernelGGL((k_model_ranks<true, true, false>), grid, block, s->rk_lds, st, d_qi, d_st, ld, d_labels, s->columns, s->clusters,
                            (const uint64_t *)s->d_first, s->d_coff, s->d_colbase, s->d_slices, s->d_save, s->total_words, s->slice_cap,
                            (uint64_t)0, (uint32_t)n, is_first, 0, (uint32_t)__builtin_ctz(s->rk_waves), (Record *)d_rec, s->d_status,
                            (const uint32_t *)s->d_clist, (const uint64_t *)s->d_cstart, (const uint32_t *)s->d_segpos,
                            (const uint32_t *)(s->d_segpos + s->clusters));
     } else {
-        hipLaunchKernelGGL((k_model_ranks<false, true>), grid, block, s->rk_lds, st, d_qi, d_st, ld, d_labels, s->columns, s->clusters,
+        hipLaunchKernelGGL((k_model_ranks<false, true, false>), grid, block, s->rk_lds, st, d_qi, d_st, ld, d_labels, s->columns, s->clusters,
                            (const uint64_t *)s->d_first, s->d_coff, s->d_colbase, s->d_slices, s->d_save, s->total_words, s->slice_cap,
                            (uint64_t)0, (uint32_t)n, is_first, 0, (uint32_t)__builtin_ctz(s->rk_waves), (Record *)d_rec, s->d_status,
                            (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);

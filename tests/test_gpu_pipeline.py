@@ -90,9 +90,11 @@ def test_every_shard_is_reference_decodable(name, shards, threads):
                                          ("rescale_140k_c4", 1), ("rescale_c2_100k_c3", 1), ("rescale_c2_100k_c3", 3),
                                          ("r35_high_rate", 3), ("wide_c151", 2), ("tiny5_r10", 4), ("c2_f08", 70),
                                          ("t2k_c3_f05_M", 130)])
-def test_gpu_coder_streams_equal_host_coder_streams(name, shards):
+def test_gpu_coder_streams_equal_host_coder_streams(name, shards, monkeypatch):
     """The lane-per-shard GPU coder and the host C coder must emit the same bytes for every shard; with one shard
-    that is the reference's own stream."""
+    that is the reference's own stream. Both kinds of record between the model kernel and the interval chain: packed
+    integer triples (8 bytes, the division in the coder workgroup's two loader waves: the default) and the pairs of
+    pre-divided doubles of rounds 1-3 (QVZ_CODER_RECORDS=16)."""
     from qvz_amd import host, pipeline as P
     rows, opts, n, c, sym, means0 = setup_case(name)
     kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=shards, keep=True)
@@ -105,6 +107,11 @@ def test_gpu_coder_streams_equal_host_coder_streams(name, shards):
     small = host.planes_bytes_per_read(shards, c, opts["k"]) * 8
     d = P.encode_pass(sym, n, 0, n, means0, coder="gpu", work_bytes=small, **kw)
     assert d["streams"] == a["streams"], "segmented record workspace changed a stream"
+    monkeypatch.setenv("QVZ_CODER_RECORDS", "16")
+    b16 = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
+    d16 = P.encode_pass(sym, n, 0, n, means0, coder="gpu", work_bytes=small, **kw)
+    monkeypatch.delenv("QVZ_CODER_RECORDS")
+    assert b16["streams"] == a["streams"] and d16["streams"] == a["streams"], "16-byte records changed a stream"
     e = P.encode_pass(sym, n, 0, n, means0, coder="gpu-feed", **kw)
     assert e["streams"] == a["streams"], "feed-based GPU coder differs from the host coder"
     if shards == 1:
@@ -126,7 +133,10 @@ def test_gpu_model_kernels_agree(name, shards, monkeypatch):
     monkeypatch.setenv("QVZ_MODEL_KERNEL", "columns")
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards)
     assert streams == a["streams"]
-    small = host.planes_bytes_per_read(shards, c, opts["k"]) * 64       # 64 reads per segment
+    small = host.planes_bytes_per_read(shards, c, opts["k"]) * 64       # 64 reads per segment (128 of packed records)
+    _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
+    assert streams == a["streams"]
+    monkeypatch.setenv("QVZ_CODER_RECORDS", "16")                       # the same with the 16-byte records
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
     assert streams == a["streams"]
 
