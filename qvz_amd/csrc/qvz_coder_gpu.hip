@@ -1184,19 +1184,22 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
     while (wall_clock64() - t0 < (uint64_t)us * 100) __builtin_amdgcn_s_sleep(8);
 }
 
-#define CR_B 8       // symbols per block and lane (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps 31.5 KB of LDS so that it fits beside the model kernel's workgroups: 3 x 42.5 KB + 32.5 KB is exactly a CU's 160 KB at 100M x 150, -f 0.5)
-static_assert(CR_B == 8, "the record layout (rec_index) has 8 records per lane and block");
+// NB = symbols per block (barrier) and lane: 8 (2 x 8 x 64 records = 16 KB of ring; the whole kernel keeps 31.5 KB of LDS) or, with
+// packed records, 16 (58 KB: half as many barriers; a coder workgroup then leaves room for two model workgroups, which is what the
+// LDS padding of the 8-symbol kernel arranges on purpose)
+#define CR_B NB
 #define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
 // REC8 (round 4): the records come packed (PRec, rec8_index) and a FIFTH wave joins: waves 0 and 4 - which a round-robin
 // placement of the workgroup's waves puts on one SIMD - are two loaders that each take half of every block (symbols 0-3 /
 // 4-7: the 32-byte piece of one unit per lane), turn the integer triples into the two quotients (unpack_record) and park them
 // in the ring; waves 1, 2, 3 are interval, bits, bytes as before. The loaders are throughput work (eight independent
 // records per block and lane); the three chain waves keep a SIMD each.
-template <bool REC8>
+template <bool REC8, int NB>
 __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
                                                       uint64_t *__restrict__ sizes, int32_t *__restrict__ status, int high_prio) {
+    static_assert((NB == 8 || NB == 16) && (REC8 || NB == 8), "the record layouts have 8 records per lane and sub-block; 16-symbol blocks come with packed records only");
     __shared__ Record ring[2][CR_B][64];
     __shared__ uint32_t words[3][CR_B][64];                      // three slots: the bytes wave re-reads a rare symbol's word two blocks later
     __shared__ uint32_t ebits[2][CR_B][64];                      // value (16 bits) | bit count << 16, or CR_RARE | pending run
@@ -1250,15 +1253,17 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
 
     if (REC8 && wave >= 3) {
         // ------------------------------------ the two loaders of packed records ------------------------------------
-        const uint32_t half = wave - 3;                          // symbols 4 * half .. 4 * half + 3 of every block
+        constexpr int SUB = NB / 8;                              // sub-blocks of 8 symbols per block
+        const uint32_t half = wave - 3;                          // symbols 4 * half .. 4 * half + 3 of every sub-block
         const uint64_t nunit = (uint64_t)seg_reads * Cp / 16;    // units of 16 records in a stream's area
-        const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // blocks of the area (what a lane can load)
+        const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // sub-blocks of the area (what a lane can load)
         const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const PRec *>(rec) + ((uint64_t)blockIdx.x * nunit * 64 + lane) * 16);   // the lane's slot of unit 0 (rec8_index), 8 uint4 per unit
-        const uint64_t nfull = Tmin / CR_B;                      // blocks that are whole in every lane: no padding test
-        // block b of a lane = columns 8m .. 8m+7 of read `row` (b = row * Cp/8 + m): this wave's four are the quarter
-        // [row & 3] of unit (row / 4, 2m + half): 32 bytes. A register stage holds LD_B blocks' pieces; three stages in
-        // rotation keep two of them in flight. Past the last block the last one is loaded again (unconditional loads keep
-        // vmcnt countable).
+        const uint64_t nfull = Tmin / 8;                         // sub-blocks that are whole in every lane: no padding test
+        const uint64_t nsub = nblk * SUB;                        // sub-blocks to park (those past the last symbol as no-op records)
+        // sub-block sb of a lane = columns 8m .. 8m+7 of read `row` (sb = row * Cp/8 + m): this wave's four are the quarter
+        // [row & 3] of unit (row / 4, 2m + half): 32 bytes. A register stage holds LD_B sub-blocks' pieces; three stages in
+        // rotation keep two of them in flight. Past the last sub-block of the area the last one is loaded again (unconditional
+        // loads keep vmcnt countable).
         constexpr int LD_B = 2;
         uint64_t l_blk = 0;
         uint32_t l_row = 0, l_m = 0;
@@ -1274,38 +1279,38 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
                 }
             }
         };
-        auto park = [&](uint64_t b, const uint4 *d) {            // this wave's half of block b -> slot b & 1, then barrier b
-            const uint32_t slot = (uint32_t)(b & 1);
+        auto park = [&](uint64_t sb, const uint4 *d) {           // this wave's half of sub-block sb -> slot (block & 1); the block's barrier behind its last sub-block
+            const uint32_t slot = (uint32_t)((sb / SUB) & 1), at = (uint32_t)(sb % SUB) * 8 + half * 4;
             Record r4[4];
             r4[0] = unpack_record(d[0].x, d[0].y);
             r4[1] = unpack_record(d[0].z, d[0].w);
             r4[2] = unpack_record(d[1].x, d[1].y);
             r4[3] = unpack_record(d[1].z, d[1].w);
-            if (b < nfull) {
+            if (sb < nfull) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ring[slot][half * 4 + i][lane] = r4[i];
+                for (int i = 0; i < 4; ++i) ring[slot][at + i][lane] = r4[i];
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool pad = b * CR_B + half * 4 + i >= T;   // beyond this lane's symbols: the no-op record
-                    ring[slot][half * 4 + i][lane] = make_double2(pad ? 0.0 : r4[i].x, pad ? 0.0 : r4[i].y);
+                    const bool pad = sb * 8 + half * 4 + i >= T; // beyond this lane's symbols: the no-op record
+                    ring[slot][at + i][lane] = make_double2(pad ? 0.0 : r4[i].x, pad ? 0.0 : r4[i].y);
                 }
             }
-            CR_BARRIER();
+            if (sb % SUB == SUB - 1) CR_BARRIER();
         };
-        auto park_stage = [&](uint64_t stg, const uint4 *d) -> bool {   // false: that was the last block
+        auto park_stage = [&](uint64_t stg, const uint4 *d) -> bool {   // false: that was the last sub-block
 #pragma unroll
             for (int k = 0; k < LD_B; ++k) {
-                const uint64_t b = stg * LD_B + k;
-                if (b >= nblk) return false;
-                park(b, d + k * 2);
+                const uint64_t sb = stg * LD_B + k;
+                if (sb >= nsub) return false;
+                park(sb, d + k * 2);
             }
-            return (stg + 1) * LD_B < nblk;
+            return (stg + 1) * LD_B < nsub;
         };
         uint4 s0[LD_B * 2], s1[LD_B * 2], s2[LD_B * 2];
         load_stage(s0);
         load_stage(s1);
-        for (uint64_t t = 0; t * LD_B < nblk; t += 3) {
+        for (uint64_t t = 0; t * LD_B < nsub; t += 3) {
             load_stage(s2);
             if (!park_stage(t, s0)) break;
             load_stage(s0);
@@ -1528,7 +1533,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         uint32_t e[CR_B];
 #pragma unroll
         for (int jx = 0; jx < CR_B; ++jx) e[jx] = ebits[slot][jx][lane];
-        if ((b & 3) == 2) room();                                // (b starts at 2; the exact-bounds path below looks again itself)
+        if ((b - 2) % (32 / NB) == 0) room();                    // every 32 symbols (b starts at 2; the exact-bounds path below looks again itself)
         auto pair = [&](uint32_t e0, uint32_t e1) {
             // the pair first, in 32 bits (at most 16 + 16), then one 64-bit shift for both
             const uint32_t n2 = e1 >> 16, pn = (e0 >> 16) + n2;
@@ -1541,9 +1546,11 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         };
         // one wave-uniform test per block (a scalar branch on a vector compare stalls a lone wave for tens of cycles; per
         // pair it was four of them): a block with a long symbol in some lane - about one in 2^13 - goes pair by pair
-        if (__ballot((e[0] | e[1] | e[2] | e[3] | e[4] | e[5] | e[6] | e[7]) & CR_RARE)) {
 #pragma unroll
-            for (int jx = 0; jx < CR_B; jx += 2) {
+        for (int h = 0; h < CR_B; h += 8) {                      // eight symbols at a time: at most four complete words, then the ring is looked at
+        if (__ballot((e[h] | e[h + 1] | e[h + 2] | e[h + 3] | e[h + 4] | e[h + 5] | e[h + 6] | e[h + 7]) & CR_RARE)) {
+#pragma unroll
+            for (int jx = h; jx < h + 8; jx += 2) {
                 if (__ballot((e[jx] | e[jx + 1]) & CR_RARE)) {
                     drain();
                     piecewise(e[jx], words[wslot][jx][lane]);
@@ -1555,13 +1562,14 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
             }
         } else {
 #pragma unroll
-            for (int jx = 0; jx < CR_B; jx += 2) pair(e[jx], e[jx + 1]);
+            for (int jx = h; jx < h + 8; jx += 2) pair(e[jx], e[jx + 1]);
         }
         if (__ballot(wi - fi >= 4)) {                            // wave-uniform; then only the lanes with four words store
             if (wi - fi >= 4) {
                 *reinterpret_cast<uint4 *>(rb + (uint64_t)fi * 4) = *reinterpret_cast<const uint4 *>(myring + (fi & 15));
                 fi += 4;
             }
+        }
         }
         wslot = wslot == 2 ? 0u : wslot + 1;
     }
@@ -1846,6 +1854,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     // the pairs of doubles of rounds 1-3 (development knob: the tests run both, the streams are the same bytes)
     const bool rec8 = !(getenv("QVZ_CODER_RECORDS") && atoi(getenv("QVZ_CODER_RECORDS")) == 16);
     const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * (rec8 ? sizeof(PRec) : sizeof(Record));  // record bytes for one read of every stream
+    // symbols per barrier of the coder workgroup: QVZ_CODER_BLOCK=8|16 (development knob; 16 needs packed records)
+    const int cr_nb = rec8 && !(getenv("QVZ_CODER_BLOCK") && atoi(getenv("QVZ_CODER_BLOCK")) == 8) ? 16 : 8;
+    const void *const cr_fn = !rec8 ? reinterpret_cast<const void *>(&k_code_records<false, 8>)
+                              : cr_nb == 16 ? reinterpret_cast<const void *>(&k_code_records<true, 16>) : reinterpret_cast<const void *>(&k_code_records<true, 8>);
     uint64_t seg_reads = 0, seg_lo = 0;
 
     // Slices for k_model_ranks: the tables of one (column, cluster) packed back to back, coff[slice][quantizer] = word
@@ -1914,7 +1926,9 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
             // kernel of the segment before - released across queues at the same moment - finds room late or not at all from step
             // to step (coder phase 138 .. 190 ms, steps of 185 .. 236 ms; a 1.5 ms head start for the coder cures it as well).
             // Three to a CU is steady: 182.0-183.0 ms per step. So a fourth is kept out by asking for a little more than a quarter.
-            if (rk_waves && rk_lds * 4 <= (size_t)160 * 1024 && !getenv("QVZ_MODEL_LDS_PAD")) rk_lds = (size_t)160 * 1024 / 4 + 512;
+            // (With 16 symbols per coder block - 58 KB of LDS for a coder workgroup, which a brim-full CU could never host anyway and
+            // the head start therefore secures first - four to a CU are steady too and the better choice: 172.9 against 180.5 ms.)
+            if (cr_nb == 8 && rk_waves && rk_lds * 4 <= (size_t)160 * 1024 && !getenv("QVZ_MODEL_LDS_PAD")) rk_lds = (size_t)160 * 1024 / 4 + 512;
             if (getenv("QVZ_MODEL_LDS_PAD")) rk_lds += (size_t)atoi(getenv("QVZ_MODEL_LDS_PAD"));   // development knob: occupancy experiments
             if (we) {
                 const uint32_t w = (uint32_t)atoi(we);
@@ -1972,8 +1986,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     }
 #endif
     if (getenv("QVZ_CODER_DEBUG"))
-        fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu, %d-byte records\n",
-                shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size(), rec8 ? 8 : 16);
+        fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu, %d-byte records, %d symbols per coder block\n",
+                shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size(), rec8 ? 8 : 16, cr_nb);
     TRY(area.get((void **)&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
     TRY(area.get((void **)&d_status, sizeof(int32_t)));
@@ -2075,12 +2089,12 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     // dispatch and costs 30 ms).
     if (overlap && rk_waves) {
         hipFuncAttributes fa;
-        TRY(hipFuncGetAttributes(&fa, rec8 ? reinterpret_cast<const void *>(&k_code_records<true>) : reinterpret_cast<const void *>(&k_code_records<false>)));
+        TRY(hipFuncGetAttributes(&fa, cr_fn));
         const size_t lds_cu = 160 * 1024, beside = (lds_cu - fa.sharedSizeBytes) / rk_lds;
         if (beside >= 3) cr_pad = ((lds_cu - fa.sharedSizeBytes - beside * rk_lds) + 1024) & ~(size_t)255;
     }
     if (getenv("QVZ_CODER_LDS_PAD")) cr_pad = (size_t)atoi(getenv("QVZ_CODER_LDS_PAD"));   // development knob
-    if (cr_pad) TRY(hipFuncSetAttribute(rec8 ? reinterpret_cast<const void *>(&k_code_records<true>) : reinterpret_cast<const void *>(&k_code_records<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
+    if (cr_pad) TRY(hipFuncSetAttribute(cr_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
     if (dry) {                                                   // qvz_hip_encode_planes_prepare: everything is in place for the call that codes
         TRY(hipStreamSynchronize(st));
         goto done;
@@ -2130,10 +2144,11 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipEventRecord(e[1], s_model));
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
-        if (rec8) hipLaunchKernelGGL(k_code_records<true>, dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, (const Record *)buf, Cx, d_first, shards,
-                                     seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio);
-        else hipLaunchKernelGGL(k_code_records<false>, dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, (const Record *)buf, Cx, d_first, shards,
-                                seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio);
+#define CR_ARGS (const Record *)buf, Cx, d_first, shards, seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio
+        if (rec8 && cr_nb == 16) hipLaunchKernelGGL((k_code_records<true, 16>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        else if (rec8) hipLaunchKernelGGL((k_code_records<true, 8>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        else hipLaunchKernelGGL((k_code_records<false, 8>), dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, CR_ARGS);
+#undef CR_ARGS
         TRY(hipEventRecord(e[3], s_coder));
     }
     TRY(hipGetLastError());
@@ -2200,7 +2215,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         unsigned long long cr[16] = {0};
         (void)hipMemcpyFromSymbol(cr, HIP_SYMBOL(g_cr_prof), sizeof(cr));
         const double nb = cr[8] ? (double)cr[8] : 1.0;
-        fprintf(stderr, "k_code_records cycles per block of 8 symbols, busy/waiting: interval %.0f/%.0f  bits %.0f/%.0f  bytes %.0f/%.0f  loader %.0f/%.0f\n",
+        fprintf(stderr, "k_code_records cycles per block of symbols, busy/waiting: interval %.0f/%.0f  bits %.0f/%.0f  bytes %.0f/%.0f  loader %.0f/%.0f\n",
                 cr[0] / nb, cr[1] / nb, cr[2] / nb, cr[3] / nb, cr[4] / nb, cr[5] / nb, cr[6] / nb, cr[7] / nb);
         fprintf(stderr, "  cycles of that waiting spent in s_waitcnt lgkmcnt(0) before the barrier: interval %.0f  bits %.0f  bytes %.0f  loader %.0f\n", cr[9] / nb, cr[10] / nb, cr[11] / nb, cr[12] / nb);
         if (rec8) {
