@@ -1221,6 +1221,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
                                                       uint64_t *__restrict__ sizes, int32_t *__restrict__ status, int high_prio) {
+    constexpr int LAG = REC8 ? 1 : 0;                            // blocks the interval wave (and the two behind it) run further behind the loaders
     static_assert((NB == 8 || NB == 16) && (REC8 || NB == 8), "the record layouts have 8 records per lane and sub-block; 16-symbol blocks come with packed records only");
     __shared__ Record ring[2][CR_B][64];
     __shared__ uint32_t words[3][CR_B][64];                      // three slots: the bytes wave re-reads a rare symbol's word two blocks later
@@ -1265,7 +1266,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
 #define CR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define CR_REPORT() do { } while (0)
 #endif
-    // barriers 0 .. nblk + 1 in every wave (+ one more on the last segment for the hand-over of l and scale3).
+    // barriers 0 .. nblk + 1 + LAG in every wave (+ one more on the last segment for the hand-over of l and scale3).
     // (Beside the model kernel the interval wave is busy 1084 cycles of a block's 1370, 74 of the rest drain its LDS writes and
     // 212 pass in the barrier - 57 with the CU to itself. Tried: no barrier, the waves handing blocks over through progress
     // counters in LDS - a counter written after a block's data, read before it; a wave's LDS instructions are carried out in
@@ -1340,7 +1341,8 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
             load_stage(s1);
             if (!park_stage(t + 2, s2)) break;
         }
-        CR_BARRIER();                                            // barriers nblk and nblk + 1: the other waves run behind
+        CR_BARRIER();                                            // barriers nblk .. nblk + 2: the other waves run behind
+        CR_BARRIER();
         CR_BARRIER();
         if (is_last) CR_BARRIER();
         CR_REPORT();
@@ -1418,7 +1420,58 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         // ------------------------------------ interval chain ------------------------------------
         uint32_t l32 = 0, nu32 = 0;                              // l = 0, u = 2^22 - 1
         if (!fresh) { l32 = cs[g].l << 10; nu32 = (~cs[g].u & MASK_M) << 10; }
-        uint32_t wslot = 0;                                      // b % 3
+        uint32_t wslot = 0;                                      // (block coded) % 3
+        if (LAG) {
+            // Packed-record kernel: the wave runs one block behind the loaders - after barrier t it asks LDS for block t's
+            // records (into the register set the block before last has left) and codes block t - 1 from the registers filled
+            // a block ago, so no symbol waits for an LDS round trip. Two ring slots still do: block t + 1 is parked between
+            // barriers t and t + 1 in the slot whose reads were complete before barrier t.
+            // (The interval wave is ISSUE-bound, not latency-bound: ~22 VALU instructions per symbol at the 5-6 cycles a lone wave
+            // needs per instruction are the 135 cycles per symbol it is busy, whatever the depth of the dependent chain. Tried:
+            // fma(2^32 - s, x, c) as fma(-s, x, c') with c' = 2^32 x + c made off the chain - one dependent instruction less, five
+            // instructions more (two v_fmac and the moves of their constants): coder kernels 116.0 -> 117.6 ms. What does pay is
+            // an instruction less: the E3 count as ffbh(~(l & u') & 0x7FFFFFFF) - 1 - one v_bitop3 with the mask as third operand
+            // instead of nand and a shift by one; the count is used as it comes (one too many): shifting left by it and right by
+            // one is the old shift and mask, and the bits wave subtracts the one.)
+            Record ra[CR_B], rb2[CR_B];
+            auto load = [&](Record *r, uint32_t slot) {
+#pragma unroll
+                for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane];
+            };
+            auto code = [&](const Record *r) {
+#pragma unroll
+                for (int jx = 0; jx < CR_B; ++jx) {
+                    const double rd = 4294967296.0 - (double)(l32 + nu32);       // (u - l + 1) * 1024
+                    const uint32_t ql = (uint32_t)__builtin_fma(rd, r[jx].x, QUOT_LO);
+                    const uint32_t qc = (uint32_t)__builtin_fma(rd, r[jx].y, QUOT_HI);
+                    l32 += ql << 10;
+                    nu32 += qc << 10;
+                    const uint32_t k = (uint32_t)__builtin_clz(~(l32 ^ nu32));   // E1/E2: leading bits shared by l and u (low 10 bits stop it at 22)
+                    const uint32_t lk = l32;                                      // its top k bits go out
+                    l32 <<= k;
+                    nu32 <<= k;
+                    // E3: j positions below the MSB with l = 1, u = 0. Both MSBs are 0 here, so ~(l & nu) has its MSB set and the
+                    // leading zeros of the rest number j + 1 (never all 32: the ten low bits of l32 are zero)
+                    const uint32_t j1 = (uint32_t)__builtin_clz(~(l32 & nu32) & 0x7FFFFFFFu);
+                    l32 = (l32 << j1) >> 1;
+                    nu32 = (nu32 << j1) >> 1;
+                    words[wslot][jx][lane] = lk | (k << 5) | j1;                 // (j + 1 <= 22 fits the five bits)
+                }
+                wslot = wslot == 2 ? 0u : wslot + 1;
+            };
+            CR_BARRIER();                                        // barrier 0
+            if (nblk > 0) load(ra, 0);
+            uint64_t t = 1;
+            for (; t + 1 <= nblk; t += 2) {
+                CR_BARRIER();                                    // barrier t (odd): block t in, block t - 1 coded
+                load(rb2, 1);
+                code(ra);
+                CR_BARRIER();                                    // barrier t + 1
+                if (t + 1 < nblk) load(ra, 0);
+                code(rb2);
+            }
+            if (t == nblk) { CR_BARRIER(); code(ra); }           // an odd number of blocks: the last one
+        } else {
         for (uint64_t b = 0; b < nblk; ++b) {
             CR_BARRIER();
             const uint32_t slot = (uint32_t)(b & 1);
@@ -1443,6 +1496,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
             }
             wslot = wslot == 2 ? 0u : wslot + 1;
         }
+        }
         CR_BARRIER();
         CR_BARRIER();
         if (is_last) {
@@ -1462,16 +1516,16 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         // one v_bfm + one add. More than 16 bits (about one symbol in 2^16): left to the bytes wave, piecewise.
         uint32_t scale3 = fresh ? 0u : cs[g].scale3;
         uint32_t wslot = 0;                                      // (b - 1) % 3
-        for (uint64_t b = 0; b <= nblk; ++b) {
+        for (uint64_t b = 0; b <= nblk + LAG; ++b) {
             CR_BARRIER();
-            if (b == 0) continue;
-            const uint32_t slot = (uint32_t)((b - 1) & 1);
+            if (b < 1 + LAG) continue;
+            const uint32_t slot = (uint32_t)((b - 1 - LAG) & 1);
             uint32_t w[CR_B];
 #pragma unroll
             for (int jx = 0; jx < CR_B; ++jx) w[jx] = words[wslot][jx][lane];
 #pragma unroll
             for (int jx = 0; jx < CR_B; ++jx) {
-                const uint32_t k = (w[jx] >> 5) & 31, j = w[jx] & 31;
+                const uint32_t k = (w[jx] >> 5) & 31, j = (w[jx] & 31) - (LAG ? 1u : 0u);   // (the packed-record kernel's interval wave leaves j + 1)
                 const uint32_t top = __builtin_amdgcn_ubfe(w[jx], 32 - k, k);   // the k leading bits of l (0 when k = 0)
                 const uint32_t s3 = k ? scale3 : 0u;             // the pending run goes out only when a bit is decided
                 const uint32_t nb = k + s3;
@@ -1548,14 +1602,14 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         fi = tight ? 0u : fi;
     };
     uint32_t wslot = 0;                                          // (b - 2) % 3
-    for (uint64_t b = 0; b <= nblk + 1; ++b) {
+    for (uint64_t b = 0; b <= nblk + 1 + LAG; ++b) {
         CR_BARRIER();
-        if (b < 2) continue;
-        const uint32_t slot = (uint32_t)((b - 2) & 1);
+        if (b < 2 + LAG) continue;
+        const uint32_t slot = (uint32_t)((b - 2 - LAG) & 1);
         uint32_t e[CR_B];
 #pragma unroll
         for (int jx = 0; jx < CR_B; ++jx) e[jx] = ebits[slot][jx][lane];
-        if ((b - 2) % (32 / NB) == 0) room();                    // every 32 symbols (b starts at 2; the exact-bounds path below looks again itself)
+        if ((b - 2 - LAG) % (32 / NB) == 0) room();                    // every 32 symbols (b starts at 2; the exact-bounds path below looks again itself)
         auto pair = [&](uint32_t e0, uint32_t e1) {
             // the pair first, in 32 bits (at most 16 + 16), then one 64-bit shift for both
             const uint32_t n2 = e1 >> 16, pn = (e0 >> 16) + n2;
