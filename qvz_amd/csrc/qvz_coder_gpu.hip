@@ -497,29 +497,43 @@ __device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint3
 
 // ---- packed records (round 4): the integer triple in 8 bytes, the division on the coder's side ------------------------------
 // What the model knows about a symbol is three integers below 2^21 (n <= 2^19 + 8 * 64: a table passes the rescale threshold
-// inside a chunk at most; cum_lo < n; n - cum_hi <= n): cum_lo in bits [0, 21), n - cum_hi in [21, 42), n in [42, 63); the
-// all-zero word codes nothing. The model kernel then spends 7 integer instructions per symbol on its record instead of a
+// inside a chunk at most; cum_lo < n; n - cum_hi <= n): cum_lo in bits [0, 21), n - cum_hi in [21, 42), n in [42, 63);
+// PREC_NOOP (n = 1, the rest 0) codes nothing. The model kernel then spends 7 integer instructions per symbol on its record instead of a
 // reciprocal, two Newton steps, three conversions and two products in FP64, its transposition buffer and its stores halve, and
 // so does the record traffic in both directions. The two quotients are made where they are
 // consumed: by the two loader waves of k_code_records<true>, which share a SIMD of their own - throughput work with eight
 // independent records per block - so that nothing is added to the interval wave's chain. Same quotients to within 2^-52
 // relative (v_rcp_f64 + two Newton steps on n * 2^10, which is exact in a double), the bound Record's proof needs is 2^-47.
 typedef unsigned long long PRec;
+#define PREC_NOOP (1ull << 42)   /* n = 1, cum_lo = 0, n - cum_hi = 0: both quotients 0, nothing is coded; n is never 0 in a record (no guard in the unpacking) */
 __device__ __forceinline__ PRec pack_record(uint32_t n, uint32_t cum_lo, uint32_t fx) {
     const uint32_t nc = n - cum_lo - fx;
     const uint32_t lo = cum_lo | (nc << 21), hi = (nc >> 11) | (n << 10);
     return ((PRec)hi << 32) | lo;
 }
-__device__ __forceinline__ Record unpack_record(uint32_t lo, uint32_t hi) {
-    const uint32_t cum = lo & 0x1FFFFFu;
-    const uint32_t nc = __builtin_amdgcn_alignbit(hi, lo, 21) & 0x1FFFFFu;
-    uint32_t n10 = hi & 0xFFFFFC00u;                             // n * 2^10 (bit 63 of a record is zero)
-    n10 = n10 ? n10 : 1u;                                        // the no-op record: 0 / 1 twice
-    const double nd = (double)n10;
-    double rn = __builtin_amdgcn_rcp(nd);
-    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
-    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
-    return make_double2((double)cum * rn, (double)nc * rn);
+// Four records at a time, step by step across the four (the loaders' SIMD is the busiest of a coder workgroup's: written
+// record after record the compiler left every record's nine dependent instructions in a row).
+__device__ __forceinline__ void unpack_records4(const uint4 &a, const uint4 &b, Record *out) {
+    const uint32_t lo[4] = {a.x, a.z, b.x, b.z}, hi[4] = {a.y, a.w, b.y, b.w};
+    double nd[4], rn[4], e[4], cd[4], qd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nd[i] = (double)(hi[i] & 0xFFFFFC00u);        // n * 2^10 (bit 63 of a record is zero), exact; n >= 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rn[i] = __builtin_amdgcn_rcp(nd[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cd[i] = (double)(lo[i] & 0x1FFFFFu);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qd[i] = (double)(__builtin_amdgcn_alignbit(hi[i], lo[i], 21) & 0x1FFFFFu);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-nd[i], rn[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rn[i] = __builtin_fma(e[i], rn[i], rn[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-nd[i], rn[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rn[i] = __builtin_fma(e[i], rn[i], rn[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = make_double2(cd[i] * rn[i], qd[i] * rn[i]);
 }
 // Packed-record area of one segment: units of 4 reads x 4 columns (16 records, 128 bytes: [read & 3][column & 3]), the 64
 // streams' units of the same (read quad, column group) side by side - a model workgroup (4 adjacent columns, 64 consecutive
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                 o = q < 2 * A ? off[((uint64_t)cl * C + s) * 2 * A + q] : NO_TABLE;
             }
             Record w = make_double2(0.0, 0.0);                   // nothing to code (bad feed, reported below)
-            PRec w8 = 0;
+            PRec w8 = PREC_NOOP;
             if (o == NO_TABLE) {
                 bad = true;
             } else {
@@ -651,9 +665,9 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
             if (REC8) {
                 rec8[rec8_index(g, r + j - r0, pos, Cp, nunit)] = w8;
                 if (cluster_lane)                                // the reserved positions behind the cluster id
-                    for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = 0;
+                    for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = PREC_NOOP;
                 if (sx + 1 == Cw)                                // the read's pad records
-                    for (uint32_t pc = Cx; pc < Cp; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = 0;
+                    for (uint32_t pc = Cx; pc < Cp; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = PREC_NOOP;
                 continue;
             }
             rec[rec_index(g, r + j - r0, pos, Cp, nblk8)] = w;
@@ -1009,7 +1023,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
 #endif
     for (uint32_t rb = 0; rb < nr; rb += 64, ++chunk) {       // rb = read offset in the segment
         Record outr = make_double2(0.0, 0.0);
-        PRec outp = 0;
+        PRec outp = PREC_NOOP;
         const uint32_t tb = tb_nx, x = x_lk, card = card_nx;
         const bool ok = ok_nx;
         // where in the segment the reads of this block of four chunks lie. Everybody has drained the chunk before the last
@@ -1138,7 +1152,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 }
             }
             if (REC8) {
-                outp = ok ? pack_record(n, cum_lo, fx) : 0ull;   // (ok: n >= the alphabet size >= 1)
+                outp = ok ? pack_record(n, cum_lo, fx) : PREC_NOOP;   // (ok: n >= the alphabet size >= 1)
             } else {
                 const Record rr = DENSE ? make_record_fixed(n ? n : 1u, cum_lo, fx) : make_record(n ? n : 1u, cum_lo, fx);
                 outr = make_double2(ok ? rr.x : 0.0, ok ? rr.y : 0.0);
@@ -1305,10 +1319,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         auto park = [&](uint64_t sb, const uint4 *d) {           // this wave's half of sub-block sb -> slot (block & 1); the block's barrier behind its last sub-block
             const uint32_t slot = (uint32_t)((sb / SUB) & 1), at = (uint32_t)(sb % SUB) * 8 + half * 4;
             Record r4[4];
-            r4[0] = unpack_record(d[0].x, d[0].y);
-            r4[1] = unpack_record(d[0].z, d[0].w);
-            r4[2] = unpack_record(d[1].x, d[1].y);
-            r4[3] = unpack_record(d[1].z, d[1].w);
+            unpack_records4(d[0], d[1], r4);
             if (sb < nfull) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ring[slot][at + i][lane] = r4[i];
