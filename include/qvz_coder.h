@@ -154,6 +154,12 @@ int qvz_hip_scatter_streams(const uint8_t *d_packed, const uint64_t *h_sizes, ui
 /* GPU time of the last qvz_hip_encode_planes call, split into its model kernels and its coder kernels (HIP events on
  * the call's stream, summed over the segments). Either pointer may be NULL. */
 void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);
+/* The loaders of the coder kernel turn a packed record's integers into quotients with v_rcp_f64 and ONE Newton step when that is
+ * within 2^-47 of 1 / (n 2^10) for every n a record can hold (n = 1 .. 2^19 + 1024) on the current device - measured once per process
+ * and device over all of them -, with two steps otherwise (and with QVZ_CODER_NEWTON=2). Returns 1 for one step; *worst (may be
+ * NULL) receives the worst relative error measured for one step. */
+int qvz_coder_rcp_one_step_ok_ex(double *worst);
+int qvz_coder_rcp_one_step_ok(void);
 /* qvz_hip_encode_planes keeps its internal device buffers (table images, per-stream table saves, read lists: a few GB at
  * 100M x 150) and its two streams per device between calls; this gives the buffers of the current device back. */
 void qvz_hip_encode_planes_release(void);

@@ -513,6 +513,11 @@ __device__ __forceinline__ PRec pack_record(uint32_t n, uint32_t cum_lo, uint32_
 }
 // Four records at a time, step by step across the four (the loaders' SIMD is the busiest of a coder workgroup's: written
 // record after record the compiler left every record's nine dependent instructions in a row).
+// NEWTON = 1: v_rcp_f64 of gfx950 is good to 2^-24.4 over every n * 2^10 a record can hold (n = 1 .. 2^19 + 1024), one Newton step
+// leaves 2^-48.8 - measured over ALL of them (tools/unpack_bench.hip, tests/test_gpu_kernels.py) and checked again once per
+// process and device before the one-step kernel is used (qvz_coder_rcp_one_step_ok); the bound Record's proof needs is 2^-46
+// (2^-24 of slack over quotients up to 2^22). Two steps (2^-53) otherwise.
+template <int NEWTON>
 __device__ __forceinline__ void unpack_records4(const uint4 &a, const uint4 &b, Record *out) {
     const uint32_t lo[4] = {a.x, a.z, b.x, b.z}, hi[4] = {a.y, a.w, b.y, b.w};
     double nd[4], rn[4], e[4], cd[4], qd[4];
@@ -525,15 +530,25 @@ __device__ __forceinline__ void unpack_records4(const uint4 &a, const uint4 &b, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) qd[i] = (double)(__builtin_amdgcn_alignbit(hi[i], lo[i], 21) & 0x1FFFFFu);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-nd[i], rn[i], 1.0);
+    for (int k = 0; k < NEWTON; ++k) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rn[i] = __builtin_fma(e[i], rn[i], rn[i]);
+        for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-nd[i], rn[i], 1.0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-nd[i], rn[i], 1.0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rn[i] = __builtin_fma(e[i], rn[i], rn[i]);
+        for (int i = 0; i < 4; ++i) rn[i] = __builtin_fma(e[i], rn[i], rn[i]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = make_double2(cd[i] * rn[i], qd[i] * rn[i]);
+}
+// worst |1 - n 2^10 rn| over n = 1 .. nmax for v_rcp_f64 + NEWTON steps (the residual is exact in an fma): the relative error of rn
+template <int NEWTON>
+__global__ __launch_bounds__(256) void k_rcp_accuracy(unsigned long long *worst, uint32_t nmax) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x + 1;
+    if (n > nmax) return;
+    const double nd = (double)(n << 10);
+    double rn = __builtin_amdgcn_rcp(nd);
+    for (int k = 0; k < NEWTON; ++k) { const double e = __builtin_fma(-nd, rn, 1.0); rn = __builtin_fma(e, rn, rn); }
+    const double res = __builtin_fabs(__builtin_fma(-nd, rn, 1.0));
+    atomicMax(worst, (unsigned long long)__double_as_longlong(res));   // non-negative doubles order like their bit patterns
 }
 // Packed-record area of one segment: units of 4 reads x 4 columns (16 records, 128 bytes: [read & 3][column & 3]), the 64
 // streams' units of the same (read quad, column group) side by side - a model workgroup (4 adjacent columns, 64 consecutive
@@ -1230,7 +1245,7 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
 // 4-7: the 32-byte piece of one unit per lane), turn the integer triples into the two quotients (unpack_record) and park them
 // in the ring; waves 1, 2, 3 are interval, bits, bytes as before. The loaders are throughput work (eight independent
 // records per block and lane); the three chain waves keep a SIMD each.
-template <bool REC8, int NB>
+template <bool REC8, int NB, int NEWTON>
 __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
@@ -1319,7 +1334,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         auto park = [&](uint64_t sb, const uint4 *d) {           // this wave's half of sub-block sb -> slot (block & 1); the block's barrier behind its last sub-block
             const uint32_t slot = (uint32_t)((sb / SUB) & 1), at = (uint32_t)(sb % SUB) * 8 + half * 4;
             Record r4[4];
-            unpack_records4(d[0], d[1], r4);
+            unpack_records4<NEWTON>(d[0], d[1], r4);
             if (sb < nfull) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ring[slot][at + i][lane] = r4[i];
@@ -1808,6 +1823,36 @@ extern "C" uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uin
     return (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(Record) * ((longest_reads + 3) & ~(uint64_t)3);
 }
 
+// 1: v_rcp_f64 + ONE Newton step is within 2^-47 of 1 / (n 2^10) for every n a packed record can hold on the current device (the
+// loaders of k_code_records then save two of the unpacking's fourteen instructions per record); 0: it is not (two steps are used);
+// measured once per process and device over all n = 1 .. 2^19 + 1024. QVZ_CODER_NEWTON=2 forces the two steps.
+// *worst_out (may be NULL) receives the worst relative error found.
+extern "C" int qvz_coder_rcp_one_step_ok_ex(double *worst_out) {
+    static std::mutex mu;
+    static int verdict[64];                                      // 0 unknown, 1 good, 2 not good enough
+    static double worst_seen[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!verdict[dev]) {
+        const uint32_t nmax = (1u << 19) + 1024;
+        unsigned long long *d = nullptr, h = ~0ull;
+        if (hipMalloc(&d, sizeof(h)) == hipSuccess && hipMemset(d, 0, sizeof(h)) == hipSuccess) {
+            hipLaunchKernelGGL(k_rcp_accuracy<1>, dim3((nmax + 255) / 256), dim3(256), 0, 0, d, nmax);
+            if (hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) h = ~0ull;
+        }
+        if (d) (void)hipFree(d);
+        double w;
+        memcpy(&w, &h, sizeof(w));
+        worst_seen[dev] = h == ~0ull ? 1.0 : w;
+        verdict[dev] = worst_seen[dev] <= 0x1p-47 ? 1 : 2;
+    }
+    if (worst_out) *worst_out = worst_seen[dev];
+    if (getenv("QVZ_CODER_NEWTON") && atoi(getenv("QVZ_CODER_NEWTON")) == 2) return 0;
+    return verdict[dev] == 1 ? 1 : 0;
+}
+extern "C" int qvz_coder_rcp_one_step_ok(void) { return qvz_coder_rcp_one_step_ok_ex(nullptr); }
+
 static thread_local double g_planes_ms[2] = {0.0, 0.0};   // model kernels, coder kernels of the calling thread's last qvz_hip_encode_planes call
 extern "C" void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms) {
     if (model_ms) *model_ms = g_planes_ms[0];
@@ -1943,8 +1988,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * (rec8 ? sizeof(PRec) : sizeof(Record));  // record bytes for one read of every stream
     // symbols per barrier of the coder workgroup: QVZ_CODER_BLOCK=8|16 (development knob; 16 needs packed records)
     const int cr_nb = rec8 && !(getenv("QVZ_CODER_BLOCK") && atoi(getenv("QVZ_CODER_BLOCK")) == 8) ? 16 : 8;
-    const void *const cr_fn = !rec8 ? reinterpret_cast<const void *>(&k_code_records<false, 8>)
-                              : cr_nb == 16 ? reinterpret_cast<const void *>(&k_code_records<true, 16>) : reinterpret_cast<const void *>(&k_code_records<true, 8>);
+    const bool one_step = rec8 && qvz_coder_rcp_one_step_ok() == 1;   // (hardware reciprocal good enough for one Newton step: checked once per device)
+    const void *const cr_fn = !rec8 ? reinterpret_cast<const void *>(&k_code_records<false, 8, 2>)
+                              : cr_nb == 16 ? (one_step ? reinterpret_cast<const void *>(&k_code_records<true, 16, 1>) : reinterpret_cast<const void *>(&k_code_records<true, 16, 2>))
+                                            : (one_step ? reinterpret_cast<const void *>(&k_code_records<true, 8, 1>) : reinterpret_cast<const void *>(&k_code_records<true, 8, 2>));
     uint64_t seg_reads = 0, seg_lo = 0;
 
     // Slices for k_model_ranks: the tables of one (column, cluster) packed back to back, coff[slice][quantizer] = word
@@ -2235,9 +2282,11 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
 #define CR_ARGS (const Record *)buf, Cx, d_first, shards, seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio
-        if (rec8 && cr_nb == 16) hipLaunchKernelGGL((k_code_records<true, 16>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
-        else if (rec8) hipLaunchKernelGGL((k_code_records<true, 8>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
-        else hipLaunchKernelGGL((k_code_records<false, 8>), dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, CR_ARGS);
+        if (rec8 && cr_nb == 16 && one_step) hipLaunchKernelGGL((k_code_records<true, 16, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        else if (rec8 && cr_nb == 16) hipLaunchKernelGGL((k_code_records<true, 16, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        else if (rec8 && one_step) hipLaunchKernelGGL((k_code_records<true, 8, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        else if (rec8) hipLaunchKernelGGL((k_code_records<true, 8, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        else hipLaunchKernelGGL((k_code_records<false, 8, 2>), dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, CR_ARGS);
 #undef CR_ARGS
         TRY(hipEventRecord(e[3], s_coder));
     }

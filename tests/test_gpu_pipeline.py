@@ -120,6 +120,26 @@ def test_gpu_coder_streams_equal_host_coder_streams(name, shards, monkeypatch):
             assert b["streams"][0] == G.gz(name + ".q.gz")[-G.CASES[name]["size"]:]
 
 
+def test_one_newton_step_is_enough_on_this_device(monkeypatch):
+    """The coder's loaders refine v_rcp_f64 with ONE Newton step when that is within 2^-47 of 1 / (n 2^10) for every n a packed
+    record can hold - the proof at `Record` needs 2^-46 - and the library measures it over all n = 1 .. 2^19 + 1024 before it
+    relies on it. On gfx950 it must hold (2^-48.8 measured), or the fast kernel would silently be off; and the two-step
+    kernel (QVZ_CODER_NEWTON=2) codes the same streams."""
+    import ctypes as C
+    from qvz_amd import pipeline as P
+    from qvz_amd._lib import lib
+    worst = C.c_double()
+    assert lib().qvz_coder_rcp_one_step_ok_ex(C.byref(worst)) == 1, worst.value
+    assert 0.0 < worst.value <= 2.0 ** -47
+    rows, opts, n, c, sym, means0 = setup_case("cfg1_f05_L")
+    kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=16, keep=True)
+    a = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
+    monkeypatch.setenv("QVZ_CODER_NEWTON", "2")
+    assert lib().qvz_coder_rcp_one_step_ok() == 0
+    b = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
+    assert a["streams"] == b["streams"]
+
+
 @pytest.mark.parametrize("name,shards", [("t2k_c3_f05_M", 4), ("cfg1_f05_L", 16), ("rescale_c2_100k_c3", 1), ("r35_high_rate", 2)])
 def test_gpu_model_kernels_agree(name, shards, monkeypatch):
     """The prefix-count model (a wave per (stream, column), tables in LDS) and the lane-per-column model (tables in
