@@ -118,6 +118,10 @@ uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t colum
  * segments; first[i], reads[i] of the first min(count, cap) are written. (No counterpart in the reference: its coder is one
  * loop over the lines, src/qv_compressor.c:76-135.) */
 uint32_t qvz_coder_segment_list(uint64_t longest_reads, uint64_t seg_reads, int overlap, uint64_t *first, uint64_t *reads, uint32_t cap);
+/* ... with the first segment seg_reads / first_div reads long (4: the rule above, used with one cluster, where the coder kernels
+ * bound the phase and idle until the first model kernel has ended; 1: with several clusters, where the model kernels bound it and
+ * a short first segment would only be one more table save and load per workgroup) */
+uint32_t qvz_coder_segment_list2(uint64_t longest_reads, uint64_t seg_reads, int overlap, uint32_t first_div, uint64_t *first, uint64_t *reads, uint32_t cap);
 int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                  uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                  const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work,

@@ -857,6 +857,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     const uint64_t f0 = uniform64(first[g]);
     const uint64_t r0 = f0 + seg_lo, rend = uniform64(first[g + 1]);
     if (r0 >= rend) return;                                      // whole workgroup
+    bool bad = false;
+    // Several clusters, gridDim.z == 1: the workgroup of a (stream, column group) serves the clusters one after the other (tables
+    // in, the cluster's read list walked, tables out) instead of one workgroup per cluster: a third as many workgroups to dispatch
+    // and start per segment, the same lines of the planes out of the same L2.
+    const uint32_t nz = HAVE_LABELS && lists && gridDim.z == 1 ? K : 1u;
+    for (uint32_t zi = 0; zi < nz; ++zi) {
+    if (zi) __syncthreads();                                     // the pass before has drained its last chunk (recbuf, row slots)
+    if (nz > 1) z = zi;
     uint32_t nr = rend - r0 < seg_reads ? (uint32_t)(rend - r0) : seg_reads;   // reads of this stream in this segment
     const uint32_t *lp = nullptr;                                // list entries of this segment (stream-relative read numbers)
     if (lists) {
@@ -897,12 +905,11 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             const uint4 *src = reinterpret_cast<const uint4 *>(tmpl + b0);
             for (uint32_t i = lane; i < sw / 4; i += 64) reinterpret_cast<uint4 *>(save + (uint64_t)g * total_words + b0)[i] = src[i];
         }
-        return;
+        continue;
     }
 
     Record *const rec_g = rec + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 8;   // record 0 of this stream (rec_index; g = 0 when unit_recs = 8)
     PRec *const rec8_g = reinterpret_cast<PRec *>(rec) + (((uint64_t)(g >> 6) * nblk8) * 64 + (g & 63)) * 16;   // REC8: the same by rec8_index
-    bool bad = false;
     uint32_t chunk = 0;
     // Input: every lane loads the bytes of its own read for the next four chunks (a wave instruction = 64 contiguous bytes
     // of a plane) and keeps them in registers until the current four are used up, so the HBM latency stays off the chunk
@@ -1213,6 +1220,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             rk_u32x4s w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
             __builtin_nontemporal_store(w, reinterpret_cast<rk_u32x4s *>(save + (uint64_t)g * total_words + b0) + i);
         }
+    }                                                            // clusters of this workgroup
     if (bad) atomicOr(status, 1);
 }
 
@@ -1869,10 +1877,16 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
 
 // Segment list of a call: (first read, reads) relative to a stream's start, for the longest stream. When the two kernels
 // overlap, the first model kernel and the last coder kernel still run alone: those two segments are a quarter of the others.
-static void coder_segments(uint64_t longest, uint64_t seg_reads, bool overlap, std::vector<std::pair<uint64_t, uint64_t>> &segs) {
+// first_div: the first segment is seg_reads / first_div reads. 4 where the coder kernels bound the phase (one cluster: they idle
+// until the first model kernel has ended, so that one is short); 1 where the model kernels do (several clusters: a short first
+// segment is one more table save and load per workgroup - ~10 ms at 100M x 150 with three clusters - and buys nothing, the model
+// kernels run back to back from the start anyway). The last segment is a quarter either way: the coder codes it alone.
+static void coder_segments(uint64_t longest, uint64_t seg_reads, bool overlap, std::vector<std::pair<uint64_t, uint64_t>> &segs, uint32_t first_div = 4) {
     if (overlap && seg_reads >= 256 && longest > seg_reads) {
-        const uint64_t q = (seg_reads / 4) & ~(uint64_t)63;
-        const uint64_t tail_lo = (longest - q) & ~(uint64_t)63;                  // segment starts stay multiples of 64
+        const uint64_t q_last = (seg_reads / 4) & ~(uint64_t)63;
+        uint64_t q = (seg_reads / (first_div ? first_div : 1)) & ~(uint64_t)63;
+        const uint64_t tail_lo = (longest - q_last) & ~(uint64_t)63;             // segment starts stay multiples of 64
+        if (q > tail_lo) q = tail_lo;
         const uint64_t mid = tail_lo - q;
         // the middle in nm segments of whole 64-read chunks that differ by one chunk at most (cut as "each, each, .., the rest"
         // the rest could be a fifth of a segment: a table save and load per workgroup for a handful of chunks)
@@ -1880,7 +1894,7 @@ static void coder_segments(uint64_t longest, uint64_t seg_reads, bool overlap, s
         uint64_t nm = (mid + seg_reads - 1) / seg_reads;
         if (nm == 0) nm = 1;
         const uint64_t base = units / nm, extra = units % nm;                    // `extra` segments get one chunk more
-        segs.push_back({0, q});
+        if (q) segs.push_back({0, q});
         uint64_t lo = q;
         for (uint64_t i = 0; i < nm && lo < tail_lo; ++i) {
             uint64_t len = (base + (i < extra ? 1 : 0)) * 64;
@@ -1900,10 +1914,14 @@ static void coder_segments(uint64_t longest, uint64_t seg_reads, bool overlap, s
 
 // The rule above on its own (no device needed): tests and tools look at the cut a call would make. Returns the number of segments;
 // the first min(count, cap) are written.
+extern "C" uint32_t qvz_coder_segment_list2(uint64_t longest, uint64_t seg_reads, int overlap, uint32_t first_div, uint64_t *first, uint64_t *reads, uint32_t cap);
 extern "C" uint32_t qvz_coder_segment_list(uint64_t longest, uint64_t seg_reads, int overlap, uint64_t *first, uint64_t *reads, uint32_t cap) {
+    return qvz_coder_segment_list2(longest, seg_reads, overlap, 4, first, reads, cap);
+}
+extern "C" uint32_t qvz_coder_segment_list2(uint64_t longest, uint64_t seg_reads, int overlap, uint32_t first_div, uint64_t *first, uint64_t *reads, uint32_t cap) {
     std::vector<std::pair<uint64_t, uint64_t>> segs;
     if (!longest || seg_reads < 4) return 0;
-    coder_segments(longest, seg_reads, overlap != 0, segs);
+    coder_segments(longest, seg_reads, overlap != 0, segs, first_div);
     for (uint32_t i = 0; i < segs.size() && i < cap; ++i) {
         if (first) first[i] = segs[i].first;
         if (reads) reads[i] = segs[i].second;
@@ -2097,13 +2115,16 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     // kernels idle for about (middle segment - first segment) reads' worth of time while the pipeline fills, whatever
     // the ramp: a quarter 152.3 ms, a sixth 151.3, an eighth 149.8, a tenth 151.6 at 100M x 150 with one cluster; three
     // clusters: the workspace bounds the segment), the first and the last a quarter of that.
+    // Round 4, packed records: with several clusters the model kernels bound the phase and every segment costs them ~10 ms at
+    // 100M x 150 (12.6 GB of table saves and loads): model kernels 195 / 183.5 / 175 / 164.6 ms with 8 / 6 / 5 / 4 segments; a third
+    // of a stream with a FULL first segment (coder_segments) is the best cut, 191 against 199 ms for the phase.
     seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
     if (seg_reads > longest) seg_reads = longest;
     {
         const char *ov = getenv("QVZ_CODER_OVERLAP");            // development knob: "0" keeps everything on the caller's stream
         const uint64_t half = (work_bytes / 2 / per_read) & ~(uint64_t)63;
         if (!(ov && atoi(ov) == 0) && longest >= 1024 && half >= 64) {
-            const uint64_t div = getenv("QVZ_CODER_SEG_DIV") && atoi(getenv("QVZ_CODER_SEG_DIV")) > 0 ? (uint64_t)atoi(getenv("QVZ_CODER_SEG_DIV")) : (clusters > 1 ? 4 : 8);   // (the variable: development knob)
+            const uint64_t div = getenv("QVZ_CODER_SEG_DIV") && atoi(getenv("QVZ_CODER_SEG_DIV")) > 0 ? (uint64_t)atoi(getenv("QVZ_CODER_SEG_DIV")) : (clusters > 1 ? 3 : 8);   // (the variable: development knob)
             uint64_t target = ((longest + div - 1) / div + 63) & ~(uint64_t)63;
             seg_reads = half < target ? half : target;
             overlap = true;
@@ -2148,7 +2169,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
     }
-    coder_segments(longest, seg_reads, overlap, segs);
+    coder_segments(longest, seg_reads, overlap, segs, getenv("QVZ_CODER_FIRST_DIV") && atoi(getenv("QVZ_CODER_FIRST_DIV")) > 0 ? (uint32_t)atoi(getenv("QVZ_CODER_FIRST_DIV")) : (clusters > 1 ? 1u : 4u));   // (the variable: development knob)
     nseg = (uint32_t)segs.size();
     if (rk_waves && clusters > 1) {                              // read lists per (stream, cluster) and where the segments cut them
         std::vector<uint32_t> h_bounds(nseg + 1);
@@ -2259,7 +2280,9 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (overlap && i >= 1 && spin_us) hipLaunchKernelGGL(k_coder_spin_us, dim3(1), dim3(64), 0, s_model, spin_us);
         TRY(hipEventRecord(e[0], s_model));
         if (rk_waves) {
-            const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves, clusters), block(64 * rk_waves);   // z: the cluster a workgroup of column positions serves
+            // z: the cluster a workgroup of column positions serves - or, by default, one workgroup for all clusters of its (stream, column group) (QVZ_MODEL_CLUSTER_LOOP=0: development knob)
+            const bool zloop = !(getenv("QVZ_MODEL_CLUSTER_LOOP") && atoi(getenv("QVZ_MODEL_CLUSTER_LOOP")) == 0);
+            const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves, zloop ? 1 : clusters), block(64 * rk_waves);
             const size_t SK = (size_t)shards * clusters;
 #define RK_ARGS(LISTS) d_qi, d_st, ld, d_labels, columns, clusters, d_first, d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo, \
                        seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status, \

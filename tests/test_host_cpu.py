@@ -415,3 +415,11 @@ def test_coder_segment_cut():
             assert len(mid) == 0 or (mid.max() - mid.min() <= 64 and (mid % 64 == 0).all()), (longest, seg, mid)
         else:
             assert (r[:-1] == seg).all(), (longest, seg, r)
+        # several clusters: a full first segment (the model kernels bound the phase: no short segment in front), the short one last
+        n1 = L.qvz_coder_segment_list2(longest, seg, overlap, 1, first.ctypes.data, reads.ctypes.data, 4096)
+        f, r = first[:n1].astype(np.int64), reads[:n1].astype(np.int64)
+        assert 0 < n1 <= n and f[0] == 0 and (f[1:] == f[:-1] + r[:-1]).all() and f[-1] + r[-1] == longest
+        assert (r > 0).all() and (r <= seg).all() and (f % 64 == 0).all(), (longest, seg, overlap, r)
+        if overlap and seg >= 256 and longest > seg:
+            q = (seg // 4) // 64 * 64
+            assert r[0] == min(seg // 64 * 64, f[-1]) and q <= r[-1] < q + 64, (longest, seg, r)
