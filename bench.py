@@ -53,8 +53,8 @@ ALG_BYTES_PER_SYMBOL = {
     "quantize": 5.0,             # symbol in, draw in, (qv, qi, st) out: the -u product and the coder's two planes
     "well_draws": 3.0,           # word stream written once and read once, draw matrix written once
     "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out (host / gpu-feed coders only)
-    "model_records": 18.0,       # qi + st in, one 16-byte record out
-    "code_records": 16.0,        # record in (+ ~0.17 B/symbol of stream out); bound by the serial interval chain per stream
+    "model_records": 10.0,       # qi + st in, one packed 8-byte record out (18 with QVZ_CODER_RECORDS=16: the pairs of doubles of rounds 1-3)
+    "code_records": 8.0,         # record in (+ ~0.17 B/symbol of stream out); bound by the serial interval chain per stream
     "arith_shards": 2.0,         # gpu-feed coder: 2-byte feed entry in; latency-bound
 }
 # kernels whose time is a dependent-instruction chain per stream, not a bandwidth figure
@@ -62,11 +62,11 @@ CHAIN_KERNELS = ("code_records", "arith_shards")
 
 
 def measured_traffic(kernel, args, cfg, shards, world):
-    """HBM bytes per step of `kernel` from the committed PMC passes of this round (profiles/r03_pmc_traffic_cfgN.json), if
+    """HBM bytes per step of `kernel` from the committed PMC passes of this round (profiles/r04_pmc_traffic_cfgN.json), if
     they were taken on this very workload; None otherwise. (The counters need rocprofv3 around the process: tools/
     collect_profiles.sh runs this very script under it; bench.py itself cannot read them.)"""
     try:
-        with open(os.path.join(ROOT, "profiles", f"r03_pmc_traffic_cfg{args.config}.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r04_pmc_traffic_cfg{args.config}.json")) as f:
             t = json.load(f)
         w = t["workload"]
         same = (w["config"] == args.config and w["reads"] == cfg["reads"] and w["columns"] == cfg["cols"] and
@@ -519,6 +519,8 @@ def main():
         bps = ALG_BYTES_PER_SYMBOL[dom]
         if dom == "quantize" and (args.no_u or args.coder == "host"):
             bps = 4.0
+        if dom == "model_records" and os.environ.get("QVZ_CODER_RECORDS") == "16":
+            bps = 18.0
         extra = 0.0
         if k > 1 and dom == "pmf_hist":
             extra = float(n)
@@ -529,7 +531,7 @@ def main():
         roof = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(dom, args, cfg, shards, world),
                     ms_per_launch=round(per_launch[dom], 4), algorithmic_bytes_per_launch=int(alg_bytes),
-                    bytes_per_symbol=bps, traffic_source=f"profiles/r03_pmc_traffic_cfg{args.config}.json (rocprofv3 --pmc FETCH_SIZE / "
+                    bytes_per_symbol=bps, traffic_source=f"profiles/r04_pmc_traffic_cfg{args.config}.json (rocprofv3 --pmc FETCH_SIZE / "
                     "WRITE_SIZE passes of this workload, FETCH_SIZE x2 per the gfx950 correction); null if the workload differs")
         pmf_ach = (n * c + (n if k > 1 else 0)) / (per_launch["pmf_hist"] * 1e-3) / 1e9
         wall = {ph: round(float(np.mean([r["wall"][ph] for r in results])), 4) for ph in results[-1]["wall"]}
@@ -565,7 +567,7 @@ def main():
         }
         if args.coder == "gpu":
             # the coder phase against what SURVEY section 8(d) prices it at: 2 B per symbol in (quantizer index, state) + the streams out;
-            # everything beyond that is the builder's own intermediate record (16 B per symbol written by the model kernel, read by the chain)
+            # everything beyond that is the builder's own intermediate record (8 B per symbol written by the model kernel, read by the chain; 16 in rounds 1-3)
             tm, tc = measured_traffic("model_records", args, cfg, shards, world), measured_traffic("code_records", args, cfg, shards, world)
             survey = 2.0 * n * c + results[-1]["total_stream_bytes"]
             line["coder_phase_traffic"] = dict(hbm_bytes=(tm + tc) if tm and tc else None, survey_8d_bytes=int(survey),
