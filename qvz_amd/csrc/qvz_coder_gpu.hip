@@ -1247,6 +1247,9 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
 // packed records, 16 (58 KB: half as many barriers; a coder workgroup then leaves room for two model workgroups, which is what the
 // LDS padding of the 8-symbol kernel arranges on purpose)
 #define CR_B NB
+#ifndef QVZ_LOADER_STAGES
+#define QVZ_LOADER_STAGES 3
+#endif
 #define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
 // REC8 (round 4): the records come packed (PRec, rec8_index) and a FIFTH wave joins: waves 0 and 4 - which a round-robin
 // placement of the workgroup's waves puts on one SIMD - are two loaders that each take half of every block (symbols 0-3 /
@@ -1287,6 +1290,11 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         Tmax = v > Tmax ? v : Tmax;
         Tmin = m < Tmin ? m : Tmin;
     }
+    // (the two are the same in every lane after the exchange, which the compiler cannot see: out of a scalar register every loop
+    // bound and every "is this block whole in all lanes" below is a scalar compare and branch instead of a vector compare and an
+    // exec-mask region)
+    Tmax = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(Tmax >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)Tmax);
+    Tmin = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(Tmin >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)Tmin);
     const uint64_t nblk = (Tmax + CR_B - 1) / CR_B;              // the same in all four waves
     const bool fresh = is_first || !live;
 #ifdef QVZ_PROFILE          // busy / waiting cycles of each role between the block barriers
@@ -1317,7 +1325,16 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         const uint32_t half = wave - 3;                          // symbols 4 * half .. 4 * half + 3 of every sub-block
         const uint64_t nunit = (uint64_t)seg_reads * Cp / 16;    // units of 16 records in a stream's area
         const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // sub-blocks of the area (what a lane can load)
-        const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const PRec *>(rec) + ((uint64_t)blockIdx.x * nunit * 64 + lane) * 16);   // the lane's slot of unit 0 (rec8_index), 8 uint4 per unit
+        // Two lanes share a line: a load instruction whose 64 lanes touch 64 different lines holds the wave about as many cycles, and
+        // the loaders' SIMD is the busiest of the workgroup's. So lanes 2k and 2k + 1 take the two 16-byte halves (hp) of stream k's
+        // 32-byte piece with the first load of a sub-block and of stream 32 + k's with the second - 32 lines per instruction instead
+        // of 64 -, every lane unpacks the four records it loaded (two of either stream) and parks them where they belong by address:
+        // nothing is shuffled. The ring's stream index is XORed with 8 for symbols 2, 3 (mod 4), so that an even and an odd lane -
+        // same stream, symbols two apart: 2 KB apart - write to different banks; the interval wave reads with the same twist.
+        const uint32_t sA = lane >> 1, sB = 32 + (lane >> 1), hp = lane & 1;
+        const uint4 *p0 = reinterpret_cast<const uint4 *>(reinterpret_cast<const PRec *>(rec) + ((uint64_t)blockIdx.x * nunit * 64) * 16);   // unit 0 of the workgroup's streams (rec8_index), 8 uint4 per unit and stream
+        const uint4 *pA = p0 + sA * 8 + hp, *pB = p0 + sB * 8 + hp;
+        const uint64_t TA = __shfl(T, (int)sA, 64), TB = __shfl(T, (int)sB, 64);
         const uint64_t nfull = Tmin / 8;                         // sub-blocks that are whole in every lane: no padding test
         const uint64_t nsub = nblk * SUB;                        // sub-blocks to park (those past the last symbol as no-op records)
         // sub-block sb of a lane = columns 8m .. 8m+7 of read `row` (sb = row * Cp/8 + m): this wave's four are the quarter
@@ -1331,8 +1348,8 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
 #pragma unroll
             for (int k = 0; k < LD_B; ++k) {
                 const uint64_t at = (((uint64_t)(l_row >> 2) * (Cp >> 2) + 2 * l_m + half) * 64 * 8) + (l_row & 3) * 2;   // in uint4: a unit is 8, the 64 streams' units lie side by side
-                d[k * 2] = p[at];
-                d[k * 2 + 1] = p[at + 1];
+                d[k * 2] = pA[at];
+                d[k * 2 + 1] = pB[at];
                 if (l_blk + 1 < nblk8) {
                     ++l_blk;
                     if (++l_m == (Cp >> 3)) { l_m = 0; ++l_row; }
@@ -1341,16 +1358,20 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         };
         auto park = [&](uint64_t sb, const uint4 *d) {           // this wave's half of sub-block sb -> slot (block & 1); the block's barrier behind its last sub-block
             const uint32_t slot = (uint32_t)((sb / SUB) & 1), at = (uint32_t)(sb % SUB) * 8 + half * 4;
-            Record r4[4];
+            Record r4[4];                                        // records 2 hp, 2 hp + 1 of the piece of stream sA, then of stream sB
             unpack_records4<NEWTON>(d[0], d[1], r4);
+            const uint32_t sym = at + 2 * hp, tw = hp << 3;      // (at is a multiple of 4: bit 1 of the symbol number is hp)
             if (sb < nfull) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ring[slot][at + i][lane] = r4[i];
+                ring[slot][sym][sA ^ tw] = r4[0];
+                ring[slot][sym + 1][sA ^ tw] = r4[1];
+                ring[slot][sym][sB ^ tw] = r4[2];
+                ring[slot][sym + 1][sB ^ tw] = r4[3];
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool pad = sb * 8 + half * 4 + i >= T; // beyond this lane's symbols: the no-op record
-                    ring[slot][at + i][lane] = make_double2(pad ? 0.0 : r4[i].x, pad ? 0.0 : r4[i].y);
+                for (int i = 0; i < 2; ++i) {
+                    const uint64_t t = sb * 8 + half * 4 + 2 * hp + i;   // beyond a stream's symbols: the no-op record
+                    ring[slot][sym + i][sA ^ tw] = make_double2(t >= TA ? 0.0 : r4[i].x, t >= TA ? 0.0 : r4[i].y);
+                    ring[slot][sym + i][sB ^ tw] = make_double2(t >= TB ? 0.0 : r4[2 + i].x, t >= TB ? 0.0 : r4[2 + i].y);
                 }
             }
             if (sb % SUB == SUB - 1) CR_BARRIER();
@@ -1364,6 +1385,22 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
             }
             return (stg + 1) * LD_B < nsub;
         };
+#if QVZ_LOADER_STAGES == 5
+        uint4 s0[LD_B * 2], s1[LD_B * 2], s2[LD_B * 2], s3[LD_B * 2], s4[LD_B * 2];
+        load_stage(s0); load_stage(s1); load_stage(s2); load_stage(s3);
+        for (uint64_t t = 0; t * LD_B < nsub; t += 5) {
+            load_stage(s4);
+            if (!park_stage(t, s0)) break;
+            load_stage(s0);
+            if (!park_stage(t + 1, s1)) break;
+            load_stage(s1);
+            if (!park_stage(t + 2, s2)) break;
+            load_stage(s2);
+            if (!park_stage(t + 3, s3)) break;
+            load_stage(s3);
+            if (!park_stage(t + 4, s4)) break;
+        }
+#else
         uint4 s0[LD_B * 2], s1[LD_B * 2], s2[LD_B * 2];
         load_stage(s0);
         load_stage(s1);
@@ -1375,6 +1412,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
             load_stage(s1);
             if (!park_stage(t + 2, s2)) break;
         }
+#endif
         CR_BARRIER();                                            // barriers nblk .. nblk + 2: the other waves run behind
         CR_BARRIER();
         CR_BARRIER();
@@ -1468,9 +1506,9 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
             // instead of nand and a shift by one; the count is used as it comes (one too many): shifting left by it and right by
             // one is the old shift and mask, and the bits wave subtracts the one.)
             Record ra[CR_B], rb2[CR_B];
-            auto load = [&](Record *r, uint32_t slot) {
+            auto load = [&](Record *r, uint32_t slot) {         // (symbols 2, 3 mod 4 sit at stream ^ 8: the loaders' bank twist)
 #pragma unroll
-                for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane];
+                for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane ^ (((jx >> 1) & 1) << 3)];
             };
             auto code = [&](const Record *r) {
 #pragma unroll
