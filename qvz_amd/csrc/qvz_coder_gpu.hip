@@ -1919,6 +1919,9 @@ extern "C" int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, u
 // until the first model kernel has ended, so that one is short); 1 where the model kernels do (several clusters: a short first
 // segment is one more table save and load per workgroup - ~10 ms at 100M x 150 with three clusters - and buys nothing, the model
 // kernels run back to back from the start anyway). The last segment is a quarter either way: the coder codes it alone.
+// (The last segment's coder kernel runs after the last model kernel has ended; a SHORTER last segment - an eighth, a sixteenth - was
+// measured slower with three clusters, 197 against 192 ms: the coder kernel of the segment before it, 3776 reads long, then outlasts
+// the last model kernel by more than the short tail saves.)
 static void coder_segments(uint64_t longest, uint64_t seg_reads, bool overlap, std::vector<std::pair<uint64_t, uint64_t>> &segs, uint32_t first_div = 4) {
     if (overlap && seg_reads >= 256 && longest > seg_reads) {
         const uint64_t q_last = (seg_reads / 4) & ~(uint64_t)63;
