@@ -15,7 +15,7 @@ HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 HOST_SRCS:= $(CSRC)/host/qvz_coder.c $(CSRC)/host/qvz_encode.c $(CSRC)/host/qvz_shard.c $(CSRC)/host/qvz_decode.c $(CSRC)/host/qvz_fastq.c $(CSRC)/host/qvz_shardset.c $(CSRC)/host/qvz_multi.c $(CSRC)/host/qvz_codebook_host.c $(CSRC)/host/qvz_egress.c
 HOST_OBJS:= $(HOST_SRCS:.c=.o)
 HIP_OBJS := $(HIP_SRCS:.hip=.hip.o)
-HDRS     := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h)
+HDRS     := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/host/*.h)
 
 all: qvz_amd/libqvzhip.so qvz_amd/libqvzcompat.so qvz_amd/bin/qvz qvz_amd/bin/qvz-shardset
 

@@ -158,6 +158,10 @@ int qvz_hip_scatter_streams(const uint8_t *d_packed, const uint64_t *h_sizes, ui
 /* GPU time of the last qvz_hip_encode_planes call, split into its model kernels and its coder kernels (HIP events on
  * the call's stream, summed over the segments). Either pointer may be NULL. */
 void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);
+/* What the first qvz_hip_encode_planes call of a process needs and no codebook (its stream pair made and tested for running side
+ * by side, this file's code object loaded, the loaders' reciprocal check): ~20-25 ms that a one-shot process spends beside its
+ * upload, on a thread of its own, instead of in front of its first coder kernel. Optional; the current device is the caller's. */
+int qvz_hip_encode_planes_warmup(void);
 /* The loaders of the coder kernel turn a packed record's integers into quotients with v_rcp_f64 and ONE Newton step when that is
  * within 2^-47 of 1 / (n 2^10) for every n a record can hold (n = 1 .. 2^19 + 1024) on the current device - measured once per process
  * and device over all of them -, with two steps otherwise (and with QVZ_CODER_NEWTON=2). Returns 1 for one step; *worst (may be

@@ -111,6 +111,7 @@ SIGNATURES = {
     "qvz_coder_segment_list": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
     "qvz_coder_segment_list2": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]),
     "qvz_hip_encode_planes_last_ms": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "qvz_hip_encode_planes_warmup": (C.c_int, []),
     "qvz_coder_rcp_one_step_ok_ex": (C.c_int, [C.POINTER(C.c_double)]),
     "qvz_coder_rcp_one_step_ok": (C.c_int, []),
     "qvz_model_build": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p),

@@ -120,6 +120,8 @@ static int job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_
 /* Streaming, transposing ingest (replaces load_file's row-pointer table, lines.c:27-82): the text goes through two
  * pinned staging buffers so that the host copy of chunk k+1 (page cache -> pinned), the PCIe transfer of chunk k and its
  * transposition into the column-major matrix overlap. */
+static uint8_t *job_plane(qvz_job_t *job, int i);
+
 int qvz_ingest_rows(const uint8_t *text, uint64_t N, uint32_t C, uint8_t *d_sym, uint64_t ld, uint32_t *bad_out) {
     int rc = 0;
     const uint64_t stride = (uint64_t)C + 1;
@@ -165,14 +167,23 @@ done:
     return rc;
 }
 
+static void *coder_warmup_main(void *arg) {
+    if (qvz_hip_set_device(*(const int *)arg) == QVZ_OK) (void)qvz_hip_encode_planes_warmup();
+    return NULL;
+}
+
 int qvz_job_upload(qvz_job_t *job) {
     int rc = 0;
     const double t0 = now();
     const uint64_t ld = job->ld;
     uint32_t bad = 0;
+    pthread_t th_warm;
+    int warm_running = 0;
     if (job->uploaded) return 0;
     HIP(qvz_hip_set_device(job->opts.device));
     (void)qvz_hip_codebook_warmup();                               /* the one-time log2 check of the codebook generation, beside the upload */
+    /* ... and the coder's stream pair, code object and reciprocal check (a sharded encode's first coder call) */
+    if (getenv("QVZ_SHARDS") || getenv("QVZ_DEVICES")) warm_running = pthread_create(&th_warm, NULL, coder_warmup_main, &job->opts.device) == 0;
     HIP(qvz_hip_malloc((void **)&job->d_sym, (size_t)job->C * ld));
     HIP(qvz_hip_malloc((void **)&job->d_labels, ld));
     HIP(qvz_hip_memset(job->d_labels, 0, ld, NULL));               /* calloc'd line_t.cluster, lines.c:116 */
@@ -181,6 +192,7 @@ int qvz_job_upload(qvz_job_t *job) {
     job->uploaded = 1;
     job->t_upload = now() - t0;
 done:
+    if (warm_running) pthread_join(th_warm, NULL);
     return rc;
 }
 
@@ -601,7 +613,8 @@ int qvz_job_start_draws(qvz_job_t *job) {
         job->well_chosen = 1;
     }
     HIP(qvz_hip_set_device(job->opts.device));
-    HIP(qvz_hip_malloc((void **)&job->d_draws, (size_t)job->C * job->ld));
+    if ((job->d_draws = job_plane(job, 0))) job->draws_in_planes = 1;          /* allocated ahead of time, beside the upload */
+    else HIP(qvz_hip_malloc((void **)&job->d_draws, (size_t)job->C * job->ld));
     /* The runtime spreads streams over a few hardware queues and a queue runs its kernels in order: a side stream that
      * shares the default stream's queue would put the generator IN FRONT of the codebook kernels instead of beside them
      * (DESIGN.md section 8). A candidate is probed (~1 ms) and dropped for the next one if it does not overlap. */
@@ -645,6 +658,13 @@ static void *workspace_main(void *arg) {
     const double t0 = now();
     if (qvz_hip_malloc(&job->d_work, (size_t)want) == QVZ_OK) job->work_bytes = want; else job->d_work = NULL;
     if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: workspace of %.1f GiB allocated in %.4f s\n", want / 1073741824.0, now() - t0);
+    {   /* the planes: draws | qi | st | [qv] | err, each rounded up to 256 bytes (what qvz_job_planes hands out) */
+        const double t1 = now();
+        const uint64_t plane = ((uint64_t)job->C * job->ld + 255) & ~255ull, errb = (job->N * sizeof(double) + 255) & ~255ull;
+        const uint64_t need = plane * (job->want_text ? 4 : 3) + errb;
+        if (qvz_hip_malloc(&job->d_planes, (size_t)need) == QVZ_OK) job->planes_bytes = need; else job->d_planes = NULL;
+        if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: planes of %.1f GB allocated in %.4f s\n", need / 1e9, now() - t1);
+    }
     return NULL;
 }
 
@@ -661,6 +681,17 @@ int qvz_job_start_workspace(qvz_job_t *job, uint32_t shards) {
 
 static void workspace_join(qvz_job_t *job) {
     if (job->work_running) { pthread_join((pthread_t)job->work_thread, NULL); job->work_running = 0; }
+}
+
+/* plane i of the early allocation (0 draws, 1 qi, 2 st, 3 qv when want_text, last: the errors), or NULL when there is none (the
+ * caller then allocates its own); waits for the allocating thread */
+static uint8_t *job_plane(qvz_job_t *job, int i) {
+    workspace_join(job);
+    if (!job->d_planes) return NULL;
+    const uint64_t plane = ((uint64_t)job->C * job->ld + 255) & ~255ull;
+    const int n_planes = job->want_text ? 4 : 3;
+    if (i > n_planes || (i == 3 && !job->want_text)) return NULL;
+    return (uint8_t *)job->d_planes + plane * (uint64_t)(i < 0 ? n_planes : i);   /* i < 0: the errors, behind the planes */
 }
 
 /* The first coder call of a process loads its code object, sizes and allocates its kept buffers and makes its stream pair:
@@ -723,7 +754,8 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     const uint64_t N = job->N, ld = job->ld;
     uint16_t *d_ct = NULL, *d_qs = NULL, *h_ct = NULL, *h_qs = NULL;
     double *d_dist = NULL, *d_err = NULL;
-    uint8_t *d_qv = NULL, *d_qi = NULL, *d_st = NULL, *d_out = NULL, *d_packed = NULL, *h_buf = NULL, *image = NULL;
+    int planes_early = 0;
+    uint8_t *d_qv = NULL, *d_qi = NULL, *d_st = NULL, *d_out = NULL, *d_out_own = NULL, *d_packed = NULL, *d_packed_own = NULL, *h_buf = NULL, *image = NULL;
     int32_t *d_status = NULL, status = 0;
     uint64_t *sizes = NULL, *first = NULL;
     uint32_t *wstates = NULL;
@@ -757,10 +789,16 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     if (job->shard_bounds) memcpy(first, job->shard_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
     else qvz_shard_bounds(N, shards, first);
     /* quantizer: the qv plane (the -u product) only for a caller that wants the text */
-    if (fu) HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
-    HIP(qvz_hip_malloc((void **)&d_qi, (size_t)C * ld));
-    HIP(qvz_hip_malloc((void **)&d_st, (size_t)C * ld));
-    HIP(qvz_hip_malloc((void **)&d_err, N * sizeof(double)));
+    if (job_plane(job, 1) && (!fu || job_plane(job, 3))) {                     /* allocated ahead of time, beside the upload */
+        planes_early = 1;
+        d_qi = job_plane(job, 1); d_st = job_plane(job, 2); d_err = (double *)job_plane(job, -1);
+        if (fu) d_qv = job_plane(job, 3);
+    } else {
+        if (fu) HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
+        HIP(qvz_hip_malloc((void **)&d_qi, (size_t)C * ld));
+        HIP(qvz_hip_malloc((void **)&d_st, (size_t)C * ld));
+        HIP(qvz_hip_malloc((void **)&d_err, N * sizeof(double)));
+    }
     HIP(qvz_hip_malloc((void **)&d_status, sizeof(int32_t)));
     HIP(qvz_hip_memset(d_status, 0, sizeof(int32_t), NULL));
     HIP(qvz_hip_stream_wait(NULL, job->well_stream));                          /* the draws, on the device's side */
@@ -769,7 +807,8 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     HIP(qvz_hip_copy_d2h(&status, d_status, sizeof(status), NULL));
     HIP(qvz_hip_stream_sync(NULL));
     if (status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
-    qvz_hip_free(job->d_draws); job->d_draws = NULL;
+    if (!job->draws_in_planes) qvz_hip_free(job->d_draws);
+    job->d_draws = NULL;
     /* the symbols are not needed again either (this stage ends a job; qvz_job_release frees what is left): 15 GB at 100M x 150
      * that the coder's buffers and the -u staging can have - with -u the process is otherwise near what the card holds */
     qvz_hip_free(job->d_sym); job->d_sym = NULL;
@@ -803,17 +842,30 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         for (uint32_t bits = 6; ; bits *= 2) {
             cap = ((per * C * bits) / 8 + 512 + 3) & ~3ull;
             const double ta = now();
-            qvz_hip_free(d_out); d_out = NULL;
-            HIP(qvz_hip_malloc((void **)&d_out, (size_t)shards * cap));
-            const double tb = now();
             if (prep_running) { pthread_join(th_prep, NULL); prep_running = 0; }
-            const double tc = now();
+            const double tb = now();
             workspace_join(job);
-            if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: before the coder call: stream area of %.1f GB allocated in %.4f s, waited %.4f s for the coder's set-up thread, %.4f s for the workspace thread\n",
-                                              (double)shards * cap / 1e9, tb - ta, tc - tb, now() - tc);
+            const double tc = now();
             const int mine = job->d_work && job->work_shards == shards;        /* allocated ahead of time for this very cut */
+            /* The streams' area (11 GB at 100M x 150) comes out of the END of the record workspace when that leaves the coder room
+             * for two full segments (packed records need a third of the 96 GiB): one large hipMalloc less in front of the coder
+             * kernels - the place where a process that starts soon after another has freed its HBM was seen to stall for a
+             * second. Otherwise, and when a stream has outgrown its allotment, an allocation of its own. */
+            uint64_t work_use = mine ? job->work_bytes : 0;
+            const uint64_t area = (((uint64_t)shards * cap) + 4095) & ~4095ull;
+            const uint64_t two_segments = 2 * qvz_hip_encode_planes_work_bytes((per + (K > 1 ? 2 : 7)) / (K > 1 ? 3 : 8) + 64, C, K, shards) / 2;   /* (the helper prices 16-byte records: half) */
+            qvz_hip_free(d_out_own); d_out_own = NULL;
+            if (mine && bits == 6 && work_use > area && work_use - area >= two_segments) {
+                work_use = (work_use - area) & ~255ull;
+                d_out = (uint8_t *)job->d_work + work_use;
+            } else {
+                HIP(qvz_hip_malloc((void **)&d_out_own, (size_t)shards * cap));
+                d_out = d_out_own;
+            }
+            if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: before the coder call: waited %.4f s for the coder's set-up thread, %.4f s for the workspace thread; stream area of %.1f GB %s in %.4f s\n",
+                                              tb - ta, tc - tb, (double)shards * cap / 1e9, d_out_own ? "allocated" : "taken from the workspace", now() - tc);
             const int crc = qvz_hip_encode_planes_bounds(d_qi, d_st, ld, K > 1 ? job->d_labels : NULL, N, C, K, (const qvz_codebook_t *const *)job->cbs,
-                                                         shards, job->shard_bounds, d_out, cap, sizes, mine ? job->d_work : NULL, mine ? job->work_bytes : 0, NULL);
+                                                         shards, job->shard_bounds, d_out, cap, sizes, mine ? job->d_work : NULL, work_use, NULL);
             if (crc == QVZ_OK) break;
             if (crc != QVZ_E_NOMEM || bits >= 24) { rc = qvz_job_fail(crc, "%s", qvz_hip_last_error()); goto done; }
         }
@@ -821,7 +873,10 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         job->t_coder = t2 - t1;
         for (uint32_t g = 0; g < shards; ++g) total += sizes[g];
         /* the streams leave the device packed back to back: 1-2 bits per symbol instead of the 6 the area was sized for */
-        HIP(qvz_hip_malloc((void **)&d_packed, total ? total : 1));
+        /* (into the record workspace when there is one: the coder has finished with it, and one more large hipMalloc is one more
+         * place for a young process's allocation stall) */
+        if (job->d_work && job->work_shards == shards && !d_out_own && total <= (uint64_t)(d_out - (uint8_t *)job->d_work)) d_packed = (uint8_t *)job->d_work;
+        else { HIP(qvz_hip_malloc((void **)&d_packed_own, total ? total : 1)); d_packed = d_packed_own; }
         HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_packed, NULL));
         if (err_running) { pthread_join(th_err, NULL); err_running = 0; } else side_errors(&task_err);
         if (task_err.rc) { rc = qvz_job_fail(task_err.rc, "%s", task_err.err); goto done; }
@@ -887,8 +942,9 @@ done:
     if (err_running) pthread_join(th_err, NULL);                                /* they read device buffers freed below */
     if (text_running) pthread_join(th_text, NULL);
     free(h_ct); free(h_qs); free(sizes); free(first); free(h_buf); free(image); free(wstates);
-    qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist); qvz_hip_free(d_err); qvz_hip_free(d_qv);
-    qvz_hip_free(d_qi); qvz_hip_free(d_st); qvz_hip_free(d_out); qvz_hip_free(d_packed); qvz_hip_free(d_status);
+    qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist);
+    if (!planes_early) { qvz_hip_free(d_err); qvz_hip_free(d_qv); qvz_hip_free(d_qi); qvz_hip_free(d_st); }   /* (the early planes go with the job) */
+    qvz_hip_free(d_out_own); qvz_hip_free(d_packed_own); qvz_hip_free(d_status);
     if (job->d_draws) { qvz_hip_free(job->d_draws); job->d_draws = NULL; }
     if (job->well_stream) { qvz_hip_stream_destroy(job->well_stream); job->well_stream = NULL; }
     return rc;
@@ -910,10 +966,11 @@ void qvz_job_release(qvz_job_t *job) {
     qvz_hip_free(job->d_sym); qvz_hip_free(job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
     qvz_hip_free(job->d_counts); qvz_hip_free(job->d_acc); qvz_hip_free(job->d_moved); qvz_hip_free(job->d_kstat);
     qvz_hip_free(job->d_cnt64); qvz_hip_free(job->d_counts64);
-    qvz_hip_free(job->d_draws);
+    if (!job->draws_in_planes) qvz_hip_free(job->d_draws);
     if (job->well_stream) qvz_hip_stream_destroy(job->well_stream);
     workspace_join(job);
     qvz_hip_free(job->d_work);
+    qvz_hip_free(job->d_planes);
     memset(job, 0, sizeof(*job));
 }
 
@@ -950,7 +1007,8 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
      * what is not needed is given back - then the -u text, N (C + 1) bytes */
     if (shards && fout && !shard_prefix) qvz_prealloc_start(fout, job.N * (uint64_t)job.C / 4);
     if (shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));
-    if (shards) qvz_job_start_workspace(&job, shards);                         /* the coder's record workspace, beside the upload */
+    job.want_text = fu != NULL;
+    if (shards) qvz_job_start_workspace(&job, shards);                         /* the coder's record workspace and the quantizer's planes, beside the upload */
     if ((rc = qvz_job_upload(&job))) goto done;
     if ((rc = qvz_job_kmeans(&job, 0))) goto done;
     if (opts->verbose) printf("Clustering took %.4f seconds\n", job.t_cluster);                      /* main.c:56-58 */

@@ -51,6 +51,13 @@ typedef struct qvz_job {
     void *d_work;
     uint64_t work_bytes;
     uint32_t work_shards;
+    /* ... and, by the same thread, the quantizer's planes (coder index and state, the quantized values when the caller wants the -u
+     * text, the per-read errors) and the draw matrix: 45-60 GB at 100M x 150 whose hipMalloc calls otherwise sit in front of the
+     * quantizer and the WELL generator - where a process that starts soon after another has freed its HBM was seen to stall for up
+     * to a second, whichever large allocation came first (want_text: set by the caller before qvz_job_start_workspace) */
+    void *d_planes;
+    uint64_t planes_bytes;
+    int want_text, draws_in_planes;
     int work_running, work_rc;
     unsigned long work_thread;        /* pthread_t */
     /* ---- a job that holds PART of a file (one device of a multi-device encode, qvz_multi.c); all zero otherwise ---- */

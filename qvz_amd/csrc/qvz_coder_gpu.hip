@@ -1899,6 +1899,35 @@ extern "C" int qvz_coder_rcp_one_step_ok_ex(double *worst_out) {
 }
 extern "C" int qvz_coder_rcp_one_step_ok(void) { return qvz_coder_rcp_one_step_ok_ex(nullptr); }
 
+// The model / coder stream pair of the current device: made once, tested for running side by side when it is made
+// (qvz_hip_streams_overlap: a partner on the first stream's hardware queue is put aside and another one made, a few times at
+// most), and kept. Returns 1 with the pair, 0 when the ordinal is beyond the table (the caller makes its own), < 0 on an error.
+static int coder_stream_pair(hipStream_t *pair) {
+    static std::mutex mu;
+    static hipStream_t kept[64][2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return qvz_set_error(QVZ_E_HIP, "no current device");
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!kept[dev][0]) {
+        hipStream_t first = nullptr, second = nullptr, aside[8];
+        int naside = 0, ok = 0;
+        if (hipStreamCreateWithFlags(&first, hipStreamNonBlocking) != hipSuccess) return qvz_set_error(QVZ_E_HIP, "hipStreamCreate failed");
+        while (true) {
+            if (hipStreamCreateWithFlags(&second, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(first); return qvz_set_error(QVZ_E_HIP, "hipStreamCreate failed"); }
+            if (qvz_hip_streams_overlap(first, second, &ok) != QVZ_OK || ok || naside == 8) break;
+            aside[naside++] = second;                            // kept alive until the choice is made: destroying it would hand its queue to the next one
+        }
+        for (int i = 0; i < naside; ++i) (void)hipStreamDestroy(aside[i]);
+        if (getenv("QVZ_CODER_DEBUG")) fprintf(stderr, "qvz_hip_encode_planes: model / coder streams made for device %d, %d candidate(s) put aside, side by side: %d\n", dev, naside, ok);
+        kept[dev][0] = first;
+        kept[dev][1] = second;
+    }
+    pair[0] = kept[dev][0];
+    pair[1] = kept[dev][1];
+    return 1;
+}
+
 static thread_local double g_planes_ms[2] = {0.0, 0.0};   // model kernels, coder kernels of the calling thread's last qvz_hip_encode_planes call
 extern "C" void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms) {
     if (model_ms) *model_ms = g_planes_ms[0];
@@ -1993,6 +2022,20 @@ extern "C" int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint3
     uint64_t sizes_dummy = 0;
     return encode_planes_impl(true, nullptr, nullptr, qvz_hip_ld(n), nullptr, n, columns, clusters, cbs, shards, h_bounds, nullptr, 8, &sizes_dummy,
                               work_bytes ? (void *)(uintptr_t)256 : nullptr, work_bytes, nullptr);
+}
+
+// What a first coder call of a process needs and no codebook: the stream pair made and probed (~20 ms), the code object of
+// this file loaded, the reciprocal check of the loaders. A one-shot process runs it beside its upload (the rest of the set-up -
+// qvz_hip_encode_planes_prepare: the kept buffers, which are sized by the codebooks - then fits beside the quantizer).
+extern "C" int qvz_hip_encode_planes_warmup(void) {
+    hipStream_t pair[2];
+    const int how = coder_stream_pair(pair);
+    if (how < 0) return how;
+    (void)qvz_coder_rcp_one_step_ok();
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_code_records<true, 16, 1>));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_model_ranks<false, false, true>));
+    return QVZ_OK;
 }
 
 static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
@@ -2243,30 +2286,12 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         // (A high-priority queue for the coder kernel was tried: its segments got slower, 225 ms against 167 ms of kernel
         // time per step with three clusters at 100M x 150, and the step with them.)
         {
-            static std::mutex mu;
-            static hipStream_t kept[64][2];
-            int dev = 0;
-            TRY(hipGetDevice(&dev));
-            std::lock_guard<std::mutex> lk(mu);
-            if (dev >= 0 && dev < 64) {
-                if (!kept[dev][0]) {
-                    // ... and the pair is tested for running side by side when it is made (qvz_hip_streams_overlap): a
-                    // partner on the first stream's queue is put aside and another one made, a few times at most
-                    hipStream_t first = nullptr, second = nullptr, aside[8];
-                    int naside = 0, ok = 0;
-                    TRY(hipStreamCreateWithFlags(&first, hipStreamNonBlocking));
-                    while (true) {
-                        TRY(hipStreamCreateWithFlags(&second, hipStreamNonBlocking));
-                        if (qvz_hip_streams_overlap(first, second, &ok) != QVZ_OK || ok || naside == 8) break;
-                        aside[naside++] = second;                // kept alive until the choice is made: destroying it would hand its queue to the next one
-                    }
-                    for (int i = 0; i < naside; ++i) (void)hipStreamDestroy(aside[i]);
-                    if (getenv("QVZ_CODER_DEBUG")) fprintf(stderr, "qvz_hip_encode_planes: model / coder streams made for device %d, %d candidate(s) put aside, side by side: %d\n", dev, naside, ok);
-                    kept[dev][0] = first;
-                    kept[dev][1] = second;
-                }
-                s_model = kept[dev][0];
-                s_coder = kept[dev][1];
+            hipStream_t pair[2] = {nullptr, nullptr};
+            const int how = coder_stream_pair(pair);             // 1: the device's kept pair, 0: none kept for this ordinal, < 0: error (message set)
+            if (how < 0) { rc = how; goto done; }
+            if (how == 1) {
+                s_model = pair[0];
+                s_coder = pair[1];
                 own_streams = false;
             } else {
                 TRY(hipStreamCreateWithFlags(&s_model, hipStreamNonBlocking));

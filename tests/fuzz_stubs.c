@@ -61,3 +61,4 @@ uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t colum
 int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, const uint64_t *h_bounds, uint64_t work_bytes) { U(n); U(columns); U(clusters); U(cbs); U(shards); U(h_bounds); U(work_bytes); return nodev(); }
 int qvz_hip_codebook_warmup(void) { return nodev(); }
 int qvz_hip_codebook_exact_entropies(void) { return 0; }
+int qvz_hip_encode_planes_warmup(void) { return QVZ_E_HIP; }
