@@ -508,6 +508,8 @@ def main():
             spans.pop("arith_shards", None)
             spans["model_records"] = [r["wall"]["coder_model_kernels"] * 1e3 for r in results]
             spans["code_records"] = [r["wall"]["coder_interval_kernels"] * 1e3 for r in results]
+            if "coder_quantize_kernels" in results[-1]["wall"]:   # the quantizer as the coder pipeline's first stage: its launches, summed per step
+                spans["quantize"] = [r["wall"]["coder_quantize_kernels"] * 1e3 for r in results]
         per_launch = {name: float(np.mean(v)) for name, v in spans.items()}
         per_step = {name: float(np.sum(v)) / args.steps for name, v in spans.items()}
         # `roofline` is reported for the dominant HBM-bound kernel. The lane-per-stream coder usually takes the most

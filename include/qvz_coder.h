@@ -126,6 +126,22 @@ int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint6
                                  uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                  const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work,
                                  uint64_t work_bytes, void *stream);
+/* Quantizer and coder as one pipeline (round 4): qvz_hip_quantize (include/qvz_hip.h; same arguments, same planes, same per-read
+ * errors, same status word) launched segment by segment - for the reads of every stream that the coder's next model kernel needs -
+ * on a stream of its own, beside the model kernel of the segment before and the coder kernel of the one before that; then exactly
+ * what qvz_hip_encode_planes_bounds does with the planes d_qi / d_st (leading dimension ld_out). The reference's loop does both per
+ * line as well (src/qv_compressor.c:76-135: quantize a symbol, code it). d_qi and d_st are required; d_qv (the -u product) and d_err
+ * may be NULL. *d_status is NOT cleared here (as in qvz_hip_quantize): bit 0 = a context the codebook does not define, in which case
+ * the call returns QVZ_E_DEAD_CTX. Everything has completed when the call returns. */
+int qvz_hip_quantize_encode_planes(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t columns, uint64_t ld,
+                                   uint32_t clusters, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
+                                   uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
+                                   uint64_t ld_out, double *d_err, int32_t *d_status, const qvz_codebook_t *const *cbs,
+                                   uint32_t shards, const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard,
+                                   uint64_t *h_sizes, void *d_work, uint64_t work_bytes, void *stream);
+/* Busy time of the quantizer launches of the calling thread's last qvz_hip_quantize_encode_planes call (ms; they run beside the
+ * model and coder kernels, whose times qvz_hip_encode_planes_last_ms reports). */
+double qvz_hip_encode_planes_last_quant_ms(void);
 /* Decoder of sharded streams on the GPU, one lane per stream: the reference's
  * start_qv_decompression (src/qv_compressor.c:145-231) with arithmetic_decoder_step / decoder_last_step
  * (src/arith.c:118-205) and update_stats (src/qv_stream.c:9-25), per shard. d_in holds stream g at

@@ -1902,9 +1902,9 @@ extern "C" int qvz_coder_rcp_one_step_ok(void) { return qvz_coder_rcp_one_step_o
 // The model / coder stream pair of the current device: made once, tested for running side by side when it is made
 // (qvz_hip_streams_overlap: a partner on the first stream's hardware queue is put aside and another one made, a few times at
 // most), and kept. Returns 1 with the pair, 0 when the ordinal is beyond the table (the caller makes its own), < 0 on an error.
-static int coder_stream_pair(hipStream_t *pair) {
+static int coder_stream_pair(hipStream_t *pair, hipStream_t *third = nullptr) {
     static std::mutex mu;
-    static hipStream_t kept[64][2];
+    static hipStream_t kept[64][3];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return qvz_set_error(QVZ_E_HIP, "no current device");
     if (dev < 0 || dev >= 64) return 0;
@@ -1925,6 +1925,22 @@ static int coder_stream_pair(hipStream_t *pair) {
     }
     pair[0] = kept[dev][0];
     pair[1] = kept[dev][1];
+    if (third) {                                                 // the quantizer's stream of a fused call: beside both, where the queues allow
+        if (!kept[dev][2]) {
+            hipStream_t cand = nullptr, aside[8];
+            int naside = 0, ok = 0;
+            while (true) {
+                if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) return qvz_set_error(QVZ_E_HIP, "hipStreamCreate failed");
+                int ok_b = 0;
+                if (qvz_hip_streams_overlap(kept[dev][0], cand, &ok) != QVZ_OK || qvz_hip_streams_overlap(kept[dev][1], cand, &ok_b) != QVZ_OK || (ok && ok_b) || naside == 8) break;
+                aside[naside++] = cand;
+            }
+            for (int i = 0; i < naside; ++i) (void)hipStreamDestroy(aside[i]);
+            if (getenv("QVZ_CODER_DEBUG")) fprintf(stderr, "qvz_hip_encode_planes: quantizer stream made for device %d, %d candidate(s) put aside\n", dev, naside);
+            kept[dev][2] = cand;
+        }
+        *third = kept[dev][2];
+    }
     return 1;
 }
 
@@ -2002,7 +2018,7 @@ extern "C" uint32_t qvz_coder_segment_list2(uint64_t longest, uint64_t seg_reads
 static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                               uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                               const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
-                              void *d_work, uint64_t work_bytes, void *stream);
+                              void *d_work, uint64_t work_bytes, void *stream, const QvzQuantArgs *qz = nullptr);
 
 extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                             uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
@@ -2038,10 +2054,31 @@ extern "C" int qvz_hip_encode_planes_warmup(void) {
     return QVZ_OK;
 }
 
+// The quantizer as the pipeline's first stage (round 4): one launch per coder segment, for exactly the reads that segment's model
+// kernel needs (qvz_quantize_launch), on a stream of its own - quantizer of segment i + 1 beside the model kernel of segment i beside
+// the coder kernel of segment i - 1. The quantizer's ~20 ms at 100M x 150 and most of the wait for the first model kernels then lie
+// beside the coder kernels, which bound the phase and do not care what else the chip runs (107 ms alone and beside the model kernel).
+extern "C" int qvz_hip_quantize_encode_planes(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t columns, uint64_t ld,
+                                              uint32_t clusters, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
+                                              uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
+                                              uint64_t ld_out, double *d_err, int32_t *d_status, const qvz_codebook_t *const *cbs,
+                                              uint32_t shards, const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard,
+                                              uint64_t *h_sizes, void *d_work, uint64_t work_bytes, void *stream) {
+    const QvzQuantArgs a = {d_sym, d_labels, n, columns, ld, clusters, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status};
+    const int rc = qvz_quantize_check(a);
+    if (rc) return rc;
+    if (!d_qi || !d_st) return qvz_set_error(QVZ_E_ARG, "the coder needs the quantizer's index and state planes");
+    return encode_planes_impl(false, d_qi, d_st, ld_out, d_labels, n, columns, clusters, cbs, shards, h_bounds, d_out, cap_per_shard, h_sizes,
+                              d_work, work_bytes, stream, &a);
+}
+
+static thread_local double g_planes_quant_ms = 0.0;             // quantizer launches of the calling thread's last fused call
+extern "C" double qvz_hip_encode_planes_last_quant_ms(void) { return g_planes_quant_ms; }
+
 static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                               uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                               const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
-                              void *d_work, uint64_t work_bytes, void *stream) {
+                              void *d_work, uint64_t work_bytes, void *stream, const QvzQuantArgs *qz) {
     if (((!d_qi || !d_st || !d_out) && !dry) || !n || !columns || !clusters || !shards || !h_sizes || ld < n || (ld & 3))
         return qvz_set_error(QVZ_E_ARG, "bad plane-coder arguments");
     if (h_bounds) {                                              // the caller's cut of these n reads (a device's part of a larger file)
@@ -2109,7 +2146,9 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     uint32_t *d_clist = nullptr, *d_segpos = nullptr, *d_bounds = nullptr;   // several clusters: read lists per (stream, cluster)
     uint64_t *d_cstart = nullptr;
     bool overlap = false;
-    hipStream_t s_model = nullptr, s_coder = nullptr;
+    hipStream_t s_model = nullptr, s_coder = nullptr, s_quant = nullptr;
+    std::vector<hipEvent_t> evq;                                // fused call: per segment, the quantizer launches' start and end
+    int32_t *d_route = nullptr;
     bool own_streams = true;                                    // false: the device's kept pair (not destroyed here)
     hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> evs;                                // per segment: model start, model end, coder start, coder end
@@ -2234,6 +2273,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
     TRY(area.get((void **)&d_status, sizeof(int32_t)));
     TRY(area.get((void **)&d_cs, shards * sizeof(CoderState)));
+    if (qz) TRY(area.get((void **)&d_route, 2 * sizeof(int32_t)));
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     if (rk_waves) {
@@ -2280,7 +2320,12 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     evs.assign((size_t)nseg * 4, nullptr);
     for (size_t i = 0; i < evs.size(); ++i) TRY(hipEventCreate(&evs[i]));
     g_planes_ms[0] = g_planes_ms[1] = 0.0;
-    s_model = s_coder = st;
+    g_planes_quant_ms = 0.0;
+    if (qz) {
+        evq.assign((size_t)nseg * 2, nullptr);
+        for (size_t i = 0; i < evq.size(); ++i) TRY(hipEventCreate(&evq[i]));
+    }
+    s_model = s_coder = s_quant = st;
     if (overlap) {
         // The two streams are made once per device and kept: the runtime spreads streams over a handful of hardware queues
         // (four by default) and a queue runs its kernels in order, so a pair of streams made afresh for every call lands,
@@ -2289,22 +2334,25 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         // (A high-priority queue for the coder kernel was tried: its segments got slower, 225 ms against 167 ms of kernel
         // time per step with three clusters at 100M x 150, and the step with them.)
         {
-            hipStream_t pair[2] = {nullptr, nullptr};
-            const int how = coder_stream_pair(pair);             // 1: the device's kept pair, 0: none kept for this ordinal, < 0: error (message set)
+            hipStream_t pair[2] = {nullptr, nullptr}, third = nullptr;
+            const int how = coder_stream_pair(pair, qz ? &third : nullptr);   // 1: the device's kept streams, 0: none kept for this ordinal, < 0: error (message set)
             if (how < 0) { rc = how; goto done; }
             if (how == 1) {
                 s_model = pair[0];
                 s_coder = pair[1];
+                if (qz) s_quant = third;
                 own_streams = false;
             } else {
                 TRY(hipStreamCreateWithFlags(&s_model, hipStreamNonBlocking));
                 TRY(hipStreamCreateWithFlags(&s_coder, hipStreamNonBlocking));
+                if (qz) TRY(hipStreamCreateWithFlags(&s_quant, hipStreamNonBlocking));
             }
         }
         TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         TRY(hipEventRecord(ev_start, st));                       // uploads and whatever the caller queued before us
         TRY(hipStreamWaitEvent(s_model, ev_start, 0));
         TRY(hipStreamWaitEvent(s_coder, ev_start, 0));
+        if (qz) TRY(hipStreamWaitEvent(s_quant, ev_start, 0));
     }
     // The coder kernel is the longer of the two once they overlap, and what slows it is the model waves it shares its CUs
     // with (0.11 s alone, 0.16-0.17 s beside three model workgroups per CU, 0.15 s beside two). So when three or more
@@ -2336,6 +2384,25 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         const int is_first = i == 0, is_last = i + 1 == nseg;
         Record *buf = (Record *)((char *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * per_read : 0));
         hipEvent_t *e = &evs[(size_t)i * 4];
+        if (qz) {
+            // The quantizer runs one segment ahead of the model kernels, no more: its launch for segment i + 1 waits for the model
+            // kernel of segment i - 1 (it then shares the chip with model kernel i and coder kernel i - 1), and the planes a model
+            // kernel reads are complete when it starts (evq). Without the other streams: segment by segment on the caller's.
+            auto quantize = [&](uint32_t j) -> int {
+                if (overlap && j >= 2) { hipError_t qe = hipStreamWaitEvent(s_quant, evs[(size_t)(j - 2) * 4 + 1], 0); if (qe != hipSuccess) return qvz_set_error(QVZ_E_HIP, "hipStreamWaitEvent -> %s", hipGetErrorString(qe)); }
+                (void)hipEventRecord(evq[(size_t)j * 2], s_quant);
+                const int qrc = qvz_quantize_launch(*qz, nseg > 1 ? (const uint64_t *)d_first : nullptr, shards, segs[j].first, (uint32_t)segs[j].second, d_route, j == 0, s_quant);
+                if (qrc) return qrc;
+                hipError_t qe = hipEventRecord(evq[(size_t)j * 2 + 1], s_quant);
+                return qe == hipSuccess ? QVZ_OK : qvz_set_error(QVZ_E_HIP, "hipEventRecord -> %s", hipGetErrorString(qe));
+            };
+            if (!overlap) { if ((rc = quantize(i))) goto done; }
+            else {
+                if (i == 0 && (rc = quantize(0))) goto done;
+                if (i + 1 < nseg && (rc = quantize(i + 1))) goto done;
+                TRY(hipStreamWaitEvent(s_model, evq[(size_t)i * 2 + 1], 0));
+            }
+        }
         // Head start for the coder kernel of the segment before: it is released by an event of the model kernel that has
         // just ended, across queues, while the next model kernel follows that one in its own queue at once - and a model
         // kernel that has filled the CUs first leaves a coder workgroup (32 KB of LDS) no room wherever three model
@@ -2430,6 +2497,15 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipEventElapsedTime(&ta, evs[(size_t)i * 4], evs[(size_t)i * 4 + 1]));
         TRY(hipEventElapsedTime(&tb, evs[(size_t)i * 4 + 2], evs[(size_t)i * 4 + 3]));
         g_planes_ms[0] += ta; g_planes_ms[1] += tb;
+        if (qz) {
+            float tq = 0.f, q0 = 0.f;
+            TRY(hipEventElapsedTime(&tq, evq[(size_t)i * 2], evq[(size_t)i * 2 + 1]));
+            g_planes_quant_ms += tq;
+            if (odd_call || getenv("QVZ_CODER_DEBUG")) {
+                (void)hipEventElapsedTime(&q0, evs[0], evq[(size_t)i * 2]);   // (negative where the quantizer started first: an error, the 0 stays)
+                fprintf(stderr, "  segment %u: quantizer %.2f ms, started %.2f ms after the first model kernel's start\n", i, tq, q0);
+            }
+        }
         if (odd_call || getenv("QVZ_CODER_DEBUG")) {             // the segment's kernels on the time line of the call
             float m0 = 0.f, c0 = 0.f;
             TRY(hipEventElapsedTime(&m0, evs[0], evs[(size_t)i * 4]));
@@ -2464,6 +2540,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
 done:
 #undef TRY
     for (size_t i = 0; i < evs.size(); ++i) if (evs[i]) (void)hipEventDestroy(evs[i]);
+    for (size_t i = 0; i < evq.size(); ++i) if (evq[i]) (void)hipEventDestroy(evq[i]);
+    if (s_quant && s_quant != st) { (void)hipStreamSynchronize(s_quant); if (own_streams) (void)hipStreamDestroy(s_quant); }
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (s_model && s_model != st) { (void)hipStreamSynchronize(s_model); if (own_streams) (void)hipStreamDestroy(s_model); }
     if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); if (own_streams) (void)hipStreamDestroy(s_coder); }

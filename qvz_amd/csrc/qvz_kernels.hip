@@ -1739,13 +1739,22 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
                                                   uint64_t ldd, const double *__restrict__ dist,
                                                   uint8_t *__restrict__ qv_out, uint8_t *__restrict__ qi_out,
                                                   uint8_t *__restrict__ st_out, uint64_t ldo, double *__restrict__ err_out,
-                                                  int32_t *__restrict__ status, const int32_t *__restrict__ route) {
+                                                  int32_t *__restrict__ status, const int32_t *__restrict__ route,
+                                                  const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len) {
     __shared__ double sdist[QVZ_A * QVZ_A];
     if (route[1] == QZ_ROUTE_LDS) return;                       // the other kernel's job (qvz_hip_quantize: routing without a host round trip)
     for (uint32_t i = threadIdx.x; i < QVZ_A * QVZ_A; i += 256) sdist[i] = dist[i];
     __syncthreads();
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t i0 = 4 * t;
+    uint64_t i0 = 4 * t;
+    if (first) {                                                 // one segment of every stream (see k_quantize_lds)
+        const uint32_t tps = (seg_len + 3) / 4;
+        const uint64_t g = t / tps;
+        if (g >= shards) return;
+        const uint64_t f0 = first[g], f1 = first[g + 1], hi = f0 + seg_lo + seg_len;
+        i0 = f0 + seg_lo + 4 * (t % tps);
+        n = f1 < hi ? f1 : hi;                                   // reads of this thread's stream in this segment end here
+    }
     if (i0 >= n) return;
     uint32_t lab4 = 0;
     if (labels) lab4 = *reinterpret_cast<const uint32_t *>(labels + i0);
@@ -1815,7 +1824,8 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
                                                              const double *__restrict__ dist, uint8_t *__restrict__ qv_out,
                                                              uint8_t *__restrict__ qi_out, uint8_t *__restrict__ st_out,
                                                              uint64_t ldo, double *__restrict__ err_out,
-                                                             int32_t *__restrict__ status, const int32_t *__restrict__ route) {
+                                                             int32_t *__restrict__ status, const int32_t *__restrict__ route,
+                                                             const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len) {
     extern __shared__ uint4 qz_smem[];
     if (route[1] != QZ_ROUTE_LDS) return;                       // a general distortion matrix: k_quantize does this call
     double *sdist = reinterpret_cast<double *>(qz_smem);         // d(|x - y|), from row 0 of the matrix
@@ -1824,7 +1834,23 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     if (threadIdx.x < QVZ_A) sdist[threadIdx.x] = dist[threadIdx.x];
     const uint64_t t = (uint64_t)blockIdx.x * T + threadIdx.x;
     constexpr int R = 4 * RW;
-    const uint64_t i0 = (uint64_t)R * t;
+    // Which reads this thread takes. Whole matrix: R consecutive reads from R t. One SEGMENT of a sharded encode (`first`): the
+    // launch covers reads [first[g] + seg_lo, .. + seg_len) of every stream g, ceil(seg_len / R) threads per stream - the coder's
+    // model kernel of that segment needs exactly these reads of every stream, so it can start when this launch ends, beside the
+    // launch for the next segment. A thread's reads stay inside one stream's piece; what lies beyond
+    // the piece (or the stream) is neither loaded nor stored: i0 is a multiple of 4 there, not of R.
+    uint64_t i0 = (uint64_t)R * t;
+    if (first) {
+        const uint32_t tps = (seg_len + R - 1) / R;
+        const uint64_t g = t / tps;
+        if (g < shards) {
+            const uint64_t f0 = first[g], f1 = first[g + 1], hi = f0 + seg_lo + seg_len;
+            i0 = f0 + seg_lo + (uint64_t)R * (t % tps);
+            n = f1 < hi ? f1 : hi;                               // this thread's reads end here
+        } else {
+            n = 0;
+        }
+    }
     const bool active = i0 < n;                                  // idle threads still copy tables and meet the barriers
     uint32_t cbase[R], prev[R];                                  // cluster's table base in the column buffer, in u16
     double err[R];
@@ -1894,11 +1920,14 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
     // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
     const uint64_t io = active ? i0 : 0;
+    uint32_t woff[RW];                                           // a dword wholly beyond the thread's reads is not touched: its loads go to the thread's first dword
+#pragma unroll
+    for (int w = 0; w < RW; ++w) woff[w] = active && i0 + 4 * w < n ? 4u * w : 0u;
     uint32_t x4n[RW], d4n[RW];
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
-        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + io + 4 * w));
-        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + io + 4 * w));        // 7-bit draws, same layout
+        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + io + woff[w]));
+        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + io + woff[w]));      // 7-bit draws, same layout
     }
     for (uint32_t s = 0; s < C; ++s) {
         const uint16_t *cur = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s & 1) * per_col4 : 0u));
@@ -1909,8 +1938,8 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
             fetch(s + 1);
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
-                x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io + 4 * w));
-                d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io + 4 * w));
+                x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io + woff[w]));
+                d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io + woff[w]));
             }
         }
 #pragma unroll
@@ -1937,9 +1966,11 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
         if (active) {
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
-                if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0 + 4 * w) = qv4[w];
-                if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0 + 4 * w) = qi4[w];
-                if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0 + 4 * w) = st4[w];
+                if (w == 0 || woff[w]) {                         // (a dword beyond the thread's reads belongs to somebody else)
+                    if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0 + 4 * w) = qv4[w];
+                    if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0 + 4 * w) = qi4[w];
+                    if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0 + 4 * w) = st4[w];
+                }
             }
         }
         if (s + 1 < C) {
@@ -1956,63 +1987,77 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     if (dead || ctxmax == QVZ_NOT_FOUND) atomicOr(status, 1);
 }
 
+int qvz_quantize_check(const QvzQuantArgs &a) {
+    int rc = check_matrix(a.n, a.c, a.ld);
+    if (rc) return rc;
+    if ((rc = check_matrix(a.n, a.c, a.ld_draws))) return rc;
+    if ((a.d_qv || a.d_qi || a.d_st) && (rc = check_matrix(a.n, a.c, a.ld_out))) return rc;
+    if (a.k == 0 || a.k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", a.k);
+    if (a.k > 1 && !a.d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
+    if (!a.d_ct || !a.d_qs || !a.d_draws || !a.d_dist || !a.d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
+    return QVZ_OK;
+}
+
+int qvz_quantize_launch(const QvzQuantArgs &a, const uint64_t *d_first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len,
+                        int32_t *d_route, bool decide, hipStream_t stream) {
+    const uint64_t n = a.n;
+    const uint32_t c = a.c, k = a.k;
+    const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // development knob: "global" keeps the tables in L1/L2
+    const bool lds_possible = k <= 3 && !(force && strcmp(force, "global") == 0);
+    // [0] mirrors nothing (the kernels write the caller's d_status); [1] = route of this call
+    if (decide) hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, stream, a.d_dist, d_route + 1, lds_possible ? 1 : 0);
+    QVZ_HIP_CHECK(hipGetLastError());
+    // threads' worth of reads: the whole matrix, or ceil(seg_len / R) threads for every stream's piece of the segment
+    auto threads_for = [&](uint32_t R) -> uint64_t {
+        return d_first ? (uint64_t)shards * ((seg_len + R - 1) / R) : (n + R - 1) / R;
+    };
+    if (lds_possible) {
+        // dwords (4 reads each) per thread: 8 reads = 8 independent chains (22.6 -> 20.4 ms at 100M x 150 with one cluster)
+        // Three clusters: a column's tables are 63 KB, copied from L2 by every workgroup for every column - with 512
+        // threads x 4 reads that was 459 GB of copies per step at 100M x 150. 1024-thread workgroups with eight reads
+        // per thread copy a quarter of that: 43.2 -> 27.5 ms (1024 threads x 4 reads: 39.4; eight reads per thread in
+        // 512-thread workgroups had been slower than four). QVZ_QUANTIZE_T / _RW are development knobs.
+        const int wide = k == 3 && !(getenv("QVZ_QUANTIZE_T") && atoi(getenv("QVZ_QUANTIZE_T")) == 512);
+        const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 || wide ? 2 : 1);
+        const uint64_t tpw = wide ? 1024 : QZ_THREADS, nthreads = threads_for(rw == 2 ? 8 : 4);
+        dim3 grid((unsigned)((nthreads + tpw - 1) / tpw));
+        const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
+#define QZ_LAUNCH(NBUF, NQ, RWV, TT)                                                                                             \
+        do {                                                                                                                     \
+            QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT>),                \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+            hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT>), grid, dim3(TT), lds, stream, a.d_sym,                        \
+                               k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
+                               a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);                \
+        } while (0)
+        static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4 &&
+                      4 * 1024 >= 3 * QZ_CLUSTER4, "stage registers");
+        if (k == 1) { if (rw == 2) QZ_LAUNCH(2, 3, 2, QZ_THREADS); else QZ_LAUNCH(2, 3, 1, QZ_THREADS); }
+        else if (k == 2) { if (rw == 2) QZ_LAUNCH(2, 6, 2, QZ_THREADS); else QZ_LAUNCH(2, 6, 1, QZ_THREADS); }
+        else if (wide) { if (rw == 2) QZ_LAUNCH(1, 4, 2, 1024); else QZ_LAUNCH(1, 4, 1, 1024); }
+        else { if (rw == 2) QZ_LAUNCH(1, 8, 2, QZ_THREADS); else QZ_LAUNCH(1, 8, 1, QZ_THREADS); }
+#undef QZ_LAUNCH
+    }
+    dim3 grid((unsigned)((threads_for(4) + 255) / 256));
+    hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, stream, a.d_sym, k > 1 ? a.d_labels : nullptr, n, c, a.ld,
+                       a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, a.d_st, a.ld_out, a.d_err, a.d_status, d_route,
+                       d_first, shards, seg_lo, seg_len);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
 extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
                                 uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
                                 uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
                                 uint64_t ld_out, double *d_err, int32_t *d_status, void *stream) {
-    int rc = check_matrix(n, c, ld);
+    const QvzQuantArgs a = {d_sym, d_labels, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status};
+    const int rc = qvz_quantize_check(a);
     if (rc) return rc;
-    if ((rc = check_matrix(n, c, ld_draws))) return rc;
-    if ((d_qv || d_qi || d_st) && (rc = check_matrix(n, c, ld_out))) return rc;
-    if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
-    if (k > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
-    if (!d_ct || !d_qs || !d_draws || !d_dist || !d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
-    uint64_t n4 = (n + 3) / 4;
-    const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // development knob: "global" keeps the tables in L1/L2
-    const bool lds_possible = k <= 3 && !(force && strcmp(force, "global") == 0);
     // the route word lives behind the caller's status word in this device's scratch pair (stream-ordered like the rest of it)
-    int32_t *d_route = nullptr;
-    {
-        ScratchLock lk((hipStream_t)stream);
-        if (lk.rc) return lk.rc;
-        if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, 2 * sizeof(int32_t)));
-        d_route = lk.d->d_route;
-        // [0] mirrors nothing (the kernels write the caller's d_status); [1] = route of this call
-        hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, (hipStream_t)stream, d_dist, d_route + 1, lds_possible ? 1 : 0);
-        QVZ_HIP_CHECK(hipGetLastError());
-        if (lds_possible) {
-            // dwords (4 reads each) per thread: 8 reads = 8 independent chains (22.6 -> 20.4 ms at 100M x 150 with one cluster)
-            // Three clusters: a column's tables are 63 KB, copied from L2 by every workgroup for every column - with 512
-            // threads x 4 reads that was 459 GB of copies per step at 100M x 150. 1024-thread workgroups with eight reads
-            // per thread copy a quarter of that: 43.2 -> 27.5 ms (1024 threads x 4 reads: 39.4; eight reads per thread in
-            // 512-thread workgroups had been slower than four). QVZ_QUANTIZE_T / _RW are development knobs.
-            const int wide = k == 3 && !(getenv("QVZ_QUANTIZE_T") && atoi(getenv("QVZ_QUANTIZE_T")) == 512);
-            const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 || wide ? 2 : 1);
-            const uint64_t per_wg = (uint64_t)(wide ? 1024 : QZ_THREADS) * (rw == 2 ? 2 : 1);
-            dim3 grid((unsigned)((n4 + per_wg - 1) / per_wg));
-            const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
-#define QZ_LAUNCH(NBUF, NQ, RWV, TT)                                                                                             \
-            do {                                                                                                                 \
-                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT>),            \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT>), grid, dim3(TT), lds, (hipStream_t)stream, d_sym,         \
-                                   k > 1 ? d_labels : nullptr, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi,   \
-                                   d_st, ld_out, d_err, d_status, d_route);                                                      \
-            } while (0)
-            static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4 &&
-                          4 * 1024 >= 3 * QZ_CLUSTER4, "stage registers");
-            if (k == 1) { if (rw == 2) QZ_LAUNCH(2, 3, 2, QZ_THREADS); else QZ_LAUNCH(2, 3, 1, QZ_THREADS); }
-            else if (k == 2) { if (rw == 2) QZ_LAUNCH(2, 6, 2, QZ_THREADS); else QZ_LAUNCH(2, 6, 1, QZ_THREADS); }
-            else if (wide) { if (rw == 2) QZ_LAUNCH(1, 4, 2, 1024); else QZ_LAUNCH(1, 4, 1, 1024); }
-            else { if (rw == 2) QZ_LAUNCH(1, 8, 2, QZ_THREADS); else QZ_LAUNCH(1, 8, 1, QZ_THREADS); }
-#undef QZ_LAUNCH
-        }
-        dim3 grid((unsigned)((n4 + 255) / 256));
-        hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, (hipStream_t)stream, d_sym, k > 1 ? d_labels : nullptr, n, c, ld,
-                           d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status, d_route);
-    }
-    QVZ_HIP_CHECK(hipGetLastError());
-    return QVZ_OK;
+    ScratchLock lk((hipStream_t)stream);
+    if (lk.rc) return lk.rc;
+    if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, 2 * sizeof(int32_t)));
+    return qvz_quantize_launch(a, nullptr, 0, 0, 0, lk.d->d_route, true, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -273,11 +273,13 @@ def planes_bytes_per_read(shards, columns, k):
 
 
 def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True,
-                      work_bytes=None, bounds=None):
+                      work_bytes=None, bounds=None, quant=None):
     """GPU sharded coder fed from the quantizer's planes (qvz_hip_encode_planes): the model runs with a lane per
     (stream, column), the interval arithmetic with a lane per stream. qi/st: (columns, ld) uint8 device tensors.
     work_bytes: size of the record workspace (default: everything at once, capped at 96 GiB).
     bounds: the cut into shards (shards + 1 read numbers, every start a multiple of 4; default qvz_shard_bounds).
+    quant: None = the planes are there. Otherwise the quantizer's inputs - dict(sym, ct, qs, draws, dist, qv|None, err|None,
+    status): the planes are MADE by this call, segment by segment beside the coder's kernels (qvz_hip_quantize_encode_planes).
     Returns (sizes, streams|None, out_tensor)."""
     import torch
     k = len(codebook_handles)
@@ -306,7 +308,15 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     sizes = (C.c_uint64 * shards)()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lab = C.c_void_p(labels.data_ptr()) if labels is not None else None
-    if bounds is None:
+    if quant is not None:
+        def ptr(t):
+            return C.c_void_p(t.data_ptr()) if t is not None else None
+        hb = (C.c_uint64 * (shards + 1))(*[int(b) for b in bounds]) if bounds is not None else None
+        rc = lib().qvz_hip_quantize_encode_planes(ptr(quant["sym"]), lab, n, columns, quant["sym"].shape[1], k, ptr(quant["ct"]), ptr(quant["qs"]),
+                                                  ptr(quant["draws"]), quant["draws"].shape[1], ptr(quant["dist"]), ptr(quant.get("qv")),
+                                                  ptr(qi), ptr(st), ld, ptr(quant.get("err")), ptr(quant["status"]), arr, shards, hb,
+                                                  C.c_void_p(out.data_ptr()), cap_per_shard, sizes, C.c_void_p(work.data_ptr()), work_bytes, stream)
+    elif bounds is None:
         rc = lib().qvz_hip_encode_planes(C.c_void_p(qi.data_ptr()), C.c_void_p(st.data_ptr()), ld, lab, n, columns, k, arr, shards,
                                          C.c_void_p(out.data_ptr()), cap_per_shard, sizes, C.c_void_p(work.data_ptr()), work_bytes,
                                          stream)
@@ -320,6 +330,7 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     a, b = C.c_double(), C.c_double()
     lib().qvz_hip_encode_planes_last_ms(C.byref(a), C.byref(b))
     encode_planes_gpu.last_ms = (a.value, b.value)      # (model kernels, coder kernels) of this call
+    encode_planes_gpu.last_quant_ms = lib().qvz_hip_encode_planes_last_quant_ms() if quant is not None else None
     sizes = [int(x) for x in sizes]
     streams = None
     if want_streams:

@@ -145,16 +145,23 @@ def quantize(sym, n, ct, qs, draws, dist, labels=None, k=1, want=("qv", "qi", "s
     (well_draws)."""
     c, ld = _dims(sym, n)
     assert draws.shape == sym.shape and draws.dtype == torch.uint8
+    out = quantize_outputs(sym, n, want)
+    status = out["status"]
+    check(lib().qvz_hip_quantize(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(ct), _ptr(qs), _ptr(draws), ld,
+                                 _ptr(dist), _ptr(out["qv"]), _ptr(out["qi"]), _ptr(out["st"]), ld, _ptr(out["err"]),
+                                 _ptr(status), _stream()))
+    return out
+
+
+def quantize_outputs(sym, n, want):
+    """The quantizer's output planes (None where not wanted), per-read errors and status word, allocated."""
+    c, ld = _dims(sym, n)
     dev = sym.device
     out = {}
     for name in ("qv", "qi", "st"):
         out[name] = torch.empty((c, ld), dtype=torch.uint8, device=dev) if name in want else None
     out["err"] = torch.empty(n, dtype=torch.float64, device=dev) if "err" in want else None
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(lib().qvz_hip_quantize(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(ct), _ptr(qs), _ptr(draws), ld,
-                                 _ptr(dist), _ptr(out["qv"]), _ptr(out["qi"]), _ptr(out["st"]), ld, _ptr(out["err"]),
-                                 _ptr(status), _stream()))
-    out["status"] = status
+    out["status"] = torch.zeros(1, dtype=torch.int32, device=dev)
     return out
 
 

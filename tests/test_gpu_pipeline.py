@@ -120,6 +120,33 @@ def test_gpu_coder_streams_equal_host_coder_streams(name, shards, monkeypatch):
             assert b["streams"][0] == G.gz(name + ".q.gz")[-G.CASES[name]["size"]:]
 
 
+@pytest.mark.parametrize("name,shards,k", [("cfg1_f05_L", 4, None), ("cfg1_f05_L", 16, None), ("t2k_c3_f05_M", 1, None), ("t2k_c3_f05_M", 4, None), ("rescale_140k_c4", 24, None),
+                                           ("rescale_140k_c4", 3, 5), ("tiny5_r10", 2, None), ("wide_c151", 2, None)])
+def test_quantizer_inside_the_coder_pipeline_changes_nothing(name, shards, k, monkeypatch):
+    """qvz_hip_quantize_encode_planes launches the quantizer once per coder segment, for that segment's reads of every stream,
+    beside the coder's kernels; the planes, the per-read errors and the streams must be those of one quantizer launch followed by
+    the coder (the default; the pipeline form is QVZ_FUSED_QUANTIZE=1) - with the streams cut into many segments, few, and one, and with more clusters than the
+    LDS quantizer holds (k = 5: the other quantizer kernel)."""
+    from qvz_amd import host, pipeline as P
+    rows, opts, n, c, sym, means0 = setup_case(name)
+    if k is not None:
+        lines = P.reference_centroid_lines(n, k)
+        means0 = torch.from_numpy(np.stack([rows[i, :c] - 33 for i in lines]).astype(np.uint8)).cuda()
+    kw = dict(clusters=k or opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=shards, keep=True, coder="gpu")
+    a = P.encode_pass(sym, n, 0, n, means0, **kw)
+    assert "coder_quantize_kernels" not in a["wall"]
+    monkeypatch.setenv("QVZ_FUSED_QUANTIZE", "1")
+    per_read = host.planes_bytes_per_read(shards, c, kw["clusters"])
+    for work in (None, per_read * 8, per_read * 256):
+        b = P.encode_pass(sym, n, 0, n, means0, work_bytes=work, **kw)
+        assert b["wall"]["coder_quantize_kernels"] > 0.0
+        assert b["streams"] == a["streams"], f"streams differ (workspace {work})"
+        for key in ("qv", "qi", "st"):
+            assert torch.equal(a[key][:, :n], b[key][:, :n]), f"{key} differs (workspace {work})"
+        assert torch.equal(a["err"], b["err"]), f"per-read distortion differs (workspace {work})"
+        assert a["distortion"] == b["distortion"]
+
+
 def test_one_newton_step_is_enough_on_this_device(monkeypatch):
     """The coder's loaders refine v_rcp_f64 with ONE Newton step when that is within 2^-47 of 1 / (n 2^10) for every n a packed
     record can hold - the proof at `Record` needs 2^-46 - and the library measures it over all n = 1 .. 2^19 + 1024 before it
