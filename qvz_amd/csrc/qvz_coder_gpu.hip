@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 #include <stdint.h>
@@ -730,7 +731,7 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 // Table state crosses segment boundaries through `save` (one slice per (stream, column)).
 #define RK_NONE 0xFFFFu
 #ifdef QVZ_PROFILE          // development build (make HIPFLAGS+=-DQVZ_PROFILE): shader-clock cycles per section of the chunk loop, summed over waves
-__device__ unsigned long long g_rk_prof[8];
+__device__ unsigned long long g_rk_prof[16];   // [7] prologue, [8] table save, [9] passes, [10] whole pass, [11] .. [13] prologue: to the tables in LDS, the barrier, the first look-up; [14] first passes' prologue
 __device__ unsigned long long g_cr_prof[16];
 __device__ uint32_t g_cr_simd[8];   // SIMD of every wave of one k_code_records workgroup (HW_ID bits 5:4)
 __device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no record store, 2 no transposition/barriers, 4 no cumulative loop, 8 no table update, 16 no timers
@@ -821,7 +822,8 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                                                       uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       uint32_t log2w, Record *__restrict__ rec, int32_t *__restrict__ status,
                                                       const uint32_t *__restrict__ clist, const uint64_t *__restrict__ cstart,
-                                                      const uint32_t *__restrict__ segpos_lo, const uint32_t *__restrict__ segpos_hi) {
+                                                      const uint32_t *__restrict__ segpos_lo, const uint32_t *__restrict__ segpos_hi,
+                                                      const uint32_t *__restrict__ cgmap) {
     // records between consecutive units of a stream: 512 = 8 records x 64 interleaved streams (rec_index, the coder
     // kernel's layout); DENSE: one stream alone, its units back to back (qvz_hip_model_session_records)
     // REC8: packed 8-byte records, units of 16 (rec8_index): 1024 records between consecutive units of a stream
@@ -846,6 +848,16 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         g = (uint32_t)(pair % gridDim.x);
         cg = (uint32_t)(pair / gridDim.x);
     }
+    // cgmap: this launch serves the column groups whose tables fit the LDS it was given (the host's size classes, see
+    // qvz_hip_encode_planes). Entry i of the launch: the column group, then per wave (where its part of the LDS starts, in words) |
+    // (words of its largest slice) << 16 - a wave has room for ITS column's tables, not for the largest column's.
+    uint32_t wave_lay = (wave * (3 * slice_cap + 2 * A)) | slice_cap << 16;
+    if (cgmap) {
+        const uint32_t *ent = cgmap + (size_t)cg * (1 + W);
+        cg = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[0]);
+        wave_lay = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[1 + wave]);
+    }
+    const uint32_t wave_off = wave_lay & 0xFFFFu, wave_cap = wave_lay >> 16;
     const uint32_t sx = cg * W + wave;                           // position in the read's record group
     const bool lists = HAVE_LABELS && cg * W >= QVZ_CID_SLOTS;   // this workgroup walks cluster z's reads
     if (HAVE_LABELS && !lists && z) return;                      // the reserved positions belong to the z = 0 workgroups
@@ -862,9 +874,26 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // in, the cluster's read list walked, tables out) instead of one workgroup per cluster: a third as many workgroups to dispatch
     // and start per segment, the same lines of the planes out of the same L2.
     const uint32_t nz = HAVE_LABELS && lists && gridDim.z == 1 ? K : 1u;
+    // ... and what a pass needs before its first chunk is asked for during the pass before it (PF: the instantiations that walk
+    // lists): the list entries of its first eight chunks at that pass's start, the bytes of its first four chunks and its tables
+    // at the first `park` of that pass whose own request would lie beyond the pass's reads - into the very registers the request
+    // would have filled (the bytes); the tables are only pulled into L2. Measured before this (cycle counters of a
+    // -DQVZ_PROFILE build, three clusters at 100M x 150): a pass waited 10 100 cycles - two dependent memory round trips: list
+    // entries, then the bytes of those reads - of its 79 300 before its first chunk.
+    constexpr bool PF = HAVE_LABELS && REC8 && !DENSE;
+    typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t q_nx[4], x_nx[4];                                   // the bytes requested for the four chunks after the current four
+    uint32_t r_pfa[4] = {0, 0, 0, 0}, r_pfb[4] = {0, 0, 0, 0};   // PF: list entries of the next pass's chunks 0-3 / 4-7
+    uint32_t t_pf = 0;                                           // PF: a word of every line of the next pass's tables (pulls them into L2; never looked at)
+    bool pf_lists = false, pf_rest = false;                      // (wave-uniform) what has been asked for on behalf of the next pass
     for (uint32_t zi = 0; zi < nz; ++zi) {
     if (zi) __syncthreads();                                     // the pass before has drained its last chunk (recbuf, row slots)
+#ifdef QVZ_PROFILE
+    const unsigned long long tpass = __builtin_readcyclecounter();
+#endif
     if (nz > 1) z = zi;
+    const bool from_lists = PF && pf_lists, from_rest = PF && pf_rest;   // what the pass before has asked for on behalf of this one
+    pf_lists = pf_rest = false;
     uint32_t nr = rend - r0 < seg_reads ? (uint32_t)(rend - r0) : seg_reads;   // reads of this stream in this segment
     const uint32_t *lp = nullptr;                                // list entries of this segment (stream-relative read numbers)
     if (lists) {
@@ -888,9 +917,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // per wave: lane masks [slice_cap] u64, tables [slice_cap] u32, and per quantizer of the column its table's
     // offset in the slice | alphabet size << 16 (RK_NONE, size 0: no table), so that one LDS read resolves a symbol
     unsigned long long *msk = (REC8 ? reinterpret_cast<unsigned long long *>(rows8 + (HAVE_LABELS ? 256 : 0))
-                                    : reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride)) + (size_t)wave * ((3 * slice_cap + 2 * A) / 2);
-    uint32_t *tab = reinterpret_cast<uint32_t *>(msk + slice_cap);
-    uint32_t *cof = tab + slice_cap;
+                                    : reinterpret_cast<unsigned long long *>(recbuf + 64 * rb_stride)) + wave_off / 2;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(msk + wave_cap);
+    uint32_t *cof = tab + wave_cap;
     const bool cluster_wave = HAVE_LABELS && sx == 0;
     const bool active = HAVE_LABELS ? (cluster_wave || (lists && sx < Cx)) : sx < Cx;
     const uint32_t s = HAVE_LABELS ? sx - QVZ_CID_SLOTS : sx;
@@ -915,7 +944,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // of a plane) and keeps them in registers until the current four are used up, so the HBM latency stays off the chunk
     // loop and nothing is staged through LDS. No bounds branch: a read index past the stream's last read is clamped to
     // it, idle waves read plane 0, and `on` below ignores what such lanes loaded.
-    uint32_t q_cur = 0, x_cur = 0, lab_cur = 0, q_nx[4], x_nx[4], lab_nx[4] = {0, 0, 0, 0};
+    uint32_t q_cur = 0, x_cur = 0, lab_cur = 0, lab_nx[4] = {0, 0, 0, 0};
     uint32_t r_cur[4] = {0, 0, 0, 0}, r_nx[4] = {0, 0, 0, 0}, r_nn[4] = {0, 0, 0, 0};   // lists: stream-relative read numbers
     const uint8_t *const qplane = qi + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + (lists ? f0 : r0);
     const uint8_t *const xplane = st + (uint64_t)(active && !cluster_wave ? s : 0u) * ld + (lists ? f0 : r0);
@@ -964,6 +993,10 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         bad = bad || (on && !ok);
         tb_nx = tbs; x_lk = ok ? x : 0u; card_nx = card; ok_nx = ok;
     };
+    // PF: the pass after this one - its reads, its tables
+    uint32_t nrN = 0, n4N = 0;
+    const uint32_t *lpN = nullptr;
+    const uint4 *srcN = nullptr;
     auto park = [&](uint32_t ro) {                               // the requested bytes become the current block; request the next
         q_cur = q_nx[0] | q_nx[1] << 8 | q_nx[2] << 16 | q_nx[3] << 24;
         x_cur = x_nx[0] | x_nx[1] << 8 | x_nx[2] << 16 | x_nx[3] << 24;
@@ -971,8 +1004,29 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         if (lists) {                                             // read numbers: current <- next <- the list entries requested a block ago
 #pragma unroll
             for (int j = 0; j < 4; ++j) { r_cur[j] = r_nx[j]; r_nx[j] = r_nn[j]; }
-            fetch_list(ro + 512);
         }
+        if (PF && pf_lists && ro + 256 >= nr) {
+            // nothing of this pass is left to ask for: the first bytes of the next pass (its list entries were asked for when this
+            // pass began) and its tables instead. No `park` follows in this pass (the chunk loop skips them: q_nx / x_nx stay).
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                q_nx[j] = qplane[r_pfa[j]];
+                x_nx[j] = xplane[r_pfa[j]];
+            }
+            if (active) {
+                // the tables: there are no registers to hold them through the chunks that are left (the loop's 115 and these 16
+                // would spill), so they are only pulled into L2: one load, lane i taking a word of the slice's i-th 128-byte line
+                // (8 KB: more than a slice this kernel's LDS could hold), its result kept until the pass ends and never looked at.
+                // (An atomic load of wavefront scope is a plain global_load_dword that the compiler neither moves nor drops and
+                // whose return it counts itself - hand-issued loads into a register nobody reads would land in whatever the
+                // register has become by then.)
+                const uint32_t words = 4 * n4N, w = lane * 32;
+                t_pf = __hip_atomic_load(reinterpret_cast<const uint32_t *>(srcN) + (w < words ? w : words - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            pf_rest = true;
+            return;
+        }
+        if (lists) fetch_list(ro + 512);
         fetch(ro + 256);
     };
     // Before the first chunk a workgroup needs its tables in LDS and the bytes of its first reads in registers: the list entries
@@ -980,8 +1034,10 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // memory round trip where the order tables, barrier, list entries, bytes made three or four. A workgroup lives for some twenty
     // chunks, so what it does before the first one counts.
     if (lists) {
-        fetch_list(0);
-        fetch_list_second(256);
+        if (!from_lists) {
+            fetch_list(0);
+            fetch_list_second(256);
+        }
     } else {
         fetch(0);
     }
@@ -1001,7 +1057,6 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 cv[u] = coff[(uint64_t)slice * 2 * A + (i < 2 * A ? i : 2 * A - 1)];
             }
         }
-        typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
         for (uint32_t i0 = 0; i0 < n4; i0 += 256) {
             rk_u32x4 v[4];
 #pragma unroll
@@ -1031,17 +1086,47 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
     if (lists) {                                                 // the list entries have landed (the tables' wait): now the bytes of those reads
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r_nx[j] = r_nn[j];
+        for (int j = 0; j < 4; ++j) r_nx[j] = from_lists ? r_pfa[j] : r_nn[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r_nn[j] = r_n2[j];
-        fetch(0);
+        for (int j = 0; j < 4; ++j) r_nn[j] = from_lists ? r_pfb[j] : r_n2[j];
+        if (!from_rest) fetch(0);                                // (from_rest: q_nx / x_nx hold them)
     }
+    if (PF && nz > 1 && zi + 1 < nz) {
+        // the next pass: where its list entries, tables and offsets are; its first list entries are asked for now
+        const uint32_t zN = zi + 1;
+        const uint32_t j0 = segpos_lo[g * K + zN], j1 = segpos_hi[g * K + zN];
+        nrN = (uint32_t)__builtin_amdgcn_readfirstlane((int)(j1 - j0));
+        lpN = clist + uniform64(cstart[g * K + zN]) + j0;
+        uint32_t swN = 0;
+        if (active) {
+            const uint32_t sliceN = 1u + s * K + zN, b0N = colbase[sliceN];
+            swN = colbase[sliceN + 1] - b0N;
+            srcN = reinterpret_cast<const uint4 *>(is_first ? tmpl + b0N : save + (uint64_t)g * total_words + b0N);
+        }
+        n4N = (uint32_t)__builtin_amdgcn_readfirstlane((int)(swN / 4));
+        if (nrN && (!active || n4N)) {                           // (a next pass without a read passes its tables through by itself)
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t e = j * 64 + lane, e2 = 256 + e;
+                r_pfa[j] = lpN[e < nrN ? e : nrN - 1];
+                r_pfb[j] = lpN[e2 < nrN ? e2 : nrN - 1];
+            }
+            pf_lists = true;
+        }
+    }
+#ifdef QVZ_PROFILE
+    const unsigned long long tp1 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef QVZ_PROFILE
+    const unsigned long long tp2 = __builtin_readcyclecounter();
+#endif
     park(0);
     lookup(0, 0);
 #ifdef QVZ_PROFILE
     const int exp_ = __builtin_amdgcn_readfirstlane(g_rk_exp);
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    const unsigned long long tloop = tprev;
 #endif
     for (uint32_t rb = 0; rb < nr; rb += 64, ++chunk) {       // rb = read offset in the segment
         Record outr = make_double2(0.0, 0.0);
@@ -1197,7 +1282,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             const uint32_t row = lists ? *rowslot(rd, chunk & 3) : rb + rd;
             // The input bytes of chunks c+2 .. c+5 are taken over here (and the following four requested): the wait for
             // them also waits for every store issued so far, and at this point the latest one is a whole chunk old.
-            if (((chunk + 2) & 3) == 0) park(rb + 128);
+            if (((chunk + 2) & 3) == 0 && !(PF && pf_rest)) park(rb + 128);
             if (rb + rd < nr && col < Cp) {                      // columns Cx .. Cp-1 belong to idle waves: zero records
                 RK_EXP(1) {
                 if (REC8) RK_STORE8(&rec8_g[((uint64_t)(row >> 2) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 3) * 4 + (col & 3)], recbuf8[rd * rb_stride + cw]);
@@ -1211,8 +1296,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     if (lane == 0 && (g & 127) == 5 && (cg & 7) == 3) {             // a sample of the workgroups: same-address atomics are slow
         for (int i = 0; i < 6; ++i) atomicAdd(&g_rk_prof[i], prof[i]);
         atomicAdd(&g_rk_prof[6], (unsigned long long)chunk);
+        atomicAdd(&g_rk_prof[7], tloop - tpass);
+        atomicAdd(&g_rk_prof[11], tp1 - tpass); atomicAdd(&g_rk_prof[12], tp2 - tp1); atomicAdd(&g_rk_prof[13], tloop - tp2);
+        if (zi == 0) atomicAdd(&g_rk_prof[14], tloop - tpass);
+        atomicAdd(&g_rk_prof[9], 1ull);
     }
+    const unsigned long long tsave = __builtin_readcyclecounter();
 #endif
+    if (PF) asm volatile("" : : "v"(t_pf));                      // (the L2 pull's result is needed up to here, as far as the compiler can tell)
     if (active && !is_last)
         for (uint32_t i = lane; i < sw / 4; i += 64) {           // (read again a segment later: the non-temporal hint, as for the records)
             typedef uint32_t rk_u32x4s __attribute__((ext_vector_type(4)));
@@ -1220,6 +1311,13 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             rk_u32x4s w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
             __builtin_nontemporal_store(w, reinterpret_cast<rk_u32x4s *>(save + (uint64_t)g * total_words + b0) + i);
         }
+#ifdef QVZ_PROFILE
+    if (lane == 0 && (g & 127) == 5 && (cg & 7) == 3) {
+        const unsigned long long tend = __builtin_readcyclecounter();
+        atomicAdd(&g_rk_prof[8], tend - tsave);
+        atomicAdd(&g_rk_prof[10], tend - tpass);
+    }
+#endif
     }                                                            // clusters of this workgroup
     if (bad) atomicOr(status, 1);
 }
@@ -1977,16 +2075,35 @@ static void coder_segments(uint64_t longest, uint64_t seg_reads, bool overlap, s
         // the middle in nm segments of whole 64-read chunks that differ by one chunk at most (cut as "each, each, .., the rest"
         // the rest could be a fifth of a segment: a table save and load per workgroup for a handful of chunks)
         const uint64_t units = mid / 64;                                          // q and tail_lo are multiples of 64
-        uint64_t nm = (mid + seg_reads - 1) / seg_reads;
+        uint64_t nm = (units + seg_reads / 64 - 1) / (seg_reads / 64);           // (whole chunks: a seg_reads that is no multiple of 64 is not exceeded either)
         if (nm == 0) nm = 1;
-        const uint64_t base = units / nm, extra = units % nm;                    // `extra` segments get one chunk more
         if (q) segs.push_back({0, q});
         uint64_t lo = q;
-        for (uint64_t i = 0; i < nm && lo < tail_lo; ++i) {
-            uint64_t len = (base + (i < extra ? 1 : 0)) * 64;
-            if (i + 1 == nm || lo + len > tail_lo) len = tail_lo - lo;            // (mid is a multiple of 64: the last one ends on tail_lo)
-            if (len) segs.push_back({lo, len});
-            lo += len;
+        if (first_div == 1 && units >= 4) {
+            // Where the model kernels bound the phase the coder kernel of the last middle segment must not outlast the (short) last
+            // model kernel, or the last coder kernel starts late: the last middle segment is 0.72 of the others. Three clusters at
+            // 100M x 150 (reads per segment, coder phase): 4096 3520 3520 1072: 181.4 ms; 4096 4096 2944 1072: 178.5;
+            // 4096 4096 2432 1584: 178.9; 4096 3072 3072 1968: 180.2; 4096 4096 4016: 186.2 (model kernels 149.5 instead of 163 -
+            // a segment costs them 14 ms whatever its length - but the last coder kernel then runs alone for 35 ms).
+            const uint64_t S = seg_reads / 64;                                    // in 64-read chunks: nm - 1 segments of `each`, the last the rest (~0.72 each)
+            nm = (units * 100 + 28 * S + 100 * S - 1) / (100 * S);                // ceil(units / S + 0.28)
+            if (nm == 0) nm = 1;
+            uint64_t each = nm > 1 ? (units * 100 + (nm * 100 - 28) - 1) / (nm * 100 - 28) : units;
+            if (each > S) each = S;
+            while (nm > 1 && (nm - 1) * each >= units) --nm;                      // (the last one would be empty)
+            for (uint64_t i = 0; i < nm; ++i) {
+                const uint64_t len = i + 1 == nm ? tail_lo - lo : each * 64;
+                segs.push_back({lo, len});
+                lo += len;
+            }
+        } else {
+            const uint64_t base = units / nm, extra = units % nm;                // `extra` segments get one chunk more
+            for (uint64_t i = 0; i < nm && lo < tail_lo; ++i) {
+                uint64_t len = (base + (i < extra ? 1 : 0)) * 64;
+                if (i + 1 == nm || lo + len > tail_lo) len = tail_lo - lo;        // (mid is a multiple of 64: the last one ends on tail_lo)
+                if (len) segs.push_back({lo, len});
+                lo += len;
+            }
         }
         segs.push_back({tail_lo, longest - tail_lo});
         // (Halving the last full segment - and its second half again - so that less of the coder's work is left when the last
@@ -2144,6 +2261,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     uint32_t *d_slices = nullptr, *d_colbase = nullptr, *d_save = nullptr;
     uint32_t *d_coff = nullptr;
     uint32_t *d_clist = nullptr, *d_segpos = nullptr, *d_bounds = nullptr;   // several clusters: read lists per (stream, cluster)
+    struct RkClass { uint32_t off, count, cap; size_t lds; };    // several clusters: column groups by the LDS their tables need
+    std::vector<RkClass> rk_classes;
+    std::vector<uint32_t> h_cgmap;
+    uint32_t *d_cgmap = nullptr;
     uint64_t *d_cstart = nullptr;
     bool overlap = false;
     hipStream_t s_model = nullptr, s_coder = nullptr, s_quant = nullptr;
@@ -2185,9 +2306,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
             // beside k_code_records' 32 KB of LDS (measured with three clusters, where LDS holds one such workgroup
             // per CU: W = 4 0.40 s, W = 2 0.42 s, W = 1 0.67 s for the model kernels; W = 8 never paid).
             const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
-            auto need_of = [&](uint32_t w) {                     // records (16 bytes: list rows in their padding; packed: 1 KB of their own), per wave masks + tables + offsets
-                return (rec8 ? (size_t)64 * (w + 1) * sizeof(PRec) + (clusters > 1 ? 1024u : 0u) : (size_t)64 * (w + 1) * sizeof(Record)) + (size_t)w * (3 * slice_cap + 2 * A) * 4;
+            auto need_cap = [&](uint32_t w, uint32_t cap) {      // records (16 bytes: list rows in their padding; packed: 1 KB of their own), per wave masks + tables + offsets
+                return (rec8 ? (size_t)64 * (w + 1) * sizeof(PRec) + (clusters > 1 ? 1024u : 0u) : (size_t)64 * (w + 1) * sizeof(Record)) + (size_t)w * (3 * cap + 2 * A) * 4;
             };
+            auto need_of = [&](uint32_t w) { return need_cap(w, slice_cap); };
             const size_t budget = 160 * 1024 - 32 * 1024;
             const uint32_t order[3] = {4, 2, 1};
             for (uint32_t w : order) {
@@ -2208,6 +2330,64 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
             if (we) {
                 const uint32_t w = (uint32_t)atoi(we);
                 if (w >= 1 && w <= 16 && !(w & (w - 1)) && need_of(w) <= 160 * 1024) { rk_waves = w; rk_lds = need_of(w); }
+            }
+            // Several clusters - the model kernels bound the phase -: the launch's LDS per workgroup is sized by the LARGEST slice
+            // of any (column, cluster), and at 100M x 150 -c 3 -r 1.0 that is an outlier (920 words; 94 % of the 451 slices have
+            // 740 or fewer, half of them 364 or fewer): 50 KB, three workgroups to a CU, two beside a coder workgroup. So the column
+            // groups are sorted into classes by what their own tables need and every class gets a launch of its own with its own
+            // LDS size (`cgmap` tells a workgroup which column group it serves). The class bounds are where one more workgroup fits:
+            // a quarter of a CU's 160 KB (four on a CU without a coder workgroup - the 128 registers of the list walk allow no
+            // fifth), and a third / a quarter of what a coder workgroup leaves.
+            if (rk_waves && clusters > 1 && !(getenv("QVZ_MODEL_CLASSES") && atoi(getenv("QVZ_MODEL_CLASSES")) == 0)) {   // (the variable: development knob)
+                const uint32_t W = rk_waves, ncg = (Cp + W - 1) / W;
+                std::vector<uint32_t> capw((size_t)ncg * W, 4);                      // words of the largest slice a wave meets (over the clusters)
+                std::vector<size_t> need(ncg, 0);                                    // LDS bytes of the column group's workgroup
+                for (uint32_t cg = 0; cg < ncg; ++cg) {
+                    uint32_t sum = 0;
+                    for (uint32_t w = 0; w < W; ++w) {
+                        const uint32_t sx = cg * W + w;
+                        uint32_t words = 4;
+                        if (sx == 0) words = h_colbase[1] - h_colbase[0];
+                        else if (sx >= QVZ_CID_SLOTS && sx - QVZ_CID_SLOTS < columns)
+                            for (uint32_t c = 0; c < clusters; ++c) {
+                                const uint32_t sl = 1 + (sx - (uint32_t)QVZ_CID_SLOTS) * clusters + c;
+                                if (h_colbase[sl + 1] - h_colbase[sl] > words) words = h_colbase[sl + 1] - h_colbase[sl];
+                            }
+                        capw[(size_t)cg * W + w] = words;                             // (slices are multiples of 4 words)
+                        sum += 3 * words + 2 * A;
+                    }
+                    need[cg] = need_cap(W, 0) - (size_t)W * 2 * A * 4 + (size_t)sum * 4;
+                }
+                hipFuncAttributes fa;
+                const size_t lds_cu = 160 * 1024;
+                size_t beside = lds_cu - 58 * 1024;
+                if (hipFuncGetAttributes(&fa, cr_fn) == hipSuccess && fa.sharedSizeBytes < lds_cu) beside = lds_cu - fa.sharedSizeBytes;
+                const size_t bound[3] = {beside / 4, beside / 3, lds_cu / 4};   // ascending
+                std::vector<uint32_t> order(ncg);
+                for (uint32_t cg = 0; cg < ncg; ++cg) order[cg] = cg;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return need[a] > need[b]; });   // largest first
+                auto class_of = [&](uint32_t cg) { const size_t l = need[cg]; return l <= bound[0] ? 0 : l <= bound[1] ? 1 : l <= bound[2] ? 2 : 3; };
+                for (uint32_t i = 0; i < ncg;) {
+                    uint32_t j = i;
+                    while (j < ncg && class_of(order[j]) == class_of(order[i])) ++j;
+                    uint32_t cap = 0;
+                    for (uint32_t e = i; e < j; ++e)
+                        for (uint32_t w = 0; w < W; ++w) if (capw[(size_t)order[e] * W + w] > cap) cap = capw[(size_t)order[e] * W + w];
+                    // (sorted: the class's first needs the most)
+                    rk_classes.push_back({i * (1 + W), j - i, cap, need[order[i]] + (getenv("QVZ_MODEL_LDS_PAD") ? (size_t)atoi(getenv("QVZ_MODEL_LDS_PAD")) : 0)});
+                    i = j;
+                }
+                for (uint32_t i = 0; i < ncg; ++i) {                                  // a launch's entries: column group, then every wave's (offset | words << 16)
+                    const uint32_t cg = order[i];
+                    h_cgmap.push_back(cg);
+                    uint32_t off = 0;
+                    for (uint32_t w = 0; w < W; ++w) {
+                        const uint32_t words = capw[(size_t)cg * W + w];
+                        h_cgmap.push_back(off | words << 16);
+                        off += 3 * words + 2 * A;
+                    }
+                    if (off > 0xFFFFu) { rk_classes.clear(); break; }                 // (cannot happen: 160 KB of LDS are 40 960 words)
+                }
             }
         }
     }
@@ -2259,7 +2439,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     if (seg_reads < 4 || seg_reads > 0xFFFFFFFCull) { rc = qvz_set_error(QVZ_E_ARG, "workspace of %llu bytes holds fewer than 4 reads of %u streams", (unsigned long long)work_bytes, shards); goto done; }
 #ifdef QVZ_PROFILE
     {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_prof), z, sizeof(z));
         { unsigned long long zc[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cr_prof), zc, sizeof(zc)); }
         const int e = getenv("QVZ_RK_EXP") ? atoi(getenv("QVZ_RK_EXP")) : 0;
@@ -2269,6 +2449,14 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     if (getenv("QVZ_CODER_DEBUG"))
         fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu, %d-byte records, %d symbols per coder block\n",
                 shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size(), rec8 ? 8 : 16, cr_nb);
+    if (getenv("QVZ_CODER_DEBUG")) {                             // the slices' sizes (words), largest first
+        std::vector<uint32_t> sz;
+        for (uint32_t sl = 0; sl < nslices; ++sl) sz.push_back(h_colbase[sl + 1] - h_colbase[sl]);
+        std::sort(sz.begin(), sz.end(), [](uint32_t a, uint32_t b) { return a > b; });
+        fprintf(stderr, "  table slices (words), every %zuth of %zu, largest first:", sz.size() / 16 + 1, sz.size());
+        for (size_t i = 0; i < sz.size(); i += sz.size() / 16 + 1) fprintf(stderr, " %u", sz[i]);
+        fprintf(stderr, " .. %u\n", sz.back());
+    }
     TRY(area.get((void **)&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
     TRY(area.get((void **)&d_status, sizeof(int32_t)));
@@ -2284,6 +2472,13 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipMemcpyAsync(d_slices, h_slices.data(), h_slices.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_colbase, h_colbase.data(), h_colbase.size() * 4, hipMemcpyHostToDevice, st));
         TRY(hipMemcpyAsync(d_coff, h_coff.data(), h_coff.size() * 4, hipMemcpyHostToDevice, st));
+        if (!rk_classes.empty()) {
+            TRY(area.get((void **)&d_cgmap, h_cgmap.size() * 4));
+            TRY(hipMemcpyAsync(d_cgmap, h_cgmap.data(), h_cgmap.size() * 4, hipMemcpyHostToDevice, st));
+            if (getenv("QVZ_CODER_DEBUG"))
+                for (const RkClass &c : rk_classes)
+                    fprintf(stderr, "  model kernel class: %u column groups, slices of up to %u words, up to %zu B of LDS per workgroup\n", c.count, c.cap, c.lds);
+        }
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
@@ -2297,6 +2492,23 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
     }
     coder_segments(longest, seg_reads, overlap, segs, getenv("QVZ_CODER_FIRST_DIV") && atoi(getenv("QVZ_CODER_FIRST_DIV")) > 0 ? (uint32_t)atoi(getenv("QVZ_CODER_FIRST_DIV")) : (clusters > 1 ? 1u : 4u));   // (the variable: development knob)
+    if (overlap && getenv("QVZ_CODER_SEGS")) {                   // development knob: the cut given, "reads,reads,..." (multiples of 64, none above the buffer's)
+        std::vector<std::pair<uint64_t, uint64_t>> given;
+        uint64_t lo = 0;
+        bool fine = true;
+        for (const char *p = getenv("QVZ_CODER_SEGS"); *p && lo < longest;) {
+            char *end = nullptr;
+            uint64_t len = strtoull(p, &end, 10);
+            if (end == p) { fine = false; break; }
+            p = *end == ',' ? end + 1 : end;
+            if (lo + len > longest) len = longest - lo;
+            if (!len || len > seg_reads || ((len & 63) && lo + len < longest)) { fine = false; break; }
+            given.push_back({lo, len});
+            lo += len;
+        }
+        if (fine && lo == longest) segs = given;
+        else fprintf(stderr, "qvz_hip_encode_planes: QVZ_CODER_SEGS does not cut %llu reads into segments of at most %llu (multiples of 64): ignored\n", (unsigned long long)longest, (unsigned long long)seg_reads);
+    }
     nseg = (uint32_t)segs.size();
     if (rk_waves && clusters > 1) {                              // read lists per (stream, cluster) and where the segments cut them
         std::vector<uint32_t> h_bounds(nseg + 1);
@@ -2418,17 +2630,26 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (rk_waves) {
             // z: the cluster a workgroup of column positions serves - or, by default, one workgroup for all clusters of its (stream, column group) (QVZ_MODEL_CLUSTER_LOOP=0: development knob)
             const bool zloop = !(getenv("QVZ_MODEL_CLUSTER_LOOP") && atoi(getenv("QVZ_MODEL_CLUSTER_LOOP")) == 0);
-            const dim3 grid(shards, (Cp + rk_waves - 1) / rk_waves, zloop ? 1 : clusters), block(64 * rk_waves);
+            const dim3 block(64 * rk_waves);
             const size_t SK = (size_t)shards * clusters;
-#define RK_ARGS(LISTS) d_qi, d_st, ld, d_labels, columns, clusters, d_first, d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), slice_cap, seg_lo, \
+            // (several clusters: one launch per size class of the column groups, the largest tables first)
+            const size_t nlaunch = rk_classes.empty() ? 1 : rk_classes.size();
+            for (size_t ci = 0; ci < nlaunch; ++ci) {
+                const uint32_t ny = rk_classes.empty() ? (Cp + rk_waves - 1) / rk_waves : rk_classes[ci].count;
+                const uint32_t cap_l = rk_classes.empty() ? slice_cap : rk_classes[ci].cap;
+                const size_t lds_l = rk_classes.empty() ? rk_lds : rk_classes[ci].lds;
+                const uint32_t *map_l = rk_classes.empty() ? nullptr : d_cgmap + rk_classes[ci].off;
+                const dim3 grid(shards, ny, zloop ? 1 : clusters);
+#define RK_ARGS(LISTS) d_qi, d_st, ld, d_labels, columns, clusters, d_first, d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), cap_l, seg_lo, \
                        seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status, \
                        (const uint32_t *)(LISTS ? d_clist : nullptr), (const uint64_t *)(LISTS ? d_cstart : nullptr), \
-                       (const uint32_t *)(LISTS ? d_segpos + (size_t)i * SK : nullptr), (const uint32_t *)(LISTS ? d_segpos + (size_t)(i + 1) * SK : nullptr)
-            if (clusters > 1 && rec8) hipLaunchKernelGGL((k_model_ranks<true, false, true>), grid, block, rk_lds, s_model, RK_ARGS(true));
-            else if (clusters > 1) hipLaunchKernelGGL((k_model_ranks<true, false, false>), grid, block, rk_lds, s_model, RK_ARGS(true));
-            else if (rec8) hipLaunchKernelGGL((k_model_ranks<false, false, true>), grid, block, rk_lds, s_model, RK_ARGS(false));
-            else hipLaunchKernelGGL((k_model_ranks<false, false, false>), grid, block, rk_lds, s_model, RK_ARGS(false));
+                       (const uint32_t *)(LISTS ? d_segpos + (size_t)i * SK : nullptr), (const uint32_t *)(LISTS ? d_segpos + (size_t)(i + 1) * SK : nullptr), map_l
+                if (clusters > 1 && rec8) hipLaunchKernelGGL((k_model_ranks<true, false, true>), grid, block, lds_l, s_model, RK_ARGS(true));
+                else if (clusters > 1) hipLaunchKernelGGL((k_model_ranks<true, false, false>), grid, block, lds_l, s_model, RK_ARGS(true));
+                else if (rec8) hipLaunchKernelGGL((k_model_ranks<false, false, true>), grid, block, lds_l, s_model, RK_ARGS(false));
+                else hipLaunchKernelGGL((k_model_ranks<false, false, false>), grid, block, lds_l, s_model, RK_ARGS(false));
 #undef RK_ARGS
+            }
         } else {
 #define MC_ARGS d_qi, d_st, ld, d_labels, columns, clusters, d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status
             if (clusters > 1 && rec8) hipLaunchKernelGGL((k_model_columns<true, true>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
@@ -2516,7 +2737,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     }
 #ifdef QVZ_PROFILE
     {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rk_prof), sizeof(z));
         const double ch = z[6] ? (double)z[6] : 1.0;
         unsigned long long cr[16] = {0};
@@ -2533,6 +2754,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         }
         fprintf(stderr, "k_model_ranks cycles per wave and chunk: lookup %.0f  ranks %.0f  update+record %.0f  barrier1 %.0f  park+barrier2 %.0f  drain %.0f  (%.3g wave-chunks)\n",
                 z[0] / ch, z[1] / ch, z[2] / ch, z[3] / ch, z[4] / ch, z[5] / ch, ch);
+        if (z[9]) fprintf(stderr, "  per pass of a workgroup (a cluster's reads of a stream in a segment): %.0f cycles before the first chunk, %.0f for the table save, %.0f in all, %.1f chunks\n",
+                          (double)z[7] / z[9], (double)z[8] / z[9], (double)z[10] / z[9], ch / z[9]);
+        if (z[9]) fprintf(stderr, "    before the first chunk: %.0f until the wave's tables are in LDS, %.0f at the barrier, %.0f for the first bytes and look-up (sums over all passes / the passes; a workgroup's first passes alone: %.0f in all, summed over every pass)\n",
+                          (double)z[11] / z[9], (double)z[12] / z[9], (double)z[13] / z[9], (double)z[14] / z[9]);
     }
 #endif
     if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder input addresses a quantizer without a model table (dead context or bad state)");
@@ -2688,12 +2913,12 @@ extern "C" int qvz_hip_model_session_records(qvz_model_session *s, const uint8_t
                            (const uint64_t *)s->d_first, s->d_coff, s->d_colbase, s->d_slices, s->d_save, s->total_words, s->slice_cap,
                            (uint64_t)0, (uint32_t)n, is_first, 0, (uint32_t)__builtin_ctz(s->rk_waves), (Record *)d_rec, s->d_status,
                            (const uint32_t *)s->d_clist, (const uint64_t *)s->d_cstart, (const uint32_t *)s->d_segpos,
-                           (const uint32_t *)(s->d_segpos + s->clusters));
+                           (const uint32_t *)(s->d_segpos + s->clusters), (const uint32_t *)nullptr);
     } else {
         hipLaunchKernelGGL((k_model_ranks<false, true, false>), grid, block, s->rk_lds, st, d_qi, d_st, ld, d_labels, s->columns, s->clusters,
                            (const uint64_t *)s->d_first, s->d_coff, s->d_colbase, s->d_slices, s->d_save, s->total_words, s->slice_cap,
                            (uint64_t)0, (uint32_t)n, is_first, 0, (uint32_t)__builtin_ctz(s->rk_waves), (Record *)d_rec, s->d_status,
-                           (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     }
     QVZ_HIP_CHECK(hipGetLastError());
     s->started = 1;

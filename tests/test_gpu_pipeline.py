@@ -186,6 +186,14 @@ def test_gpu_model_kernels_agree(name, shards, monkeypatch):
     monkeypatch.setenv("QVZ_CODER_RECORDS", "16")                       # the same with the 16-byte records
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
     assert streams == a["streams"]
+    # several clusters: one launch for all column groups with the LDS of the largest slice (QVZ_MODEL_CLASSES=0) against the default,
+    # a launch per size class of the column groups with every wave's LDS region sized by its own column's slices
+    monkeypatch.delenv("QVZ_CODER_RECORDS")
+    monkeypatch.delenv("QVZ_MODEL_KERNEL")
+    monkeypatch.setenv("QVZ_MODEL_CLASSES", "0")
+    for work in (None, small):
+        _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=work)
+        assert streams == a["streams"]
 
 
 def test_gpu_coder_reports_overflow_and_bad_feed():

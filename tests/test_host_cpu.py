@@ -423,3 +423,9 @@ def test_coder_segment_cut():
         if overlap and seg >= 256 and longest > seg:
             q = (seg // 4) // 64 * 64
             assert r[0] == min(seg // 64 * 64, f[-1]) and q <= r[-1] < q + 64, (longest, seg, r)
+            # the middle: equal segments, then one of about 0.72 of them (its coder kernel must not outlast the short last model kernel)
+            mid = r[1:-1]
+            if len(mid) > 1:
+                assert (mid[:-1] == mid[0]).all() and 0 < mid[-1] <= mid[0], (longest, seg, mid)
+                if mid[0] < seg // 64 * 64:                      # not capped by the buffer: the ratio is the rule's
+                    assert 0.72 * mid[0] - 64 * len(mid) <= mid[-1] <= 0.72 * mid[0] + 64, (longest, seg, mid)

@@ -64,7 +64,7 @@ profile-build)
   cp -r . /tmp/prof_build && cd /tmp/prof_build && touch qvz_amd/csrc/*.hip &&
   make -s HIPFLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Iinclude -Iqvz_amd/csrc -DQVZ_PROFILE" > /dev/null 2>&1 || exit 1
   env "$@" QVZ_CODER_DEBUG=1 QVZ_CB_DEBUG=1 timeout -k 10 400 python3 bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extras 2> $out/profile_build.txt | line
-  grep -E "cycles|lm_design|segment|streams made|host side" $out/profile_build.txt | tail -30 ;;
+  grep -E "cycles|lm_design|segment|streams made|host side|before the first chunk" $out/profile_build.txt | tail -30 ;;
 streams)
   : > $out/sweep.jsonl
   for s in 1024 2048 4096 8192 16384; do
