@@ -851,13 +851,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // cgmap: this launch serves the column groups whose tables fit the LDS it was given (the host's size classes, see
     // qvz_hip_encode_planes). Entry i of the launch: the column group, then per wave (where its part of the LDS starts, in words) |
     // (words of its largest slice) << 16 - a wave has room for ITS column's tables, not for the largest column's.
-    uint32_t wave_lay = (wave * (3 * slice_cap + 2 * A)) | slice_cap << 16;
+    uint32_t wave_off = wave * (3 * slice_cap + 2 * A), wave_cap = slice_cap;   // (no map: every wave has room for the largest slice)
     if (cgmap) {
         const uint32_t *ent = cgmap + (size_t)cg * (1 + W);
         cg = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[0]);
-        wave_lay = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[1 + wave]);
+        const uint32_t lay = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[1 + wave]);
+        wave_off = lay & 0xFFFFu;
+        wave_cap = lay >> 16;
     }
-    const uint32_t wave_off = wave_lay & 0xFFFFu, wave_cap = wave_lay >> 16;
     const uint32_t sx = cg * W + wave;                           // position in the read's record group
     const bool lists = HAVE_LABELS && cg * W >= QVZ_CID_SLOTS;   // this workgroup walks cluster z's reads
     if (HAVE_LABELS && !lists && z) return;                      // the reserved positions belong to the z = 0 workgroups
@@ -2338,7 +2339,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
             // LDS size (`cgmap` tells a workgroup which column group it serves). The class bounds are where one more workgroup fits:
             // a quarter of a CU's 160 KB (four on a CU without a coder workgroup - the 128 registers of the list walk allow no
             // fifth), and a third / a quarter of what a coder workgroup leaves.
-            if (rk_waves && clusters > 1 && !(getenv("QVZ_MODEL_CLASSES") && atoi(getenv("QVZ_MODEL_CLASSES")) == 0)) {   // (the variable: development knob)
+            const char *mc = getenv("QVZ_MODEL_CLASSES");       // development knob: 0 = never, 1 = with one cluster as well
+            if (rk_waves && (clusters > 1 || (mc && atoi(mc) == 1)) && !(mc && atoi(mc) == 0)) {
                 const uint32_t W = rk_waves, ncg = (Cp + W - 1) / W;
                 std::vector<uint32_t> capw((size_t)ncg * W, 4);                      // words of the largest slice a wave meets (over the clusters)
                 std::vector<size_t> need(ncg, 0);                                    // LDS bytes of the column group's workgroup
@@ -2347,7 +2349,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
                     for (uint32_t w = 0; w < W; ++w) {
                         const uint32_t sx = cg * W + w;
                         uint32_t words = 4;
-                        if (sx == 0) words = h_colbase[1] - h_colbase[0];
+                        if (clusters == 1) { if (sx < columns) words = h_colbase[sx + 1] - h_colbase[sx]; }
+                        else if (sx == 0) words = h_colbase[1] - h_colbase[0];
                         else if (sx >= QVZ_CID_SLOTS && sx - QVZ_CID_SLOTS < columns)
                             for (uint32_t c = 0; c < clusters; ++c) {
                                 const uint32_t sl = 1 + (sx - (uint32_t)QVZ_CID_SLOTS) * clusters + c;
