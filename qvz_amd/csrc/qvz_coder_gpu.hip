@@ -878,14 +878,13 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // ... and what a pass needs before its first chunk is asked for during the pass before it (PF: the instantiations that walk
     // lists): the list entries of its first eight chunks at that pass's start, the bytes of its first four chunks and its tables
     // at the first `park` of that pass whose own request would lie beyond the pass's reads - into the very registers the request
-    // would have filled (the bytes); the tables are only pulled into L2. Measured before this (cycle counters of a
+    // would have filled (the bytes). Measured before this (cycle counters of a
     // -DQVZ_PROFILE build, three clusters at 100M x 150): a pass waited 10 100 cycles - two dependent memory round trips: list
     // entries, then the bytes of those reads - of its 79 300 before its first chunk.
     constexpr bool PF = HAVE_LABELS && REC8 && !DENSE;
     typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
     uint32_t q_nx[4], x_nx[4];                                   // the bytes requested for the four chunks after the current four
     uint32_t r_pfa[4] = {0, 0, 0, 0}, r_pfb[4] = {0, 0, 0, 0};   // PF: list entries of the next pass's chunks 0-3 / 4-7
-    uint32_t t_pf = 0;                                           // PF: a word of every line of the next pass's tables (pulls them into L2; never looked at)
     bool pf_lists = false, pf_rest = false;                      // (wave-uniform) what has been asked for on behalf of the next pass
     for (uint32_t zi = 0; zi < nz; ++zi) {
     if (zi) __syncthreads();                                     // the pass before has drained its last chunk (recbuf, row slots)
@@ -995,9 +994,8 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         tb_nx = tbs; x_lk = ok ? x : 0u; card_nx = card; ok_nx = ok;
     };
     // PF: the pass after this one - its reads, its tables
-    uint32_t nrN = 0, n4N = 0;
+    uint32_t nrN = 0;
     const uint32_t *lpN = nullptr;
-    const uint4 *srcN = nullptr;
     auto park = [&](uint32_t ro) {                               // the requested bytes become the current block; request the next
         q_cur = q_nx[0] | q_nx[1] << 8 | q_nx[2] << 16 | q_nx[3] << 24;
         x_cur = x_nx[0] | x_nx[1] << 8 | x_nx[2] << 16 | x_nx[3] << 24;
@@ -1007,22 +1005,16 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             for (int j = 0; j < 4; ++j) { r_cur[j] = r_nx[j]; r_nx[j] = r_nn[j]; }
         }
         if (PF && pf_lists && ro + 256 >= nr) {
-            // nothing of this pass is left to ask for: the first bytes of the next pass (its list entries were asked for when this
-            // pass began) and its tables instead. No `park` follows in this pass (the chunk loop skips them: q_nx / x_nx stay).
+            // nothing of this pass is left to ask for: the first bytes of the next pass instead (its list entries were asked for when
+            // this pass began). No `park` follows in this pass (the chunk loop skips them: q_nx / x_nx stay).
+            // (The tables: there are no registers to hold a slice through the chunks that are left - the loop's 115 and these 16
+            // spill -, and a load that only pulled them into L2 - one word of every line, an atomic load of wavefront scope, which is
+            // a plain global_load_dword that the compiler neither moves nor drops and whose return it counts itself - changed
+            // nothing: a later pass waits ~7 700 cycles for its tables like a workgroup's first.)
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 q_nx[j] = qplane[r_pfa[j]];
                 x_nx[j] = xplane[r_pfa[j]];
-            }
-            if (active) {
-                // the tables: there are no registers to hold them through the chunks that are left (the loop's 115 and these 16
-                // would spill), so they are only pulled into L2: one load, lane i taking a word of the slice's i-th 128-byte line
-                // (8 KB: more than a slice this kernel's LDS could hold), its result kept until the pass ends and never looked at.
-                // (An atomic load of wavefront scope is a plain global_load_dword that the compiler neither moves nor drops and
-                // whose return it counts itself - hand-issued loads into a register nobody reads would land in whatever the
-                // register has become by then.)
-                const uint32_t words = 4 * n4N, w = lane * 32;
-                t_pf = __hip_atomic_load(reinterpret_cast<const uint32_t *>(srcN) + (w < words ? w : words - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
             pf_rest = true;
             return;
@@ -1093,19 +1085,12 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         if (!from_rest) fetch(0);                                // (from_rest: q_nx / x_nx hold them)
     }
     if (PF && nz > 1 && zi + 1 < nz) {
-        // the next pass: where its list entries, tables and offsets are; its first list entries are asked for now
+        // the next pass: its first list entries are asked for now
         const uint32_t zN = zi + 1;
         const uint32_t j0 = segpos_lo[g * K + zN], j1 = segpos_hi[g * K + zN];
         nrN = (uint32_t)__builtin_amdgcn_readfirstlane((int)(j1 - j0));
         lpN = clist + uniform64(cstart[g * K + zN]) + j0;
-        uint32_t swN = 0;
-        if (active) {
-            const uint32_t sliceN = 1u + s * K + zN, b0N = colbase[sliceN];
-            swN = colbase[sliceN + 1] - b0N;
-            srcN = reinterpret_cast<const uint4 *>(is_first ? tmpl + b0N : save + (uint64_t)g * total_words + b0N);
-        }
-        n4N = (uint32_t)__builtin_amdgcn_readfirstlane((int)(swN / 4));
-        if (nrN && (!active || n4N)) {                           // (a next pass without a read passes its tables through by itself)
+        if (nrN) {                                               // (a next pass without a read passes its tables through by itself)
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t e = j * 64 + lane, e2 = 256 + e;
@@ -1304,7 +1289,6 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     }
     const unsigned long long tsave = __builtin_readcyclecounter();
 #endif
-    if (PF) asm volatile("" : : "v"(t_pf));                      // (the L2 pull's result is needed up to here, as far as the compiler can tell)
     if (active && !is_last)
         for (uint32_t i = lane; i < sw / 4; i += 64) {           // (read again a segment later: the non-temporal hint, as for the records)
             typedef uint32_t rk_u32x4s __attribute__((ext_vector_type(4)));
