@@ -194,6 +194,12 @@ def test_gpu_model_kernels_agree(name, shards, monkeypatch):
     for work in (None, small):
         _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=work)
         assert streams == a["streams"]
+    # ... and the classes with workgroups of two waves and of one (the map carries a layout per wave), with one cluster as well
+    monkeypatch.setenv("QVZ_MODEL_CLASSES", "1")
+    for waves in ("2", "1", "4"):
+        monkeypatch.setenv("QVZ_MODEL_WAVES", waves)
+        _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
+        assert streams == a["streams"], f"classes with {waves} wave(s) per workgroup changed a stream"
 
 
 def test_gpu_coder_reports_overflow_and_bad_feed():
