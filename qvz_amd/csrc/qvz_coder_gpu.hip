@@ -734,7 +734,7 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 __device__ unsigned long long g_rk_prof[16];   // [7] prologue, [8] table save, [9] passes, [10] whole pass, [11] .. [13] prologue: to the tables in LDS, the barrier, the first look-up; [14] first passes' prologue
 __device__ unsigned long long g_cr_prof[16];
 __device__ uint32_t g_cr_simd[8];   // SIMD of every wave of one k_code_records workgroup (HW_ID bits 5:4)
-__device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no record store, 2 no transposition/barriers, 4 no cumulative loop, 8 no table update, 16 no timers
+__device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no record store, 2 no transposition/barriers, 4 no cumulative loop, 8 no table update, 16 no timers, 32 / 64 no OR into the table's / the entry's lane mask
 #define RK_T(i) do { if (!(exp_ & 16)) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
 #define RK_EXP(bit) if (!(exp_ & (bit)))
 #else
@@ -1138,7 +1138,9 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             // instructions cost more than the LDS cycles gave back, model kernels 130.8 -> 136 ms at 100M x 150 -f 0.5.)
             {
                 const unsigned long long bit = ok ? 1ull << lane : 0ull;
+                RK_EXP(32)
                 __hip_atomic_fetch_or(&msk[tb], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                RK_EXP(64)
                 __hip_atomic_fetch_or(&msk[tb + 2 + x], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // counts before this chunk, and ranks inside it: earlier lanes with the same table (e), the same table and
