@@ -1816,7 +1816,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
 // copies (k = 1: 20.1 -> 19.7 ms, k = 3: 24.9 -> 24.3 ms at 100M x 150; the same hint on the output planes' STORES: 13 % slower)
 #define QZ_LD(p) __builtin_nontemporal_load(p)
 #define QZ_CLUSTER4 (10 + QVZ_QS_STRIDE / 8)       // uint4 per cluster and column: ct (9) + pad (1) + qs (1296)
-template <int NBUF, int NQ, int RW, int T>   // RW dwords = 4 * RW consecutive reads per thread, T threads per workgroup
+template <int NBUF, int NQ, int RW, int T, bool SEG>   // RW dwords = 4 * RW consecutive reads per thread, T threads per workgroup; SEG: one segment of every stream (`first`)
 __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                              uint64_t n, uint32_t C, uint64_t ld, uint32_t K,
                                                              const uint16_t *__restrict__ ct, const uint16_t *__restrict__ qs,
@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     // launch for the next segment. A thread's reads stay inside one stream's piece; what lies beyond
     // the piece (or the stream) is neither loaded nor stored: i0 is a multiple of 4 there, not of R.
     uint64_t i0 = (uint64_t)R * t;
-    if (first) {
+    if (SEG) {
         const uint32_t tps = (seg_len + R - 1) / R;
         const uint64_t g = t / tps;
         if (g < shards) {
@@ -1920,9 +1920,11 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
     // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
     const uint64_t io = active ? i0 : 0;
-    uint32_t woff[RW];                                           // a dword wholly beyond the thread's reads is not touched: its loads go to the thread's first dword
+    // SEG: a dword wholly beyond the thread's reads is not touched, its loads go to the thread's first dword. (Only then: the tests per
+    // dword in the column loop cost the whole-matrix launch 1.3 of its 19.5 ms when they were unconditional.)
+    uint32_t woff[RW];
 #pragma unroll
-    for (int w = 0; w < RW; ++w) woff[w] = active && i0 + 4 * w < n ? 4u * w : 0u;
+    for (int w = 0; w < RW; ++w) woff[w] = !SEG || (active && i0 + 4 * w < n) ? 4u * w : 0u;
     uint32_t x4n[RW], d4n[RW];
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
@@ -1966,7 +1968,7 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
         if (active) {
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
-                if (w == 0 || woff[w]) {                         // (a dword beyond the thread's reads belongs to somebody else)
+                if (!SEG || w == 0 || woff[w]) {                 // (SEG: a dword beyond the thread's reads belongs to somebody else)
                     if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0 + 4 * w) = qv4[w];
                     if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0 + 4 * w) = qi4[w];
                     if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0 + 4 * w) = st4[w];
@@ -2024,11 +2026,19 @@ int qvz_quantize_launch(const QvzQuantArgs &a, const uint64_t *d_first, uint32_t
         const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
 #define QZ_LAUNCH(NBUF, NQ, RWV, TT)                                                                                             \
         do {                                                                                                                     \
-            QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT>),                \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
-            hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT>), grid, dim3(TT), lds, stream, a.d_sym,                        \
-                               k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
-                               a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);                \
+            if (d_first) {                                                                                                       \
+                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT, true>),      \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT, true>), grid, dim3(TT), lds, stream, a.d_sym,              \
+                                   k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
+                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);            \
+            } else {                                                                                                             \
+                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT, false>),     \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT, false>), grid, dim3(TT), lds, stream, a.d_sym,             \
+                                   k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
+                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);            \
+            }                                                                                                                    \
         } while (0)
         static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4 &&
                       4 * 1024 >= 3 * QZ_CLUSTER4, "stage registers");
