@@ -151,6 +151,15 @@ void qvz_codebook_tables(const qvz_codebook_t *cb, uint16_t *ct, uint16_t *qs) {
         }
         for (uint32_t qi = 0; qi < 2 * A; ++qi) {
             const size_t t = ((size_t)s * 2 * A + qi) * A;
+            /* a quantizer the column does not have (most of the 144: a -f codebook has a handful of contexts) is a row of one value
+             * in `q` (zeros): all its table entries are the same, written without looking each up (this loop over all 1.5 million
+             * entries of a 150-column codebook took 0.5 ms between the last codebook kernel and the quantizer's launch) */
+            if (qi >= 2u * cb->nctx[s] && memcmp(cb->q + t, cb->q + t + 1, A - 1) == 0) {
+                const uint8_t qv = cb->q[t];
+                const uint16_t e = (uint16_t)(qv | (cb->out_idx[t + qv] << 8));
+                for (int x = 0; x < A; ++x) qs[t + x] = e;
+                continue;
+            }
             for (int x = 0; x < A; ++x) {
                 const uint8_t qv = cb->q[t + x];
                 qs[t + x] = (uint16_t)(qv | (cb->out_idx[t + qv] << 8));

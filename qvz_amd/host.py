@@ -231,7 +231,7 @@ def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_pe
                                      n, columns, k, arr, shards, C.c_void_p(out.data_ptr()), cap_per_shard, sizes, stream)
     if rc:
         raise QvzHipError(f"qvz_hip_encode_shards failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
-    sizes = [int(x) for x in sizes]
+    sizes = np.ctypeslib.as_array(sizes).tolist()   # (8192 Python ints by a list comprehension over the ctypes array took 0.6 ms)
     streams = None
     if want_streams:
         host_out = out.view(shards, cap_per_shard).cpu().numpy()
@@ -331,7 +331,7 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     lib().qvz_hip_encode_planes_last_ms(C.byref(a), C.byref(b))
     encode_planes_gpu.last_ms = (a.value, b.value)      # (model kernels, coder kernels) of this call
     encode_planes_gpu.last_quant_ms = lib().qvz_hip_encode_planes_last_quant_ms() if quant is not None else None
-    sizes = [int(x) for x in sizes]
+    sizes = np.ctypeslib.as_array(sizes).tolist()   # (8192 Python ints by a list comprehension over the ctypes array took 0.6 ms)
     streams = None
     if want_streams:
         host_out = out.view(shards, cap_per_shard).cpu().numpy()

@@ -182,6 +182,7 @@ def test_coder_long_pending_run_and_alignment():
 
 
 def test_quantizer_tables_from_host_builder():
+    from qvz_amd._lib import lib
     rows, opts, labels, ocbs, ref = oracle_side("t2k_c3_f05_M")
     for o in ocbs:
         cb = product_codebook_from_oracle(o)
@@ -195,6 +196,17 @@ def test_quantizer_tables_from_host_builder():
                 qv = o.q[s, qi].astype(np.int64)
                 want = o.q[s, qi].astype(np.uint16) | (o.out_idx[s, qi][qv].astype(np.uint16) << 8)
                 np.testing.assert_array_equal(qs[s, qi], want)
+        # every entry, the quantizers a column does not have included (rows of one value, which the converter writes without looking
+        # each entry up), by the same formula over the product's own arrays - into a buffer that was NOT zero before
+        qv = cb.q.astype(np.int64)
+        want = cb.q.astype(np.uint16) | (np.take_along_axis(cb.out_idx, qv, axis=2).astype(np.uint16) << 8)
+        ct2 = np.full((o.c, 72), 0xABCD, dtype=np.uint16)
+        qs2 = np.full((o.c, 144, 72), 0xABCD, dtype=np.uint16)
+        lib().qvz_codebook_tables(cb.handle, ct2.ctypes.data, qs2.ctypes.data)
+        np.testing.assert_array_equal(qs2, want)
+        np.testing.assert_array_equal(ct2, ct)
+        dead = qs2[:, 2 * int(o.nctx.max()):]
+        assert dead.size and (dead == dead[:, :, :1]).all()      # (one value per row: the quantizer does not exist)
 
 
 def make_fastq(rows, seed=0, crlf=False, final_newline=True):
