@@ -1873,7 +1873,8 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     for (int r = 0; r < R; ++r) {
         uint32_t l = 0;
         if (labels && active && i0 + r < ld) l = labels[i0 + r];
-        cbase[r] = (l < K ? l : 0u) * (QZ_CLUSTER4 * 8);
+        // (NQ == 3 is the one-cluster instantiation: a base the compiler knows to be 0 is one address instruction less per symbol)
+        cbase[r] = NQ == 3 ? 0u : (l < K ? l : 0u) * (QZ_CLUSTER4 * 8);
         dead = dead || (active && i0 + r < n && l >= K);
         prev[r] = 0;
         err[r] = 0.0;
