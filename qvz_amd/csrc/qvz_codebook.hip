@@ -1033,7 +1033,7 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 }
 
 static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-static thread_local unsigned long long cb_stat[6];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns
+static thread_local unsigned long long cb_stat[7];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns; [6] windows after a column's first
 static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 // exact mode: |entropy - target| at or below this is re-decided by the host's libm (a one-bit miss of the device's log2 restatement
 // moves an entropy of at most ~6.2 bits by a few ulps of 8.9e-16; the band is a thousand times that and is met about once in 1e12 decisions)
@@ -1513,6 +1513,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             } else {
             if (s == 0 || round) QVZ_HIP_CHECK(hipMemsetAsync(W.stop, 0xff, A * sizeof(uint32_t), st));   // (k_ctx_propagate resets it otherwise)
             ++round;
+            cb_stat[6] += 1;
             const uint32_t seqw = launch_window(d_rows, hin_d, nu, win);         // the plan is read from host memory
             QVZ_HIP_CHECK(hipGetLastError());
             { const int rc_ = await(seqw, 1); if (rc_) return rc_; }
@@ -1564,7 +1565,10 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             }
             if (any_gpu) win = win * 2 > A ? A : win * 2;
         }
-        window0 = smax + 3 < 8 ? 8 : (smax + 3 > A ? A : smax + 3);
+        {
+            static const uint32_t margin = getenv("QVZ_CB_WINDOW_MARGIN") ? (uint32_t)atoi(getenv("QVZ_CB_WINDOW_MARGIN")) : 3u;   // development knob
+            window0 = smax + margin < 8 ? 8 : (smax + margin > A ? A : smax + margin);
+        }
 
         // ratios from libm entropies, store (optimize_for_entropy :263-268, store_cond_quantizers_indexed :152-157)
         const double t_rt = cb_now();
@@ -1655,6 +1659,7 @@ static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const dou
     if (getenv("QVZ_CB_DEBUG") && C > 1)
         fprintf(stderr, "  first windows: %llu blocks, %llu designs completed, %.1f iterations on average; per column the longest design: %.1f iterations at most, %.0f shader cycles (S = %.1f on average)\n",
                 cb_stat[4], cb_stat[0], cb_stat[0] ? (double)cb_stat[1] / cb_stat[0] : 0.0, (double)cb_stat[2] / (C - 1), (double)cb_stat[3] / (C - 1), (double)cb_stat[5] / (C - 1));
+    if (getenv("QVZ_CB_DEBUG")) fprintf(stderr, "  windows after a column's first: %llu over %u columns\n", cb_stat[6], C);
     return rc;
 }
 
