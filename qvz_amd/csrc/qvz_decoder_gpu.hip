@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
                                                       const uint2 *__restrict__ ctx2, uint32_t *__restrict__ arena,
                                                       uint32_t arena_words, const uint8_t *__restrict__ draws, uint64_t ld,
                                                       uint8_t *__restrict__ qv, uint8_t *__restrict__ labels,
-                                                      int32_t *__restrict__ status) {
+                                                      int32_t *__restrict__ status, uint32_t lanes) {
     extern __shared__ uint32_t stage[];                          // [C][64] dwords: 4 reads of a column per lane; then ctx2 (CTX_LDS)
     uint2 *lctx = reinterpret_cast<uint2 *>(stage + (size_t)C * 64);
     if (CTX_LDS) {
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
     }
     const uint2 *cx = CTX_LDS ? lctx : ctx2;
     const uint32_t lane = threadIdx.x;
-    const uint32_t g = blockIdx.x * 64 + lane;
-    const bool live = g < shards;
+    const uint32_t g = blockIdx.x * lanes + lane;                 // `lanes` streams per wave (64, or 32 when that puts a workgroup on every CU)
+    const bool live = lane < lanes && g < shards;
     const uint64_t r0 = live ? first[g] : 0, nreads = live ? first[g + 1] - r0 : 0;
     uint64_t most = nreads;
     for (int o = 32; o > 0; o >>= 1) { const uint64_t v = __shfl_xor(most, o, 64); most = v > most ? v : most; }
@@ -255,6 +255,17 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     for (uint32_t g = 0; g < shards; ++g)
         if (h_sizes[g] > cap_per_shard) return qvz_set_error(QVZ_E_ARG, "stream %u is longer than cap_per_shard", g);
     hipStream_t st = (hipStream_t)stream;
+    // A workgroup is one wave (its LDS - staging, context table - lets one or two live on a CU). 8192 streams as 128 waves of 64 lanes
+    // leave every other CU idle; as 256 waves of 32 lanes every CU has one and the decode of 100M x 150 takes 3.77 instead of 4.05 s
+    // (fewer lanes than that need more workgroups than there are CUs and run in rounds: 16 lanes 6.5 s). QVZ_DECODER_LANES: development knob.
+    uint32_t dec_lanes = 64;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            (shards + 31) / 32 <= (uint32_t)cus) dec_lanes = 32;
+        if (getenv("QVZ_DECODER_LANES")) dec_lanes = (uint32_t)atoi(getenv("QVZ_DECODER_LANES"));
+        if (dec_lanes < 1 || dec_lanes > 64) dec_lanes = 64;
+    }
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
     if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
         return qvz_set_error(QVZ_E_NOMEM, "model build failed");
@@ -341,8 +352,8 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
 #define DEC_LAUNCH(LBL, CLDS)                                                                                                       \
     do {                                                                                                                            \
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode_shards<LBL, CLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_decode_shards<LBL, CLDS>), dim3((shards + 63) / 64), dim3(64), lds, st, d_in, cap_per_shard, d_sizes,    \
-                           d_first, shards, columns, clusters, d_ctx, d_arena, dwords, d_draws, ld, d_qv, d_labels, d_status);      \
+        hipLaunchKernelGGL((k_decode_shards<LBL, CLDS>), dim3((shards + dec_lanes - 1) / dec_lanes), dim3(64), lds, st, d_in, cap_per_shard, d_sizes, \
+                           d_first, shards, columns, clusters, d_ctx, d_arena, dwords, d_draws, ld, d_qv, d_labels, d_status, dec_lanes); \
     } while (0)
     if (clusters > 1) { if (ctx_lds) DEC_LAUNCH(true, true); else DEC_LAUNCH(true, false); }
     else { if (ctx_lds) DEC_LAUNCH(false, true); else DEC_LAUNCH(false, false); }
