@@ -102,6 +102,29 @@ int qvz_encode_file_sharded(const char *in_path, const char *out_prefix, const q
 int qvz_encode_file_devices(const char *in_path, const char *out_path, const qvz_options_t *opts, const int *devices,
                             uint32_t ndev, uint32_t shards, qvz_result_t *res);
 
+/* Rate-distortion sweep (reference generate_rd.sh:1-17: twenty `qvz -c 1 -f 0 ... 0.95 -s` encodes of one file; SURVEY.md
+ * section 8f row 2). One file, `npoints` operating points: the upload, the cluster labels (cluster.c:212-244) and the conditional
+ * counters (codebook.c:185-205) do not depend on -f / -r / -d / -D and are made ONCE; per point what is left is the codebooks,
+ * the quantizer and the coding. Everything else in `opts` (clusters, threshold, seed, device, -u, -s, -v) holds for all points.
+ * shards == 0: every point's output is the reference's single-stream file, byte for byte what `qvz <flags of the point>`
+ * writes for the same WELL state; shards > 0: a shard set per point (GPU coder), what qvz_encode_file_shardset writes.
+ * Outputs: "<out_path>.NN" (and "<-u name>.NN") with NN = the point's two-digit index when keep_all, else every point
+ * overwrites out_path as the reference's script does. With opts->stats every point prints the reference's -s line
+ * (main.c:125) - the lines generate_rd.sh collects; a point's `time` is its own seconds, the first point's includes the shared
+ * phases. res (may be NULL): npoints results. */
+typedef struct qvz_sweep_point {
+    int mode;                 /* QVZ_MODE_RATIO (-f) or QVZ_MODE_FIXED (-r) */
+    double ratio;
+    int distortion;           /* QVZ_DIST_* */
+    const char *dist_file;    /* -D FILE when distortion == QVZ_DIST_CUSTOM */
+} qvz_sweep_point_t;
+int qvz_encode_file_sweep(const char *in_path, const char *out_path, const qvz_options_t *opts, const qvz_sweep_point_t *points,
+                          uint32_t npoints, uint32_t shards, int keep_all, qvz_result_t *res);
+/* The points of a sweep from text (the qvz front end's QVZ_SWEEP): "rd" = the reference script's twenty, -f 0, .05 ... .95, spelled
+ * as `bc -l` prints them; else "<f|r>:<v>,<v>,..." with `opts`' distortion. Returns the number of points (0: not understood,
+ * or more than `max`). */
+uint32_t qvz_sweep_parse(const char *text, const qvz_options_t *opts, qvz_sweep_point_t *points, uint32_t max);
+
 /* Decode direction (`qvz -x`, reference src/main.c:132-183, start_qv_decompression src/qv_compressor.c:145-231).
  * qvz_decode_file: a reference-format .q file (one stream) -> text; the serial arithmetic decoder runs on one host
  * core as in the reference, the WELL draws come from the GPU word stream. qvz_decode_shard_files: the files

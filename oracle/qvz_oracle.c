@@ -82,35 +82,43 @@ void orc_pick_centroids(uint64_t n, uint32_t k, int reseed, uint64_t *lines_out)
     }
 }
 
+/* One assignment pass, cluster_lines -> do_cluster_assignment (cluster.c:65-75, :136-171): every read goes to the nearest of the k
+ * means (raw bytes), the lowest id winning ties (strict <, cluster.c:160); counts[j] = reads assigned to j. */
+void orc_assign(const uint8_t *rows, uint64_t n, uint32_t c, uint32_t k, const uint8_t *means, uint8_t *labels, uint32_t *counts) {
+    const size_t stride = (size_t)c + 1;
+    double *dist = (double *)malloc(k * sizeof(double));
+    for (uint32_t j = 0; j < k; ++j) counts[j] = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *x = rows + i * stride;
+        for (uint32_t j = 0; j < k; ++j) {     /* find_distance cluster.c:176-187 */
+            double dd = 0.0;
+            const uint8_t *m = means + (size_t)j * c;
+            for (uint32_t s = 0; s < c; ++s) {
+                uint32_t data = x[s], mean = m[s];
+                dd += (data - mean) * (data - mean);   /* uint32 wraparound square, exact */
+            }
+            dist[j] = dd;
+        }
+        uint8_t id = 0;                        /* assign_cluster cluster.c:149-171 */
+        double best = dist[0];
+        for (uint32_t j = 1; j < k; ++j)
+            if (dist[j] < best) { id = (uint8_t)j; best = dist[j]; }
+        labels[i] = id;
+        counts[id] += 1;
+    }
+    free(dist);
+}
+
 int orc_kmeans(const uint8_t *rows, uint64_t n, uint32_t c, uint32_t k, double threshold,
                const uint64_t *centroid_lines, uint8_t *labels, uint8_t *means, uint32_t *counts) {
     const size_t stride = (size_t)c + 1;
     uint64_t *acc = (uint64_t *)malloc((size_t)k * c * sizeof(uint64_t));
-    double *dist = (double *)malloc(k * sizeof(double));
     for (uint32_t j = 0; j < k; ++j)               /* cluster.c:201 memcpy of raw bytes */
         memcpy(means + (size_t)j * c, rows + centroid_lines[j] * stride, c);
 
     int iter = 0, loop = 1;
     while (iter < 1000 && loop) {                  /* cluster.c:221, cluster.h:9 */
-        for (uint32_t j = 0; j < k; ++j) counts[j] = 0;
-        for (uint64_t i = 0; i < n; ++i) {         /* cluster_lines -> do_cluster_assignment */
-            const uint8_t *x = rows + i * stride;
-            for (uint32_t j = 0; j < k; ++j) {     /* find_distance cluster.c:176-187 */
-                double dd = 0.0;
-                const uint8_t *m = means + (size_t)j * c;
-                for (uint32_t s = 0; s < c; ++s) {
-                    uint32_t data = x[s], mean = m[s];
-                    dd += (data - mean) * (data - mean);   /* uint32 wraparound square, exact */
-                }
-                dist[j] = dd;
-            }
-            uint8_t id = 0;                        /* assign_cluster cluster.c:149-171 */
-            double best = dist[0];
-            for (uint32_t j = 1; j < k; ++j)
-                if (dist[j] < best) { id = (uint8_t)j; best = dist[j]; }
-            labels[i] = id;
-            counts[id] += 1;
-        }
+        orc_assign(rows, n, c, k, means, labels, counts);
         /* recalculate_means cluster.c:80-131 */
         memset(acc, 0, (size_t)k * c * sizeof(uint64_t));
         for (uint64_t i = 0; i < n; ++i) {
@@ -120,7 +128,7 @@ int orc_kmeans(const uint8_t *rows, uint64_t n, uint32_t c, uint32_t k, double t
         }
         double move_max = 0.0;
         for (uint32_t j = 0; j < k; ++j) {
-            if (counts[j] == 0) { free(acc); free(dist); return -1; }
+            if (counts[j] == 0) { free(acc); return -1; }
             double moved = 0.0;
             for (uint32_t s = 0; s < c; ++s) {
                 uint8_t new_mean = (uint8_t)(acc[(size_t)j * c + s] / counts[j]);
@@ -133,7 +141,7 @@ int orc_kmeans(const uint8_t *rows, uint64_t n, uint32_t c, uint32_t k, double t
         loop = move_max > threshold;               /* cluster.c:230-233 */
         iter += 1;
     }
-    free(acc); free(dist);
+    free(acc);
     return iter;
 }
 

@@ -58,7 +58,12 @@ int orc_kmeans(const uint8_t *rows, uint64_t n, uint32_t c, uint32_t k, double t
                const uint64_t *centroid_lines, uint8_t *labels, uint8_t *means_out,
                uint32_t *counts_out);
 
-/* codebook.c:193-205 : cnt[k][C][72][72] u32 (column 0 uses prev row 0). cnt must be zeroed. */
+/* One assignment pass of the loop above (cluster.c:65-75, :136-187) against given means (raw bytes): labels and counts. The
+ * reference's final labels are those of its LAST assignment pass, i.e. against the means before the last update. */
+void orc_assign(const uint8_t *rows, uint64_t n, uint32_t c, uint32_t k, const uint8_t *means, uint8_t *labels, uint32_t *counts);
+
+/* codebook.c:193-205 : cnt[k][C][72][72] u32 (column 0 uses prev row 0). Increments: cnt zeroed by the
+ * caller for a file's counters, or carried over to count a file in pieces. */
 void orc_stats(const uint8_t *rows, const uint8_t *labels, uint64_t n, uint32_t c, uint32_t k,
                uint32_t *cnt);
 

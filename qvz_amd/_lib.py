@@ -133,6 +133,8 @@ SIGNATURES = {
     "qvz_encode_file_sharded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qvz_encode_last_error": (C.c_char_p, []),
     "qvz_encode_file_devices": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_void_p]),
+    "qvz_encode_file_sweep": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
+    "qvz_sweep_parse": (C.c_uint32, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "qvz_egress_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p]),
     "qvz_ingest_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_hip_scatter_streams": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),

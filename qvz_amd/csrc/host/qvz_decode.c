@@ -361,19 +361,16 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
     if (!fo) return qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
     {
         /* The text's pages are made while the GPU decodes - but N and C are a header's claim until the streams have decoded, and
-         * a small crafted file may claim 1e9 x 150: pages are made ahead only for a text the output's file system has room for
-         * (on tmpfs that is RAM: a claim beyond it is refused here, where a true one would fail in the writes anyway). */
+         * a small crafted file may claim 1e9 x 150: pages are made ahead only for a text the output's file system reports room
+         * for. A file system that reports less (or nothing: some FUSE, network and quota-limited mounts) gets no pages made
+         * ahead and the writes decide - a valid decode is not refused on a mount's word. (N * (C + 1) itself cannot wrap:
+         * qvz_plausible_matrix above.) */
         const uint64_t text = N * ((uint64_t)C + 1);
         struct statvfs vfs;
         struct stat ost;
-        if (fstat(fileno(fo), &ost) == 0 && S_ISREG(ost.st_mode) && fstatvfs(fileno(fo), &vfs) == 0) {
-            const uint64_t room = (uint64_t)vfs.f_bavail * (uint64_t)vfs.f_frsize;
-            if (text > room) {
-                rc = qvz_job_fail(QVZ_E_DATA, "the header claims %llu bytes of text, the output's file system has room for %llu", (unsigned long long)text, (unsigned long long)room);
-                goto done;
-            }
+        if (fstat(fileno(fo), &ost) == 0 && S_ISREG(ost.st_mode) && fstatvfs(fileno(fo), &vfs) == 0 && vfs.f_blocks != 0 &&
+            text <= (uint64_t)vfs.f_bavail * (uint64_t)vfs.f_frsize)
             qvz_prealloc_start(fo, text);
-        }
     }
     const double t_0 = dec_now();
     double t_up = t_0, t_dec = t_0;

@@ -121,6 +121,7 @@ static int job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_
  * pinned staging buffers so that the host copy of chunk k+1 (page cache -> pinned), the PCIe transfer of chunk k and its
  * transposition into the column-major matrix overlap. */
 static uint8_t *job_plane(qvz_job_t *job, int i);
+static uint8_t *early_draws_plane(qvz_job_t *job);
 
 int qvz_ingest_rows(const uint8_t *text, uint64_t N, uint32_t C, uint8_t *d_sym, uint64_t ld, uint32_t *bad_out) {
     int rc = 0;
@@ -613,8 +614,8 @@ int qvz_job_start_draws(qvz_job_t *job) {
         job->well_chosen = 1;
     }
     HIP(qvz_hip_set_device(job->opts.device));
-    if ((job->d_draws = job_plane(job, 0))) job->draws_in_planes = 1;          /* allocated ahead of time, beside the upload */
-    else HIP(qvz_hip_malloc((void **)&job->d_draws, (size_t)job->C * job->ld));
+    if (!(job->d_draws = early_draws_plane(job)))                              /* allocated ahead of time, beside the upload */
+        HIP(qvz_hip_malloc((void **)&job->d_draws, (size_t)job->C * job->ld));
     /* The runtime spreads streams over a few hardware queues and a queue runs its kernels in order: a side stream that
      * shares the default stream's queue would put the generator IN FRONT of the codebook kernels instead of beside them
      * (DESIGN.md section 8). A candidate is probed (~1 ms) and dropped for the next one if it does not overlap. */
@@ -641,30 +642,37 @@ done:
 static void *workspace_main(void *arg) {
     qvz_job_t *job = (qvz_job_t *)arg;
     uint64_t free_b = 0, per = 0;
+    const uint64_t plane = ((uint64_t)job->C * job->ld + 255) & ~255ull, errb = (job->N * sizeof(double) + 255) & ~255ull;
     job->work_rc = qvz_hip_set_device(job->opts.device);
-    if (job->work_rc) return NULL;
+    if (job->work_rc) { __atomic_store_n(&job->draws_early_state, 2, __ATOMIC_RELEASE); return NULL; }
+    /* First the draw matrix, an allocation of its own: the WELL generator is the first to need any of this (it starts beside the
+     * codebooks, qvz_job_start_draws waits for THIS allocation only), and the matrix is given back right after the quantizer - room
+     * the coder's stream area and the -u staging can have. */
+    const double t0 = now();
+    void *d = NULL;
+    if (qvz_hip_malloc(&d, (size_t)plane) != QVZ_OK) d = NULL;
+    job->d_draws_early = (uint8_t *)d;
+    __atomic_store_n(&job->draws_early_state, 2, __ATOMIC_RELEASE);
+    {   /* then the quantizer's planes: qi | st | [qv] | err, each rounded up to 256 bytes (what job_plane hands out) */
+        const uint64_t need = plane * (job->want_text ? 3 : 2) + errb;
+        if (qvz_hip_malloc(&job->d_planes, (size_t)need) == QVZ_OK) job->planes_bytes = need; else job->d_planes = NULL;
+        if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: draws + planes of %.1f GB allocated in %.4f s\n", (plane + need) / 1e9, now() - t0);
+    }
+    /* last the coder's record workspace, the largest and the last to be needed: everything at once if it fits, 96 GiB at most,
+     * and 24 GiB of what is free now are left alone (the matrix is being uploaded, the stream area may need an allocation) */
     if (job->shard_bounds) { for (uint32_t g = 0; g < job->work_shards; ++g) if (job->shard_bounds[g + 1] - job->shard_bounds[g] > per) per = job->shard_bounds[g + 1] - job->shard_bounds[g]; }
     else per = (job->N + job->work_shards - 1) / job->work_shards + 4;
     uint64_t want = qvz_hip_encode_planes_work_bytes(per, job->C, job->K, job->work_shards);
-    /* everything at once if it fits: 96 GiB at most, and never more than a third of what is free now - the matrix, the
-     * draws and the quantizer's planes (5 x C x ld bytes) are still to come */
-    const uint64_t planes = 5 * (uint64_t)job->C * job->ld + job->N * 8;
     if (want > (96ull << 30)) want = 96ull << 30;
     if (qvz_hip_mem_info(&free_b, NULL) == QVZ_OK) {
-        const uint64_t room = free_b > planes + (24ull << 30) ? free_b - planes - (24ull << 30) : 0;
+        const uint64_t missing = (job->d_planes ? 0 : plane * 4 + errb) + (job->d_draws_early ? 0 : plane);   /* what the stages will allocate themselves */
+        const uint64_t room = free_b > missing + (24ull << 30) ? free_b - missing - (24ull << 30) : 0;
         if (want > room) want = room;
     }
     if (want < (1ull << 30)) return NULL;                                       /* little room: the coder sizes its own later */
-    const double t0 = now();
+    const double t1 = now();
     if (qvz_hip_malloc(&job->d_work, (size_t)want) == QVZ_OK) job->work_bytes = want; else job->d_work = NULL;
-    if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: workspace of %.1f GiB allocated in %.4f s\n", want / 1073741824.0, now() - t0);
-    {   /* the planes: draws | qi | st | [qv] | err, each rounded up to 256 bytes (what qvz_job_planes hands out) */
-        const double t1 = now();
-        const uint64_t plane = ((uint64_t)job->C * job->ld + 255) & ~255ull, errb = (job->N * sizeof(double) + 255) & ~255ull;
-        const uint64_t need = plane * (job->want_text ? 4 : 3) + errb;
-        if (qvz_hip_malloc(&job->d_planes, (size_t)need) == QVZ_OK) job->planes_bytes = need; else job->d_planes = NULL;
-        if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: planes of %.1f GB allocated in %.4f s\n", need / 1e9, now() - t1);
-    }
+    if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: workspace of %.1f GiB allocated in %.4f s\n", want / 1073741824.0, now() - t1);
     return NULL;
 }
 
@@ -674,8 +682,10 @@ int qvz_job_start_workspace(qvz_job_t *job, uint32_t shards) {
     job->work_shards = shards;
     const char *how = getenv("QVZ_WORK_EARLY");                                /* development knob: thread (default) | sync | off */
     if (how && strcmp(how, "off") == 0) return 0;
+    job->draws_early_state = 1;                                                 /* 1: being allocated, 2: decided (d_draws_early or NULL) */
     if (how && strcmp(how, "sync") == 0) { workspace_main(job); return 0; }
     if (pthread_create(&th, NULL, workspace_main, job) == 0) { job->work_thread = (unsigned long)th; job->work_running = 1; }
+    else job->draws_early_state = 0;
     return 0;
 }
 
@@ -683,15 +693,25 @@ static void workspace_join(qvz_job_t *job) {
     if (job->work_running) { pthread_join((pthread_t)job->work_thread, NULL); job->work_running = 0; }
 }
 
-/* plane i of the early allocation (0 draws, 1 qi, 2 st, 3 qv when want_text, last: the errors), or NULL when there is none (the
- * caller then allocates its own); waits for the allocating thread */
+/* The draw matrix of the early allocation, handed over ONCE (the caller owns and frees it), or NULL when there is none: waits for
+ * that one allocation, not for the thread - the record workspace behind it is up to 96 GiB and may take a second in a young process. */
+static uint8_t *early_draws_plane(qvz_job_t *job) {
+    if (!job->draws_early_state) return NULL;                                   /* no early allocation was started */
+    while (__atomic_load_n(&job->draws_early_state, __ATOMIC_ACQUIRE) == 1) usleep(20);
+    uint8_t *d = job->d_draws_early;
+    job->d_draws_early = NULL;
+    return d;
+}
+
+/* plane i of the early allocation (0 qi, 1 st, 2 qv when want_text; i < 0: the errors, behind the planes), or NULL when there is
+ * none (the caller then allocates its own); waits for the allocating thread */
 static uint8_t *job_plane(qvz_job_t *job, int i) {
     workspace_join(job);
     if (!job->d_planes) return NULL;
     const uint64_t plane = ((uint64_t)job->C * job->ld + 255) & ~255ull;
-    const int n_planes = job->want_text ? 4 : 3;
-    if (i > n_planes || (i == 3 && !job->want_text)) return NULL;
-    return (uint8_t *)job->d_planes + plane * (uint64_t)(i < 0 ? n_planes : i);   /* i < 0: the errors, behind the planes */
+    const int n_planes = job->want_text ? 3 : 2;
+    if (i >= n_planes) return NULL;
+    return (uint8_t *)job->d_planes + plane * (uint64_t)(i < 0 ? n_planes : i);
 }
 
 /* The first coder call of a process loads its code object, sizes and allocates its kept buffers and makes its stream pair:
@@ -789,10 +809,10 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     if (job->shard_bounds) memcpy(first, job->shard_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
     else qvz_shard_bounds(N, shards, first);
     /* quantizer: the qv plane (the -u product) only for a caller that wants the text */
-    if (job_plane(job, 1) && (!fu || job_plane(job, 3))) {                     /* allocated ahead of time, beside the upload */
+    if (job_plane(job, 0) && (!fu || job_plane(job, 2))) {                     /* allocated ahead of time, beside the upload */
         planes_early = 1;
-        d_qi = job_plane(job, 1); d_st = job_plane(job, 2); d_err = (double *)job_plane(job, -1);
-        if (fu) d_qv = job_plane(job, 3);
+        d_qi = job_plane(job, 0); d_st = job_plane(job, 1); d_err = (double *)job_plane(job, -1);
+        if (fu) d_qv = job_plane(job, 2);
     } else {
         if (fu) HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
         HIP(qvz_hip_malloc((void **)&d_qi, (size_t)C * ld));
@@ -807,11 +827,13 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     HIP(qvz_hip_copy_d2h(&status, d_status, sizeof(status), NULL));
     HIP(qvz_hip_stream_sync(NULL));
     if (status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
-    if (!job->draws_in_planes) qvz_hip_free(job->d_draws);
-    job->d_draws = NULL;
-    /* the symbols are not needed again either (this stage ends a job; qvz_job_release frees what is left): 15 GB at 100M x 150
-     * that the coder's buffers and the -u staging can have - with -u the process is otherwise near what the card holds */
-    qvz_hip_free(job->d_sym); job->d_sym = NULL;
+    if (!job->keep_resident) {                                                  /* (a sweep's next point quantizes the same matrix with the same draws) */
+        qvz_hip_free(job->d_draws);                                            /* 15 GB at 100M x 150, an allocation of its own for this */
+        job->d_draws = NULL;
+        /* the symbols are not needed again either (this stage ends a job; qvz_job_release frees what is left): 15 GB at 100M x
+         * 150 that the coder's buffers and the -u staging can have - with -u the process is otherwise near what the card holds */
+        qvz_hip_free(job->d_sym); job->d_sym = NULL;
+    }
     t1 = now();
     job->t_quantize = t1 - t0;
 
@@ -945,8 +967,10 @@ done:
     qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist);
     if (!planes_early) { qvz_hip_free(d_err); qvz_hip_free(d_qv); qvz_hip_free(d_qi); qvz_hip_free(d_st); }   /* (the early planes go with the job) */
     qvz_hip_free(d_out_own); qvz_hip_free(d_packed_own); qvz_hip_free(d_status);
-    if (job->d_draws) { qvz_hip_free(job->d_draws); job->d_draws = NULL; }
-    if (job->well_stream) { qvz_hip_stream_destroy(job->well_stream); job->well_stream = NULL; }
+    if (!job->keep_resident || rc) {
+        if (job->d_draws) { qvz_hip_free(job->d_draws); job->d_draws = NULL; }
+        if (job->well_stream) { qvz_hip_stream_destroy(job->well_stream); job->well_stream = NULL; }
+    }
     return rc;
 }
 
@@ -966,30 +990,67 @@ void qvz_job_release(qvz_job_t *job) {
     qvz_hip_free(job->d_sym); qvz_hip_free(job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
     qvz_hip_free(job->d_counts); qvz_hip_free(job->d_acc); qvz_hip_free(job->d_moved); qvz_hip_free(job->d_kstat);
     qvz_hip_free(job->d_cnt64); qvz_hip_free(job->d_counts64);
-    if (!job->draws_in_planes) qvz_hip_free(job->d_draws);
+    qvz_hip_free(job->d_draws);
     if (job->well_stream) qvz_hip_stream_destroy(job->well_stream);
     workspace_join(job);
+    qvz_hip_free(job->d_draws_early);                                           /* never handed over: no draws were started */
     qvz_hip_free(job->d_work);
     qvz_hip_free(job->d_planes);
     memset(job, 0, sizeof(*job));
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
+/* a rate-distortion sweep's side of encode_buffer: the points, where their outputs go, where their results go */
+typedef struct {
+    const qvz_sweep_point_t *points;
+    uint32_t n;
+    const char *out_path, *u_path;
+    int keep_all;
+    qvz_result_t *res;            /* [n] or NULL */
+} sweep_t;
+
 static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
-                         qvz_result_t *res, const char *shard_prefix, uint32_t shards);
+                         qvz_result_t *res, const char *shard_prefix, uint32_t shards, const sweep_t *sw);
 
 int qvz_encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
                       qvz_result_t *res) {
-    return encode_buffer(text, bytes, fout, fu, opts, res, NULL, 0);
+    return encode_buffer(text, bytes, fout, fu, opts, res, NULL, 0, NULL);
+}
+
+static void job_drop_codebooks(qvz_job_t *job) {
+    if (job->cbs) { for (uint32_t j = 0; j < job->K; ++j) qvz_codebook_free(job->cbs[j]); free(job->cbs); job->cbs = NULL; }
+    job->deferred_decisions = 0;
+}
+
+/* the operating point of a sweep: what -f / -r / -d / -D set (main.c:240-297); nothing the clustering or the counters read */
+static int job_set_point(qvz_job_t *job, const qvz_sweep_point_t *pt) {
+    job->opts.mode = pt->mode;
+    job->opts.ratio = pt->ratio;
+    job->opts.distortion = pt->distortion;
+    job->opts.dist_file = pt->dist_file;
+    if (pt->distortion == QVZ_DIST_CUSTOM) {
+        if (qvz_distortion_matrix_file(pt->dist_file, job->h_dist)) return qvz_job_fail(QVZ_E_ARG, "%s", qvz_hip_last_error());
+    } else if (qvz_distortion_matrix(pt->distortion, job->h_dist)) {
+        return qvz_job_fail(QVZ_E_ARG, "%s", qvz_hip_last_error());
+    }
+    return 0;
+}
+
+static FILE *sweep_open(const char *path, uint32_t idx, int keep_all, const char *how) {
+    char name[4096];
+    if (!keep_all) return fopen(path, how);
+    if ((size_t)snprintf(name, sizeof(name), "%s.%02u", path, idx) >= sizeof(name)) return NULL;
+    return fopen(name, how);
 }
 
 static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *fu, const qvz_options_t *opts,
-                         qvz_result_t *res, const char *shard_prefix, uint32_t shards) {
+                         qvz_result_t *res, const char *shard_prefix, uint32_t shards, const sweep_t *sw) {
     qvz_job_t job;
     qvz_result_t R;
     memset(&R, 0, sizeof(R));
-    const double t_start = now();
+    double t_start = now();
     uint8_t *fq_rows = NULL;                                      /* FASTQ input: the quality lines, in load_file's layout */
+    const uint32_t npoints = sw ? sw->n : 1;
     if (opts->input_format == QVZ_INPUT_FASTQ || (opts->input_format == QVZ_INPUT_AUTO && qvz_fastq_detect(text, bytes))) {
         uint64_t reads = 0;
         uint32_t columns = 0;
@@ -1001,63 +1062,137 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
     }
     int rc = qvz_job_init(&job, text, bytes, 0, 0, opts);
     if (rc) { free(fq_rows); return rc; }
-    uint64_t head_bytes = 0;
     /* pages of the big outputs, made by a helper thread beside everything up to their egress (host/qvz_egress.c): the shard
      * set first - its size is not known yet: 2 bits per symbol are assumed, what is written beyond goes through pwrite and
-     * what is not needed is given back - then the -u text, N (C + 1) bytes */
-    if (shards && fout && !shard_prefix) qvz_prealloc_start(fout, job.N * (uint64_t)job.C / 4);
-    if (shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));
-    job.want_text = fu != NULL;
+     * what is not needed is given back - then the -u text, N (C + 1) bytes (a sweep: per point, when its files are opened) */
+    if (!sw && shards && fout && !shard_prefix) qvz_prealloc_start(fout, job.N * (uint64_t)job.C / 4);
+    if (!sw && shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));
+    job.want_text = sw ? sw->u_path != NULL : fu != NULL;
     if (shards) qvz_job_start_workspace(&job, shards);                         /* the coder's record workspace and the quantizer's planes, beside the upload */
     if ((rc = qvz_job_upload(&job))) goto done;
     if ((rc = qvz_job_kmeans(&job, 0))) goto done;
     if (opts->verbose) printf("Clustering took %.4f seconds\n", job.t_cluster);                      /* main.c:56-58 */
     if ((rc = qvz_job_stats(&job))) goto done;
-    if (shards && (rc = qvz_job_start_draws(&job))) goto done;                  /* the WELL generator runs beside the codebooks */
-    if ((rc = qvz_job_codebooks(&job))) goto done;
-    if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", job.t_stats + job.t_codebook);   /* main.c:66-67 */
-    if (shards && !shard_prefix) {                                              /* one shard-set file */
-        if ((rc = qvz_job_compress_shardset(&job, fout, fu, shards, &R.stream_bytes, &R.file_bytes, &R.distortion))) goto done;
-    } else if (shards) {
-        if ((rc = qvz_job_compress_sharded(&job, shard_prefix, fu, shards, &R.stream_bytes, &R.distortion))) goto done;
-        head_bytes = qvz_shard_file_image(NULL, job.K, job.C, 0, (const qvz_codebook_t *const *)job.cbs, job.well_state, NULL, 0) - 128;
-        R.file_bytes = (uint64_t)shards * (head_bytes + 128) + R.stream_bytes;
-    } else {
-        if ((rc = qvz_job_write_codebooks(&job, fout, &head_bytes))) goto done;
-        if ((rc = qvz_job_compress(&job, fout, fu, &R.stream_bytes, &R.distortion))) goto done;
-        R.file_bytes = head_bytes + 128 + R.stream_bytes;
-    }
-    R.lines = job.N;
-    R.columns = job.C;
-    R.kmeans_iterations = job.kmeans_iterations;
-    R.deferred_decisions = job.deferred_decisions;
-    R.t_upload = job.t_upload; R.t_cluster = job.t_cluster; R.t_stats = job.t_stats; R.t_codebook = job.t_codebook;
-    R.t_encode = job.t_encode;
-    R.t_quantize = job.t_quantize; R.t_coder = job.t_coder; R.t_egress = job.t_egress;
-    R.t_total = now() - t_start;
-    if (opts->verbose) {                                                       /* main.c:96-121 */
-        switch (opts->distortion) {
-            case QVZ_DIST_MANHATTAN: printf("L1 distortion: %f\n", R.distortion); break;
-            case QVZ_DIST_MSE: printf("MSE distortion: %f\n", R.distortion); break;
-            case QVZ_DIST_LORENTZ: printf("log(1+L1) distortion: %f\n", R.distortion); break;
-            case QVZ_DIST_CUSTOM: printf("Custom distortion: %f\n", R.distortion); break;          /* main.c:110-112 */
-            default: break;
+    for (uint32_t p = 0; p < npoints; ++p) {
+        uint64_t head_bytes = 0;
+        if (sw) {                                                               /* the point's flags and files; the shared phases count for the first */
+            if (p) { t_start = now(); job.t_upload = job.t_cluster = job.t_stats = 0.0; }
+            job_drop_codebooks(&job);
+            if ((rc = job_set_point(&job, &sw->points[p]))) goto done;
+            if (sw->out_path && !shard_prefix) {
+                fout = sweep_open(sw->out_path, p, sw->keep_all, "wb");        /* main.c:74 */
+                if (!fout) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); goto done; }
+            }
+            if (sw->u_path) {
+                fu = sweep_open(sw->u_path, p, sw->keep_all, "w");              /* main.c:81 */
+                if (!fu) { rc = qvz_job_fail(QVZ_E_ARG, "Unable to open uncompressed file"); goto done; }
+            }
+            job.keep_resident = p + 1 < npoints;                                /* the matrix and the draws serve the next point too */
         }
-        printf("Lines: %llu\n", (unsigned long long)R.lines);
-        printf("Columns: %u\n", R.columns);
-        printf("Total bytes used: %llu\n", (unsigned long long)R.stream_bytes);
-        printf("Encoding took %.4f seconds.\n", R.t_total);                    /* prints the TOTAL timer, main.c:119 */
-        printf("Total time elapsed: %.4f seconds.\n", R.t_total);
+        if (sw && shards && fout && !shard_prefix) qvz_prealloc_start(fout, job.N * (uint64_t)job.C / 4);
+        if (sw && shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));
+        if (shards && (rc = qvz_job_start_draws(&job))) goto done;              /* the WELL generator runs beside the codebooks */
+        if ((rc = qvz_job_codebooks(&job))) goto done;
+        if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", job.t_stats + job.t_codebook);   /* main.c:66-67 */
+        if (shards && !shard_prefix) {                                          /* one shard-set file */
+            if ((rc = qvz_job_compress_shardset(&job, fout, fu, shards, &R.stream_bytes, &R.file_bytes, &R.distortion))) goto done;
+        } else if (shards) {
+            if ((rc = qvz_job_compress_sharded(&job, shard_prefix, fu, shards, &R.stream_bytes, &R.distortion))) goto done;
+            head_bytes = qvz_shard_file_image(NULL, job.K, job.C, 0, (const qvz_codebook_t *const *)job.cbs, job.well_state, NULL, 0) - 128;
+            R.file_bytes = (uint64_t)shards * (head_bytes + 128) + R.stream_bytes;
+        } else {
+            if ((rc = qvz_job_write_codebooks(&job, fout, &head_bytes))) goto done;
+            if ((rc = qvz_job_compress(&job, fout, fu, &R.stream_bytes, &R.distortion))) goto done;
+            R.file_bytes = head_bytes + 128 + R.stream_bytes;
+        }
+        R.lines = job.N;
+        R.columns = job.C;
+        R.kmeans_iterations = job.kmeans_iterations;
+        R.deferred_decisions = job.deferred_decisions;
+        R.t_upload = job.t_upload; R.t_cluster = job.t_cluster; R.t_stats = job.t_stats; R.t_codebook = job.t_codebook;
+        R.t_encode = job.t_encode;
+        R.t_quantize = job.t_quantize; R.t_coder = job.t_coder; R.t_egress = job.t_egress;
+        R.t_total = now() - t_start;
+        if (opts->verbose) {                                                       /* main.c:96-121 */
+            switch (job.opts.distortion) {
+                case QVZ_DIST_MANHATTAN: printf("L1 distortion: %f\n", R.distortion); break;
+                case QVZ_DIST_MSE: printf("MSE distortion: %f\n", R.distortion); break;
+                case QVZ_DIST_LORENTZ: printf("log(1+L1) distortion: %f\n", R.distortion); break;
+                case QVZ_DIST_CUSTOM: printf("Custom distortion: %f\n", R.distortion); break;          /* main.c:110-112 */
+                default: break;
+            }
+            printf("Lines: %llu\n", (unsigned long long)R.lines);
+            printf("Columns: %u\n", R.columns);
+            printf("Total bytes used: %llu\n", (unsigned long long)R.stream_bytes);
+            printf("Encoding took %.4f seconds.\n", R.t_total);                    /* prints the TOTAL timer, main.c:119 */
+            printf("Total time elapsed: %.4f seconds.\n", R.t_total);
+        }
+        if (opts->stats)                                                           /* main.c:124-126 */
+            printf("rate, %.4f, distortion, %.4f, time, %.4f, size, %llu \n", (R.stream_bytes * 8.) / ((double)R.lines * R.columns),
+                   R.distortion, R.t_total, (unsigned long long)R.stream_bytes);
+        if (sw) {
+            if (sw->res) sw->res[p] = R;
+            qvz_prealloc_finish(fu);
+            if (shards && !shard_prefix) qvz_prealloc_finish(fout);
+            if (fu) { fclose(fu); fu = NULL; }
+            if (fout) { fclose(fout); fout = NULL; }
+        }
     }
-    if (opts->stats)                                                           /* main.c:124-126 */
-        printf("rate, %.4f, distortion, %.4f, time, %.4f, size, %llu \n", (R.stream_bytes * 8.) / ((double)R.lines * R.columns),
-               R.distortion, R.t_total, (unsigned long long)R.stream_bytes);
 done:
     qvz_prealloc_finish(fu);
     if (shards && !shard_prefix) qvz_prealloc_finish(fout);
+    if (sw) { if (fu) fclose(fu); if (fout) fclose(fout); }                    /* a point that failed half-way */
     qvz_job_release(&job);
     free(fq_rows);
     if (res) *res = R;
+    return rc;
+}
+
+uint32_t qvz_sweep_parse(const char *text, const qvz_options_t *opts, qvz_sweep_point_t *points, uint32_t max) {
+    uint32_t n = 0;
+    if (!text || !opts || !points) return 0;
+    if (strcmp(text, "rd") == 0) {                                              /* generate_rd.sh:5-8: comp = idx * 0.05 through bc -l, -c 1 -f $comp */
+        if (max < 20) return 0;
+        for (uint32_t idx = 0; idx < 20; ++idx) {
+            char comp[16];
+            snprintf(comp, sizeof(comp), ".%02u", idx * 5);                    /* "0", ".05", ".10" ... as bc prints them; atof as main.c:241 */
+            points[idx].mode = QVZ_MODE_RATIO;
+            points[idx].ratio = idx ? atof(comp) : atof("0");
+            points[idx].distortion = opts->distortion;
+            points[idx].dist_file = opts->dist_file;
+        }
+        return 20;
+    }
+    if ((text[0] != 'f' && text[0] != 'r') || text[1] != ':') return 0;
+    const char *q = text + 2;
+    while (*q) {
+        char *end;
+        const double v = strtod(q, &end);                                       /* atof's conversion (main.c:241,247) */
+        if (end == q || n == max) return 0;
+        points[n].mode = text[0] == 'f' ? QVZ_MODE_RATIO : QVZ_MODE_FIXED;
+        points[n].ratio = v;
+        points[n].distortion = opts->distortion;
+        points[n].dist_file = opts->dist_file;
+        ++n;
+        q = *end == ',' ? end + 1 : end;
+        if (*end && *end != ',') return 0;
+    }
+    return n;
+}
+
+int qvz_encode_file_sweep(const char *in_path, const char *out_path, const qvz_options_t *opts, const qvz_sweep_point_t *points,
+                          uint32_t npoints, uint32_t shards, int keep_all, qvz_result_t *res) {
+    if (!in_path || !out_path || !opts || !points || !npoints || npoints > 100) return qvz_job_fail(QVZ_E_ARG, "a sweep needs 1..100 points");
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) return qvz_job_fail(QVZ_E_ARG, "load_file returned error: 1");       /* LF_ERROR_NOT_FOUND, lines.h:18 */
+    struct stat st;
+    if (fstat(fd, &st) || st.st_size == 0) { close(fd); return qvz_job_fail(QVZ_E_DATA, "empty or unreadable input"); }
+    void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);   /* lines.c:64 */
+    if (map == MAP_FAILED) { close(fd); return qvz_job_fail(QVZ_E_NOMEM, "mmap failed"); }
+    const sweep_t sw = {points, npoints, out_path, opts->uncompressed_name, keep_all, res};
+    const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, NULL, NULL, opts, NULL, NULL, shards, &sw);
+    munmap(map, (size_t)st.st_size);
+    close(fd);
     return rc;
 }
 
@@ -1097,7 +1232,7 @@ int qvz_encode_file_sharded(const char *in_path, const char *out_prefix, const q
         fu = fopen(opts->uncompressed_name, "w");
         if (!fu) { munmap(map, (size_t)st.st_size); close(fd); return qvz_job_fail(QVZ_E_ARG, "Unable to open uncompressed file"); }
     }
-    const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, NULL, fu, opts, res, out_prefix, shards);
+    const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, NULL, fu, opts, res, out_prefix, shards, NULL);
     if (fu) fclose(fu);
     munmap(map, (size_t)st.st_size);
     close(fd);
@@ -1120,7 +1255,7 @@ int qvz_encode_file_shardset(const char *in_path, const char *out_path, const qv
         fu = fopen(opts->uncompressed_name, "w");
         if (!fu) { fclose(fout); munmap(map, (size_t)st.st_size); close(fd); return qvz_job_fail(QVZ_E_ARG, "Unable to open uncompressed file"); }
     }
-    const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, fout, fu, opts, res, NULL, shards);
+    const int rc = encode_buffer((const uint8_t *)map, (uint64_t)st.st_size, fout, fu, opts, res, NULL, shards, NULL);
     if (fu) fclose(fu);
     fclose(fout);
     munmap(map, (size_t)st.st_size);

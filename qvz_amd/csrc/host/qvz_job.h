@@ -38,6 +38,7 @@ typedef struct qvz_job {
     double *d_moved;
     int32_t *d_kstat;
     int uploaded, clustered, counted;
+    int keep_resident;          /* a sweep: the sharded compress leaves the matrix and the draws for the next operating point */
     double t_upload, t_cluster, t_stats, t_codebook, t_encode;
     double t_quantize, t_coder, t_egress;   /* inside t_encode of a sharded encode: WELL wait + quantizer, coder kernels, what leaves the device afterwards */
     /* WELL draws of the whole part, started on a side stream before the codebooks are generated (they depend on the seed
@@ -57,7 +58,9 @@ typedef struct qvz_job {
      * to a second, whichever large allocation came first (want_text: set by the caller before qvz_job_start_workspace) */
     void *d_planes;
     uint64_t planes_bytes;
-    int want_text, draws_in_planes;
+    int want_text;
+    uint8_t *d_draws_early;           /* the draw matrix: allocated first, an allocation of its own (given back after the quantizer) */
+    int draws_early_state;            /* 0 none, 1 being allocated, 2 decided: qvz_job_start_draws waits for this, not for the thread */
     int work_running, work_rc;
     unsigned long work_thread;        /* pthread_t */
     /* ---- a job that holds PART of a file (one device of a multi-device encode, qvz_multi.c); all zero otherwise ---- */

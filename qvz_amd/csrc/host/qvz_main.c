@@ -4,7 +4,10 @@
  * on the MI355X through libqvzhip.
  * Environment (additions): QVZ_WELL_SEED=debug|time (default time), QVZ_DEVICE=<ordinal>,
  * QVZ_CHUNK_READS=<n>, QVZ_SHARDS=<n> (sharded output: one shard-set file, include/qvz_shardset.h; with
- * QVZ_SHARD_FILES=1 one reference-format file per shard instead), QVZ_INPUT=fastq|qual, QVZ_TIMING=1 (phase seconds on stderr). */
+ * QVZ_SHARD_FILES=1 one reference-format file per shard instead), QVZ_INPUT=fastq|qual, QVZ_TIMING=1 (phase seconds on stderr),
+ * QVZ_SWEEP=rd | f:<v>,<v>,... | r:<v>,<v>,... (a rate-distortion sweep in one process, reference generate_rd.sh:1-17: the
+ * cluster labels and the counters are made once, every point prints its -s line and writes <output>.NN; QVZ_SWEEP_OUT=last:
+ * every point overwrites <output> as the script's encodes do). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -150,6 +153,22 @@ int main(int argc, char **argv) {
             devices[ndev++] = (int)d;
             p = *end == ',' ? end + 1 : end;
         }
+    }
+    if (getenv("QVZ_SWEEP")) {                                    /* generate_rd.sh in one process (include/qvz_encode.h) */
+        qvz_sweep_point_t points[100];
+        const uint32_t np = qvz_sweep_parse(getenv("QVZ_SWEEP"), &opts, points, 100);
+        if (!np || ndev > 1 || files) {
+            printf("QVZ_SWEEP: expected rd, f:<v>,<v>,... or r:<v>,<v>,... (at most 100 points; not with several QVZ_DEVICES or QVZ_SHARD_FILES)\n");
+            exit(1);
+        }
+        if (ndev == 1) opts.device = devices[0];
+        opts.stats = 1;                                           /* the -s lines are the sweep's product (generate_rd.sh:8,16) */
+        const int keep_all = !(getenv("QVZ_SWEEP_OUT") && strcmp(getenv("QVZ_SWEEP_OUT"), "last") == 0);
+        if (qvz_encode_file_sweep(input_name, output_name, &opts, points, np, shards, keep_all, NULL)) {
+            printf("%s\n", qvz_encode_last_error());
+            exit(1);
+        }
+        return 0;
     }
     if (ndev == 1) opts.device = devices[0];                      /* one ordinal named: that GPU, through the single-device driver */
     if (ndev > 1 && files) {                                      /* options that cannot be honoured together are refused, not ignored */

@@ -1970,7 +1970,9 @@ extern "C" int qvz_coder_rcp_one_step_ok_ex(double *worst_out) {
         unsigned long long *d = nullptr, h = ~0ull;
         if (hipMalloc(&d, sizeof(h)) == hipSuccess && hipMemset(d, 0, sizeof(h)) == hipSuccess) {
             hipLaunchKernelGGL(k_rcp_accuracy<1>, dim3((nmax + 255) / 256), dim3(256), 0, 0, d, nmax);
-            if (hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) h = ~0ull;
+            // a launch that failed leaves the memset's zero behind - which would read as "exact": only a residual the kernel
+            // really wrote counts (some divisor of 2^19 always leaves a non-zero one)
+            if (hipGetLastError() != hipSuccess || hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || h == 0) h = ~0ull;
         }
         if (d) (void)hipFree(d);
         double w;

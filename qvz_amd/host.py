@@ -115,6 +115,50 @@ def encode_file_devices(in_path, out_path, devices, shards, clusters=1, mode=MOD
     return r
 
 
+class SweepPoint(C.Structure):
+    """qvz_sweep_point_t (include/qvz_encode.h)."""
+    _fields_ = [("mode", C.c_int), ("ratio", C.c_double), ("distortion", C.c_int), ("dist_file", C.c_char_p)]
+
+
+def sweep_points(text, dist="M", dist_file=None):
+    """qvz_sweep_parse: "rd" (the reference script's twenty points) or "<f|r>:<v>,<v>,..." -> list of (mode, ratio)."""
+    o = default_options()
+    o.distortion = DIST.get(dist, dist)
+    if dist_file:
+        o.dist_file = dist_file.encode()
+    pts = (SweepPoint * 100)()
+    n = lib().qvz_sweep_parse(text.encode(), C.byref(o), pts, 100)
+    return [(pts[i].mode, pts[i].ratio) for i in range(n)]
+
+
+def encode_file_sweep(in_path, out_path, points, shards=0, keep_all=True, clusters=1, dist="M", threshold=4.0, u_path=None,
+                      seed_mode=None, device=0, stats=False, dist_file=None):
+    """Rate-distortion sweep in one job (qvz_encode_file_sweep; reference generate_rd.sh:1-17): `points` is a list of
+    (mode, ratio) or (mode, ratio, dist) operating points; labels and counters are made once. Outputs out_path.NN (-u: u_path.NN)
+    when keep_all. Returns the list of Results."""
+    o = default_options()
+    o.clusters, o.cluster_threshold, o.device, o.stats = clusters, threshold, device, int(stats)
+    if u_path:
+        o.uncompressed_name = u_path.encode()
+    if seed_mode is not None:
+        o.seed_mode = seed_mode
+    pts = (SweepPoint * len(points))()
+    keep = []
+    for i, pt in enumerate(points):
+        d = pt[2] if len(pt) > 2 else dist
+        pts[i].mode, pts[i].ratio = pt[0], pt[1]
+        if d == "D" or (isinstance(d, str) and d not in DIST):
+            keep.append((dist_file if d == "D" else d).encode())
+            pts[i].distortion, pts[i].dist_file = 4, keep[-1]
+        else:
+            pts[i].distortion = DIST.get(d, d)
+    res = (Result * len(points))()
+    rc = lib().qvz_encode_file_sweep(in_path.encode(), out_path.encode(), C.byref(o), pts, len(points), shards, int(keep_all), res)
+    if rc:
+        raise QvzHipError(f"qvz_encode_file_sweep failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+    return list(res)
+
+
 def shardset_stat(path):
     si = ShardsetInfo()
     rc = lib().qvz_shardset_stat(path.encode(), C.byref(si))

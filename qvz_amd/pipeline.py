@@ -13,6 +13,7 @@ reduced counters; quantisation and coding are embarrassingly parallel per shard 
 """
 import ctypes
 import os
+import threading
 import time
 
 import numpy as np
@@ -22,19 +23,21 @@ from . import host
 from . import kernels as K
 
 LINES_PER_BLOCK = 1_000_000   # reference include/lines.h:12
+_RAND_LOCK = threading.Lock()
 
 
 def reference_centroid_lines(n_total, k, reseed=True):
     """Read indices the reference picks as initial centroids (cluster.c:198-201): libc rand(), fresh-process state."""
     libc = ctypes.CDLL(None)
-    if reseed:
-        libc.srand(1)
     blocks = (n_total + LINES_PER_BLOCK - 1) // LINES_PER_BLOCK
     lines = []
-    for _ in range(k):
-        b = libc.rand() % blocks
-        count = min(LINES_PER_BLOCK, n_total - b * LINES_PER_BLOCK)
-        lines.append(b * LINES_PER_BLOCK + libc.rand() % count)
+    with _RAND_LOCK:                  # libc's generator is the process's: ranks that are threads (LocalWorld) draw one after the other
+        if reseed:
+            libc.srand(1)
+        for _ in range(k):
+            b = libc.rand() % blocks
+            count = min(LINES_PER_BLOCK, n_total - b * LINES_PER_BLOCK)
+            lines.append(b * LINES_PER_BLOCK + libc.rand() % count)
     return lines
 
 
@@ -238,11 +241,71 @@ class HipBackend:
         return [len(s) for s in streams], streams, None, feed, None
 
 
+def all_reduce_sum(t, group):
+    """SUM of `t` over the ranks of `group`, in place: a torch.distributed process group (RCCL when the ranks are the GPUs of a
+    node - backend "nccl" -, gloo between CPU ranks), or a group object with an all_reduce method of its own (LocalWorld)."""
+    if hasattr(group, "all_reduce"):
+        group.all_reduce(t)
+    else:
+        import torch.distributed as dist_mod
+        dist_mod.all_reduce(t, group=group)
+
+
+class LocalWorld:
+    """`world` ranks as THREADS of one process that share one device: the read-sharded schedule of encode_pass with more parts
+    than a box has GPUs (a test box has one, and allows few processes on it), the counterpart of the C driver's host-staged sum
+    for an ordinal listed more than once (host/qvz_multi.c). group(rank) is what a rank passes to encode_pass as `group`; the
+    sum is taken when all ranks have arrived. serial(backend) wraps a compute backend so that one rank at a time is inside the
+    C library (its coder keeps per-device buffers and streams; the library is not re-entrant by contract)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._barrier = threading.Barrier(world)
+        self._slots = [None] * world
+        self._lock = threading.Lock()
+
+    def group(self, rank):
+        return _LocalGroup(self, rank)
+
+    def serial(self, backend):
+        return _SerialBackend(backend, self._lock)
+
+
+class _LocalGroup:
+    def __init__(self, world, rank):
+        self._w, self.rank = world, rank
+
+    def all_reduce(self, t):
+        w = self._w
+        w._slots[self.rank] = t
+        w._barrier.wait()                                  # every rank's tensor is there (same stream: in issue order)
+        total = w._slots[0].clone()
+        for other in w._slots[1:]:
+            total += other
+        w._barrier.wait()                                  # ... and has been read by everybody before anyone overwrites its own
+        t.copy_(total)
+
+
+class _SerialBackend:
+    def __init__(self, inner, lock):
+        self._inner, self._lock = inner, lock
+
+    def __getattr__(self, name):
+        attr = getattr(self._inner, name)
+        if not callable(attr):
+            return attr
+
+        def locked(*a, **kw):
+            with self._lock:
+                return attr(*a, **kw)
+        return locked
+
+
 def fetch_centroids(backend, sym, n, first_read, n_total, k, group=None, lines=None):
     """The k reads the reference copies as initial centroids (cluster.c:198-201): their global numbers come from libc
     rand() in a fresh process's state, identical on every rank; each is fetched from the rank that owns it and made
     global by a SUM over ranks (k * c bytes; SURVEY.md section 8e, collective 1)."""
-    import torch.distributed as dist_mod
     if lines is None:
         lines = reference_centroid_lines(n_total, k)
     c = sym.shape[0]
@@ -252,7 +315,7 @@ def fetch_centroids(backend, sym, n, first_read, n_total, k, group=None, lines=N
         rows = backend.read_rows(sym, [i for _, i in mine])
         means[torch.as_tensor([j for j, _ in mine], dtype=torch.long, device=means.device)] = rows.to(torch.int32)
     if group is not None:
-        dist_mod.all_reduce(means, group=group)
+        all_reduce_sum(means, group)
     return means.to(torch.uint8).contiguous()
 
 
@@ -275,7 +338,6 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     want_reuse=True on the first operating point and hand its result["reuse"] to the others (rd_sweep below).
     backend: who computes (default: HipBackend, the HIP kernels on this process's GPU).
     """
-    import torch.distributed as dist_mod
     c, ld = sym.shape
     k = clusters
     assert first_read % 4 == 0, "shards must start on a WELL word boundary"
@@ -291,8 +353,10 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     counts = be.zeros(k, torch.int32)
     acc = be.zeros((k, c), torch.int64)
     iters = 0
+    means_assigned = means0          # the means the LAST assignment pass measured against: what the final labels belong to (cluster.c:221-233)
     if reuse is not None:
         labels, means, iters = reuse["labels"], reuse["means"], reuse["kmeans_iterations"]
+        means_assigned = reuse.get("means_assigned", means)
     # One cluster: every read is in it whatever the centroid is (cluster.c:75-98 finds the nearest of one), so there is
     # no assignment pass, and the one accumulation the reference's loop amounts to (column sums of the bytes) is read off
     # the PMF counters below instead of costing a pass over the symbols of its own.
@@ -301,8 +365,9 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
         acc.zero_()
         be.kmeans_step(sym, n, means, labels, counts, acc)
         if group is not None:
-            dist_mod.all_reduce(acc, group=group)
-            dist_mod.all_reduce(counts, group=group)
+            all_reduce_sum(acc, group)
+            all_reduce_sum(counts, group)
+        means_assigned = means.clone()
         moved, status = be.kmeans_update(acc, counts, means)
         iters += 1
         mv = moved[0].item()
@@ -321,7 +386,7 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
         cnt = be.zeros((k, c, 72, 72), torch.int32)
         be.pmf_hist(sym, n, labels if k > 1 else None, k, cnt)
         if group is not None:
-            dist_mod.all_reduce(cnt, group=group)
+            all_reduce_sum(cnt, group)
     if k == 1 and reuse is None:
         # sum over the reads of symbol_s = sum over x of x * #(X_s = x), exact in int64 (means are kept as symbols, byte - 33:
         # floor((sum + 33 n) / n) = floor(sum / n) + 33); a second iteration would recompute the same sums, so the iteration
@@ -395,17 +460,17 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
 
     err_sum = (out["err"] / float(c)).sum()
     if group is not None:
-        dist_mod.all_reduce(err_sum, group=group)
+        all_reduce_sum(err_sum, group)
     distortion = float(err_sum.item()) / float(n_total)
     wall["total"] = time.perf_counter() - t0
     res = dict(stream_bytes=stream_sizes, total_stream_bytes=sum(stream_sizes), distortion=distortion,
                kmeans_iterations=iters, deferred=deferred, wall=wall, codebooks=cbs)
     if want_reuse:
-        res["reuse"] = dict(labels=labels, means=means, kmeans_iterations=iters, cnt=cnt, draws=draws)
+        res["reuse"] = dict(labels=labels, means=means, means_assigned=means_assigned, kmeans_iterations=iters, cnt=cnt, draws=draws)
     if keep_device and coder != "host":
         res.update(coded=coded, cap_per_shard=coded.numel() // shards, qv=out["qv"], labels=labels)
     if keep:
-        res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, err=out["err"], feed=feed, qi=out["qi"], st=out["st"])
+        res.update(streams=streams, qv=out["qv"], labels=labels, cnt=cnt, means=means, means_assigned=means_assigned, err=out["err"], feed=feed, qi=out["qi"], st=out["st"])
     return res
 
 

@@ -64,3 +64,23 @@ def case_opts(name):
 
 def phase(name):
     return np.load(os.path.join(GOLD, name + ".phase.npz"))
+
+
+SWEEPS = MANIFEST.get("sweeps", {})
+
+
+def sweep_rows(name):
+    """input rows of a rate-distortion sweep fixture (reference generate_rd.sh:1-17, one reference run per point)"""
+    e = SWEEPS[name]
+    spec = e["input"]
+    rows = O.qgen1_rows(spec["seed"], spec["n"], spec["c"])
+    assert md5(rows.tobytes()) == e["input_md5"], f"{name}: input md5 mismatch"
+    return rows
+
+
+def sweep_opts(name):
+    """-> (k, oracle mode, [ratio as the reference's atof reads the script's spelling])"""
+    e = SWEEPS[name]
+    k = int(e["fixed"].split()[1])
+    mode = O.MODE_RATIO if e["flag"] == "-f" else O.MODE_FIXED
+    return k, mode, [float(p["comp"]) for p in e["points"]]

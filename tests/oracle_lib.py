@@ -57,6 +57,8 @@ def lib():
         L.orc_kmeans.restype = C.c_int
         L.orc_kmeans.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, u64p, u8p, u8p, u32p]
         L.orc_stats.argtypes = [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint32, u32p]
+        L.orc_assign.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32, u8p, u8p, u32p]
+        L.orc_assign.restype = None
         L.orc_marginals.argtypes = [u32p, C.c_uint32, f64p]
         L.orc_lloyd_max.restype = C.c_double
         L.orc_lloyd_max.argtypes = [f64p, f64p, C.c_uint32, u8p, u8p, u8p, f64p]
@@ -147,10 +149,24 @@ def kmeans(rows, k, threshold=4.0, centroids=None):
     return labels, means, counts, iters
 
 
-def stats(rows, labels, k):
+def assign(rows, means_raw):
+    """One assignment pass (cluster.c:136-187) of the reads against k means given as raw bytes -> (labels, counts)."""
+    n, c1 = rows.shape
+    means_raw = np.ascontiguousarray(means_raw, dtype=np.uint8)
+    k = means_raw.shape[0]
+    assert means_raw.shape == (k, c1 - 1)
+    labels = np.zeros(n, dtype=np.uint8)
+    counts = np.zeros(k, dtype=np.uint32)
+    lib().orc_assign(_p(rows, C.c_uint8), n, c1 - 1, k, _p(means_raw, C.c_uint8), _p(labels, C.c_uint8), _p(counts, C.c_uint32))
+    return labels, counts
+
+
+def stats(rows, labels, k, out=None):
+    """cnt[k][c][72][72] of the reads; out: counters of earlier pieces of the same file to add to."""
     n, c1 = rows.shape
     c = c1 - 1
-    cnt = np.zeros((k, c, A, A), dtype=np.uint32)
+    cnt = np.zeros((k, c, A, A), dtype=np.uint32) if out is None else out
+    assert cnt.shape == (k, c, A, A) and cnt.dtype == np.uint32 and cnt.flags.c_contiguous
     lib().orc_stats(_p(rows, C.c_uint8), _p(labels, C.c_uint8), n, c, k, _p(cnt, C.c_uint32))
     return cnt
 

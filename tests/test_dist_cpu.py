@@ -101,3 +101,63 @@ def test_rank_read_ranges_are_word_aligned_and_cover_everything():
                 assert a % 4 == 0 or a == b      # only an empty trailing shard may start off a word boundary
                 prev = b
             assert prev == n_total
+
+
+def run_local_world(world, n_total, cols, seed, make_sym, make_backend, **kw):
+    """The product's schedule with `world` ranks as threads of this process (pipeline.LocalWorld): every rank owns
+    rank_read_range's reads, gets make_sym(first, n) as its matrix and make_backend() (serialised) as its compute backend.
+    -> [(first, last, result of encode_pass)] by rank."""
+    import threading
+    from qvz_amd import pipeline as P
+    lw = P.LocalWorld(world)
+    backends = [lw.serial(make_backend()) for _ in range(world)]              # made on this thread: one-time set-up is not re-entrant
+    out, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            first, last = P.rank_read_range(n_total, world, rank)
+            sym = make_sym(first, last - first)
+            out[rank] = (first, last, P.encode_pass(sym, last - first, first, n_total, None, group=lw.group(rank), keep=True,
+                                                    backend=backends[rank], **kw), backends[rank])
+        except BaseException as exc:  # noqa: BLE001 - a rank that dies must not leave the others in the barrier
+            errors.append((rank, repr(exc)))
+            lw._barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=900)
+    assert not errors, errors
+    return out
+
+
+def test_eight_rank_partition_equals_single_process():
+    """BASELINE configs[4]'s partition - eight parts, -c 3 -d M -r 1.0 - at a size the oracle finishes in seconds, ranks as
+    threads (pipeline.LocalWorld): the centroid reads lie on three different ranks, every rank's labels, all-reduced counters,
+    codebooks, quantized rows and stream equal the single-process oracle's; the streams byte for byte, against the oracle coding
+    the rank's reads from the WELL state it steps to itself."""
+    from qvz_amd import pipeline as P
+    n_total, cols, k, seed, world = 10000, 24, 3, 1, 8
+    lines = P.reference_centroid_lines(n_total, k)
+    owners = {next(r for r in range(world) if P.rank_read_range(n_total, world, r)[0] <= ln < P.rank_read_range(n_total, world, r)[1]) for ln in lines}
+    assert len(owners) == 3, (lines, owners)
+    got = run_local_world(world, n_total, cols, seed, lambda first, n: sym_from_rows(O.qgen1_rows(seed, n, cols, first=first)), OracleBackend,
+                          clusters=k, mode=O.MODE_FIXED, ratio=1.0, dist="M", shards=1)
+    rows = O.qgen1_rows(seed, n_total, cols)
+    labels, means, _, iters = O.kmeans(rows, k)
+    cnt = O.stats(rows, labels, k)
+    dmat = O.distortion("M")
+    cbs = [O.generate_codebook(cnt[j], dmat, O.MODE_FIXED, 1.0) for j in range(k)]
+    single = O.encode_stream(rows, labels, cbs, dmat)
+    blob = b"".join(cb.serialize() for cb in cbs)
+    assert got[0][0] == 0 and got[-1][1] == n_total and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    for first, last, r, be in got:
+        assert r["kmeans_iterations"] == iters and r["means"].numpy().tobytes() == (means - 33).tobytes()
+        assert r["labels"][: last - first].numpy().tobytes() == labels[first:last].tobytes()
+        assert r["cnt"].numpy().astype(np.uint32).tobytes() == cnt.tobytes()
+        assert b"".join(cb.serialize() for cb in r["codebooks"]) == blob
+        assert abs(r["distortion"] - single["distortion"]) < 1e-9 * max(1.0, single["distortion"])
+        assert (r["qv"][:, : last - first].numpy().T + 33).tobytes() == single["u"][first:last, :cols].tobytes()
+        state = O.well_states_at([first * cols // 4])[0]
+        assert r["streams"][0] == O.encode_stream(rows[first:last], labels[first:last], cbs, dmat, well_state=state)["stream"]

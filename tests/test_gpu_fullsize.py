@@ -10,7 +10,12 @@ What can be checked at that size without a 100M-read CPU run:
       stream must equal the GPU's byte for byte. The WELL state at each shard's first draw is found by STEPPING the
       oracle's generator through the file's whole draw stream (3.75e9 words, a few seconds of one host core) - no
       product code is involved in the oracle's leg, the jump-ahead included;
-  (d) counters: every (cluster, column) tile sums to the number of reads labelled with that cluster.
+  (d) counters: every (cluster, column) tile sums to the number of reads labelled with that cluster;
+  (e) the labels and the counters of the WHOLE matrix against the oracle: host processes (tests/oracle_workers.py, no GPU)
+      regenerate all reads from QGEN-1's definition, assign each to the nearest of the means the last assignment pass measured
+      against (orc_assign, cluster.c:136-187) and count its symbol pairs under the oracle's own label (orc_stats,
+      codebook.c:185-205): every one of the 1e8 labels and every one of the k x 150 x 72 x 72 counters must equal the GPU's -
+      nothing of (b) and (c) rests on labels or counters only the GPU has seen.
 """
 import numpy as np
 import pytest
@@ -69,6 +74,16 @@ def test_full_size_encode_round_trip_and_oracle_parity(name):
     per_cluster = torch.bincount(labels[:n].to(torch.int64), minlength=k)
     tile_sums = cnt.sum(dim=(2, 3), dtype=torch.int64)                           # (k, C)
     assert torch.equal(tile_sums, per_cluster[:, None].expand(k, C))
+
+    # (e) every label and every counter against the oracle's own, all reads regenerated on host cores
+    import oracle_workers as W
+    means_raw = (r["reuse"]["means_assigned"].cpu().numpy() + 33).astype(np.uint8) if k > 1 else None
+    labels_h = labels[:n].cpu().numpy() if k > 1 else None
+    ocnt, mismatch, ocounts = W.recount(seed, n, C, k, means_raw=means_raw, gpu_labels=labels_h)
+    assert mismatch < 0, f"read {mismatch}: the GPU's k-means label differs from the oracle's"
+    assert np.array_equal(ocounts.astype(np.int64), per_cluster.cpu().numpy())
+    assert np.array_equal(ocnt, cnt.cpu().numpy().astype(np.uint32)), "PMF counters of the whole matrix differ from the oracle's"
+    del ocnt, labels_h
 
     # (a) decode all streams on the GPU: must reproduce the quantizer's plane (and the labels)
     qv, lab = host.decode_shards_gpu(r["coded"], r["cap_per_shard"], sizes, n, C, [cb.handle for cb in r["codebooks"]], SHARDS,

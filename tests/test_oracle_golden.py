@@ -25,6 +25,20 @@ def test_encode_byte_identical(name):
         assert r["u"] == G.gz(name + ".u.gz")
 
 
+@pytest.mark.parametrize("name", sorted(G.SWEEPS))
+def test_sweep_points_byte_identical(name):
+    """The reference's rate-distortion sweep (generate_rd.sh:1-17; `-c 1 -f 0 ... .95`, and its commented `-c 3 -r 0 ... 1.90`): at
+    every operating point the oracle writes the reference's .q and -u and prints its -s fields."""
+    e = G.SWEEPS[name]
+    rows = G.sweep_rows(name)
+    k, mode, ratios = G.sweep_opts(name)
+    assert len(ratios) == 20
+    for pt, ratio in zip(e["points"], ratios):
+        r = O.encode(rows, k=k, mode=mode, ratio=ratio, dist="M")
+        assert (len(r["q"]), G.md5(r["q"]), G.md5(r["u"]), r["size"]) == (pt["q_size"], pt["q_md5"], pt["u_md5"], pt["size"]), pt["comp"]
+        assert (f"{r['rate']:.4f}", f"{r['distortion']:.4f}") == (pt["rate"], pt["distortion"]), pt["comp"]
+
+
 @pytest.mark.parametrize("name", [n for n, e in G.CASES.items() if e["stored"]])
 def test_decode_matches_u(name):
     """The invariant the reference's own test.sh checks: decode(encode(x)) == the -u dump."""

@@ -89,6 +89,42 @@ CASES = [
 ]
 
 
+# Rate-distortion sweeps: the reference's generate_rd.sh:1-17 - twenty encodes of one file, `comp` spelled as `bc -l` prints
+# idx * step ("0", ".05", ".10" ... / "1.00", "1.10" ...). The script's active line is `-c 1 -f $comp -s`, its commented one
+# `-c 3 -r $comp -s` with step 0.10. Every point is one run of the reference binary; what is kept is the md5 of its .q and -u,
+# and the fields of its -s line.
+def bc_l(idx, step_hundredths):
+    v = idx * step_hundredths
+    return "0" if v == 0 else (f"{v // 100}" if v >= 100 else "") + f".{v % 100:02d}"
+
+
+SWEEPS = [
+    dict(name="rd_t2k", inp=dict(kind="qgen1", seed=1, n=2000, c=30), fixed="-c 1", flag="-f", comps=[bc_l(i, 5) for i in range(20)]),
+    dict(name="rd_c3r_t2k", inp=dict(kind="qgen1", seed=1, n=2000, c=30), fixed="-c 3", flag="-r", comps=[bc_l(i, 10) for i in range(20)]),
+]
+
+
+def run_sweeps(manifest, td):
+    manifest["sweeps"] = {}
+    for sw in SWEEPS:
+        rows = input_rows(sw["inp"])
+        text = rows.tobytes()
+        inp = os.path.join(td, sw["name"] + ".txt")
+        open(inp, "wb").write(text)
+        points = []
+        for comp in sw["comps"]:
+            q, u = os.path.join(td, "sw.q"), os.path.join(td, "sw.u")
+            out = subprocess.run([os.path.join(REF, "qvz_ref_fixedseed")] + sw["fixed"].split() + [sw["flag"], comp, "-s", "-u", u, inp, q],
+                                 check=True, capture_output=True, text=True).stdout
+            sline = [ln for ln in out.splitlines() if ln.startswith("rate,")][0].split(",")
+            qb, ub = open(q, "rb").read(), open(u, "rb").read()
+            points.append(dict(comp=comp, q_md5=md5(qb), u_md5=md5(ub), q_size=len(qb), rate=sline[1].strip(), distortion=sline[3].strip(),
+                               size=int(sline[7])))
+            print(f"{sw['name']:12s} {sw['flag']} {comp:5s} rate={sline[1].strip()} dist={sline[3].strip()} size={int(sline[7])}")
+        manifest["sweeps"][sw["name"]] = dict(input=sw["inp"], input_md5=md5(text), fixed=sw["fixed"], flag=sw["flag"], points=points,
+                                              source="reference generate_rd.sh:1-17, one run of oracle/_ref/qvz_ref_fixedseed per point")
+
+
 def dist_asym_text():
     """72 rows x 72 columns, row x column y = cost of reconstructing x as y: overshoot costs 1.5|x-y|, undershoot 2|x-y|.
     Short numbers: the reference reads rows through a 1024-byte line buffer (distortion.c:105,117)."""
@@ -128,7 +164,7 @@ def main():
     manifest = {"generator": "tools/make_golden.py", "reference_binary": "oracle/_ref/qvz_ref_fixedseed "
                 "(reference sources + -DLINUX -DDEBUG -O3: WELL state = 32 x 0x55555555)", "cases": {}}
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None      # regenerate one case, keep the rest
-    if only:
+    if only:                                                                             # (--only sweeps: the sweeps alone)
         manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
     open(os.path.join(GOLD, "dist_asym.txt"), "wb").write(dist_asym_text())
     with tempfile.TemporaryDirectory() as td:
@@ -173,6 +209,8 @@ def main():
             manifest["cases"][name] = entry
             print(f"{name:18s} q={len(qb):8d} rate={entry['rate']:.4f} dist={entry['distortion']:.4f} "
                   f"size={entry['size']}")
+        if not only or only == "sweeps":
+            run_sweeps(manifest, td)
     # WELL known-answer vector from the reference's own well.c (state 32 x 0x55555555)
     manifest["well_kat"] = dict(state="32 x 0x55555555", first_words=["0x82fd4280", "0x815ebfd5", "0x5303e800", "0x2e7c4815"],
                                 first_draws=[0, 5, 117, 23, 85, 127, 122, 10, 0, 80, 15, 24],
