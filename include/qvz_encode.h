@@ -125,6 +125,42 @@ int qvz_encode_file_sweep(const char *in_path, const char *out_path, const qvz_o
  * or more than `max`). */
 uint32_t qvz_sweep_parse(const char *text, const qvz_options_t *opts, qvz_sweep_point_t *points, uint32_t max);
 
+/* The hot path over a matrix that is ALREADY in HBM: the stages of the reference's encode() (main.c:42-91: do_kmeans_clustering,
+ * calculate_statistics, generate_codebooks, start_qv_compression) with neither text nor files on either side - a caller that
+ * holds the reads on the device (column-major symbols, include/qvz_hip.h: d_sym[s * ld + i] = byte - 33, ld = qvz_hip_ld(n)),
+ * and the step bench.py times. `shards` independent reference-format streams coded by the GPU coder stay on the device packed
+ * back to back, with the quantized values (want_qv) and the labels; qvz_resident_products says where. A handle keeps its big
+ * device buffers between encodes; nothing computed is carried from one encode to the next.
+ *   A PART of a file (one GPU of several, one process each): reads [first_read, first_read + n) of n_total, first_read a multiple of
+ * 4, and `allreduce` - the sum, in place on `stream`, of `count` elements of a device buffer over all parts: width 4 / 8 = unsigned
+ * integers of that many bytes, -8 = doubles. RCCL's ncclAllReduce is that function (bench.py hands torch.distributed's in);
+ * it is called for the centroid reads (k x c, once), the k-means sums (per iteration), the counters (once) and the distortion.
+ * centroid_lines: the k read numbers cluster.c:198-201 draws (NULL: drawn here with libc rand() after srand(1) - the state a
+ * process starts in, which is where the reference binary draws them).
+ * res: lines / columns of the part, stream_bytes of its streams, the FILE's distortion (a fixed-order device sum, not the
+ * reference's sequential one: within 1e-6 relative), iterations, phase seconds. */
+typedef struct qvz_resident qvz_resident_t;
+typedef int (*qvz_allreduce_fn)(void *ctx, void *d_buf, uint64_t count, int width, void *stream);
+typedef struct qvz_resident_products {
+    const uint8_t *d_streams;          /* device: the streams packed back to back, stream g h_sizes[g] bytes              */
+    const uint64_t *h_sizes;           /* host: [shards]                                                                    */
+    uint32_t shards, clusters;
+    uint64_t stream_bytes;
+    const uint8_t *d_qv;               /* device: quantized values, the layout of d_sym (NULL unless want_qv)               */
+    const uint8_t *d_labels;           /* device: [ld] cluster of every read                                                */
+    const struct qvz_codebook *const *codebooks;   /* [clusters] (include/qvz_codebook.h)                                   */
+    uint32_t well_state[32];           /* the file's WELL state (shard g starts first_read + bounds[g] reads into its draws) */
+    double model_kernels_ms, coder_kernels_ms;     /* busy time of the coder phase's two kernel families                    */
+    double kmeans_kernels_ms, pmf_kernel_ms, quantize_kernel_ms;   /* HIP events around the launches, on their stream (k-means: all iterations) */
+} qvz_resident_products_t;
+int qvz_resident_open(int device, qvz_resident_t **out);
+int qvz_resident_encode(qvz_resident_t *r, const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint64_t first_read,
+                        uint64_t n_total, const qvz_options_t *opts, uint32_t shards, int want_qv, const uint64_t *centroid_lines,
+                        qvz_allreduce_fn allreduce, void *allreduce_ctx, qvz_result_t *res);
+/* what the last encode left (valid until the next encode on the handle, or its close) */
+int qvz_resident_products(const qvz_resident_t *r, qvz_resident_products_t *out);
+void qvz_resident_close(qvz_resident_t *r);
+
 /* Decode direction (`qvz -x`, reference src/main.c:132-183, start_qv_decompression src/qv_compressor.c:145-231).
  * qvz_decode_file: a reference-format .q file (one stream) -> text; the serial arithmetic decoder runs on one host
  * core as in the reference, the WELL draws come from the GPU word stream. qvz_decode_shard_files: the files

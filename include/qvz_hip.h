@@ -57,6 +57,11 @@ int qvz_hip_device_count(void);
  * The reference has no counterpart: it mmaps the input and callocs everything (src/lines.c:64,116). */
 int qvz_hip_set_device(int device);
 int qvz_hip_mem_info(uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the current device */
+/* events on a stream, for timing a launch from C: elapsed_ms waits for the second event */
+int qvz_hip_event_create(void **event);
+int qvz_hip_event_record(void *event, void *stream);
+int qvz_hip_event_elapsed_ms(void *first, void *second, double *ms);
+int qvz_hip_event_destroy(void *event);
 int qvz_hip_malloc(void **d_ptr, size_t bytes);
 int qvz_hip_free(void *d_ptr);
 int qvz_hip_malloc_host(void **h_ptr, size_t bytes);   /* pinned host memory for async copies */
@@ -122,6 +127,15 @@ int qvz_hip_kmeans_update64(const uint64_t *d_acc, const uint64_t *d_counts, uin
                             uint8_t *d_means, double *d_moved, int32_t *d_status, void *stream);
 /* d_dst[i] = d_src[i]: a part's u32 counters widened so that their sum over the parts cannot wrap */
 int qvz_hip_widen_u32(const uint32_t *d_src, uint64_t *d_dst, uint64_t count, void *stream);
+/* The k reads the reference copies as initial centroids (initialize_kmeans_clustering, cluster.c:198-201) out of a matrix that is in
+ * HBM: d_out[j][s] = symbol s of read d_idx[j] (a read number of THIS matrix), all zero for d_idx[j] = ~0 (a read another part
+ * of the file owns: the SUM over the parts then holds every centroid; SURVEY.md section 8e, collective 1). */
+int qvz_hip_gather_reads(const uint8_t *d_sym, uint64_t ld, uint32_t c, const uint64_t *d_idx /*[k]*/, uint32_t k,
+                         uint32_t *d_out /*[k][c]*/, void *stream);
+/* d_sum[0] = sum over the reads of d_err[i] / columns (the term start_qv_compression adds per line, qv_compressor.c:127) in a
+ * fixed order - reproducible, but not the reference's one sequential sum: within 1e-6 relative of it (north_star's tolerance for
+ * the distortion), what a part of a sharded file contributes to the all-reduced total. d_sum: 1025 doubles (the sum + scratch). */
+int qvz_hip_sum_errors(const double *d_err, uint64_t n, uint32_t c, double *d_sum /*[1025]*/, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Conditional-PMF counters. Replaces the counting loop of calculate_statistics

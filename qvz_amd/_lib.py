@@ -135,6 +135,17 @@ SIGNATURES = {
     "qvz_encode_file_devices": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_void_p]),
     "qvz_encode_file_sweep": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "qvz_sweep_parse": (C.c_uint32, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "qvz_resident_open": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "qvz_resident_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32,
+                                      C.c_int, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qvz_resident_products": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "qvz_resident_close": (None, [C.c_void_p]),
+    "qvz_hip_gather_reads": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "qvz_hip_sum_errors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "qvz_hip_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "qvz_hip_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "qvz_hip_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "qvz_hip_event_destroy": (C.c_int, [C.c_void_p]),
     "qvz_egress_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p]),
     "qvz_ingest_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_hip_scatter_streams": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),

@@ -56,6 +56,42 @@ void qvz_options_default(qvz_options_t *o) {
     o->seed_mode = QVZ_SEED_TIME;
 }
 
+/* a launch timed with events on its stream, for a job that reports kernel times (qvz_resident_*): TIMED(job, &job->k_x_ms, call) */
+typedef struct { void *a, *b; } span_t;
+static void span_begin(qvz_job_t *job, span_t *sp) {
+    sp->a = sp->b = NULL;
+    if (!job->keep_device) return;
+    if (qvz_hip_event_create(&sp->a) || qvz_hip_event_create(&sp->b) || qvz_hip_event_record(sp->a, NULL)) { qvz_hip_event_destroy(sp->a); qvz_hip_event_destroy(sp->b); sp->a = sp->b = NULL; }
+}
+static void span_end(span_t *sp) { if (sp->a) (void)qvz_hip_event_record(sp->b, NULL); }
+static void span_add(span_t *sp, double *ms) {                                  /* after the stream has been synchronised */
+    double d = 0.0;
+    if (sp->a && qvz_hip_event_elapsed_ms(sp->a, sp->b, &d) == QVZ_OK) *ms += d;
+    qvz_hip_event_destroy(sp->a); qvz_hip_event_destroy(sp->b);
+    sp->a = sp->b = NULL;
+}
+
+/* A big device buffer of a job: from the job's pool when it has one (qvz_resident_*: the block of that role is kept between
+ * encodes, replaced when too small), else a plain allocation. job_free gives it back the same way. */
+static int job_malloc(qvz_job_t *job, void **p, size_t bytes, int role) {
+    if (!job->pool) return qvz_hip_malloc(p, bytes);
+    qvz_pool_t *pl = job->pool;
+    if (pl->ptr[role] && pl->bytes[role] < bytes) { qvz_hip_free(pl->ptr[role]); pl->ptr[role] = NULL; pl->bytes[role] = 0; }
+    if (!pl->ptr[role]) {
+        const int rc = qvz_hip_malloc(&pl->ptr[role], bytes);
+        if (rc) { pl->ptr[role] = NULL; return rc; }
+        pl->bytes[role] = bytes;
+    }
+    *p = pl->ptr[role];
+    return QVZ_OK;
+}
+
+static void job_free(qvz_job_t *job, void *p) {
+    if (!p) return;
+    if (job->pool) for (int r = 1; r < QVZ_POOL_ROLES; ++r) if (job->pool->ptr[r] == p) return;   /* stays with the pool */
+    qvz_hip_free(p);
+}
+
 /* ------------------------------------------------------------------------------------------------------- */
 static int job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_t lines, uint32_t columns,
                     const qvz_options_t *opts, int draw_centroids);
@@ -271,7 +307,10 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
         int32_t kstat = 0;
         HIP(qvz_hip_memset(job->d_counts, 0, K * sizeof(uint32_t), NULL));
         HIP(qvz_hip_memset(job->d_acc, 0, (size_t)K * C * sizeof(uint64_t), NULL));
+        span_t sp;
+        span_begin(job, &sp);
         HIP(qvz_hip_kmeans_step(job->d_sym, N, C, ld, K, job->d_means, job->d_labels, job->d_counts, job->d_acc, NULL));
+        span_end(&sp);
         if (job->allreduce) {                                                   /* the sums of every part of the file, 64 bits wide */
             HIP(qvz_hip_widen_u32(job->d_counts, job->d_counts64, K, NULL));
             HIP(job->allreduce(job->allreduce_ctx, job->d_acc, (uint64_t)K * C, 8, NULL));
@@ -282,6 +321,7 @@ int qvz_job_kmeans(qvz_job_t *job, int want_host_labels) {
         HIP(qvz_hip_copy_d2h(h_moved, job->d_moved, (K + 1) * sizeof(double), NULL));
         HIP(qvz_hip_copy_d2h(&kstat, job->d_kstat, sizeof(kstat), NULL));
         HIP(qvz_hip_stream_sync(NULL));
+        span_add(&sp, &job->k_kmeans_ms);
         if (kstat) { rc = qvz_job_fail(QVZ_E_EMPTY, "a cluster went empty during k-means (the reference divides by zero here, cluster.c:113)"); goto done; }
         if (job->opts.verbose) {
             for (uint32_t j = 0; j < K; ++j) printf("Cluster %d moved %f.\n", j, h_moved[1 + j]);   /* cluster.c:126-127 */
@@ -318,13 +358,17 @@ int qvz_job_stats(qvz_job_t *job) {
     if ((rc = qvz_job_upload(job))) return rc;
     HIP(qvz_hip_malloc((void **)&job->d_cnt, words * sizeof(uint32_t)));
     HIP(qvz_hip_memset(job->d_cnt, 0, words * sizeof(uint32_t), NULL));
+    span_t sp;
+    span_begin(job, &sp);
     HIP(qvz_hip_pmf_hist(job->d_sym, job->K > 1 ? job->d_labels : NULL, job->N, job->C, job->ld, job->K, job->d_cnt, NULL));
+    span_end(&sp);
     if (job->allreduce) {                                                       /* counters of the whole file, 64 bits wide */
         HIP(qvz_hip_malloc((void **)&job->d_cnt64, words * sizeof(uint64_t)));
         HIP(qvz_hip_widen_u32(job->d_cnt, job->d_cnt64, words, NULL));
         HIP(job->allreduce(job->allreduce_ctx, job->d_cnt64, words, 8, NULL));
     }
     HIP(qvz_hip_stream_sync(NULL));
+    span_add(&sp, &job->k_pmf_ms);
     job->counted = 1;
     job->t_stats = now() - t0;
 done:
@@ -615,7 +659,7 @@ int qvz_job_start_draws(qvz_job_t *job) {
     }
     HIP(qvz_hip_set_device(job->opts.device));
     if (!(job->d_draws = early_draws_plane(job)))                              /* allocated ahead of time, beside the upload */
-        HIP(qvz_hip_malloc((void **)&job->d_draws, (size_t)job->C * job->ld));
+        HIP(job_malloc(job, (void **)&job->d_draws, (size_t)job->C * job->ld, QVZ_POOL_DRAWS));
     /* The runtime spreads streams over a few hardware queues and a queue runs its kernels in order: a side stream that
      * shares the default stream's queue would put the generator IN FRONT of the codebook kernels instead of beside them
      * (DESIGN.md section 8). A candidate is probed (~1 ms) and dropped for the next one if it does not overlap. */
@@ -814,25 +858,30 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         d_qi = job_plane(job, 0); d_st = job_plane(job, 1); d_err = (double *)job_plane(job, -1);
         if (fu) d_qv = job_plane(job, 2);
     } else {
-        if (fu) HIP(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
-        HIP(qvz_hip_malloc((void **)&d_qi, (size_t)C * ld));
-        HIP(qvz_hip_malloc((void **)&d_st, (size_t)C * ld));
-        HIP(qvz_hip_malloc((void **)&d_err, N * sizeof(double)));
+        if (fu || job->want_text) HIP(job_malloc(job, (void **)&d_qv, (size_t)C * ld, QVZ_POOL_QV));
+        HIP(job_malloc(job, (void **)&d_qi, (size_t)C * ld, QVZ_POOL_QI));
+        HIP(job_malloc(job, (void **)&d_st, (size_t)C * ld, QVZ_POOL_ST));
+        HIP(job_malloc(job, (void **)&d_err, N * sizeof(double), QVZ_POOL_ERR));
     }
     HIP(qvz_hip_malloc((void **)&d_status, sizeof(int32_t)));
     HIP(qvz_hip_memset(d_status, 0, sizeof(int32_t), NULL));
     HIP(qvz_hip_stream_wait(NULL, job->well_stream));                          /* the draws, on the device's side */
+    span_t sp_q;
+    span_begin(job, &sp_q);
     HIP(qvz_hip_quantize(job->d_sym, K > 1 ? job->d_labels : NULL, N, C, ld, K, d_ct, d_qs, job->d_draws, ld, d_dist, d_qv, d_qi, d_st,
                          ld, d_err, d_status, NULL));
+    span_end(&sp_q);
     HIP(qvz_hip_copy_d2h(&status, d_status, sizeof(status), NULL));
     HIP(qvz_hip_stream_sync(NULL));
+    span_add(&sp_q, &job->k_quantize_ms);
     if (status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
     if (!job->keep_resident) {                                                  /* (a sweep's next point quantizes the same matrix with the same draws) */
-        qvz_hip_free(job->d_draws);                                            /* 15 GB at 100M x 150, an allocation of its own for this */
+        job_free(job, job->d_draws);                                           /* 15 GB at 100M x 150, an allocation of its own for this */
         job->d_draws = NULL;
         /* the symbols are not needed again either (this stage ends a job; qvz_job_release frees what is left): 15 GB at 100M x
          * 150 that the coder's buffers and the -u staging can have - with -u the process is otherwise near what the card holds */
-        qvz_hip_free(job->d_sym); job->d_sym = NULL;
+        if (!job->sym_borrowed) qvz_hip_free(job->d_sym);
+        job->d_sym = NULL;
     }
     t1 = now();
     job->t_quantize = t1 - t0;
@@ -850,7 +899,8 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         if (!job->out_err) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
         task_err.keep = job->out_err;
     }
-    err_running = pthread_create(&th_err, NULL, side_errors, &task_err) == 0;
+    if (job->keep_device) HIP(qvz_hip_sum_errors(d_err, N, C, job->d_errsum, NULL));   /* a resident encode: this part's sum stays on the device */
+    else err_running = pthread_create(&th_err, NULL, side_errors, &task_err) == 0;
     if (fu) {
         task_text.fu = fu; task_text.d_qv = d_qv; task_text.N = N; task_text.C = C; task_text.ld = ld;
         if (overlap_text) text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
@@ -876,12 +926,12 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
             uint64_t work_use = mine ? job->work_bytes : 0;
             const uint64_t area = (((uint64_t)shards * cap) + 4095) & ~4095ull;
             const uint64_t two_segments = 2 * qvz_hip_encode_planes_work_bytes((per + (K > 1 ? 2 : 7)) / (K > 1 ? 3 : 8) + 64, C, K, shards) / 2;   /* (the helper prices 16-byte records: half) */
-            qvz_hip_free(d_out_own); d_out_own = NULL;
+            job_free(job, d_out_own); d_out_own = NULL;
             if (mine && bits == 6 && work_use > area && work_use - area >= two_segments) {
                 work_use = (work_use - area) & ~255ull;
                 d_out = (uint8_t *)job->d_work + work_use;
             } else {
-                HIP(qvz_hip_malloc((void **)&d_out_own, (size_t)shards * cap));
+                HIP(job_malloc(job, (void **)&d_out_own, (size_t)shards * cap, QVZ_POOL_OUT));
                 d_out = d_out_own;
             }
             if (getenv("QVZ_TIMING")) fprintf(stderr, "qvz_timing: before the coder call: waited %.4f s for the coder's set-up thread, %.4f s for the workspace thread; stream area of %.1f GB %s in %.4f s\n",
@@ -898,13 +948,23 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         /* (into the record workspace when there is one: the coder has finished with it, and one more large hipMalloc is one more
          * place for a young process's allocation stall) */
         if (job->d_work && job->work_shards == shards && !d_out_own && total <= (uint64_t)(d_out - (uint8_t *)job->d_work)) d_packed = (uint8_t *)job->d_work;
-        else { HIP(qvz_hip_malloc((void **)&d_packed_own, total ? total : 1)); d_packed = d_packed_own; }
+        else { HIP(job_malloc(job, (void **)&d_packed_own, total ? total : 1, QVZ_POOL_PACKED)); d_packed = d_packed_own; }
         HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_packed, NULL));
-        if (err_running) { pthread_join(th_err, NULL); err_running = 0; } else side_errors(&task_err);
-        if (task_err.rc) { rc = qvz_job_fail(task_err.rc, "%s", task_err.err); goto done; }
-        if (distortion_out) *distortion_out = task_err.sum / ((double)N);      /* qv_compressor.c:139-140 */
+        if (job->keep_device) {
+            HIP(qvz_hip_copy_d2h(&job->r_errsum, job->d_errsum, sizeof(double), NULL));
+            HIP(qvz_hip_stream_sync(NULL));
+            if (distortion_out) *distortion_out = job->r_errsum / ((double)N);
+        } else {
+            if (err_running) { pthread_join(th_err, NULL); err_running = 0; } else side_errors(&task_err);
+            if (task_err.rc) { rc = qvz_job_fail(task_err.rc, "%s", task_err.err); goto done; }
+            if (distortion_out) *distortion_out = task_err.sum / ((double)N);  /* qv_compressor.c:139-140 */
+        }
         if (fu && !text_running) text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
-        if (job->collect) {                                                     /* a part of a file: the caller assembles the whole */
+        if (job->keep_device) {                                                 /* a resident encode: the products stay where they are */
+            job->r_packed = d_packed; job->r_total = total;
+            job->r_sizes = sizes; sizes = NULL;
+            job->r_qv = d_qv;
+        } else if (job->collect) {                                                     /* a part of a file: the caller assembles the whole */
             h_buf = (uint8_t *)malloc(total ? total : 1);
             if (!h_buf) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
             HIP(qvz_hip_copy_d2h(h_buf, d_packed, total, NULL));
@@ -965,10 +1025,10 @@ done:
     if (text_running) pthread_join(th_text, NULL);
     free(h_ct); free(h_qs); free(sizes); free(first); free(h_buf); free(image); free(wstates);
     qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist);
-    if (!planes_early) { qvz_hip_free(d_err); qvz_hip_free(d_qv); qvz_hip_free(d_qi); qvz_hip_free(d_st); }   /* (the early planes go with the job) */
-    qvz_hip_free(d_out_own); qvz_hip_free(d_packed_own); qvz_hip_free(d_status);
+    if (!planes_early) { job_free(job, d_err); job_free(job, d_qv); job_free(job, d_qi); job_free(job, d_st); }   /* (the early planes go with the job) */
+    job_free(job, d_out_own); job_free(job, d_packed_own); qvz_hip_free(d_status);
     if (!job->keep_resident || rc) {
-        if (job->d_draws) { qvz_hip_free(job->d_draws); job->d_draws = NULL; }
+        if (job->d_draws) { job_free(job, job->d_draws); job->d_draws = NULL; }
         if (job->well_stream) { qvz_hip_stream_destroy(job->well_stream); job->well_stream = NULL; }
     }
     return rc;
@@ -987,14 +1047,16 @@ int qvz_job_compress_shardset(qvz_job_t *job, FILE *fout, FILE *fu, uint32_t sha
 void qvz_job_release(qvz_job_t *job) {
     if (job->cbs) { for (uint32_t j = 0; j < job->K; ++j) qvz_codebook_free(job->cbs[j]); free(job->cbs); }
     free(job->h_labels); free(job->h_means); free(job->h_counts); free(job->h_acc);
-    qvz_hip_free(job->d_sym); qvz_hip_free(job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
+    if (!job->sym_borrowed) qvz_hip_free(job->d_sym);
+    job_free(job, job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
     qvz_hip_free(job->d_counts); qvz_hip_free(job->d_acc); qvz_hip_free(job->d_moved); qvz_hip_free(job->d_kstat);
     qvz_hip_free(job->d_cnt64); qvz_hip_free(job->d_counts64);
-    qvz_hip_free(job->d_draws);
+    job_free(job, job->d_draws);
     if (job->well_stream) qvz_hip_stream_destroy(job->well_stream);
     workspace_join(job);
     qvz_hip_free(job->d_draws_early);                                           /* never handed over: no draws were started */
-    qvz_hip_free(job->d_work);
+    job_free(job, job->d_work);
+    qvz_hip_free(job->d_errsum); free(job->r_sizes);
     qvz_hip_free(job->d_planes);
     memset(job, 0, sizeof(*job));
 }
@@ -1261,4 +1323,172 @@ int qvz_encode_file_shardset(const char *in_path, const char *out_path, const qv
     munmap(map, (size_t)st.st_size);
     close(fd);
     return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* The hot path over a matrix that is in HBM already (include/qvz_encode.h): the stages of encode() (main.c:42-91) without the
+ * text on either side - no ingest, no files. What bench.py times; what a caller that holds the reads on the device calls. */
+struct qvz_resident {
+    int device;
+    qvz_pool_t pool;
+    qvz_job_t job;               /* the last encode's job: its codebooks, labels and products are the caller's to read until the next */
+    int have_job;
+    uint32_t shards;
+    double model_ms, coder_ms;
+};
+
+int qvz_resident_open(int device, qvz_resident_t **out) {
+    if (!out) return qvz_job_fail(QVZ_E_ARG, "null argument");
+    qvz_resident_t *r = (qvz_resident_t *)calloc(1, sizeof(*r));
+    if (!r) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
+    r->device = device;
+    if (qvz_hip_set_device(device)) { free(r); return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); }
+    (void)qvz_hip_codebook_warmup();                              /* once per process: the device's log2 against this host's libm */
+    (void)qvz_hip_encode_planes_warmup();
+    *out = r;
+    return 0;
+}
+
+static void resident_drop_job(qvz_resident_t *r) {
+    if (r->have_job) { qvz_job_release(&r->job); r->have_job = 0; }
+}
+
+void qvz_resident_close(qvz_resident_t *r) {
+    if (!r) return;
+    (void)qvz_hip_set_device(r->device);
+    resident_drop_job(r);
+    for (int i = 1; i < QVZ_POOL_ROLES; ++i) qvz_hip_free(r->pool.ptr[i]);
+    free(r);
+}
+
+int qvz_resident_encode(qvz_resident_t *r, const uint8_t *d_sym, uint64_t n, uint32_t c, uint64_t ld, uint64_t first_read,
+                        uint64_t n_total, const qvz_options_t *opts, uint32_t shards, int want_qv, const uint64_t *centroid_lines,
+                        qvz_allreduce_fn allreduce, void *allreduce_ctx, qvz_result_t *res) {
+    int rc = 0;
+    qvz_result_t R;
+    memset(&R, 0, sizeof(R));
+    if (!r || !d_sym || !opts || !shards) return qvz_job_fail(QVZ_E_ARG, "null argument");
+    if (ld != qvz_hip_ld(n)) return qvz_job_fail(QVZ_E_ARG, "the matrix's leading dimension must be qvz_hip_ld(n) = %llu", (unsigned long long)qvz_hip_ld(n));
+    if (n_total < first_read + n) return qvz_job_fail(QVZ_E_ARG, "reads %llu + %llu beyond the file's %llu", (unsigned long long)first_read, (unsigned long long)n, (unsigned long long)n_total);
+    if (!allreduce && (first_read || n_total != n)) return qvz_job_fail(QVZ_E_ARG, "a part of a file needs the all-reduce of its statistics");
+    const double t_start = now();
+    qvz_job_t *job = &r->job;
+    uint8_t *rows = NULL;
+    uint64_t *d_idx = NULL;
+    uint32_t *d_cent = NULL, *h_cent = NULL;
+    if (qvz_hip_set_device(r->device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
+    resident_drop_job(r);                                         /* the previous encode's products end here */
+    qvz_options_t o = *opts;
+    o.device = r->device;
+    o.uncompressed_name = NULL;
+    if (o.seed_mode == QVZ_SEED_TIME && allreduce) return qvz_job_fail(QVZ_E_ARG, "the parts of one file need ONE WELL state: seed_mode debug or explicit");
+    const uint32_t K = (uint32_t)o.clusters;
+    const uint64_t stride = (uint64_t)c + 1;
+    if (o.clusters < 1 || o.clusters > 255) return qvz_job_fail(QVZ_E_ARG, "clusters must be 1..255");
+    /* the centroid reads (cluster.c:198-204): their numbers from libc rand() in a fresh process's state unless the caller names
+     * them, their bytes from the part that holds each (a sum over the parts: everybody else contributes zeros) */
+    uint64_t lines[256];
+    if (centroid_lines) memcpy(lines, centroid_lines, K * sizeof(uint64_t));
+    else {
+        uint32_t block_count = (uint32_t)(n_total / QVZ_LINES_PER_BLOCK);
+        if ((uint64_t)block_count * QVZ_LINES_PER_BLOCK != n_total) block_count += 1;
+        srand(1);                                                 /* a process that has just started: where the reference binary draws them */
+        for (uint32_t j = 0; j < K; ++j) {
+            const uint32_t block_id = (uint32_t)rand() % block_count;
+            const uint64_t left = n_total - (uint64_t)block_id * QVZ_LINES_PER_BLOCK;
+            lines[j] = (uint64_t)block_id * QVZ_LINES_PER_BLOCK + (uint32_t)rand() % (left > QVZ_LINES_PER_BLOCK ? (uint32_t)QVZ_LINES_PER_BLOCK : (uint32_t)left);
+        }
+    }
+    rows = (uint8_t *)malloc((size_t)K * stride);
+    h_cent = (uint32_t *)malloc((size_t)K * c * sizeof(uint32_t));
+    if (!rows || !h_cent) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto fail; }
+    {
+        uint64_t idx[256];
+        for (uint32_t j = 0; j < K; ++j) idx[j] = lines[j] >= first_read && lines[j] < first_read + n ? lines[j] - first_read : ~0ull;
+        if (qvz_hip_malloc((void **)&d_idx, K * sizeof(uint64_t)) || qvz_hip_malloc((void **)&d_cent, (size_t)K * c * sizeof(uint32_t)) ||
+            qvz_hip_copy_h2d(d_idx, idx, K * sizeof(uint64_t), NULL) || qvz_hip_gather_reads(d_sym, ld, c, d_idx, K, d_cent, NULL) ||
+            (allreduce && allreduce(allreduce_ctx, d_cent, (uint64_t)K * c, 4, NULL)) ||
+            qvz_hip_copy_d2h(h_cent, d_cent, (size_t)K * c * sizeof(uint32_t), NULL) || qvz_hip_stream_sync(NULL)) {
+            rc = qvz_job_fail(QVZ_E_HIP, "centroid reads: %s", qvz_hip_last_error());
+            goto fail;
+        }
+        for (uint32_t j = 0; j < K; ++j) {
+            for (uint32_t s = 0; s < c; ++s) rows[(size_t)j * stride + s] = (uint8_t)(h_cent[(size_t)j * c + s] + 33);
+            rows[(size_t)j * stride + c] = '\n';
+        }
+    }
+    if ((rc = qvz_job_init_part(job, NULL, n, c, &o, first_read, rows))) goto fail;
+    r->have_job = 1;
+    job->pool = &r->pool;
+    job->d_sym = (uint8_t *)d_sym;                                /* (read only) */
+    job->sym_borrowed = 1;
+    job->uploaded = 1;
+    job->keep_device = 1;
+    job->want_text = want_qv != 0;
+    job->allreduce = allreduce;
+    job->allreduce_ctx = allreduce_ctx;
+    if (qvz_hip_malloc((void **)&job->d_errsum, 1025 * sizeof(double))) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto fail; }
+    if (job_malloc(job, (void **)&job->d_labels, ld, QVZ_POOL_LABELS) || qvz_hip_memset(job->d_labels, 0, ld, NULL)) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto fail; }
+    if ((rc = qvz_job_kmeans(job, 0))) goto fail;
+    if ((rc = qvz_job_stats(job))) goto fail;
+    if ((rc = qvz_job_start_draws(job))) goto fail;               /* the WELL generator runs beside the codebooks */
+    if ((rc = qvz_job_codebooks(job))) goto fail;
+    {   /* the coder's record workspace: everything at once if it fits, 96 GiB at most, 24 GiB of what is free left alone */
+        uint64_t free_b = 0, want = qvz_hip_encode_planes_work_bytes((n + shards - 1) / shards + 4, c, K, shards);
+        if (want > (96ull << 30)) want = 96ull << 30;
+        if (r->pool.bytes[QVZ_POOL_WORK] < want && qvz_hip_mem_info(&free_b, NULL) == QVZ_OK) {
+            const uint64_t planes = (r->pool.ptr[QVZ_POOL_QI] ? 0 : (uint64_t)c * ld * (want_qv ? 3 : 2) + n * 8) + (r->pool.ptr[QVZ_POOL_DRAWS] ? 0 : (uint64_t)c * ld);
+            const uint64_t have = r->pool.bytes[QVZ_POOL_WORK];
+            const uint64_t room = free_b + have > planes + (24ull << 30) ? free_b + have - planes - (24ull << 30) : 0;
+            if (want > room) want = room;
+        }
+        if (want >= (1ull << 30) && job_malloc(job, &job->d_work, (size_t)want, QVZ_POOL_WORK) == QVZ_OK) { job->work_bytes = r->pool.bytes[QVZ_POOL_WORK]; job->work_shards = shards; }
+        else job->d_work = NULL;
+    }
+    if ((rc = compress_sharded_impl(job, NULL, NULL, NULL, shards, &R.stream_bytes, NULL, &R.distortion))) goto fail;
+    qvz_hip_encode_planes_last_ms(&r->model_ms, &r->coder_ms);
+    r->shards = shards;
+    if (allreduce) {                                              /* the file's distortion: the parts' sums, then / N (qv_compressor.c:139-140) */
+        if (qvz_hip_copy_h2d(job->d_errsum, &job->r_errsum, sizeof(double), NULL) || allreduce(allreduce_ctx, job->d_errsum, 1, -8, NULL) ||
+            qvz_hip_copy_d2h(&job->r_errsum, job->d_errsum, sizeof(double), NULL) || qvz_hip_stream_sync(NULL)) {
+            rc = qvz_job_fail(QVZ_E_HIP, "distortion sum: %s", qvz_hip_last_error());
+            goto fail;
+        }
+        R.distortion = job->r_errsum / ((double)n_total);
+    }
+    R.lines = n; R.columns = c;
+    R.file_bytes = 0;
+    R.kmeans_iterations = job->kmeans_iterations;
+    R.deferred_decisions = job->deferred_decisions;
+    R.t_cluster = job->t_cluster; R.t_stats = job->t_stats; R.t_codebook = job->t_codebook; R.t_encode = job->t_encode;
+    R.t_quantize = job->t_quantize; R.t_coder = job->t_coder; R.t_egress = job->t_egress;
+    R.t_total = now() - t_start;
+fail:
+    job->centroid_rows = NULL;
+    free(rows); free(h_cent);
+    qvz_hip_free(d_idx); qvz_hip_free(d_cent);
+    if (rc) resident_drop_job(r);
+    if (res) *res = R;
+    return rc;
+}
+
+int qvz_resident_products(const qvz_resident_t *r, qvz_resident_products_t *out) {
+    if (!r || !out) return qvz_job_fail(QVZ_E_ARG, "null argument");
+    if (!r->have_job || !r->job.r_sizes) return qvz_job_fail(QVZ_E_ARG, "no encode has completed on this handle");
+    memset(out, 0, sizeof(*out));
+    out->d_streams = r->job.r_packed;
+    out->h_sizes = r->job.r_sizes;
+    out->shards = r->shards;
+    out->stream_bytes = r->job.r_total;
+    out->d_qv = r->job.r_qv;
+    out->d_labels = r->job.d_labels;
+    out->codebooks = (const qvz_codebook_t *const *)r->job.cbs;
+    out->clusters = r->job.K;
+    memcpy(out->well_state, r->job.well_state, sizeof(out->well_state));
+    out->model_kernels_ms = r->model_ms;
+    out->coder_kernels_ms = r->coder_ms;
+    out->kmeans_kernels_ms = r->job.k_kmeans_ms;
+    out->pmf_kernel_ms = r->job.k_pmf_ms;
+    out->quantize_kernel_ms = r->job.k_quantize_ms;
+    return 0;
 }

@@ -12,6 +12,15 @@
 
 #define QVZ_LINES_PER_BLOCK 1000000ull   /* MAX_LINES_PER_BLOCK, reference include/lines.h:12 */
 
+/* Device blocks that outlive a job (include/qvz_encode.h, qvz_resident_*): a process that encodes one resident matrix after another
+ * keeps its big buffers - labels, draws, the quantizer's planes, the stream area, the record workspace - instead of returning 100+ GB
+ * to the driver and asking for them again every time. A block is found by its role; one that is too small is replaced. */
+enum { QVZ_POOL_LABELS = 1, QVZ_POOL_DRAWS, QVZ_POOL_QI, QVZ_POOL_ST, QVZ_POOL_QV, QVZ_POOL_ERR, QVZ_POOL_OUT, QVZ_POOL_PACKED, QVZ_POOL_WORK, QVZ_POOL_ROLES };
+typedef struct qvz_pool {
+    void *ptr[QVZ_POOL_ROLES];
+    uint64_t bytes[QVZ_POOL_ROLES];
+} qvz_pool_t;
+
 typedef struct qvz_job {
     /* input view: rows of C+1 bytes (Q+33 ... '\n') in file order */
     const uint8_t *text;
@@ -38,6 +47,15 @@ typedef struct qvz_job {
     double *d_moved;
     int32_t *d_kstat;
     int uploaded, clustered, counted;
+    /* ---- a job over a matrix that is in HBM already (qvz_resident_encode); all zero otherwise ---- */
+    qvz_pool_t *pool;           /* the big device buffers come from here and go back there                                       */
+    int sym_borrowed;           /* d_sym is the caller's                                                                          */
+    int keep_device;            /* the sharded compress leaves its products on the device: no file, no host copy                  */
+    uint8_t *r_packed, *r_qv;   /* the streams packed back to back / the quantized values (pool blocks)                           */
+    uint64_t *r_sizes, r_total; /* malloc'd [shards]                                                                              */
+    double k_kmeans_ms, k_pmf_ms, k_quantize_ms;   /* busy time of the kernels (HIP events on their stream; k-means: all iterations) */
+    double *d_errsum;           /* [1025] this part's distortion sum (qvz_hip_sum_errors)                                          */
+    double r_errsum;
     int keep_resident;          /* a sweep: the sharded compress leaves the matrix and the draws for the next operating point */
     double t_upload, t_cluster, t_stats, t_codebook, t_encode;
     double t_quantize, t_coder, t_egress;   /* inside t_encode of a sharded encode: WELL wait + quantizer, coder kernels, what leaves the device afterwards */

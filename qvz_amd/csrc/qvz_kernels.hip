@@ -810,6 +810,52 @@ extern "C" int qvz_hip_widen_u32(const uint32_t *d_src, uint64_t *d_dst, uint64_
     return QVZ_OK;
 }
 
+// The k centroid reads of a file whose matrix is in HBM (cluster.c:198-201 copies the reads' bytes): out[j][s] = symbol s of read
+// idx[j], or 0 for a read this part does not own (idx = ~0) - a SUM over the parts then holds every centroid.
+__global__ __launch_bounds__(256) void k_gather_reads(const uint8_t *__restrict__ sym, uint64_t ld, uint32_t c, const unsigned long long *__restrict__ idx,
+                                                      uint32_t *__restrict__ out) {
+    const unsigned long long i = idx[blockIdx.x];
+    for (uint32_t s = threadIdx.x; s < c; s += 256) out[(size_t)blockIdx.x * c + s] = i == ~0ull ? 0u : sym[(size_t)s * ld + i];
+}
+
+extern "C" int qvz_hip_gather_reads(const uint8_t *d_sym, uint64_t ld, uint32_t c, const uint64_t *d_idx, uint32_t k, uint32_t *d_out, void *stream) {
+    if (!d_sym || !d_idx || !d_out || !c || !k) return qvz_set_error(QVZ_E_ARG, "bad gather arguments");
+    hipLaunchKernelGGL(k_gather_reads, dim3(k), dim3(256), 0, (hipStream_t)stream, d_sym, ld, c, reinterpret_cast<const unsigned long long *>(d_idx), d_out);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
+// sum over the reads of err[i] / columns (the per-read term of qv_compressor.c:127) in a FIXED order - 1024 strided partial sums,
+// each a sequential sum, then the partials in index order - so that the same input gives the same double on every run; the
+// reference's own order (one sequential sum over the file) is what the file drivers keep on the host (qvz_sum_errors).
+__global__ __launch_bounds__(256) void k_sum_errors(const double *__restrict__ err, uint64_t n, double cols, double *__restrict__ partial) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) acc += err[i] / cols;
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(64) void k_sum_partials(const double *__restrict__ partial, uint32_t count, double *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double acc = 0.0;
+        for (uint32_t i = 0; i < count; ++i) acc += partial[i];
+        out[0] = acc;
+    }
+}
+
+extern "C" int qvz_hip_sum_errors(const double *d_err, uint64_t n, uint32_t c, double *d_sum /*[1 + 1024]: the sum, then scratch*/, void *stream) {
+    if (!d_err || !d_sum || !c) return qvz_set_error(QVZ_E_ARG, "bad sum arguments");
+    hipLaunchKernelGGL(k_sum_errors, dim3(1024), dim3(256), 0, (hipStream_t)stream, d_err, n, (double)c, d_sum + 1);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, (hipStream_t)stream, d_sum + 1, 1024u, d_sum);
+    QVZ_HIP_CHECK(hipGetLastError());
+    return QVZ_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Conditional-PMF counters (reference src/codebook.c:193-205).
 //
@@ -2224,6 +2270,23 @@ extern "C" int qvz_hip_streams_overlap(void *stream_a, void *stream_b, int *over
     *overlap = best < 330e-6;
     return QVZ_OK;
 }
+
+// HIP events around a kernel, on the stream it is launched on: how a host driver in C times one launch (bench.py's roofline figures)
+extern "C" int qvz_hip_event_create(void **event) {
+    hipEvent_t e;
+    QVZ_HIP_CHECK(hipEventCreate(&e));
+    *event = (void *)e;
+    return QVZ_OK;
+}
+extern "C" int qvz_hip_event_record(void *event, void *stream) { QVZ_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return QVZ_OK; }
+extern "C" int qvz_hip_event_elapsed_ms(void *first, void *second, double *ms) {   // waits for `second`
+    float f = 0.f;
+    QVZ_HIP_CHECK(hipEventSynchronize((hipEvent_t)second));
+    QVZ_HIP_CHECK(hipEventElapsedTime(&f, (hipEvent_t)first, (hipEvent_t)second));
+    *ms = (double)f;
+    return QVZ_OK;
+}
+extern "C" int qvz_hip_event_destroy(void *event) { if (event) QVZ_HIP_CHECK(hipEventDestroy((hipEvent_t)event)); return QVZ_OK; }
 
 extern "C" int qvz_hip_stream_destroy(void *stream) { QVZ_HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); return QVZ_OK; }
 extern "C" int qvz_hip_stream_sync(void *stream) { QVZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); return QVZ_OK; }

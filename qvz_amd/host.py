@@ -115,6 +115,117 @@ def encode_file_devices(in_path, out_path, devices, shards, clusters=1, mode=MOD
     return r
 
 
+class ResidentProducts(C.Structure):
+    """qvz_resident_products_t (include/qvz_encode.h)."""
+    _fields_ = [("d_streams", C.c_void_p), ("h_sizes", C.POINTER(C.c_uint64)), ("shards", C.c_uint32), ("clusters", C.c_uint32),
+                ("stream_bytes", C.c_uint64), ("d_qv", C.c_void_p), ("d_labels", C.c_void_p), ("codebooks", C.POINTER(C.c_void_p)),
+                ("well_state", C.c_uint32 * 32), ("model_kernels_ms", C.c_double), ("coder_kernels_ms", C.c_double),
+                ("kmeans_kernels_ms", C.c_double), ("pmf_kernel_ms", C.c_double), ("quantize_kernel_ms", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
+
+
+class _DevicePtr:
+    """A device buffer the C side owns, seen as a tensor (the __cuda_array_interface__ protocol; no copy)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr, count, dtype="|u1"):
+    import torch
+    return torch.as_tensor(_DevicePtr(ptr, count, dtype), device="cuda")
+
+
+def group_allreduce(group):
+    """qvz_allreduce_fn over a process group (torch.distributed: RCCL between the GPUs of a node, gloo in rehearsals) or a
+    pipeline.LocalWorld group: the sum the parts of one file owe each other."""
+    from .pipeline import all_reduce_sum
+
+    def cb(_ctx, d_buf, count, width, _stream):
+        try:
+            t = device_view(d_buf, count, {4: "<i4", 8: "<i8", -8: "<f8"}[width])     # two's complement: the unsigned sum bit for bit
+            all_reduce_sum(t, group)
+            return 0
+        except Exception as exc:  # noqa: BLE001 - reported through the C side's error code
+            cb.error = repr(exc)
+            return 1
+    cb.error = None
+    fn = ALLREDUCE_FN(cb)
+    fn._py = cb
+    return fn
+
+
+class Resident:
+    """qvz_resident_* (include/qvz_encode.h): the whole hot path in C over a symbol matrix that is in HBM - what bench.py times.
+    The handle keeps its device buffers between encodes."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().qvz_resident_open(device, C.byref(self.h))
+        if rc:
+            raise QvzHipError(f"qvz_resident_open failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+
+    def encode(self, sym, n, shards, clusters=1, mode=MODE_RATIO, ratio=0.5, dist="M", threshold=4.0, want_qv=False, first_read=0,
+               n_total=None, group=None, centroid_lines=None, seed_mode=SEED_DEBUG, well_state=None):
+        """-> (Result, ResidentProducts). sym: (c, ld) uint8 device tensor of reads [first_read, first_read + n) of n_total."""
+        o = default_options()
+        o.clusters, o.mode, o.ratio, o.distortion, o.cluster_threshold = clusters, mode, ratio, DIST.get(dist, dist), threshold
+        o.seed_mode = seed_mode
+        if well_state is not None:
+            o.seed_mode = SEED_EXPLICIT
+            for i, v in enumerate(np.asarray(well_state, dtype=np.uint32)):
+                o.well_state[i] = int(v)
+        c, ld = sym.shape
+        fn = group_allreduce(group) if group is not None else None
+        lines = (C.c_uint64 * clusters)(*[int(x) for x in centroid_lines]) if centroid_lines is not None else None
+        r = Result()
+        rc = lib().qvz_resident_encode(self.h, C.c_void_p(sym.data_ptr()), n, c, ld, first_read, n if n_total is None else n_total,
+                                       C.byref(o), shards, int(want_qv), lines, C.cast(fn, C.c_void_p) if fn else None, None, C.byref(r))
+        if rc:
+            extra = f" [all-reduce: {fn._py.error}]" if fn is not None and fn._py.error else ""
+            raise QvzHipError(f"qvz_resident_encode failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}{extra}")
+        p = ResidentProducts()
+        rc = lib().qvz_resident_products(self.h, C.byref(p))
+        if rc:
+            raise QvzHipError(f"qvz_resident_products failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+        return r, p
+
+    @staticmethod
+    def codebook_bytes(p):
+        """the codebooks of the last encode in the file format (write_codebook, codebook.c:500-555), one bytes object per cluster"""
+        out = []
+        for j in range(p.clusters):
+            h = C.c_void_p(p.codebooks[j])
+            buf = np.zeros(lib().qvz_codebook_write(None, h), dtype=np.uint8)
+            lib().qvz_codebook_write(buf.ctypes.data_as(C.c_void_p), h)
+            out.append(buf.tobytes())
+        return out
+
+    @staticmethod
+    def streams(p):
+        """the last encode's streams as a list of bytes (copied from the device)"""
+        sizes = [int(p.h_sizes[g]) for g in range(p.shards)]
+        packed = device_view(p.d_streams, max(p.stream_bytes, 1)).cpu().numpy()[: p.stream_bytes].tobytes()
+        out, at = [], 0
+        for sz in sizes:
+            out.append(packed[at:at + sz])
+            at += sz
+        return out
+
+    def close(self):
+        if self.h:
+            lib().qvz_resident_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class SweepPoint(C.Structure):
     """qvz_sweep_point_t (include/qvz_encode.h)."""
     _fields_ = [("mode", C.c_int), ("ratio", C.c_double), ("distortion", C.c_int), ("dist_file", C.c_char_p)]
