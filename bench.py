@@ -133,18 +133,83 @@ def cpu_baseline(cfg, cores_note):
                 host=cores_note)
 
 
+def cpu_quota_cores(cores):
+    """the CPU time this process may use per second of wall (cgroup v2 cpu.max / v1 cfs quota), in cores; `cores` when unlimited"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline_multi_core(cfg, cores):
+    """The reference has no threaded mode; what a user with T cores can do is cut the file and run T copies.
+    T = min(64, cores, the cgroup's CPU quota) copies of oracle/_ref/qvz_ref (the oracle when the reference did not travel), each on
+    its own 500k-read piece of the workload's QGEN-1 stream, all started together: symbols of all pieces / wall. Every copy pays
+    the N-independent codebook generation for its piece, as T separate files would."""
+    import torch
+    import oracle_lib as O
+    from qvz_amd import kernels as K
+    c = cfg["cols"]
+    flags = ["-c", str(cfg["clusters"]), "-d", cfg["dist"], "-" + cfg["mode"], str(cfg["ratio"])]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "qvz_ref")
+    kind = "reference" if os.path.exists(ref_bin) else "port"
+    t_procs = max(1, min(64, cores, cpu_quota_cores(cores)))
+    m = 500_000
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    with tempfile.TemporaryDirectory(dir=base) as td:
+        for i in range(t_procs):                                 # the pieces' text, made on the GPU (the CPU generator takes 23 ns per symbol)
+            K.untranspose_text(K.qgen1(cfg["seed"], m, c, first=i * m), m).cpu().numpy().tofile(os.path.join(td, f"p{i}.txt"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if kind == "reference":
+            procs = [subprocess.Popen([ref_bin] + flags + [os.path.join(td, f"p{i}.txt"), os.path.join(td, f"p{i}.q")], stdout=subprocess.DEVNULL,
+                                      stderr=subprocess.DEVNULL) for i in range(t_procs)]
+        else:
+            code = ("import sys, numpy as np; sys.path.insert(0, %r); import oracle_lib as O; rows = np.fromfile(sys.argv[1], dtype=np.uint8).reshape(-1, %d); "
+                    "O.encode(rows, k=%d, mode=%d, ratio=%r, dist=%r, want_u=False)") % (os.path.join(ROOT, "tests"), c + 1, cfg["clusters"],
+                                                                                      O.MODE_RATIO if cfg["mode"] == "f" else O.MODE_FIXED, cfg["ratio"], cfg["dist"])
+            procs = [subprocess.Popen([sys.executable, "-c", code, os.path.join(td, f"p{i}.txt")]) for i in range(t_procs)]
+        codes = [p.wait(timeout=900) for p in procs]
+        wall = time.perf_counter() - t0
+    if any(codes):
+        return dict(failed=f"{sum(1 for x in codes if x)} of {t_procs} copies failed")
+    return dict(value=round(t_procs * m * c / wall, 1), unit="quality-symbols/s", cores=t_procs, kind=kind, wall_seconds=round(wall, 2),
+                sample=f"{t_procs} processes side by side, each the whole encode() of its own piece of {m} reads x {c} cols (QGEN-1 seed {cfg['seed']}, reads "
+                       f"i * {m} ...), flags {' '.join(flags)}; {cores} host cores visible, CPU quota {cpu_quota_cores(cores)}",
+                note="T separate files: T codebook sets, T streams - not the product the single-thread figure stands for; the honest many-core figure of a "
+                     "program that has no threads")
+
+
 def product_report(r, n, c, k, shards, steps, elapsed):
     """What the streams of the last timed step cost as a product: packed on the device, copied to the host, written as ONE
     shard set (include/qvz_shardset.h: codebooks once + stream index + streams); measured once, outside the timed steps."""
     import torch
     from qvz_amd import host
-    sizes = r["stream_bytes"]
-    handles = [cb.handle for cb in r["codebooks"]]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    packed = host.gather_streams(r["coded"], r["cap_per_shard"], sizes)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
+    if "products" in r:          # the C driver's step: the streams lie packed on the device already
+        p = r["products"]
+        sizes = [int(p.h_sizes[g]) for g in range(p.shards)]
+        handles = [p.codebooks[j] for j in range(p.clusters)]
+        torch.cuda.synchronize()
+        t0 = t1 = time.perf_counter()
+        packed = host.device_view(p.d_streams, max(int(p.stream_bytes), 1))[: int(p.stream_bytes)]
+    else:
+        sizes = r["stream_bytes"]
+        handles = [cb.handle for cb in r["codebooks"]]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        packed = host.gather_streams(r["coded"], r["cap_per_shard"], sizes)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
     pinned = torch.empty(packed.numel(), dtype=torch.uint8, pin_memory=True)
     t2 = time.perf_counter()
     pinned.copy_(packed, non_blocking=True)
@@ -396,6 +461,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="host coder threads per rank (default: cores / ranks)")
     ap.add_argument("--coder", choices=["host", "gpu", "gpu-feed"], default="gpu",
                     help="arithmetic coder: host threads, or one GPU lane per shard (byte-identical streams)")
+    ap.add_argument("--driver", choices=["c", "python"], default="c",
+                    help="who runs the stages of the timed step: the C driver (qvz_resident_encode; GPU coder only) or qvz_amd/pipeline.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the product / ingest / strict / 72-symbol PMF measurements after the timed steps")
     ap.add_argument("--no-u", action="store_true", help="do not write the quantized-value plane (the -u product) in the timed step")
@@ -458,7 +525,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed step is the C driver's (qvz_resident_encode, include/qvz_encode.h: host code in C, HIP kernels behind the C-ABI);
+    # torch supplies the resident matrix and - for N > 1 - the RCCL all-reduce the C side calls back into. --driver python runs
+    # the same stages from qvz_amd/pipeline.py (what the tests drive with other backends and coders).
+    use_c = args.driver == "c" and args.coder == "gpu"
+    resident = host.Resident(local) if use_c else None
+
+    def step_c():
+        r, p = resident.encode(sym, n, shards, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], want_qv=not args.no_u,
+                               first_read=first, n_total=n_total, group=group)
+        stats_in_cluster = r.t_stats if k == 1 else 0.0          # one cluster: the counters are made inside the clustering stage (they give it its sums)
+        wall = dict(kmeans=r.t_cluster - stats_in_cluster, pmf=r.t_stats, codebook=r.t_codebook, quantize=r.t_quantize, coder=r.t_coder,
+                    coder_model_kernels=p.model_kernels_ms * 1e-3, coder_interval_kernels=p.coder_kernels_ms * 1e-3, total=r.t_total)
+        kernels = dict(pmf_hist=[p.pmf_kernel_ms], quantize=[p.quantize_kernel_ms])
+        if k > 1:
+            kernels["kmeans_step"] = [p.kmeans_kernels_ms / max(1, r.kmeans_iterations)] * r.kmeans_iterations
+        return dict(stream_bytes=None, total_stream_bytes=int(r.stream_bytes), distortion=r.distortion, kmeans_iterations=r.kmeans_iterations,
+                    deferred=r.deferred_decisions, wall=wall, kernels=kernels, products=p)
+
     def step(timer=None):
+        if use_c:
+            return step_c()
         return P.encode_pass(sym, n, first, n_total, means0, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"],
                              shards=shards, threads=threads, group=group, timer=timer, device_index=local,
                              coder=args.coder, keep_device=not args.no_u and args.coder != "host")
@@ -515,6 +602,10 @@ def main():
         del qv, lab, draws, r
     if rank == 0:
         spans = timer.totals_ms()
+        if use_c:                    # the C driver's own HIP events around its launches, on their stream (qvz_resident_products)
+            for r in results:
+                for name, v in r["kernels"].items():
+                    spans.setdefault(name, []).extend(v)
         if args.coder == "gpu":      # the planes coder times its two kernel families itself (HIP events inside the C call)
             spans.pop("arith_shards", None)
             spans["model_records"] = [r["wall"]["coder_model_kernels"] * 1e3 for r in results]
@@ -560,7 +651,8 @@ def main():
                        "columns": c, "clusters": k, "coder": f"{shards} independent reference-format streams per GPU "
                        + (f"on {threads} host threads" if args.coder == "host" else
                           "coded on the GPU (model: a wave per stream and column; interval chain: a lane per stream)"),
-                       "parallelism": f"read-sharded x{world}"},
+                       "parallelism": f"read-sharded x{world}",
+                       "host_driver": "C: qvz_resident_encode (include/qvz_encode.h)" if use_c else "Python: qvz_amd/pipeline.py encode_pass"},
             "bits_per_symbol": round(stream_bytes * 8.0 / (n_total * c), 5),
             "distortion": results[-1]["distortion"], "kmeans_iterations": results[-1]["kmeans_iterations"],
             "phase_seconds": wall,
@@ -600,10 +692,12 @@ def main():
             except Exception as exc:       # noqa: BLE001 - reported, not swallowed
                 line[name] = dict(failed=f"{type(exc).__name__}: {exc}"[:600])
 
-        if not args.no_extras and world == 1 and args.coder == "gpu" and "coded" in results[-1]:
+        if not args.no_extras and world == 1 and args.coder == "gpu" and ("coded" in results[-1] or "products" in results[-1]):
             guarded("product", product_report, results[-1], n, c, k, shards, args.steps, elapsed)
-            for key in ("coded", "qv", "labels"):
+            for key in ("coded", "qv", "labels", "products"):
                 results[-1].pop(key, None)
+            if resident is not None:
+                resident.close()                                  # its buffers (150+ GB) make room for what follows
             guarded("ingest", ingest_report, cfg, n, c)
             guarded("roofline_pmf_hist_72_symbols", pmf72_report, n, c)
             guarded("strict", strict_report, cfg, c)
@@ -611,6 +705,11 @@ def main():
             guarded("e2e_cli", e2e_cli_report, cfg, sym, n, c, shards)
         if not args.no_cpu_baseline and world == 1:               # the CPU baseline is timed on rank 0 of the 1-GPU run only
             guarded("cpu_baseline", cpu_baseline, CONFIGS[args.config], f"{cores} host cores visible, 1 used")
+            if isinstance(line.get("cpu_baseline"), dict) and "failed" not in line["cpu_baseline"]:
+                try:
+                    line["cpu_baseline"]["multi_core"] = cpu_baseline_multi_core(CONFIGS[args.config], cores)
+                except Exception as exc:   # noqa: BLE001 - reported, not swallowed
+                    line["cpu_baseline"]["multi_core"] = dict(failed=f"{type(exc).__name__}: {exc}"[:400])
             if "gpu_model" in line.get("strict", {}) and line.get("cpu_baseline", {}).get("seconds_per_symbol"):   # the byte-identical single-stream file against the reference ON THIS HOST
                 ref_ns = line["cpu_baseline"]["seconds_per_symbol"] * 1e9
                 gpu_ns = line["strict"]["gpu_model"]["ns_per_symbol"]

@@ -1417,6 +1417,7 @@ int qvz_resident_encode(qvz_resident_t *r, const uint8_t *d_sym, uint64_t n, uin
             rows[(size_t)j * stride + c] = '\n';
         }
     }
+    const double t_setup = now();
     if ((rc = qvz_job_init_part(job, NULL, n, c, &o, first_read, rows))) goto fail;
     r->have_job = 1;
     job->pool = &r->pool;
@@ -1463,6 +1464,10 @@ int qvz_resident_encode(qvz_resident_t *r, const uint8_t *d_sym, uint64_t n, uin
     R.t_cluster = job->t_cluster; R.t_stats = job->t_stats; R.t_codebook = job->t_codebook; R.t_encode = job->t_encode;
     R.t_quantize = job->t_quantize; R.t_coder = job->t_coder; R.t_egress = job->t_egress;
     R.t_total = now() - t_start;
+    if (getenv("QVZ_TIMING"))
+        fprintf(stderr, "qvz_timing: resident encode: before the stages %.4f s (previous job's release, centroid reads), stages %.4f (cluster %.4f stats %.4f "
+                        "codebook %.4f quantize %.4f coder %.4f after the coder %.4f), total %.4f\n", t_setup - t_start, R.t_total - (t_setup - t_start),
+                R.t_cluster, R.t_stats, R.t_codebook, R.t_quantize, R.t_coder, R.t_egress, R.t_total);
 fail:
     job->centroid_rows = NULL;
     free(rows); free(h_cent);

@@ -91,7 +91,7 @@ def test_bad_arguments_are_refused():
     sym = upload(rows)
     res = host.Resident(0)
     with pytest.raises(QvzHipError, match="all-reduce"):
-        res.encode(sym, 1000, 2, first_read=1000, n_total=2000)              # a part without its collective
+        res.encode(sym, rows.shape[0], 2, first_read=4, n_total=rows.shape[0] + 4)   # a part without its collective
     with pytest.raises(QvzHipError):
         res.encode(sym, rows.shape[0], 0)
     with pytest.raises(QvzHipError):
