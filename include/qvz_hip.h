@@ -57,6 +57,9 @@ int qvz_hip_device_count(void);
  * The reference has no counterpart: it mmaps the input and callocs everything (src/lines.c:64,116). */
 int qvz_hip_set_device(int device);
 int qvz_hip_mem_info(uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the current device */
+/* a stream for throughput work beside another stream's chain of small kernels: lowest queue priority; leave_cus > 0: a CU mask
+ * that keeps it off the first leave_cus CUs of every XCD instead */
+int qvz_hip_stream_create_beside(void **stream, int leave_cus);
 /* events on a stream, for timing a launch from C: elapsed_ms waits for the second event */
 int qvz_hip_event_create(void **event);
 int qvz_hip_event_record(void *event, void *stream);

@@ -146,6 +146,7 @@ SIGNATURES = {
     "qvz_resident_close": (None, [C.c_void_p]),
     "qvz_hip_gather_reads": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "qvz_hip_sum_errors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "qvz_hip_stream_create_beside": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "qvz_hip_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "qvz_hip_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "qvz_hip_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),

@@ -450,7 +450,7 @@ static int qpipe_open(qvz_job_t *job, int want_qv, int piped) {
             int n = 0, good = -1;
             while (n < 8 && good < 0) {
                 int o1 = 0, o2 = 1;
-                if (qvz_hip_stream_create(&cand[n])) break;
+                if (qvz_hip_stream_create_beside(&cand[n], getenv("QVZ_QUANT_LEAVE_CUS") ? atoi(getenv("QVZ_QUANT_LEAVE_CUS")) : 0)) break;
                 if (qvz_hip_streams_overlap(cand[n], NULL, &o1) == QVZ_OK && o1 &&
                     (!job->well_stream || (qvz_hip_streams_overlap(cand[n], job->well_stream, &o2) == QVZ_OK && o2))) good = n;
                 ++n;

@@ -1991,6 +1991,18 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     fetch(s0);
     park(tbuf + (NBUF == 2 ? (s0 & 1) * per_col4 : 0u));
     __syncthreads();
+    if (s0) {
+        // the rows of symbol 0 that stand in for reads past n (above) have no carry: they enter the range through the first context
+        // column s0 defines - from there on they walk through contexts that exist, as from column 0
+        const uint16_t *c0 = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s0 & 1) * per_col4 : 0u));
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (!active || i0 + r >= n) {
+                uint32_t p = 0;
+                while (p < QVZ_A - 1 && (c0[cbase[r] + p] & 0xFF) == QVZ_NOT_FOUND) ++p;
+                prev[r] = p;
+            }
+    }
     // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
     // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
     const uint64_t io = active ? i0 : 0;
@@ -2284,6 +2296,33 @@ extern "C" int qvz_hip_stream_create(void **stream) {
     *stream = (void *)s;
     return QVZ_OK;
 }
+// A stream for throughput work that is to run BESIDE a chain of small latency-bound kernels on another stream (the quantizer beside
+// the codebook generation): lowest queue priority, so that a workgroup slot that frees up goes to the small kernels first, and -
+// leave_cus > 0 - a CU mask that keeps it off the first leave_cus CUs of every group of 32 (an XCD), which the small kernels then
+// have to themselves.
+extern "C" int qvz_hip_stream_create_beside(void **stream, int leave_cus) {
+    hipStream_t s = nullptr;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo: the numerically greatest = lowest priority
+    if (leave_cus > 0) {
+        int dev = 0, cus = 0;
+        QVZ_HIP_CHECK(hipGetDevice(&dev));
+        QVZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        uint32_t mask[32] = {0};
+        const int words = (cus + 31) / 32 < 32 ? (cus + 31) / 32 : 32;
+        const char *how = getenv("QVZ_CU_MASK_LAYOUT");          // development knob: "interleaved" - bit i is CU i / 8 of XCD i % 8
+        for (int i = 0; i < cus && i < 1024; ++i) {
+            const bool left = how && strcmp(how, "interleaved") == 0 ? i / 8 < leave_cus : i % 32 < leave_cus;
+            if (!left) mask[i / 32] |= 1u << (i % 32);
+        }
+        QVZ_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+    } else {
+        QVZ_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo));
+    }
+    *stream = (void *)s;
+    return QVZ_OK;
+}
+
 // Do two streams run their kernels side by side? The runtime multiplexes a process's streams onto a handful of hardware
 // queues (four by default; RCCL, torch's stream pool and every library in the process draw from the same few), a queue runs
 // its kernels in order, and which queue a new stream gets depends on what was created before it. So a stream that is
