@@ -67,13 +67,6 @@ int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h
  * not a restatement; whenever the u32 counters do not wrap it gives the same codebook, bit for bit. */
 int qvz_hip_generate_codebook64(const uint64_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
                                 double guard, qvz_codebook_t *out, void *stream);
-/* Progress of the calling thread's NEXT qvz_hip_generate_codebook(64) call: fn(ctx, s) runs on that thread once columns 0 .. s of
- * `out` are final (generate_codebooks makes the columns one after the other, codebook.c:392-468), so that what consumes a column's
- * tables - the quantizer - can start before the last column exists. Cleared when that call returns. */
-void qvz_hip_codebook_on_column(void (*fn)(void *ctx, uint32_t column), void *ctx);
-/* The quantizer's device tables (include/qvz_hip.h) of columns [s0, s1) of a codebook: ct + s0 * QVZ_CT_STRIDE and
- * qs + s0 * QVZ_QS_STRIDE onwards are written, as qvz_codebook_tables writes them for all columns. */
-void qvz_codebook_tables_columns(const qvz_codebook_t *cb, uint16_t *ct, uint16_t *qs, uint32_t s0, uint32_t s1);
 
 /* Marginal pmfs of one cluster, h_marg[s*72 + x]: the second half of calculate_statistics
  * (reference src/codebook.c:208-219, combine_pmfs src/pmf.c:189-205), bit-identical to the reference's values. */

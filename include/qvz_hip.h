@@ -57,9 +57,6 @@ int qvz_hip_device_count(void);
  * The reference has no counterpart: it mmaps the input and callocs everything (src/lines.c:64,116). */
 int qvz_hip_set_device(int device);
 int qvz_hip_mem_info(uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the current device */
-/* a stream for throughput work beside another stream's chain of small kernels: lowest queue priority; leave_cus > 0: a CU mask
- * that keeps it off the first leave_cus CUs of every XCD instead */
-int qvz_hip_stream_create_beside(void **stream, int leave_cus);
 /* events on a stream, for timing a launch from C: elapsed_ms waits for the second event */
 int qvz_hip_event_create(void **event);
 int qvz_hip_event_record(void *event, void *stream);
@@ -190,16 +187,6 @@ int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, 
                      uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
                      uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi,
                      uint8_t *d_st, uint64_t ld_out, double *d_err, int32_t *d_status, void *stream);
-/* The same for columns [s0, s1) of every read, so that a matrix can be quantized in column ranges as the codebook's columns
- * become final (the reference's loop walks a line's columns in order, qv_compressor.c:88-120; a read's state between two columns
- * is its previous quantized value and its error sum): a range with s0 > 0 takes both from d_carry[i] / d_err[i], one with
- * s1 < c leaves them there. d_ct / d_qs are indexed by absolute column. The ranges of one matrix must be launched in order on
- * one stream; the outputs equal those of one qvz_hip_quantize call bit for bit. */
-int qvz_hip_quantize_columns(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
-                             uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
-                             uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
-                             uint64_t ld_out, double *d_err, int32_t *d_status, uint32_t s0, uint32_t s1, uint8_t *d_carry /*[ld]*/,
-                             void *stream);
 
 /* Coder feed: column-major quantizer indices / state indices (pitch ld) -> read-major pairs
  * d_feed[i*c + s] = qi | st << 8, the order compress_qv consumes them in (qv_compressor.c:89-119). */

@@ -42,10 +42,6 @@ SIGNATURES = {
     "qvz_hip_well_jump": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]),
     "qvz_hip_quantize": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u16p, u16p, u8p,
                                    C.c_uint64, f64p, u8p, u8p, u8p, C.c_uint64, f64p, C.c_void_p, C.c_void_p]),
-    "qvz_hip_quantize_columns": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u16p, u16p, u8p,
-                                           C.c_uint64, f64p, u8p, u8p, u8p, C.c_uint64, f64p, C.c_void_p, C.c_uint32, C.c_uint32, u8p, C.c_void_p]),
-    "qvz_hip_codebook_on_column": (None, [C.c_void_p, C.c_void_p]),
-    "qvz_codebook_tables_columns": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "qvz_hip_pack_feed": (C.c_int, [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint64, u16p, C.c_void_p]),
     "qvz_hip_set_device": (C.c_int, [C.c_int]),
     "qvz_hip_mem_info": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -146,7 +142,6 @@ SIGNATURES = {
     "qvz_resident_close": (None, [C.c_void_p]),
     "qvz_hip_gather_reads": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "qvz_hip_sum_errors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
-    "qvz_hip_stream_create_beside": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "qvz_hip_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "qvz_hip_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "qvz_hip_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),

@@ -141,10 +141,8 @@ size_t qvz_codebook_write(uint8_t *buf, const qvz_codebook_t *cb) {
     return pos;
 }
 
-void qvz_codebook_tables(const qvz_codebook_t *cb, uint16_t *ct, uint16_t *qs) { qvz_codebook_tables_columns(cb, ct, qs, 0, cb->C); }
-
-void qvz_codebook_tables_columns(const qvz_codebook_t *cb, uint16_t *ct, uint16_t *qs, uint32_t s0, uint32_t s1) {
-    for (uint32_t s = s0; s < s1 && s < cb->C; ++s) {
+void qvz_codebook_tables(const qvz_codebook_t *cb, uint16_t *ct, uint16_t *qs) {
+    for (uint32_t s = 0; s < cb->C; ++s) {
         for (int p = 0; p < A; ++p) {
             const uint8_t ctx = cb->ctx_idx[(size_t)s * A + p];
             ct[(size_t)s * A + p] = ctx == QVZ_NOT_FOUND

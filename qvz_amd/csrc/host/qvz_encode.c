@@ -375,162 +375,6 @@ done:
     return rc;
 }
 
-/* ---- the quantizer as a pipe behind the codebook generation ------------------------------------------------------------------
- * generate_codebooks makes a codebook column by column (codebook.c:392-468), a chain of small latency-bound kernels and host round
- * trips that leaves the chip idle for 18-27 ms at 100M x 150; the quantizer (qv_compressor.c:88-120) needs of the codebook only
- * the columns it is at. So the matrix is quantized in column RANGES, each launched - on a stream of its own, beside the
- * generation's kernels - as soon as its columns are final in every cluster's codebook (qvz_hip_codebook_on_column); a read's state
- * between two ranges is its previous quantized value and its error sum (qvz_hip_quantize_columns). Same planes, bit for bit. */
-static uint8_t *job_plane(qvz_job_t *job, int i);
-static pthread_mutex_t g_qp_mu = PTHREAD_MUTEX_INITIALIZER;      /* (short sections: a table build and a few launches) */
-
-static int quant_piped(void) {                                    /* QVZ_QUANT_PIPE=0 (development knob): one quantizer launch behind the codebooks */
-    const char *e = getenv("QVZ_QUANT_PIPE");
-    return !(e && atoi(e) == 0);
-}
-
-static void qpipe_close(qvz_job_t *job) {
-    qvz_qpipe_t *qp = job->qp;
-    if (!qp) return;
-    if (!qp->planes_early) { job_free(job, qp->d_err); job_free(job, qp->d_qv); job_free(job, qp->d_qi); job_free(job, qp->d_st); }
-    job_free(job, qp->d_ct); job_free(job, qp->d_qs); job_free(job, qp->d_carry);
-    qvz_hip_free(qp->d_dist); qvz_hip_free(qp->d_status);
-    if (!qp->h_pooled) qvz_hip_free_host(qp->h_ct);
-    for (uint32_t i = 0; i < qp->nev; ++i) qvz_hip_event_destroy(qp->ev[i]);
-    if (qp->stream && !(job->pool && job->pool->quant_stream == qp->stream)) qvz_hip_stream_destroy(qp->stream);
-    free(qp);
-    job->qp = NULL;
-}
-
-/* buffers of the quantizer; piped: a stream of its own that runs beside the default one, ranges of `step` columns */
-static int qpipe_open(qvz_job_t *job, int want_qv, int piped) {
-    int rc = 0;
-    const uint32_t C = job->C, K = job->K;
-    const uint64_t N = job->N, ld = job->ld;
-    const size_t ctn = (size_t)K * C * QVZ_CT_STRIDE, qsn = (size_t)K * C * QVZ_QS_STRIDE;
-    if (job->qp) return 0;
-    qvz_qpipe_t *qp = (qvz_qpipe_t *)calloc(1, sizeof(*qp));
-    if (!qp) return qvz_job_fail(QVZ_E_NOMEM, "host alloc");
-    job->qp = qp;
-    qp->C = C; qp->K = K; qp->piped = piped;
-    qp->step = piped ? (C + 5) / 6 < 8 ? 8 : (C + 5) / 6 : C;
-    if (getenv("QVZ_QUANT_STEP") && atoi(getenv("QVZ_QUANT_STEP")) > 0) qp->step = (uint32_t)atoi(getenv("QVZ_QUANT_STEP"));   /* development knob: columns per range */
-    {   /* the tables as the host builds them: pinned (the copies are asynchronous), kept by a resident handle */
-        const size_t hb = (ctn + qsn) * sizeof(uint16_t);
-        if (job->pool) {
-            if (job->pool->h_tables && job->pool->h_tables_bytes < hb) { qvz_hip_free_host(job->pool->h_tables); job->pool->h_tables = NULL; }
-            if (!job->pool->h_tables) { HIP(qvz_hip_malloc_host(&job->pool->h_tables, hb)); job->pool->h_tables_bytes = hb; }
-            qp->h_ct = (uint16_t *)job->pool->h_tables;
-            qp->h_pooled = 1;
-        } else HIP(qvz_hip_malloc_host((void **)&qp->h_ct, hb));
-        qp->h_qs = qp->h_ct + ctn;
-    }
-    HIP(job_malloc(job, (void **)&qp->d_ct, ctn * sizeof(uint16_t), QVZ_POOL_CT));
-    HIP(job_malloc(job, (void **)&qp->d_qs, qsn * sizeof(uint16_t), QVZ_POOL_QS));
-    HIP(qvz_hip_malloc((void **)&qp->d_dist, sizeof(job->h_dist)));
-    HIP(qvz_hip_malloc((void **)&qp->d_status, sizeof(int32_t)));
-    if (qp->step < C) HIP(job_malloc(job, (void **)&qp->d_carry, ld, QVZ_POOL_CARRY));
-    /* the planes: the qv plane (the -u product) only for a caller that wants the text */
-    if (job_plane(job, 0) && (!want_qv || job_plane(job, 2))) {                /* allocated ahead of time, beside the upload */
-        qp->planes_early = 1;
-        qp->d_qi = job_plane(job, 0); qp->d_st = job_plane(job, 1); qp->d_err = (double *)job_plane(job, -1);
-        if (want_qv) qp->d_qv = job_plane(job, 2);
-    } else {
-        if (want_qv) HIP(job_malloc(job, (void **)&qp->d_qv, (size_t)C * ld, QVZ_POOL_QV));
-        HIP(job_malloc(job, (void **)&qp->d_qi, (size_t)C * ld, QVZ_POOL_QI));
-        HIP(job_malloc(job, (void **)&qp->d_st, (size_t)C * ld, QVZ_POOL_ST));
-        HIP(job_malloc(job, (void **)&qp->d_err, N * sizeof(double), QVZ_POOL_ERR));
-    }
-    if (piped) {
-        if (job->pool && job->pool->quant_stream) qp->stream = job->pool->quant_stream;
-        else {
-            /* a stream that shares the default stream's hardware queue would put a range's 3 ms of quantizer IN FRONT of the
-             * generation's next kernel: probed like the WELL stream (qvz_job_start_draws), against that one too */
-            void *cand[8] = {NULL};
-            int n = 0, good = -1;
-            while (n < 8 && good < 0) {
-                int o1 = 0, o2 = 1;
-                if (qvz_hip_stream_create_beside(&cand[n], getenv("QVZ_QUANT_LEAVE_CUS") ? atoi(getenv("QVZ_QUANT_LEAVE_CUS")) : 0)) break;
-                if (qvz_hip_streams_overlap(cand[n], NULL, &o1) == QVZ_OK && o1 &&
-                    (!job->well_stream || (qvz_hip_streams_overlap(cand[n], job->well_stream, &o2) == QVZ_OK && o2))) good = n;
-                ++n;
-            }
-            if (good < 0 && n > 0) good = n - 1;
-            for (int i = 0; i < n; ++i) if (i != good) qvz_hip_stream_destroy(cand[i]);
-            if (good < 0) { rc = qvz_job_fail(QVZ_E_HIP, "no stream for the quantizer: %s", qvz_hip_last_error()); goto done; }
-            qp->stream = cand[good];
-            if (job->pool) job->pool->quant_stream = qp->stream;
-        }
-    }
-    HIP(qvz_hip_copy_h2d(qp->d_dist, job->h_dist, sizeof(job->h_dist), qp->stream));
-    HIP(qvz_hip_memset(qp->d_status, 0, sizeof(int32_t), qp->stream));
-done:
-    if (rc) qpipe_close(job);
-    return rc;
-}
-
-/* columns [a, b) of every cluster's codebook are final: their tables go up and the quantizer takes the range (caller holds g_qp_mu) */
-static int qpipe_launch(qvz_job_t *job, uint32_t a, uint32_t b) {
-    int rc = 0;
-    qvz_qpipe_t *qp = job->qp;
-    const uint32_t C = job->C, K = job->K;
-    for (uint32_t j = 0; j < K; ++j) {
-        const size_t ct0 = ((size_t)j * C + a) * QVZ_CT_STRIDE, qs0 = ((size_t)j * C + a) * QVZ_QS_STRIDE;
-        qvz_codebook_tables_columns(job->cbs[j], qp->h_ct + (size_t)j * C * QVZ_CT_STRIDE, qp->h_qs + (size_t)j * C * QVZ_QS_STRIDE, a, b);
-        HIP(qvz_hip_copy_h2d(qp->d_ct + ct0, qp->h_ct + ct0, (size_t)(b - a) * QVZ_CT_STRIDE * sizeof(uint16_t), qp->stream));
-        HIP(qvz_hip_copy_h2d(qp->d_qs + qs0, qp->h_qs + qs0, (size_t)(b - a) * QVZ_QS_STRIDE * sizeof(uint16_t), qp->stream));
-    }
-    if (a == 0) HIP(qvz_hip_stream_wait(qp->stream, job->well_stream));        /* the draws, on the device's side */
-    if (job->keep_device && qp->nev + 2 <= 32 && qvz_hip_event_create(&qp->ev[qp->nev]) == QVZ_OK) {
-        if (qvz_hip_event_create(&qp->ev[qp->nev + 1]) == QVZ_OK) { (void)qvz_hip_event_record(qp->ev[qp->nev], qp->stream); qp->nev += 2; }
-        else qvz_hip_event_destroy(qp->ev[qp->nev]);
-    }
-    HIP(qvz_hip_quantize_columns(job->d_sym, K > 1 ? job->d_labels : NULL, job->N, C, job->ld, K, qp->d_ct, qp->d_qs, job->d_draws, job->ld, qp->d_dist,
-                                 qp->d_qv, qp->d_qi, qp->d_st, job->ld, qp->d_err, qp->d_status, a, b, qp->d_carry, qp->stream));
-    if (job->keep_device && qp->nev && !(qp->nev & 1)) (void)qvz_hip_event_record(qp->ev[qp->nev - 1], qp->stream);
-    qp->launched = b;
-done:
-    return rc;
-}
-
-/* cluster j's codebook has its columns 0 .. s final (called on the thread that generates it) */
-static void qpipe_column(qvz_job_t *job, uint32_t j, uint32_t s) {
-    qvz_qpipe_t *qp = job->qp;
-    if (!qp || !qp->piped || qp->rc) return;
-    pthread_mutex_lock(&g_qp_mu);
-    qp->ready[j] = s + 1;
-    uint32_t m = qp->C;
-    for (uint32_t c = 0; c < qp->K; ++c) if (qp->ready[c] < m) m = qp->ready[c];
-    while (!qp->rc && qp->launched < m) {
-        const uint32_t b = qp->launched + qp->step < qp->C ? qp->launched + qp->step : qp->C;
-        if (b > m) break;
-        if (qpipe_launch(job, qp->launched, b)) { qp->rc = QVZ_E_HIP; snprintf(qp->err, sizeof(qp->err), "quantizer range: %s", qvz_encode_last_error()); }
-    }
-    pthread_mutex_unlock(&g_qp_mu);
-}
-
-/* everything that is still to be quantized, then the default stream waits for the quantizer's; *status: the dead-context word */
-static int qpipe_finish(qvz_job_t *job, int32_t *status) {
-    int rc = 0;
-    qvz_qpipe_t *qp = job->qp;
-    pthread_mutex_lock(&g_qp_mu);
-    if (qp->rc) rc = qvz_job_fail(qp->rc, "%s", qp->err);
-    while (!rc && qp->launched < qp->C) {
-        const uint32_t b = qp->launched + qp->step < qp->C ? qp->launched + qp->step : qp->C;
-        rc = qpipe_launch(job, qp->launched, b);
-    }
-    pthread_mutex_unlock(&g_qp_mu);
-    if (rc) return rc;
-    HIP(qvz_hip_copy_d2h(status, qp->d_status, sizeof(*status), qp->stream));
-    HIP(qvz_hip_stream_sync(qp->stream));
-    for (uint32_t i = 0; i + 1 < qp->nev; i += 2) {
-        double ms = 0.0;
-        if (qvz_hip_event_elapsed_ms(qp->ev[i], qp->ev[i + 1], &ms) == QVZ_OK) job->k_quantize_ms += ms;
-    }
-done:
-    return rc;
-}
-
 /* One cluster's generation: a chain of small kernels and host round trips (qvz_codebook.hip). The clusters' codebooks are
  * independent, so with several clusters each gets a host thread and a stream of its own. */
 typedef struct {
@@ -542,17 +386,11 @@ typedef struct {
     char err[256];
 } cb_task_t;
 
-static void cb_column(void *ctx, uint32_t s) {
-    cb_task_t *t = (cb_task_t *)ctx;
-    qpipe_column(t->job, t->j, s);
-}
-
 static void *cb_task(void *arg) {
     cb_task_t *t = (cb_task_t *)arg;
     qvz_job_t *job = t->job;
     const size_t tile = (size_t)job->C * A * A;
     int rc = qvz_hip_set_device(job->opts.device);                              /* the device is a per-thread setting */
-    if (!rc && job->qp && job->qp->piped) qvz_hip_codebook_on_column(cb_column, t);   /* the quantizer follows the columns as they become final */
     if (!rc)
         rc = job->d_cnt64 ? qvz_hip_generate_codebook64(job->d_cnt64 + t->j * tile, job->C, job->h_dist, job->opts.mode, job->opts.ratio, 0.0,
                                                         job->cbs[t->j], t->stream)
@@ -582,14 +420,28 @@ int qvz_job_codebooks(qvz_job_t *job) {
     }
     HIP(qvz_hip_stream_sync(NULL));                                            /* the counters are complete */
     /* cluster 0 on the calling thread and the default stream, the others on threads and streams of their own */
-    for (uint32_t j = 1; j < K; ++j) {
-        if (qvz_hip_stream_create(&task[j].stream)) task[j].stream = NULL;     /* no stream: the default one, in turn */
-        if (pthread_create(&th[j], NULL, cb_task, &task[j])) { th[j] = 0; cb_task(&task[j]); }
+    {
+        /* a stream per cluster that runs beside the default stream, the WELL generator's and the other clusters' (a resident handle
+         * keeps them: eight at most, the clusters beyond share in turn) */
+        void *others[10];
+        int nothers = 0;
+        others[nothers++] = job->well_stream;
+        for (uint32_t j = 1; j < K; ++j) {
+            void **kept = job->pool && j <= 8 ? &job->pool->cb_stream[j - 1] : NULL;
+            if (kept && *kept) task[j].stream = *kept;
+            else {
+                task[j].stream = j <= 8 ? side_stream(others, nothers) : NULL;  /* no stream: the default one, in turn */
+                if (kept) *kept = task[j].stream;
+            }
+            if (task[j].stream && nothers < 10) others[nothers++] = task[j].stream;
+        }
     }
+    for (uint32_t j = 1; j < K; ++j)
+        if (pthread_create(&th[j], NULL, cb_task, &task[j])) { th[j] = 0; cb_task(&task[j]); }
     cb_task(&task[0]);
     for (uint32_t j = 1; j < K; ++j) if (th[j]) pthread_join(th[j], NULL);
     for (uint32_t j = 0; j < K; ++j) {
-        if (task[j].stream) qvz_hip_stream_destroy(task[j].stream);
+        if (task[j].stream && !(job->pool && j >= 1 && j <= 8 && job->pool->cb_stream[j - 1] == task[j].stream)) qvz_hip_stream_destroy(task[j].stream);
         if (task[j].rc && !rc) rc = qvz_job_fail(task[j].rc, "%s", task[j].err);
         job->deferred_decisions += task[j].deferred;
     }
@@ -804,6 +656,28 @@ done:
     return rc;
 }
 
+/* A stream whose kernels run BESIDE the default stream's and those of `others`: candidates are probed (~1 ms each,
+ * qvz_hip_streams_overlap) and the first that overlaps with all of them is kept; NULL when none can be made. */
+static void *side_stream(void *const *others, int nothers) {
+    void *cand[8] = {NULL};
+    int n = 0, good = -1;
+    while (n < 8 && good < 0) {
+        int ok = 0;
+        if (qvz_hip_stream_create(&cand[n])) break;
+        if (qvz_hip_streams_overlap(cand[n], NULL, &ok) == QVZ_OK && ok) {
+            good = n;
+            for (int i = 0; i < nothers && good >= 0; ++i) {
+                int o = 1;
+                if (others[i] && (qvz_hip_streams_overlap(cand[n], others[i], &o) != QVZ_OK || !o)) good = -1;
+            }
+        }
+        ++n;
+    }
+    if (good < 0 && n > 0) good = n - 1;                                        /* none overlaps with everything: the last one, in turn */
+    for (int i = 0; i < n; ++i) if (i != good) qvz_hip_stream_destroy(cand[i]);
+    return good < 0 ? NULL : cand[good];
+}
+
 /* The WELL state of the file (qv_stream.c:70-89) and its draw matrix. The draws depend on the seed only, so they are
  * generated on a side stream beside the codebook generation (small latency-bound kernels and host round trips): 25 ms of
  * generator and transposition kernels at 100M x 150 that the quantizer would otherwise wait for. */
@@ -827,18 +701,7 @@ int qvz_job_start_draws(qvz_job_t *job) {
      * (DESIGN.md section 8). A candidate is probed (~1 ms) and dropped for the next one if it does not overlap. */
     if (job->pool && job->pool->well_stream) job->well_stream = job->pool->well_stream;   /* a resident handle's: made and probed once */
     else {
-        void *cand[8] = {NULL};
-        int n = 0, good = -1;
-        while (n < 8 && good < 0) {
-            int overlap = 0;
-            if (qvz_hip_stream_create(&cand[n])) break;
-            if (qvz_hip_streams_overlap(cand[n], NULL, &overlap) == QVZ_OK && overlap) good = n;
-            ++n;
-        }
-        if (good < 0 && n > 0) good = n - 1;
-        for (int i = 0; i < n; ++i) if (i != good) qvz_hip_stream_destroy(cand[i]);
-        if (good < 0) { rc = qvz_job_fail(QVZ_E_HIP, "no stream for the WELL draws: %s", qvz_hip_last_error()); goto done; }
-        job->well_stream = cand[good];
+        if (!(job->well_stream = side_stream(NULL, 0))) { rc = qvz_job_fail(QVZ_E_HIP, "no stream for the WELL draws: %s", qvz_hip_last_error()); goto done; }
         if (job->pool) job->pool->well_stream = job->well_stream;
     }
     HIP(qvz_hip_stream_wait(job->well_stream, NULL));
@@ -980,9 +843,11 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     double t1, t2;
     const uint32_t C = job->C, K = job->K;
     const uint64_t N = job->N, ld = job->ld;
-    double *d_err = NULL;
+    uint16_t *d_ct = NULL, *d_qs = NULL, *h_ct = NULL, *h_qs = NULL;
+    double *d_dist = NULL, *d_err = NULL;
+    int planes_early = 0;
     uint8_t *d_qv = NULL, *d_qi = NULL, *d_st = NULL, *d_out = NULL, *d_out_own = NULL, *d_packed = NULL, *d_packed_own = NULL, *h_buf = NULL, *image = NULL;
-    int32_t status = 0;
+    int32_t *d_status = NULL, status = 0;
     uint64_t *sizes = NULL, *first = NULL;
     uint32_t *wstates = NULL;
     pthread_t th_text, th_err, th_prep;
@@ -996,16 +861,46 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     if ((rc = qvz_job_start_draws(job))) goto done;                            /* already running when the caller started them */
     if (!(getenv("QVZ_CODER_PREPARE") && atoi(getenv("QVZ_CODER_PREPARE")) == 0))   /* development knob: 0 = the coder call sets itself up */
         prep_running = pthread_create(&th_prep, NULL, prepare_main, &task_prep) == 0;
-    sizes = (uint64_t *)calloc(shards, sizeof(uint64_t));
-    first = (uint64_t *)calloc((size_t)shards + 1, sizeof(uint64_t));
-    if (!sizes || !first) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+    {
+        const size_t ctn = (size_t)K * C * QVZ_CT_STRIDE, qsn = (size_t)K * C * QVZ_QS_STRIDE;
+        h_ct = (uint16_t *)malloc(ctn * sizeof(uint16_t));
+        h_qs = (uint16_t *)malloc(qsn * sizeof(uint16_t));
+        sizes = (uint64_t *)calloc(shards, sizeof(uint64_t));
+        first = (uint64_t *)calloc((size_t)shards + 1, sizeof(uint64_t));
+        if (!h_ct || !h_qs || !sizes || !first) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+        for (uint32_t j = 0; j < K; ++j)
+            qvz_codebook_tables(job->cbs[j], h_ct + (size_t)j * C * QVZ_CT_STRIDE, h_qs + (size_t)j * C * QVZ_QS_STRIDE);
+        HIP(qvz_hip_malloc((void **)&d_ct, ctn * sizeof(uint16_t)));
+        HIP(qvz_hip_malloc((void **)&d_qs, qsn * sizeof(uint16_t)));
+        HIP(qvz_hip_malloc((void **)&d_dist, sizeof(job->h_dist)));
+        HIP(qvz_hip_copy_h2d(d_ct, h_ct, ctn * sizeof(uint16_t), NULL));
+        HIP(qvz_hip_copy_h2d(d_qs, h_qs, qsn * sizeof(uint16_t), NULL));
+        HIP(qvz_hip_copy_h2d(d_dist, job->h_dist, sizeof(job->h_dist), NULL));
+    }
     if (job->shard_bounds) memcpy(first, job->shard_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
     else qvz_shard_bounds(N, shards, first);
-    /* The quantizer: most of it has run beside the codebook generation when the caller opened the pipe before that (qpipe_open /
-     * qvz_job_codebooks); what is left - the last range, or everything - is launched now. */
-    if ((rc = qpipe_open(job, fu != NULL || job->want_text, 0))) goto done;    /* (no-op when it is open) */
-    if ((rc = qpipe_finish(job, &status))) goto done;
-    d_qv = job->qp->d_qv; d_qi = job->qp->d_qi; d_st = job->qp->d_st; d_err = job->qp->d_err;
+    /* quantizer: the qv plane (the -u product) only for a caller that wants the text */
+    if (job_plane(job, 0) && (!fu || job_plane(job, 2))) {                     /* allocated ahead of time, beside the upload */
+        planes_early = 1;
+        d_qi = job_plane(job, 0); d_st = job_plane(job, 1); d_err = (double *)job_plane(job, -1);
+        if (fu) d_qv = job_plane(job, 2);
+    } else {
+        if (fu || job->want_text) HIP(job_malloc(job, (void **)&d_qv, (size_t)C * ld, QVZ_POOL_QV));
+        HIP(job_malloc(job, (void **)&d_qi, (size_t)C * ld, QVZ_POOL_QI));
+        HIP(job_malloc(job, (void **)&d_st, (size_t)C * ld, QVZ_POOL_ST));
+        HIP(job_malloc(job, (void **)&d_err, N * sizeof(double), QVZ_POOL_ERR));
+    }
+    HIP(qvz_hip_malloc((void **)&d_status, sizeof(int32_t)));
+    HIP(qvz_hip_memset(d_status, 0, sizeof(int32_t), NULL));
+    HIP(qvz_hip_stream_wait(NULL, job->well_stream));                          /* the draws, on the device's side */
+    span_t sp_q;
+    span_begin(job, &sp_q);
+    HIP(qvz_hip_quantize(job->d_sym, K > 1 ? job->d_labels : NULL, N, C, ld, K, d_ct, d_qs, job->d_draws, ld, d_dist, d_qv, d_qi, d_st,
+                         ld, d_err, d_status, NULL));
+    span_end(&sp_q);
+    HIP(qvz_hip_copy_d2h(&status, d_status, sizeof(status), NULL));
+    HIP(qvz_hip_stream_sync(NULL));
+    span_add(&sp_q, &job->k_quantize_ms);
     if (status) { rc = qvz_job_fail(QVZ_E_DEAD_CTX, "quantizer reached a context the codebook does not define (assert in the reference, codebook.c:164)"); goto done; }
     if (!job->keep_resident) {                                                  /* (a sweep's next point quantizes the same matrix with the same draws) */
         job_free(job, job->d_draws);                                           /* 15 GB at 100M x 150, an allocation of its own for this */
@@ -1155,9 +1050,10 @@ done:
     if (prep_running) pthread_join(th_prep, NULL);
     if (err_running) pthread_join(th_err, NULL);                                /* they read device buffers freed below */
     if (text_running) pthread_join(th_text, NULL);
-    free(sizes); free(first); free(h_buf); free(image); free(wstates);
-    if (!job->keep_device || rc) qpipe_close(job);                              /* (a resident encode's planes are its products: they go with the job) */
-    job_free(job, d_out_own); job_free(job, d_packed_own);
+    free(h_ct); free(h_qs); free(sizes); free(first); free(h_buf); free(image); free(wstates);
+    qvz_hip_free(d_ct); qvz_hip_free(d_qs); qvz_hip_free(d_dist);
+    if (!planes_early) { job_free(job, d_err); job_free(job, d_qv); job_free(job, d_qi); job_free(job, d_st); }   /* (the early planes go with the job) */
+    job_free(job, d_out_own); job_free(job, d_packed_own); qvz_hip_free(d_status);
     if (!job->keep_resident || rc) {
         if (job->d_draws) { job_free(job, job->d_draws); job->d_draws = NULL; }
         if (job->well_stream && !(job->pool && job->pool->well_stream == job->well_stream)) qvz_hip_stream_destroy(job->well_stream);
@@ -1179,7 +1075,6 @@ int qvz_job_compress_shardset(qvz_job_t *job, FILE *fout, FILE *fu, uint32_t sha
 void qvz_job_release(qvz_job_t *job) {
     if (job->cbs) { for (uint32_t j = 0; j < job->K; ++j) qvz_codebook_free(job->cbs[j]); free(job->cbs); }
     free(job->h_labels); free(job->h_means); free(job->h_counts); free(job->h_acc);
-    qpipe_close(job);
     if (!job->sym_borrowed) qvz_hip_free(job->d_sym);
     job_free(job, job->d_labels); qvz_hip_free(job->d_means); qvz_hip_free(job->d_cnt);
     qvz_hip_free(job->d_counts); qvz_hip_free(job->d_acc); qvz_hip_free(job->d_moved); qvz_hip_free(job->d_kstat);
@@ -1287,7 +1182,6 @@ static int encode_buffer(const uint8_t *text, uint64_t bytes, FILE *fout, FILE *
         if (sw && shards && fout && !shard_prefix) qvz_prealloc_start(fout, job.N * (uint64_t)job.C / 4);
         if (sw && shards && fu) qvz_prealloc_start(fu, job.N * ((uint64_t)job.C + 1));
         if (shards && (rc = qvz_job_start_draws(&job))) goto done;              /* the WELL generator runs beside the codebooks */
-        if (shards && quant_piped() && (rc = qpipe_open(&job, fu != NULL, 1))) goto done;   /* ... and the quantizer follows their columns */
         if ((rc = qvz_job_codebooks(&job))) goto done;
         if (opts->verbose) printf("Stats and codebook generation took %.4f seconds\n", job.t_stats + job.t_codebook);   /* main.c:66-67 */
         if (shards && !shard_prefix) {                                          /* one shard-set file */
@@ -1492,9 +1386,8 @@ void qvz_resident_close(qvz_resident_t *r) {
     (void)qvz_hip_set_device(r->device);
     resident_drop_job(r);
     for (int i = 1; i < QVZ_POOL_ROLES; ++i) qvz_hip_free(r->pool.ptr[i]);
-    qvz_hip_free_host(r->pool.h_tables);
     if (r->pool.well_stream) qvz_hip_stream_destroy(r->pool.well_stream);
-    if (r->pool.quant_stream) qvz_hip_stream_destroy(r->pool.quant_stream);
+    for (int i = 0; i < 8; ++i) if (r->pool.cb_stream[i]) qvz_hip_stream_destroy(r->pool.cb_stream[i]);
     free(r);
 }
 
@@ -1570,7 +1463,6 @@ int qvz_resident_encode(qvz_resident_t *r, const uint8_t *d_sym, uint64_t n, uin
     if ((rc = qvz_job_kmeans(job, 0))) goto fail;
     if ((rc = qvz_job_stats(job))) goto fail;
     if ((rc = qvz_job_start_draws(job))) goto fail;               /* the WELL generator runs beside the codebooks */
-    if (quant_piped() && (rc = qpipe_open(job, want_qv != 0, 1))) goto fail;   /* ... and the quantizer follows their columns */
     if ((rc = qvz_job_codebooks(job))) goto fail;
     {   /* the coder's record workspace: everything at once if it fits, 96 GiB at most, 24 GiB of what is free left alone */
         uint64_t free_b = 0, want = qvz_hip_encode_planes_work_bytes((n + shards - 1) / shards + 4, c, K, shards);

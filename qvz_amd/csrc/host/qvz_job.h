@@ -15,32 +15,15 @@
 /* Device blocks that outlive a job (include/qvz_encode.h, qvz_resident_*): a process that encodes one resident matrix after another
  * keeps its big buffers - labels, draws, the quantizer's planes, the stream area, the record workspace - instead of returning 100+ GB
  * to the driver and asking for them again every time. A block is found by its role; one that is too small is replaced. */
-enum { QVZ_POOL_LABELS = 1, QVZ_POOL_DRAWS, QVZ_POOL_QI, QVZ_POOL_ST, QVZ_POOL_QV, QVZ_POOL_ERR, QVZ_POOL_OUT, QVZ_POOL_PACKED, QVZ_POOL_WORK, QVZ_POOL_CT, QVZ_POOL_QS,
-       QVZ_POOL_CARRY, QVZ_POOL_ROLES };
+enum { QVZ_POOL_LABELS = 1, QVZ_POOL_DRAWS, QVZ_POOL_QI, QVZ_POOL_ST, QVZ_POOL_QV, QVZ_POOL_ERR, QVZ_POOL_OUT, QVZ_POOL_PACKED, QVZ_POOL_WORK, QVZ_POOL_ROLES };
 typedef struct qvz_pool {
     void *ptr[QVZ_POOL_ROLES];
     uint64_t bytes[QVZ_POOL_ROLES];
-    void *h_tables;             /* pinned: the quantizer's tables as the host builds them */
-    uint64_t h_tables_bytes;
-    void *well_stream, *quant_stream;   /* side streams, made once and probed for running beside the default stream */
+    /* side streams, made once and probed for running beside the default stream (and one another): the WELL generator's, and one per
+     * cluster beyond the first for the codebook generations. The runtime spreads streams over a few hardware queues; a fresh stream
+     * per encode lands on the default stream's queue every few encodes and its work then runs in turn instead of beside */
+    void *well_stream, *cb_stream[8];
 } qvz_pool_t;
-
-/* The quantizer fed column range by column range while the codebooks' later columns are still being generated (qvz_encode.c). */
-typedef struct qvz_qpipe {
-    uint32_t C, K, step, launched;    /* columns per range; columns handed to the quantizer so far */
-    uint32_t ready[256];              /* per cluster: columns of its codebook that are final */
-    int piped;                        /* 0: one launch for all columns, on the default stream, when the codebooks are complete */
-    void *stream;
-    uint16_t *h_ct, *h_qs, *d_ct, *d_qs;
-    double *d_dist, *d_err;
-    int32_t *d_status;
-    uint8_t *d_carry, *d_qv, *d_qi, *d_st;
-    int planes_early, h_pooled;
-    void *ev[2 * 16];                 /* events around the range launches (a job that reports kernel times) */
-    uint32_t nev;
-    int rc;
-    char err[200];
-} qvz_qpipe_t;
 
 typedef struct qvz_job {
     /* input view: rows of C+1 bytes (Q+33 ... '\n') in file order */
@@ -77,7 +60,6 @@ typedef struct qvz_job {
     double k_kmeans_ms, k_pmf_ms, k_quantize_ms;   /* busy time of the kernels (HIP events on their stream; k-means: all iterations) */
     double *d_errsum;           /* [1025] this part's distortion sum (qvz_hip_sum_errors)                                          */
     double r_errsum;
-    qvz_qpipe_t *qp;            /* the quantizer's buffers and progress (sharded compress) */
     int keep_resident;          /* a sweep: the sharded compress leaves the matrix and the draws for the next operating point */
     double t_upload, t_cluster, t_stats, t_codebook, t_encode;
     double t_quantize, t_coder, t_egress;   /* inside t_encode of a sharded encode: WELL wait + quantizer, coder kernels, what leaves the device afterwards */

@@ -1268,7 +1268,6 @@ static int generate_on_device(const void *d_cnt, bool wide, uint32_t C, const do
     return QVZ_OK;
 }
 
-static inline void column_final(uint32_t s);
 static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
                     qvz_codebook_t *cb, hipStream_t st, CbWork &W) {
     const size_t tile = (size_t)A * A;
@@ -1612,28 +1611,12 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         memcpy(hq, cb->q + (size_t)s * 2 * tile, 2 * tile);
         for (uint32_t j = 0; j < A; ++j) hr[j] = j < nu ? cb->ratio[(size_t)s * A + j] : 0.0;
         nprev = nu;                                                              // (k_cb_stage_in of the next column reads hq / hr)
-        column_final(s);
     }
     return QVZ_OK;
 }
 
 static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double ratio,
                              double guard, qvz_codebook_t *out, void *stream);
-
-// The calling thread's NEXT generation reports its progress: fn(ctx, s) on that thread once columns 0 .. s of the codebook are final
-// (context lists, quantizer tables, ratios) - the columns come one after the other (generate_codebooks' loop, codebook.c:392-468),
-// and what consumes a column's tables (the quantizer, host/qvz_encode.c) need not wait for the last. Cleared when the call returns.
-static thread_local void (*g_on_column)(void *, uint32_t) = nullptr;
-static thread_local void *g_on_column_ctx = nullptr;
-static thread_local uint32_t g_on_column_next = 0;               // first column not reported yet
-extern "C" void qvz_hip_codebook_on_column(void (*fn)(void *ctx, uint32_t column), void *ctx) {
-    g_on_column = fn;
-    g_on_column_ctx = ctx;
-    g_on_column_next = 0;
-}
-static inline void column_final(uint32_t s) {
-    if (g_on_column && s + 1 > g_on_column_next) { g_on_column_next = s + 1; g_on_column(g_on_column_ctx, s); }
-}
 
 extern "C" int qvz_hip_generate_codebook(const uint32_t *d_cnt, uint32_t C, const double *h_dist, int mode, double ratio,
                                          double guard, qvz_codebook_t *out, void *stream) {
@@ -1659,8 +1642,6 @@ static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const dou
     const double t_gen = cb_now();
     const int rc = generate(d_cnt, wide, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
     (void)hipStreamSynchronize((hipStream_t)stream);
-    if (rc == QVZ_OK) column_final(C - 1);                       // (a flow that does not report column by column: everything at once)
-    g_on_column = nullptr;
     g_cb_active.fetch_sub(1);
     cbw_give_back(W);
     if (getenv("QVZ_CB_DEBUG"))                                  // development knob

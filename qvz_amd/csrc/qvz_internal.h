@@ -33,10 +33,6 @@ struct QvzQuantArgs {                 // everything qvz_hip_quantize takes
     uint64_t ld_out;
     double *d_err;
     int32_t *d_status;
-    // columns [s0, s1) of every read (s1 = 0: all of them). A range that does not start at column 0 takes each read's previous
-    // quantized value from d_carry and its error sum so far from d_err; one that does not end at c leaves them there for the next.
-    uint32_t s0 = 0, s1 = 0;
-    uint8_t *d_carry = nullptr;
 };
 int qvz_quantize_check(const QvzQuantArgs &a);
 // Launches the quantizer on `stream`. d_first == nullptr: all n reads. Otherwise one SEGMENT of a sharded encode: the reads

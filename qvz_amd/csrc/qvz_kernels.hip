@@ -1786,8 +1786,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
                                                   uint8_t *__restrict__ qv_out, uint8_t *__restrict__ qi_out,
                                                   uint8_t *__restrict__ st_out, uint64_t ldo, double *__restrict__ err_out,
                                                   int32_t *__restrict__ status, const int32_t *__restrict__ route,
-                                                  const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len,
-                                                  uint32_t s0, uint32_t s1, uint8_t *__restrict__ carry) {
+                                                  const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len) {
     __shared__ double sdist[QVZ_A * QVZ_A];
     if (route[1] == QZ_ROUTE_LDS) return;                       // the other kernel's job (qvz_hip_quantize: routing without a host round trip)
     for (uint32_t i = threadIdx.x; i < QVZ_A * QVZ_A; i += 256) sdist[i] = dist[i];
@@ -1815,15 +1814,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
         ctp[r] = ct + (uint64_t)l * C * QVZ_CT_STRIDE;
         qsp[r] = qs + (uint64_t)l * C * QVZ_QS_STRIDE;
     }
-    if (s0) {                                                    // a later column range of these reads: where the range before left off
-        const uint32_t p4 = *reinterpret_cast<const uint32_t *>(carry + i0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            prev[r] = (p4 >> (8 * r)) & 0xFF;
-            if (i0 + r < n) err[r] = err_out[i0 + r];
-        }
-    }
-    for (uint32_t s = s0; s < s1; ++s) {
+    for (uint32_t s = 0; s < C; ++s) {
         const uint32_t x4 = *reinterpret_cast<const uint32_t *>(D + (uint64_t)s * ld + i0);
         const uint32_t d4 = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)s * ldd + i0);   // 7-bit draws, same layout
         uint32_t qv4 = 0, qi4 = 0, st4 = 0;
@@ -1854,7 +1845,6 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
         for (int r = 0; r < 4; ++r)
             if (i0 + r < n) err_out[i0 + r] = err[r];
     }
-    if (carry && s1 < C) *reinterpret_cast<uint32_t *>(carry + i0) = prev[0] | (prev[1] << 8) | (prev[2] << 16) | (prev[3] << 24);
     if (dead) atomicOr(status, 1);
 }
 
@@ -1881,8 +1871,7 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
                                                              uint8_t *__restrict__ qi_out, uint8_t *__restrict__ st_out,
                                                              uint64_t ldo, double *__restrict__ err_out,
                                                              int32_t *__restrict__ status, const int32_t *__restrict__ route,
-                                                             const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len,
-                                                             uint32_t s0, uint32_t s1, uint8_t *__restrict__ carry) {
+                                                             const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len) {
     extern __shared__ uint4 qz_smem[];
     if (route[1] != QZ_ROUTE_LDS) return;                       // a general distortion matrix: k_quantize does this call
     double *sdist = reinterpret_cast<double *>(qz_smem);         // d(|x - y|), from row 0 of the matrix
@@ -1972,37 +1961,9 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
             if (i < per_col4) dst[i] = make_uint4(stg[q].x, stg[q].y, stg[q].z, stg[q].w);
         }
     };
-    // A column range [s0, s1) of a matrix that is quantized in pieces (beside the codebook generation, whose columns come one after
-    // the other: host/qvz_encode.c): every read's chain is picked up where the range before left it - the previous quantized value
-    // (the context, codebook.c:162-171) and the error summed so far, in the reference's order (qv_compressor.c:97,118).
-    if (s0 && active) {
-#pragma unroll
-        for (int w = 0; w < RW; ++w) {
-            if (!SEG || w == 0 || i0 + 4 * w < n) {
-                const uint32_t p4 = *reinterpret_cast<const uint32_t *>(carry + i0 + 4 * w);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    prev[4 * w + b] = (p4 >> (8 * b)) & 0xFF;
-                    if (i0 + 4 * w + b < n) err[4 * w + b] = err_out[i0 + 4 * w + b];
-                }
-            }
-        }
-    }
-    fetch(s0);
-    park(tbuf + (NBUF == 2 ? (s0 & 1) * per_col4 : 0u));
+    fetch(0);
+    park(tbuf);
     __syncthreads();
-    if (s0) {
-        // the rows of symbol 0 that stand in for reads past n (above) have no carry: they enter the range through the first context
-        // column s0 defines - from there on they walk through contexts that exist, as from column 0
-        const uint16_t *c0 = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s0 & 1) * per_col4 : 0u));
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (!active || i0 + r >= n) {
-                uint32_t p = 0;
-                while (p < QVZ_A - 1 && (c0[cbase[r] + p] & 0xFF) == QVZ_NOT_FOUND) ++p;
-                prev[r] = p;
-            }
-    }
     // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
     // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
     const uint64_t io = active ? i0 : 0;
@@ -2014,15 +1975,15 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     uint32_t x4n[RW], d4n[RW];
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
-        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + (uint64_t)s0 * ld + io + woff[w]));
-        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + (uint64_t)s0 * ldd + io + woff[w]));      // 7-bit draws, same layout
+        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + io + woff[w]));
+        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + io + woff[w]));      // 7-bit draws, same layout
     }
-    for (uint32_t s = s0; s < s1; ++s) {
+    for (uint32_t s = 0; s < C; ++s) {
         const uint16_t *cur = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s & 1) * per_col4 : 0u));
         uint32_t x4[RW], d4[RW], qv4[RW], qi4[RW], st4[RW];
 #pragma unroll
         for (int w = 0; w < RW; ++w) { x4[w] = x4n[w] & xmask[w]; d4[w] = d4n[w]; qv4[w] = qi4[w] = st4[w] = 0; }
-        if (s + 1 < s1) {
+        if (s + 1 < C) {
             fetch(s + 1);
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
@@ -2061,7 +2022,7 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
                 }
             }
         }
-        if (s + 1 < s1) {
+        if (s + 1 < C) {
             if (NBUF == 1) __syncthreads();                      // everybody is done with column s's tables
             park(tbuf + (NBUF == 2 ? ((s + 1) & 1) * per_col4 : 0u));
         }
@@ -2071,12 +2032,6 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (i0 + r < n) err_out[i0 + r] = err[r];
-    }
-    if (carry && s1 < C && active) {
-#pragma unroll
-        for (int w = 0; w < RW; ++w)
-            if (!SEG || w == 0 || woff[w])
-                *reinterpret_cast<uint32_t *>(carry + i0 + 4 * w) = prev[4 * w] | (prev[4 * w + 1] << 8) | (prev[4 * w + 2] << 16) | (prev[4 * w + 3] << 24);
     }
     if (dead || ctxmax == QVZ_NOT_FOUND) atomicOr(status, 1);
 }
@@ -2089,8 +2044,6 @@ int qvz_quantize_check(const QvzQuantArgs &a) {
     if (a.k == 0 || a.k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", a.k);
     if (a.k > 1 && !a.d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for k > 1");
     if (!a.d_ct || !a.d_qs || !a.d_draws || !a.d_dist || !a.d_status) return qvz_set_error(QVZ_E_ARG, "null table pointer");
-    if (a.s1 && (a.s0 >= a.s1 || a.s1 > a.c)) return qvz_set_error(QVZ_E_ARG, "columns [%u, %u) of %u", a.s0, a.s1, a.c);
-    if (a.s1 && (a.s0 > 0 || a.s1 < a.c) && (!a.d_carry || !a.d_err)) return qvz_set_error(QVZ_E_ARG, "a column range needs the carry plane and the error sums");
     return QVZ_OK;
 }
 
@@ -2098,7 +2051,6 @@ int qvz_quantize_launch(const QvzQuantArgs &a, const uint64_t *d_first, uint32_t
                         int32_t *d_route, bool decide, hipStream_t stream) {
     const uint64_t n = a.n;
     const uint32_t c = a.c, k = a.k;
-    const uint32_t s0 = a.s1 ? a.s0 : 0u, s1 = a.s1 ? a.s1 : c;  // the column range (all columns unless the caller names one)
     const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // development knob: "global" keeps the tables in L1/L2
     const bool lds_possible = k <= 3 && !(force && strcmp(force, "global") == 0);
     // [0] mirrors nothing (the kernels write the caller's d_status); [1] = route of this call
@@ -2126,13 +2078,13 @@ int qvz_quantize_launch(const QvzQuantArgs &a, const uint64_t *d_first, uint32_t
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
                 hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT, true>), grid, dim3(TT), lds, stream, a.d_sym,              \
                                    k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
-                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len, s0, s1, a.d_carry); \
+                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);            \
             } else {                                                                                                             \
                 QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT, false>),     \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
                 hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT, false>), grid, dim3(TT), lds, stream, a.d_sym,             \
                                    k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
-                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len, s0, s1, a.d_carry); \
+                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);            \
             }                                                                                                                    \
         } while (0)
         static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4 &&
@@ -2146,7 +2098,7 @@ int qvz_quantize_launch(const QvzQuantArgs &a, const uint64_t *d_first, uint32_t
     dim3 grid((unsigned)((threads_for(4) + 255) / 256));
     hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, stream, a.d_sym, k > 1 ? a.d_labels : nullptr, n, c, a.ld,
                        a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, a.d_st, a.ld_out, a.d_err, a.d_status, d_route,
-                       d_first, shards, seg_lo, seg_len, s0, s1, a.d_carry);
+                       d_first, shards, seg_lo, seg_len);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
 }
@@ -2159,21 +2111,6 @@ extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, u
     const int rc = qvz_quantize_check(a);
     if (rc) return rc;
     // the route word lives behind the caller's status word in this device's scratch pair (stream-ordered like the rest of it)
-    ScratchLock lk((hipStream_t)stream);
-    if (lk.rc) return lk.rc;
-    if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, 2 * sizeof(int32_t)));
-    return qvz_quantize_launch(a, nullptr, 0, 0, 0, lk.d->d_route, true, (hipStream_t)stream);
-}
-
-extern "C" int qvz_hip_quantize_columns(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
-                                        uint32_t k, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
-                                        uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
-                                        uint64_t ld_out, double *d_err, int32_t *d_status, uint32_t s0, uint32_t s1, uint8_t *d_carry,
-                                        void *stream) {
-    QvzQuantArgs a = {d_sym, d_labels, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status};
-    a.s0 = s0; a.s1 = s1; a.d_carry = d_carry;
-    const int rc = qvz_quantize_check(a);
-    if (rc) return rc;
     ScratchLock lk((hipStream_t)stream);
     if (lk.rc) return lk.rc;
     if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, 2 * sizeof(int32_t)));
@@ -2296,33 +2233,6 @@ extern "C" int qvz_hip_stream_create(void **stream) {
     *stream = (void *)s;
     return QVZ_OK;
 }
-// A stream for throughput work that is to run BESIDE a chain of small latency-bound kernels on another stream (the quantizer beside
-// the codebook generation): lowest queue priority, so that a workgroup slot that frees up goes to the small kernels first, and -
-// leave_cus > 0 - a CU mask that keeps it off the first leave_cus CUs of every group of 32 (an XCD), which the small kernels then
-// have to themselves.
-extern "C" int qvz_hip_stream_create_beside(void **stream, int leave_cus) {
-    hipStream_t s = nullptr;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo: the numerically greatest = lowest priority
-    if (leave_cus > 0) {
-        int dev = 0, cus = 0;
-        QVZ_HIP_CHECK(hipGetDevice(&dev));
-        QVZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        uint32_t mask[32] = {0};
-        const int words = (cus + 31) / 32 < 32 ? (cus + 31) / 32 : 32;
-        const char *how = getenv("QVZ_CU_MASK_LAYOUT");          // development knob: "interleaved" - bit i is CU i / 8 of XCD i % 8
-        for (int i = 0; i < cus && i < 1024; ++i) {
-            const bool left = how && strcmp(how, "interleaved") == 0 ? i / 8 < leave_cus : i % 32 < leave_cus;
-            if (!left) mask[i / 32] |= 1u << (i % 32);
-        }
-        QVZ_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
-    } else {
-        QVZ_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo));
-    }
-    *stream = (void *)s;
-    return QVZ_OK;
-}
-
 // Do two streams run their kernels side by side? The runtime multiplexes a process's streams onto a handful of hardware
 // queues (four by default; RCCL, torch's stream pool and every library in the process draw from the same few), a queue runs
 // its kernels in order, and which queue a new stream gets depends on what was created before it. So a stream that is

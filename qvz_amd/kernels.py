@@ -153,20 +153,6 @@ def quantize(sym, n, ct, qs, draws, dist, labels=None, k=1, want=("qv", "qi", "s
     return out
 
 
-def quantize_columns(sym, n, ct, qs, draws, dist, cuts, labels=None, k=1, want=("qv", "qi", "st", "err")):
-    """The same matrix quantized in the column ranges [cuts[i], cuts[i + 1]) (qvz_hip_quantize_columns): every read's previous
-    quantized value and error sum travel from range to range through a carry plane. Bit for bit what quantize() gives."""
-    c, ld = _dims(sym, n)
-    assert cuts[0] == 0 and "err" in want
-    out = quantize_outputs(sym, n, want)
-    carry = torch.zeros(ld, dtype=torch.uint8, device=sym.device)
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        check(lib().qvz_hip_quantize_columns(_ptr(sym), _ptr(labels), n, c, ld, k, _ptr(ct), _ptr(qs), _ptr(draws), ld, _ptr(dist),
-                                             _ptr(out["qv"]), _ptr(out["qi"]), _ptr(out["st"]), ld, _ptr(out["err"]), _ptr(out["status"]),
-                                             a, b, _ptr(carry), _stream()))
-    return out
-
-
 def quantize_outputs(sym, n, want):
     """The quantizer's output planes (None where not wanted), per-read errors and status word, allocated."""
     c, ld = _dims(sym, n)

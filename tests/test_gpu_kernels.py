@@ -438,43 +438,6 @@ def test_quantize_kernels_agree_and_general_distortion_matrix(K, monkeypatch):
     np.testing.assert_array_equal(e["err"].cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("name,cuts", [("t2k_r10_M", [0, 7, 8, 30]), ("t2k_c3_f05_M", [0, 1, 2, 15, 29, 30]), ("twolevel_c2_f05", [0, 5, 20]),
-                                       ("cfg1_r10_M", [0, 17, 34, 51, 68, 85, 100]), ("t2k_f05_L", [0, 30])])
-def test_quantize_in_column_ranges_equals_one_launch(K, monkeypatch, name, cuts):
-    """qvz_hip_quantize_columns (what lets the quantizer run beside the codebook generation, whose columns come one after the
-    other): ranges of odd and even starts, of one column, with one, two and three clusters - planes, per-read error BITS and the
-    reference's -u text as from one launch over all columns; the same through the gather kernel and with a general matrix."""
-    rows = G.case_rows(name)
-    opts = G.case_opts(name)
-    n, c, k = rows.shape[0], rows.shape[1] - 1, opts["k"]
-    labels_np = O.kmeans(rows, k)[0]
-    cnt = O.stats(rows, labels_np, k)
-    d = O.distortion(opts["dist"])
-    cbs = [O.generate_codebook(cnt[j], d, opts["mode"], opts["ratio"]) for j in range(k)]
-    sym = upload_sym(K, rows)
-    lab = torch.zeros(sym.shape[1], dtype=torch.uint8, device="cuda")
-    lab[:n] = torch.from_numpy(labels_np).cuda()
-    ct, qs = tables_from_codebooks(cbs)
-    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
-    g = np.ascontiguousarray(np.random.default_rng(3).random((72, 72))).reshape(-1)
-    for how, dist in (("lds", d), ("global", d), ("general", g)):
-        if how == "global":
-            monkeypatch.setenv("QVZ_QUANTIZE_KERNEL", "global")
-        dd = torch.from_numpy(dist).cuda()
-        one = K.quantize(sym, n, ct, qs, draws, dd, labels=lab, k=k)
-        many = K.quantize_columns(sym, n, ct, qs, draws, dd, cuts, labels=lab, k=k)
-        monkeypatch.delenv("QVZ_QUANTIZE_KERNEL", raising=False)
-        assert int(many["status"].item()) == 0
-        for key in ("qv", "qi", "st"):
-            assert torch.equal(many[key][:, :n], one[key][:, :n]), (how, key)
-        assert torch.equal(many["err"], one["err"]), how
-        if how == "lds":
-            assert G.md5(K.untranspose_text(many["qv"], n).cpu().numpy().tobytes()) == G.CASES[name]["u_md5"]
-    from qvz_amd._lib import QvzHipError
-    with pytest.raises(QvzHipError):
-        K.quantize_columns(sym, n, ct, qs, draws, torch.from_numpy(d).cuda(), [0, c + 1], labels=lab, k=k)
-
-
 def test_quantize_reports_undefined_context(K):
     rows = O.qgen1_rows(4, 400, 12)
     cnt = O.stats(rows, np.zeros(400, np.uint8), 1)
