@@ -158,6 +158,7 @@ static int job_init(qvz_job_t *job, const uint8_t *text, uint64_t bytes, uint64_
  * transposition into the column-major matrix overlap. */
 static uint8_t *job_plane(qvz_job_t *job, int i);
 static uint8_t *early_draws_plane(qvz_job_t *job);
+static void *side_stream(void *const *others, int nothers);
 
 int qvz_ingest_rows(const uint8_t *text, uint64_t N, uint32_t C, uint8_t *d_sym, uint64_t ld, uint32_t *bad_out) {
     int rc = 0;
