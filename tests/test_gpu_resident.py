@@ -107,7 +107,7 @@ def test_eight_parts_through_the_c_entry_with_a_callback_all_reduce():
     reads lie on three different parts."""
     import threading
     from qvz_amd import host, kernels as K, pipeline as P
-    n_total, cols, k, seed, world, shards = 800_000, 50, 3, 23, 8, 3
+    n_total, cols, k, seed, world, shards = 1_000_000, 50, 3, 23, 8, 3
     rows = O.qgen1_rows(seed, n_total, cols)
     lines = [int(x) for x in O.pick_centroids(n_total, k)]
     assert len({next(r for r in range(world) if P.rank_read_range(n_total, world, r)[0] <= ln < P.rank_read_range(n_total, world, r)[1]) for ln in lines}) == 3
