@@ -1341,28 +1341,22 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
 // 4-7: the 32-byte piece of one unit per lane), turn the integer triples into the two quotients (unpack_record) and park them
 // in the ring; waves 1, 2, 3 are interval, bits, bytes as before. The loaders are throughput work (eight independent
 // records per block and lane); the three chain waves keep a SIMD each.
-// S = streams per workgroup (round 5): 64 - a lane per stream in every wave, two loaders - or 32 (packed records only): the chain
-// waves run with their upper halves idle, ONE loader wave serves the 32 streams (lane pair 2k, 2k + 1 = the two 16-byte halves of
-// stream k's 32-byte piece; first load = symbols 0-3 of a sub-block, second = symbols 4-7), so a workgroup is four waves, one to a
-// SIMD, its LDS halves, and 8192 streams are 256 workgroups - one for every CU instead of one for every other. The record area is
-// the model kernel's either way (groups of 64 streams side by side: workgroup b reads the half (b & 1) of group b >> 1).
-template <bool REC8, int NB, int NEWTON, int S = 64>
-__global__ __launch_bounds__(REC8 ? (S == 32 ? 256 : 320) : 256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
+template <bool REC8, int NB, int NEWTON>
+__global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
                                                       uint64_t *__restrict__ sizes, int32_t *__restrict__ status, int high_prio) {
     constexpr int LAG = REC8 ? 1 : 0;                            // blocks the interval wave (and the two behind it) run further behind the loaders
     static_assert((NB == 8 || NB == 16) && (REC8 || NB == 8), "the record layouts have 8 records per lane and sub-block; 16-symbol blocks come with packed records only");
-    static_assert(S == 64 || (S == 32 && REC8), "32 streams per workgroup come with packed records only");
-    __shared__ Record ring[2][CR_B][S];
-    __shared__ uint32_t words[3][CR_B][S];                       // three slots: the bytes wave re-reads a rare symbol's word two blocks later
-    __shared__ uint32_t ebits[2][CR_B][S];                       // value (16 bits) | bit count << 16, or CR_RARE | pending run
-    __shared__ uint32_t final_l[S], final_s3[S];
-    __shared__ uint4 oring[S * 5];                               // the bytes wave's output ring: 16 words per lane, 80-byte stride
+    __shared__ Record ring[2][CR_B][64];
+    __shared__ uint32_t words[3][CR_B][64];                      // three slots: the bytes wave re-reads a rare symbol's word two blocks later
+    __shared__ uint32_t ebits[2][CR_B][64];                      // value (16 bits) | bit count << 16, or CR_RARE | pending run
+    __shared__ uint32_t final_l[64], final_s3[64];
+    __shared__ uint4 oring[64 * 5];                              // the bytes wave's output ring: 16 words per lane, 80-byte stride
     const uint32_t hw_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // role: 0 interval, 1 bits, 2 bytes, 3 loader (REC8: of symbols 0-3; S = 32: of all eight), 4 (REC8, S = 64 only) loader of symbols 4-7
+    // role: 0 interval, 1 bits, 2 bytes, 3 loader (REC8: of symbols 0-3), 4 (REC8 only) loader of symbols 4-7
     const uint32_t wave = !REC8 ? hw_wave : hw_wave == 0 ? 3u : hw_wave == 4 ? 4u : hw_wave - 1;
-    const uint32_t g = blockIdx.x * S + (lane & (S - 1));       // (S = 32: lanes 32-63 mirror 0-31 until the chain waves drop them)
+    const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read (rec_index)
     if (high_prio) {
@@ -1388,7 +1382,6 @@ __global__ __launch_bounds__(REC8 ? (S == 32 ? 256 : 320) : 256) void k_code_rec
     Tmin = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(Tmin >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)Tmin);
     const uint64_t nblk = (Tmax + CR_B - 1) / CR_B;              // the same in all four waves
     const bool fresh = is_first || !live;
-    if (S == 32 && wave < 3 && lane >= 32) return;               // a chain wave's upper half has no stream (its barriers are the wave's: unaffected)
 #ifdef QVZ_PROFILE          // busy / waiting cycles of each role between the block barriers
     unsigned long long cr_busy = 0, cr_wait = 0, cr_drain = 0, cr_t = __builtin_readcyclecounter();   // cr_drain: the part of cr_wait spent in s_waitcnt lgkmcnt(0)
 #define CR_BARRIER() do { const unsigned long long a_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
@@ -1423,11 +1416,9 @@ __global__ __launch_bounds__(REC8 ? (S == 32 ? 256 : 320) : 256) void k_code_rec
         // of 64 -, every lane unpacks the four records it loaded (two of either stream) and parks them where they belong by address:
         // nothing is shuffled. The ring's stream index is XORed with 8 for symbols 2, 3 (mod 4), so that an even and an odd lane -
         // same stream, symbols two apart: 2 KB apart - write to different banks; the interval wave reads with the same twist.
-        // (S = 32: one loader; "B" is the same stream's other piece - symbols 4-7, the next unit - instead of stream 32 + k's)
-        const uint32_t sA = lane >> 1, sB = S == 32 ? sA : 32 + (lane >> 1), hp = lane & 1;
-        const uint32_t grp = S == 32 ? blockIdx.x >> 1 : blockIdx.x, sub = S == 32 ? (blockIdx.x & 1) * 32 : 0;   // the 64-stream group of the record area and this workgroup's place in it
-        const uint4 *p0 = reinterpret_cast<const uint4 *>(reinterpret_cast<const PRec *>(rec) + ((uint64_t)grp * nunit * 64) * 16) + sub * 8;   // unit 0 of the workgroup's streams (rec8_index), 8 uint4 per unit and stream
-        const uint4 *pA = p0 + sA * 8 + hp, *pB = S == 32 ? pA + 64 * 8 : p0 + sB * 8 + hp;
+        const uint32_t sA = lane >> 1, sB = 32 + (lane >> 1), hp = lane & 1;
+        const uint4 *p0 = reinterpret_cast<const uint4 *>(reinterpret_cast<const PRec *>(rec) + ((uint64_t)blockIdx.x * nunit * 64) * 16);   // unit 0 of the workgroup's streams (rec8_index), 8 uint4 per unit and stream
+        const uint4 *pA = p0 + sA * 8 + hp, *pB = p0 + sB * 8 + hp;
         const uint64_t TA = __shfl(T, (int)sA, 64), TB = __shfl(T, (int)sB, 64);
         const uint64_t nfull = Tmin / 8;                         // sub-blocks that are whole in every lane: no padding test
         const uint64_t nsub = nblk * SUB;                        // sub-blocks to park (those past the last symbol as no-op records)
@@ -1441,7 +1432,7 @@ __global__ __launch_bounds__(REC8 ? (S == 32 ? 256 : 320) : 256) void k_code_rec
         auto load_stage = [&](uint4 *d) {
 #pragma unroll
             for (int k = 0; k < LD_B; ++k) {
-                const uint64_t at = (((uint64_t)(l_row >> 2) * (Cp >> 2) + 2 * l_m + (S == 32 ? 0 : half)) * 64 * 8) + (l_row & 3) * 2;   // in uint4: a unit is 8, the 64 streams' units lie side by side
+                const uint64_t at = (((uint64_t)(l_row >> 2) * (Cp >> 2) + 2 * l_m + half) * 64 * 8) + (l_row & 3) * 2;   // in uint4: a unit is 8, the 64 streams' units lie side by side
                 d[k * 2] = pA[at];
                 d[k * 2 + 1] = pB[at];
                 if (l_blk + 1 < nblk8) {
@@ -1451,22 +1442,21 @@ __global__ __launch_bounds__(REC8 ? (S == 32 ? 256 : 320) : 256) void k_code_rec
             }
         };
         auto park = [&](uint64_t sb, const uint4 *d) {           // this wave's half of sub-block sb -> slot (block & 1); the block's barrier behind its last sub-block
-            const uint32_t slot = (uint32_t)((sb / SUB) & 1), at = (uint32_t)(sb % SUB) * 8 + (S == 32 ? 0 : half * 4);
-            Record r4[4];                                        // records 2 hp, 2 hp + 1 of the piece of stream sA, then of stream sB (S = 32: of sA's next piece)
+            const uint32_t slot = (uint32_t)((sb / SUB) & 1), at = (uint32_t)(sb % SUB) * 8 + half * 4;
+            Record r4[4];                                        // records 2 hp, 2 hp + 1 of the piece of stream sA, then of stream sB
             unpack_records4<NEWTON>(d[0], d[1], r4);
             const uint32_t sym = at + 2 * hp, tw = hp << 3;      // (at is a multiple of 4: bit 1 of the symbol number is hp)
-            const uint32_t symB = S == 32 ? sym + 4 : sym;       // where the second piece's records go
             if (sb < nfull) {
                 ring[slot][sym][sA ^ tw] = r4[0];
                 ring[slot][sym + 1][sA ^ tw] = r4[1];
-                ring[slot][symB][sB ^ tw] = r4[2];
-                ring[slot][symB + 1][sB ^ tw] = r4[3];
+                ring[slot][sym][sB ^ tw] = r4[2];
+                ring[slot][sym + 1][sB ^ tw] = r4[3];
             } else {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const uint64_t t = sb * 8 + (S == 32 ? 0 : half * 4) + 2 * hp + i, tB = S == 32 ? t + 4 : t;   // beyond a stream's symbols: the no-op record
+                    const uint64_t t = sb * 8 + half * 4 + 2 * hp + i;   // beyond a stream's symbols: the no-op record
                     ring[slot][sym + i][sA ^ tw] = make_double2(t >= TA ? 0.0 : r4[i].x, t >= TA ? 0.0 : r4[i].y);
-                    ring[slot][symB + i][sB ^ tw] = make_double2(tB >= TB ? 0.0 : r4[2 + i].x, tB >= TB ? 0.0 : r4[2 + i].y);
+                    ring[slot][sym + i][sB ^ tw] = make_double2(t >= TB ? 0.0 : r4[2 + i].x, t >= TB ? 0.0 : r4[2 + i].y);
                 }
             }
             if (sb % SUB == SUB - 1) CR_BARRIER();
@@ -2244,10 +2234,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     // symbols per barrier of the coder workgroup: QVZ_CODER_BLOCK=8|16 (development knob; 16 needs packed records)
     const int cr_nb = rec8 && !(getenv("QVZ_CODER_BLOCK") && atoi(getenv("QVZ_CODER_BLOCK")) == 8) ? 16 : 8;
     const bool one_step = rec8 && qvz_coder_rcp_one_step_ok() == 1;   // (hardware reciprocal good enough for one Newton step: checked once per device)
-    // streams per coder workgroup: QVZ_CODER_STREAMS=32|64 (development knob; 32 needs packed records and 16-symbol blocks)
-    const bool cr_s32 = rec8 && cr_nb == 16 && (getenv("QVZ_CODER_STREAMS") ? atoi(getenv("QVZ_CODER_STREAMS")) == 32 : false);
-    const void *const cr_fn = cr_s32 ? (one_step ? reinterpret_cast<const void *>(&k_code_records<true, 16, 1, 32>) : reinterpret_cast<const void *>(&k_code_records<true, 16, 2, 32>))
-                              : !rec8 ? reinterpret_cast<const void *>(&k_code_records<false, 8, 2>)
+    const void *const cr_fn = !rec8 ? reinterpret_cast<const void *>(&k_code_records<false, 8, 2>)
                               : cr_nb == 16 ? (one_step ? reinterpret_cast<const void *>(&k_code_records<true, 16, 1>) : reinterpret_cast<const void *>(&k_code_records<true, 16, 2>))
                                             : (one_step ? reinterpret_cast<const void *>(&k_code_records<true, 8, 1>) : reinterpret_cast<const void *>(&k_code_records<true, 8, 2>));
     uint64_t seg_reads = 0, seg_lo = 0;
@@ -2666,9 +2653,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
 #define CR_ARGS (const Record *)buf, Cx, d_first, shards, seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio
-        if (cr_s32 && one_step) hipLaunchKernelGGL((k_code_records<true, 16, 1, 32>), dim3((shards + 31) / 32), dim3(256), cr_pad, s_coder, CR_ARGS);
-        else if (cr_s32) hipLaunchKernelGGL((k_code_records<true, 16, 2, 32>), dim3((shards + 31) / 32), dim3(256), cr_pad, s_coder, CR_ARGS);
-        else if (rec8 && cr_nb == 16 && one_step) hipLaunchKernelGGL((k_code_records<true, 16, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        if (rec8 && cr_nb == 16 && one_step) hipLaunchKernelGGL((k_code_records<true, 16, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
         else if (rec8 && cr_nb == 16) hipLaunchKernelGGL((k_code_records<true, 16, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
         else if (rec8 && one_step) hipLaunchKernelGGL((k_code_records<true, 8, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
         else if (rec8) hipLaunchKernelGGL((k_code_records<true, 8, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
