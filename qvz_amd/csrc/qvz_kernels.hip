@@ -979,18 +979,13 @@ __device__ __noinline__ void pmf_count_slow(uint32_t x, uint32_t p, uint32_t lra
 // they stay in registers over all columns beside prv / cur / nxt (six groups per thread as with one cluster), no label is
 // loaded twice, and a symbol's tile is one v_bfe + one v_mad away. A group that holds a label outside the pass's clusters
 // (never, for labels that come from the k-means kernels) takes the per-symbol path with its label bytes read again.
-// 3 (round 5) the label folded INTO the symbols: AA * label is added to every byte of a group as it arrives (one v_add per four
-// symbols; AA * kt <= 256), in `cur` and therefore in `prv` a column later, so that 4 x' + 4 AA p' + base - the one-cluster
-// address, two VALU instructions per symbol - lands in cluster l's tile when the tiles lie (AA + 1) AA dwords apart:
-// (p + AA l) AA + (x + AA l) = p AA + x + l (AA AA + AA). The range check is made on the raw bytes, when they arrive.
 template <int LMODE, int Q>
 __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                           uint64_t n, uint32_t C, uint64_t ld, uint32_t kb, uint32_t kt,
                                                           uint32_t R, uint32_t AA, uint32_t G, uint32_t *__restrict__ cnt) {
     extern __shared__ uint32_t tile[];   // [R][G][kt][AA][AA] (+1 dword skew per replica)
     const uint32_t T = PMF_WALK_T;
-    constexpr bool MERGED = LMODE == 3;
-    const uint32_t ts = MERGED ? AA * AA + AA : AA * AA, cs = kt * ts;   // one cluster's tile (MERGED: and the gap behind it), one column's tiles
+    const uint32_t ts = AA * AA, cs = kt * ts;                   // one cluster's tile, one column's tiles
     const uint32_t rs = G * cs + 1;                              // replica stride
     uint32_t *mine = tile + (threadIdx.x % R) * rs;
     const uint64_t slab0 = (uint64_t)blockIdx.x * T * 16 * Q;
@@ -1003,27 +998,16 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
     uint32_t full = 0, part = 0;
     constexpr bool HAVE_LABELS = LMODE != 0;
     constexpr bool PACKED = LMODE == 2;
-    uint4 prv[Q], cur[Q], lab[PACKED ? 1 : Q];                   // MERGED: lab[q] = AA * label in every byte
+    uint4 prv[Q], cur[Q], lab[PACKED ? 1 : Q];
     uint32_t lab2[PACKED ? Q : 1];                               // PACKED: 16 labels x 2 bits
-    uint32_t lbad = 0;                                           // PACKED / MERGED: bit q = group q holds a label outside [kb, kb + kt)
+    uint32_t lbad = 0;                                           // PACKED: bit q = group q holds a label outside [kb, kb + kt)
     uint32_t pbad[Q];                                            // range check of prv[q], made when it was cur[q]
-    uint32_t cbadq[MERGED ? Q : 1];                              // MERGED: range check of cur[q], made on its raw bytes when they arrived
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if (ROW(q) + 16 <= n) full |= 1u << q; else if (ROW(q) < n) part |= 1u << q;
         prv[q] = make_uint4(0, 0, 0, 0);                         // column 0 counts under prev = 0 (codebook.c:200)
         pbad[q] = 0;
-        if (MERGED) {
-            const uint4 lv = LIVE(q) ? *reinterpret_cast<const uint4 *>(labels + ROW(q)) : make_uint4(0, 0, 0, 0);
-            const uint32_t kk = 0x01010101u * (0x80u - kt);      // byte + (128 - kt) sets bit 7 iff byte >= kt (kb = 0 in this mode)
-            const uint32_t bad = (((lv.x + kk) | lv.x) | ((lv.y + kk) | lv.y) | ((lv.z + kk) | lv.z) | ((lv.w + kk) | lv.w)) & 0x80808080u;
-            lab[q] = make_uint4(lv.x * AA, lv.y * AA, lv.z * AA, lv.w * AA);   // (label < kt, AA * kt <= 256: no byte carries into the next)
-            if (bad) {                                           // cold: counted after the column walk, symbol by symbol
-                lbad |= 1u << q;
-                full &= ~(1u << q);
-                part &= ~(1u << q);
-            }
-        } else if (!PACKED) {
+        if (!PACKED) {
             lab[q] = make_uint4(0, 0, 0, 0);
             if (HAVE_LABELS && Q <= 2 && LIVE(q)) lab[q] = *reinterpret_cast<const uint4 *>(labels + ROW(q));
         } else {
@@ -1049,14 +1033,6 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
         cur[q] = LIVE(q) ? *reinterpret_cast<const uint4 *>(D + ROW(q)) : make_uint4(0, 0, 0, 0);
     }
     const uint32_t k80 = 0x01010101u * (0x80u - AA);             // byte + (128 - AA) sets bit 7 iff byte >= AA
-    if (MERGED) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {                            // column 0 as it arrived: checked raw, then the labels go in
-            cbadq[q] = (((cur[q].x + k80) | cur[q].x) | ((cur[q].y + k80) | cur[q].y) | ((cur[q].z + k80) | cur[q].z) | ((cur[q].w + k80) | cur[q].w)) & 0x80808080u;
-            cur[q] = make_uint4(cur[q].x + lab[q].x, cur[q].y + lab[q].y, cur[q].z + lab[q].z, cur[q].w + lab[q].w);
-            prv[q] = lab[q];                                     // column 0 counts under prev = 0 (codebook.c:200): p' = AA * label
-        }
-    }
     const uint32_t dump = (uint32_t)(uintptr_t)(pmf_lds_u32 *)tile + (uint32_t)(((mine - tile) + rs - 1) * 4);   // the replica's skew dword
     pmf_u16x2 coef;
     coef.x = 4;                                                  // byte address = 4*x + 4*AA*p + tile base
@@ -1074,7 +1050,7 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
             // With more than two groups per thread the labels do not stay in registers beside prv / cur / nxt (four groups
             // spilled: 16.6 ms instead of 7.1 at 100M x 150, k = 3): they are asked for again in every column - 1 byte per read
             // and column out of L2 / the Infinity Cache (the label vector is 100 MB) - and bigger slabs mean fewer flushes.
-            if (HAVE_LABELS && !PACKED && !MERGED && Q > 2) {
+            if (HAVE_LABELS && !PACKED && Q > 2) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q)
                     lab[q] = LIVE(q) ? *reinterpret_cast<const uint4 *>(labels + ROW(q)) : make_uint4(0, 0, 0, 0);
@@ -1093,9 +1069,8 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                 asm volatile("" : "+v"(l2));
                 // one range check per 16-byte group and column: bit 7 of a byte of cbad is set iff that symbol is outside
                 // the tile; the group's check as `prev` is the one it got as `cur` a column earlier
-                const uint32_t cbad = MERGED ? cbadq[q]
-                                             : (((cw[0] + k80) | cw[0]) | ((cw[1] + k80) | cw[1]) | ((cw[2] + k80) | cw[2]) |
-                                                ((cw[3] + k80) | cw[3])) & 0x80808080u;
+                const uint32_t cbad = (((cw[0] + k80) | cw[0]) | ((cw[1] + k80) | cw[1]) | ((cw[2] + k80) | cw[2]) |
+                                       ((cw[3] + k80) | cw[3])) & 0x80808080u;
                 const uint32_t gbad = cbad | pbad[q];
                 pbad[q] = cbad;
                 auto fast_word = [&](int w) {
@@ -1114,8 +1089,6 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                     for (int b = 0; b < 4; ++b) {
                         if (PACKED) {
                             addr[b] = __umul24(__builtin_amdgcn_ubfe(l2, 8 * w + 2 * b, 2), ts * 4) + addr[b];
-                        } else if (MERGED) {
-                            // (the label is in the bytes: the one-cluster address is cluster l's)
                         } else if (HAVE_LABELS) {
                             const uint32_t l = ((lw[w] >> (8 * b)) & 0xFF) - kb;
                             // a read of a cluster outside this pass's tiles (or of no cluster at all) counts into the
@@ -1130,16 +1103,6 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                 if (FULL(q) && gbad == 0) {                      // the usual case: sixteen pairs inside the tile
 #pragma unroll
                     for (int w = 0; w < 4; ++w) fast_word(w);
-                } else if (MERGED && LIVE(q)) {
-                    // a byte outside the tile somewhere in the group, or the matrix's last, partial group: symbol by symbol, with the
-                    // raw bytes asked for again (a byte >= AA plus AA * label may have carried into its neighbour)
-                    for (uint32_t r = 0; r < 16 && ROW(q) + r < n; ++r) {
-                        const uint32_t x = D[(uint64_t)s * ld + ROW(q) + r], p = s ? D[(uint64_t)(s - 1) * ld + ROW(q) + r] : 0u;
-                        const uint32_t l = labels[ROW(q) + r];
-                        if (x >= QVZ_A || p >= QVZ_A || l >= kt) continue;
-                        if (x < AA && p < AA) atomicAdd(&col_tile[l * ts + p * AA + x], 1u);
-                        else atomicAdd(&gcol[(uint64_t)l * C * PMF_TILE + p * QVZ_A + x], 1u);
-                    }
                 } else if (FULL(q)) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
@@ -1161,10 +1124,6 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
                                                     kb, kt, AA, col_tile, gcol, C);
                 }
                 prv[q] = cur[q];
-                if (MERGED) {                                    // the next column as it arrived: checked raw, then the labels go in
-                    cbadq[q] = (((nxt[q].x + k80) | nxt[q].x) | ((nxt[q].y + k80) | nxt[q].y) | ((nxt[q].z + k80) | nxt[q].z) | ((nxt[q].w + k80) | nxt[q].w)) & 0x80808080u;
-                    cur[q] = make_uint4(nxt[q].x + lab[q].x, nxt[q].y + lab[q].y, nxt[q].z + lab[q].z, nxt[q].w + lab[q].w);
-                } else
                 cur[q] = nxt[q];
             }
         }
@@ -1175,8 +1134,8 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
         for (uint32_t i = 2 * threadIdx.x; i < (g1 - g0) * cs; i += 2 * T) {
             uint32_t v0 = 0, v1 = 0;
             for (uint32_t r = 0; r < R; ++r) { v0 += tile[r * rs + i]; v1 += tile[r * rs + i + 1]; }
-            if (v0 | v1) {                                       // (MERGED: the gap behind a cluster's tile is never counted into)
-                const uint32_t s = g0 + i / cs, l = (i % cs) / ts, e = (i % cs) % ts;   // AA is even: e and e + 1 share a row
+            if (v0 | v1) {
+                const uint32_t s = g0 + i / cs, l = (i % cs) / ts, e = i % ts;          // AA is even: e and e + 1 share a row
                 atomicAdd(reinterpret_cast<unsigned long long *>(
                               &cnt[(((uint64_t)(kb + l) * C + s) * QVZ_A + e / AA) * QVZ_A + e % AA]),
                           (unsigned long long)v0 | ((unsigned long long)v1 << 32));
@@ -1184,7 +1143,7 @@ __global__ __launch_bounds__(PMF_WALK_T) void k_pmf_walk(const uint8_t *__restri
         }
         __syncthreads();
     }
-    if ((PACKED || MERGED) && lbad) {
+    if (PACKED && lbad) {
         // Groups that hold a label outside this pass's clusters (a caller's own label vector; the k-means kernels never write
         // one): counted here, symbol by symbol, straight into the global counters.
         for (int q = 0; q < Q; ++q) {
@@ -1306,12 +1265,7 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
         // column-walking kernel: slabs of 16384*Q rows, G column tiles x R replicas of the counters in LDS
         for (uint32_t kb = 0; kb < k; kb += PMF_KT) {
             const uint32_t kt = (k - kb) < PMF_KT ? (k - kb) : PMF_KT;
-            // labels of 2 .. 4 clusters: folded into the symbol bytes (k_pmf_walk<3>: the one-cluster address arithmetic) when AA * k fits a
-            // byte, else packed to 2 bits; QVZ_PMF_LABELS=packed | bytes (development knob) asks for the older forms
-            const char *lab_env = getenv("QVZ_PMF_LABELS");
-            const bool packed_ok = k > 1 && k <= 4 && !(lab_env && strcmp(lab_env, "bytes") == 0);
-            const bool merged = packed_ok && AA * k <= 256 && !(lab_env && strcmp(lab_env, "packed") == 0);
-            const size_t tile_bytes = (size_t)kt * (merged ? AA * AA + AA : AA * AA) * sizeof(uint32_t);
+            const size_t tile_bytes = (size_t)kt * AA * AA * sizeof(uint32_t);
             // The kernel's ~96 VGPRs leave room for one 1024-thread block per CU, so a block may use the whole LDS.
             // Measured (tools/tune_pmf2.py, 100M x 150, 42 symbols): G = 3 column tiles x R = 5 replicas is the best
             // (4.30 ms; R = 5, G = 2: 4.43; R = 3, G = 3: 4.59; more than 5 replicas buy nothing).
@@ -1332,8 +1286,7 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
             // with labels (k > 1) kept in registers two groups are the limit: four spill (100M x 150, k = 3: 16.9 ms against 7.2)
             // (k > 1, labels re-read per column: four groups 6.4 ms, two 7.1, six 9.0 at 100M x 150, k = 3)
             // (k = 2 .. 4 with the labels packed to 2 bits in registers - QVZ_PMF_LABELS=bytes keeps the byte path -: six groups again)
-            const bool packed = packed_ok && !merged;
-            // (merged labels: AA * label of every read stays in registers, four dwords per group - four groups are what 128 VGPRs hold)
+            const bool packed = k > 1 && k <= 4 && !(getenv("QVZ_PMF_LABELS") && strcmp(getenv("QVZ_PMF_LABELS"), "bytes") == 0);
             if (Q == 0) Q = ((k == 1 || packed) && n >= 768ull * 98304) ? 6 : (n >= 768ull * 65536) ? 4 : (n >= 768ull * 32768 ? 2 : 1);
             if (Q != 1 && Q != 2 && Q != 4 && Q != 6) Q = 4;
             const uint64_t slab = (uint64_t)PMF_WALK_T * 16 * Q;
@@ -1348,8 +1301,6 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
     } while (0)
             if (k == 1) {
                 if (Q == 6) LAUNCH_WALK(0, 6); else if (Q >= 4) LAUNCH_WALK(0, 4); else if (Q == 2) LAUNCH_WALK(0, 2); else LAUNCH_WALK(0, 1);
-            } else if (merged) {
-                if (Q >= 4) LAUNCH_WALK(3, 4); else if (Q == 2) LAUNCH_WALK(3, 2); else LAUNCH_WALK(3, 1);
             } else if (packed) {
                 if (Q == 6) LAUNCH_WALK(2, 6); else if (Q >= 4) LAUNCH_WALK(2, 4); else if (Q == 2) LAUNCH_WALK(2, 2); else LAUNCH_WALK(2, 1);
             } else {
