@@ -53,13 +53,12 @@ ALG_BYTES_PER_SYMBOL = {
     "kmeans_step": 1.0,          # one pass per iteration: each symbol read once (+1 B/read of labels written)
     "quantize": 5.0,             # symbol in, draw in, (qv, qi, st) out: the -u product and the coder's two planes
     "well_draws": 3.0,           # word stream written once and read once, draw matrix written once
-    "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out (host / gpu-feed coders only)
-    "model_records": 10.0,       # qi + st in, one packed 8-byte record out (18 with QVZ_CODER_RECORDS=16: the pairs of doubles of rounds 1-3)
+    "pack_feed": 4.0,            # qi + st in, 2-byte feed entry out (host coder only)
+    "model_records": 10.0,       # qi + st in, one packed 8-byte record out
     "code_records": 8.0,         # record in (+ ~0.17 B/symbol of stream out); bound by the serial interval chain per stream
-    "arith_shards": 2.0,         # gpu-feed coder: 2-byte feed entry in; latency-bound
 }
 # kernels whose time is a dependent-instruction chain per stream, not a bandwidth figure
-CHAIN_KERNELS = ("code_records", "arith_shards")
+CHAIN_KERNELS = ("code_records",)
 
 
 def measured_traffic(kernel, args, cfg, shards, world):
@@ -459,7 +458,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (testing)")
     ap.add_argument("--shards", type=int, default=0, help="arithmetic-coded streams per GPU (default: host threads)")
     ap.add_argument("--threads", type=int, default=0, help="host coder threads per rank (default: cores / ranks)")
-    ap.add_argument("--coder", choices=["host", "gpu", "gpu-feed"], default="gpu",
+    ap.add_argument("--coder", choices=["host", "gpu"], default="gpu",
                     help="arithmetic coder: host threads, or one GPU lane per shard (byte-identical streams)")
     ap.add_argument("--driver", choices=["c", "python"], default="c",
                     help="who runs the stages of the timed step: the C driver (qvz_resident_encode; GPU coder only) or qvz_amd/pipeline.py")
@@ -623,8 +622,6 @@ def main():
         bps = ALG_BYTES_PER_SYMBOL[dom]
         if dom == "quantize" and (args.no_u or args.coder == "host"):
             bps = 4.0
-        if dom == "model_records" and os.environ.get("QVZ_CODER_RECORDS") == "16":
-            bps = 18.0
         extra = 0.0
         if k > 1 and dom == "pmf_hist":
             extra = float(n)

@@ -67,33 +67,29 @@ int qvz_encode_shards_device(const uint16_t *d_feed, const uint8_t *d_labels, ui
                              uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                              uint32_t threads, int device, uint8_t **streams, uint64_t *sizes);
 
-/* The same sharded coding on the GPU ("wavefront-serial" coder): one lane per shard runs the identical integer
- * interval arithmetic and adaptive model, so stream g is byte-identical to what qvz_encode_shards_device (and the
- * reference, for a file holding only that shard's reads) produces. d_out: shards * cap_per_shard bytes in HBM,
- * stream g at d_out + g*cap_per_shard; h_sizes[g] receives its length. Fails with QVZ_E_NOMEM if a stream outgrows
- * cap_per_shard (worst case 22 bits/symbol; 1 byte/symbol is ample for real data) and with QVZ_E_DEAD_CTX if the feed
- * reaches a dead context (per-shard models hold live contexts only, qvz_codebook_t.live). */
-int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint64_t n, uint32_t columns,
-                          uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, uint8_t *d_out,
-                          uint64_t cap_per_shard, uint64_t *h_sizes, void *stream);
-
-/* The GPU sharded coder fed straight from the quantizer's output planes (d_qi[s*ld+i], d_st[s*ld+i], as written by
- * qvz_hip_quantize; no packed feed). Same streams, byte for byte, as qvz_hip_encode_shards / qvz_encode_shards_device.
+/* The sharded coding on the GPU, fed straight from the quantizer's output planes (d_qi[s*ld+i], d_st[s*ld+i], as written by
+ * qvz_hip_quantize): stream g is byte-identical to what qvz_encode_shards_device - and the reference, for a file holding only
+ * that shard's reads (src/qv_compressor.c:76-135, src/arith.c:24-116, src/qv_stream.c:9-25) - produces. d_out: shards *
+ * cap_per_shard bytes in HBM, stream g at d_out + g * cap_per_shard; h_sizes[g] receives its length. QVZ_E_NOMEM if a stream
+ * outgrows cap_per_shard (worst case 22 bits per symbol), QVZ_E_DEAD_CTX if a symbol reaches a dead context (the models hold
+ * live contexts only, qvz_codebook_t.live).
  *
  * The adaptive model of a column depends on that column's symbols only (update_stats touches one table and a table
  * belongs to one column, qv_stream.c:9-25), so the model does not have to run inside the serial chain:
  *   model  one wave per (stream, column), one lane per read: the counts a symbol sees are the table's counts plus
  *          8 x (earlier reads of the chunk with the same table / the same state / a smaller state), taken from lane
  *          bit-masks in LDS; chunks in which a table passes the rescale threshold (n > 2^19) are replayed serially.
- *          It leaves a 16-byte record per symbol: cum_lo / n and (n - cum_hi) / n as doubles (pre-scaled by 2^-10).
- *   coder  one lane per stream walks its records: two fused multiply-adds give the new bounds exactly
- *          (arith.c:47-48), then E1/E2/E3 renormalisation (arith.c:50-97) and the bit output, split over four
- *          waves (record loader / interval chain / pending-bit count / byte stream) that hand blocks over through LDS.
+ *          It leaves an 8-byte record per symbol: the integers n, cum_lo and n - cum_hi (21 bits each).
+ *   coder  one lane per stream walks its records: two loader waves turn a record into the two quotients (reciprocal + one
+ *          Newton step), two fused multiply-adds give the new bounds exactly (arith.c:47-48), then E1/E2/E3 renormalisation
+ *          (arith.c:50-97) and the bit output, split over three more waves (interval chain / pending-bit count / byte stream)
+ *          that hand blocks of 16 symbols over through LDS.
  * Records pass through d_work (work_bytes, 16-byte aligned) in segments of as many reads per stream as fit:
- * 16 bytes x (shards rounded up to 64) x (columns, + 8 reserved positions when clusters > 1, rounded up to 8) per read;
+ * 8 bytes x (shards rounded up to 64) x (columns, + 8 reserved positions when clusters > 1, rounded up to 8) per read;
  * d_work = NULL: a workspace of 4/5 of the free device memory, at most 96 GiB and what the whole input needs, is
- * allocated for the call. With room for two segments the model kernel of one runs beside the coder kernel of the other. Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel
- * with one lane per (stream, column) and the tables in HBM.
+ * allocated for the call. With room for two segments the model kernel of one runs beside the coder kernel of the other.
+ * Codebooks whose largest column needs more table space than LDS offers fall back to a model kernel with one lane per
+ * (stream, column) and the tables in HBM.
  * d_labels must be readable up to n rounded up to a multiple of 4. The emitter checks its room once per 16 symbols:
  * a stream that comes within 256 bytes of cap_per_shard is reported as overflowed (QVZ_E_NOMEM). */
 int qvz_hip_encode_planes(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
@@ -126,22 +122,6 @@ int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint6
                                  uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                  const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes, void *d_work,
                                  uint64_t work_bytes, void *stream);
-/* Quantizer and coder as one pipeline (round 4): qvz_hip_quantize (include/qvz_hip.h; same arguments, same planes, same per-read
- * errors, same status word) launched segment by segment - for the reads of every stream that the coder's next model kernel needs -
- * on a stream of its own, beside the model kernel of the segment before and the coder kernel of the one before that; then exactly
- * what qvz_hip_encode_planes_bounds does with the planes d_qi / d_st (leading dimension ld_out). The reference's loop does both per
- * line as well (src/qv_compressor.c:76-135: quantize a symbol, code it). d_qi and d_st are required; d_qv (the -u product) and d_err
- * may be NULL. *d_status is NOT cleared here (as in qvz_hip_quantize): bit 0 = a context the codebook does not define, in which case
- * the call returns QVZ_E_DEAD_CTX. Everything has completed when the call returns. */
-int qvz_hip_quantize_encode_planes(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t columns, uint64_t ld,
-                                   uint32_t clusters, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
-                                   uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
-                                   uint64_t ld_out, double *d_err, int32_t *d_status, const qvz_codebook_t *const *cbs,
-                                   uint32_t shards, const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard,
-                                   uint64_t *h_sizes, void *d_work, uint64_t work_bytes, void *stream);
-/* Busy time of the quantizer launches of the calling thread's last qvz_hip_quantize_encode_planes call (ms; they run beside the
- * model and coder kernels, whose times qvz_hip_encode_planes_last_ms reports). */
-double qvz_hip_encode_planes_last_quant_ms(void);
 /* Decoder of sharded streams on the GPU, one lane per stream: the reference's
  * start_qv_decompression (src/qv_compressor.c:145-231) with arithmetic_decoder_step / decoder_last_step
  * (src/arith.c:118-205) and update_stats (src/qv_stream.c:9-25), per shard. d_in holds stream g at
@@ -180,7 +160,7 @@ void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms);
 int qvz_hip_encode_planes_warmup(void);
 /* The loaders of the coder kernel turn a packed record's integers into quotients with v_rcp_f64 and ONE Newton step when that is
  * within 2^-47 of 1 / (n 2^10) for every n a record can hold (n = 1 .. 2^19 + 1024) on the current device - measured once per process
- * and device over all of them -, with two steps otherwise (and with QVZ_CODER_NEWTON=2). Returns 1 for one step; *worst (may be
+ * and device over all of them -, with two steps otherwise (and with the test hook QVZ_CODER=newton=2). Returns 1 for one step; *worst (may be
  * NULL) receives the worst relative error measured for one step. */
 int qvz_coder_rcp_one_step_ok_ex(double *worst);
 int qvz_coder_rcp_one_step_ok(void);

@@ -91,9 +91,6 @@ SIGNATURES = {
     "qvz_encode_shards_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
-    "qvz_hip_encode_shards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
-                                        C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64,
-                                        C.POINTER(C.c_uint64), C.c_void_p]),
     "qvz_hip_encode_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.c_void_p]),
@@ -106,11 +103,6 @@ SIGNATURES = {
     "qvz_hip_decode_shards_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
                                                C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
-    "qvz_hip_quantize_encode_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
-                                                 C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
-                                                 C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
-                                                 C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64, C.c_void_p]),
-    "qvz_hip_encode_planes_last_quant_ms": (C.c_double, []),
     "qvz_hip_encode_planes_prepare": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64]),
     "qvz_hip_encode_planes_work_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "qvz_coder_segment_list": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),

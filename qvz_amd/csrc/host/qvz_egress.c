@@ -131,8 +131,11 @@ static void *prealloc_main(void *arg) {
 }
 
 int qvz_prealloc_start(FILE *f, uint64_t bytes) {
-    const uint64_t least = getenv("QVZ_PREALLOC_MIN") ? strtoull(getenv("QVZ_PREALLOC_MIN"), NULL, 10) : 256ull << 20;   /* (the variable: tests) */
-    if (!f || bytes < least || (getenv("QVZ_PREALLOC") && atoi(getenv("QVZ_PREALLOC")) == 0)) return 0;
+    /* QVZ_PREALLOC: "0" turns the page helper off; test hooks: "min=<bytes>" smallest output it is started for (default 256 MiB),
+     * "fail" the failure path behind the ftruncate (comma-separated) */
+    const char *pe = getenv("QVZ_PREALLOC"), *pm = pe ? strstr(pe, "min=") : NULL;
+    const uint64_t least = pm ? strtoull(pm + 4, NULL, 10) : 256ull << 20;
+    if (!f || bytes < least || (pe && strcmp(pe, "0") == 0)) return 0;
     fflush(f);
     const int64_t base = (int64_t)ftello(f);
     const int fd = fileno(f);
@@ -159,7 +162,7 @@ int qvz_prealloc_start(FILE *f, uint64_t bytes) {
     if (p->map != MAP_FAILED) {
         pthread_mutex_lock(&g_pre_mu);
         for (int i = 0; i < 8 && slot < 0; ++i) if (!g_pre[i]) slot = i;
-        if (getenv("QVZ_PREALLOC_FAIL")) slot = -1;                            /* tests: the failure path behind the ftruncate */
+        if (pe && strstr(pe, "fail")) slot = -1;                               /* tests: the failure path behind the ftruncate */
         if (slot >= 0 && pthread_create(&p->th, NULL, prealloc_main, p) == 0) g_pre[slot] = p; else slot = -1;
         pthread_mutex_unlock(&g_pre_mu);
     }

@@ -752,10 +752,7 @@ int qvz_job_start_workspace(qvz_job_t *job, uint32_t shards) {
     pthread_t th;
     if (job->d_work || job->work_running || !shards) return 0;
     job->work_shards = shards;
-    const char *how = getenv("QVZ_WORK_EARLY");                                /* development knob: thread (default) | sync | off */
-    if (how && strcmp(how, "off") == 0) return 0;
     job->draws_early_state = 1;                                                 /* 1: being allocated, 2: decided (d_draws_early or NULL) */
-    if (how && strcmp(how, "sync") == 0) { workspace_main(job); return 0; }
     if (pthread_create(&th, NULL, workspace_main, job) == 0) { job->work_thread = (unsigned long)th; job->work_running = 1; }
     else job->draws_early_state = 0;
     return 0;
@@ -860,8 +857,7 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     if (!shards || (!job->shard_bounds && shards > qvz_shard_limit(N))) return qvz_job_fail(QVZ_E_ARG, "%u shards for %llu reads: a shard needs at least 4 reads", shards, (unsigned long long)N);
 
     if ((rc = qvz_job_start_draws(job))) goto done;                            /* already running when the caller started them */
-    if (!(getenv("QVZ_CODER_PREPARE") && atoi(getenv("QVZ_CODER_PREPARE")) == 0))   /* development knob: 0 = the coder call sets itself up */
-        prep_running = pthread_create(&th_prep, NULL, prepare_main, &task_prep) == 0;
+    prep_running = pthread_create(&th_prep, NULL, prepare_main, &task_prep) == 0;
     {
         const size_t ctn = (size_t)K * C * QVZ_CT_STRIDE, qsn = (size_t)K * C * QVZ_QS_STRIDE;
         h_ct = (uint16_t *)malloc(ctn * sizeof(uint16_t));
@@ -914,12 +910,9 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     t1 = now();
     job->t_quantize = t1 - t0;
 
-    /* beside the coder kernels: the per-read errors (0.8 GB over PCIe, then the file-order sum on one host core). The -u text
-     * starts when the coder has finished and runs beside the way out of the streams; QVZ_EGRESS_OVERLAP=1 starts it beside the
-     * coder kernels instead. Measured on a settled GPU the two schedules do not differ beyond the noise of the file writes
-     * (coder phase 0.16-0.17 s either way, the whole encode 3.4-4.8 s: profiles/r03_e2e_cli.txt); the 1-3 s coder phases first
-     * blamed on the overlap were the allocation stall of a process that starts right after another has freed its HBM. */
-    const int overlap_text = getenv("QVZ_EGRESS_OVERLAP") && atoi(getenv("QVZ_EGRESS_OVERLAP"));
+    /* beside the coder kernels: the per-read errors (0.8 GB over PCIe, then the file-order sum on one host core). The -u text starts
+     * when the coder has finished and runs beside the way out of the streams (started beside the coder kernels instead it made no
+     * difference beyond the noise of the file writes: profiles/r03_e2e_cli.txt). */
     task_err.device = task_text.device = job->opts.device;
     task_err.d_err = d_err; task_err.N = N; task_err.C = C;
     if (job->collect) {
@@ -931,7 +924,6 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
     else err_running = pthread_create(&th_err, NULL, side_errors, &task_err) == 0;
     if (fu) {
         task_text.fu = fu; task_text.d_qv = d_qv; task_text.N = N; task_text.C = C; task_text.ld = ld;
-        if (overlap_text) text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
     }
     {   /* coding. Room per stream: 6 bits per symbol to begin with (real data needs 1-2); a stream that outgrows it
          * (-r above 6, near-uniform input) makes the coder report QVZ_E_NOMEM and the call is repeated with twice the room,
@@ -948,12 +940,12 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
             const double tc = now();
             const int mine = job->d_work && job->work_shards == shards;        /* allocated ahead of time for this very cut */
             /* The streams' area (11 GB at 100M x 150) comes out of the END of the record workspace when that leaves the coder room
-             * for two full segments (packed records need a third of the 96 GiB): one large hipMalloc less in front of the coder
+             * for two full segments (a third of the 96 GiB): one large hipMalloc less in front of the coder
              * kernels - the place where a process that starts soon after another has freed its HBM was seen to stall for a
              * second. Otherwise, and when a stream has outgrown its allotment, an allocation of its own. */
             uint64_t work_use = mine ? job->work_bytes : 0;
             const uint64_t area = (((uint64_t)shards * cap) + 4095) & ~4095ull;
-            const uint64_t two_segments = 2 * qvz_hip_encode_planes_work_bytes((per + (K > 1 ? 2 : 7)) / (K > 1 ? 3 : 8) + 64, C, K, shards) / 2;   /* (the helper prices 16-byte records: half) */
+            const uint64_t two_segments = 2 * qvz_hip_encode_planes_work_bytes((per + (K > 1 ? 2 : 7)) / (K > 1 ? 3 : 8) + 64, C, K, shards);
             job_free(job, d_out_own); d_out_own = NULL;
             if (mine && bits == 6 && work_use > area && work_use - area >= two_segments) {
                 work_use = (work_use - area) & ~255ull;

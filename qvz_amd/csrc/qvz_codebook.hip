@@ -126,20 +126,8 @@ struct LmIn {
 // The two 72-term sums (p_temp, and the xpmf rows) gather three operands per term from L1/L2; in one workgroup - one
 // CU - they were bound by that CU's load path (64 us and 30 us of the 96 us per column). They are spread over the
 // chip: a thread per output element as before, the same terms in the same order.
-__global__ __launch_bounds__(256) void k_ctx_ptemp(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
-                                                   uint32_t nprev, const double *__restrict__ prev_qpmf,   // [72][72]
-                                                   double *__restrict__ ptemp) {                           // [72][72]: (k, j)
-    // hoisted p_temp(k,j) = sum_x prev_qpmf[x][j] * P_{s-1}(k|x) * marg_{s-2}[x]   (codebook.c:318-321)
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= A * nprev) return;
-    const double *Pc = P + (uint64_t)(s - 1) * A * A;
-    const double *mm = marg + (uint64_t)(s - 2) * A;
-    const uint32_t k = e / nprev, j = e % nprev;
-    double pt = 0;
-#pragma unroll 8
-    for (int x = 0; x < A; ++x) pt += prev_qpmf[x * A + j] * Pc[x * A + k] * mm[x];   // loads run ahead, the sum stays in order
-    ptemp[k * A + j] = pt;
-}
+// (p_temp(k, j) = sum_x prev_qpmf[x][j] * P_{s-1}(k|x) * marg_{s-2}[x], codebook.c:318-321, of column s + 1 is computed by extra
+// rows of column s's design window launch - k_lm_window's rider -, which needs column s's qpmf only.)
 
 // qpmf rows: one workgroup per symbol k (rows are renormalised on their own), a thread per context idx
 __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t nprev, uint32_t nu,
@@ -637,8 +625,7 @@ struct LmRider {           // k_ctx_ptemp of the next column riding on a window 
 template <bool TOEP, bool MONO>
 __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm, const double *__restrict__ distT,
                                                   const LmIn *__restrict__ in, LmDesign *__restrict__ out,
-                                                  uint32_t *__restrict__ stop, double guard, int exact,
-                                                  const uint32_t *__restrict__ limits, LmRider rider) {
+                                                  uint32_t *__restrict__ stop, double guard, int exact, LmRider rider) {
     CB_PRIO();
     // Rows of the grid beyond the window (blockIdx.y >= rider.rows) carry k_ctx_ptemp of the NEXT column: it needs this
     // column's qpmf only, and as blocks of this launch it runs on CUs the designs leave idle instead of being one more
@@ -655,9 +642,6 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
         rider.ptemp[k * A + j] = pt;
         return;
     }
-    // limits (device-driven flow, k_cb_decide): {contexts of this column, window width, run this round at all}. The grid is
-    // the largest a column can need (72 x 72); what lies outside the column's own numbers returns at once.
-    if (limits && (blockIdx.x >= limits[0] || blockIdx.y >= limits[1] || !limits[2])) return;
     extern __shared__ double sm[];
     double *dl = sm;
     double *p = sm + (TOEP ? A : A * A);
@@ -705,218 +689,6 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     }
 }
 
-// ---- the whole generation driven from the device -------------------------------------------------------------------------
-// With exact entropies on the device nothing in a column needs the host: what the host loop below ("host driver") does
-// between two columns - replay the walk over the window's designs (codebook.c:249-258), pick the pair, the ratio (:263-268),
-// store the quantizers, merge the next column's context symbols (:419-438) - is one small kernel, k_cb_decide, and the 150
-// columns are enqueued in one go: propagate -> xpmf -> design window -> decide, grids sized for the largest column, the
-// column's own numbers (contexts, window width) read from device memory. A walk that runs off its window (the window
-// follows the previous column's largest state count + 3) gets a second, full-width round that is enqueued for every
-// column and returns at once when nobody asked for it. The codebook is assembled on the host from the device arrays
-// at the end. An experiment kept behind QVZ_CB_FLOW=device (same bytes, slower: see generate()).
-struct CbCtl {
-    uint32_t lim1[4];      // {contexts of the current column, width of its first window, 1, blocks of k_cb_decide that have arrived}   (k_lm_window limits, round 1)
-    uint32_t lim2[4];      // {contexts, 72, redo, contexts whose walk ran off the first window}                                          (round 2)
-    uint32_t smax;         // largest state count chosen in this column so far
-    uint32_t err;          // nonzero: (column + 1) | reason << 16 - the host falls back to its own loop
-};
-
-struct CbDevBook {         // the codebook as the device builds it (flat device arrays, copied out at the end)
-    uint8_t *nctx;         // [C + 1]
-    uint8_t *ctxsym;       // [C + 1][72]
-    uint8_t *q;            // [C][144][72]
-    uint8_t *recon;        // [C][144][72]
-    uint8_t *nstates;      // [C][144]
-    double *ratio;         // [C][72]
-    uint8_t *live;         // [C][72]
-};
-
-// column 0 (codebook.c:392-411): one context, the symbol 0; its row is P(X_0); the plan of its window
-__global__ __launch_bounds__(128) void k_cb_col0(const double *__restrict__ P0, LmIn *__restrict__ lin, CbCtl *__restrict__ ctl,
-                                                 CbDevBook book, uint32_t *__restrict__ stop, int ratio_mode, double opt_ratio,
-                                                 uint32_t force_win) {
-    __shared__ double ent[A];
-    const uint32_t k = threadIdx.x;
-    if (k < A) { const double v = P0[k]; ent[k] = v > 0.0 ? v * qvz_log2_glibc(v) : 0.0; stop[k] = 0xFFFFFFFFu; }
-    __syncthreads();
-    if (k == 0) {
-        bool zero = true, degenerate = true;
-        double h = 0.0;
-        for (int i = 0; i < A; ++i) {
-            const double x = P0[i];
-            if (x != 0.0) zero = false;
-            if (x != 0.0 && x != 1.0) degenerate = false;
-            h -= ent[i];
-        }
-        const bool target0 = ratio_mode ? (degenerate || opt_ratio == 0.0) : opt_ratio == 0.0;
-        LmIn I;
-        I.target = target0 ? 0.0 : ratio_mode ? h * opt_ratio : opt_ratio;
-        I.mode = zero ? 0 : target0 ? 2 : 1;
-        I.startS = 1;
-        for (int i = 0; i < 6; ++i) I.pad[i] = 0;
-        lin[0] = I;
-        book.nctx[0] = 1;
-        book.ctxsym[0] = 0;
-        ctl->lim1[0] = 1; ctl->lim1[1] = force_win ? force_win : 16; ctl->lim1[2] = 1; ctl->lim1[3] = 0;
-        ctl->lim2[0] = 1; ctl->lim2[1] = A; ctl->lim2[2] = 0; ctl->lim2[3] = 0;
-        ctl->smax = 1; ctl->err = 0;
-    }
-}
-
-// the device-driven variants of the three context kernels: the same bodies, the column's numbers from device memory
-__global__ __launch_bounds__(256) void k_ctx_ptemp_dev(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
-                                                       const uint8_t *__restrict__ nctx, const double *__restrict__ prev_qpmf,
-                                                       double *__restrict__ ptemp) {
-    const uint32_t nprev = nctx[s - 1];
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= A * nprev) return;
-    const double *Pc = P + (uint64_t)(s - 1) * A * A;
-    const double *mm = marg + (uint64_t)(s - 2) * A;
-    const uint32_t k = e / nprev, j = e % nprev;
-    double pt = 0;
-#pragma unroll 8
-    for (int x = 0; x < A; ++x) pt += prev_qpmf[x * A + j] * Pc[x * A + k] * mm[x];
-    ptemp[k * A + j] = pt;
-}
-
-// round: 1 = after the column's first window, 2 = after the full-width one (only if round 1 asked for it).
-// One WAVE per context (block j = context j, lane = design of the window): the walk over the window is two ballots, the
-// chosen pair's tables are copied by the lanes; the last block to arrive (a ticket in the control block) finishes the
-// column: the next column's context symbols, its window width. (One block with a thread per context took 90 us per
-// column - dependent global loads one after the other - against 93 us for the design window itself.)
-__global__ __launch_bounds__(64) void k_cb_decide(uint32_t s, uint32_t C, int round, LmIn *__restrict__ lin, const LmDesign *__restrict__ out,
-                                                  const LmDesign *__restrict__ zero, CbCtl *__restrict__ ctl, CbDevBook book,
-                                                  uint32_t *__restrict__ stop, uint32_t force_win) {
-    __shared__ uint32_t present[A];
-    __shared__ uint32_t s_last;
-    const uint32_t j = blockIdx.x, lane = threadIdx.x;
-    const uint32_t nu = ctl->lim1[0];
-    if (j >= nu) return;
-    if (round == 2 && !ctl->lim2[2]) return;                     // nobody asked for a second round
-    const uint32_t win = round == 1 ? ctl->lim1[1] : (uint32_t)A;
-    const LmIn I = lin[j];
-    const LmDesign *d = out + (size_t)j * A;                     // grid.y of the window launches is 72
-    const LmDesign *lo = nullptr, *hi = nullptr;
-    uint32_t loS = 0, hiS = 0, err = 0;
-    double ratio = 0.0;
-    bool settle = false, live = true, unfinished = false;
-    if (round == 1 && I.mode == 0) {                             // all-zero pmf: every design has entropy 0 (the host loop's replay)
-        live = false;
-        if (I.target == 0.0) { lo = hi = zero + 0; loS = hiS = 1; ratio = 1.0; }
-        else {
-            uint32_t states = 1;
-            do { states += 1; } while (0.0 < I.target && states < A);
-            lo = zero + (states - 2); loS = states - 1;          // zero[S - 1] is the design with S states
-            hi = zero + (states - 1); hiS = states;
-            ratio = 0.0 < I.target ? 0.0 : 1.0;
-        }
-        settle = true;
-    } else if (round == 1 && I.mode == 2) {                      // target 0: one state, lo == hi
-        if (!d[0].valid) err |= 1u;
-        lo = hi = d; loS = hiS = d[0].S; ratio = 1.0;
-        settle = true;
-    } else if (I.mode == 1) {
-        // the walk (codebook.c:249-258) over designs d[0] (S = 1) .. d[win - 1]: lane w looks at design w (and w + 64)
-        uint64_t ends[2] = {0, 0}, invalid[2] = {0, 0};          // bit w (w - 64): the walk ends at design w / design w is missing
-        for (uint32_t half = 0; half < 2; ++half) {
-            const uint32_t w = lane + 64 * half;
-            const bool in = w < win && w < A;
-            bool e_ = false, v_ = true;
-            if (in) {
-                v_ = d[w].valid != 0;
-                e_ = w >= 1 && v_ && (!(d[w].hdev < I.target) || d[w].S >= A);
-            }
-            ends[half] = __ballot(e_);
-            invalid[half] = __ballot(in && !v_);
-            if (win <= 64) break;
-        }
-        if (ends[0]) {
-            const uint32_t w = (uint32_t)__builtin_ctzll(ends[0]);
-            if (invalid[0] & ((2ull << w) - 1)) err |= 2u;       // a design the walk passes is missing
-            lo = d + (w - 1); hi = d + w;
-        } else if (ends[1]) {
-            const uint32_t w = (uint32_t)__builtin_ctzll(ends[1]);
-            if (invalid[0] || (invalid[1] & ((2ull << w) - 1))) err |= 2u;
-            lo = d + (64 + w - 1); hi = d + (64 + w);
-        }
-        if (hi) {
-            loS = lo->S; hiS = hi->S;
-            const double lo_e = lo->hdev, hi_e = hi->hdev;       // optimize_for_entropy, codebook.c:263-268
-            if (I.target == 0.0) ratio = 1.0;
-            else if (hi_e < I.target) ratio = 0.0;
-            else if (lo_e >= I.target || hi_e == lo_e) ratio = 1.0;
-            else ratio = (I.target - hi_e) / (lo_e - hi_e);
-            settle = true;
-            if (lane == 0) atomicMax(&ctl->smax, hiS);
-        } else if (round == 1) {
-            unfinished = true;                                   // ran off the window: the full-width round
-            if (invalid[0] | invalid[1]) err |= 2u;
-            if (lane == 0) stop[j] = 0xFFFFFFFFu;
-        } else {
-            err |= 4u;                                           // cannot be: S = 72 always ends the walk
-        }
-    }
-    if (settle) {
-        const size_t t0 = ((size_t)s * 2 * A + 2 * j) * A;
-        for (uint32_t e = lane; e < A; e += 64) {
-            book.q[t0 + e] = lo->q[e];
-            book.q[t0 + A + e] = hi->q[e];
-            book.recon[t0 + e] = e < loS ? lo->recon[e] : 0;
-            book.recon[t0 + A + e] = e < hiS ? hi->recon[e] : 0;
-        }
-        if (lane == 0) {
-            book.nstates[(size_t)s * 2 * A + 2 * j] = (uint8_t)loS;
-            book.nstates[(size_t)s * 2 * A + 2 * j + 1] = (uint8_t)hiS;
-            book.ratio[(size_t)s * A + j] = ratio;
-            book.live[(size_t)s * A + j] = live ? 1 : 0;
-            LmIn done_plan = I;
-            done_plan.mode = 3;                                  // settled: no block of a later round works for this context
-            lin[j] = done_plan;
-        }
-    }
-    if (lane == 0) {
-        if (unfinished) atomicAdd(&ctl->lim2[3], 1u);
-        if (err) atomicCAS(&ctl->err, 0u, (s + 1) | (err << 16));
-    }
-    // the last block to arrive finishes the column
-    __threadfence();
-    __syncthreads();
-    if (lane == 0) s_last = atomicAdd(&ctl->lim1[3], 1u) == nu - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const bool redo = round == 1 && ctl->lim2[3] != 0;
-    if (redo) {
-        if (lane == 0) { ctl->lim2[0] = nu; ctl->lim2[1] = A; ctl->lim2[2] = 1; ctl->lim2[3] = 0; ctl->lim1[3] = 0; }
-        return;
-    }
-    // the union of all output alphabets of the column (ascending lists merged, pmf.c:312-357 = the sorted set)
-    for (uint32_t e = lane; e < A; e += 64) present[e] = 0;
-    __syncthreads();
-    for (uint32_t t = 0; t < 2 * nu; ++t) {
-        const size_t n0 = (size_t)s * 2 * A + t;
-        const uint32_t S = book.nstates[n0];
-        for (uint32_t e = lane; e < S; e += 64) present[book.recon[n0 * A + e]] = 1;
-    }
-    __syncthreads();
-    const uint64_t m0 = __ballot(present[lane] != 0);
-    const uint64_t m1 = __ballot(lane < A - 64 && present[64 + lane] != 0);
-    const uint32_t n = (uint32_t)__builtin_popcountll(m0) + (uint32_t)__builtin_popcountll(m1);
-    if (s + 1 <= C) {
-        if (present[lane]) book.ctxsym[(size_t)(s + 1) * A + __builtin_popcountll(m0 & ((1ull << lane) - 1))] = (uint8_t)lane;
-        if (lane < A - 64 && present[64 + lane])
-            book.ctxsym[(size_t)(s + 1) * A + __builtin_popcountll(m0) + __builtin_popcountll(m1 & ((1ull << lane) - 1))] = (uint8_t)(64 + lane);
-    }
-    if (lane == 0) {
-        if (s + 1 <= C) book.nctx[s + 1] = (uint8_t)n;
-        const uint32_t sm = ctl->smax;
-        const uint32_t w0 = force_win ? force_win : sm + 3 < 8 ? 8 : (sm + 3 > A ? A : sm + 3);
-        ctl->lim1[0] = n; ctl->lim1[1] = w0; ctl->lim1[2] = 1; ctl->lim1[3] = 0;
-        ctl->lim2[0] = n; ctl->lim2[1] = A; ctl->lim2[2] = 0; ctl->lim2[3] = 0;
-        ctl->smax = 1;
-    }
-}
-
 // ---- the per-column hand-over between device and host without stream synchronisation ------------------------------------
 // A column costs one exchange with the host (its libm entropies decide, section "host driver" below). Through
 // hipMemcpyAsync + hipStreamSynchronize that exchange took ~140 us of a column's ~250; the kernels' own time is ~110 us.
@@ -932,15 +704,6 @@ __global__ __launch_bounds__(64) void k_cb_flag(volatile uint32_t *flag, uint32_
 
 __global__ __launch_bounds__(256) void k_cb_copy_f64(const double *__restrict__ src, double *__restrict__ dst, uint32_t count) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = src[i];
-}
-
-// host (mapped) -> device: the previous column's tables [144][72] and ratios [72], this column's context symbols [nu]
-__global__ __launch_bounds__(256) void k_cb_stage_in(const uint4 *__restrict__ hq, const double *__restrict__ hr, const uint8_t *__restrict__ hu,
-                                                     uint4 *__restrict__ qprev, double *__restrict__ rprev, uint8_t *__restrict__ ctx_sym, uint32_t nu) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < 2 * A * A / 16) qprev[t] = hq[t];
-    if (t < A) rprev[t] = hr[t];
-    if (t < nu) ctx_sym[t] = hu[t];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -973,26 +736,18 @@ struct ZeroDesign { uint8_t q[A], recon[A]; };
 
 struct CbWork {
     double *P = nullptr, *marg = nullptr, *qpmf[2] = {nullptr, nullptr}, *xpmf = nullptr, *dist = nullptr, *zero_rows = nullptr;
-    double *rprev = nullptr, *ptemp = nullptr;
-    uint8_t *qprev = nullptr, *ctx_sym = nullptr;
+    double *ptemp = nullptr;
     LmIn *lin = nullptr;
     LmDesign *hout = nullptr;                      // the design windows' results: mapped host memory the kernels write
     uint32_t *stop = nullptr;
     uint8_t *pin = nullptr;                        // pinned staging for everything else that crosses PCIe per column
     uint32_t *flag = nullptr;                      // mapped host word the device raises when a column's results are in host memory
     uint32_t seq = 0;
-    // device-driven flow: the codebook as the device builds it, its control block, the design windows' results in HBM
-    CbCtl *ctl = nullptr;
-    CbDevBook book = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    LmDesign *dout = nullptr, *dzero = nullptr;
-    uint8_t *hbook = nullptr;                      // pinned: where the device book lands at the end
     uint32_t capC = 0;                             // columns the buffers were sized for (0: nothing allocated)
     int device = -1;
     void release() {
-        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, rprev, ptemp, qprev, ctx_sym, lin, stop,
-                        ctl, book.nctx, book.ctxsym, book.q, book.recon, book.nstates, book.ratio, book.live, dout, dzero};
+        void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, ptemp, lin, stop};
         for (void *p : ptrs) if (p) (void)hipFree(p);
-        if (hbook) (void)hipHostFree(hbook);
         if (hout) (void)hipHostFree(hout);
         if (pin) (void)hipHostFree(pin);
         if (flag) (void)hipHostFree(flag);
@@ -1037,7 +792,7 @@ static thread_local unsigned long long cb_stat[7];   // QVZ_CB_DEBUG: designs ru
 static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 // exact mode: |entropy - target| at or below this is re-decided by the host's libm (a one-bit miss of the device's log2 restatement
 // moves an entropy of at most ~6.2 bits by a few ulps of 8.9e-16; the band is a thousand times that and is met about once in 1e12 decisions)
-#define QVZ_EXACT_BAND 1e-12   /* QVZ_CB_EXACT_BAND overrides it (tests: a huge band makes the libm re-decide everything) */
+#define QVZ_EXACT_BAND 1e-12   /* QVZ_CB_LOG2=band=<x> overrides it (tests: a huge band makes the libm re-decide everything) */
 static std::atomic<unsigned long long> g_exact_rechecked{0}, g_exact_mismatch{0};
 extern "C" void qvz_hip_codebook_exact_recheck_counts(unsigned long long *rechecked, unsigned long long *mismatched) {
     if (rechecked) *rechecked = g_exact_rechecked.load();
@@ -1154,8 +909,7 @@ static Log2Check *log2_check_start() {
 }
 
 extern "C" int qvz_hip_codebook_warmup(void) {                   // starts the check on a thread of its own; returns at once
-    const char *e = getenv("QVZ_CB_LOG2");
-    if (e && strcmp(e, "host") == 0) return QVZ_OK;
+    if (qvz_env_flag("QVZ_CB_LOG2", "host")) return QVZ_OK;
     return log2_check_start() ? QVZ_OK : qvz_set_error(QVZ_E_HIP, "no current device");
 }
 
@@ -1163,109 +917,12 @@ static bool log2_exact_on_this_device();
 extern "C" int qvz_hip_codebook_exact_entropies(void) { return log2_exact_on_this_device() ? 1 : 0; }
 
 static bool log2_exact_on_this_device() {
-    const char *e = getenv("QVZ_CB_LOG2");
-    if (e && strcmp(e, "host") == 0) return false;
+    if (qvz_env_flag("QVZ_CB_LOG2", "host")) return false;
     Log2Check *L = log2_check_start();
     if (!L) return false;
     std::unique_lock<std::mutex> lk(L->mu);
     L->cv.wait(lk, [&] { return L->state >= 2; });
     return L->state == 2;
-}
-
-// layout of the device book in its pinned landing area
-static size_t cb_book_bytes(uint32_t C) {
-    const size_t tile = (size_t)A * A;
-    return (size_t)C * A * sizeof(double) + 2 * (size_t)C * 2 * tile + (size_t)C * 2 * A + (size_t)C * A + (size_t)(C + 1) * A + (C + 1) + sizeof(CbCtl) + 64;
-}
-
-// The device-driven generation (see k_cb_decide). Returns QVZ_OK with `cb` filled, or a negative code; *fallback is set when
-// the device reported something the host loop should look at instead (never seen; the host loop is then run by the caller).
-static int generate_on_device(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double opt_ratio,
-                              qvz_codebook_t *cb, hipStream_t st, CbWork &W, bool toep, bool mono, bool *fallback) {
-    const size_t tile = (size_t)A * A;
-    *fallback = false;
-    (void)h_dist;
-    QVZ_HIP_CHECK(hipMemsetAsync(W.zero_rows, 0, tile * sizeof(double), st));
-    if (wide) hipLaunchKernelGGL(k_cond_pmf<unsigned long long>, dim3(C * A), dim3(64), 0, st, (const unsigned long long *)d_cnt, W.P);
-    else hipLaunchKernelGGL(k_cond_pmf<uint32_t>, dim3(C * A), dim3(64), 0, st, (const uint32_t *)d_cnt, W.P);
-    hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
-    auto window = [&](const double *rows, const LmIn *in, LmDesign *out, dim3 grid, const uint32_t *limits) {
-        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), grid, dim3(64), LM_LDS_BYTES(true), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits, LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0});
-        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), grid, dim3(64), LM_LDS_BYTES(true), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits, LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0});
-        else hipLaunchKernelGGL((k_lm_window<false, false>), grid, dim3(64), LM_LDS_BYTES(false), st, rows, W.dist, in, out, W.stop, 0.0, 1, limits, LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0});
-    };
-    // designs for the all-zero pmf depend only on (distortion, S): one launch, 72 waves; dzero[S - 1]
-    {
-        LmIn zin[A];
-        memset(zin, 0, sizeof(zin));
-        for (int S = 1; S <= A; ++S) { zin[S - 1].mode = 2; zin[S - 1].startS = (uint8_t)S; }
-        QVZ_HIP_CHECK(hipMemcpyAsync(W.lin, zin, sizeof(zin), hipMemcpyHostToDevice, st));
-        QVZ_HIP_CHECK(hipStreamSynchronize(st));                 // zin is on this stack frame
-        window(W.zero_rows, W.lin, W.dzero, dim3(A, 1), nullptr);
-    }
-    const CbDevBook B = W.book;
-    const int ratio_mode = mode == QVZ_MODE_RATIO ? 1 : 0;
-    const uint32_t force_win = getenv("QVZ_CB_FIRST_WINDOW") ? (uint32_t)atoi(getenv("QVZ_CB_FIRST_WINDOW")) : 0u;   // development knob (2 .. 72): tests the second round
-    int pq = 0;
-    for (uint32_t s = 0; s < C; ++s) {
-        const double *rows;
-        if (s == 0) {
-            hipLaunchKernelGGL(k_cb_col0, dim3(1), dim3(128), 0, st, (const double *)W.P, W.lin, W.ctl, B, W.stop, ratio_mode, opt_ratio, force_win);
-            rows = W.P;
-        } else {
-            if (s >= 2) hipLaunchKernelGGL(k_ctx_ptemp_dev, dim3((A * A + 255) / 256), dim3(256), 0, st, W.P, W.marg, s, (const uint8_t *)B.nctx, W.qpmf[pq], W.ptemp);
-            hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, 0u, 0u, (const uint8_t *)(B.ctxsym + (size_t)s * A),
-                               (const uint8_t *)(B.q + (size_t)(s - 1) * 2 * tile), (const double *)(B.ratio + (size_t)(s - 1) * A), W.ptemp,
-                               W.qpmf[pq ^ 1], W.stop, (const uint8_t *)B.nctx);
-            hipLaunchKernelGGL(k_ctx_xpmf, dim3(A), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf, (double *)nullptr, W.lin, ratio_mode,
-                               opt_ratio, 1, (LmIn *)nullptr, (const uint8_t *)B.nctx);
-            pq ^= 1;
-            rows = W.xpmf;
-        }
-        window(rows, W.lin, W.dout, dim3(A, A), W.ctl->lim1);
-        hipLaunchKernelGGL(k_cb_decide, dim3(A), dim3(64), 0, st, s, C, 1, W.lin, (const LmDesign *)W.dout, (const LmDesign *)W.dzero, W.ctl, B, W.stop, force_win);
-        window(rows, W.lin, W.dout, dim3(A, A), W.ctl->lim2);
-        hipLaunchKernelGGL(k_cb_decide, dim3(A), dim3(64), 0, st, s, C, 2, W.lin, (const LmDesign *)W.dout, (const LmDesign *)W.dzero, W.ctl, B, W.stop, force_win);
-    }
-    QVZ_HIP_CHECK(hipGetLastError());
-    // the book comes home in one piece
-    uint8_t *h = W.hbook;
-    double *h_ratio = reinterpret_cast<double *>(h);
-    uint8_t *h_q = h + (size_t)C * A * sizeof(double), *h_recon = h_q + (size_t)C * 2 * tile, *h_nst = h_recon + (size_t)C * 2 * tile;
-    uint8_t *h_live = h_nst + (size_t)C * 2 * A, *h_sym = h_live + (size_t)C * A, *h_nctx = h_sym + (size_t)(C + 1) * A;
-    CbCtl *h_ctl = reinterpret_cast<CbCtl *>(h_nctx + ((C + 1 + 7) & ~7u));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_ratio, B.ratio, (size_t)C * A * sizeof(double), hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_q, B.q, (size_t)C * 2 * tile, hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_recon, B.recon, (size_t)C * 2 * tile, hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_nst, B.nstates, (size_t)C * 2 * A, hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_live, B.live, (size_t)C * A, hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_sym, B.ctxsym, (size_t)(C + 1) * A, hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_nctx, B.nctx, C + 1, hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipMemcpyAsync(h_ctl, W.ctl, sizeof(CbCtl), hipMemcpyDeviceToHost, st));
-    QVZ_HIP_CHECK(hipStreamSynchronize(st));
-    if (h_ctl->err) {
-        if (getenv("QVZ_CB_DEBUG")) fprintf(stderr, "qvz: device-driven codebook generation reported %#x: the host loop takes over\n", h_ctl->err);
-        *fallback = true;
-        return QVZ_OK;
-    }
-    for (uint32_t s = 0; s < C; ++s) {
-        const uint32_t nu = h_nctx[s];
-        if (nu == 0 || nu > A) { *fallback = true; return QVZ_OK; }
-        cb->nctx[s] = (uint8_t)nu;
-        memcpy(cb->ctx_sym + (size_t)s * A, h_sym + (size_t)s * A, nu);
-        for (uint32_t i = 0; i < nu; ++i) cb->ctx_idx[(size_t)s * A + h_sym[(size_t)s * A + i]] = (uint8_t)i;
-        for (uint32_t j = 0; j < nu; ++j) {
-            for (uint32_t b = 0; b < 2; ++b) {
-                const size_t t = ((size_t)s * 2 * A + 2 * j + b) * A;
-                store_design(cb, s, 2 * j + b, h_q + t, h_recon + t, h_nst[(size_t)s * 2 * A + 2 * j + b]);
-            }
-            const double ratio = h_ratio[(size_t)s * A + j];
-            cb->ratio[(size_t)s * A + j] = ratio;
-            cb->qratio[(size_t)s * A + j] = (uint8_t)(ratio * 128.);                   // store_cond_quantizers_indexed, codebook.c:156
-            cb->live[(size_t)s * A + j] = h_live[(size_t)s * A + j];
-        }
-    }
-    return QVZ_OK;
 }
 
 static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_dist, int mode, double opt_ratio, double guard,
@@ -1283,25 +940,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         QVZ_HIP_CHECK(hipMalloc(&W.ptemp, tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.dist, tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.zero_rows, tile * sizeof(double)));
-        QVZ_HIP_CHECK(hipMalloc(&W.rprev, A * sizeof(double)));
-        QVZ_HIP_CHECK(hipMalloc(&W.qprev, 2 * tile));
-        QVZ_HIP_CHECK(hipMalloc(&W.ctx_sym, A));
         QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
         QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocMapped));
         QVZ_HIP_CHECK(hipMalloc(&W.stop, A * sizeof(uint32_t)));
         QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A) + A * sizeof(LmIn), hipHostMallocMapped));
         QVZ_HIP_CHECK(hipHostMalloc(&W.flag, 64, hipHostMallocMapped));
-        QVZ_HIP_CHECK(hipMalloc(&W.ctl, sizeof(CbCtl)));
-        QVZ_HIP_CHECK(hipMalloc(&W.book.nctx, C + 1));
-        QVZ_HIP_CHECK(hipMalloc(&W.book.ctxsym, (size_t)(C + 1) * A));
-        QVZ_HIP_CHECK(hipMalloc(&W.book.q, (size_t)C * 2 * tile));
-        QVZ_HIP_CHECK(hipMalloc(&W.book.recon, (size_t)C * 2 * tile));
-        QVZ_HIP_CHECK(hipMalloc(&W.book.nstates, (size_t)C * 2 * A));
-        QVZ_HIP_CHECK(hipMalloc(&W.book.ratio, (size_t)C * A * sizeof(double)));
-        QVZ_HIP_CHECK(hipMalloc(&W.book.live, (size_t)C * A));
-        QVZ_HIP_CHECK(hipMalloc(&W.dout, tile * sizeof(LmDesign)));
-        QVZ_HIP_CHECK(hipMalloc(&W.dzero, A * sizeof(LmDesign)));
-        QVZ_HIP_CHECK(hipHostMalloc(&W.hbook, cb_book_bytes(C), hipHostMallocDefault));
         *W.flag = 0;
         W.seq = 0;
         W.capC = C;
@@ -1320,16 +963,6 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             for (int r = 0; r < A; ++r) hT[i * A + r] = h_dist[i + A * r];
         QVZ_HIP_CHECK(hipMemcpyAsync(W.dist, hT, tile * sizeof(double), hipMemcpyHostToDevice, st));
         QVZ_HIP_CHECK(hipStreamSynchronize(st));
-    }
-    // With entropies the device can be trusted with (the log2 check, above), the columns need no host: QVZ_CB_FLOW=device
-    // enqueues all of them at once and assembles the book at the end (generate_on_device). It is NOT the default: measured
-    // at 100M x 150 it is slower than the loop below (33.8 against 29.7 ms with -f 0.5, 23.6 against 18.5 with -r 1.0;
-    // profiles/r03_codebook_device_flow.txt) - seven dependent launches per column, each with its dispatch gap, cost
-    // more than the one host round trip they replace, and the design window's critical path is the same either way.
-    if (getenv("QVZ_CB_FLOW") && strcmp(getenv("QVZ_CB_FLOW"), "device") == 0 && log2_exact_on_this_device()) {
-        bool fallback = false;
-        const int rc_ = generate_on_device(d_cnt, wide, C, h_dist, mode, opt_ratio, cb, st, W, toep, mono, &fallback);
-        if (rc_ || !fallback) return rc_;
     }
     QVZ_HIP_CHECK(hipMemsetAsync(W.zero_rows, 0, tile * sizeof(double), st));
 
@@ -1364,23 +997,18 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     // libm; then the targets and every `entropy < target` come from the device and the host calls libm no more. Otherwise
     // the device values only steer and the host's libm decides inside the guard band, as before.
     const bool exact = log2_exact_on_this_device();
-    if (exact) guard = getenv("QVZ_CB_EXACT_BAND") ? atof(getenv("QVZ_CB_EXACT_BAND")) : QVZ_EXACT_BAND;   // the band inside which the host's libm is asked again
+    if (exact) { guard = QVZ_EXACT_BAND; (void)qvz_env_number("QVZ_CB_LOG2", "band", &guard); }   // the band inside which the host's libm is asked again (test hook: band=<x>)
     const bool cb_debug = getenv("QVZ_CB_DEBUG") != nullptr;
-    const bool spin = !getenv("QVZ_CB_SYNC");                           // development knob: wait with hipStreamSynchronize instead
     // Waits for hand-over number `seq`, raised by a k_cb_flag (flag_after): everything enqueued before it has run and its
     // results are in host memory.
     auto await = [&](uint32_t seq, int which) -> int {
         const double t_ = cb_now();
-        if (spin) {
-            uint64_t polls = 0;
-            while (__atomic_load_n(W.flag, __ATOMIC_ACQUIRE) != seq) {
-                if ((++polls & 0xFFFF) == 0 && cb_now() - t_ > 5.0) {    // something is wrong: let the runtime say what
-                    QVZ_HIP_CHECK(hipStreamSynchronize(st));
-                    if (__atomic_load_n(W.flag, __ATOMIC_ACQUIRE) != seq) return qvz_set_error(QVZ_E_HIP, "codebook hand-over flag never arrived");
-                }
+        uint64_t polls = 0;
+        while (__atomic_load_n(W.flag, __ATOMIC_ACQUIRE) != seq) {
+            if ((++polls & 0xFFFF) == 0 && cb_now() - t_ > 5.0) {        // something is wrong: let the runtime say what
+                QVZ_HIP_CHECK(hipStreamSynchronize(st));
+                if (__atomic_load_n(W.flag, __ATOMIC_ACQUIRE) != seq) return qvz_set_error(QVZ_E_HIP, "codebook hand-over flag never arrived");
             }
-        } else {
-            QVZ_HIP_CHECK(hipStreamSynchronize(st));
         }
         cb_wait[which] += cb_now() - t_;
         if (cb_debug && cb_now() - t_ > 5e-3) fprintf(stderr, "  long hand-over wait: %.1f ms for flag %u (kind %d)\n", (cb_now() - t_) * 1e3, seq, which);
@@ -1391,12 +1019,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         hipLaunchKernelGGL(k_cb_flag, dim3(1), dim3(64), 0, st, (volatile uint32_t *)flag_d, seq);
         return seq;
     };
-    const bool stage_kernel = getenv("QVZ_CB_STAGE") != nullptr;        // development knob: copy the host's tables to the device first
     auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win, LmRider rider = LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0}) -> uint32_t {
         const uint32_t extra = rider.rows ? (A * rider.nprev + 64 * nu - 1) / (64 * nu) : 0;     // rows of nu blocks x 64 threads for A * nprev sums
-        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr, rider);
-        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr, rider);
-        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, (const uint32_t *)nullptr, rider);
+        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, rider);
+        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, rider);
+        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, rider);
         return flag_after();
     };
     LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
@@ -1436,13 +1063,6 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             // (k_ctx_ptemp of this column ran behind the previous column's window, while the host was busy: it needs nothing
             // from the host.) The propagation reads the previous column's tables and ratios (slot (s - 1) & 1) and this
             // column's context symbols straight from mapped host memory: a few hundred bytes per workgroup.
-            if (stage_kernel) {
-                hipLaunchKernelGGL(k_cb_stage_in, dim3((2 * A * A / 16 + 255) / 256), dim3(256), 0, st,
-                                   reinterpret_cast<const uint4 *>(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
-                                   (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A), reinterpret_cast<uint4 *>(W.qprev), W.rprev, W.ctx_sym, nu);
-                hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu, (const uint8_t *)W.ctx_sym, (const uint8_t *)W.qprev,
-                                   (const double *)W.rprev, W.ptemp, W.qpmf[pq ^ 1], W.stop, (const uint8_t *)nullptr);
-            } else
             hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu, (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A),
                                (const uint8_t *)(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
                                W.ptemp, W.qpmf[pq ^ 1], W.stop, (const uint8_t *)nullptr);
@@ -1453,12 +1073,9 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             pq ^= 1;
             d_rows = W.xpmf;
             win0 = window0;
-            // p_temp of column s + 1 needs this column's qpmf only: it rides on the window launch (QVZ_CB_PTEMP=own: a launch of its own behind it)
-            const bool ride = s + 1 < C && !(getenv("QVZ_CB_PTEMP") && strcmp(getenv("QVZ_CB_PTEMP"), "own") == 0);
-            seq0 = ride ? launch_window(d_rows, W.lin, nu, win0, LmRider{W.P, W.marg, W.qpmf[pq], W.ptemp, s + 1, nu, win0})
-                        : launch_window(d_rows, W.lin, nu, win0);
-            if (s + 1 < C && !ride)
-                hipLaunchKernelGGL(k_ctx_ptemp, dim3((A * nu + 255) / 256), dim3(256), 0, st, W.P, W.marg, s + 1, nu, W.qpmf[pq], W.ptemp);
+            // p_temp of column s + 1 needs this column's qpmf only: it rides on the window launch
+            seq0 = s + 1 < C ? launch_window(d_rows, W.lin, nu, win0, LmRider{W.P, W.marg, W.qpmf[pq], W.ptemp, s + 1, nu, win0})
+                             : launch_window(d_rows, W.lin, nu, win0);
         }
         QVZ_HIP_CHECK(hipGetLastError());
         { const int rc_ = await(seq0, 0); if (rc_) return rc_; }
@@ -1566,7 +1183,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             if (any_gpu) win = win * 2 > A ? A : win * 2;
         }
         {
-            static const uint32_t margin = getenv("QVZ_CB_WINDOW_MARGIN") ? (uint32_t)atoi(getenv("QVZ_CB_WINDOW_MARGIN")) : 3u;   // development knob
+            const uint32_t margin = 3u;
             window0 = smax + margin < 8 ? 8 : (smax + margin > A ? A : smax + margin);
         }
 

@@ -69,386 +69,12 @@ __device__ __forceinline__ void lc_run(LaneCoder &c, uint32_t bit, uint32_t coun
     }
 }
 
-__device__ __forceinline__ uint32_t clz_field(uint32_t v, uint32_t width) {
-    return v ? (uint32_t)__clz((int)v) - (32 - width) : width;
-}
-
-// floor(prod / n) for prod < 2^42, n < 2^21 (so the quotient fits 32 bits). rn ~ 1/n from v_rcp_f64: the estimate
-// is within one of the true quotient, and one correction step against the exact remainder settles it.
-__device__ __forceinline__ uint32_t exact_div(uint64_t prod, uint32_t n, double rn) {
-    const double pd = (double)(uint32_t)(prod >> 32) * 4294967296.0 + (double)(uint32_t)prod;   // exact: prod < 2^53
-    uint32_t q = (uint32_t)(pd * rn);
-    const int64_t r = (int64_t)prod - (int64_t)((uint64_t)q * n);
-    if (r < 0) q -= 1;
-    else if (r >= (int64_t)n) q += 1;
-    return q;
-}
-
-__device__ __forceinline__ double fast_rcp(uint32_t n) { return __builtin_amdgcn_rcp((double)n); }
-
-// arithmetic_encoder_step (arith.c:24-97) + update_stats (qv_stream.c:9-25) on table t ([n][card][counts...])
-__device__ __forceinline__ void lc_encode(LaneCoder &c, uint32_t *__restrict__ t, uint32_t x) {
-    const uint32_t n = t[0], card = t[1];
-    uint32_t cum_lo = 0;
-    for (uint32_t i = 0; i < x; ++i) cum_lo += t[2 + i];
-    const uint32_t fx = t[2 + x];
-    const uint32_t cum_hi = cum_lo + fx;
-    const uint32_t range = c.u - c.l + 1;
-    const double rn = fast_rcp(n);
-    uint32_t u = c.l + exact_div((uint64_t)range * cum_hi, n, rn) - 1;
-    uint32_t l = c.l + exact_div((uint64_t)range * cum_lo, n, rn);
-
-    const uint32_t diff = l ^ u;
-    if (!(diff & MSB)) {                                        // E1/E2 batch
-        const uint32_t k = clz_field(diff, M_BITS);
-        const uint32_t top = l >> (M_BITS - k);
-        const uint32_t b = top >> (k - 1);
-        lc_put(c, b, 1);
-        if (c.scale3) { lc_run(c, !b, c.scale3); c.scale3 = 0; }
-        if (k > 1) lc_put(c, top & ((1u << (k - 1)) - 1), k - 1);
-        l = (l << k) & MASK_M;
-        u = ((u << k) & MASK_M) | ((1u << k) - 1);
-    }
-    {                                                           // E3 batch
-        const uint32_t ones_l = clz_field((~l) & MASK_M1, M_BITS - 1);
-        const uint32_t zeros_u = clz_field(u & MASK_M1, M_BITS - 1);
-        const uint32_t j = ones_l < zeros_u ? ones_l : zeros_u;
-        if (j) {
-            c.scale3 += j;
-            l = (l << j) & MASK_M1;
-            u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
-        }
-    }
-    c.l = l;
-    c.u = u;
-
-    t[2 + x] = fx + STEP;                                       // qv_stream.c:12-13
-    uint32_t nn = n + STEP;
-    if (nn > RESCALE) {                                         // qv_stream.c:15-24
-        nn = 0;
-        for (uint32_t i = 0; i < card; ++i) {
-            const uint32_t v = t[2 + i];
-            if (v) { const uint32_t h = (v >> 1) + 1; t[2 + i] = h; nn += h; }
-        }
-    }
-    t[0] = nn;
-}
-
-__global__ __launch_bounds__(64) void k_arith_shards(const uint16_t *__restrict__ feed, const uint8_t *__restrict__ labels,
-                                                     uint32_t C, uint32_t K, const uint64_t *__restrict__ first,
-                                                     uint32_t shards, const uint32_t *__restrict__ off,
-                                                     uint32_t *__restrict__ arena, uint32_t arena_words,
-                                                     uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ sizes,
-                                                     int32_t *__restrict__ status) {
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= shards) return;
-    const uint64_t r0 = first[g], r1 = first[g + 1];
-    uint32_t *ar = arena + (uint64_t)g * arena_words;
-    LaneCoder c;
-    c.l = 0; c.u = MASK_M; c.scale3 = 0; c.nbits = 0; c.acc = 0;
-    c.out = out + (uint64_t)g * cap; c.pos = 0; c.cap = cap; c.overflow = false;
-    bool bad = false;
-
-    for (uint64_t i = r0; i < r1; ++i) {
-        uint32_t cl = 0;
-        if (K > 1) {
-            cl = labels[i];
-            if (cl >= K) { bad = true; cl = 0; }
-            lc_encode(c, ar, cl);                               // qv_write_cluster (table 0 of the arena)
-        }
-        const uint32_t *offc = off + (uint64_t)cl * C * 2 * A;
-        const uint16_t *f = feed + i * C;
-        for (uint32_t s = 0; s < C; ++s) {
-            const uint32_t v = f[s];
-            const uint32_t qi = v & 0xFF, st = v >> 8;
-            const uint32_t o = qi < 2 * A ? offc[s * 2 * A + qi] : NO_TABLE;
-            if (o == NO_TABLE || st >= ar[o + 1]) { bad = true; continue; }
-            lc_encode(c, ar + o, st);                           // compress_qv
-        }
-    }
-    // encoder_last_step (arith.c:99-116) + stream_finish_byte (os_stream.c:105-110)
-    const uint32_t b = c.l >> (M_BITS - 1);
-    lc_put(c, b, 1);
-    if (c.scale3) { lc_run(c, !b, c.scale3); c.scale3 = 0; }
-    lc_put(c, c.l & MASK_M1, M_BITS - 1);
-    uint64_t total_bits = c.pos * 8 + c.nbits;
-    if (total_bits % 8) { const uint32_t pad = 8 - (uint32_t)(total_bits % 8); lc_put(c, 0, pad); total_bits += pad; }
-    else { lc_put(c, 0, 8); total_bits += 8; }                  // aligned streams still get one 0x00 byte
-    const uint64_t bytes = total_bits / 8;
-    while (c.nbits) {                                           // spill the remaining whole bytes
-        const uint32_t take = c.nbits >= 8 ? 8 : c.nbits;
-        const uint8_t byte = (uint8_t)((c.acc >> (c.nbits - take)) << (8 - take));
-        if (c.pos < c.cap) c.out[c.pos] = byte; else c.overflow = true;
-        c.pos += 1;
-        c.nbits -= take;
-    }
-    sizes[g] = bytes;
-    if (bad) atomicOr(status, 1);
-    if (c.overflow) atomicOr(status, 2);
-}
-
-// ---- helpers of the model-wave / coder-wave kernel below --------------------------------------------------------
-// (A software-pipelined single-wave variant - feed, table offsets and table headers prefetched a block ahead - stood
-// here until the kernels further down replaced it: 1.72 s on the 100M x 150 workload)
-struct Hdr { uint4 a, b; };   // a = {n, card, c0, c1}, b = {c2, c3, c4, c5}
-
-// Branch-light interval step. Lanes of a wave are different streams, so every data-dependent `if` costs the whole
-// wave both sides plus exec-mask bookkeeping; the first version spent most of its instructions there. Here the
-// renormalisation is written with shift counts that may be zero, and the common case of the pending-bit run
-// (scale3 <= 9, so that the first bit, the run and the remaining k-1 bits fit one 31-bit pattern) is folded into a
-// single emit. Same integers as arithmetic_encoder_step (arith.c:24-97); only the control flow differs.
-__device__ __forceinline__ void lc_interval(LaneCoder &c, uint32_t n, uint32_t cum_lo, uint32_t fx) {
-    const uint32_t range = c.u - c.l + 1;
-    const double rn = fast_rcp(n);
-    uint32_t u = c.l + exact_div((uint64_t)range * (cum_lo + fx), n, rn) - 1;
-    uint32_t l = c.l + exact_div((uint64_t)range * cum_lo, n, rn);
-    const uint32_t diff = l ^ u;
-    // E1/E2: k leading bits shared by l and u (k = 0 when the MSBs differ)
-    const uint32_t lz = diff ? (uint32_t)__clz((int)diff) - (32 - M_BITS) : M_BITS;
-    const uint32_t k = (diff & MSB) ? 0u : lz;
-    const uint32_t top = l >> (M_BITS - k);                      // k = 0: l >> 22 = 0
-    const uint32_t km1 = k ? k - 1 : 0u;
-    const uint32_t s3 = k ? c.scale3 : 0u;                        // the pending run is flushed only when a bit is decided
-    if (s3 > 9) {                                                // rare: long run, emit piecewise
-        const uint32_t b = top >> km1;
-        lc_put(c, b, 1);
-        lc_run(c, !b, s3);
-        if (km1) lc_put(c, top & ((1u << km1) - 1), km1);
-    } else {
-        // pattern = b, then s3 copies of !b, then the remaining k-1 bits of top
-        const uint32_t b = top >> km1;
-        const uint32_t rest = top & ((1u << km1) - 1);
-        const uint32_t run = b ? 0u : ((1u << s3) - 1);
-        const uint32_t bits = (((b << s3) | run) << km1) | rest;
-        const uint32_t nb = k + s3;                              // 0 when k = 0
-        c.acc = (c.acc << nb) | bits;
-        c.nbits += nb;
-        if (c.nbits >= 32) lc_flush32(c);
-    }
-    c.scale3 = k ? 0u : c.scale3;
-    l = (l << k) & MASK_M;
-    u = ((u << k) & MASK_M) | ((1u << k) - 1);
-    // E3: j positions below the MSB where l has ones and u has zeros (j = 0 is a no-op)
-    const uint32_t nl = (~l) & MASK_M1, nu = u & MASK_M1;
-    const uint32_t ones_l = nl ? (uint32_t)__clz((int)nl) - (32 - (M_BITS - 1)) : M_BITS - 1;
-    const uint32_t zeros_u = nu ? (uint32_t)__clz((int)nu) - (32 - (M_BITS - 1)) : M_BITS - 1;
-    const uint32_t j = ones_l < zeros_u ? ones_l : zeros_u;
-    c.scale3 += j;
-    c.l = (l << j) & MASK_M1;
-    c.u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
-}
-
-// ---- model wave + coder wave ---------------------------------------------------------------------------------------
-// A stream's speed is its instruction count (see above), so the per-symbol chain is cut in two and run on two SIMDs.
-// Workgroup = 2 waves serving the same 64 streams:
-//   wave 1 (model): owns the adaptive tables. Prefetches feed -> table offset -> table header a block ahead, picks
-//                   cum_lo / freq / n for every symbol, applies update_stats (count += 8, halve-and-+1 rescale,
-//                   qv_stream.c:9-25) and parks the (n, cum_lo, freq) triples of an 8-symbol block in an LDS ring;
-//   wave 0 (coder): reads triples (LDS only), runs the interval arithmetic + renormalisation + bit output
-//                   (arith.c:24-97). It issues no global loads at all.
-// The model never needs the coder's state and the coder never needs the tables, so the two chains are independent
-// given the triples; one raw s_barrier per block (no fence: __syncthreads() would drain vmcnt) and two ring slots
-// keep the model at most one block ahead. The tables are private to the model wave, so its header prefetch is safe
-// because a table is touched again only C symbols later (a table belongs to one column; C >= 32 here).
-#define MC_BS 8
-template <bool HAVE_LABELS>
-__global__ __launch_bounds__(128) void k_arith_shards_mc(const uint16_t *__restrict__ feed, const uint8_t *__restrict__ labels,
-                                                         uint32_t C, uint32_t K, const uint64_t *__restrict__ first,
-                                                         uint32_t shards, const uint32_t *__restrict__ off,
-                                                         uint32_t *__restrict__ arena, uint32_t arena_words,
-                                                         uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ sizes,
-                                                         int32_t *__restrict__ status) {
-    // [slot][symbol][0..2 = symbol triple, 3..5 = cluster-id triple (n = 0: none)][lane]
-    __shared__ uint32_t ring[2][MC_BS][6][64];
-    __shared__ unsigned long long s_nblk;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * 64 + lane;
-    const bool live = g < shards;
-    const uint64_t r0 = live ? first[g] : 0, r1 = live ? first[g + 1] : 0;
-    const uint64_t T = (r1 - r0) * C;
-    const uint64_t nblk = (T + MC_BS - 1) / MC_BS;
-    if (threadIdx.x == 0) s_nblk = 0;
-    __syncthreads();
-    if (wave == 0) atomicMax(&s_nblk, (unsigned long long)nblk);
-    __syncthreads();
-    const uint64_t nmax = s_nblk;
-
-    if (wave == 1) {
-        // ------------------------------------ model wave ------------------------------------
-        uint32_t *ar = arena + (uint64_t)(live ? g : 0) * arena_words;
-        const uint16_t *fbase = feed + r0 * C;
-        bool bad = false;
-        auto label_of = [&](uint64_t i) -> uint32_t {
-            if (!HAVE_LABELS) return 0u;
-            const uint32_t cl = labels[i];
-            return cl < K ? cl : 0u;
-        };
-        auto load_feed = [&](uint64_t blk) -> uint4 {
-            const uint64_t t0 = blk * MC_BS;
-            if (t0 + MC_BS <= T) {
-                const uint2 a = *reinterpret_cast<const uint2 *>(fbase + t0);      // 8-byte aligned (r0 % 4 == 0)
-                const uint2 b = *reinterpret_cast<const uint2 *>(fbase + t0 + 4);
-                return make_uint4(a.x, a.y, b.x, b.y);
-            }
-            uint32_t v[MC_BS];
-            for (int j = 0; j < MC_BS; ++j) v[j] = (t0 + j < T) ? fbase[t0 + j] : 0u;
-            return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-        };
-        auto entry = [](const uint4 &w, int j) -> uint32_t {
-            const uint32_t word = j < 2 ? w.x : (j < 4 ? w.y : (j < 6 ? w.z : w.w));
-            return (word >> (16 * (j & 1))) & 0xFFFF;
-        };
-        uint64_t pi = r0;                                        // look-up cursor (runs ahead of the update cursor)
-        uint32_t ps = 0;
-        const uint32_t *poffc = off + (uint64_t)(r0 < r1 ? label_of(r0) : 0u) * C * 2 * A;
-        auto lookup_block = [&](const uint4 &w, uint64_t blk, uint32_t *o) {
-#pragma unroll
-            for (int j = 0; j < MC_BS; ++j) {
-                o[j] = NO_TABLE;
-                if (blk * MC_BS + j < T) {
-                    const uint32_t qi = entry(w, j) & 0xFF;
-                    if (qi < 2 * A) o[j] = poffc[ps * 2 * A + qi];
-                    if (++ps == C) {
-                        ps = 0;
-                        ++pi;
-                        if (pi < r1) poffc = off + (uint64_t)label_of(pi) * C * 2 * A;
-                    }
-                }
-            }
-        };
-        auto load_hdrs = [&](const uint32_t *o, Hdr *h) {
-#pragma unroll
-            for (int j = 0; j < MC_BS; ++j) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(ar + (o[j] == NO_TABLE ? 0u : o[j]));
-                h[j].a = p[0];
-                h[j].b = p[1];
-            }
-        };
-        // update_stats on a table whose first counts are in registers; returns the triple
-        auto model_step = [&](uint32_t *t, const Hdr &h, uint32_t x, uint32_t &n_out, uint32_t &cum_out, uint32_t &fx_out) {
-            const uint32_t n = h.a.x, card = h.a.y;
-            uint32_t cum_lo, fx;
-            if (x < 6) {
-                const uint32_t c0 = h.a.z, c1 = h.a.w, c2 = h.b.x, c3 = h.b.y, c4 = h.b.z, c5 = h.b.w;
-                cum_lo = (x > 0 ? c0 : 0u) + (x > 1 ? c1 : 0u) + (x > 2 ? c2 : 0u) + (x > 3 ? c3 : 0u) + (x > 4 ? c4 : 0u);
-                fx = x == 0 ? c0 : x == 1 ? c1 : x == 2 ? c2 : x == 3 ? c3 : x == 4 ? c4 : c5;
-            } else {
-                cum_lo = h.a.z + h.a.w + h.b.x + h.b.y + h.b.z + h.b.w;
-                for (uint32_t i = 6; i < x; ++i) cum_lo += t[2 + i];
-                fx = t[2 + x];
-            }
-            t[2 + x] = fx + STEP;
-            uint32_t nn = n + STEP;
-            if (nn > RESCALE) {
-                nn = 0;
-                for (uint32_t i = 0; i < card; ++i) {
-                    const uint32_t v = t[2 + i];
-                    if (v) { const uint32_t hv = (v >> 1) + 1; t[2 + i] = hv; nn += hv; }
-                }
-            }
-            t[0] = nn;
-            n_out = n; cum_out = cum_lo; fx_out = fx;
-        };
-
-        uint4 f0 = load_feed(0), f1 = load_feed(1), f2 = load_feed(2);
-        uint32_t o_cur[MC_BS], o_next[MC_BS], o_nn[MC_BS];
-        Hdr h_cur[MC_BS], h_next[MC_BS];
-        lookup_block(f0, 0, o_cur);
-        lookup_block(f1, 1, o_next);
-        load_hdrs(o_cur, h_cur);
-        uint64_t ci = r0;                                        // update cursor
-        uint32_t cs = 0;
-        for (uint64_t b = 0; b <= nmax; ++b) {
-            if (b < nmax) {
-                load_hdrs(o_next, h_next);                       // block b+1
-                lookup_block(f2, b + 2, o_nn);                   // block b+2
-                const uint4 f3 = load_feed(b + 3);               // block b+3
-                const uint32_t slot = (uint32_t)(b & 1);
-#pragma unroll
-                for (int j = 0; j < MC_BS; ++j) {
-                    uint32_t n1 = 0, cum1 = 0, fx1 = 0, n0 = 0, cum0 = 0, fx0 = 0;
-                    if (b * MC_BS + j < T) {
-                        if (HAVE_LABELS) {
-                            if (cs == 0) {                       // qv_write_cluster: table 0, straight from memory
-                                const uint32_t raw = labels[ci];
-                                if (raw >= K) bad = true;
-                                const uint32_t cl = raw < K ? raw : 0u;
-                                n0 = ar[0];
-                                for (uint32_t i = 0; i < cl; ++i) cum0 += ar[2 + i];
-                                fx0 = ar[2 + cl];
-                                ar[2 + cl] = fx0 + STEP;
-                                uint32_t nn = n0 + STEP;
-                                if (nn > RESCALE) {
-                                    nn = 0;
-                                    for (uint32_t i = 0; i < K; ++i) { const uint32_t v = (ar[2 + i] >> 1) + 1; ar[2 + i] = v; nn += v; }
-                                }
-                                ar[0] = nn;
-                            }
-                            if (++cs == C) { cs = 0; ++ci; }
-                        }
-                        const uint32_t st = entry(f0, j) >> 8;
-                        const uint32_t o = o_cur[j];
-                        if (o == NO_TABLE || st >= h_cur[j].a.y) bad = true;
-                        else model_step(ar + o, h_cur[j], st, n1, cum1, fx1);
-                    }
-                    ring[slot][j][0][lane] = n1; ring[slot][j][1][lane] = cum1; ring[slot][j][2][lane] = fx1;
-                    if (HAVE_LABELS) { ring[slot][j][3][lane] = n0; ring[slot][j][4][lane] = cum0; ring[slot][j][5][lane] = fx0; }
-                }
-#pragma unroll
-                for (int j = 0; j < MC_BS; ++j) { h_cur[j] = h_next[j]; o_cur[j] = o_next[j]; o_next[j] = o_nn[j]; }
-                f0 = f1; f1 = f2; f2 = f3;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        if (bad) atomicOr(status, 1);
-        return;
-    }
-
-    // ------------------------------------ coder wave ------------------------------------
-    LaneCoder c;
-    c.l = 0; c.u = MASK_M; c.scale3 = 0; c.nbits = 0; c.acc = 0;
-    c.out = out + (uint64_t)(live ? g : 0) * cap; c.pos = 0; c.cap = cap; c.overflow = false;
-    for (uint64_t b = 0; b <= nmax; ++b) {
-        asm volatile("s_barrier" ::: "memory");                  // the model wave parked block b in slot b&1 before barrier b
-        if (b == nmax) break;                                    // (while we code it, the model fills the other slot)
-        const uint32_t slot = (uint32_t)(b & 1);
-#pragma unroll
-        for (int j = 0; j < MC_BS; ++j) {
-            if (HAVE_LABELS) {
-                const uint32_t n0 = ring[slot][j][3][lane];
-                if (n0) lc_interval(c, n0, ring[slot][j][4][lane], ring[slot][j][5][lane]);
-            }
-            const uint32_t n1 = ring[slot][j][0][lane];
-            if (n1) lc_interval(c, n1, ring[slot][j][1][lane], ring[slot][j][2][lane]);
-        }
-    }
-    if (!live) return;
-    const uint32_t bb = c.l >> (M_BITS - 1);                     // encoder_last_step + stream_finish_byte
-    lc_put(c, bb, 1);
-    if (c.scale3) { lc_run(c, !bb, c.scale3); c.scale3 = 0; }
-    lc_put(c, c.l & MASK_M1, M_BITS - 1);
-    uint64_t total_bits = c.pos * 8 + c.nbits;
-    if (total_bits % 8) { const uint32_t pad = 8 - (uint32_t)(total_bits % 8); lc_put(c, 0, pad); total_bits += pad; }
-    else { lc_put(c, 0, 8); total_bits += 8; }
-    const uint64_t bytes = total_bits / 8;
-    while (c.nbits) {
-        const uint32_t take = c.nbits >= 8 ? 8 : c.nbits;
-        const uint8_t byte = (uint8_t)((c.acc >> (c.nbits - take)) << (8 - take));
-        if (c.pos < c.cap) c.out[c.pos] = byte; else c.overflow = true;
-        c.pos += 1;
-        c.nbits -= take;
-    }
-    sizes[g] = bytes;
-    if (c.overflow) atomicOr(status, 2);
-}
-
 // ---- column-parallel model + streaming coder ------------------------------------------------------------------------
-// PMC on the kernels above (profiles/, 100M x 150, 8192 streams): 52 % of the wave cycles parked on s_waitcnt, 49 % L2
-// misses, ~1.1 TB fetched + 0.6 TB written for 15 G symbols. A lane that walks its reads column by column touches a
-// different table (a different 64-128 B line of its 0.5 MB arena) every symbol, so the "latency-bound" chain was in fact
-// random HBM traffic. But the adaptive model of column s is a function of the column-s symbols only (a table belongs
-// to one column, update_stats touches nothing else, qv_stream.c:9-25): only the interval arithmetic is a serial
-// chain over the whole read. Hence two kernels:
+// A lane that walks its stream's reads column by column with the whole model in an arena of its own (rounds 1-2; removed in round
+// 5, HISTORY.md) touches a different table - a different 64-128 B line of 0.5 MB - every symbol: measured, 52 % of the wave cycles
+// parked on s_waitcnt, 49 % L2 misses, ~1.1 TB fetched + 0.6 TB written for 15 G symbols; the "latency-bound" chain was random HBM
+// traffic. But the adaptive model of column s is a function of the column-s symbols only (a table belongs to one column, update_stats
+// touches nothing else, qv_stream.c:9-25): only the interval arithmetic is a serial chain over the whole read. Hence two kernels:
 //   k_model_columns  one lane per (stream, column) - 1.2 M lanes at 8192 x 150 instead of 8192. The lane walks its
 //                    stream's reads for that column, so its working set is the handful of tables of one column
 //                    (L1/L2 resident) and qi/st are read along the read axis. It emits the 8-byte record
@@ -484,18 +110,6 @@ typedef double2 Record;
 // records makes it 45 % slower (137 -> 198 ms): its loader asks for half lines, and the other half then comes from HBM again.
 typedef double rk_d2 __attribute__((ext_vector_type(2)));
 #define RK_STORE(ptr, val) do { const Record v_ = (val); rk_d2 w_; w_.x = v_.x; w_.y = v_.y; __builtin_nontemporal_store(w_, reinterpret_cast<rk_d2 *>(ptr)); } while (0)
-// The two quotients need not be correctly rounded, only within 2^-47 of cum / n (see above: the budget is 2^-24 over
-// R <= 2^22): 1/n from v_rcp_f64 plus two Newton steps (relative error ~2^-52) times the numerator is far inside that,
-// and costs a dozen instructions instead of two IEEE divisions.
-__device__ __forceinline__ Record make_record(uint32_t n, uint32_t cum_lo, uint32_t fx) {
-    const double nd = (double)n;
-    double rn = __builtin_amdgcn_rcp(nd);
-    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
-    rn = __builtin_fma(__builtin_fma(-nd, rn, 1.0), rn, rn);
-    rn *= 0x1p-10;
-    return make_double2((double)cum_lo * rn, (double)(n - cum_lo - fx) * rn);
-}
-
 // ---- packed records (round 4): the integer triple in 8 bytes, the division on the coder's side ------------------------------
 // What the model knows about a symbol is three integers below 2^21 (n <= 2^19 + 8 * 64: a table passes the rescale threshold
 // inside a chunk at most; cum_lo < n; n - cum_hi <= n): cum_lo in bits [0, 21), n - cum_hi in [21, 42), n in [42, 63);
@@ -590,11 +204,8 @@ __device__ __forceinline__ Record make_record_fixed(uint32_t n, uint32_t cum_lo,
 // other halves it reads a read later (out of L2). (With 8 columns of one read per unit the model kernel wrote half
 // lines, and those writes slowed the coder's reads beside them.)
 #define QVZ_CID_SLOTS 8   // several clusters: record positions 0 (cluster id) .. 7 (zero records) precede the columns (k_model_ranks)
-__device__ __forceinline__ uint64_t rec_index(uint32_t g, uint64_t row, uint32_t col, uint32_t Cp, uint64_t nblk8) {
-    return (((uint64_t)(g >> 6) * nblk8 + (row >> 1) * (Cp >> 2) + (col >> 2)) * 64 + (g & 63)) * 8 + (row & 1) * 4 + (col & 3);
-}
 
-template <bool HAVE_LABELS, bool REC8>
+template <bool HAVE_LABELS>
 __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict__ qi, const uint8_t *__restrict__ st, uint64_t ld,
                                                        const uint8_t *__restrict__ labels, uint32_t C, uint32_t K,
                                                        const uint64_t *__restrict__ first, uint32_t shards,
@@ -612,7 +223,7 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
     const uint64_t r1 = rend < r0 + seg_reads ? rend : r0 + seg_reads;
     uint32_t *ar = arena + (uint64_t)g * arena_words;
     const uint32_t Cp = (Cx + 7) & ~7u;
-    const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8, nunit = (uint64_t)seg_reads * Cp / 16;
+    const uint64_t nunit = (uint64_t)seg_reads * Cp / 16;
     PRec *const rec8 = reinterpret_cast<PRec *>(rec);
     const bool cluster_lane = HAVE_LABELS && sx == 0;
     const uint32_t s = HAVE_LABELS ? sx - 1 : sx;
@@ -675,22 +286,14 @@ __global__ __launch_bounds__(256) void k_model_columns(const uint8_t *__restrict
                         }
                     }
                     t[0] = nn;
-                    if (REC8) w8 = pack_record(n, cum_lo, fx); else w = make_record(n, cum_lo, fx);
+                    w8 = pack_record(n, cum_lo, fx);
                 }
             }
-            if (REC8) {
-                rec8[rec8_index(g, r + j - r0, pos, Cp, nunit)] = w8;
-                if (cluster_lane)                                // the reserved positions behind the cluster id
-                    for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = PREC_NOOP;
-                if (sx + 1 == Cw)                                // the read's pad records
-                    for (uint32_t pc = Cx; pc < Cp; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = PREC_NOOP;
-                continue;
-            }
-            rec[rec_index(g, r + j - r0, pos, Cp, nblk8)] = w;
+            rec8[rec8_index(g, r + j - r0, pos, Cp, nunit)] = w8;
             if (cluster_lane)                                    // the reserved positions behind the cluster id
-                for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec[rec_index(g, r + j - r0, pc, Cp, nblk8)] = make_double2(0.0, 0.0);
+                for (uint32_t pc = 1; pc < QVZ_CID_SLOTS; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = PREC_NOOP;
             if (sx + 1 == Cw)                                    // the read's pad records
-                for (uint32_t pc = Cx; pc < Cp; ++pc) rec[rec_index(g, r + j - r0, pc, Cp, nblk8)] = make_double2(0.0, 0.0);
+                for (uint32_t pc = Cx; pc < Cp; ++pc) rec8[rec8_index(g, r + j - r0, pc, Cp, nunit)] = PREC_NOOP;
         }
     }
     if (bad) atomicOr(status, 1);
@@ -827,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     // records between consecutive units of a stream: 512 = 8 records x 64 interleaved streams (rec_index, the coder
     // kernel's layout); DENSE: one stream alone, its units back to back (qvz_hip_model_session_records)
     // REC8: packed 8-byte records, units of 16 (rec8_index): 1024 records between consecutive units of a stream
-    static_assert(!(DENSE && REC8), "the host's chain takes 16-byte fixed-point records");
+    static_assert(DENSE != REC8, "packed records for the GPU coder, 16-byte fixed-point records for the host's chain (DENSE)");
     constexpr uint32_t unit_recs = DENSE ? 8u : REC8 ? 1024u : 512u;
     extern __shared__ uint4 rk_smem[];
     // the wave index is wave-uniform, which the compiler cannot see: readfirstlane keeps everything derived from it
@@ -1249,7 +852,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             if (REC8) {
                 outp = ok ? pack_record(n, cum_lo, fx) : PREC_NOOP;   // (ok: n >= the alphabet size >= 1)
             } else {
-                const Record rr = DENSE ? make_record_fixed(n ? n : 1u, cum_lo, fx) : make_record(n ? n : 1u, cum_lo, fx);
+                const Record rr = make_record_fixed(n ? n : 1u, cum_lo, fx);   // (DENSE: the host's chain)
                 outr = make_double2(ok ? rr.x : 0.0, ok ? rr.y : 0.0);
             }
         }
@@ -1341,13 +944,13 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
 // 4-7: the 32-byte piece of one unit per lane), turn the integer triples into the two quotients (unpack_record) and park them
 // in the ring; waves 1, 2, 3 are interval, bits, bytes as before. The loaders are throughput work (eight independent
 // records per block and lane); the three chain waves keep a SIMD each.
-template <bool REC8, int NB, int NEWTON>
-__global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
+template <int NB, int NEWTON>
+__global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
                                                       uint64_t *__restrict__ sizes, int32_t *__restrict__ status, int high_prio) {
-    constexpr int LAG = REC8 ? 1 : 0;                            // blocks the interval wave (and the two behind it) run further behind the loaders
-    static_assert((NB == 8 || NB == 16) && (REC8 || NB == 8), "the record layouts have 8 records per lane and sub-block; 16-symbol blocks come with packed records only");
+    constexpr int LAG = 1;                                       // blocks the interval wave (and the two behind it) run behind the loaders
+    static_assert(NB == 8 || NB == 16, "the record layout has 8 records per lane and sub-block");
     __shared__ Record ring[2][CR_B][64];
     __shared__ uint32_t words[3][CR_B][64];                      // three slots: the bytes wave re-reads a rare symbol's word two blocks later
     __shared__ uint32_t ebits[2][CR_B][64];                      // value (16 bits) | bit count << 16, or CR_RARE | pending run
@@ -1355,14 +958,14 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
     __shared__ uint4 oring[64 * 5];                              // the bytes wave's output ring: 16 words per lane, 80-byte stride
     const uint32_t hw_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // role: 0 interval, 1 bits, 2 bytes, 3 loader (REC8: of symbols 0-3), 4 (REC8 only) loader of symbols 4-7
-    const uint32_t wave = !REC8 ? hw_wave : hw_wave == 0 ? 3u : hw_wave == 4 ? 4u : hw_wave - 1;
+    const uint32_t wave = hw_wave == 0 ? 3u : hw_wave == 4 ? 4u : hw_wave - 1;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read (rec_index)
     if (high_prio) {
         // all waves of the latency chain issue ahead of the throughput kernels sharing the CU; REC8: the two loaders, which are
         // throughput work themselves, one step below the three chain waves
-        if (REC8 && wave >= 3) asm volatile("s_setprio 2"); else asm volatile("s_setprio 3");
+        if (wave >= 3) asm volatile("s_setprio 2"); else asm volatile("s_setprio 3");
     }
     uint64_t T = 0;
     if (live) {
@@ -1404,7 +1007,7 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
     // 110 ms) and beside the model kernel (223 against 139): a hand-over costs a write's and a read's LDS latency plus the
     // poll's sleep where the barrier costs tens of cycles, and the polling waves take LDS slots from the one that works.)
 
-    if (REC8 && wave >= 3) {
+    if (wave >= 3) {
         // ------------------------------------ the two loaders of packed records ------------------------------------
         constexpr int SUB = NB / 8;                              // sub-blocks of 8 symbols per block
         const uint32_t half = wave - 3;                          // symbols 4 * half .. 4 * half + 3 of every sub-block
@@ -1506,135 +1109,28 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
         return;
     }
 
-    if (!REC8 && wave == 3) {
-        // ------------------------------------ loader ------------------------------------
-        const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;     // blocks of 8 records in a stream's area
-        const Record *p = rec + ((uint64_t)blockIdx.x * nblk8 * 64 + lane) * 8;   // the lane's slot of unit 0 (rec_index)
-        const uint64_t nfull = Tmin / CR_B;                      // blocks that are whole in every lane: no padding test
-        // A register stage holds LD_B ring blocks (a 256-byte run of the lane's records); three stages in rotation
-        // keep two of them (512 bytes per lane) in flight. No copies between stages: a copy would wait for its load.
-        constexpr int LD_B = 2;
-        // block b of a lane = columns 8m .. 8m+7 of read `row` (b = row * Cp/8 + m): the halves [row & 1] of the units
-        // (row / 2, 2m) and (row / 2, 2m + 1). Stages are requested in order, so (row, m) are counted along; past the last
-        // block the last one is loaded again (unconditional loads keep vmcnt countable).
-        uint64_t l_blk = 0;
-        uint32_t l_row = 0, l_m = 0;
-        auto load_stage = [&](uint64_t stg, Record *d) {
-            (void)stg;
-#pragma unroll
-            for (int k = 0; k < LD_B; ++k) {
-                const uint64_t base = ((uint64_t)(l_row >> 1) * (Cp >> 2) + 2 * l_m) * 512 + (l_row & 1) * 4;
-#pragma unroll
-                for (int i = 0; i < CR_B; ++i) d[k * CR_B + i] = p[base + (i >> 2) * 512 + (i & 3)];
-                if (l_blk + 1 < nblk8) {
-                    ++l_blk;
-                    if (++l_m == (Cp >> 3)) { l_m = 0; ++l_row; }
-                }
-            }
-        };
-        auto park = [&](uint64_t b, const Record *d) {           // block b -> slot b & 1, then barrier b
-            const uint32_t slot = (uint32_t)(b & 1);
-            if (b < nfull) {
-#pragma unroll
-                for (int i = 0; i < CR_B; ++i) ring[slot][i][lane] = d[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < CR_B; ++i) {
-                    const bool pad = b * CR_B + i >= T;          // beyond this lane's symbols: the no-op record
-                    ring[slot][i][lane] = make_double2(pad ? 0.0 : d[i].x, pad ? 0.0 : d[i].y);
-                }
-            }
-            CR_BARRIER();
-        };
-        auto park_stage = [&](uint64_t stg, const Record *d) -> bool {   // false: that was the last block
-#pragma unroll
-            for (int k = 0; k < LD_B; ++k) {
-                const uint64_t b = stg * LD_B + k;
-                if (b >= nblk) return false;
-                park(b, d + k * CR_B);
-            }
-            return (stg + 1) * LD_B < nblk;
-        };
-        Record s0[LD_B * CR_B], s1[LD_B * CR_B], s2[LD_B * CR_B];
-        load_stage(0, s0);
-        load_stage(1, s1);
-        for (uint64_t t = 0; t * LD_B < nblk; t += 3) {
-            load_stage(t + 2, s2);
-            if (!park_stage(t, s0)) break;
-            load_stage(t + 3, s0);
-            if (!park_stage(t + 1, s1)) break;
-            load_stage(t + 4, s1);
-            if (!park_stage(t + 2, s2)) break;
-        }
-        CR_BARRIER();                                            // barriers nblk and nblk + 1: the other waves run behind
-        CR_BARRIER();
-        if (is_last) CR_BARRIER();
-        CR_REPORT();
-        return;
-    }
-
     if (wave == 0) {
         // ------------------------------------ interval chain ------------------------------------
         uint32_t l32 = 0, nu32 = 0;                              // l = 0, u = 2^22 - 1
         if (!fresh) { l32 = cs[g].l << 10; nu32 = (~cs[g].u & MASK_M) << 10; }
         uint32_t wslot = 0;                                      // (block coded) % 3
-        if (LAG) {
-            // Packed-record kernel: the wave runs one block behind the loaders - after barrier t it asks LDS for block t's
-            // records (into the register set the block before last has left) and codes block t - 1 from the registers filled
-            // a block ago, so no symbol waits for an LDS round trip. Two ring slots still do: block t + 1 is parked between
-            // barriers t and t + 1 in the slot whose reads were complete before barrier t.
-            // (The interval wave is ISSUE-bound, not latency-bound: ~22 VALU instructions per symbol at the 5-6 cycles a lone wave
-            // needs per instruction are the 135 cycles per symbol it is busy, whatever the depth of the dependent chain. Tried:
-            // fma(2^32 - s, x, c) as fma(-s, x, c') with c' = 2^32 x + c made off the chain - one dependent instruction less, five
-            // instructions more (two v_fmac and the moves of their constants): coder kernels 116.0 -> 117.6 ms. What does pay is
-            // an instruction less: the E3 count as ffbh(~(l & u') & 0x7FFFFFFF) - 1 - one v_bitop3 with the mask as third operand
-            // instead of nand and a shift by one; the count is used as it comes (one too many): shifting left by it and right by
-            // one is the old shift and mask, and the bits wave subtracts the one.)
-            Record ra[CR_B], rb2[CR_B];
-            auto load = [&](Record *r, uint32_t slot) {         // (symbols 2, 3 mod 4 sit at stream ^ 8: the loaders' bank twist)
+        // Packed-record kernel: the wave runs one block behind the loaders - after barrier t it asks LDS for block t's
+        // records (into the register set the block before last has left) and codes block t - 1 from the registers filled
+        // a block ago, so no symbol waits for an LDS round trip. Two ring slots still do: block t + 1 is parked between
+        // barriers t and t + 1 in the slot whose reads were complete before barrier t.
+        // (The interval wave is ISSUE-bound, not latency-bound: ~22 VALU instructions per symbol at the 5-6 cycles a lone wave
+        // needs per instruction are the 135 cycles per symbol it is busy, whatever the depth of the dependent chain. Tried:
+        // fma(2^32 - s, x, c) as fma(-s, x, c') with c' = 2^32 x + c made off the chain - one dependent instruction less, five
+        // instructions more (two v_fmac and the moves of their constants): coder kernels 116.0 -> 117.6 ms. What does pay is
+        // an instruction less: the E3 count as ffbh(~(l & u') & 0x7FFFFFFF) - 1 - one v_bitop3 with the mask as third operand
+        // instead of nand and a shift by one; the count is used as it comes (one too many): shifting left by it and right by
+        // one is the old shift and mask, and the bits wave subtracts the one.)
+        Record ra[CR_B], rb2[CR_B];
+        auto load = [&](Record *r, uint32_t slot) {         // (symbols 2, 3 mod 4 sit at stream ^ 8: the loaders' bank twist)
 #pragma unroll
-                for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane ^ (((jx >> 1) & 1) << 3)];
-            };
-            auto code = [&](const Record *r) {
-#pragma unroll
-                for (int jx = 0; jx < CR_B; ++jx) {
-                    const double rd = 4294967296.0 - (double)(l32 + nu32);       // (u - l + 1) * 1024
-                    const uint32_t ql = (uint32_t)__builtin_fma(rd, r[jx].x, QUOT_LO);
-                    const uint32_t qc = (uint32_t)__builtin_fma(rd, r[jx].y, QUOT_HI);
-                    l32 += ql << 10;
-                    nu32 += qc << 10;
-                    const uint32_t k = (uint32_t)__builtin_clz(~(l32 ^ nu32));   // E1/E2: leading bits shared by l and u (low 10 bits stop it at 22)
-                    const uint32_t lk = l32;                                      // its top k bits go out
-                    l32 <<= k;
-                    nu32 <<= k;
-                    // E3: j positions below the MSB with l = 1, u = 0. Both MSBs are 0 here, so ~(l & nu) has its MSB set and the
-                    // leading zeros of the rest number j + 1 (never all 32: the ten low bits of l32 are zero)
-                    const uint32_t j1 = (uint32_t)__builtin_clz(~(l32 & nu32) & 0x7FFFFFFFu);
-                    l32 = (l32 << j1) >> 1;
-                    nu32 = (nu32 << j1) >> 1;
-                    words[wslot][jx][lane] = lk | (k << 5) | j1;                 // (j + 1 <= 22 fits the five bits)
-                }
-                wslot = wslot == 2 ? 0u : wslot + 1;
-            };
-            CR_BARRIER();                                        // barrier 0
-            if (nblk > 0) load(ra, 0);
-            uint64_t t = 1;
-            for (; t + 1 <= nblk; t += 2) {
-                CR_BARRIER();                                    // barrier t (odd): block t in, block t - 1 coded
-                load(rb2, 1);
-                code(ra);
-                CR_BARRIER();                                    // barrier t + 1
-                if (t + 1 < nblk) load(ra, 0);
-                code(rb2);
-            }
-            if (t == nblk) { CR_BARRIER(); code(ra); }           // an odd number of blocks: the last one
-        } else {
-        for (uint64_t b = 0; b < nblk; ++b) {
-            CR_BARRIER();
-            const uint32_t slot = (uint32_t)(b & 1);
-            Record r[CR_B];                                      // all LDS reads up front: their latency overlaps the chain
-#pragma unroll
-            for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane];
+            for (int jx = 0; jx < CR_B; ++jx) r[jx] = ring[slot][jx][lane ^ (((jx >> 1) & 1) << 3)];
+        };
+        auto code = [&](const Record *r) {
 #pragma unroll
             for (int jx = 0; jx < CR_B; ++jx) {
                 const double rd = 4294967296.0 - (double)(l32 + nu32);       // (u - l + 1) * 1024
@@ -1646,14 +1142,27 @@ __global__ __launch_bounds__(REC8 ? 320 : 256) void k_code_records(const Record 
                 const uint32_t lk = l32;                                      // its top k bits go out
                 l32 <<= k;
                 nu32 <<= k;
-                const uint32_t j = (uint32_t)__builtin_clz(~(l32 & nu32) << 1);   // E3: positions below the MSB with l = 1, u = 0
-                l32 = (l32 << j) & 0x7FFFFFFFu;
-                nu32 = (nu32 << j) & 0x7FFFFFFFu;
-                words[wslot][jx][lane] = lk | (k << 5) | j;
+                // E3: j positions below the MSB with l = 1, u = 0. Both MSBs are 0 here, so ~(l & nu) has its MSB set and the
+                // leading zeros of the rest number j + 1 (never all 32: the ten low bits of l32 are zero)
+                const uint32_t j1 = (uint32_t)__builtin_clz(~(l32 & nu32) & 0x7FFFFFFFu);
+                l32 = (l32 << j1) >> 1;
+                nu32 = (nu32 << j1) >> 1;
+                words[wslot][jx][lane] = lk | (k << 5) | j1;                 // (j + 1 <= 22 fits the five bits)
             }
             wslot = wslot == 2 ? 0u : wslot + 1;
+        };
+        CR_BARRIER();                                        // barrier 0
+        if (nblk > 0) load(ra, 0);
+        uint64_t t = 1;
+        for (; t + 1 <= nblk; t += 2) {
+            CR_BARRIER();                                    // barrier t (odd): block t in, block t - 1 coded
+            load(rb2, 1);
+            code(ra);
+            CR_BARRIER();                                    // barrier t + 1
+            if (t + 1 < nblk) load(ra, 0);
+            code(rb2);
         }
-        }
+        if (t == nblk) { CR_BARRIER(); code(ra); }           // an odd number of blocks: the last one
         CR_BARRIER();
         CR_BARRIER();
         if (is_last) {
@@ -1833,67 +1342,6 @@ __global__ __launch_bounds__(256) void k_arena_fill(const uint32_t *__restrict__
         arena[i] = tmpl[i % words];
 }
 
-extern "C" int qvz_hip_encode_shards(const uint16_t *d_feed, const uint8_t *d_labels, uint64_t n, uint32_t columns,
-                                     uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, uint8_t *d_out,
-                                     uint64_t cap_per_shard, uint64_t *h_sizes, void *stream) {
-    if (!d_feed || !n || !columns || !clusters || !shards || !d_out || !h_sizes) return qvz_set_error(QVZ_E_ARG, "bad shard-coder arguments");
-    if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "labels required for clusters > 1");
-    if ((cap_per_shard & 3) || cap_per_shard < 8) return qvz_set_error(QVZ_E_ARG, "cap_per_shard must be a multiple of 4, at least 8");
-    hipStream_t st = (hipStream_t)stream;
-    uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
-    if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
-        return qvz_set_error(QVZ_E_NOMEM, "model build failed");
-    uint64_t *h_first = (uint64_t *)malloc((shards + 1) * sizeof(uint64_t));
-    if (!h_first) { free(h_arena); free(h_off); return qvz_set_error(QVZ_E_NOMEM, "host alloc"); }
-    qvz_shard_bounds(n, shards, h_first);
-
-    uint32_t *d_tmpl = nullptr, *d_off = nullptr, *d_arena = nullptr;
-    uint64_t *d_first = nullptr, *d_sizes = nullptr;
-    int32_t *d_status = nullptr;
-    int rc = QVZ_OK;
-    int32_t status = 0;
-    const size_t offn = (size_t)clusters * columns * 2 * A;
-    const char *variant = getenv("QVZ_CODER_KERNEL");            // development knob: "simple" selects the unpipelined kernel
-#define TRY(expr)                                                                                                    \
-    do {                                                                                                             \
-        hipError_t e_ = (expr);                                                                                      \
-        if (e_ != hipSuccess) { rc = qvz_set_error(QVZ_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); goto done; } \
-    } while (0)
-    TRY(hipMalloc(&d_tmpl, (size_t)words * 4));
-    TRY(hipMalloc(&d_off, offn * 4));
-    TRY(hipMalloc(&d_arena, ((size_t)words * shards + 8) * 4));   // + slack: a header prefetch reads 32 bytes
-    TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
-    TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
-    TRY(hipMalloc(&d_status, sizeof(int32_t)));
-    TRY(hipMemcpyAsync(d_tmpl, h_arena, (size_t)words * 4, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
-    TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
-    if (columns >= 32 && !(variant && strcmp(variant, "mc") != 0)) {
-        if (clusters > 1)
-            hipLaunchKernelGGL(k_arith_shards_mc<true>, dim3((shards + 63) / 64), dim3(128), 0, st, d_feed, d_labels, columns,
-                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
-        else
-            hipLaunchKernelGGL(k_arith_shards_mc<false>, dim3((shards + 63) / 64), dim3(128), 0, st, d_feed, d_labels, columns,
-                               clusters, d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
-    } else {
-        hipLaunchKernelGGL(k_arith_shards, dim3((shards + 63) / 64), dim3(64), 0, st, d_feed, d_labels, columns, clusters,
-                           d_first, shards, d_off, d_arena, words, d_out, cap_per_shard, d_sizes, d_status);
-    }
-    TRY(hipGetLastError());
-    TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TRY(hipStreamSynchronize(st));
-    if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder feed addresses a quantizer without a model table (dead context or bad state)");
-    else if (status & 2) rc = qvz_set_error(QVZ_E_NOMEM, "a shard's stream exceeded cap_per_shard=%llu bytes", (unsigned long long)cap_per_shard);
-done:
-#undef TRY
-    (void)hipFree(d_tmpl); (void)hipFree(d_off); (void)hipFree(d_arena); (void)hipFree(d_first); (void)hipFree(d_sizes); (void)hipFree(d_status);
-    free(h_arena); free(h_off); free(h_first);
-    return rc;
-}
-
 extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                             uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                             const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
@@ -1910,8 +1358,6 @@ struct KeptArea {
     std::vector<void *> extra;
     void begin() {
         used = 0; want = 0;
-        // development knob: the area holds the previous call's bytes; a call must not depend on finding zeros there
-        if (base && getenv("QVZ_CODER_POISON")) { (void)hipMemset(base, 0xA5, cap); (void)hipDeviceSynchronize(); }
     }
     hipError_t get(void **p, size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
@@ -1951,12 +1397,12 @@ extern "C" void qvz_hip_encode_planes_release(void) {
 extern "C" uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards) {
     const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);
     const uint32_t Cp = (Cx + 7) & ~7u;
-    return (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(Record) * ((longest_reads + 3) & ~(uint64_t)3);
+    return (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(PRec) * ((longest_reads + 3) & ~(uint64_t)3);
 }
 
 // 1: v_rcp_f64 + ONE Newton step is within 2^-47 of 1 / (n 2^10) for every n a packed record can hold on the current device (the
 // loaders of k_code_records then save two of the unpacking's fourteen instructions per record); 0: it is not (two steps are used);
-// measured once per process and device over all n = 1 .. 2^19 + 1024. QVZ_CODER_NEWTON=2 forces the two steps.
+// measured once per process and device over all n = 1 .. 2^19 + 1024. QVZ_CODER=newton=2 (test hook) forces the two steps.
 // *worst_out (may be NULL) receives the worst relative error found.
 extern "C" int qvz_coder_rcp_one_step_ok_ex(double *worst_out) {
     static std::mutex mu;
@@ -1981,7 +1427,7 @@ extern "C" int qvz_coder_rcp_one_step_ok_ex(double *worst_out) {
         verdict[dev] = worst_seen[dev] <= 0x1p-47 ? 1 : 2;
     }
     if (worst_out) *worst_out = worst_seen[dev];
-    if (getenv("QVZ_CODER_NEWTON") && atoi(getenv("QVZ_CODER_NEWTON")) == 2) return 0;
+    { double steps = 0.0; if (qvz_env_number("QVZ_CODER", "newton", &steps) && steps == 2.0) return 0; }   // (test hook: the two-step kernel)
     return verdict[dev] == 1 ? 1 : 0;
 }
 extern "C" int qvz_coder_rcp_one_step_ok(void) { return qvz_coder_rcp_one_step_ok_ex(nullptr); }
@@ -1989,9 +1435,9 @@ extern "C" int qvz_coder_rcp_one_step_ok(void) { return qvz_coder_rcp_one_step_o
 // The model / coder stream pair of the current device: made once, tested for running side by side when it is made
 // (qvz_hip_streams_overlap: a partner on the first stream's hardware queue is put aside and another one made, a few times at
 // most), and kept. Returns 1 with the pair, 0 when the ordinal is beyond the table (the caller makes its own), < 0 on an error.
-static int coder_stream_pair(hipStream_t *pair, hipStream_t *third = nullptr) {
+static int coder_stream_pair(hipStream_t *pair) {
     static std::mutex mu;
-    static hipStream_t kept[64][3];
+    static hipStream_t kept[64][2];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return qvz_set_error(QVZ_E_HIP, "no current device");
     if (dev < 0 || dev >= 64) return 0;
@@ -2012,22 +1458,6 @@ static int coder_stream_pair(hipStream_t *pair, hipStream_t *third = nullptr) {
     }
     pair[0] = kept[dev][0];
     pair[1] = kept[dev][1];
-    if (third) {                                                 // the quantizer's stream of a fused call: beside both, where the queues allow
-        if (!kept[dev][2]) {
-            hipStream_t cand = nullptr, aside[8];
-            int naside = 0, ok = 0;
-            while (true) {
-                if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) return qvz_set_error(QVZ_E_HIP, "hipStreamCreate failed");
-                int ok_b = 0;
-                if (qvz_hip_streams_overlap(kept[dev][0], cand, &ok) != QVZ_OK || qvz_hip_streams_overlap(kept[dev][1], cand, &ok_b) != QVZ_OK || (ok && ok_b) || naside == 8) break;
-                aside[naside++] = cand;
-            }
-            for (int i = 0; i < naside; ++i) (void)hipStreamDestroy(aside[i]);
-            if (getenv("QVZ_CODER_DEBUG")) fprintf(stderr, "qvz_hip_encode_planes: quantizer stream made for device %d, %d candidate(s) put aside\n", dev, naside);
-            kept[dev][2] = cand;
-        }
-        *third = kept[dev][2];
-    }
     return 1;
 }
 
@@ -2124,7 +1554,7 @@ extern "C" uint32_t qvz_coder_segment_list2(uint64_t longest, uint64_t seg_reads
 static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                               uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                               const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
-                              void *d_work, uint64_t work_bytes, void *stream, const QvzQuantArgs *qz = nullptr);
+                              void *d_work, uint64_t work_bytes, void *stream);
 
 extern "C" int qvz_hip_encode_planes_bounds(const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                                             uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
@@ -2155,36 +1585,15 @@ extern "C" int qvz_hip_encode_planes_warmup(void) {
     if (how < 0) return how;
     (void)qvz_coder_rcp_one_step_ok();
     hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_code_records<true, 16, 1>));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_code_records<16, 1>));
     (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_model_ranks<false, false, true>));
     return QVZ_OK;
 }
 
-// The quantizer as the pipeline's first stage (round 4): one launch per coder segment, for exactly the reads that segment's model
-// kernel needs (qvz_quantize_launch), on a stream of its own - quantizer of segment i + 1 beside the model kernel of segment i beside
-// the coder kernel of segment i - 1. The quantizer's ~20 ms at 100M x 150 and most of the wait for the first model kernels then lie
-// beside the coder kernels, which bound the phase and do not care what else the chip runs (107 ms alone and beside the model kernel).
-extern "C" int qvz_hip_quantize_encode_planes(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t columns, uint64_t ld,
-                                              uint32_t clusters, const uint16_t *d_ct, const uint16_t *d_qs, const uint8_t *d_draws,
-                                              uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
-                                              uint64_t ld_out, double *d_err, int32_t *d_status, const qvz_codebook_t *const *cbs,
-                                              uint32_t shards, const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard,
-                                              uint64_t *h_sizes, void *d_work, uint64_t work_bytes, void *stream) {
-    const QvzQuantArgs a = {d_sym, d_labels, n, columns, ld, clusters, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status};
-    const int rc = qvz_quantize_check(a);
-    if (rc) return rc;
-    if (!d_qi || !d_st) return qvz_set_error(QVZ_E_ARG, "the coder needs the quantizer's index and state planes");
-    return encode_planes_impl(false, d_qi, d_st, ld_out, d_labels, n, columns, clusters, cbs, shards, h_bounds, d_out, cap_per_shard, h_sizes,
-                              d_work, work_bytes, stream, &a);
-}
-
-static thread_local double g_planes_quant_ms = 0.0;             // quantizer launches of the calling thread's last fused call
-extern "C" double qvz_hip_encode_planes_last_quant_ms(void) { return g_planes_quant_ms; }
-
 static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st, uint64_t ld, const uint8_t *d_labels, uint64_t n,
                               uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                               const uint64_t *h_bounds, uint8_t *d_out, uint64_t cap_per_shard, uint64_t *h_sizes,
-                              void *d_work, uint64_t work_bytes, void *stream, const QvzQuantArgs *qz) {
+                              void *d_work, uint64_t work_bytes, void *stream) {
     if (((!d_qi || !d_st || !d_out) && !dry) || !n || !columns || !clusters || !shards || !h_sizes || ld < n || (ld & 3))
         return qvz_set_error(QVZ_E_ARG, "bad plane-coder arguments");
     if (h_bounds) {                                              // the caller's cut of these n reads (a device's part of a larger file)
@@ -2204,7 +1613,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     double t_first_launch = 0.0, t_enqueued = 0.0, t_synced = 0.0, t_tables = 0.0, t_work = 0.0, t_area = 0.0;
     uint32_t spin_us = 0;
     bool odd_call = false;
-    const int coder_prio = getenv("QVZ_CODER_PRIO") ? atoi(getenv("QVZ_CODER_PRIO")) : 1;   // development knob: 0 = the coder waves issue at normal priority
+    const int coder_prio = 1;                                    // the chain waves issue ahead of the throughput kernels that share their CU
     hipStream_t st = (hipStream_t)stream;
     const uint32_t Cx = columns + (clusters > 1 ? (uint32_t)QVZ_CID_SLOTS : 0u);   // record positions per read (k_model_ranks)
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
@@ -2227,16 +1636,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     int32_t status = 0;
     const size_t offn = (size_t)clusters * columns * 2 * A;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read incl. pad, streams padded to 64 (rec_index)
-    // packed 8-byte records (the division on the coder's side) unless QVZ_CODER_RECORDS=16 asks for
-    // the pairs of doubles of rounds 1-3 (development knob: the tests run both, the streams are the same bytes)
-    const bool rec8 = !(getenv("QVZ_CODER_RECORDS") && atoi(getenv("QVZ_CODER_RECORDS")) == 16);
-    const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * (rec8 ? sizeof(PRec) : sizeof(Record));  // record bytes for one read of every stream
-    // symbols per barrier of the coder workgroup: QVZ_CODER_BLOCK=8|16 (development knob; 16 needs packed records)
-    const int cr_nb = rec8 && !(getenv("QVZ_CODER_BLOCK") && atoi(getenv("QVZ_CODER_BLOCK")) == 8) ? 16 : 8;
-    const bool one_step = rec8 && qvz_coder_rcp_one_step_ok() == 1;   // (hardware reciprocal good enough for one Newton step: checked once per device)
-    const void *const cr_fn = !rec8 ? reinterpret_cast<const void *>(&k_code_records<false, 8, 2>)
-                              : cr_nb == 16 ? (one_step ? reinterpret_cast<const void *>(&k_code_records<true, 16, 1>) : reinterpret_cast<const void *>(&k_code_records<true, 16, 2>))
-                                            : (one_step ? reinterpret_cast<const void *>(&k_code_records<true, 8, 1>) : reinterpret_cast<const void *>(&k_code_records<true, 8, 2>));
+    // packed 8-byte records, the division on the coder's side; 16 symbols per barrier of the coder workgroup
+    const uint64_t per_read = (uint64_t)((shards + 63) & ~63u) * Cp * sizeof(PRec);  // record bytes for one read of every stream
+    const bool one_step = qvz_coder_rcp_one_step_ok() == 1;      // (hardware reciprocal good enough for one Newton step: checked once per device)
+    const void *const cr_fn = one_step ? reinterpret_cast<const void *>(&k_code_records<16, 1>) : reinterpret_cast<const void *>(&k_code_records<16, 2>);
     uint64_t seg_reads = 0, seg_lo = 0;
 
     // Slices for k_model_ranks: the tables of one (column, cluster) packed back to back, coff[slice][quantizer] = word
@@ -2256,9 +1659,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     uint32_t *d_cgmap = nullptr;
     uint64_t *d_cstart = nullptr;
     bool overlap = false;
-    hipStream_t s_model = nullptr, s_coder = nullptr, s_quant = nullptr;
-    std::vector<hipEvent_t> evq;                                // fused call: per segment, the quantizer launches' start and end
-    int32_t *d_route = nullptr;
+    hipStream_t s_model = nullptr, s_coder = nullptr;
     bool own_streams = true;                                    // false: the device's kept pair (not destroyed here)
     hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> evs;                                // per segment: model start, model end, coder start, coder end
@@ -2289,14 +1690,12 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         }
         h_colbase[nslices] = (uint32_t)h_slices.size();
         slice_cap = (slice_cap + 3) & ~3u;
-        const char *mk = getenv("QVZ_MODEL_KERNEL");             // development knob: "columns" forces the lane-per-column kernel
-        if (fits && !(mk && strcmp(mk, "columns") == 0)) {
+        if (fits && !qvz_env_flag("QVZ_CODER", "columns")) {      // (test hook: the lane-per-column kernel, what tables beyond the LDS get)
             // W = columns (waves) per workgroup: records leave as W * 16-byte runs. W = 4 wherever a workgroup fits
             // beside k_code_records' 32 KB of LDS (measured with three clusters, where LDS holds one such workgroup
             // per CU: W = 4 0.40 s, W = 2 0.42 s, W = 1 0.67 s for the model kernels; W = 8 never paid).
-            const char *we = getenv("QVZ_MODEL_WAVES");          // development knob: force W (a power of two <= 16)
-            auto need_cap = [&](uint32_t w, uint32_t cap) {      // records (16 bytes: list rows in their padding; packed: 1 KB of their own), per wave masks + tables + offsets
-                return (rec8 ? (size_t)64 * (w + 1) * sizeof(PRec) + (clusters > 1 ? 1024u : 0u) : (size_t)64 * (w + 1) * sizeof(Record)) + (size_t)w * (3 * cap + 2 * A) * 4;
+            auto need_cap = [&](uint32_t w, uint32_t cap) {      // packed records (+ 1 KB of list rows with several clusters), per wave masks + tables + offsets
+                return (size_t)64 * (w + 1) * sizeof(PRec) + (clusters > 1 ? 1024u : 0u) + (size_t)w * (3 * cap + 2 * A) * 4;
             };
             auto need_of = [&](uint32_t w) { return need_cap(w, slice_cap); };
             const size_t budget = 160 * 1024 - 32 * 1024;
@@ -2307,19 +1706,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
                 rk_waves = w; rk_lds = need;
                 break;
             }
-            // Packed records shrank the transposition buffer, and at 100M x 150 -f 0.5 a FOURTH workgroup then fits a CU (4 x 40.4 KB):
-            // the model kernel gains (110 against 122 ms busy) but fills every CU to the brim the moment it starts, and the coder
-            // kernel of the segment before - released across queues at the same moment - finds room late or not at all from step
-            // to step (coder phase 138 .. 190 ms, steps of 185 .. 236 ms; a 1.5 ms head start for the coder cures it as well).
-            // Three to a CU is steady: 182.0-183.0 ms per step. So a fourth is kept out by asking for a little more than a quarter.
-            // (With 16 symbols per coder block - 58 KB of LDS for a coder workgroup, which a brim-full CU could never host anyway and
-            // the head start therefore secures first - four to a CU are steady too and the better choice: 172.9 against 180.5 ms.)
-            if (cr_nb == 8 && rk_waves && rk_lds * 4 <= (size_t)160 * 1024 && !getenv("QVZ_MODEL_LDS_PAD")) rk_lds = (size_t)160 * 1024 / 4 + 512;
-            if (getenv("QVZ_MODEL_LDS_PAD")) rk_lds += (size_t)atoi(getenv("QVZ_MODEL_LDS_PAD"));   // development knob: occupancy experiments
-            if (we) {
-                const uint32_t w = (uint32_t)atoi(we);
-                if (w >= 1 && w <= 16 && !(w & (w - 1)) && need_of(w) <= 160 * 1024) { rk_waves = w; rk_lds = need_of(w); }
-            }
+            // (At 100M x 150 -f 0.5 four such workgroups fit a CU, 4 x 40.4 KB: steady beside the 16-symbol coder workgroup, whose 58 KB a
+            // brim-full CU could never host anyway and which its head start therefore secures first.)
             // Several clusters - the model kernels bound the phase -: the launch's LDS per workgroup is sized by the LARGEST slice
             // of any (column, cluster), and at 100M x 150 -c 3 -r 1.0 that is an outlier (920 words; 94 % of the 451 slices have
             // 740 or fewer, half of them 364 or fewer): 50 KB, three workgroups to a CU, two beside a coder workgroup. So the column
@@ -2327,8 +1715,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
             // LDS size (`cgmap` tells a workgroup which column group it serves). The class bounds are where one more workgroup fits:
             // a quarter of a CU's 160 KB (four on a CU without a coder workgroup - the 128 registers of the list walk allow no
             // fifth), and a third / a quarter of what a coder workgroup leaves.
-            const char *mc = getenv("QVZ_MODEL_CLASSES");       // development knob: 0 = never, 1 = with one cluster as well
-            if (rk_waves && (clusters > 1 || (mc && atoi(mc) == 1)) && !(mc && atoi(mc) == 0)) {
+            if (rk_waves && clusters > 1) {
                 const uint32_t W = rk_waves, ncg = (Cp + W - 1) / W;
                 std::vector<uint32_t> capw((size_t)ncg * W, 4);                      // words of the largest slice a wave meets (over the clusters)
                 std::vector<size_t> need(ncg, 0);                                    // LDS bytes of the column group's workgroup
@@ -2365,7 +1752,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
                     for (uint32_t e = i; e < j; ++e)
                         for (uint32_t w = 0; w < W; ++w) if (capw[(size_t)order[e] * W + w] > cap) cap = capw[(size_t)order[e] * W + w];
                     // (sorted: the class's first needs the most)
-                    rk_classes.push_back({i * (1 + W), j - i, cap, need[order[i]] + (getenv("QVZ_MODEL_LDS_PAD") ? (size_t)atoi(getenv("QVZ_MODEL_LDS_PAD")) : 0)});
+                    rk_classes.push_back({i * (1 + W), j - i, cap, need[order[i]]});
                     i = j;
                 }
                 for (uint32_t i = 0; i < ncg; ++i) {                                  // a launch's entries: column group, then every wave's (offset | words << 16)
@@ -2415,14 +1802,13 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
     if (seg_reads > longest) seg_reads = longest;
     {
-        const char *ov = getenv("QVZ_CODER_OVERLAP");            // development knob: "0" keeps everything on the caller's stream
         const uint64_t half = (work_bytes / 2 / per_read) & ~(uint64_t)63;
-        if (!(ov && atoi(ov) == 0) && longest >= 1024 && half >= 64) {
-            const uint64_t div = getenv("QVZ_CODER_SEG_DIV") && atoi(getenv("QVZ_CODER_SEG_DIV")) > 0 ? (uint64_t)atoi(getenv("QVZ_CODER_SEG_DIV")) : (clusters > 1 ? 3 : 8);   // (the variable: development knob)
+        if (longest >= 1024 && half >= 64) {
+            const uint64_t div = clusters > 1 ? 3 : 8;
             uint64_t target = ((longest + div - 1) / div + 63) & ~(uint64_t)63;
             // (short streams - 10M x 150 over 8192 streams: 1224 reads - are not cut below 512 reads a segment: an eighth would be
             // 192 reads, ten kernel pairs of a millisecond each whose starts and table saves outweigh the shorter fill: 17.1 -> 16.1 ms)
-            if (!(getenv("QVZ_CODER_SEG_DIV")) && target < 512) target = 512;
+            if (target < 512) target = 512;
             seg_reads = half < target ? half : target;
             overlap = true;
         }
@@ -2433,13 +1819,11 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_prof), z, sizeof(z));
         { unsigned long long zc[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cr_prof), zc, sizeof(zc)); }
-        const int e = getenv("QVZ_RK_EXP") ? atoi(getenv("QVZ_RK_EXP")) : 0;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_exp), &e, sizeof(e));
     }
 #endif
     if (getenv("QVZ_CODER_DEBUG"))
-        fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu, %d-byte records, %d symbols per coder block\n",
-                shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size(), rec8 ? 8 : 16, cr_nb);
+        fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu\n",
+                shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size());
     if (getenv("QVZ_CODER_DEBUG")) {                             // the slices' sizes (words), largest first
         std::vector<uint32_t> sz;
         for (uint32_t sl = 0; sl < nslices; ++sl) sz.push_back(h_colbase[sl + 1] - h_colbase[sl]);
@@ -2452,7 +1836,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
     TRY(area.get((void **)&d_status, sizeof(int32_t)));
     TRY(area.get((void **)&d_cs, shards * sizeof(CoderState)));
-    if (qz) TRY(area.get((void **)&d_route, 2 * sizeof(int32_t)));
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     if (rk_waves) {
@@ -2470,8 +1853,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
                 for (const RkClass &c : rk_classes)
                     fprintf(stderr, "  model kernel class: %u column groups, slices of up to %u words, up to %zu B of LDS per workgroup\n", c.count, c.cap, c.lds);
         }
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
-        TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     } else {                                                     // lane-per-column kernel with per-stream arenas in HBM
@@ -2482,24 +1863,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipMemcpyAsync(d_off, h_off, offn * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, words, shards, d_arena);
     }
-    coder_segments(longest, seg_reads, overlap, segs, getenv("QVZ_CODER_FIRST_DIV") && atoi(getenv("QVZ_CODER_FIRST_DIV")) > 0 ? (uint32_t)atoi(getenv("QVZ_CODER_FIRST_DIV")) : (clusters > 1 ? 1u : 4u));   // (the variable: development knob)
-    if (overlap && getenv("QVZ_CODER_SEGS")) {                   // development knob: the cut given, "reads,reads,..." (multiples of 64, none above the buffer's)
-        std::vector<std::pair<uint64_t, uint64_t>> given;
-        uint64_t lo = 0;
-        bool fine = true;
-        for (const char *p = getenv("QVZ_CODER_SEGS"); *p && lo < longest;) {
-            char *end = nullptr;
-            uint64_t len = strtoull(p, &end, 10);
-            if (end == p) { fine = false; break; }
-            p = *end == ',' ? end + 1 : end;
-            if (lo + len > longest) len = longest - lo;
-            if (!len || len > seg_reads || ((len & 63) && lo + len < longest)) { fine = false; break; }
-            given.push_back({lo, len});
-            lo += len;
-        }
-        if (fine && lo == longest) segs = given;
-        else fprintf(stderr, "qvz_hip_encode_planes: QVZ_CODER_SEGS does not cut %llu reads into segments of at most %llu (multiples of 64): ignored\n", (unsigned long long)longest, (unsigned long long)seg_reads);
-    }
+    coder_segments(longest, seg_reads, overlap, segs, clusters > 1 ? 1u : 4u);
     nseg = (uint32_t)segs.size();
     if (rk_waves && clusters > 1) {                              // read lists per (stream, cluster) and where the segments cut them
         std::vector<uint32_t> h_bounds(nseg + 1);
@@ -2523,12 +1887,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     evs.assign((size_t)nseg * 4, nullptr);
     for (size_t i = 0; i < evs.size(); ++i) TRY(hipEventCreate(&evs[i]));
     g_planes_ms[0] = g_planes_ms[1] = 0.0;
-    g_planes_quant_ms = 0.0;
-    if (qz) {
-        evq.assign((size_t)nseg * 2, nullptr);
-        for (size_t i = 0; i < evq.size(); ++i) TRY(hipEventCreate(&evq[i]));
-    }
-    s_model = s_coder = s_quant = st;
+    s_model = s_coder = st;
     if (overlap) {
         // The two streams are made once per device and kept: the runtime spreads streams over a handful of hardware queues
         // (four by default) and a queue runs its kernels in order, so a pair of streams made afresh for every call lands,
@@ -2537,25 +1896,22 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         // (A high-priority queue for the coder kernel was tried: its segments got slower, 225 ms against 167 ms of kernel
         // time per step with three clusters at 100M x 150, and the step with them.)
         {
-            hipStream_t pair[2] = {nullptr, nullptr}, third = nullptr;
-            const int how = coder_stream_pair(pair, qz ? &third : nullptr);   // 1: the device's kept streams, 0: none kept for this ordinal, < 0: error (message set)
+            hipStream_t pair[2] = {nullptr, nullptr};
+            const int how = coder_stream_pair(pair);   // 1: the device's kept streams, 0: none kept for this ordinal, < 0: error (message set)
             if (how < 0) { rc = how; goto done; }
             if (how == 1) {
                 s_model = pair[0];
                 s_coder = pair[1];
-                if (qz) s_quant = third;
                 own_streams = false;
             } else {
                 TRY(hipStreamCreateWithFlags(&s_model, hipStreamNonBlocking));
                 TRY(hipStreamCreateWithFlags(&s_coder, hipStreamNonBlocking));
-                if (qz) TRY(hipStreamCreateWithFlags(&s_quant, hipStreamNonBlocking));
             }
         }
         TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         TRY(hipEventRecord(ev_start, st));                       // uploads and whatever the caller queued before us
         TRY(hipStreamWaitEvent(s_model, ev_start, 0));
         TRY(hipStreamWaitEvent(s_coder, ev_start, 0));
-        if (qz) TRY(hipStreamWaitEvent(s_quant, ev_start, 0));
     }
     // The coder kernel is the longer of the two once they overlap, and what slows it is the model waves it shares its CUs
     // with (0.11 s alone, 0.16-0.17 s beside three model workgroups per CU, 0.15 s beside two). So when three or more
@@ -2568,7 +1924,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         const size_t lds_cu = 160 * 1024, beside = (lds_cu - fa.sharedSizeBytes) / rk_lds;
         if (beside >= 3) cr_pad = ((lds_cu - fa.sharedSizeBytes - beside * rk_lds) + 1024) & ~(size_t)255;
     }
-    if (getenv("QVZ_CODER_LDS_PAD")) cr_pad = (size_t)atoi(getenv("QVZ_CODER_LDS_PAD"));   // development knob
     if (cr_pad) TRY(hipFuncSetAttribute(cr_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cr_pad));
     if (dry) {                                                   // qvz_hip_encode_planes_prepare: everything is in place for the call that codes
         TRY(hipStreamSynchronize(st));
@@ -2579,7 +1934,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     // LDS between them slowly (three clusters); with one cluster the model kernel's workgroups - since they ask for their
     // tables and their first bytes at once - fill the chip faster than 128 coder workgroups find their CUs: at 10M x 150 the coder
     // kernels took 15 or 18-20 ms from step to step with 40 us, 15.5 with 200 (step 43-44 -> 41.7-42.1 ms; 100M x 150: no change)
-    spin_us = getenv("QVZ_CODER_HEADSTART_US") ? (uint32_t)atoi(getenv("QVZ_CODER_HEADSTART_US")) : (clusters > 1 ? 40u : 200u);   // (the variable: development knob)
+    spin_us = clusters > 1 ? 40u : 200u;
     for (uint32_t i = 0; i < nseg; ++i) {
         seg_lo = segs[i].first;
         const uint32_t seg_len = (uint32_t)segs[i].second;       // both kernels lay the segment's records out for this many reads
@@ -2587,25 +1942,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         const int is_first = i == 0, is_last = i + 1 == nseg;
         Record *buf = (Record *)((char *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * per_read : 0));
         hipEvent_t *e = &evs[(size_t)i * 4];
-        if (qz) {
-            // The quantizer runs one segment ahead of the model kernels, no more: its launch for segment i + 1 waits for the model
-            // kernel of segment i - 1 (it then shares the chip with model kernel i and coder kernel i - 1), and the planes a model
-            // kernel reads are complete when it starts (evq). Without the other streams: segment by segment on the caller's.
-            auto quantize = [&](uint32_t j) -> int {
-                if (overlap && j >= 2) { hipError_t qe = hipStreamWaitEvent(s_quant, evs[(size_t)(j - 2) * 4 + 1], 0); if (qe != hipSuccess) return qvz_set_error(QVZ_E_HIP, "hipStreamWaitEvent -> %s", hipGetErrorString(qe)); }
-                (void)hipEventRecord(evq[(size_t)j * 2], s_quant);
-                const int qrc = qvz_quantize_launch(*qz, nseg > 1 ? (const uint64_t *)d_first : nullptr, shards, segs[j].first, (uint32_t)segs[j].second, d_route, j == 0, s_quant);
-                if (qrc) return qrc;
-                hipError_t qe = hipEventRecord(evq[(size_t)j * 2 + 1], s_quant);
-                return qe == hipSuccess ? QVZ_OK : qvz_set_error(QVZ_E_HIP, "hipEventRecord -> %s", hipGetErrorString(qe));
-            };
-            if (!overlap) { if ((rc = quantize(i))) goto done; }
-            else {
-                if (i == 0 && (rc = quantize(0))) goto done;
-                if (i + 1 < nseg && (rc = quantize(i + 1))) goto done;
-                TRY(hipStreamWaitEvent(s_model, evq[(size_t)i * 2 + 1], 0));
-            }
-        }
         // Head start for the coder kernel of the segment before: it is released by an event of the model kernel that has
         // just ended, across queues, while the next model kernel follows that one in its own queue at once - and a model
         // kernel that has filled the CUs first leaves a coder workgroup (32 KB of LDS) no room wherever three model
@@ -2619,8 +1955,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (overlap && i >= 1 && spin_us) hipLaunchKernelGGL(k_coder_spin_us, dim3(1), dim3(64), 0, s_model, spin_us);
         TRY(hipEventRecord(e[0], s_model));
         if (rk_waves) {
-            // z: the cluster a workgroup of column positions serves - or, by default, one workgroup for all clusters of its (stream, column group) (QVZ_MODEL_CLUSTER_LOOP=0: development knob)
-            const bool zloop = !(getenv("QVZ_MODEL_CLUSTER_LOOP") && atoi(getenv("QVZ_MODEL_CLUSTER_LOOP")) == 0);
+            // one workgroup serves all clusters of its (stream, column group), one after the other (gridDim.z == 1)
             const dim3 block(64 * rk_waves);
             const size_t SK = (size_t)shards * clusters;
             // (several clusters: one launch per size class of the column groups, the largest tables first)
@@ -2630,34 +1965,27 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
                 const uint32_t cap_l = rk_classes.empty() ? slice_cap : rk_classes[ci].cap;
                 const size_t lds_l = rk_classes.empty() ? rk_lds : rk_classes[ci].lds;
                 const uint32_t *map_l = rk_classes.empty() ? nullptr : d_cgmap + rk_classes[ci].off;
-                const dim3 grid(shards, ny, zloop ? 1 : clusters);
+                const dim3 grid(shards, ny, 1);
 #define RK_ARGS(LISTS) d_qi, d_st, ld, d_labels, columns, clusters, d_first, d_coff, d_colbase, d_slices, d_save, (uint32_t)h_slices.size(), cap_l, seg_lo, \
                        seg_len, is_first, is_last, (uint32_t)__builtin_ctz(rk_waves), buf, d_status, \
                        (const uint32_t *)(LISTS ? d_clist : nullptr), (const uint64_t *)(LISTS ? d_cstart : nullptr), \
                        (const uint32_t *)(LISTS ? d_segpos + (size_t)i * SK : nullptr), (const uint32_t *)(LISTS ? d_segpos + (size_t)(i + 1) * SK : nullptr), map_l
-                if (clusters > 1 && rec8) hipLaunchKernelGGL((k_model_ranks<true, false, true>), grid, block, lds_l, s_model, RK_ARGS(true));
-                else if (clusters > 1) hipLaunchKernelGGL((k_model_ranks<true, false, false>), grid, block, lds_l, s_model, RK_ARGS(true));
-                else if (rec8) hipLaunchKernelGGL((k_model_ranks<false, false, true>), grid, block, lds_l, s_model, RK_ARGS(false));
-                else hipLaunchKernelGGL((k_model_ranks<false, false, false>), grid, block, lds_l, s_model, RK_ARGS(false));
+                if (clusters > 1) hipLaunchKernelGGL((k_model_ranks<true, false, true>), grid, block, lds_l, s_model, RK_ARGS(true));
+                else hipLaunchKernelGGL((k_model_ranks<false, false, true>), grid, block, lds_l, s_model, RK_ARGS(false));
 #undef RK_ARGS
             }
         } else {
 #define MC_ARGS d_qi, d_st, ld, d_labels, columns, clusters, d_first, shards, d_off, d_arena, words, seg_lo, seg_len, buf, d_status
-            if (clusters > 1 && rec8) hipLaunchKernelGGL((k_model_columns<true, true>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
-            else if (clusters > 1) hipLaunchKernelGGL((k_model_columns<true, false>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
-            else if (rec8) hipLaunchKernelGGL((k_model_columns<false, true>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
-            else hipLaunchKernelGGL((k_model_columns<false, false>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
+            if (clusters > 1) hipLaunchKernelGGL((k_model_columns<true>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
+            else hipLaunchKernelGGL((k_model_columns<false>), dim3(mblocks), dim3(256), 0, s_model, MC_ARGS);
 #undef MC_ARGS
         }
         TRY(hipEventRecord(e[1], s_model));
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
 #define CR_ARGS (const Record *)buf, Cx, d_first, shards, seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio
-        if (rec8 && cr_nb == 16 && one_step) hipLaunchKernelGGL((k_code_records<true, 16, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
-        else if (rec8 && cr_nb == 16) hipLaunchKernelGGL((k_code_records<true, 16, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
-        else if (rec8 && one_step) hipLaunchKernelGGL((k_code_records<true, 8, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
-        else if (rec8) hipLaunchKernelGGL((k_code_records<true, 8, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
-        else hipLaunchKernelGGL((k_code_records<false, 8, 2>), dim3((shards + 63) / 64), dim3(256), cr_pad, s_coder, CR_ARGS);
+        if (one_step) hipLaunchKernelGGL((k_code_records<16, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        else hipLaunchKernelGGL((k_code_records<16, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
 #undef CR_ARGS
         TRY(hipEventRecord(e[3], s_coder));
     }
@@ -2673,8 +2001,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         hipEvent_t ev_done = nullptr;
         TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
         hipError_t qe = hipEventRecord(ev_done, st);
-        const char *wk = getenv("QVZ_CODER_WAIT");               // development knob: "block" = hipStreamSynchronize as before
-        if (wk && strcmp(wk, "block") == 0 && qe == hipSuccess) qe = hipStreamSynchronize(st);
         while (qe == hipSuccess) {
             qe = hipEventQuery(ev_done);
             if (qe != hipErrorNotReady) break;
@@ -2709,15 +2035,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         TRY(hipEventElapsedTime(&ta, evs[(size_t)i * 4], evs[(size_t)i * 4 + 1]));
         TRY(hipEventElapsedTime(&tb, evs[(size_t)i * 4 + 2], evs[(size_t)i * 4 + 3]));
         g_planes_ms[0] += ta; g_planes_ms[1] += tb;
-        if (qz) {
-            float tq = 0.f, q0 = 0.f;
-            TRY(hipEventElapsedTime(&tq, evq[(size_t)i * 2], evq[(size_t)i * 2 + 1]));
-            g_planes_quant_ms += tq;
-            if (odd_call || getenv("QVZ_CODER_DEBUG")) {
-                (void)hipEventElapsedTime(&q0, evs[0], evq[(size_t)i * 2]);   // (negative where the quantizer started first: an error, the 0 stays)
-                fprintf(stderr, "  segment %u: quantizer %.2f ms, started %.2f ms after the first model kernel's start\n", i, tq, q0);
-            }
-        }
         if (odd_call || getenv("QVZ_CODER_DEBUG")) {             // the segment's kernels on the time line of the call
             float m0 = 0.f, c0 = 0.f;
             TRY(hipEventElapsedTime(&m0, evs[0], evs[(size_t)i * 4]));
@@ -2737,7 +2054,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         fprintf(stderr, "k_code_records cycles per block of symbols, busy/waiting: interval %.0f/%.0f  bits %.0f/%.0f  bytes %.0f/%.0f  loader %.0f/%.0f\n",
                 cr[0] / nb, cr[1] / nb, cr[2] / nb, cr[3] / nb, cr[4] / nb, cr[5] / nb, cr[6] / nb, cr[7] / nb);
         fprintf(stderr, "  cycles of that waiting spent in s_waitcnt lgkmcnt(0) before the barrier: interval %.0f  bits %.0f  bytes %.0f  loader %.0f\n", cr[9] / nb, cr[10] / nb, cr[11] / nb, cr[12] / nb);
-        if (rec8) {
+        {
             uint32_t simd[8] = {0};
             (void)hipMemcpyFromSymbol(simd, HIP_SYMBOL(g_cr_simd), sizeof(simd));
             fprintf(stderr, "  second loader %.0f/%.0f; SIMD of the workgroup's waves 0..4 (loader, interval, bits, bytes, loader): %u %u %u %u %u\n", cr[13] / nb, cr[14] / nb,
@@ -2756,8 +2073,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
 done:
 #undef TRY
     for (size_t i = 0; i < evs.size(); ++i) if (evs[i]) (void)hipEventDestroy(evs[i]);
-    for (size_t i = 0; i < evq.size(); ++i) if (evq[i]) (void)hipEventDestroy(evq[i]);
-    if (s_quant && s_quant != st) { (void)hipStreamSynchronize(s_quant); if (own_streams) (void)hipStreamDestroy(s_quant); }
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (s_model && s_model != st) { (void)hipStreamSynchronize(s_model); if (own_streams) (void)hipStreamDestroy(s_model); }
     if (s_coder && s_coder != st) { (void)hipStreamSynchronize(s_coder); if (own_streams) (void)hipStreamDestroy(s_coder); }

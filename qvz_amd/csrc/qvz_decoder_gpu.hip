@@ -257,14 +257,12 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     hipStream_t st = (hipStream_t)stream;
     // A workgroup is one wave (its LDS - staging, context table - lets one or two live on a CU). 8192 streams as 128 waves of 64 lanes
     // leave every other CU idle; as 256 waves of 32 lanes every CU has one and the decode of 100M x 150 takes 3.77 instead of 4.05 s
-    // (fewer lanes than that need more workgroups than there are CUs and run in rounds: 16 lanes 6.5 s). QVZ_DECODER_LANES: development knob.
+    // (fewer lanes than that need more workgroups than there are CUs and run in rounds: 16 lanes 6.5 s).
     uint32_t dec_lanes = 64;
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
             (shards + 31) / 32 <= (uint32_t)cus) dec_lanes = 32;
-        if (getenv("QVZ_DECODER_LANES")) dec_lanes = (uint32_t)atoi(getenv("QVZ_DECODER_LANES"));
-        if (dec_lanes < 1 || dec_lanes > 64) dec_lanes = 64;
     }
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
     if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))

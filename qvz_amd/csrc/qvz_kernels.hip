@@ -350,8 +350,7 @@ extern "C" int qvz_hip_kmeans_assign(const uint8_t *d_sym, uint64_t n, uint32_t 
     uint64_t n4 = (n + 3) / 4;
     dim3 grid((unsigned)((n4 + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-    const char *old_k = getenv("QVZ_KMEANS_KERNEL");             // development knob: "4" keeps the 4-reads-per-thread kernels
-    if (k >= 2 && k <= 4 && !(old_k && atoi(old_k) == 4)) {
+    if (k >= 2 && k <= 4) {
         dim3 g16((unsigned)((n + 4095) / 4096));
         const size_t lds = (size_t)c * sizeof(uint32_t);
         if (k == 2) hipLaunchKernelGGL(k_kmeans_assign16<2>, g16, dim3(256), lds, st, d_sym, n, c, ld, d_means, d_labels, d_counts);
@@ -499,8 +498,7 @@ extern "C" int qvz_hip_kmeans_accumulate(const uint8_t *d_sym, const uint8_t *d_
     dim3 grid(c, slabs);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(d_acc);
-    const char *old_k = getenv("QVZ_KMEANS_KERNEL");             // development knob: "4" keeps the column-per-block kernel
-    if (k >= 2 && k <= 4 && !(old_k && atoi(old_k) == 4)) {
+    if (k >= 2 && k <= 4) {
         dim3 g16((unsigned)((n + 4095) / 4096));
         const size_t lds = (size_t)k * c * sizeof(uint32_t);
         if (k == 2) hipLaunchKernelGGL(k_kmeans_accum16<2>, g16, dim3(256), lds, st, d_sym, d_labels, n, c, ld, acc);
@@ -710,8 +708,7 @@ extern "C" int qvz_hip_kmeans_step(const uint8_t *d_sym, uint64_t n, uint32_t c,
     int rc = check_matrix(n, c, ld);
     if (rc) return rc;
     if (k == 0 || k > 255) return qvz_set_error(QVZ_E_ARG, "k=%u out of range 1..255", k);
-    const char *knob = getenv("QVZ_KMEANS_FUSED");               // development knob: "0" keeps the two-pass kernels
-    if (k < 2 || k > 8 || c > 16 * KMS_NT || (knob && atoi(knob) == 0)) {
+    if (k < 2 || k > 8 || c > 16 * KMS_NT) {                     // shapes the one-pass kernel does not take: assignment, then sums
         rc = qvz_hip_kmeans_assign(d_sym, n, c, ld, k, d_means, d_labels, d_counts, stream);
         if (rc) return rc;
         return qvz_hip_kmeans_accumulate(d_sym, d_labels, n, c, ld, k, d_acc, stream);
@@ -1226,11 +1223,6 @@ struct ScratchLock {                // RAII: lock the current device's scratch f
     }
 };
 
-static unsigned env_uint(const char *name, unsigned dflt) {
-    const char *v = getenv(name);
-    return v && *v ? (unsigned)strtoul(v, nullptr, 10) : dflt;
-}
-
 extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, uint64_t n, uint32_t c, uint64_t ld,
                                 uint32_t k, uint32_t *d_cnt, void *stream) {
     int rc = check_matrix(n, c, ld);
@@ -1241,7 +1233,10 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
     hipStream_t st = (hipStream_t)stream;
 
     // tile side from a device-side sample of the data (one tiny launch + a 4-byte read back)
-    unsigned AA = env_uint("QVZ_PMF_AA", 0);
+    // QVZ_PMF (test hook, "key=number,..."): aa = side of the LDS tile instead of the sampled one, algo = 0 the two-read kernel / 1
+    // the column-walking one whatever the size, q = its groups per thread - the choices the sizes below make, at sizes a test can afford
+    double opt = 0.0;
+    unsigned AA = qvz_env_number("QVZ_PMF", "aa", &opt) ? (unsigned)opt : 0u;
     if (AA == 0) {
         ScratchLock lk(st);
         if (lk.rc) return lk.rc;
@@ -1260,33 +1255,27 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
 
     const unsigned lds_budget = 160 * 1024;
     // The walking kernel needs >= ~1000 slabs of 16384 rows to fill the chip; smaller inputs use the two-read kernel.
-    const unsigned algo = env_uint("QVZ_PMF_ALGO", n >= 1000ull * 16384 ? 1 : 0);
+    const unsigned algo = qvz_env_number("QVZ_PMF", "algo", &opt) ? (unsigned)opt : (n >= 1000ull * 16384 ? 1u : 0u);
     if (algo >= 1) {
         // column-walking kernel: slabs of 16384*Q rows, G column tiles x R replicas of the counters in LDS
         for (uint32_t kb = 0; kb < k; kb += PMF_KT) {
             const uint32_t kt = (k - kb) < PMF_KT ? (k - kb) : PMF_KT;
             const size_t tile_bytes = (size_t)kt * AA * AA * sizeof(uint32_t);
             // The kernel's ~96 VGPRs leave room for one 1024-thread block per CU, so a block may use the whole LDS.
-            // Measured (tools/tune_pmf2.py, 100M x 150, 42 symbols): G = 3 column tiles x R = 5 replicas is the best
-            // (4.30 ms; R = 5, G = 2: 4.43; R = 3, G = 3: 4.59; more than 5 replicas buy nothing).
-            unsigned R = env_uint("QVZ_PMF_R", 0), G = env_uint("QVZ_PMF_G", 0);
-            if (G == 0) G = 3;
-            if (R == 0) {
-                R = (unsigned)(lds_budget / (G * tile_bytes + 4));
-                if (R > 5) R = 5;
-                if (R < 1) R = 1;
-            }
-            if (G < 1) G = 1;
-            if (G > c) G = c;
-            while (R > 1 && (size_t)R * (G * tile_bytes + 4) > lds_budget) R -= 1;
+            // Measured (100M x 150, 42 symbols): G = 3 column tiles x R = 5 replicas is the best (4.30 ms; R = 5, G = 2: 4.43;
+            // R = 3, G = 3: 4.59; more than 5 replicas buy nothing; three clusters, two replicas of three tiles: the same within 0.1 ms
+            // for any (G, R) the LDS holds - what is left there is the flush, three times the global atomics).
+            unsigned G = c < 3 ? c : 3;
+            unsigned R = (unsigned)(lds_budget / (G * tile_bytes + 4));
+            if (R > 5) R = 5;
+            if (R < 1) R = 1;
             while (G > 1 && (size_t)R * (G * tile_bytes + 4) > lds_budget) G -= 1;
             const size_t lds = (size_t)R * (G * tile_bytes + 4);
-            unsigned Q = env_uint("QVZ_PMF_Q", 0);
-            // bigger slabs = fewer blocks = fewer flush atomics; six groups per thread is what 128 VGPRs hold (k = 1)
-            // with labels (k > 1) kept in registers two groups are the limit: four spill (100M x 150, k = 3: 16.9 ms against 7.2)
-            // (k > 1, labels re-read per column: four groups 6.4 ms, two 7.1, six 9.0 at 100M x 150, k = 3)
-            // (k = 2 .. 4 with the labels packed to 2 bits in registers - QVZ_PMF_LABELS=bytes keeps the byte path -: six groups again)
-            const bool packed = k > 1 && k <= 4 && !(getenv("QVZ_PMF_LABELS") && strcmp(getenv("QVZ_PMF_LABELS"), "bytes") == 0);
+            // bigger slabs = fewer blocks = fewer flush atomics; six groups per thread is what 128 VGPRs hold (k = 1, and k = 2 .. 4 with
+            // the labels packed to 2 bits in registers); more clusters: the label bytes are asked for again in every column (four
+            // groups 6.4 ms, two 7.1, six 9.0 at 100M x 150, k = 3 before the packed form)
+            const bool packed = k > 1 && k <= 4;
+            unsigned Q = qvz_env_number("QVZ_PMF", "q", &opt) ? (unsigned)opt : 0u;
             if (Q == 0) Q = ((k == 1 || packed) && n >= 768ull * 98304) ? 6 : (n >= 768ull * 65536) ? 4 : (n >= 768ull * 32768 ? 2 : 1);
             if (Q != 1 && Q != 2 && Q != 4 && Q != 6) Q = 4;
             const uint64_t slab = (uint64_t)PMF_WALK_T * 16 * Q;
@@ -1315,22 +1304,18 @@ extern "C" int qvz_hip_pmf_hist(const uint8_t *d_sym, const uint8_t *d_labels, u
         const uint32_t kt = (k - kb) < PMF_KT ? (k - kb) : PMF_KT;
         const size_t tile_bytes = ((size_t)kt * AA * AA + 1) * sizeof(uint32_t);
         // replicas: as many as fit in half the LDS (two 1024-thread blocks per CU = full occupancy), at most 16
-        unsigned R = env_uint("QVZ_PMF_R", 0);
-        if (R == 0) {
-            R = (unsigned)((lds_budget / 2) / tile_bytes);
-            if (R > 16) R = 16;
-        }
+        unsigned R = (unsigned)((lds_budget / 2) / tile_bytes);
+        if (R > 16) R = 16;
         if (R < 1) R = 1;
         while (R > 1 && R * tile_bytes > lds_budget) R -= 1;
         const size_t lds = R * tile_bytes;
-        unsigned T = env_uint("QVZ_PMF_T", 1024);
-        if (T != 256 && T != 512 && T != 1024) T = 1024;
+        const unsigned T = 1024;
         unsigned per_cu = (unsigned)(lds_budget / lds);
         if (per_cu * T > 2048) per_cu = 2048 / T;
         if (per_cu < 1) per_cu = 1;
         const uint64_t chunks = (n + (uint64_t)T * 16 - 1) / ((uint64_t)T * 16);
         // enough blocks for several rounds per CU so the tail is short, few enough that the flush stays negligible
-        unsigned slabs = env_uint("QVZ_PMF_SLABS", (256 * per_cu * 4 + c - 1) / c);
+        unsigned slabs = (256 * per_cu * 4 + c - 1) / c;
         if (slabs < 1) slabs = 1;
         if (slabs > chunks) slabs = (unsigned)chunks;
         dim3 grid(c, slabs);
@@ -1707,8 +1692,6 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
     uint32_t TR = (DT_MAX_WORDS * 4 - 8) / c;                    // reads per tile: TR*c draws fit the LDS buffer
     TR &= ~3u;
     if (TR > 256) TR = 256;
-    if (getenv("QVZ_DRAWS_TR") && (uint32_t)atoi(getenv("QVZ_DRAWS_TR")) >= 4 && (uint32_t)atoi(getenv("QVZ_DRAWS_TR")) < TR)   // development knob
-        TR = (uint32_t)atoi(getenv("QVZ_DRAWS_TR")) & ~3u;
     if (TR < 4) return qvz_set_error(QVZ_E_ARG, "c=%u too wide for the draw transposer", c);
     const size_t tile_lds = ((size_t)TR * c / 4 + 4) * sizeof(uint32_t);   // what a tile needs, not the 60 KB the widest may: more tiles per CU
     // Reads per generator pass. A generator thread runs 8192 words (218 reads at C = 150) serially, so a pass of 2^22 reads
@@ -1722,7 +1705,7 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
     { uint64_t a = c, b = per_chunk; while (b) { const uint64_t t = a % b; a = b; b = t; } per_chunk /= a; }
     uint64_t unit = per_chunk;                                       // lcm(TR, per_chunk)
     { uint64_t a = TR, b = per_chunk; while (b) { const uint64_t t = a % b; a = b; b = t; } unit = TR / a * per_chunk; }
-    const uint64_t chunk = 1ull << (getenv("QVZ_WELL_PASS_LOG2") ? atoi(getenv("QVZ_WELL_PASS_LOG2")) : 24);
+    const uint64_t chunk = 1ull << 24;
     const uint64_t chunk_reads = chunk / unit ? (chunk / unit) * unit : unit;
     const uint64_t need_lin = (n < chunk_reads ? ((n + TR - 1) / TR) * TR : chunk_reads) * c / 4 + 8;
     const uint64_t need = well_phys(need_lin, WELL_PAD) + WELL_PAD + 8;                        // the chunks lie WELL_PAD words apart
@@ -1785,22 +1768,13 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
                                                   uint64_t ldd, const double *__restrict__ dist,
                                                   uint8_t *__restrict__ qv_out, uint8_t *__restrict__ qi_out,
                                                   uint8_t *__restrict__ st_out, uint64_t ldo, double *__restrict__ err_out,
-                                                  int32_t *__restrict__ status, const int32_t *__restrict__ route,
-                                                  const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len) {
+                                                  int32_t *__restrict__ status, const int32_t *__restrict__ route) {
     __shared__ double sdist[QVZ_A * QVZ_A];
     if (route[1] == QZ_ROUTE_LDS) return;                       // the other kernel's job (qvz_hip_quantize: routing without a host round trip)
     for (uint32_t i = threadIdx.x; i < QVZ_A * QVZ_A; i += 256) sdist[i] = dist[i];
     __syncthreads();
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint64_t i0 = 4 * t;
-    if (first) {                                                 // one segment of every stream (see k_quantize_lds)
-        const uint32_t tps = (seg_len + 3) / 4;
-        const uint64_t g = t / tps;
-        if (g >= shards) return;
-        const uint64_t f0 = first[g], f1 = first[g + 1], hi = f0 + seg_lo + seg_len;
-        i0 = f0 + seg_lo + 4 * (t % tps);
-        n = f1 < hi ? f1 : hi;                                   // reads of this thread's stream in this segment end here
-    }
+    const uint64_t i0 = 4 * t;
     if (i0 >= n) return;
     uint32_t lab4 = 0;
     if (labels) lab4 = *reinterpret_cast<const uint32_t *>(labels + i0);
@@ -1862,7 +1836,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t *__restrict__ D,
 // copies (k = 1: 20.1 -> 19.7 ms, k = 3: 24.9 -> 24.3 ms at 100M x 150; the same hint on the output planes' STORES: 13 % slower)
 #define QZ_LD(p) __builtin_nontemporal_load(p)
 #define QZ_CLUSTER4 (10 + QVZ_QS_STRIDE / 8)       // uint4 per cluster and column: ct (9) + pad (1) + qs (1296)
-template <int NBUF, int NQ, int RW, int T, bool SEG>   // RW dwords = 4 * RW consecutive reads per thread, T threads per workgroup; SEG: one segment of every stream (`first`)
+template <int NBUF, int NQ, int RW, int T>   // RW dwords = 4 * RW consecutive reads per thread, T threads per workgroup
 __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ D, const uint8_t *__restrict__ labels,
                                                              uint64_t n, uint32_t C, uint64_t ld, uint32_t K,
                                                              const uint16_t *__restrict__ ct, const uint16_t *__restrict__ qs,
@@ -1870,8 +1844,7 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
                                                              const double *__restrict__ dist, uint8_t *__restrict__ qv_out,
                                                              uint8_t *__restrict__ qi_out, uint8_t *__restrict__ st_out,
                                                              uint64_t ldo, double *__restrict__ err_out,
-                                                             int32_t *__restrict__ status, const int32_t *__restrict__ route,
-                                                             const uint64_t *__restrict__ first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len) {
+                                                             int32_t *__restrict__ status, const int32_t *__restrict__ route) {
     extern __shared__ uint4 qz_smem[];
     if (route[1] != QZ_ROUTE_LDS) return;                       // a general distortion matrix: k_quantize does this call
     double *sdist = reinterpret_cast<double *>(qz_smem);         // d(|x - y|), from row 0 of the matrix
@@ -1880,23 +1853,7 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     if (threadIdx.x < QVZ_A) sdist[threadIdx.x] = dist[threadIdx.x];
     const uint64_t t = (uint64_t)blockIdx.x * T + threadIdx.x;
     constexpr int R = 4 * RW;
-    // Which reads this thread takes. Whole matrix: R consecutive reads from R t. One SEGMENT of a sharded encode (`first`): the
-    // launch covers reads [first[g] + seg_lo, .. + seg_len) of every stream g, ceil(seg_len / R) threads per stream - the coder's
-    // model kernel of that segment needs exactly these reads of every stream, so it can start when this launch ends, beside the
-    // launch for the next segment. A thread's reads stay inside one stream's piece; what lies beyond
-    // the piece (or the stream) is neither loaded nor stored: i0 is a multiple of 4 there, not of R.
-    uint64_t i0 = (uint64_t)R * t;
-    if (SEG) {
-        const uint32_t tps = (seg_len + R - 1) / R;
-        const uint64_t g = t / tps;
-        if (g < shards) {
-            const uint64_t f0 = first[g], f1 = first[g + 1], hi = f0 + seg_lo + seg_len;
-            i0 = f0 + seg_lo + (uint64_t)R * (t % tps);
-            n = f1 < hi ? f1 : hi;                               // this thread's reads end here
-        } else {
-            n = 0;
-        }
-    }
+    const uint64_t i0 = (uint64_t)R * t;                         // this thread's R consecutive reads
     const bool active = i0 < n;                                  // idle threads still copy tables and meet the barriers
     uint32_t cbase[R], prev[R];                                  // cluster's table base in the column buffer, in u16
     double err[R];
@@ -1952,9 +1909,8 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
         // every load issued so far has landed (the stage registers pass through the wait, so nothing that reads them moves above it)
         if constexpr (NQ == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]) : : "memory");
         else if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]) : : "memory");
-        else if constexpr (NQ == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]) : : "memory");
-        static_assert(NQ == 3 || NQ == 4 || NQ == 6 || NQ == 8, "stage registers");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]) : : "memory");
+        static_assert(NQ == 3 || NQ == 4 || NQ == 6, "stage registers");
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint32_t i = threadIdx.x + q * T;
@@ -1967,16 +1923,11 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
     // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
     const uint64_t io = active ? i0 : 0;
-    // SEG: a dword wholly beyond the thread's reads is not touched, its loads go to the thread's first dword. (Only then: the tests per
-    // dword in the column loop cost the whole-matrix launch 1.3 of its 19.5 ms when they were unconditional.)
-    uint32_t woff[RW];
-#pragma unroll
-    for (int w = 0; w < RW; ++w) woff[w] = !SEG || (active && i0 + 4 * w < n) ? 4u * w : 0u;
     uint32_t x4n[RW], d4n[RW];
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
-        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + io + woff[w]));
-        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + io + woff[w]));      // 7-bit draws, same layout
+        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + io + 4 * w));
+        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + io + 4 * w));      // 7-bit draws, same layout
     }
     for (uint32_t s = 0; s < C; ++s) {
         const uint16_t *cur = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s & 1) * per_col4 : 0u));
@@ -1987,8 +1938,8 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
             fetch(s + 1);
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
-                x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io + woff[w]));
-                d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io + woff[w]));
+                x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io + 4 * w));
+                d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io + 4 * w));
             }
         }
 #pragma unroll
@@ -2015,11 +1966,9 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
         if (active) {
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
-                if (!SEG || w == 0 || woff[w]) {                 // (SEG: a dword beyond the thread's reads belongs to somebody else)
-                    if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0 + 4 * w) = qv4[w];
-                    if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0 + 4 * w) = qi4[w];
-                    if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0 + 4 * w) = st4[w];
-                }
+                if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0 + 4 * w) = qv4[w];
+                if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0 + 4 * w) = qi4[w];
+                if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0 + 4 * w) = st4[w];
             }
         }
         if (s + 1 < C) {
@@ -2036,7 +1985,22 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     if (dead || ctxmax == QVZ_NOT_FOUND) atomicOr(status, 1);
 }
 
-int qvz_quantize_check(const QvzQuantArgs &a) {
+struct QvzQuantArgs {                 // everything qvz_hip_quantize takes
+    const uint8_t *d_sym, *d_labels;
+    uint64_t n;
+    uint32_t c;
+    uint64_t ld;
+    uint32_t k;
+    const uint16_t *d_ct, *d_qs;
+    const uint8_t *d_draws;
+    uint64_t ld_draws;
+    const double *d_dist;
+    uint8_t *d_qv, *d_qi, *d_st;
+    uint64_t ld_out;
+    double *d_err;
+    int32_t *d_status;
+};
+static int quantize_check(const QvzQuantArgs &a) {
     int rc = check_matrix(a.n, a.c, a.ld);
     if (rc) return rc;
     if ((rc = check_matrix(a.n, a.c, a.ld_draws))) return rc;
@@ -2047,58 +2011,40 @@ int qvz_quantize_check(const QvzQuantArgs &a) {
     return QVZ_OK;
 }
 
-int qvz_quantize_launch(const QvzQuantArgs &a, const uint64_t *d_first, uint32_t shards, uint64_t seg_lo, uint32_t seg_len,
-                        int32_t *d_route, bool decide, hipStream_t stream) {
+static int quantize_launch(const QvzQuantArgs &a, int32_t *d_route, hipStream_t stream) {
     const uint64_t n = a.n;
     const uint32_t c = a.c, k = a.k;
-    const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // development knob: "global" keeps the tables in L1/L2
+    const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // test hook: "global" keeps the tables in L1/L2 (the kernel of more than three clusters)
     const bool lds_possible = k <= 3 && !(force && strcmp(force, "global") == 0);
     // [0] mirrors nothing (the kernels write the caller's d_status); [1] = route of this call
-    if (decide) hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, stream, a.d_dist, d_route + 1, lds_possible ? 1 : 0);
+    hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, stream, a.d_dist, d_route + 1, lds_possible ? 1 : 0);
     QVZ_HIP_CHECK(hipGetLastError());
-    // threads' worth of reads: the whole matrix, or ceil(seg_len / R) threads for every stream's piece of the segment
-    auto threads_for = [&](uint32_t R) -> uint64_t {
-        return d_first ? (uint64_t)shards * ((seg_len + R - 1) / R) : (n + R - 1) / R;
-    };
     if (lds_possible) {
         // dwords (4 reads each) per thread: 8 reads = 8 independent chains (22.6 -> 20.4 ms at 100M x 150 with one cluster)
         // Three clusters: a column's tables are 63 KB, copied from L2 by every workgroup for every column - with 512
         // threads x 4 reads that was 459 GB of copies per step at 100M x 150. 1024-thread workgroups with eight reads
         // per thread copy a quarter of that: 43.2 -> 27.5 ms (1024 threads x 4 reads: 39.4; eight reads per thread in
-        // 512-thread workgroups had been slower than four). QVZ_QUANTIZE_T / _RW are development knobs.
-        const int wide = k == 3 && !(getenv("QVZ_QUANTIZE_T") && atoi(getenv("QVZ_QUANTIZE_T")) == 512);
-        const int rw = getenv("QVZ_QUANTIZE_RW") ? atoi(getenv("QVZ_QUANTIZE_RW")) : (k <= 2 || wide ? 2 : 1);
-        const uint64_t tpw = wide ? 1024 : QZ_THREADS, nthreads = threads_for(rw == 2 ? 8 : 4);
+        // 512-thread workgroups had been slower than four).
+        const uint64_t tpw = k == 3 ? 1024 : QZ_THREADS, nthreads = (n + 7) / 8;
         dim3 grid((unsigned)((nthreads + tpw - 1) / tpw));
         const size_t col = (size_t)k * QZ_CLUSTER4 * 16, lds = (size_t)QVZ_A * 8 + (k <= 2 ? 2 : 1) * col;
-#define QZ_LAUNCH(NBUF, NQ, RWV, TT)                                                                                             \
+#define QZ_LAUNCH(NBUF, NQ, TT)                                                                                                  \
         do {                                                                                                                     \
-            if (d_first) {                                                                                                       \
-                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT, true>),      \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT, true>), grid, dim3(TT), lds, stream, a.d_sym,              \
-                                   k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
-                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);            \
-            } else {                                                                                                             \
-                QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, RWV, TT, false>),     \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-                hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, RWV, TT, false>), grid, dim3(TT), lds, stream, a.d_sym,             \
-                                   k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
-                                   a.d_st, a.ld_out, a.d_err, a.d_status, d_route, d_first, shards, seg_lo, seg_len);            \
-            }                                                                                                                    \
+            QVZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quantize_lds<NBUF, NQ, 2, TT>),                   \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+            hipLaunchKernelGGL((k_quantize_lds<NBUF, NQ, 2, TT>), grid, dim3(TT), lds, stream, a.d_sym,                          \
+                               k > 1 ? a.d_labels : nullptr, n, c, a.ld, k, a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, \
+                               a.d_st, a.ld_out, a.d_err, a.d_status, d_route);                                                  \
         } while (0)
-        static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 8 * QZ_THREADS >= 3 * QZ_CLUSTER4 &&
-                      4 * 1024 >= 3 * QZ_CLUSTER4, "stage registers");
-        if (k == 1) { if (rw == 2) QZ_LAUNCH(2, 3, 2, QZ_THREADS); else QZ_LAUNCH(2, 3, 1, QZ_THREADS); }
-        else if (k == 2) { if (rw == 2) QZ_LAUNCH(2, 6, 2, QZ_THREADS); else QZ_LAUNCH(2, 6, 1, QZ_THREADS); }
-        else if (wide) { if (rw == 2) QZ_LAUNCH(1, 4, 2, 1024); else QZ_LAUNCH(1, 4, 1, 1024); }
-        else { if (rw == 2) QZ_LAUNCH(1, 8, 2, QZ_THREADS); else QZ_LAUNCH(1, 8, 1, QZ_THREADS); }
+        static_assert(3 * QZ_THREADS >= QZ_CLUSTER4 && 6 * QZ_THREADS >= 2 * QZ_CLUSTER4 && 4 * 1024 >= 3 * QZ_CLUSTER4, "stage registers");
+        if (k == 1) QZ_LAUNCH(2, 3, QZ_THREADS);
+        else if (k == 2) QZ_LAUNCH(2, 6, QZ_THREADS);
+        else QZ_LAUNCH(1, 4, 1024);
 #undef QZ_LAUNCH
     }
-    dim3 grid((unsigned)((threads_for(4) + 255) / 256));
+    dim3 grid((unsigned)(((n + 3) / 4 + 255) / 256));
     hipLaunchKernelGGL(k_quantize, grid, dim3(256), 0, stream, a.d_sym, k > 1 ? a.d_labels : nullptr, n, c, a.ld,
-                       a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, a.d_st, a.ld_out, a.d_err, a.d_status, d_route,
-                       d_first, shards, seg_lo, seg_len);
+                       a.d_ct, a.d_qs, a.d_draws, a.ld_draws, a.d_dist, a.d_qv, a.d_qi, a.d_st, a.ld_out, a.d_err, a.d_status, d_route);
     QVZ_HIP_CHECK(hipGetLastError());
     return QVZ_OK;
 }
@@ -2108,13 +2054,13 @@ extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, u
                                 uint64_t ld_draws, const double *d_dist, uint8_t *d_qv, uint8_t *d_qi, uint8_t *d_st,
                                 uint64_t ld_out, double *d_err, int32_t *d_status, void *stream) {
     const QvzQuantArgs a = {d_sym, d_labels, n, c, ld, k, d_ct, d_qs, d_draws, ld_draws, d_dist, d_qv, d_qi, d_st, ld_out, d_err, d_status};
-    const int rc = qvz_quantize_check(a);
+    const int rc = quantize_check(a);
     if (rc) return rc;
     // the route word lives behind the caller's status word in this device's scratch pair (stream-ordered like the rest of it)
     ScratchLock lk((hipStream_t)stream);
     if (lk.rc) return lk.rc;
     if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, 2 * sizeof(int32_t)));
-    return qvz_quantize_launch(a, nullptr, 0, 0, 0, lk.d->d_route, true, (hipStream_t)stream);
+    return quantize_launch(a, lk.d->d_route, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

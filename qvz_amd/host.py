@@ -370,30 +370,6 @@ def encode_shards_device(feed, labels, n, columns, codebook_handles, shards, thr
     return out
 
 
-def encode_shards_gpu(feed, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True):
-    """GPU sharded coder (one lane per shard). Returns (sizes, streams|None, out_tensor)."""
-    import torch
-    k = len(codebook_handles)
-    arr = (C.c_void_p * k)(*codebook_handles)
-    if cap_per_shard is None:
-        per = (n + shards - 1) // shards + 4
-        cap_per_shard = (per * columns * 3) // 4 + 512          # 6 bits/symbol
-    cap_per_shard = (cap_per_shard + 3) & ~3
-    out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=feed.device)
-    sizes = (C.c_uint64 * shards)()
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = lib().qvz_hip_encode_shards(C.c_void_p(feed.data_ptr()), C.c_void_p(labels.data_ptr()) if labels is not None else None,
-                                     n, columns, k, arr, shards, C.c_void_p(out.data_ptr()), cap_per_shard, sizes, stream)
-    if rc:
-        raise QvzHipError(f"qvz_hip_encode_shards failed ({rc}): {lib().qvz_hip_last_error().decode(errors='replace')}")
-    sizes = np.ctypeslib.as_array(sizes).tolist()   # (8192 Python ints by a list comprehension over the ctypes array took 0.6 ms)
-    streams = None
-    if want_streams:
-        host_out = out.view(shards, cap_per_shard).cpu().numpy()
-        streams = [host_out[g, : sizes[g]].tobytes() for g in range(shards)]
-    return sizes, streams, out
-
-
 _KEPT_WORK = {}
 
 
@@ -421,20 +397,18 @@ def release_workspace(device=None):
 
 
 def planes_bytes_per_read(shards, columns, k):
-    """Record-workspace bytes that one read of every stream takes in qvz_hip_encode_planes: 16 bytes per record, streams
+    """Record-workspace bytes that one read of every stream takes in qvz_hip_encode_planes: 8 bytes per record, streams
     padded to a multiple of 64, records per read (columns, behind 8 reserved positions - the cluster id and seven zero
     records - when k > 1) padded to a multiple of 8."""
-    return 16 * ((shards + 63) // 64 * 64) * ((columns + (8 if k > 1 else 0) + 7) // 8 * 8)
+    return 8 * ((shards + 63) // 64 * 64) * ((columns + (8 if k > 1 else 0) + 7) // 8 * 8)
 
 
 def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_per_shard=None, want_streams=True,
-                      work_bytes=None, bounds=None, quant=None):
+                      work_bytes=None, bounds=None):
     """GPU sharded coder fed from the quantizer's planes (qvz_hip_encode_planes): the model runs with a lane per
     (stream, column), the interval arithmetic with a lane per stream. qi/st: (columns, ld) uint8 device tensors.
     work_bytes: size of the record workspace (default: everything at once, capped at 96 GiB).
     bounds: the cut into shards (shards + 1 read numbers, every start a multiple of 4; default qvz_shard_bounds).
-    quant: None = the planes are there. Otherwise the quantizer's inputs - dict(sym, ct, qs, draws, dist, qv|None, err|None,
-    status): the planes are MADE by this call, segment by segment beside the coder's kernels (qvz_hip_quantize_encode_planes).
     Returns (sizes, streams|None, out_tensor)."""
     import torch
     k = len(codebook_handles)
@@ -453,25 +427,16 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
         if cap_given is None:
             cap_per_shard = (((per + 4) * columns * 3) // 4 + 512 + 3) & ~3
     if work_bytes is None:
-        # default: everything at once, capped (QVZ_WORK_GIB, 96 GiB of the 288 unless set); fewer, longer segments mean
-        # fewer save/restore round trips of the model tables between segments
-        import os
-        work_bytes = min(per_read * longest, int(os.environ.get("QVZ_WORK_GIB", "96")) << 30)
+        # default: everything at once, capped at 96 GiB of the 288; fewer, longer segments mean fewer save/restore round trips of the
+        # model tables between segments
+        work_bytes = min(per_read * longest, 96 << 30)
     work_bytes = max(work_bytes, per_read * 4)
     work = kept_workspace(qi.device, work_bytes)
     out = torch.empty(shards * cap_per_shard, dtype=torch.uint8, device=qi.device)
     sizes = (C.c_uint64 * shards)()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lab = C.c_void_p(labels.data_ptr()) if labels is not None else None
-    if quant is not None:
-        def ptr(t):
-            return C.c_void_p(t.data_ptr()) if t is not None else None
-        hb = (C.c_uint64 * (shards + 1))(*[int(b) for b in bounds]) if bounds is not None else None
-        rc = lib().qvz_hip_quantize_encode_planes(ptr(quant["sym"]), lab, n, columns, quant["sym"].shape[1], k, ptr(quant["ct"]), ptr(quant["qs"]),
-                                                  ptr(quant["draws"]), quant["draws"].shape[1], ptr(quant["dist"]), ptr(quant.get("qv")),
-                                                  ptr(qi), ptr(st), ld, ptr(quant.get("err")), ptr(quant["status"]), arr, shards, hb,
-                                                  C.c_void_p(out.data_ptr()), cap_per_shard, sizes, C.c_void_p(work.data_ptr()), work_bytes, stream)
-    elif bounds is None:
+    if bounds is None:
         rc = lib().qvz_hip_encode_planes(C.c_void_p(qi.data_ptr()), C.c_void_p(st.data_ptr()), ld, lab, n, columns, k, arr, shards,
                                          C.c_void_p(out.data_ptr()), cap_per_shard, sizes, C.c_void_p(work.data_ptr()), work_bytes,
                                          stream)
@@ -485,7 +450,6 @@ def encode_planes_gpu(qi, st, labels, n, columns, codebook_handles, shards, cap_
     a, b = C.c_double(), C.c_double()
     lib().qvz_hip_encode_planes_last_ms(C.byref(a), C.byref(b))
     encode_planes_gpu.last_ms = (a.value, b.value)      # (model kernels, coder kernels) of this call
-    encode_planes_gpu.last_quant_ms = lib().qvz_hip_encode_planes_last_quant_ms() if quant is not None else None
     sizes = np.ctypeslib.as_array(sizes).tolist()   # (8192 Python ints by a list comprehension over the ctypes array took 0.6 ms)
     streams = None
     if want_streams:

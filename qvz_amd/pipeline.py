@@ -203,24 +203,6 @@ class HipBackend:
         with self.timer.span("quantize"):
             return K.quantize(sym, n, ct, qs, draws, ddist, labels=labels, k=k, want=want)
 
-    def quantize_code(self, sym, n, cbs, draws, dmat, labels, k, want, shards, keep, work_bytes):
-        """Quantizer and GPU coder as ONE pipeline (qvz_hip_quantize_encode_planes): the planes are made segment by segment
-        beside the coder's kernels. -> (quantizer outputs, then what code() returns + the quantizer launches' busy ms)"""
-        ct, qs = K.upload_tables(cbs, self.device)
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-        ddist = torch.from_numpy(dmat).to(self.device)
-        out = K.quantize_outputs(sym, n, want)
-        handles = [cb.handle for cb in cbs]
-        quant = dict(sym=sym, ct=ct, qs=qs, draws=draws, dist=ddist, qv=out["qv"], err=out["err"], status=out["status"])
-        sizes, streams, coded = host.encode_planes_gpu(out["qi"], out["st"], labels, n, sym.shape[0], handles, shards,
-                                                       want_streams=keep, work_bytes=work_bytes, quant=quant)
-        feed = None
-        if keep:
-            with self.timer.span("pack_feed"):
-                feed = K.pack_feed(out["qi"], out["st"], n)
-        return out, sizes, streams, coded, feed, host.encode_planes_gpu.last_ms, host.encode_planes_gpu.last_quant_ms
-
     def code(self, out, labels, n, c, cbs, shards, threads, coder, keep, work_bytes):
         """-> (stream sizes, streams as bytes | None, coded device tensor | None, feed | None, (model ms, coder ms) | None)"""
         handles = [cb.handle for cb in cbs]
@@ -233,10 +215,6 @@ class HipBackend:
                 sizes, streams, coded = host.encode_planes_gpu(out["qi"], out["st"], labels, n, c, handles, shards,
                                                                want_streams=keep, work_bytes=work_bytes)
             return sizes, streams, coded, feed, host.encode_planes_gpu.last_ms
-        if coder == "gpu-feed":
-            with self.timer.span("arith_shards"):
-                sizes, streams, coded = host.encode_shards_gpu(feed, labels, n, c, handles, shards, want_streams=keep)
-            return sizes, streams, coded, feed, None
         streams = host.encode_shards_device(feed, labels, n, c, handles, shards, threads, device=self.device_index)
         return [len(s) for s in streams], streams, None, feed, None
 
@@ -325,8 +303,7 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     """Runs k-means -> PMF -> codebooks -> WELL -> quantize -> feed -> sharded arithmetic coding for the reads
     [first_read, first_read+n) held in `sym` (this rank's shard of a file with n_total reads).
     coder: "host" = `threads` host threads over the packed feed (qvz_encode_shards_device); "gpu" = the column-parallel
-    model + lane-per-stream coder fed from the quantizer's planes (qvz_hip_encode_planes); "gpu-feed" = the older
-    lane-per-stream kernel over the packed feed (qvz_hip_encode_shards). All produce byte-identical streams.
+    model + lane-per-stream coder fed from the quantizer's planes (qvz_hip_encode_planes). Byte-identical streams.
 
     means0: (clusters, c) uint8 device tensor of the initial centroids (symbols), or None: fetch_centroids gets them from
     the ranks that own them. first_read must be a multiple of 4.
@@ -420,43 +397,21 @@ def encode_pass(sym, n, first_read, n_total, means0, *, clusters=1, mode=host.MO
     # the quantized values themselves (the -u product) are written only for a caller that keeps them: the coder needs
     # the quantizer index and the state, the distortion the per-read error
     want = ("qv", "qi", "st", "err") if (keep or keep_device) else ("qi", "st", "err")
-    # QVZ_FUSED_QUANTIZE=1 (development knob): the quantizer as the first stage of the GPU coder's pipeline - launched per coder
-    # segment, beside the model and coder kernels of the segments before. Bit-identical and NOT faster (DESIGN.md section 6 item 14:
-    # the chip is busy throughout the coder phase, the quantizer's work only displaces the model kernel's), so the default stays
-    # one quantizer launch for everything, then the coder.
-    fused = coder == "gpu" and os.environ.get("QVZ_FUSED_QUANTIZE", "0") == "1"
-    if fused:
-        try:
-            out, stream_sizes, streams, coded, feed, kernel_ms, quant_ms = be.quantize_code(
-                sym, n, cbs, draws, dmat, labels if k > 1 else None, k, want, shards, keep, work_bytes)
-        except host.QvzHipError as exc:
-            if "dead context" in str(exc):
-                raise RuntimeError("quantizer met a context the codebook does not define") from exc
-            raise
-        if not want_reuse and reuse is None:
-            del draws
-        if int(out["status"].item()):
-            raise RuntimeError("quantizer met a context the codebook does not define")
-        wall["quantize"] = 0.0                                    # inside the coder phase
-        wall["coder_quantize_kernels"] = quant_ms * 1e-3
-        wall["coder_model_kernels"], wall["coder_interval_kernels"] = (x * 1e-3 for x in kernel_ms)
-        wall["coder"] = time.perf_counter() - t3
-    else:
-        out = be.quantize(sym, n, cbs, draws, dmat, labels if k > 1 else None, k, want)
-        if not want_reuse and reuse is None:
-            del draws
-        if int(out["status"].item()):
-            raise RuntimeError("quantizer met a context the codebook does not define")
-        be.sync()
-        wall["quantize"] = time.perf_counter() - t3
+    out = be.quantize(sym, n, cbs, draws, dmat, labels if k > 1 else None, k, want)
+    if not want_reuse and reuse is None:
+        del draws
+    if int(out["status"].item()):
+        raise RuntimeError("quantizer met a context the codebook does not define")
+    be.sync()
+    wall["quantize"] = time.perf_counter() - t3
 
-        # ---- arithmetic coding: `shards` independent reference-format streams ----
-        t4 = time.perf_counter()
-        stream_sizes, streams, coded, feed, kernel_ms = be.code(out, labels if k > 1 else None, n, c, cbs, shards, threads, coder,
-                                                                keep, work_bytes)
-        if kernel_ms is not None:
-            wall["coder_model_kernels"], wall["coder_interval_kernels"] = (x * 1e-3 for x in kernel_ms)
-        wall["coder"] = time.perf_counter() - t4
+    # ---- arithmetic coding: `shards` independent reference-format streams ----
+    t4 = time.perf_counter()
+    stream_sizes, streams, coded, feed, kernel_ms = be.code(out, labels if k > 1 else None, n, c, cbs, shards, threads, coder,
+                                                            keep, work_bytes)
+    if kernel_ms is not None:
+        wall["coder_model_kernels"], wall["coder_interval_kernels"] = (x * 1e-3 for x in kernel_ms)
+    wall["coder"] = time.perf_counter() - t4
 
     err_sum = (out["err"] / float(c)).sum()
     if group is not None:

@@ -119,7 +119,7 @@ int main(int argc, char **argv) {
     snprintf(out, sizeof(out), "%s/out", work);
     FILE *sink = fopen("/dev/null", "w");
     {   /* the output side once under the sanitizers: pages made ahead and the writer's mapping (host/qvz_egress.c), exact and wrong estimates */
-        setenv("QVZ_PREALLOC_MIN", "1", 1);
+        setenv("QVZ_PREALLOC", "min=1", 1);
         const size_t n = (3u << 20) + 77;
         uint8_t *buf = (uint8_t *)malloc(n), *back = (uint8_t *)malloc(n + 64);
         for (size_t i = 0; i < n; ++i) buf[i] = (uint8_t)(rnd() >> 7);

@@ -62,3 +62,10 @@ int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint32_t cluster
 int qvz_hip_codebook_warmup(void) { return nodev(); }
 int qvz_hip_codebook_exact_entropies(void) { return 0; }
 int qvz_hip_encode_planes_warmup(void) { return QVZ_E_HIP; }
+int qvz_hip_event_create(void **event) { U(event); return nodev(); }
+int qvz_hip_event_record(void *event, void *stream) { U(event); U(stream); return nodev(); }
+int qvz_hip_event_elapsed_ms(void *first, void *second, double *ms) { U(first); U(second); U(ms); return nodev(); }
+int qvz_hip_event_destroy(void *event) { U(event); return nodev(); }
+int qvz_hip_sum_errors(const double *d_err, uint64_t n, uint32_t c, double *d_sum, void *stream) { U(d_err); U(n); U(c); U(d_sum); U(stream); return nodev(); }
+int qvz_hip_gather_reads(const uint8_t *d_sym, uint64_t ld, uint32_t c, const uint64_t *d_idx, uint32_t k, uint32_t *d_out, void *stream) { U(d_sym); U(ld); U(c); U(d_idx); U(k); U(d_out); U(stream); return nodev(); }
+void qvz_hip_encode_planes_last_ms(double *model_ms, double *coder_ms) { if (model_ms) *model_ms = 0.0; if (coder_ms) *coder_ms = 0.0; }

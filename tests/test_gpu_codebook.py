@@ -90,20 +90,14 @@ def test_device_entropies_decide_like_the_hosts_libm(K, name, monkeypatch):
         a, deferred = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
         assert deferred == 0                                      # nothing is deferred to the host when the device's values are exact
         assert_same_codebook(a, refs[j])
-        # (2) all columns driven from the device (QVZ_CB_FLOW=device, k_cb_decide): nothing crosses to the host until the book is complete
-        monkeypatch.setenv("QVZ_CB_FLOW", "device")
-        b, deferred = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
-        monkeypatch.delenv("QVZ_CB_FLOW")
-        assert deferred == 0
-        assert_same_codebook(b, a)                                # ratio bits included
-        # (2b) the band inside which the host's libm re-decides (1e-12 by default: about one decision in 1e12) made huge: every
+        # (2) the band inside which the host's libm re-decides (1e-12 by default: about one decision in 1e12) made huge: every
         # decision goes through the re-check, the libm's targets and entropies must equal the device's bit for bit, same book
         import ctypes
         r0, m0 = ctypes.c_ulonglong(), ctypes.c_ulonglong()
         lib().qvz_hip_codebook_exact_recheck_counts(ctypes.byref(r0), ctypes.byref(m0))
-        monkeypatch.setenv("QVZ_CB_EXACT_BAND", "1e30")
+        monkeypatch.setenv("QVZ_CB_LOG2", "band=1e30")
         e, deferred = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
-        monkeypatch.delenv("QVZ_CB_EXACT_BAND")
+        monkeypatch.delenv("QVZ_CB_LOG2")
         r1, m1 = ctypes.c_ulonglong(), ctypes.c_ulonglong()
         lib().qvz_hip_codebook_exact_recheck_counts(ctypes.byref(r1), ctypes.byref(m1))
         assert_same_codebook(e, a)
@@ -114,17 +108,6 @@ def test_device_entropies_decide_like_the_hosts_libm(K, name, monkeypatch):
         c_, _ = K.generate_codebook(dev_cnt, d, opts["mode"], opts["ratio"])
         monkeypatch.delenv("QVZ_CB_LOG2")
         assert_same_codebook(c_, a)
-
-
-@pytest.mark.parametrize("name", ["t2k_r10_M", "r35_high_rate", "uniform72_f09_M"])
-def test_device_driven_generation_with_a_window_that_is_too_short(K, name, monkeypatch):
-    """The design window of a column follows the previous column's largest state count + 3; a walk that runs off it gets the
-    second, full-width round (k_cb_decide, round 2). Forced here for every column by a first window of two designs."""
-    rows, opts, cnt, d, refs = oracle_codebooks(name)
-    monkeypatch.setenv("QVZ_CB_FLOW", "device")
-    monkeypatch.setenv("QVZ_CB_FIRST_WINDOW", "2")
-    cb, _ = K.generate_codebook(torch.from_numpy(cnt[0].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"])
-    assert_same_codebook(cb, refs[0])
 
 
 def test_device_tables_match_python_builder(K):

@@ -215,7 +215,7 @@ def test_cli_text_written_through_preallocated_pages(tmp_path, name):
     e = G.CASES[name]
     inp, _ = write_input(tmp_path, name)
     outs = {}
-    for tag, extra in (("pwrite", {"QVZ_PREALLOC": "0"}), ("mapped", {"QVZ_PREALLOC_MIN": "1"})):
+    for tag, extra in (("pwrite", {"QVZ_PREALLOC": "0"}), ("mapped", {"QVZ_PREALLOC": "min=1"})):
         q, u, d = (str(tmp_path / f"{tag}.{x}") for x in ("qset", "u", "dec"))
         env = dict(os.environ, QVZ_WELL_SEED="debug", QVZ_SHARDS="5", **extra)
         subprocess.run([QVZ_BIN] + e["flags"].split() + ["-u", u, inp, q], env=env, check=True, capture_output=True)

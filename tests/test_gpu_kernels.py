@@ -218,20 +218,19 @@ def test_pmf_kernel_variants_agree(K, aa, monkeypatch):
     rows = O.qgen1_rows(11, n, c)
     ref = O.stats(rows, np.zeros(n, np.uint8), 1)
     sym = upload_sym(K, rows)
-    monkeypatch.setenv("QVZ_PMF_AA", str(aa))
     for algo, q in (("0", "0"), ("1", "0"), ("1", "4"), ("1", "6")):
-        monkeypatch.setenv("QVZ_PMF_ALGO", algo)
-        monkeypatch.setenv("QVZ_PMF_Q", q)                 # 16-byte groups per thread of the walking kernel (0 = by size)
+        # test hook: the kernel and its 16-byte groups per thread (0 = by size) that full-size inputs select, and the tile's side
+        monkeypatch.setenv("QVZ_PMF", f"aa={aa},algo={algo},q={q}")
         cnt = K.pmf_hist(sym, n)
         np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint32), ref, err_msg=f"algo={algo} Q={q}")
 
 
-@pytest.mark.parametrize("k,aa,q", [(2, 0, 0), (3, 0, 4), (3, 30, 6), (4, 0, 6), (4, 72, 2)])
-def test_pmf_labels_packed_to_two_bits_count_like_label_bytes(K, k, aa, q, monkeypatch):
-    """Up to four clusters: the walking kernel packs a thread's labels to 2 bits each and keeps them in registers over all
-    columns (QVZ_PMF_LABELS=bytes: the label bytes, asked for again in every column). Same counters as the oracle's
+@pytest.mark.parametrize("k,aa,q", [(2, 0, 0), (3, 0, 4), (3, 30, 6), (4, 0, 6), (4, 72, 2), (5, 0, 4), (9, 40, 2)])
+def test_pmf_with_labels_counts_like_the_oracle(K, k, aa, q, monkeypatch):
+    """Up to four clusters the walking kernel packs a thread's labels to 2 bits each and keeps them in registers over all columns;
+    more clusters: the label bytes, asked for again in every column (nine: two passes of the tiles). Same counters as the oracle's
     calculate_statistics restatement (codebook.c:193-205), with a ragged last group, a tile hint below the alphabet, and a
-    caller's label vector that holds values outside the clusters (those reads count nowhere, on either path)."""
+    caller's label vector that holds values outside the clusters (those reads count nowhere)."""
     n, c = 70001, 14
     rows = O.qgen1_rows(21, n, c)
     rng = np.random.default_rng(k * 1000 + aa)
@@ -240,9 +239,7 @@ def test_pmf_labels_packed_to_two_bits_count_like_label_bytes(K, k, aa, q, monke
     lab = torch.zeros(sym.shape[1], dtype=torch.uint8, device="cuda")
     lab[:n] = torch.from_numpy(labels_np).cuda()
     ref = O.stats(rows, labels_np, k)
-    monkeypatch.setenv("QVZ_PMF_ALGO", "1")
-    monkeypatch.setenv("QVZ_PMF_AA", str(aa))
-    monkeypatch.setenv("QVZ_PMF_Q", str(q))
+    monkeypatch.setenv("QVZ_PMF", f"algo=1,aa={aa},q={q}")
     packed = K.pmf_hist(sym, n, labels=lab, k=k)
     np.testing.assert_array_equal(packed.cpu().numpy().astype(np.uint32), ref)
     # a label vector with strangers in it: cluster ids k .. 255 in 1 % of the reads (also 3 -> the 2-bit field's own value when k = 3)
@@ -252,9 +249,6 @@ def test_pmf_labels_packed_to_two_bits_count_like_label_bytes(K, k, aa, q, monke
     odd[where[:50]] = k
     lab[:n] = torch.from_numpy(odd).cuda()
     packed = K.pmf_hist(sym, n, labels=lab, k=k)
-    monkeypatch.setenv("QVZ_PMF_LABELS", "bytes")
-    by_bytes = K.pmf_hist(sym, n, labels=lab, k=k)
-    assert torch.equal(packed, by_bytes)
     keep = odd < k
     ref_odd = O.stats(np.ascontiguousarray(rows[keep]), np.ascontiguousarray(odd[keep]), k)
     np.testing.assert_array_equal(packed.cpu().numpy().astype(np.uint32), ref_odd)
@@ -456,8 +450,7 @@ def test_quantize_reports_undefined_context(K):
 @pytest.mark.parametrize("n,c,algo", [(10_000_000, 150, ""), (10_000_000, 150, "1")])
 def test_full_size_pmf_properties(K, n, c, algo, monkeypatch):
     if algo:
-        monkeypatch.setenv("QVZ_PMF_ALGO", algo)          # the walking kernel with six groups per thread, as bench.py's
-        monkeypatch.setenv("QVZ_PMF_Q", "6")              # 100M reads select it
+        monkeypatch.setenv("QVZ_PMF", f"algo={algo},q=6")   # the walking kernel with six groups per thread, as bench.py's 100M reads select it
     sym = K.qgen1(2, n, c)
     cnt = K.pmf_hist(sym, n).to(torch.int64)[0]          # (c, 72, 72)
     per_col = cnt.sum(dim=(1, 2))

@@ -91,10 +91,8 @@ def test_every_shard_is_reference_decodable(name, shards, threads):
                                          ("r35_high_rate", 3), ("wide_c151", 2), ("tiny5_r10", 4), ("c2_f08", 70),
                                          ("t2k_c3_f05_M", 130)])
 def test_gpu_coder_streams_equal_host_coder_streams(name, shards, monkeypatch):
-    """The lane-per-shard GPU coder and the host C coder must emit the same bytes for every shard; with one shard
-    that is the reference's own stream. Both kinds of record between the model kernel and the interval chain: packed
-    integer triples (8 bytes, the division in the coder workgroup's two loader waves: the default) and the pairs of
-    pre-divided doubles of rounds 1-3 (QVZ_CODER_RECORDS=16)."""
+    """The GPU coder (model kernel + lane-per-stream interval chain over packed 8-byte records) and the host C coder must emit the
+    same bytes for every shard; with one shard that is the reference's own stream."""
     from qvz_amd import host, pipeline as P
     rows, opts, n, c, sym, means0 = setup_case(name)
     kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=shards, keep=True)
@@ -107,51 +105,17 @@ def test_gpu_coder_streams_equal_host_coder_streams(name, shards, monkeypatch):
     small = host.planes_bytes_per_read(shards, c, opts["k"]) * 8
     d = P.encode_pass(sym, n, 0, n, means0, coder="gpu", work_bytes=small, **kw)
     assert d["streams"] == a["streams"], "segmented record workspace changed a stream"
-    monkeypatch.setenv("QVZ_CODER_RECORDS", "16")
-    b16 = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
-    d16 = P.encode_pass(sym, n, 0, n, means0, coder="gpu", work_bytes=small, **kw)
-    monkeypatch.delenv("QVZ_CODER_RECORDS")
-    assert b16["streams"] == a["streams"] and d16["streams"] == a["streams"], "16-byte records changed a stream"
-    e = P.encode_pass(sym, n, 0, n, means0, coder="gpu-feed", **kw)
-    assert e["streams"] == a["streams"], "feed-based GPU coder differs from the host coder"
     if shards == 1:
         assert b["total_stream_bytes"] == G.CASES[name]["size"]
         if G.CASES[name]["stored"]:
             assert b["streams"][0] == G.gz(name + ".q.gz")[-G.CASES[name]["size"]:]
 
 
-@pytest.mark.parametrize("name,shards,k", [("cfg1_f05_L", 4, None), ("cfg1_f05_L", 16, None), ("t2k_c3_f05_M", 1, None), ("t2k_c3_f05_M", 4, None), ("rescale_140k_c4", 24, None),
-                                           ("rescale_140k_c4", 3, 5), ("tiny5_r10", 2, None), ("wide_c151", 2, None)])
-def test_quantizer_inside_the_coder_pipeline_changes_nothing(name, shards, k, monkeypatch):
-    """qvz_hip_quantize_encode_planes launches the quantizer once per coder segment, for that segment's reads of every stream,
-    beside the coder's kernels; the planes, the per-read errors and the streams must be those of one quantizer launch followed by
-    the coder (the default; the pipeline form is QVZ_FUSED_QUANTIZE=1) - with the streams cut into many segments, few, and one, and with more clusters than the
-    LDS quantizer holds (k = 5: the other quantizer kernel)."""
-    from qvz_amd import host, pipeline as P
-    rows, opts, n, c, sym, means0 = setup_case(name)
-    if k is not None:
-        lines = P.reference_centroid_lines(n, k)
-        means0 = torch.from_numpy(np.stack([rows[i, :c] - 33 for i in lines]).astype(np.uint8)).cuda()
-    kw = dict(clusters=k or opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=shards, keep=True, coder="gpu")
-    a = P.encode_pass(sym, n, 0, n, means0, **kw)
-    assert "coder_quantize_kernels" not in a["wall"]
-    monkeypatch.setenv("QVZ_FUSED_QUANTIZE", "1")
-    per_read = host.planes_bytes_per_read(shards, c, kw["clusters"])
-    for work in (None, per_read * 8, per_read * 256):
-        b = P.encode_pass(sym, n, 0, n, means0, work_bytes=work, **kw)
-        assert b["wall"]["coder_quantize_kernels"] > 0.0
-        assert b["streams"] == a["streams"], f"streams differ (workspace {work})"
-        for key in ("qv", "qi", "st"):
-            assert torch.equal(a[key][:, :n], b[key][:, :n]), f"{key} differs (workspace {work})"
-        assert torch.equal(a["err"], b["err"]), f"per-read distortion differs (workspace {work})"
-        assert a["distortion"] == b["distortion"]
-
-
 def test_one_newton_step_is_enough_on_this_device(monkeypatch):
     """The coder's loaders refine v_rcp_f64 with ONE Newton step when that is within 2^-47 of 1 / (n 2^10) for every n a packed
     record can hold - the proof at `Record` needs 2^-46 - and the library measures it over all n = 1 .. 2^19 + 1024 before it
     relies on it. On gfx950 it must hold (2^-48.8 measured), or the fast kernel would silently be off; and the two-step
-    kernel (QVZ_CODER_NEWTON=2) codes the same streams."""
+    kernel (test hook QVZ_CODER=newton=2) codes the same streams."""
     import ctypes as C
     from qvz_amd import pipeline as P
     from qvz_amd._lib import lib
@@ -161,7 +125,7 @@ def test_one_newton_step_is_enough_on_this_device(monkeypatch):
     rows, opts, n, c, sym, means0 = setup_case("cfg1_f05_L")
     kw = dict(clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"], shards=16, keep=True)
     a = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
-    monkeypatch.setenv("QVZ_CODER_NEWTON", "2")
+    monkeypatch.setenv("QVZ_CODER", "newton=2")
     assert lib().qvz_coder_rcp_one_step_ok() == 0
     b = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
     assert a["streams"] == b["streams"]
@@ -177,29 +141,15 @@ def test_gpu_model_kernels_agree(name, shards, monkeypatch):
     a = P.encode_pass(sym, n, 0, n, means0, coder="gpu", **kw)
     handles = [cb.handle for cb in a["codebooks"]]
     labels = a["labels"] if opts["k"] > 1 else None
-    monkeypatch.setenv("QVZ_MODEL_KERNEL", "columns")
+    monkeypatch.setenv("QVZ_CODER", "columns")                          # test hook: the fall-back kernel whatever the tables' size
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards)
     assert streams == a["streams"]
-    small = host.planes_bytes_per_read(shards, c, opts["k"]) * 64       # 64 reads per segment (128 of packed records)
+    small = host.planes_bytes_per_read(shards, c, opts["k"]) * 128      # 128 reads per segment
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
     assert streams == a["streams"]
-    monkeypatch.setenv("QVZ_CODER_RECORDS", "16")                       # the same with the 16-byte records
+    monkeypatch.delenv("QVZ_CODER")
     _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
     assert streams == a["streams"]
-    # several clusters: one launch for all column groups with the LDS of the largest slice (QVZ_MODEL_CLASSES=0) against the default,
-    # a launch per size class of the column groups with every wave's LDS region sized by its own column's slices
-    monkeypatch.delenv("QVZ_CODER_RECORDS")
-    monkeypatch.delenv("QVZ_MODEL_KERNEL")
-    monkeypatch.setenv("QVZ_MODEL_CLASSES", "0")
-    for work in (None, small):
-        _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=work)
-        assert streams == a["streams"]
-    # ... and the classes with workgroups of two waves and of one (the map carries a layout per wave), with one cluster as well
-    monkeypatch.setenv("QVZ_MODEL_CLASSES", "1")
-    for waves in ("2", "1", "4"):
-        monkeypatch.setenv("QVZ_MODEL_WAVES", waves)
-        _, streams, _ = host.encode_planes_gpu(a["qi"], a["st"], labels, n, c, handles, shards, work_bytes=small)
-        assert streams == a["streams"], f"classes with {waves} wave(s) per workgroup changed a stream"
 
 
 def test_gpu_coder_reports_overflow_and_bad_feed():
@@ -209,13 +159,7 @@ def test_gpu_coder_reports_overflow_and_bad_feed():
                       keep=True)
     handles = [cb.handle for cb in r["codebooks"]]
     with pytest.raises(Exception, match="cap_per_shard"):
-        host.encode_shards_gpu(r["feed"], None, n, c, handles, 2, cap_per_shard=64)
-    with pytest.raises(Exception, match="cap_per_shard"):
         host.encode_planes_gpu(r["qi"], r["st"], None, n, c, handles, 2, cap_per_shard=64)
-    feed = r["feed"].clone()
-    feed[10, 3] = 143          # quantizer index with no model table
-    with pytest.raises(Exception, match="model table"):
-        host.encode_shards_gpu(feed, None, n, c, handles, 2)
     qi = r["qi"].clone()
     qi[3, 10] = 143
     with pytest.raises(Exception, match="model table"):

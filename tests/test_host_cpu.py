@@ -378,7 +378,7 @@ def test_big_outputs_through_pages_made_ahead(tmp_path, estimate_of, monkeypatch
     libc.fclose.argtypes = [C.c_void_p]
     L.qvz_host_write_slabs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
     L.qvz_host_write_slabs.restype = C.c_int
-    monkeypatch.setenv("QVZ_PREALLOC_MIN", "1")
+    monkeypatch.setenv("QVZ_PREALLOC", "min=1")
     rng = np.random.default_rng(11)
     head = b"header written by stdio\n" * 3                     # not page aligned: the mapping starts inside a page
     n = (21 << 20) + 4321
@@ -388,7 +388,7 @@ def test_big_outputs_through_pages_made_ahead(tmp_path, estimate_of, monkeypatch
     if estimate_of == "too_much_and_no_helper":
         # the helper thread / table slot cannot be had AFTER the file was made longer for the mapping: the length is given
         # back at once (nobody would later - the over-estimate's zero bytes would stay behind the shard set)
-        monkeypatch.setenv("QVZ_PREALLOC_FAIL", "1")
+        monkeypatch.setenv("QVZ_PREALLOC", "min=1,fail")
     path = str(tmp_path / "out.bin")
     f = libc.fopen(path.encode(), b"w")
     assert f
