@@ -1,17 +1,10 @@
-// qvz_coder_gpu.hip - "wavefront-serial" arithmetic coder on gfx950: one LANE per shard.
+// qvz_coder_gpu.hip - the arithmetic coder on gfx950 for sharded output (include/qvz_coder.h, SURVEY.md section 8e option B).
 //
-// The reference's stream (src/arith.c:24-116, src/qv_stream.c:9-25) is one serial chain of interval updates, so a
-// single stream cannot be parallelised bit-exactly. Sharded output (include/qvz_coder.h, SURVEY.md section 8e option B)
-// gives S independent chains: each lane below codes one contiguous range of reads exactly as the reference would
-// code a file holding only those reads - same integer interval arithmetic, same E1/E2/E3 renormalisation, same
-// adaptive counts (init 1, step 8, halve-and-+1 when n > 2^19) - with its own model arena in HBM. Lanes of a wave
-// run the same (read, column) step at the same time; what differs per lane is data: table addresses, symbol
-// values, shift counts. The kernel is latency-bound integer work, not a bandwidth kernel: its roofline is the
-// dependent-instruction chain per symbol, and throughput scales with the number of shards in flight.
-//
-// Exactness notes (same restructurings as the host coder, qvz_amd/csrc/host/qvz_coder.c):
-//   floor(range*cum/n): q = (u64)(prod * (1.0/n)) corrected by one step against prod - q*n; prod < 2^42, n < 2^21.
-//   E1/E2 and E3 loops: one count-leading-zeros batch each.
+// The reference's stream (src/arith.c:24-116, src/qv_stream.c:9-25) is one serial chain of interval updates: a single stream cannot
+// be parallelised bit-exactly. S contiguous read ranges give S independent chains, each coded exactly as the reference would code a
+// file holding only those reads - same integer interval arithmetic, same E1/E2/E3 renormalisation, same adaptive counts (init 1,
+// step 8, halve-and-+1 when n > 2^19). The adaptive model runs per (stream, column) in k_model_ranks, the chain with a lane per
+// stream in k_code_records; DESIGN.md section 4 has the layout and the numbers, HISTORY.md what was tried and dropped.
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -337,12 +330,9 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 __device__ unsigned long long g_rk_prof[16];   // [7] prologue, [8] table save, [9] passes, [10] whole pass, [11] .. [13] prologue: to the tables in LDS, the barrier, the first look-up; [14] first passes' prologue
 __device__ unsigned long long g_cr_prof[16];
 __device__ uint32_t g_cr_simd[8];   // SIMD of every wave of one k_code_records workgroup (HW_ID bits 5:4)
-__device__ int g_rk_exp;     // timing experiments (results are wrong): 1 no record store, 2 no transposition/barriers, 4 no cumulative loop, 8 no table update, 16 no timers, 32 / 64 no OR into the table's / the entry's lane mask
-#define RK_T(i) do { if (!(exp_ & 16)) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
-#define RK_EXP(bit) if (!(exp_ & (bit)))
+#define RK_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define RK_T(i) do { } while (0)
-#define RK_EXP(bit)
 #endif
 // Read lists per (stream, cluster) for k_model_ranks<true>: list[cstart[g*K + l] + j] = number (relative to the stream's
 // first read) of the j-th read of stream g that belongs to cluster l. One workgroup of four waves per stream; wave w owns
@@ -713,7 +703,6 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     park(0);
     lookup(0, 0);
 #ifdef QVZ_PROFILE
-    const int exp_ = __builtin_amdgcn_readfirstlane(g_rk_exp);
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     const unsigned long long tloop = tprev;
 #endif
@@ -741,9 +730,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             // instructions cost more than the LDS cycles gave back, model kernels 130.8 -> 136 ms at 100M x 150 -f 0.5.)
             {
                 const unsigned long long bit = ok ? 1ull << lane : 0ull;
-                RK_EXP(32)
                 __hip_atomic_fetch_or(&msk[tb], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                RK_EXP(64)
                 __hip_atomic_fetch_or(&msk[tb + 2 + x], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // counts before this chunk, and ranks inside it: earlier lanes with the same table (e), the same table and
@@ -772,7 +759,6 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 // runs from the nearer end): such a chunk loads one or two entries per lane instead of four - a quarter or half of
                 // the round trip's 48 bytes per lane, of the selects and of the mask counts. (Timing experiment, 100M x 150 -f 0.5:
                 // without this loop the model kernels take 30 % less.) Wave-uniform branches.
-                RK_EXP(4)
                 if (!__ballot(left > 2)) {
                     if (__ballot(left > 1)) {
                         uint32_t c0 = tp[0], c1 = tp[1];
@@ -790,7 +776,6 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                     }
                     left = 0;
                 }
-                RK_EXP(4)
                 while (__ballot(left > 0)) {
                     uint32_t c0 = tp[0], c1 = tp[1], c2 = tp[2], c3 = tp[3];
                     unsigned long long m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
@@ -818,7 +803,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
                 // 130.8 ms at 100M x 150 with one cluster, 234.8 -> 228.5 with three). Lanes without a symbol sit on table 0,
                 // state 0 and store what the lanes that do have them store. (One store per entry by the first lane that holds it
                 // needs two exec-mask regions: measured 4 % slower than the atomics had been.)
-                RK_EXP(8) {
+                {
                 tab[tb + 2 + x] = c_x + STEP * same;
                 tab[tb] = n_b + STEP * hits;
                 }
@@ -858,13 +843,11 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         }
         Record *buf = recbuf;
         RK_T(2);
-        RK_EXP(2)
         __syncthreads();                                         // the previous chunk has been drained
         RK_T(3);
         if (REC8) recbuf8[lane * rb_stride + wave] = outp;
         else buf[lane * rb_stride + wave] = outr;
         if (new_rows) *rowslot(lane, 3) = r_cur[3] - (uint32_t)seg_lo;
-        RK_EXP(2)
         __syncthreads();
         RK_T(4);
         {                                                        // W adjacent columns of one read = W * 16 contiguous bytes
@@ -875,7 +858,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
             // them also waits for every store issued so far, and at this point the latest one is a whole chunk old.
             if (((chunk + 2) & 3) == 0 && !(PF && pf_rest)) park(rb + 128);
             if (rb + rd < nr && col < Cp) {                      // columns Cx .. Cp-1 belong to idle waves: zero records
-                RK_EXP(1) {
+                {
                 if (REC8) RK_STORE8(&rec8_g[((uint64_t)(row >> 2) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 3) * 4 + (col & 3)], recbuf8[rd * rb_stride + cw]);
                 else RK_STORE(&rec_g[((uint64_t)(row >> 1) * (Cp >> 2) + (col >> 2)) * unit_recs + (row & 1) * 4 + (col & 3)], buf[rd * rb_stride + cw]);
                 }
@@ -1787,18 +1770,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         d_work = own_work;
     }
     t_work = wall_ms();
-    // Segments. With room for two record buffers the model kernel of segment i+1 runs beside the coder kernel of
-    // segment i on a second HIP stream (the coder keeps three waves on half of the CUs busy with a latency chain; the
-    // model kernel is throughput work that fills the rest); segments are then at most an eighth of a stream - a quarter with
-    // several clusters, where a segment costs three times the workgroup starts: 309 against 325 ms per step - (every segment
-    // costs the model kernel a table load and save per workgroup - 5 ms per segment at 100M x 150 in round 2, when a
-    // quarter was the best cut; less since a workgroup asks for its tables and its first bytes at once -, and the coder
-    // kernels idle for about (middle segment - first segment) reads' worth of time while the pipeline fills, whatever
-    // the ramp: a quarter 152.3 ms, a sixth 151.3, an eighth 149.8, a tenth 151.6 at 100M x 150 with one cluster; three
-    // clusters: the workspace bounds the segment), the first and the last a quarter of that.
-    // Round 4, packed records: with several clusters the model kernels bound the phase and every segment costs them ~10 ms at
-    // 100M x 150 (12.6 GB of table saves and loads): model kernels 195 / 183.5 / 175 / 164.6 ms with 8 / 6 / 5 / 4 segments; a third
-    // of a stream with a FULL first segment (coder_segments) is the best cut, 191 against 199 ms for the phase.
+    // Segments. With room for two record buffers the model kernel of segment i + 1 runs beside the coder kernel of segment i on a
+    // second HIP stream. A segment costs the model kernel a table load and save per workgroup, and the coder kernels idle while the
+    // pipeline fills: an eighth of a stream with one cluster (first and last a quarter of that), a third with several - where the model
+    // kernels bound the phase and a segment costs them ~10 ms at 100M x 150 - with a FULL first segment (measurements: HISTORY.md).
     seg_reads = (work_bytes / per_read) & ~(uint64_t)3;
     if (seg_reads > longest) seg_reads = longest;
     {
@@ -1824,14 +1799,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     if (getenv("QVZ_CODER_DEBUG"))
         fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu\n",
                 shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size());
-    if (getenv("QVZ_CODER_DEBUG")) {                             // the slices' sizes (words), largest first
-        std::vector<uint32_t> sz;
-        for (uint32_t sl = 0; sl < nslices; ++sl) sz.push_back(h_colbase[sl + 1] - h_colbase[sl]);
-        std::sort(sz.begin(), sz.end(), [](uint32_t a, uint32_t b) { return a > b; });
-        fprintf(stderr, "  table slices (words), every %zuth of %zu, largest first:", sz.size() / 16 + 1, sz.size());
-        for (size_t i = 0; i < sz.size(); i += sz.size() / 16 + 1) fprintf(stderr, " %u", sz[i]);
-        fprintf(stderr, " .. %u\n", sz.back());
-    }
     TRY(area.get((void **)&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
     TRY(area.get((void **)&d_status, sizeof(int32_t)));
@@ -1849,9 +1816,6 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (!rk_classes.empty()) {
             TRY(area.get((void **)&d_cgmap, h_cgmap.size() * 4));
             TRY(hipMemcpyAsync(d_cgmap, h_cgmap.data(), h_cgmap.size() * 4, hipMemcpyHostToDevice, st));
-            if (getenv("QVZ_CODER_DEBUG"))
-                for (const RkClass &c : rk_classes)
-                    fprintf(stderr, "  model kernel class: %u column groups, slices of up to %u words, up to %zu B of LDS per workgroup\n", c.count, c.cap, c.lds);
         }
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_model_ranks<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
@@ -1942,15 +1906,10 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         const int is_first = i == 0, is_last = i + 1 == nseg;
         Record *buf = (Record *)((char *)d_work + (overlap ? (size_t)(i & 1) * seg_reads * per_read : 0));
         hipEvent_t *e = &evs[(size_t)i * 4];
-        // Head start for the coder kernel of the segment before: it is released by an event of the model kernel that has
-        // just ended, across queues, while the next model kernel follows that one in its own queue at once - and a model
-        // kernel that has filled the CUs first leaves a coder workgroup (32 KB of LDS) no room wherever three model
-        // workgroups take a CU's LDS between them (three clusters at 100M x 150: the coder kernel of a segment then took
-        // 44 ms instead of 25, ending with the model kernel beside it). A one-wave kernel that spins for a few tens of
-        // microseconds in front of the model kernel lets the 128 coder workgroups onto the idle CUs first.
-        // (The spin sits BEHIND the wait for the buffer: since the packed records the model kernel of a segment is the shorter of the
-        // two, so coder kernel i - 2 usually ends after model kernel i - 1, and coder kernel i - 1, queued behind it, and this model
-        // kernel would otherwise be released at the same instant: coder kernels of 123 .. 144 ms from step to step.)
+        // Head start for the coder kernel of the segment before: it is released by an event of the model kernel that has just ended,
+        // across queues, while the next model kernel follows in its own queue at once - and a model kernel that has filled the CUs
+        // first leaves the coder workgroups no room. A one-wave kernel that spins for a few tens of microseconds in front of the model
+        // kernel - BEHIND the wait for the buffer, or both kernels are released at the same instant - lets them onto the CUs first.
         if (overlap && i >= 2) TRY(hipStreamWaitEvent(s_model, evs[(size_t)(i - 2) * 4 + 3], 0));   // the coder has drained this buffer
         if (overlap && i >= 1 && spin_us) hipLaunchKernelGGL(k_coder_spin_us, dim3(1), dim3(64), 0, s_model, spin_us);
         TRY(hipEventRecord(e[0], s_model));
@@ -1994,9 +1953,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     if (overlap) TRY(hipStreamWaitEvent(st, evs[(size_t)(nseg - 1) * 4 + 3], 0));   // the last coder kernel ends after everything else
     TRY(hipMemcpyAsync(h_sizes, d_sizes, shards * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    // The wait for a whole encode (0.15 - 0.25 s) polls an event (a load of the completion signal every 20 us) instead of
-    // blocking in hipStreamSynchronize; it made no measurable difference (the seconds-long calls that prompted it turned out
-    // to sit in hipMalloc, see KeptArea) and is kept because it does not depend on interrupt delivery.
+    // the wait polls an event (a load of the completion signal every 20 us): it does not depend on interrupt delivery
     {
         hipEvent_t ev_done = nullptr;
         TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
