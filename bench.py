@@ -62,17 +62,18 @@ CHAIN_KERNELS = ("code_records",)
 
 
 def measured_traffic(kernel, args, cfg, shards, world):
-    """HBM bytes per step of `kernel` from the committed PMC passes of this round (profiles/r04_pmc_traffic_cfgN.json), if
+    """HBM bytes per step of `kernel` from the committed PMC passes of this round (profiles/r05_pmc_traffic_cfgN.json, else round 4's), if
     they were taken on this very workload; None otherwise. (The counters need rocprofv3 around the process: tools/
     collect_profiles.sh runs this very script under it; bench.py itself cannot read them.)"""
     try:
-        with open(os.path.join(ROOT, "profiles", f"r04_pmc_traffic_cfg{args.config}.json")) as f:
+        path = next(p for p in (os.path.join(ROOT, "profiles", f"r{rr:02d}_pmc_traffic_cfg{args.config}.json") for rr in (5, 4)) if os.path.exists(p))
+        with open(path) as f:
             t = json.load(f)
         w = t["workload"]
         same = (w["config"] == args.config and w["reads"] == cfg["reads"] and w["columns"] == cfg["cols"] and
                 w["coder"] == args.coder and w["shards"] == shards and world == 1 and w.get("qv_plane_written", False) == (not args.no_u))
         return t["kernels"][kernel]["hbm_bytes"] if same and kernel in t["kernels"] else None
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         return None
 
 
@@ -187,6 +188,22 @@ def cpu_baseline_multi_core(cfg, cores):
                        f"i * {m} ...), flags {' '.join(flags)}; {cores} host cores visible, CPU quota {cpu_quota_cores(cores)}",
                 note="T separate files: T codebook sets, T streams - not the product the single-thread figure stands for; the honest many-core figure of a "
                      "program that has no threads")
+
+
+def c_step(resident, sym, n, shards, cfg, mode, want_qv, first=0, n_total=None, group=None):
+    """One step through the C driver (qvz_resident_encode, include/qvz_encode.h) -> the dict main() works with: phase seconds
+    as the driver measured them, its own HIP-event kernel times (qvz_resident_products), the products' handle."""
+    k = cfg["clusters"]
+    r, p = resident.encode(sym, n, shards, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], want_qv=want_qv,
+                           first_read=first, n_total=n_total, group=group)
+    stats_in_cluster = r.t_stats if k == 1 else 0.0          # one cluster: the counters are made inside the clustering stage (they give it its sums)
+    wall = dict(kmeans=r.t_cluster - stats_in_cluster, pmf=r.t_stats, codebook=r.t_codebook, quantize=r.t_quantize, coder=r.t_coder,
+                coder_model_kernels=p.model_kernels_ms * 1e-3, coder_interval_kernels=p.coder_kernels_ms * 1e-3, total=r.t_total)
+    kernels = dict(pmf_hist=[p.pmf_kernel_ms], quantize=[p.quantize_kernel_ms])
+    if k > 1:
+        kernels["kmeans_step"] = [p.kmeans_kernels_ms / max(1, r.kmeans_iterations)] * r.kmeans_iterations
+    return dict(stream_bytes=None, total_stream_bytes=int(r.stream_bytes), distortion=r.distortion, kmeans_iterations=r.kmeans_iterations,
+                deferred=r.deferred_decisions, wall=wall, kernels=kernels, products=p)
 
 
 def product_report(r, n, c, k, shards, steps, elapsed):
@@ -313,7 +330,11 @@ def other_configs_report(args, done_cfg, sym_done, threads):
         sym = sym_done if same else K.qgen1(cfg["seed"], n, c)
         mode = host.MODE_RATIO if cfg["mode"] == "f" else host.MODE_FIXED
 
+        resident = host.Resident(torch.cuda.current_device()) if args.driver == "c" else None
+
         def step():
+            if resident is not None:
+                return c_step(resident, sym, n, 8192, cfg, mode, not args.no_u)
             return P.encode_pass(sym, n, 0, n, None, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], shards=8192,
                                  threads=threads, coder="gpu", keep_device=not args.no_u)
 
@@ -328,10 +349,18 @@ def other_configs_report(args, done_cfg, sym_done, threads):
             each.append(round(r["wall"]["total"] * 1e3, 1))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 2
-        out.append(dict(config=cid, workload=cfg["name"], ms_per_step=round(dt * 1e3, 3), step_ms=each, value=round(n * c / dt, 1),
-                        bits_per_symbol=round(r["total_stream_bytes"] * 8.0 / (n * c), 5), kmeans_iterations=r["kmeans_iterations"],
-                        phase_seconds={ph: round(v, 4) for ph, v in r["wall"].items()}))
+        rec = dict(config=cid, workload=cfg["name"], ms_per_step=round(dt * 1e3, 3), step_ms=each, value=round(n * c / dt, 1),
+                   bits_per_symbol=round(r["total_stream_bytes"] * 8.0 / (n * c), 5), kmeans_iterations=r["kmeans_iterations"],
+                   phase_seconds={ph: round(v, 4) for ph, v in r["wall"].items()})
+        if "kernels" in r:                                       # the PMF pass of this configuration against the roofline (1 B per symbol, + 1 B per read of labels)
+            pmf_ms = float(np.mean(r["kernels"]["pmf_hist"]))
+            ach = (n * c + (n if k > 1 else 0)) / (pmf_ms * 1e-3) / 1e9
+            rec["roofline_pmf_hist"] = dict(kernel="pmf_hist", bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                            frac=round(ach / HBM_PEAK_GBPS, 4), ms_per_launch=round(pmf_ms, 4))
+        out.append(rec)
         del r
+        if resident is not None:
+            resident.close()
         if not same:
             del sym
         torch.cuda.empty_cache()
@@ -531,16 +560,7 @@ def main():
     resident = host.Resident(local) if use_c else None
 
     def step_c():
-        r, p = resident.encode(sym, n, shards, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"], want_qv=not args.no_u,
-                               first_read=first, n_total=n_total, group=group)
-        stats_in_cluster = r.t_stats if k == 1 else 0.0          # one cluster: the counters are made inside the clustering stage (they give it its sums)
-        wall = dict(kmeans=r.t_cluster - stats_in_cluster, pmf=r.t_stats, codebook=r.t_codebook, quantize=r.t_quantize, coder=r.t_coder,
-                    coder_model_kernels=p.model_kernels_ms * 1e-3, coder_interval_kernels=p.coder_kernels_ms * 1e-3, total=r.t_total)
-        kernels = dict(pmf_hist=[p.pmf_kernel_ms], quantize=[p.quantize_kernel_ms])
-        if k > 1:
-            kernels["kmeans_step"] = [p.kmeans_kernels_ms / max(1, r.kmeans_iterations)] * r.kmeans_iterations
-        return dict(stream_bytes=None, total_stream_bytes=int(r.stream_bytes), distortion=r.distortion, kmeans_iterations=r.kmeans_iterations,
-                    deferred=r.deferred_decisions, wall=wall, kernels=kernels, products=p)
+        return c_step(resident, sym, n, shards, cfg, mode, not args.no_u, first=first, n_total=n_total, group=group)
 
     def step(timer=None):
         if use_c:
@@ -632,7 +652,7 @@ def main():
         roof = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=measured_traffic(dom, args, cfg, shards, world),
                     ms_per_launch=round(per_launch[dom], 4), algorithmic_bytes_per_launch=int(alg_bytes),
-                    bytes_per_symbol=bps, traffic_source=f"profiles/r04_pmc_traffic_cfg{args.config}.json (rocprofv3 --pmc FETCH_SIZE / "
+                    bytes_per_symbol=bps, traffic_source=f"profiles/r05_pmc_traffic_cfg{args.config}.json, else r04 (rocprofv3 --pmc FETCH_SIZE / "
                     "WRITE_SIZE passes of this workload, FETCH_SIZE x2 per the gfx950 correction); null if the workload differs")
         pmf_ach = (n * c + (n if k > 1 else 0)) / (per_launch["pmf_hist"] * 1e-3) / 1e9
         wall = {ph: round(float(np.mean([r["wall"][ph] for r in results])), 4) for ph in results[-1]["wall"]}
