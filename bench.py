@@ -697,7 +697,7 @@ def main():
                                                phase_ms=round(wall["coder"] * 1e3, 2),
                                                survey_bytes_over_phase_GBps=round(survey / wall["coder"] / 1e9, 1),
                                                note="model + chain kernels' HBM bytes (PMC, profiles/) over SURVEY 8(d)'s bytes for the phase: the records' "
-                                                    "round trip through HBM is the price of splitting the adaptive model from the serial chain (DESIGN.md section 6.7)")
+                                                    "round trip through HBM is the price of splitting the adaptive model from the serial chain (DESIGN.md section 4)")
         if args.roundtrip and args.coder != "host":
             line["roundtrip"] = roundtrip
         line["qv_plane_written_in_step"] = not args.no_u and args.coder != "host"

@@ -699,7 +699,7 @@ int qvz_job_start_draws(qvz_job_t *job) {
         HIP(job_malloc(job, (void **)&job->d_draws, (size_t)job->C * job->ld, QVZ_POOL_DRAWS));
     /* The runtime spreads streams over a few hardware queues and a queue runs its kernels in order: a side stream that
      * shares the default stream's queue would put the generator IN FRONT of the codebook kernels instead of beside them
-     * (DESIGN.md section 8). A candidate is probed (~1 ms) and dropped for the next one if it does not overlap. */
+     * (HISTORY.md section 8). A candidate is probed (~1 ms) and dropped for the next one if it does not overlap. */
     if (job->pool && job->pool->well_stream) job->well_stream = job->pool->well_stream;   /* a resident handle's: made and probed once */
     else {
         if (!(job->well_stream = side_stream(NULL, 0))) { rc = qvz_job_fail(QVZ_E_HIP, "no stream for the WELL draws: %s", qvz_hip_last_error()); goto done; }

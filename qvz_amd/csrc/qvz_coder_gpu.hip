@@ -108,7 +108,7 @@ typedef double rk_d2 __attribute__((ext_vector_type(2)));
 // inside a chunk at most; cum_lo < n; n - cum_hi <= n): cum_lo in bits [0, 21), n - cum_hi in [21, 42), n in [42, 63);
 // PREC_NOOP (n = 1, the rest 0) codes nothing. The model kernel then spends 7 integer instructions per symbol on its record instead of a
 // reciprocal, two Newton steps, three conversions and two products in FP64, its transposition buffer and its stores halve, and
-// so does the record traffic in both directions. The two quotients are made where they are
+// so does the record traffic in both directions (HISTORY.md section 6 item 10). The two quotients are made where they are
 // consumed: by the two loader waves of k_code_records<true>, which share a SIMD of their own - throughput work with eight
 // independent records per block - so that nothing is added to the interval wave's chain. Same quotients to within 2^-52
 // relative (v_rcp_f64 + two Newton steps on n * 2^10, which is exact in a double), the bound Record's proof needs is 2^-47.
@@ -1374,7 +1374,7 @@ extern "C" void qvz_hip_encode_planes_release(void) {
 }
 
 // Bytes of record workspace that let qvz_hip_encode_planes code streams of up to `longest_reads` reads in one segment
-// (16 bytes per record, streams padded to 64, record positions per read padded to 8). A caller that
+// (8 bytes per record, streams padded to 64, record positions per read padded to 8). A caller that
 // allocates the workspace itself - early, beside other work - asks this, caps it (96 GiB, what is free) and passes it in.
 // (Sized for 16-byte records whichever kind a call uses: packed ones need half.)
 extern "C" uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards) {

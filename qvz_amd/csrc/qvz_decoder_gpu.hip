@@ -82,7 +82,7 @@ __device__ __forceinline__ uint32_t ld_take(LaneDecoder &d, uint32_t nb) {   // 
 // so that the 64 bytes the decode needs anyway - four independent 16-byte loads, ONE memory round trip for a lane whose
 // table lies in HBM or the Infinity Cache - also hold the quality values of the first eight states: with the output
 // alphabet behind the counts, in another cache line, mapping the state back to a value was a second dependent round trip
-// for every symbol (4.2 s for 100M x 150 reads). *val: the value of the state (x < card).
+// for every symbol (4.2 s for 100M x 150 reads; HISTORY.md section 6b). *val: the value of the state (x < card).
 __device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restrict__ t, bool last, uint32_t *val) {
     // The first 12 counts come in with the header, so the cumulative search runs in registers: walking the counts one
     // dependent load at a time cost several cache round trips per symbol.

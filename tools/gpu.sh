@@ -6,17 +6,15 @@
 #   tests [pytest args]          a pytest selection (default: the whole -m gpu suite, no -x)
 #   bench [bench.py args]        one bench line -> bench.jsonl
 #   steps <config> <n>           per-step phase times over n steps (periodic slow steps: two streams on one hardware queue)
-#   knob <ENV> <config> v1 v2 .. one bench line per value of a development knob (QVZ_WORK_GIB, QVZ_CODER_HEADSTART_US,
-#                                QVZ_CODER_LDS_PAD, QVZ_CODER_PRIO, QVZ_MODEL_LDS_PAD, QVZ_MODEL_WAVES, QVZ_WELL_PASS_LOG2,
-#                                QVZ_QUANTIZE_T, QVZ_QUANTIZE_RW, GPU_MAX_HW_QUEUES, QVZ_CB_FLOW, QVZ_CB_LOG2, QVZ_CB_PTEMP, ...)
+#   knob <ENV> <config> v1 v2 .. one bench line per value of an environment variable (GPU_MAX_HW_QUEUES, ...)
 #   profiles <config>            bench lines + rocprofv3 kernel stats + the two PMC passes of one configuration (-> profiles/)
 #   stats <config>               rocprofv3 --kernel-trace --stats of one configuration (kernel_stats.csv)
 #   profile-build <config> [ENV=v ...]   a -DQVZ_PROFILE build in /tmp (cycle counters of the coder / model / Lloyd-Max kernels)
 #   streams                      stream-count sweep of the default workload (bits per symbol against ms per step)
 #   cli                          the full-size file-to-file tests through the qvz binary
 #   e2e [pause]                  the qvz binary file to file at 100M x 150, several runs, `pause` seconds between processes
-#   pmf                          PMF pass with three clusters: label bytes against 2-bit labels, groups per thread
-#   codebook                     codebook parity tests, then the phase three ways (host loop / device flow / host libm)
+#   pmf                          PMF parity tests, then the pass's roofline fraction with one and with three clusters
+#   codebook                     codebook parity tests, then the phase with the device's entropies and with the host's libm
 #   decoder                      decoder parity tests, then the full-size round trip
 #   n2 [reads]                   the driver's N = 2 launch line of bench.py with both ranks on this box's one GPU (gloo), then N = 1 beside it
 #   host                         cores, memory, tmpfs and I/O rates of the box (tools/io_bench.c)
@@ -92,39 +90,16 @@ host.egress_rows(K.qgen1(3, 100_000_000, 150), 100_000_000, '$d/in.txt')"
   cmp $d/out.dec $d/out.u && echo "decoded == -u" | tee -a $out/runs.txt; rm -rf $d ;;
 pmf)
   timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py -x -q -k pmf > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest.log
-  python3 - > $out/pmf3.txt 2>&1 <<'PY'
-import os, torch
-from qvz_amd import kernels as K
-n, c, k = 100_000_000, 150, 3
-sym = K.qgen1(3, n, c)
-lab = (torch.arange(sym.shape[1], device="cuda") * 2654435761 >> 7).remainder(3).to(torch.uint8)
-def run(tag, **env):
-    for key in ("QVZ_PMF_LABELS", "QVZ_PMF_Q", "QVZ_PMF_G", "QVZ_PMF_R"):
-        os.environ.pop(key, None)
-    os.environ.update(env)
-    cnt = torch.zeros((k, c, 72, 72), dtype=torch.int32, device="cuda")
-    K.pmf_hist(sym, n, labels=lab, k=k, cnt=cnt)
-    ms = []
-    for _ in range(5):
-        cnt.zero_()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); K.pmf_hist(sym, n, labels=lab, k=k, cnt=cnt); b.record(); torch.cuda.synchronize()
-        ms.append(a.elapsed_time(b))
-    print(f"{tag:32s} {min(ms):.3f} ms  {(n * c + n) / min(ms) / 1e6:.0f} GB/s = {(n * c + n) / min(ms) / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
-    return cnt
-a = run("label bytes, 4 groups", QVZ_PMF_LABELS="bytes")
-same = True
-for q in (4, 6):
-    same = same and bool(torch.equal(a, run(f"2-bit labels, {q} groups", QVZ_PMF_Q=str(q))))
-print("equal:", same)
-PY
-  cat $out/pmf3.txt ;;
+  for cfg in 2 3; do
+    timeout -k 10 300 python3 bench.py --config $cfg --steps 4 --warmup 1 --no-cpu-baseline --no-extras 2> $out/err$cfg.txt | python3 -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('config $cfg', d['roofline_pmf_hist'])"
+  done ;;
 codebook)
   timeout -k 10 900 python3 -m pytest tests/test_gpu_codebook.py tests/test_gpu_encode.py tests/test_gpu_dropin.py -x -q > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest.log
   for cfg in 2 1 3; do
-    for how in default device-flow host-libm; do
-      echo "== config $cfg, $how"; unset QVZ_CB_LOG2 QVZ_CB_FLOW
-      [ $how = host-libm ] && export QVZ_CB_LOG2=host; [ $how = device-flow ] && export QVZ_CB_FLOW=device
+    for how in default host-libm; do
+      echo "== config $cfg, $how"; unset QVZ_CB_LOG2
+      [ $how = host-libm ] && export QVZ_CB_LOG2=host
       QVZ_CB_DEBUG=1 timeout -k 10 300 python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline --no-extras 2> $out/err_${cfg}_$how.txt | line
       grep -m2 "qvz_hip_generate_codebook" $out/err_${cfg}_$how.txt | cut -c1-220
     done
