@@ -203,7 +203,7 @@ def c_step(resident, sym, n, shards, cfg, mode, want_qv, first=0, n_total=None, 
     if k > 1:
         kernels["kmeans_step"] = [p.kmeans_kernels_ms / max(1, r.kmeans_iterations)] * r.kmeans_iterations
     return dict(stream_bytes=None, total_stream_bytes=int(r.stream_bytes), distortion=r.distortion, kmeans_iterations=r.kmeans_iterations,
-                deferred=r.deferred_decisions, wall=wall, kernels=kernels, products=p)
+                deferred=r.deferred_decisions, wall=wall, kernels=kernels, products=p, resident=resident)
 
 
 def product_report(r, n, c, k, shards, steps, elapsed):
@@ -211,13 +211,15 @@ def product_report(r, n, c, k, shards, steps, elapsed):
     shard set (include/qvz_shardset.h: codebooks once + stream index + streams); measured once, outside the timed steps."""
     import torch
     from qvz_amd import host
-    if "products" in r:          # the C driver's step: the streams lie packed on the device already
+    if "products" in r:          # the C driver's step: packed by the handle on request (qvz_resident_pack)
         p = r["products"]
         sizes = [int(p.h_sizes[g]) for g in range(p.shards)]
         handles = [p.codebooks[j] for j in range(p.clusters)]
         torch.cuda.synchronize()
-        t0 = t1 = time.perf_counter()
-        packed = host.device_view(p.d_streams, max(int(p.stream_bytes), 1))[: int(p.stream_bytes)]
+        t0 = time.perf_counter()
+        packed = r["resident"].pack()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
     else:
         sizes = r["stream_bytes"]
         handles = [cb.handle for cb in r["codebooks"]]
@@ -711,7 +713,7 @@ def main():
 
         if not args.no_extras and world == 1 and args.coder == "gpu" and ("coded" in results[-1] or "products" in results[-1]):
             guarded("product", product_report, results[-1], n, c, k, shards, args.steps, elapsed)
-            for key in ("coded", "qv", "labels", "products"):
+            for key in ("coded", "qv", "labels", "products", "resident"):
                 results[-1].pop(key, None)
             if resident is not None:
                 resident.close()                                  # its buffers (150+ GB) make room for what follows

@@ -129,7 +129,7 @@ uint32_t qvz_sweep_parse(const char *text, const qvz_options_t *opts, qvz_sweep_
  * calculate_statistics, generate_codebooks, start_qv_compression) with neither text nor files on either side - a caller that
  * holds the reads on the device (column-major symbols, include/qvz_hip.h: d_sym[s * ld + i] = byte - 33, ld = qvz_hip_ld(n)),
  * and the step bench.py times. `shards` independent reference-format streams coded by the GPU coder stay on the device packed
- * back to back, with the quantized values (want_qv) and the labels; qvz_resident_products says where. A handle keeps its big
+ * each in its slot of the stream area (qvz_resident_pack: back to back), with the quantized values (want_qv) and the labels; qvz_resident_products says where. A handle keeps its big
  * device buffers between encodes; nothing computed is carried from one encode to the next.
  *   A PART of a file (one GPU of several, one process each): reads [first_read, first_read + n) of n_total, first_read a multiple of
  * 4, and `allreduce` - the sum, in place on `stream`, of `count` elements of a device buffer over all parts: width 4 / 8 = unsigned
@@ -142,7 +142,9 @@ uint32_t qvz_sweep_parse(const char *text, const qvz_options_t *opts, qvz_sweep_
 typedef struct qvz_resident qvz_resident_t;
 typedef int (*qvz_allreduce_fn)(void *ctx, void *d_buf, uint64_t count, int width, void *stream);
 typedef struct qvz_resident_products {
-    const uint8_t *d_streams;          /* device: the streams packed back to back, stream g h_sizes[g] bytes              */
+    const uint8_t *d_coded;            /* device: stream g at d_coded + g * cap_per_stream, h_sizes[g] bytes                */
+    uint64_t cap_per_stream;
+    const uint8_t *d_streams;          /* device: the streams packed back to back - NULL until qvz_resident_pack has made them */
     const uint64_t *h_sizes;           /* host: [shards]                                                                    */
     uint32_t shards, clusters;
     uint64_t stream_bytes;
@@ -159,6 +161,9 @@ int qvz_resident_encode(qvz_resident_t *r, const uint8_t *d_sym, uint64_t n, uin
                         qvz_allreduce_fn allreduce, void *allreduce_ctx, qvz_result_t *res);
 /* what the last encode left (valid until the next encode on the handle, or its close) */
 int qvz_resident_products(const qvz_resident_t *r, qvz_resident_products_t *out);
+/* the last encode's streams packed back to back on the device (what travels to the host and into a shard set: 1-2 bits per symbol
+ * instead of the area's 6): made on the first call, *d_packed (may be NULL) receives the address; products then reports it too */
+int qvz_resident_pack(qvz_resident_t *r, const uint8_t **d_packed);
 void qvz_resident_close(qvz_resident_t *r);
 
 /* Decode direction (`qvz -x`, reference src/main.c:132-183, start_qv_decompression src/qv_compressor.c:145-231).

@@ -131,6 +131,7 @@ SIGNATURES = {
     "qvz_resident_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32,
                                       C.c_int, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p]),
     "qvz_resident_products": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "qvz_resident_pack": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "qvz_resident_close": (None, [C.c_void_p]),
     "qvz_hip_gather_reads": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "qvz_hip_sum_errors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -967,9 +967,11 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         /* the streams leave the device packed back to back: 1-2 bits per symbol instead of the 6 the area was sized for */
         /* (into the record workspace when there is one: the coder has finished with it, and one more large hipMalloc is one more
          * place for a young process's allocation stall) */
-        if (job->d_work && job->work_shards == shards && !d_out_own && total <= (uint64_t)(d_out - (uint8_t *)job->d_work)) d_packed = (uint8_t *)job->d_work;
-        else { HIP(job_malloc(job, (void **)&d_packed_own, total ? total : 1, QVZ_POOL_PACKED)); d_packed = d_packed_own; }
-        HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_packed, NULL));
+        if (!job->keep_device) {                                                /* (a resident encode packs when it is asked to: qvz_resident_pack) */
+            if (job->d_work && job->work_shards == shards && !d_out_own && total <= (uint64_t)(d_out - (uint8_t *)job->d_work)) d_packed = (uint8_t *)job->d_work;
+            else { HIP(job_malloc(job, (void **)&d_packed_own, total ? total : 1, QVZ_POOL_PACKED)); d_packed = d_packed_own; }
+            HIP(qvz_hip_gather_streams(d_out, cap, sizes, shards, d_packed, NULL));
+        }
         if (job->keep_device) {
             HIP(qvz_hip_copy_d2h(&job->r_errsum, job->d_errsum, sizeof(double), NULL));
             HIP(qvz_hip_stream_sync(NULL));
@@ -981,7 +983,8 @@ static int compress_sharded_impl(qvz_job_t *job, const char *prefix, FILE *fset,
         }
         if (fu && !text_running) text_running = pthread_create(&th_text, NULL, side_text, &task_text) == 0;
         if (job->keep_device) {                                                 /* a resident encode: the products stay where they are */
-            job->r_packed = d_packed; job->r_total = total;
+            job->r_out = d_out; job->r_cap = cap; job->r_out_in_work = d_out_own == NULL;
+            job->r_packed = NULL; job->r_total = total;
             job->r_sizes = sizes; sizes = NULL;
             job->r_qv = d_qv;
         } else if (job->collect) {                                                     /* a part of a file: the caller assembles the whole */
@@ -1504,6 +1507,8 @@ int qvz_resident_products(const qvz_resident_t *r, qvz_resident_products_t *out)
     if (!r || !out) return qvz_job_fail(QVZ_E_ARG, "null argument");
     if (!r->have_job || !r->job.r_sizes) return qvz_job_fail(QVZ_E_ARG, "no encode has completed on this handle");
     memset(out, 0, sizeof(*out));
+    out->d_coded = r->job.r_out;
+    out->cap_per_stream = r->job.r_cap;
     out->d_streams = r->job.r_packed;
     out->h_sizes = r->job.r_sizes;
     out->shards = r->shards;
@@ -1519,4 +1524,23 @@ int qvz_resident_products(const qvz_resident_t *r, qvz_resident_products_t *out)
     out->pmf_kernel_ms = r->job.k_pmf_ms;
     out->quantize_kernel_ms = r->job.k_quantize_ms;
     return 0;
+}
+
+int qvz_resident_pack(qvz_resident_t *r, const uint8_t **d_packed) {
+    int rc = 0;
+    if (!r || !r->have_job || !r->job.r_sizes) return qvz_job_fail(QVZ_E_ARG, "no encode has completed on this handle");
+    qvz_job_t *job = &r->job;
+    if (!job->r_packed) {
+        uint8_t *dst = NULL;
+        if (qvz_hip_set_device(r->device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
+        /* into the front of the record workspace when the stream area lies behind it there (the coder has finished with it) */
+        if (job->r_out_in_work && job->d_work && job->r_total <= (uint64_t)(job->r_out - (uint8_t *)job->d_work)) dst = (uint8_t *)job->d_work;
+        else HIP(job_malloc(job, (void **)&dst, job->r_total ? job->r_total : 1, QVZ_POOL_PACKED));
+        HIP(qvz_hip_gather_streams(job->r_out, job->r_cap, job->r_sizes, r->shards, dst, NULL));
+        HIP(qvz_hip_stream_sync(NULL));
+        job->r_packed = dst;
+    }
+    if (d_packed) *d_packed = job->r_packed;
+done:
+    return rc;
 }

@@ -55,7 +55,10 @@ typedef struct qvz_job {
     qvz_pool_t *pool;           /* the big device buffers come from here and go back there                                       */
     int sym_borrowed;           /* d_sym is the caller's                                                                          */
     int keep_device;            /* the sharded compress leaves its products on the device: no file, no host copy                  */
-    uint8_t *r_packed, *r_qv;   /* the streams packed back to back / the quantized values (pool blocks)                           */
+    uint8_t *r_packed, *r_qv;   /* the streams packed back to back (made on request) / the quantized values (pool blocks)         */
+    uint8_t *r_out;             /* the streams where the coder wrote them: stream g at r_out + g * r_cap                           */
+    uint64_t r_cap;
+    int r_out_in_work;          /* ... inside the record workspace (behind the records)                                           */
     uint64_t *r_sizes, r_total; /* malloc'd [shards]                                                                              */
     double k_kmeans_ms, k_pmf_ms, k_quantize_ms;   /* busy time of the kernels (HIP events on their stream; k-means: all iterations) */
     double *d_errsum;           /* [1025] this part's distortion sum (qvz_hip_sum_errors)                                          */

@@ -117,7 +117,8 @@ def encode_file_devices(in_path, out_path, devices, shards, clusters=1, mode=MOD
 
 class ResidentProducts(C.Structure):
     """qvz_resident_products_t (include/qvz_encode.h)."""
-    _fields_ = [("d_streams", C.c_void_p), ("h_sizes", C.POINTER(C.c_uint64)), ("shards", C.c_uint32), ("clusters", C.c_uint32),
+    _fields_ = [("d_coded", C.c_void_p), ("cap_per_stream", C.c_uint64), ("d_streams", C.c_void_p), ("h_sizes", C.POINTER(C.c_uint64)),
+                ("shards", C.c_uint32), ("clusters", C.c_uint32),
                 ("stream_bytes", C.c_uint64), ("d_qv", C.c_void_p), ("d_labels", C.c_void_p), ("codebooks", C.POINTER(C.c_void_p)),
                 ("well_state", C.c_uint32 * 32), ("model_kernels_ms", C.c_double), ("coder_kernels_ms", C.c_double),
                 ("kmeans_kernels_ms", C.c_double), ("pmf_kernel_ms", C.c_double), ("quantize_kernel_ms", C.c_double)]
@@ -203,11 +204,20 @@ class Resident:
             out.append(buf.tobytes())
         return out
 
-    @staticmethod
-    def streams(p):
-        """the last encode's streams as a list of bytes (copied from the device)"""
+    def pack(self):
+        """qvz_resident_pack: the last encode's streams back to back on the device -> uint8 device tensor (a view)"""
+        d = C.c_void_p()
+        rc = lib().qvz_resident_pack(self.h, C.byref(d))
+        if rc:
+            raise QvzHipError(f"qvz_resident_pack failed ({rc}): {lib().qvz_encode_last_error().decode(errors='replace')}")
+        p = ResidentProducts()
+        lib().qvz_resident_products(self.h, C.byref(p))
+        return device_view(d.value, max(int(p.stream_bytes), 1))[: int(p.stream_bytes)]
+
+    def streams(self, p):
+        """the last encode's streams as a list of bytes (packed on the device, then copied)"""
         sizes = [int(p.h_sizes[g]) for g in range(p.shards)]
-        packed = device_view(p.d_streams, max(p.stream_bytes, 1)).cpu().numpy()[: p.stream_bytes].tobytes()
+        packed = self.pack().cpu().numpy().tobytes()
         out, at = [], 0
         for sz in sizes:
             out.append(packed[at:at + sz])

@@ -23,7 +23,7 @@ def upload(rows):
     return sym
 
 
-def check_against_oracle(rows, opts, r, p, shards, first=0, n_total=None, whole=None):
+def check_against_oracle(h, rows, opts, r, p, shards, first=0, n_total=None, whole=None):
     """one part's products against the single-process oracle of the WHOLE file (whole = its rows when `rows` is a part)"""
     from qvz_amd import host
     whole = rows if whole is None else whole
@@ -42,7 +42,8 @@ def check_against_oracle(rows, opts, r, p, shards, first=0, n_total=None, whole=
     assert np.array_equal(qv, single["u"][first:first + n, :c])
     assert abs(r.distortion - single["distortion"]) < 1e-9 * max(1.0, single["distortion"])
     bounds = host.shard_bounds(n, shards)
-    streams = host.Resident.streams(p)
+    assert not p.d_streams and p.d_coded and p.cap_per_stream >= max(int(p.h_sizes[g]) for g in range(shards))   # packed on request only
+    streams = h.streams(p)
     assert r.stream_bytes == sum(len(x) for x in streams) == p.stream_bytes
     for g in range(shards):
         a, b = first + bounds[g], first + bounds[g + 1]
@@ -61,10 +62,10 @@ def test_resident_encode_equals_the_oracle_and_the_reference(name, shards):
     res = host.Resident(0)
     hmode = host.MODE_RATIO if opts["mode"] == O.MODE_RATIO else host.MODE_FIXED
     r, p = res.encode(upload(rows), rows.shape[0], shards, clusters=opts["k"], mode=hmode, ratio=opts["ratio"], dist=opts["dist"], want_qv=True)
-    single = check_against_oracle(rows, opts, r, p, shards)
+    single = check_against_oracle(res, rows, opts, r, p, shards)
     assert G.md5(single["u"].tobytes()) == e["u_md5"] and f"{r.distortion:.4f}" == f"{e['distortion']:.4f}"
     if shards == 1:                                               # one stream: the reference's own stream, byte for byte
-        assert host.Resident.streams(p)[0] == G.gz(name + ".q.gz")[-e["size"]:]
+        assert res.streams(p)[0] == G.gz(name + ".q.gz")[-e["size"]:]
     assert p.pmf_kernel_ms > 0 and p.quantize_kernel_ms > 0 and p.model_kernels_ms > 0 and p.coder_kernels_ms > 0
     res.close()
 
@@ -77,7 +78,7 @@ def test_one_handle_many_encodes():
         rows, opts = G.case_rows(name), G.case_opts(name)
         hmode = host.MODE_RATIO if opts["mode"] == O.MODE_RATIO else host.MODE_FIXED
         r, p = res.encode(upload(rows), rows.shape[0], shards, clusters=opts["k"], mode=hmode, ratio=opts["ratio"], dist=opts["dist"], want_qv=True)
-        check_against_oracle(rows, opts, r, p, shards)
+        check_against_oracle(res, rows, opts, r, p, shards)
     # without the quantized values: nothing written, the streams unchanged
     r2, p2 = res.encode(upload(rows), rows.shape[0], shards, clusters=opts["k"], mode=hmode, ratio=opts["ratio"], dist=opts["dist"])
     assert not p2.d_qv and r2.stream_bytes == r.stream_bytes
@@ -145,7 +146,7 @@ def test_eight_parts_through_the_c_entry_with_a_callback_all_reduce():
         t.join(timeout=600)
     assert not errors, errors
     opts = dict(k=k, mode=O.MODE_FIXED, ratio=1.0, dist="M")
-    for first, last, r, p in out:
-        check_against_oracle(rows[first:last], opts, r, p, shards, first=first, n_total=n_total, whole=rows)
+    for rank, (first, last, r, p) in enumerate(out):
+        check_against_oracle(handles[rank], rows[first:last], opts, r, p, shards, first=first, n_total=n_total, whole=rows)
     for h in handles:
         h.close()
