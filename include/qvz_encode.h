@@ -174,6 +174,10 @@ void qvz_resident_close(qvz_resident_t *r);
  * stream_bytes, file_bytes. */
 int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_result_t *res);
 int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_path, int device, qvz_result_t *res);
+/* The GPU decoder works in slabs of whole streams - draws, decode, text, next slab - when a file's matrices (2 C bytes per read)
+ * do not fit the device at once, as a file of 2^32 reads and more never does. reads: most reads per slab (a stream longer than
+ * that is a slab by itself); 0 = by the device's free memory, the default. Process-wide; the output does not depend on it. */
+void qvz_decode_set_slab_reads(uint64_t reads);
 
 const char *qvz_encode_last_error(void);
 

@@ -338,27 +338,33 @@ int qvz_decode_file(const char *in_path, const char *out_path, int device, qvz_r
  * decoder and written as text. streams[g] points at sizes[g] bytes. */
 static double dec_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
+/* A file is decoded in SLABS of whole streams when its matrices - the draws and the quantized values, 2 C bytes per read - do not fit
+ * the device at once (a file of 2^32 reads and more always: 1.3 TB at 150 columns): the streams of a slab are decoded together,
+ * their text is appended, the next slab follows with the WELL generator advanced to its first read. 0 = by the device's free memory;
+ * the setter is a test hook (slabs of a few thousand reads on small files must give the same text). */
+static uint64_t g_slab_reads = 0;
+void qvz_decode_set_slab_reads(uint64_t reads) { g_slab_reads = reads; }
+
 int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codebook_t *const *cbs, const uint32_t *well,
                            uint32_t shards, const uint64_t *bounds, const uint8_t *const *streams, const uint64_t *sizes,
                            const char *out_path, int device) {
     int rc = QVZ_OK;
     uint8_t *h_packed = NULL, *d_packed = NULL, *d_in = NULL, *d_draws = NULL, *d_qv = NULL, *d_labels = NULL;
+    uint64_t *first = NULL, *rel = NULL;
     FILE *fo = NULL;
-    uint64_t cap = 0, total = 0;
-    int contiguous = 1;
-    for (uint32_t g = 0; g < shards; ++g) {
-        if (sizes[g] > cap) cap = sizes[g];
-        if (g + 1 < shards && streams[g + 1] != streams[g] + sizes[g]) contiguous = 0;
-        total += sizes[g];
-    }
-    cap = (cap + 7) & ~3ull;
     /* N and C come from a file somebody else wrote: every product below must be the number it looks like */
-    if (!qvz_plausible_matrix(N, C) || shards == 0 || cap > (UINT64_MAX >> 1) / shards)
+    if (!qvz_plausible_matrix(N, C) || shards == 0)
         return qvz_job_fail(QVZ_E_DATA, "implausible size: %llu lines of %u columns in %u streams", (unsigned long long)N, C, shards);
-    const uint64_t ld = qvz_hip_ld(N);
-    if (qvz_hip_set_device(device)) return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error());
+    first = (uint64_t *)malloc(((size_t)shards + 1) * sizeof(uint64_t));
+    rel = (uint64_t *)malloc(((size_t)shards + 1) * sizeof(uint64_t));
+    if (!first || !rel) { free(first); free(rel); return qvz_job_fail(QVZ_E_NOMEM, "host alloc"); }
+    if (bounds) memcpy(first, bounds, ((size_t)shards + 1) * sizeof(uint64_t));
+    else qvz_shard_bounds(N, shards, first);
+    for (uint32_t g = 0; g < shards; ++g)
+        if (first[g + 1] < first[g] || first[g + 1] > N) { free(first); free(rel); return qvz_job_fail(QVZ_E_DATA, "the streams' read ranges are not in order"); }
+    if (qvz_hip_set_device(device)) { free(first); free(rel); return qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); }
     fo = fopen(out_path, "w");
-    if (!fo) return qvz_job_fail(QVZ_E_ARG, "Unable to open output file");
+    if (!fo) { free(first); free(rel); return qvz_job_fail(QVZ_E_ARG, "Unable to open output file"); }
     {
         /* The text's pages are made while the GPU decodes - but N and C are a header's claim until the streams have decoded, and
          * a small crafted file may claim 1e9 x 150: pages are made ahead only for a text the output's file system reports room
@@ -372,44 +378,79 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
             text <= (uint64_t)vfs.f_bavail * (uint64_t)vfs.f_frsize)
             qvz_prealloc_start(fo, text);
     }
-    const double t_0 = dec_now();
-    double t_up = t_0, t_dec = t_0;
+    /* reads per slab: what two matrices of C bytes per read may take of the free memory (40 % of it; the streams and the labels
+     * are small beside them), never 2^32 or more (the kernels' per-call read counts), at least one stream */
+    uint64_t slab_reads = g_slab_reads;
+    if (!slab_reads) {
+        uint64_t free_b = 0;
+        slab_reads = 1ull << 31;
+        if (qvz_hip_mem_info(&free_b, NULL) == QVZ_OK && free_b / 5 * 2 / (2ull * C + 1) < slab_reads) slab_reads = free_b / 5 * 2 / (2ull * C + 1);
+    }
+    if (slab_reads >= (1ull << 32)) slab_reads = (1ull << 32) - 256;
 #define HIPC(call) do { if ((call) != QVZ_OK) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; } } while (0)
-    /* the streams go up packed (they lie back to back in a shard set; the pieces of shard FILES are packed first) through
-     * pinned slabs and are spread to the decoder's fixed-stride layout on the device */
-    if (!contiguous) {
-        h_packed = (uint8_t *)malloc(total ? total : 1);
-        if (!h_packed) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
-        for (uint64_t g = 0, at = 0; g < shards; at += sizes[g], ++g) memcpy(h_packed + at, streams[g], sizes[g]);
+    double t_upload = 0.0, t_decode = 0.0, t_egress = 0.0;
+    uint32_t nslabs = 0;
+    for (uint32_t g0 = 0; g0 < shards;) {
+        /* the slab: streams g0 .. g1 - 1 */
+        uint32_t g1 = g0 + 1;
+        while (g1 < shards && first[g1 + 1] - first[g0] <= slab_reads) ++g1;
+        const uint32_t ns = g1 - g0;
+        const uint64_t r0 = first[g0], n = first[g1] - r0, ld = qvz_hip_ld(n);
+        uint64_t cap = 0, total = 0;
+        int contiguous = 1;
+        if (n >= (1ull << 32)) { rc = qvz_job_fail(QVZ_E_DATA, "stream %u: %llu reads from read %llu cannot be decoded in one piece", g0, (unsigned long long)n, (unsigned long long)r0); goto done; }
+        for (uint32_t g = g0; g < g1; ++g) {
+            if (sizes[g] > cap) cap = sizes[g];
+            if (g + 1 < g1 && streams[g + 1] != streams[g] + sizes[g]) contiguous = 0;
+            total += sizes[g];
+            rel[g - g0] = first[g] - r0;
+        }
+        rel[ns] = n;
+        cap = (cap + 7) & ~3ull;
+        if (cap > (UINT64_MAX >> 1) / ns) { rc = qvz_job_fail(QVZ_E_DATA, "implausible stream sizes"); goto done; }
+        const double t_0 = dec_now();
+        /* the streams go up packed (they lie back to back in a shard set; the pieces of shard FILES are packed first) through
+         * pinned slabs and are spread to the decoder's fixed-stride layout on the device */
+        if (!contiguous) {
+            h_packed = (uint8_t *)malloc(total ? total : 1);
+            if (!h_packed) { rc = qvz_job_fail(QVZ_E_NOMEM, "host alloc"); goto done; }
+            for (uint64_t g = g0, at = 0; g < g1; at += sizes[g], ++g) memcpy(h_packed + at, streams[g], sizes[g]);
+        }
+        HIPC(qvz_hip_malloc((void **)&d_packed, total ? total : 1));
+        HIPC(qvz_hip_malloc((void **)&d_in, (size_t)ns * cap));
+        HIPC(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
+        HIPC(qvz_hip_well_draws(well, r0, n, C, d_draws, ld, NULL));            /* beside the upload; the generator advanced to the slab's first read */
+        if ((rc = qvz_ingress_bytes(d_packed, contiguous ? streams[g0] : h_packed, total))) goto done;
+        HIPC(qvz_hip_scatter_streams(d_packed, sizes + g0, ns, d_in, cap, NULL));
+        qvz_hip_free(d_packed); d_packed = NULL;
+        free(h_packed); h_packed = NULL;
+        const double t_up = dec_now();
+        HIPC(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
+        HIPC(qvz_hip_malloc((void **)&d_labels, ld));
+        if (qvz_hip_decode_shards_bounds(d_in, cap, sizes + g0, n, C, K, cbs, ns, rel, d_draws, ld, d_qv, d_labels, NULL)) {
+            rc = qvz_job_fail(QVZ_E_DATA, "%s", qvz_hip_last_error());
+            goto done;
+        }
+        HIPC(qvz_hip_stream_sync(NULL));
+        const double t_dec = dec_now();
+        qvz_hip_free(d_draws); d_draws = NULL;
+        qvz_hip_free(d_in); d_in = NULL;
+        if ((rc = qvz_egress_text(fo, d_qv, n, C, ld, NULL))) goto done;        /* the text leaves in slabs: no N-sized host buffer */
+        qvz_hip_free(d_qv); d_qv = NULL;
+        qvz_hip_free(d_labels); d_labels = NULL;
+        t_upload += t_up - t_0; t_decode += t_dec - t_up; t_egress += dec_now() - t_dec;
+        nslabs += 1;
+        g0 = g1;
     }
-    HIPC(qvz_hip_malloc((void **)&d_packed, total ? total : 1));
-    HIPC(qvz_hip_malloc((void **)&d_in, (size_t)shards * cap));
-    HIPC(qvz_hip_malloc((void **)&d_draws, (size_t)C * ld));
-    HIPC(qvz_hip_well_draws(well, 0, N, C, d_draws, ld, NULL));                /* beside the upload */
-    if ((rc = qvz_ingress_bytes(d_packed, contiguous ? streams[0] : h_packed, total))) goto done;
-    HIPC(qvz_hip_scatter_streams(d_packed, sizes, shards, d_in, cap, NULL));
-    qvz_hip_free(d_packed); d_packed = NULL;
-    t_up = dec_now();
-    HIPC(qvz_hip_malloc((void **)&d_qv, (size_t)C * ld));
-    HIPC(qvz_hip_malloc((void **)&d_labels, ld));
-    if (qvz_hip_decode_shards_bounds(d_in, cap, sizes, N, C, K, cbs, shards, bounds, d_draws, ld, d_qv, d_labels, NULL)) {
-        rc = qvz_job_fail(QVZ_E_DATA, "%s", qvz_hip_last_error());
-        goto done;
-    }
-    HIPC(qvz_hip_stream_sync(NULL));
 #undef HIPC
-    t_dec = dec_now();
-    qvz_hip_free(d_draws); d_draws = NULL;
-    qvz_hip_free(d_in); d_in = NULL;
-    rc = qvz_egress_text(fo, d_qv, N, C, ld, NULL);                            /* the text leaves in slabs: no N-sized host buffer */
     if (getenv("QVZ_TIMING"))                                                  /* where the wall time went, one line on stderr */
-        fprintf(stderr, "qvz_timing: decode upload=%.4f decode=%.4f egress=%.4f lines=%llu columns=%u streams=%u\n", t_up - t_0, t_dec - t_up,
-                dec_now() - t_dec, (unsigned long long)N, C, shards);
+        fprintf(stderr, "qvz_timing: decode upload=%.4f decode=%.4f egress=%.4f lines=%llu columns=%u streams=%u slabs=%u\n", t_upload, t_decode, t_egress,
+                (unsigned long long)N, C, shards, nslabs);
 done:
     qvz_prealloc_finish(fo);
     if (fo) fclose(fo);
     qvz_hip_free(d_packed); qvz_hip_free(d_in); qvz_hip_free(d_draws); qvz_hip_free(d_qv); qvz_hip_free(d_labels);
-    free(h_packed);
+    free(h_packed); free(first); free(rel);
     return rc;
 }
 

@@ -453,6 +453,40 @@ def test_cli_qvz_devices_env(tmp_path):
     assert G.md5(open(d, "rb").read()) == e["u_md5"]
 
 
+@pytest.mark.parametrize("name,shards", [("t2k_c3_f05_M", 16), ("cfg1_f05_L", 64), ("r35_high_rate", 5)])
+def test_decoding_in_slabs_gives_the_same_text(tmp_path, name, shards):
+    """A file whose matrices do not fit the device - any file of 2^32 reads and more - is decoded in slabs of whole streams: draws
+    from the generator advanced to the slab's first read, decode, text appended (qvz_decode_set_slab_reads). Forced on small
+    files: one stream per slab, a few streams per slab with a ragged last slab, and the default (one slab) all give the
+    reference's -u text, for a shard set and for shard files."""
+    from qvz_amd import host
+    from qvz_amd._lib import lib
+    e = G.CASES[name]
+    inp, _ = write_input(tmp_path, name)
+    opts = G.case_opts(name)
+    n = e["input"]["n"]
+    q, prefix = str(tmp_path / "x.qset"), str(tmp_path / "p")
+    fresh_process_rand()
+    host.encode_file_shardset(inp, q, shards, clusters=opts["k"], mode=opts["mode"], ratio=opts["ratio"], dist=opts["dist"],
+                              seed_mode=host.SEED_DEBUG)
+    host.shardset_split(q, prefix)
+    per = -(-n // shards)
+    try:
+        for slab in (1, per * 3 + 1, n - 1, n, 0):
+            lib().qvz_decode_set_slab_reads(slab)
+            dec = str(tmp_path / f"x{slab}.dec")
+            assert lib().qvz_shardset_decode(q.encode(), dec.encode(), 0, None) == 0, lib().qvz_encode_last_error()
+            assert G.md5(open(dec, "rb").read()) == e["u_md5"], f"shard set, slabs of {slab} reads"
+            assert lib().qvz_decode_shard_files(prefix.encode(), shards, dec.encode(), 0, None) == 0, lib().qvz_encode_last_error()
+            assert G.md5(open(dec, "rb").read()) == e["u_md5"], f"shard files, slabs of {slab} reads"
+    finally:
+        lib().qvz_decode_set_slab_reads(0)
+    # the binary reports how many slabs it took (QVZ_TIMING) - the default on a small file is one
+    env = dict(os.environ, QVZ_TIMING="1")
+    err = subprocess.run([QVZ_BIN, "-x", q, str(tmp_path / "cli.dec")], env=env, capture_output=True, text=True, check=True).stderr
+    assert re.search(r"qvz_timing: decode .* slabs=1\b", err), err
+
+
 def test_sharded_streams_that_outgrow_their_first_allotment(tmp_path):
     """Near-uniform input over all 72 symbols at -f 1.0 needs more than the 6 bits per symbol a stream is given at first
     (log2 72 = 6.17): the GPU coder reports the overflow, the driver repeats the coding with twice the room, and the set
