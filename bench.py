@@ -608,19 +608,30 @@ def main():
     roundtrip = None
     if args.roundtrip and args.coder != "host":
         # full-size parity property: encode -> decode of every stream reproduces the quantized values bit for bit
-        r = P.encode_pass(sym, n, first, n_total, means0, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"],
-                          shards=shards, threads=threads, group=group, device_index=local, coder=args.coder, keep_device=True)
         draws = K.well_draws(np.full(32, 0x55555555, dtype=np.uint32), first, n, c)
+        if use_c:                    # one more step of the C driver, keeping the quantized values; its products stay in the handle
+            rr = c_step(resident, sym, n, shards, cfg, mode, True, first, n_total, group)
+            p = rr["products"]
+            ldq = sym.shape[1]
+            coded = host.device_view(p.d_coded, p.cap_per_stream * shards)
+            sizes = [int(p.h_sizes[g]) for g in range(shards)]
+            want_qv = host.device_view(p.d_qv, c * ldq).view(c, ldq)
+            want_lab = host.device_view(p.d_labels, n) if k > 1 else None
+            handles, cap = [p.codebooks[j] for j in range(k)], int(p.cap_per_stream)
+        else:
+            r = P.encode_pass(sym, n, first, n_total, means0, clusters=k, mode=mode, ratio=cfg["ratio"], dist=cfg["dist"],
+                              shards=shards, threads=threads, group=group, device_index=local, coder=args.coder, keep_device=True)
+            coded, cap, sizes, want_qv, want_lab = r["coded"], r["cap_per_shard"], r["stream_bytes"], r["qv"], r["labels"]
+            handles = [cb.handle for cb in r["codebooks"]]
         torch.cuda.synchronize()
         td = time.perf_counter()
-        qv, lab = host.decode_shards_gpu(r["coded"], r["cap_per_shard"], r["stream_bytes"], n, c,
-                                         [cb.handle for cb in r["codebooks"]], shards, draws)
+        qv, lab = host.decode_shards_gpu(coded, cap, sizes, n, c, handles, shards, draws)
         torch.cuda.synchronize()
         td = time.perf_counter() - td
-        same = bool(torch.equal(qv[:, :n], r["qv"][:, :n])) and (k == 1 or bool(torch.equal(lab[:n], r["labels"][:n])))
+        same = bool(torch.equal(qv[:, :n], want_qv[:, :n])) and (k == 1 or bool(torch.equal(lab[:n], want_lab[:n])))
         roundtrip = dict(decoded_equals_quantized=same, decode_seconds=round(td, 4),
                          decode_symbols_per_second=round(n * c / td, 1), streams=shards)
-        del qv, lab, draws, r
+        del qv, lab, draws
     if rank == 0:
         spans = timer.totals_ms()
         if use_c:                    # the C driver's own HIP events around its launches, on their stream (qvz_resident_products)

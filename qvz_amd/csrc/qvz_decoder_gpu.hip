@@ -38,35 +38,70 @@
 #define STEP 8u
 #define NO_TABLE 0xFFFFFFFFu
 
-// floor(prod / d) for prod < 2^53, quotient < 2^32: estimate by v_rcp_f64, one correction against the exact remainder
-__device__ __forceinline__ uint32_t dec_div(uint64_t prod, uint32_t d) {
-    const double pd = (double)(uint32_t)(prod >> 32) * 4294967296.0 + (double)(uint32_t)prod;
-    uint32_t q = (uint32_t)(pd * __builtin_amdgcn_rcp((double)d));
-    const int64_t r = (int64_t)prod - (int64_t)((uint64_t)q * d);
-    if (r < 0) q -= 1;
-    else if (r >= (int64_t)d) q += 1;
-    return q;
+// 1 / d to the last bit or two: v_rcp_f64 (good to 2^-23 of the value: a seed) and two Newton steps, the residual exact in an fma
+__device__ __forceinline__ double dec_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(e, r, r);
 }
+#define DEC_QUOT_LO 5.9604644775390625e-08    /* 2^-24 */
+#define DEC_QUOT_HI 0.99999994039535522461    /* 1 - 2^-24 */
 
+#ifdef QVZ_PROFILE          // development build: shader cycles of one wave per section of the symbol chain
+__device__ unsigned long long g_dec_prof[8];
+#define DP_NOW() __builtin_readcyclecounter()
+#else
+#define DP_NOW() 0ull
+#endif
+
+typedef uint32_t dec_u32x4 __attribute__((ext_vector_type(4)));
+
+// The interval is kept as the encoder's chain keeps it (qvz_coder_gpu.hip, Record): l and ~u left-aligned in 32 bits - l32 = l << 10,
+// nu32 = (~u & MASK) << 10 - so that (u - l + 1) * 1024 = 2^32 - (l32 + nu32), the shared leading bits of l and u are the leading
+// zeros of ~(l32 ^ nu32), the E3 positions those of ~(l32 & nu32) below the top bit, and a shift keeps the invariants without
+// masks; the tag the same way (t32 = t << 10). Every quotient is a product with a reciprocal made to the last bits:
+//   sub = floor((gap n - 1) / R)       = trunc((gap n - 1/2) / R): the true value is a multiple of 1 / R (R <= 2^22), the shifted one
+//                                        at least 2^-23 away from an integer on either side, the computed one within 2^-30 of it
+//   l  += floor(R cum_lo / n),  ~u += ceil(R (n - cum_hi) / n): the encoder's two fma, its constants and its proof (there)
+// instead of three divisions with exact integer remainders (35 instructions each, of the ~450 a symbol took).
 struct LaneDecoder {
-    uint32_t l, u, t;
+    uint32_t l32, nu32, t32;
     uint64_t buf;            // next bits of the stream, left-aligned
     uint32_t avail;          // valid bits in buf
     const uint8_t *src;
     uint64_t pos, size;      // next byte to load (multiple of 4), stream length
+    // the dword behind `buf` is requested when its predecessor is consumed and looked at a refill later (~23 symbols at 1.4 bits
+    // per symbol): a load whose value is needed at once would also wait - loads return in order - for the next symbol's table
+    // header, which is requested before the interval update so that its round trip passes behind that work
+    uint32_t next_raw, next_left;   // the raw dword and how many of its bytes belong to the stream (0: past the end, nothing loaded)
+#ifdef QVZ_PROFILE
+    unsigned long long c_head, c_rest, c_n;
+#endif
 };
 
-__device__ __forceinline__ void ld_refill(LaneDecoder &d) {     // afterwards avail > 32 (zeros past the end, os_stream.c:36-52)
+__device__ __forceinline__ void ld_request(LaneDecoder &d) {     // the stream's next dword -> next_raw (zeros past the end, os_stream.c:36-52)
+    const bool in = d.pos < d.size;
+    const uint64_t left = d.size - d.pos;
+    d.next_left = !in ? 0u : left < 4 ? (uint32_t)left : 4u;
+    // one unconditional load (past the end: the stream's first dword, which nobody looks at): a load under a condition was a second
+    // register for the dword and a copy - a use, so a wait - right behind the load. (The area behind a stream is readable.)
+    d.next_raw = *reinterpret_cast<const uint32_t *>(d.src + (in ? d.pos : 0));
+    d.pos += 4;
+}
+
+// Called at the top of a symbol, when the symbol's table header has just landed - and with it, loads return in order, the dword
+// requested at the refill before: no wait. Afterwards avail >= 32: enough for the E1/E2 bits of the symbol (22 at most); the E3
+// bits (21 at most) find avail >= 21 unless E1/E2 took twelve or more, and ld_back refills then (with a wait) before it takes them.
+__device__ __forceinline__ void ld_refill(LaneDecoder &d) {
     if (d.avail <= 32) {
-        uint32_t w = 0;
-        if (d.pos < d.size) {
-            w = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(d.src + d.pos));   // the area behind a stream is readable
-            const uint64_t left = d.size - d.pos;
-            if (left < 4) w &= ~0u << (8 * (4 - (uint32_t)left));
-        }
+        uint32_t w = __builtin_bswap32(d.next_raw);
+        w = d.next_left >= 4 ? w : d.next_left ? w & (~0u << (8 * (4 - d.next_left))) : 0u;
         d.buf |= (uint64_t)w << (32 - d.avail);
         d.avail += 32;
-        d.pos += 4;
+        __builtin_amdgcn_sched_barrier(0);                       // the old dword is used up: the new one may take its register
+        ld_request(d);
     }
 }
 
@@ -77,58 +112,69 @@ __device__ __forceinline__ uint32_t ld_take(LaneDecoder &d, uint32_t nb) {   // 
     return v;
 }
 
-// One symbol with table t; returns the state, or 0xFFFFFFFF on a corrupt stream. Decoder tables are laid out
-//   [n][card][recon 0..7, a byte each][counts 0 .. card-1][recon 8 .. card-1]
+// Decoder tables are laid out, 64 bytes aligned,
+//   [n][card][recon 0..7, a byte each][counts 0 .. card-1, zeros up to twelve][counts 12 ..][recon 8 .. card-1]
 // so that the 64 bytes the decode needs anyway - four independent 16-byte loads, ONE memory round trip for a lane whose
-// table lies in HBM or the Infinity Cache - also hold the quality values of the first eight states: with the output
-// alphabet behind the counts, in another cache line, mapping the state back to a value was a second dependent round trip
-// for every symbol (4.2 s for 100M x 150 reads; HISTORY.md section 6b). *val: the value of the state (x < card).
-__device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restrict__ t, bool last, uint32_t *val) {
-    // The first 12 counts come in with the header, so the cumulative search runs in registers: walking the counts one
-    // dependent load at a time cost several cache round trips per symbol.
-    const uint4 h0 = reinterpret_cast<const uint4 *>(t)[0], h1 = reinterpret_cast<const uint4 *>(t)[1],
-                h2 = reinterpret_cast<const uint4 *>(t)[2], h3 = reinterpret_cast<const uint4 *>(t)[3];
-    const uint32_t n = h0.x, card = h0.y;
-    const uint32_t cn[12] = {h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
-    const uint32_t range = d.u - d.l + 1;
-    const uint64_t gap = (uint64_t)(d.t - d.l) + 1;
-    const uint32_t sub = dec_div(gap * n - 1, range);           // arith.c:134 / :199 (below n, so 32 bits hold it either way)
-    uint32_t cum = 0, k = 0, fxr = 0;                            // arith.c:136-139: first k with c_0 + .. + c_k > sub
-    bool found = false;
+// table lies in HBM or the Infinity Cache, one half of a 128-byte line - also hold the quality values of the first eight states:
+// with the output alphabet behind the counts, in another cache line, mapping the state back to a value was a second dependent
+// round trip for every symbol (4.2 s for 100M x 150 reads; HISTORY.md section 6b). The zeros behind a short table's counts let
+// the search run over twelve counts without asking where the table ends.
+struct DecHeader { dec_u32x4 a, b, c, d; };
+__device__ __forceinline__ DecHeader ld_header(const uint32_t *t) {
+    DecHeader h;
+    h.a = reinterpret_cast<const dec_u32x4 *>(t)[0]; h.b = reinterpret_cast<const dec_u32x4 *>(t)[1];
+    h.c = reinterpret_cast<const dec_u32x4 *>(t)[2]; h.d = reinterpret_cast<const dec_u32x4 *>(t)[3];
+    return h;
+}
+__device__ __forceinline__ uint32_t dec_counts_end(uint32_t card) { return 4 + (card > 12 ? card : 12u); }   // where recon 8.. begins, in words
+
+// A symbol is decoded in three parts so that the NEXT symbol's table header can be requested as soon as this symbol's value -
+// the next context - is known, and its memory round trip (2 300 of a symbol's 4 800 cycles when it was waited for at the top of
+// the next symbol: profiles/r05_decoder_cycles.txt) passes behind the interval update:
+//   ld_front   the state x of the tag under the table (arith.c:134-139), its value, the counts below it (lo) and its own (fx)
+//   ld_update  update_stats (qv_stream.c:12-24): the table's two stores, the halving when n passes the limit
+//   ld_back    the interval and the tag after the symbol (arith.c:146-181)
+// All three are straight-line code for every lane - a lane without a symbol to decode works on the tables of a stream that
+// does not exist (the arena's last slot), its results go nowhere -: per-lane conditions around them cost more scalar mask
+// instructions than they saved vector ones (a lone wave pays every instruction with its issue latency). Branches are left where
+// lanes rarely go: tables of more than twelve states, states beyond the eighth, the halving, the stream's next dword.
+// Returns the state; *ok = false when the tag runs off the table (the counts of a table add up to n and the tag lies inside the
+// interval whatever the stream's bits are, so this is a table or an interval nobody made).
+__device__ __forceinline__ uint32_t ld_front(const LaneDecoder &d, const DecHeader &h, const uint32_t *__restrict__ t,
+                                             uint32_t *val, uint32_t *lo_out, uint32_t *fx_out, bool *ok) {
+    const uint32_t n = h.a.x, card = h.a.y;
+    const uint32_t cn[12] = {h.b.x, h.b.y, h.b.z, h.b.w, h.c.x, h.c.y, h.c.z, h.c.w, h.d.x, h.d.y, h.d.z, h.d.w};
+    const double rd = 4294967296.0 - (double)(d.l32 + d.nu32);  // (u - l + 1) * 1024
+    const double nd = (double)n;
+    const double num = __builtin_fma((double)(d.t32 - d.l32), nd, __builtin_fma(1024.0, nd, -512.0));   // ((t - l + 1) n - 1/2) * 1024, exact (t - l + 1 may be 2^22)
+    const uint32_t sub = (uint32_t)(num * dec_rcp(rd));         // arith.c:134 / :199 (below n)
+    // arith.c:136-139: the state x whose counts straddle sub - lo = c_0 + .. + c_(x-1) <= sub < lo + c_x. The first twelve counts
+    // came with the header (walking them one dependent load at a time cost several cache round trips per symbol); behind a
+    // short table's counts they are zeros, the running sum stays n there and n > sub.
+    uint32_t lo = 0, fx = cn[0], x = 0, p = cn[0];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const bool take = !found && (uint32_t)i < card && sub >= cum;
-        cum += take ? cn[i] : 0u;
-        fxr = take ? cn[i] : fxr;
-        k += take ? 1u : 0u;
-        found = found || !take;
+    for (int i = 1; i < 12; ++i) {
+        const bool take = p <= sub;
+        lo = take ? p : lo;
+        fx = take ? cn[i] : fx;
+        x += take ? 1u : 0u;
+        p += cn[i];
     }
-    while (k >= 12 && k < card && sub >= cum) { fxr = t[4 + k++]; cum += fxr; }   // long tables: the rest from memory
-    if (sub >= cum) return 0xFFFFFFFFu;                          // ran off the table: not a stream of this model
-    const uint32_t x = k - 1;
+    if (card > 12 && p <= sub) {                                 // long tables: the rest from memory
+        uint32_t k = 12;
+        do { lo = p; fx = t[4 + k]; p += fx; x = k++; } while (k < card && p <= sub);
+    }
+    *ok = sub - lo < fx;                                         // (lo <= sub by construction)
     // the state's value: one of the eight bytes that came with the header, or - long tables, rare states - behind the counts
-    *val = x < 8 ? ((x < 4 ? h0.z : h0.w) >> (8 * (x & 3))) & 0xFF
-                 : (t[4 + card + ((x - 8) >> 2)] >> (8 * (x & 3))) & 0xFF;
-    if (last) return x;                                          // decoder_last_step: nothing else changes
-    const uint32_t fx = fxr, cum_lo = cum - fx;
-    uint32_t u = d.l + dec_div((uint64_t)range * cum, n) - 1;    // arith.c:146-147
-    uint32_t l = d.l + dec_div((uint64_t)range * cum_lo, n);
-    uint32_t tg = d.t;
-    // E1/E2 (arith.c:158-170): k1 leading bits shared by l and u leave, k1 stream bits enter the tag
-    const uint32_t diff = l ^ u;
-    const uint32_t k1 = diff ? (uint32_t)__clz((int)diff) - (32 - M_BITS) : M_BITS;
-    l = (l << k1) & MASK_M;
-    u = ((u << k1) & MASK_M) | ((1u << k1) - 1);
-    tg = ((tg << k1) & MASK_M) | ld_take(d, k1);
-    ld_refill(d);
-    // E3 (arith.c:171-181): j positions below the MSB with l = 1, u = 0; the tag's new MSB is flipped once
-    const uint32_t xx = (~l | u) & MASK_M1;
-    const uint32_t j = xx ? (uint32_t)__clz((int)xx) - (32 - (M_BITS - 1)) : M_BITS - 1;
-    l = (l << j) & MASK_M1;
-    u = ((u << j) & MASK_M1) | MSB | ((1u << j) - 1);
-    tg = (((tg << j) & MASK_M) | ld_take(d, j)) ^ (j ? MSB : 0u);
-    ld_refill(d);
-    d.l = l; d.u = u; d.t = tg;
+    uint32_t v = ((x & 4 ? h.a.w : h.a.z) >> (8 * (x & 3))) & 0xFF;
+    if (x >= 8) v = (t[dec_counts_end(card) + ((x - 8) >> 2)] >> (8 * (x & 3))) & 0xFF;
+    *val = v;
+    *lo_out = lo;
+    *fx_out = fx;
+    return x;
+}
+
+__device__ __forceinline__ void ld_update(uint32_t *__restrict__ t, uint32_t x, uint32_t fx, uint32_t n, uint32_t card) {
     t[4 + x] = fx + STEP;                                        // update_stats, qv_stream.c:12-24
     uint32_t nn = n + STEP;
     if (nn > RESCALE) {
@@ -139,7 +185,36 @@ __device__ __forceinline__ uint32_t ld_decode(LaneDecoder &d, uint32_t *__restri
         }
     }
     t[0] = nn;
-    return x;
+}
+
+__device__ __forceinline__ void ld_back(LaneDecoder &d, uint32_t lo, uint32_t fx, uint32_t n) {
+    const double rd = 4294967296.0 - (double)(d.l32 + d.nu32);
+    const double rn = dec_rcp((double)(n << 10));                // n <= 2^19 + 8: exact
+    const uint32_t ql = (uint32_t)__builtin_fma(rd, (double)lo * rn, DEC_QUOT_LO);            // arith.c:146-147
+    const uint32_t qc = (uint32_t)__builtin_fma(rd, (double)(n - lo - fx) * rn, DEC_QUOT_HI);
+    uint32_t l32 = d.l32 + (ql << 10), nu32 = d.nu32 + (qc << 10);
+    // E1/E2 (arith.c:158-170): k leading bits shared by l and u leave (the low ten bits stop the count at 22), k stream bits enter the tag
+    const uint32_t k = (uint32_t)__builtin_clz(~(l32 ^ nu32));
+    l32 <<= k;
+    nu32 <<= k;
+    // E3 (arith.c:171-181): j positions below the MSB with l = 1, u = 0 (both MSBs are 0 here: the leading zeros of the rest number
+    // j + 1, never all 32); the tag's new MSB is flipped once
+    const uint32_t j1 = (uint32_t)__builtin_clz(~(l32 & nu32) & 0x7FFFFFFFu);
+    d.l32 = (l32 << j1) >> 1;
+    d.nu32 = (nu32 << j1) >> 1;
+    const uint32_t total = k + j1 - 1;                           // bits the tag takes from the stream: 43 at most
+    uint32_t t32 = d.t32;
+    if (total < 32) {                                            // (avail >= 32 at the top of a symbol: ld_refill)
+        const uint32_t bits = ((uint32_t)(d.buf >> 32) >> 1) >> (31 - total);
+        t32 = (t32 << total) | (bits << 10);
+        d.buf <<= total;
+        d.avail -= total;
+    } else {                                                     // one symbol in 2^31
+        t32 = (t32 << k) | (ld_take(d, k) << 10);
+        ld_refill(d);
+        t32 = (t32 << (j1 - 1)) | (ld_take(d, j1 - 1) << 10);
+    }
+    d.t32 = t32 ^ (j1 > 1 ? 0x80000000u : 0u);
 }
 
 // The per-symbol chain is context -> table -> output alphabet. Two of its three memory round trips are shortened:
@@ -167,19 +242,31 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
     const uint64_t r0 = live ? first[g] : 0, nreads = live ? first[g + 1] - r0 : 0;
     uint64_t most = nreads;
     for (int o = 32; o > 0; o >>= 1) { const uint64_t v = __shfl_xor(most, o, 64); most = v > most ? v : most; }
-    uint32_t *ar = arena + (uint64_t)(live ? g : 0) * arena_words;
+    uint32_t *const nobody = arena + (uint64_t)shards * arena_words;   // the tables of a stream that does not exist
+    uint32_t *const ar = live ? arena + (uint64_t)g * arena_words : nobody;
     LaneDecoder d;
-    d.l = 0; d.u = MASK_M; d.t = 0; d.buf = 0; d.avail = 0; d.pos = 0;
+    d.l32 = 0; d.nu32 = 0; d.t32 = 0; d.buf = 0; d.avail = 0; d.pos = 0;   // l = 0, u = 2^22 - 1
     d.src = in + (uint64_t)(live ? g : 0) * cap;
     d.size = live ? sizes[g] : 0;
+#ifdef QVZ_PROFILE
+    d.c_head = d.c_rest = d.c_n = 0;
+    const unsigned long long dp_start = DP_NOW();
+#endif
+    ld_request(d);
     ld_refill(d);
-    d.t = ld_take(d, M_BITS);                                    // qv_stream.c:112-113
+    d.t32 = ld_take(d, M_BITS) << 10;                            // qv_stream.c:112-113
     ld_refill(d);
     bool bad = false;
     uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
+    // where the table of (cluster cl, column s) after the value pv lies, with this lane's draw of the symbol (codebook.c:165-170);
+    // NO_TABLE when pv is no context of the column or the context is dead (no table: such a stream is not of this model)
+    auto table_of = [&](uint32_t cl, uint32_t s, uint32_t pv, uint32_t draw) -> uint32_t {
+        const uint2 cv = cx[((size_t)cl * C + s) * A + pv];
+        const uint32_t o = draw >= (cv.x >> 24) ? cv.y : (cv.x & 0xFFFFFFu);
+        return cv.x == NO_TABLE || o == 0xFFFFFFu ? NO_TABLE : o;
+    };
 
     for (uint64_t i = 0; i < most; ++i) {
-        const bool on = i < nreads && !bad;
         if ((i & 3) == 0 && i < nreads) {
             // the WELL draws of the next 4 reads, all columns, in one burst of independent dword loads (fetched one by
             // one inside the symbol chain each of them was a cache miss of its own); a draw sits in the staging byte
@@ -187,28 +274,71 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
             for (uint32_t s = 0; s < C; ++s)
                 stage[s * 64 + lane] = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)s * ld + r0 + i);
         }
-        if (on) {
-            uint32_t cl = 0;
-            if (HAVE_LABELS) {                                   // qv_read_cluster, qv_compressor.c:36-43
-                uint32_t unused;
-                cl = ld_decode(d, ar, false, &unused);
-                if (cl >= K) { bad = true; cl = 0; }                                 // (0xFFFFFFFF, ran off the table, included)
-                labels[r0 + i] = (uint8_t)cl;
+        const bool mine = i < nreads;                            // this lane has a read i; it decodes it unless the stream has failed (`bad`)
+        const uint32_t bsel = (uint32_t)(i & 3);
+        uint32_t cl = 0;
+        if (HAVE_LABELS) {                                       // qv_read_cluster, qv_compressor.c:36-43
+            uint32_t *tl = mine && !bad ? ar : nobody;
+            DecHeader h = ld_header(tl);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(h.a), "+v"(h.b), "+v"(h.c), "+v"(h.d) : : "memory");
+            uint32_t unused, lo, fx;
+            bool ok;
+            ld_refill(d);
+            const uint32_t x = ld_front(d, h, tl, &unused, &lo, &fx, &ok);
+            ld_update(tl, x, fx, h.a.x, h.a.y);
+            ld_back(d, lo, fx, h.a.x);
+            if (mine && !bad) {
+                if (ok && x < K) { cl = x; labels[r0 + i] = (uint8_t)x; }
+                else bad = true;
             }
-            uint32_t prev = 0;
-            for (uint32_t s = 0; s < C && !bad; ++s) {
-                const uint2 cv = cx[((size_t)cl * C + s) * A + prev];
-                if (cv.x == NO_TABLE) { bad = true; break; }                         // previous value is no context of this column
-                const uint32_t draw = sb[(s * 64 + lane) * 4 + (uint32_t)(i & 3)] & 127;   // well.c:33-46
-                const uint32_t o = draw >= (cv.x >> 24) ? cv.y : (cv.x & 0xFFFFFFu); // hi : lo quantizer, codebook.c:165-170
-                if (o == 0xFFFFFFu) { bad = true; break; }                           // dead context: no table
-                const bool last = i + 1 == nreads && s + 1 == C;                     // qv_compressor.c:222-225
-                uint32_t value = 0;
-                const uint32_t x = ld_decode(d, ar + o, last, &value);
-                if (x == 0xFFFFFFFFu) { bad = true; break; }                         // ran off the table
-                prev = value;                                                        // the quantizer's output alphabet
-                sb[(s * 64 + lane) * 4 + (uint32_t)(i & 3)] = (uint8_t)prev;
+        }
+        // column 0's table (the previous value is 0 there)
+        uint32_t *tA = nobody, *tB = nobody;
+        {
+            const uint32_t o = table_of(cl, 0, 0, sb[lane * 4 + bsel] & 127);       // well.c:33-46
+            bad = bad || (mine && o == NO_TABLE);
+            if (mine && !bad) tA = ar + o;
+        }
+        // One column: the header hc of table tc has been requested; the next column's table is known as soon as this symbol's value
+        // is, and its header (hn, tn) is requested BEFORE the table's update and the interval's: its round trip passes behind
+        // them (and the update's stores, which nobody waits for, queue behind it). Two header register sets in turn (a copy
+        // would be a use: a wait). (The last symbol of a stream changes no state in the reference - decoder_last_step,
+        // qv_compressor.c:222-225 -; here it does, and nobody looks at that state again.)
+        auto column = [&](uint32_t s, DecHeader &hc, uint32_t *tc, DecHeader &hn, uint32_t *&tn) {
+            // (the draw of the next column, before this column's value goes into the staging area: another byte, but the compiler cannot know)
+            const uint32_t draw_next = s + 1 < C ? sb[((s + 1) * 64 + lane) * 4 + bsel] & 127u : 0u;
+#ifdef QVZ_PROFILE
+            const unsigned long long dp0 = DP_NOW();
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc.a), "+v"(hc.b), "+v"(hc.c), "+v"(hc.d) : : "memory");   // the header - and every load before it
+#ifdef QVZ_PROFILE
+            const unsigned long long dp1 = DP_NOW();
+            d.c_head += dp1 - dp0; d.c_n += 1;
+#endif
+            uint32_t value, lo, fx;
+            bool ok;
+            ld_refill(d);
+            const uint32_t x = ld_front(d, hc, tc, &value, &lo, &fx, &ok);
+            sb[(s * 64 + lane) * 4 + bsel] = (uint8_t)value;                         // the quantizer's output alphabet
+            bad = bad || (mine && !ok);
+            // the next column's table is known now: its header is on its way while the interval is updated
+            tn = nobody;
+            if (s + 1 < C) {
+                const uint32_t o = table_of(cl, s + 1, value, draw_next);
+                bad = bad || (mine && o == NO_TABLE);                                // the value is no context of the next column
+                if (mine && !bad) tn = ar + o;
             }
+            hn = ld_header(tn);
+            ld_update(tc, x, fx, hc.a.x, hc.a.y);
+            ld_back(d, lo, fx, hc.a.x);
+#ifdef QVZ_PROFILE
+            d.c_rest += DP_NOW() - dp1;
+#endif
+        };
+        DecHeader hA = ld_header(tA), hB;
+        for (uint32_t s = 0; s < C; s += 2) {
+            column(s, hA, tA, hB, tB);
+            if (s + 1 < C) column(s + 1, hB, tB, hA, tA);
         }
         if ((i & 3) == 3 || i + 1 == most) {                     // 4 reads of every column collected: out as dwords
             const uint64_t i0 = i & ~(uint64_t)3;
@@ -224,6 +354,12 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
         }
     }
     if (bad) atomicOr(status, 1);
+#ifdef QVZ_PROFILE
+    if (lane == 0 && (blockIdx.x & 15) == 3) {
+        atomicAdd(&g_dec_prof[0], d.c_head); atomicAdd(&g_dec_prof[1], d.c_rest); atomicAdd(&g_dec_prof[2], d.c_n);
+        atomicAdd(&g_dec_prof[3], DP_NOW() - dp_start);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_dec_arena_fill(const uint32_t *__restrict__ tmpl, uint32_t words, uint32_t shards,
@@ -290,7 +426,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     } while (0)
     if (!h_first) { rc = qvz_set_error(QVZ_E_NOMEM, "host alloc"); goto done; }
     {
-        // every table of qvz_model_build ([n][card][counts]) re-laid as [n][card][recon 0..7][counts][recon 8..], 16-byte aligned;
+        // every table of qvz_model_build ([n][card][counts]) re-laid as [n][card][recon 0..7][counts, twelve at least][recon 8..], 64-byte aligned;
         // the cluster-id table first (its "values" are the ids themselves and are not used)
         auto put_table = [&](const uint32_t *tb, const uint8_t *rc8) {
             const uint32_t card = tb[1];
@@ -300,13 +436,13 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
                 for (uint32_t b = 0; b < 4 && w0 + b < card; ++b) w |= (uint32_t)(rc8 ? rc8[w0 + b] : w0 + b) << (8 * b);
                 h_dar.push_back(w);
             }
-            for (uint32_t i = 0; i < card; ++i) h_dar.push_back(tb[2 + i]);
+            for (uint32_t i = 0; i < card || i < 12; ++i) h_dar.push_back(i < card ? tb[2 + i] : 0u);
             for (uint32_t i = 8; i < card; i += 4) {
                 uint32_t w = 0;
                 for (uint32_t b = 0; b < 4 && i + b < card; ++b) w |= (uint32_t)(rc8 ? rc8[i + b] : i + b) << (8 * b);
                 h_dar.push_back(w);
             }
-            while (h_dar.size() & 3) h_dar.push_back(0);
+            while (h_dar.size() & 15) h_dar.push_back(0);
         };
         put_table(h_arena, nullptr);                             // offset 0: [n][clusters][counts of the cluster ids]
         for (uint32_t c = 0; c < clusters; ++c)
@@ -336,7 +472,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     if (h_bounds) memcpy(h_first, h_bounds, ((size_t)shards + 1) * sizeof(uint64_t));
     else qvz_shard_bounds(n, shards, h_first);
     TRY(hipMalloc(&d_tmpl, (size_t)dwords * 4));
-    TRY(hipMalloc(&d_arena, ((size_t)dwords * shards + 16) * 4));   // + slack: a header read covers 64 bytes
+    TRY(hipMalloc(&d_arena, (size_t)dwords * ((size_t)shards + 1) * 4));   // + the tables of a stream that does not exist (lanes without a symbol to decode)
     TRY(hipMalloc(&d_ctx, ctxn * sizeof(uint2)));
     TRY(hipMalloc(&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&d_sizes, shards * sizeof(uint64_t)));
@@ -346,7 +482,10 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     TRY(hipMemcpyAsync(d_first, h_first, (shards + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_sizes, h_sizes, shards * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_dec_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, dwords, shards, d_arena);
+    hipLaunchKernelGGL(k_dec_arena_fill, dim3(2048), dim3(256), 0, st, d_tmpl, dwords, shards + 1, d_arena);
+#ifdef QVZ_PROFILE
+    { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_prof), z, sizeof(z)); }
+#endif
 #define DEC_LAUNCH(LBL, CLDS)                                                                                                       \
     do {                                                                                                                            \
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode_shards<LBL, CLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -360,6 +499,14 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     TRY(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TRY(hipStreamSynchronize(st));
     if (status) rc = qvz_set_error(QVZ_E_DATA, "a stream does not decode with these codebooks (unknown context, table or state)");
+#ifdef QVZ_PROFILE
+    {
+        unsigned long long dp[8];
+        (void)hipMemcpyFromSymbol(dp, HIP_SYMBOL(g_dec_prof), sizeof(dp));
+        if (dp[2]) fprintf(stderr, "k_decode_shards cycles per symbol (lane 0 of every 16th wave): table header wait %.0f, rest of the symbol %.0f, all %.0f (%llu symbols; %u words of tables per stream, %u lanes per wave)\n",
+                           (double)dp[0] / dp[2], (double)dp[1] / dp[2], (double)dp[3] / dp[2], dp[2], dwords, dec_lanes);
+    }
+#endif
 done:
 #undef TRY
     (void)hipFree(d_tmpl); (void)hipFree(d_arena); (void)hipFree(d_ctx);

@@ -16,6 +16,7 @@
 #   pmf                          PMF parity tests, then the pass's roofline fraction with one and with three clusters
 #   codebook                     codebook parity tests, then the phase with the device's entropies and with the host's libm
 #   decoder                      decoder parity tests, then the full-size round trip
+#   decoder-profile <config>     a -DQVZ_PROFILE build in /tmp: cycles per symbol of the decoder's chain (table wait / the rest)
 #   n2 [reads]                   the driver's N = 2 launch line of bench.py with both ranks on this box's one GPU (gloo), then N = 1 beside it
 #   host                         cores, memory, tmpfs and I/O rates of the box (tools/io_bench.c)
 tag=${1:?tag}; action=${2:?action}; shift 2
@@ -110,6 +111,13 @@ decoder)
     timeout -k 10 400 python3 bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-extras --roundtrip 2> $out/err$cfg.txt | python3 -c "
 import json,sys; print('config $cfg', json.loads(sys.stdin.readline())['roundtrip'])"
   done ;;
+decoder-profile)
+  cfg=${1:-2}
+  cp -r . /tmp/prof_build && cd /tmp/prof_build && touch qvz_amd/csrc/qvz_decoder_gpu.hip &&
+  make -s HIPFLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Iinclude -Iqvz_amd/csrc -DQVZ_PROFILE" > /dev/null 2>&1 || exit 1
+  timeout -k 10 400 python3 bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-extras --roundtrip 2> $out/decoder_profile.txt | python3 -c "
+import json,sys; print('config $cfg', json.loads(sys.stdin.readline())['roundtrip'])"
+  grep "k_decode_shards" $out/decoder_profile.txt ;;
 n2)
   reads=${1:-20000000}
   QVZ_BENCH_ONE_DEVICE=1 QVZ_BENCH_BACKEND=gloo timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
