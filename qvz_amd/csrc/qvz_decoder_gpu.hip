@@ -415,7 +415,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     int32_t *d_status = nullptr;
     int rc = QVZ_OK;
     int32_t status = 0;
-    uint32_t dwords = 0;
+    uint32_t dwords = 0, dwords_stride = 0;
     const size_t lds_stage = (size_t)columns * 64 * 4, lds_ctx = ctxn * sizeof(uint2);
     const bool ctx_lds = lds_stage + lds_ctx <= 150 * 1024;
     const size_t lds = lds_stage + (ctx_lds ? lds_ctx : 0);
@@ -454,7 +454,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
                     put_table(h_arena + o, cbs[c]->recon + (((size_t)s * 2 * A) + j) * A);
                 }
         if (h_dar.size() >= 0xFFFFFFu) { rc = qvz_set_error(QVZ_E_ARG, "model too large for the decoder's 24-bit table offsets"); goto done; }
-        dwords = (uint32_t)h_dar.size();
+        dwords = dwords_stride = (uint32_t)h_dar.size();
         for (uint32_t c = 0; c < clusters; ++c)
             for (uint32_t s = 0; s < columns; ++s)
                 for (uint32_t pv = 0; pv < A; ++pv) {
@@ -490,8 +490,11 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     do {                                                                                                                            \
         TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode_shards<LBL, CLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_decode_shards<LBL, CLDS>), dim3((shards + dec_lanes - 1) / dec_lanes), dim3(64), lds, st, d_in, cap_per_shard, d_sizes, \
-                           d_first, shards, columns, clusters, d_ctx, d_arena, dwords, d_draws, ld, d_qv, d_labels, d_status, dec_lanes); \
+                           d_first, shards, columns, clusters, d_ctx, d_arena, dwords_stride, d_draws, ld, d_qv, d_labels, d_status, dec_lanes); \
     } while (0)
+#ifdef QVZ_PROFILE          // QVZ_DEC_SHARED_ARENA=1: every stream on one set of tables (wrong output; what a symbol costs when its table comes from the cache)
+    if (getenv("QVZ_DEC_SHARED_ARENA")) dwords_stride = 0;
+#endif
     if (clusters > 1) { if (ctx_lds) DEC_LAUNCH(true, true); else DEC_LAUNCH(true, false); }
     else { if (ctx_lds) DEC_LAUNCH(false, true); else DEC_LAUNCH(false, false); }
 #undef DEC_LAUNCH

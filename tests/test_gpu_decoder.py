@@ -74,7 +74,9 @@ def test_decoder_rejects_a_foreign_stream():
 @pytest.mark.parametrize("name,shards", [("t2k_c3_f05_M", 5), ("t2k_r10_M", 3)])
 def test_decoder_survives_mutated_streams(name, shards):
     """Streams somebody damaged: bit flips, zeroed and random runs, truncated and over-stated lengths, streams swapped
-    between shards. A decode either fails with the library's data error or returns values of the alphabet - it never reads
+    between shards, a tag of all ones under the whole interval. A damaged stream still has ONE decode - the arithmetic is exact
+    whatever the bits are -: every stream must decode to what the ORACLE's decoder (= the reference's) reads out of it, or be
+    refused where the oracle gives up (a value that is no context). The decoder never reads
     outside its tables or its stream (the kernel takes every table offset from the validated codebooks, checks every state
     against the table's size and reads zeros behind a stream's stated end, as the reference's stream reader does,
     os_stream.c:36-52). The untouched streams decode to the quantizer's output before and after."""
@@ -86,21 +88,52 @@ def test_decoder_survives_mutated_streams(name, shards):
     good = [bytes(s) for s in r["streams"]]
     outcomes = {"rejected": 0, "decoded": 0}
 
+    first = host.shard_bounds(n, shards)
+    books = b"".join(cb.serialize() for cb in r["codebooks"])
+    # the codebooks as a READER has them (qvz_codebook_read: every context a previous value can name has its tables, as in the
+    # reference's decoder; the encoder's own leave out contexts no read of the input reaches, and a damaged stream may reach one)
+    import ctypes as C
+    from qvz_amd._lib import lib
+    parsed, at = [], C.c_size_t(0)
+    image = np.frombuffer(books, dtype=np.uint8)
+    for _ in r["codebooks"]:
+        cb = K.Codebook(c)
+        assert lib().qvz_codebook_read(image.ctypes.data, image.size, C.byref(at), cb.handle) == 0
+        parsed.append(cb)
+    handles = [cb.handle for cb in parsed]
+
+    def oracle_says(g, stream):
+        """what the ORACLE's decoder (= the reference's, start_qv_decompression) reads out of this stream as shard g's file:
+        the text, or None where it meets a value that is no context / a cluster that does not exist"""
+        lines = first[g + 1] - first[g]
+        image = (bytes([opts["k"]]) + c.to_bytes(4, "big") + lines.to_bytes(4, "big") + books +
+                 K.well_jump(O.WELL_DEBUG_STATE, first[g] * c // 4).tobytes() + bytes(stream))
+        try:
+            return O.decode(image)
+        except AssertionError:
+            return None
+
     def run(streams, sizes=None):
         coded, cap = upload_streams(streams)
+        sz = sizes or [len(x) for x in streams]
+        # a damaged stream still has ONE decode - the arithmetic is exact whatever the bits are -: the oracle's
+        want = [oracle_says(g, bytes(streams[g][:sz[g]])) for g in range(shards)]   # (an over-stated size reads the slot's zeros: what the oracle reads behind a stream's end)
         try:
-            qv, labels = host.decode_shards_gpu(coded, cap, sizes or [len(x) for x in streams], n, c, handles, shards, draws)
+            qv, labels = host.decode_shards_gpu(coded, cap, sz, n, c, handles, shards, draws)
         except Exception as e:                                   # noqa: BLE001
             assert "does not decode" in str(e) or "longer than cap" in str(e), e
+            assert None in want or "longer than cap" in str(e), "the oracle decodes every stream of a set the GPU decoder refused"
             outcomes["rejected"] += 1
             return None
         torch.cuda.synchronize()
         assert int(qv[:, :n].max()) < 72
+        assert None not in want, "the GPU decoder accepted a stream the oracle's decoder gives up on"
+        assert K.untranspose_text(qv, n).cpu().numpy().tobytes() == b"".join(want), "a damaged stream decodes differently"
         outcomes["decoded"] += 1
         return qv
 
     assert torch.equal(run(good)[:, :n], r["qv"][:, :n])
-    for trial in range(40):
+    for trial in range(48):
         streams = [bytearray(x) for x in good]
         g = int(rng.integers(shards))
         kind = trial % 8
@@ -127,10 +160,13 @@ def test_decoder_survives_mutated_streams(name, shards):
         elif kind == 6:                                          # two shards' streams swapped
             h = (g + 1) % shards
             streams[g], streams[h] = streams[h], streams[g]
-        else:                                                    # all ones / all zeros
-            streams[g] = bytearray([0xFF if trial & 8 else 0x00]) * len(streams[g])
+        else:                                                    # all ones / all zeros; or only the first bytes: tag = 2^22 - 1 under the whole interval
+            if trial & 16:
+                streams[g][:3 + trial % 3] = bytes([0xFF]) * (3 + trial % 3)
+            else:
+                streams[g] = bytearray([0xFF if trial & 8 else 0x00]) * len(streams[g])
         run([bytes(x) for x in streams], sizes)
-    assert outcomes["rejected"] > 0 and outcomes["decoded"] > 1, outcomes
+    assert outcomes["decoded"] + outcomes["rejected"] == 49 and outcomes["decoded"] > 40, outcomes   # (rejection itself: test_decoder_rejects_a_foreign_stream)
     assert torch.equal(run(good)[:, :n], r["qv"][:, :n])
 
 

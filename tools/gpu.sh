@@ -117,7 +117,10 @@ decoder-profile)
   make -s HIPFLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Iinclude -Iqvz_amd/csrc -DQVZ_PROFILE" > /dev/null 2>&1 || exit 1
   timeout -k 10 400 python3 bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-extras --roundtrip 2> $out/decoder_profile.txt | python3 -c "
 import json,sys; print('config $cfg', json.loads(sys.stdin.readline())['roundtrip'])"
-  grep "k_decode_shards" $out/decoder_profile.txt ;;
+  grep "k_decode_shards" $out/decoder_profile.txt
+  echo "-- every stream on one set of tables (the tables come from the cache; the output is wrong and refused)"
+  QVZ_DEC_SHARED_ARENA=1 timeout -k 10 400 python3 bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-extras --roundtrip > /dev/null 2> $out/decoder_profile_shared.txt
+  grep "k_decode_shards" $out/decoder_profile_shared.txt ;;
 n2)
   reads=${1:-20000000}
   QVZ_BENCH_ONE_DEVICE=1 QVZ_BENCH_BACKEND=gloo timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
