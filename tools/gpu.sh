@@ -87,7 +87,7 @@ host.egress_rows(K.qgen1(3, 100_000_000, 150), 100_000_000, '$d/in.txt')"
     sleep $pause; echo "== qvz -s $flags (after ${pause} s)"
     qvz_amd/bin/qvz -s $flags $d/in.txt $d/out.qset 2>&1 | grep -E "qvz_timing|host side" | cut -c1-260
   done | tee $out/runs.txt
-  sleep $pause; ( time qvz_amd/bin/qvz -x $d/out.qset $d/out.dec ) 2>&1 | grep real | tee -a $out/runs.txt
+  sleep $pause; ( time qvz_amd/bin/qvz -x $d/out.qset $d/out.dec ) 2>&1 | grep -E "real|qvz_timing" | tee -a $out/runs.txt
   cmp $d/out.dec $d/out.u && echo "decoded == -u" | tee -a $out/runs.txt; rm -rf $d ;;
 pmf)
   timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py -x -q -k pmf > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest.log
