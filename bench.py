@@ -447,7 +447,7 @@ def e2e_cli_report(cfg, sym, n, c, shards):
                                 "which says nothing about this code" % settle,
                     note="tmpfs files (page cache; MAKING new tmpfs pages tops out at ~4-7 GB/s on this host whatever the thread count: the pages of "
                          "the -u text (15.1 GB) and of the shard set are made by a helper thread from the moment their size is known, the "
-                         "writers copy through a mapping - host/qvz_egress.c, QVZ_PREALLOC=0 turns it off); child processes, HIP start-up included in the wall times; host threads: 4 copy "
+                         "writers copy through a mapping - host/qvz_egress.c, QVZ_PREALLOC=0 turns it off); child processes, HIP start-up included in the wall times; host threads: 8 copy "
                          "threads each way (QVZ_COPY_THREADS), one per cluster for codebooks, one for the file-order error sum")
     finally:
         shutil.rmtree(td, ignore_errors=True)
