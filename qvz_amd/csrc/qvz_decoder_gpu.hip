@@ -68,6 +68,8 @@ typedef uint32_t dec_u32x4 __attribute__((ext_vector_type(4)));
 // instead of three divisions with exact integer remainders (35 instructions each, of the ~450 a symbol took).
 struct LaneDecoder {
     uint32_t l32, nu32, t32;
+    double rd, rr;           // (u - l + 1) * 1024 and its reciprocal: made at the end of a symbol's interval update - behind the next
+                             // table's round trip -, not at the top of the next symbol, where that table's search waits for them
     uint64_t buf;            // next bits of the stream, left-aligned
     uint32_t avail;          // valid bits in buf
     const uint8_t *src;
@@ -144,10 +146,9 @@ __device__ __forceinline__ uint32_t ld_front(const LaneDecoder &d, const DecHead
                                              uint32_t *val, uint32_t *lo_out, uint32_t *fx_out, bool *ok) {
     const uint32_t n = h.a.x, card = h.a.y;
     const uint32_t cn[12] = {h.b.x, h.b.y, h.b.z, h.b.w, h.c.x, h.c.y, h.c.z, h.c.w, h.d.x, h.d.y, h.d.z, h.d.w};
-    const double rd = 4294967296.0 - (double)(d.l32 + d.nu32);  // (u - l + 1) * 1024
     const double nd = (double)n;
     const double num = __builtin_fma((double)(d.t32 - d.l32), nd, __builtin_fma(1024.0, nd, -512.0));   // ((t - l + 1) n - 1/2) * 1024, exact (t - l + 1 may be 2^22)
-    const uint32_t sub = (uint32_t)(num * dec_rcp(rd));         // arith.c:134 / :199 (below n)
+    const uint32_t sub = (uint32_t)(num * d.rr);                // arith.c:134 / :199 (below n)
     // arith.c:136-139: the state x whose counts straddle sub - lo = c_0 + .. + c_(x-1) <= sub < lo + c_x. The first twelve counts
     // came with the header (walking them one dependent load at a time cost several cache round trips per symbol); behind a
     // short table's counts they are zeros, the running sum stays n there and n > sub.
@@ -188,7 +189,7 @@ __device__ __forceinline__ void ld_update(uint32_t *__restrict__ t, uint32_t x, 
 }
 
 __device__ __forceinline__ void ld_back(LaneDecoder &d, uint32_t lo, uint32_t fx, uint32_t n) {
-    const double rd = 4294967296.0 - (double)(d.l32 + d.nu32);
+    const double rd = d.rd;
     const double rn = dec_rcp((double)(n << 10));                // n <= 2^19 + 8: exact
     const uint32_t ql = (uint32_t)__builtin_fma(rd, (double)lo * rn, DEC_QUOT_LO);            // arith.c:146-147
     const uint32_t qc = (uint32_t)__builtin_fma(rd, (double)(n - lo - fx) * rn, DEC_QUOT_HI);
@@ -215,6 +216,8 @@ __device__ __forceinline__ void ld_back(LaneDecoder &d, uint32_t lo, uint32_t fx
         t32 = (t32 << (j1 - 1)) | (ld_take(d, j1 - 1) << 10);
     }
     d.t32 = t32 ^ (j1 > 1 ? 0x80000000u : 0u);
+    d.rd = 4294967296.0 - (double)(d.l32 + d.nu32);
+    d.rr = dec_rcp(d.rd);
 }
 
 // The per-symbol chain is context -> table -> output alphabet. Two of its three memory round trips are shortened:
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
     uint32_t *const ar = live ? arena + (uint64_t)g * arena_words : nobody;
     LaneDecoder d;
     d.l32 = 0; d.nu32 = 0; d.t32 = 0; d.buf = 0; d.avail = 0; d.pos = 0;   // l = 0, u = 2^22 - 1
+    d.rd = 4294967296.0; d.rr = dec_rcp(4294967296.0);
     d.src = in + (uint64_t)(live ? g : 0) * cap;
     d.size = live ? sizes[g] : 0;
 #ifdef QVZ_PROFILE
