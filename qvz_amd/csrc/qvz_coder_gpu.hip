@@ -329,6 +329,7 @@ __device__ __forceinline__ uint64_t lc_finish(LaneCoder &c) {
 #ifdef QVZ_PROFILE          // development build (make HIPFLAGS+=-DQVZ_PROFILE): shader-clock cycles per section of the chunk loop, summed over waves
 __device__ unsigned long long g_rk_prof[16];   // [7] prologue, [8] table save, [9] passes, [10] whole pass, [11] .. [13] prologue: to the tables in LDS, the barrier, the first look-up; [14] first passes' prologue
 __device__ unsigned long long g_cr_prof[16];
+__device__ int g_rk_drain;                     // QVZ_RK_DRAIN=1: a pass drains what is in flight before it asks for its tables, timed
 __device__ uint32_t g_cr_simd[8];   // SIMD of every wave of one k_code_records workgroup (HW_ID bits 5:4)
 #define RK_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } while (0)
 #else
@@ -627,6 +628,14 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
     } else {
         fetch(0);
     }
+#ifdef QVZ_PROFILE          // how long what the pass before left in flight (its records, its table save) takes to drain: the tables' loads queue behind it
+    unsigned long long tdrain = 0;
+    if (g_rk_drain) {
+        const unsigned long long td0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tdrain = __builtin_readcyclecounter() - td0;
+    }
+#endif
     if (active) {
         // the slice comes in as 16-byte loads issued back to back, the offset table is ready-made on the host (no dependent
         // second load). (Written as `for (i ..) tab[i] = src[i]` the compiler made a loop of load, s_waitcnt vmcnt(0), store:
@@ -873,6 +882,7 @@ __global__ __launch_bounds__(1024) void k_model_ranks(const uint8_t *__restrict_
         atomicAdd(&g_rk_prof[7], tloop - tpass);
         atomicAdd(&g_rk_prof[11], tp1 - tpass); atomicAdd(&g_rk_prof[12], tp2 - tp1); atomicAdd(&g_rk_prof[13], tloop - tp2);
         if (zi == 0) atomicAdd(&g_rk_prof[14], tloop - tpass);
+        atomicAdd(&g_rk_prof[15], tdrain);
         atomicAdd(&g_rk_prof[9], 1ull);
     }
     const unsigned long long tsave = __builtin_readcyclecounter();
@@ -1793,6 +1803,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     {
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_prof), z, sizeof(z));
+        { const int dr = getenv("QVZ_RK_DRAIN") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rk_drain), &dr, sizeof(dr)); }
         { unsigned long long zc[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cr_prof), zc, sizeof(zc)); }
     }
 #endif
@@ -2023,6 +2034,7 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
                           (double)z[7] / z[9], (double)z[8] / z[9], (double)z[10] / z[9], ch / z[9]);
         if (z[9]) fprintf(stderr, "    before the first chunk: %.0f until the wave's tables are in LDS, %.0f at the barrier, %.0f for the first bytes and look-up (sums over all passes / the passes; a workgroup's first passes alone: %.0f in all, summed over every pass)\n",
                           (double)z[11] / z[9], (double)z[12] / z[9], (double)z[13] / z[9], (double)z[14] / z[9]);
+        if (z[9] && z[15]) fprintf(stderr, "    QVZ_RK_DRAIN: of the cycles until the tables are in LDS, %.0f drain what was in flight before the tables were asked for\n", (double)z[15] / z[9]);
     }
 #endif
     if (status & 1) rc = qvz_set_error(QVZ_E_DEAD_CTX, "coder input addresses a quantizer without a model table (dead context or bad state)");
