@@ -61,6 +61,29 @@ def test_round_trip_of_gpu_coded_shards(name, shards):
     assert G.md5(K.untranspose_text(qv, n).cpu().numpy().tobytes()) == G.CASES[name]["u_md5"]
 
 
+def test_round_trip_with_more_clusters_than_a_table_header_holds():
+    """Fourteen clusters: the cluster-id table has more states than the twelve counts that come with a table's header (the search
+    goes on in memory), its own values 8 .. 13 lie behind the counts. Round trip of the GPU coder's streams, and every shard's
+    file - header, codebooks, WELL state, stream - decodes with the ORACLE's decoder to the same text."""
+    from qvz_amd import host, kernels as K, pipeline as P
+    n, c, k, shards = 48_000, 36, 14, 6
+    sym = K.qgen1(11, n, c)
+    means0 = torch.stack([sym[:, 977 * j + 5] for j in range(k)]).contiguous()
+    r = P.encode_pass(sym, n, 0, n, means0, clusters=k, mode=host.MODE_RATIO, ratio=0.6, dist="M", shards=shards, coder="gpu", keep=True)
+    assert len(set(r["labels"][:n].cpu().numpy().tolist())) == k, "every cluster should own reads"
+    coded, cap = upload_streams(r["streams"])
+    draws = K.well_draws(O.WELL_DEBUG_STATE, 0, n, c)
+    qv, labels = host.decode_shards_gpu(coded, cap, r["stream_bytes"], n, c, [cb.handle for cb in r["codebooks"]], shards, draws)
+    assert torch.equal(qv[:, :n], r["qv"][:, :n]) and torch.equal(labels[:n], r["labels"][:n])
+    text = K.untranspose_text(qv, n).cpu().numpy().tobytes()
+    first = host.shard_bounds(n, shards)
+    books = b"".join(cb.serialize() for cb in r["codebooks"])
+    for g in range(shards):
+        image = (bytes([k]) + c.to_bytes(4, "big") + (first[g + 1] - first[g]).to_bytes(4, "big") + books +
+                 K.well_jump(O.WELL_DEBUG_STATE, first[g] * c // 4).tobytes() + bytes(r["streams"][g]))
+        assert O.decode(image) == text[first[g] * (c + 1):first[g + 1] * (c + 1)], f"shard {g}"
+
+
 def test_decoder_rejects_a_foreign_stream():
     from qvz_amd import host, kernels as K
     rows, opts, n, c, r = encode("t2k_r10_M", 2)
