@@ -93,8 +93,8 @@ __device__ __forceinline__ void ld_request(LaneDecoder &d) {     // the stream's
     d.pos += 4;
 }
 
-// Called at the top of a symbol, when the symbol's table header has just landed - and with it, loads return in order, the dword
-// requested at the refill before: no wait. Afterwards avail >= 32: enough for the E1/E2 bits of the symbol (22 at most); the E3
+// Called once per symbol, behind the request for the next symbol's table header; the dword it consumes was requested at the refill
+// before - before this symbol's header was waited for, and loads return in order -: no wait. Afterwards avail >= 32: enough for the E1/E2 bits of the symbol (22 at most); the E3
 // bits (21 at most) find avail >= 21 unless E1/E2 took twelve or more, and ld_back refills then (with a wait) before it takes them.
 __device__ __forceinline__ void ld_refill(LaneDecoder &d) {
     if (d.avail <= 32) {
@@ -321,7 +321,6 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
 #endif
             uint32_t value, lo, fx;
             bool ok;
-            ld_refill(d);
             const uint32_t x = ld_front(d, hc, tc, &value, &lo, &fx, &ok);
             sb[(s * 64 + lane) * 4 + bsel] = (uint8_t)value;                         // the quantizer's output alphabet
             bad = bad || (mine && !ok);
@@ -333,6 +332,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
                 if (mine && !bad) tn = ar + o;
             }
             hn = ld_header(tn);
+            ld_refill(d);                                        // (the search needs no stream bits: the refill waits until the header is on its way)
             ld_update(tc, x, fx, hc.a.x, hc.a.y);
             ld_back(d, lo, fx, hc.a.x);
 #ifdef QVZ_PROFILE
