@@ -142,6 +142,10 @@ int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_per_shard, co
                                  const uint64_t *h_bounds, const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels,
                                  void *stream);
 
+/* Bytes of adaptive tables the decoder keeps per stream in device memory (a call needs that for every stream it is given, and
+ * once more): what a caller that decodes a file in slabs of streams budgets with (host/qvz_decode.c). */
+uint64_t qvz_hip_decode_tables_bytes(uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs);
+
 /* The streams of a GPU coder call (stream g at d_coded + g * cap_per_shard, h_sizes[g] bytes) packed back to back into
  * d_packed (sum of the sizes): what travels to the host and into a shard set, instead of the whole fixed-stride area. */
 int qvz_hip_gather_streams(const uint8_t *d_coded, uint64_t cap_per_shard, const uint64_t *h_sizes, uint32_t shards,

@@ -178,6 +178,9 @@ int qvz_decode_shard_files(const char *prefix, uint32_t shards, const char *out_
  * do not fit the device at once, as a file of 2^32 reads and more never does. reads: most reads per slab (a stream longer than
  * that is a slab by itself); 0 = by the device's free memory, the default. Process-wide; the output does not depend on it. */
 void qvz_decode_set_slab_reads(uint64_t reads);
+/* the same with a limit on the streams of a slab too (every stream of a slab has its adaptive tables in device memory; 0 = by the
+ * device's free memory) */
+void qvz_decode_set_slab(uint64_t reads, uint32_t streams);
 
 const char *qvz_encode_last_error(void);
 

@@ -100,6 +100,7 @@ SIGNATURES = {
     "qvz_hip_decode_shards": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "qvz_hip_decode_tables_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "qvz_hip_decode_shards_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
                                                C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "qvz_decode_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p]),
     "qvz_decode_shard_files": (C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_int, C.c_void_p]),
     "qvz_decode_set_slab_reads": (None, [C.c_uint64]),
+    "qvz_decode_set_slab": (None, [C.c_uint64, C.c_uint32]),
     "qvz_codebook_read": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "qvz_encode_file_sharded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qvz_encode_last_error": (C.c_char_p, []),

@@ -343,7 +343,9 @@ static double dec_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, 
  * their text is appended, the next slab follows with the WELL generator advanced to its first read. 0 = by the device's free memory;
  * the setter is a test hook (slabs of a few thousand reads on small files must give the same text). */
 static uint64_t g_slab_reads = 0;
-void qvz_decode_set_slab_reads(uint64_t reads) { g_slab_reads = reads; }
+static uint32_t g_slab_streams = 0;
+void qvz_decode_set_slab_reads(uint64_t reads) { g_slab_reads = reads; g_slab_streams = 0; }
+void qvz_decode_set_slab(uint64_t reads, uint32_t streams) { g_slab_reads = reads; g_slab_streams = streams; }
 
 int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codebook_t *const *cbs, const uint32_t *well,
                            uint32_t shards, const uint64_t *bounds, const uint8_t *const *streams, const uint64_t *sizes,
@@ -387,13 +389,23 @@ int qvz_decode_streams_gpu(uint32_t K, uint32_t C, uint64_t N, const qvz_codeboo
         if (qvz_hip_mem_info(&free_b, NULL) == QVZ_OK && free_b / 5 * 2 / (2ull * C + 1) < slab_reads) slab_reads = free_b / 5 * 2 / (2ull * C + 1);
     }
     if (slab_reads >= (1ull << 32)) slab_reads = (1ull << 32) - 256;
+    /* ... and streams per slab: every stream of a slab has its adaptive tables in device memory (0.9 MB at 150 columns): a third of
+     * the free memory for them at most (a million short streams would otherwise ask for a terabyte) */
+    uint32_t slab_streams = shards;
+    {
+        uint64_t free_b = 0;
+        const uint64_t per = qvz_hip_decode_tables_bytes(C, K, cbs);
+        if (per && qvz_hip_mem_info(&free_b, NULL) == QVZ_OK && free_b / 3 / per < slab_streams) slab_streams = (uint32_t)(free_b / 3 / per);
+        if (g_slab_streams && g_slab_streams < slab_streams) slab_streams = g_slab_streams;
+        if (slab_streams < 1) slab_streams = 1;
+    }
 #define HIPC(call) do { if ((call) != QVZ_OK) { rc = qvz_job_fail(QVZ_E_HIP, "%s", qvz_hip_last_error()); goto done; } } while (0)
     double t_upload = 0.0, t_decode = 0.0, t_egress = 0.0;
     uint32_t nslabs = 0;
     for (uint32_t g0 = 0; g0 < shards;) {
         /* the slab: streams g0 .. g1 - 1 */
         uint32_t g1 = g0 + 1;
-        while (g1 < shards && first[g1 + 1] - first[g0] <= slab_reads) ++g1;
+        while (g1 < shards && g1 - g0 < slab_streams && first[g1 + 1] - first[g0] <= slab_reads) ++g1;
         const uint32_t ns = g1 - g0;
         const uint64_t r0 = first[g0], n = first[g1] - r0, ld = qvz_hip_ld(n);
         uint64_t cap = 0, total = 0;

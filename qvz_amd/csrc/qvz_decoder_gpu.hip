@@ -373,6 +373,21 @@ __global__ __launch_bounds__(256) void k_dec_arena_fill(const uint32_t *__restri
         arena[i] = tmpl[i % words];
 }
 
+// words of one decoder table of `card` states (the layout above), and of all the tables of one stream
+static uint32_t dec_table_words(uint32_t card) {
+    const uint32_t w = 4 + (card > 12 ? card : 12u) + (card > 8 ? (card - 8 + 3) / 4 : 0u);
+    return (w + 15) & ~15u;
+}
+extern "C" uint64_t qvz_hip_decode_tables_bytes(uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs) {
+    if (!cbs || !columns || !clusters) return 0;
+    uint64_t words = dec_table_words(clusters);                  // the cluster-id table
+    for (uint32_t c = 0; c < clusters; ++c)
+        for (uint32_t s = 0; s < columns; ++s)
+            for (uint32_t j = 0; j < 2u * cbs[c]->nctx[s]; ++j)
+                if (cbs[c]->live[(size_t)s * A + j / 2]) words += dec_table_words(cbs[c]->nstates[(size_t)s * 2 * A + j]);   // (qvz_model_build, QVZ_MODEL_LIVE_ONLY)
+    return words * 4;
+}
+
 extern "C" int qvz_hip_decode_shards(const uint8_t *d_in, uint64_t cap_per_shard, const uint64_t *h_sizes, uint64_t n,
                                      uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards,
                                      const uint8_t *d_draws, uint64_t ld, uint8_t *d_qv, uint8_t *d_labels, void *stream) {
@@ -459,6 +474,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
                 }
         if (h_dar.size() >= 0xFFFFFFu) { rc = qvz_set_error(QVZ_E_ARG, "model too large for the decoder's 24-bit table offsets"); goto done; }
         dwords = dwords_stride = (uint32_t)h_dar.size();
+        if ((uint64_t)dwords * 4 != qvz_hip_decode_tables_bytes(columns, clusters, cbs)) { rc = qvz_set_error(QVZ_E_ARG, "decoder tables: %u words built, %llu bytes announced", dwords, (unsigned long long)qvz_hip_decode_tables_bytes(columns, clusters, cbs)); goto done; }
         for (uint32_t c = 0; c < clusters; ++c)
             for (uint32_t s = 0; s < columns; ++s)
                 for (uint32_t pv = 0; pv < A; ++pv) {

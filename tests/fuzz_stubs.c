@@ -56,6 +56,7 @@ int qvz_hip_stream_wait(void *stream, void *other) { U(stream); U(other); return
 int qvz_hip_streams_overlap(void *stream_a, void *stream_b, int *overlap) { U(stream_a); U(stream_b); U(overlap); return nodev(); }
 int qvz_hip_untranspose_rows(const uint8_t *d_qv, uint64_t first, uint64_t n, uint32_t c, uint64_t ld, uint8_t *d_text, void *stream) { U(d_qv); U(first); U(n); U(c); U(ld); U(d_text); U(stream); return nodev(); }
 int qvz_hip_scatter_streams(const uint8_t *d_packed, const uint64_t *h_sizes, uint32_t shards, uint8_t *d_coded, uint64_t cap_per_shard, void *stream) { U(d_packed); U(h_sizes); U(shards); U(d_coded); U(cap_per_shard); U(stream); return nodev(); }
+uint64_t qvz_hip_decode_tables_bytes(uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs) { U(columns); U(clusters); U(cbs); return 0; }
 int qvz_hip_mem_info(uint64_t *free_bytes, uint64_t *total_bytes) { U(free_bytes); U(total_bytes); return nodev(); }
 uint64_t qvz_hip_encode_planes_work_bytes(uint64_t longest_reads, uint32_t columns, uint32_t clusters, uint32_t shards) { U(longest_reads); U(columns); U(clusters); U(shards); return 0; }
 int qvz_hip_encode_planes_prepare(uint64_t n, uint32_t columns, uint32_t clusters, const qvz_codebook_t *const *cbs, uint32_t shards, const uint64_t *h_bounds, uint64_t work_bytes) { U(n); U(columns); U(clusters); U(cbs); U(shards); U(h_bounds); U(work_bytes); return nodev(); }

@@ -472,11 +472,14 @@ def test_decoding_in_slabs_gives_the_same_text(tmp_path, name, shards):
     host.shardset_split(q, prefix)
     per = -(-n // shards)
     try:
-        for slab in (1, per * 3 + 1, n - 1, n, 0):
-            lib().qvz_decode_set_slab_reads(slab)
-            dec = str(tmp_path / f"x{slab}.dec")
+        for slab in (1, per * 3 + 1, n - 1, n, 0, (0, 1), (0, shards - 1), (per * 5, 2)):
+            if isinstance(slab, tuple):
+                lib().qvz_decode_set_slab(*slab)                 # ... and a limit on the streams of a slab (their tables' memory)
+            else:
+                lib().qvz_decode_set_slab_reads(slab)
+            dec = str(tmp_path / "x.slab.dec")
             assert lib().qvz_shardset_decode(q.encode(), dec.encode(), 0, None) == 0, lib().qvz_encode_last_error()
-            assert G.md5(open(dec, "rb").read()) == e["u_md5"], f"shard set, slabs of {slab} reads"
+            assert G.md5(open(dec, "rb").read()) == e["u_md5"], f"shard set, slabs of {slab} reads / (reads, streams)"
             assert lib().qvz_decode_shard_files(prefix.encode(), shards, dec.encode(), 0, None) == 0, lib().qvz_encode_last_error()
             assert G.md5(open(dec, "rb").read()) == e["u_md5"], f"shard files, slabs of {slab} reads"
     finally:
