@@ -1,0 +1,107 @@
+"""The product binary against the REFERENCE binary on inputs and options no fixture holds: seeded random shapes (reads, columns),
+symbol distributions, cluster counts, rate modes, targets and distortion measures. Where the unmodified reference travelled with the
+repo (oracle/_ref/qvz_ref_fixedseed: the reference compiled with its own -DDEBUG, i.e. a fixed WELL seed) it is RUN on every input,
+in a process of its own, and `qvz` - QVZ_WELL_SEED=debug, a process of its own too: both draw their centroids from a fresh
+rand() - must write the same `.q`, the same `-u` text and the same `-s` line; elsewhere the oracle's encode() stands in. Then the
+same input as a shard set: `qvz -x` of it is the reference's `-u` text."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_encode import QVZ_BIN, ROOT, fresh_process_rand
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("torch")
+
+REF_FIXED = os.path.join(ROOT, "oracle", "_ref", "qvz_ref_fixedseed")
+
+
+def make_case(seed):
+    """(rows, flags, k): rows in the text layout ((n, c + 1) bytes, '\\n' terminated), the command line's options"""
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 6
+    n = int(rng.choice([37, 64, 250, 1001, 2500, 6000]))
+    c = int(rng.choice([2, 3, 7, 16, 33, 60]))
+    k = 1
+    if kind == 0:                                                # QGEN-1: the bench's generator (classes of reads, position-dependent qualities)
+        n = max(n, 1001)
+        rows = O.qgen1_rows(seed, n, c)
+        k = int(rng.choice([1, 2, 3]))
+    elif kind == 1:                                              # uniform over a window of the alphabet
+        lo = int(rng.integers(0, 60))
+        hi = int(rng.integers(lo + 1, 72))
+        rows = np.full((n, c + 1), 10, dtype=np.uint8)
+        rows[:, :c] = 33 + rng.integers(lo, hi + 1, size=(n, c))
+    elif kind == 2:                                              # a handful of distinct values, skewed
+        vals = rng.choice(72, size=int(rng.integers(2, 6)), replace=False)
+        p = rng.dirichlet(np.ones(len(vals)) * 0.6)
+        rows = np.full((n, c + 1), 10, dtype=np.uint8)
+        rows[:, :c] = 33 + rng.choice(vals, size=(n, c), p=p)
+    elif kind == 3:                                              # a random walk along the read: strong dependence on the previous column
+        rows = np.full((n, c + 1), 10, dtype=np.uint8)
+        x = rng.integers(20, 50, size=n)
+        for s in range(c):
+            x = np.clip(x + rng.integers(-2, 3, size=n), 0, 71)
+            rows[:, s] = 33 + x
+    elif kind == 4:                                              # constant columns between noisy ones
+        rows = np.full((n, c + 1), 10, dtype=np.uint8)
+        rows[:, :c] = 33 + rng.integers(30, 42, size=(n, c))
+        rows[:, ::2][:, : (c + 1) // 2] = 33 + int(rng.integers(0, 72))
+        rows[:, c] = 10
+    else:                                                        # the whole alphabet, every symbol somewhere
+        rows = np.full((n, c + 1), 10, dtype=np.uint8)
+        rows[:, :c] = 33 + rng.integers(0, 72, size=(n, c))
+    dist = str(rng.choice(["M", "L", "A"]))
+    if rng.integers(2):
+        flags = ["-f", f"{rng.choice([0.0, 0.1, 0.33, 0.5, 0.75, 0.95, 1.0]):.2f}"]
+    else:
+        flags = ["-r", f"{rng.choice([0.0, 0.25, 0.5, 1.0, 1.7, 2.5, 4.0]):.2f}"]
+    return np.ascontiguousarray(rows), ["-c", str(k), "-d", dist] + flags, k
+
+
+def stats_fields(stdout):
+    m = re.search(r"rate, ([\d.]+), distortion, ([\d.naninf-]+), time, [\d.]+, size, (\d+)", stdout)
+    return m.groups() if m else None
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_input_against_the_reference_binary(tmp_path, seed):
+    rows, flags, k = make_case(seed)
+    n, c = rows.shape[0], rows.shape[1] - 1
+    inp = str(tmp_path / "in.txt")
+    open(inp, "wb").write(rows.tobytes())
+    ref_q, ref_u, our_q, our_u = (str(tmp_path / x) for x in ("ref.q", "ref.u", "our.q", "our.u"))
+    env = dict(os.environ, QVZ_WELL_SEED="debug")
+    if os.path.exists(REF_FIXED):
+        try:
+            ref = subprocess.run([REF_FIXED, "-s", "-u", ref_u] + flags + [inp, ref_q], capture_output=True, text=True, timeout=120)
+        except subprocess.TimeoutExpired:
+            pytest.skip("the reference does not finish on this input")
+        ok = ref.returncode == 0 and os.path.exists(ref_q) and stats_fields(ref.stdout) and "nan" not in ref.stdout
+        if not ok:                                               # a degenerate input the reference itself gives up on (an empty cluster divides by zero)
+            ours = subprocess.run([QVZ_BIN, "-s"] + flags + [inp, our_q], env=env, capture_output=True, text=True, timeout=120)
+            assert ours.returncode != 0 or "nan" in ours.stdout or k > 1, "the reference fails on an input the product encodes without a word"
+            pytest.skip(f"the reference fails here (rc {ref.returncode})")
+        want_q, want_u, want_s = open(ref_q, "rb").read(), open(ref_u, "rb").read(), stats_fields(ref.stdout)
+    else:
+        mode = O.MODE_RATIO if flags[4] == "-f" else O.MODE_FIXED
+        fresh_process_rand()
+        e = O.encode(rows, k=k, mode=mode, ratio=float(flags[5]), dist=flags[3])
+        want_q, want_u = e["q"], e["u"]
+        want_s = (f"{e['rate']:.4f}", f"{e['distortion']:.4f}", str(e["size"]))
+    ours = subprocess.run([QVZ_BIN, "-s", "-u", our_u] + flags + [inp, our_q], env=env, capture_output=True, text=True, timeout=120)
+    assert ours.returncode == 0, ours.stdout[-1500:] + ours.stderr[-1500:]
+    assert open(our_u, "rb").read() == want_u, f"-u differs ({n} x {c}, {' '.join(flags)})"
+    assert open(our_q, "rb").read() == want_q, f".q differs ({n} x {c}, {' '.join(flags)})"
+    assert stats_fields(ours.stdout) == tuple(want_s), (ours.stdout, want_s)
+    # the same input as a shard set: its decode is the reference's -u text
+    shards = 1 + seed % 5
+    if n // 4 >= shards:
+        qset, dec = str(tmp_path / "our.qset"), str(tmp_path / "our.dec")
+        subprocess.run([QVZ_BIN] + flags + [inp, qset], env=dict(env, QVZ_SHARDS=str(shards)), check=True, capture_output=True, timeout=120)
+        subprocess.run([QVZ_BIN, "-x", qset, dec], env=env, check=True, capture_output=True, timeout=120)
+        assert open(dec, "rb").read() == want_u, f"the shard set ({shards} streams) does not decode to the reference's -u text"
