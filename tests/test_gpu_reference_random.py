@@ -2,8 +2,9 @@
 symbol distributions, cluster counts, rate modes, targets and distortion measures. Where the unmodified reference travelled with the
 repo (oracle/_ref/qvz_ref_fixedseed: the reference compiled with its own -DDEBUG, i.e. a fixed WELL seed) it is RUN on every input,
 in a process of its own, and `qvz` - QVZ_WELL_SEED=debug, a process of its own too: both draw their centroids from a fresh
-rand() - must write the same `.q`, the same `-u` text and the same `-s` line; elsewhere the oracle's encode() stands in. Then the
-same input as a shard set: `qvz -x` of it is the reference's `-u` text."""
+rand() - must write the same `.q`, the same `-u` text and the same `-s` line; elsewhere the oracle's encode() stands in. So must the
+reference's unmodified main.c linked on the compat library (oracle/_ref/qvz_dropin). Then the same input as a shard set:
+`qvz -x` of it is the reference's `-u` text."""
 import os
 import re
 import subprocess
@@ -18,6 +19,7 @@ pytestmark = pytest.mark.gpu
 pytest.importorskip("torch")
 
 REF_FIXED = os.path.join(ROOT, "oracle", "_ref", "qvz_ref_fixedseed")
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "qvz_dropin")        # the reference's unmodified main.c on qvz_amd/libqvzcompat.so
 
 
 def make_case(seed):
@@ -98,6 +100,13 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
     assert open(our_u, "rb").read() == want_u, f"-u differs ({n} x {c}, {' '.join(flags)})"
     assert open(our_q, "rb").read() == want_q, f".q differs ({n} x {c}, {' '.join(flags)})"
     assert stats_fields(ours.stdout) == tuple(want_s), (ours.stdout, want_s)
+    # the drop-in boundary: the reference's own main.c, linked on the compat library, writes the same three things
+    if os.path.exists(DROPIN):
+        dq, du = str(tmp_path / "drop.q"), str(tmp_path / "drop.u")
+        drop = subprocess.run([DROPIN, "-s", "-u", du] + flags + [inp, dq], env=env, capture_output=True, text=True, timeout=120)
+        assert drop.returncode == 0, drop.stdout[-1500:] + drop.stderr[-1500:]
+        assert open(dq, "rb").read() == want_q and open(du, "rb").read() == want_u, f"drop-in differs ({n} x {c}, {' '.join(flags)})"
+        assert stats_fields(drop.stdout) == tuple(want_s)
     # the same input as a shard set: its decode is the reference's -u text
     shards = 1 + seed % 5
     if n // 4 >= shards:
