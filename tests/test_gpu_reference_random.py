@@ -58,6 +58,8 @@ def make_case(seed):
         rows = np.full((n, c + 1), 10, dtype=np.uint8)
         rows[:, :c] = 33 + rng.integers(0, 72, size=(n, c))
     dist = str(rng.choice(["M", "L", "A"]))
+    if seed >= 36:                                               # -D FILE: a matrix of the caller's (distortion.c:100-145), written beside the input
+        dist = "file"
     if rng.integers(2):
         flags = ["-f", f"{rng.choice([0.0, 0.1, 0.33, 0.5, 0.75, 0.95, 1.0]):.2f}"]
     else:
@@ -65,17 +67,43 @@ def make_case(seed):
     return np.ascontiguousarray(rows), ["-c", str(k), "-d", dist] + flags, k
 
 
+def distortion_text(seed):
+    """A 72 x 72 cost matrix as -D reads it: row = true value, column = reconstruction, short numbers (the reference reads a row
+    through a 1024-byte buffer). Four kinds: asymmetric slopes, a function of |x - y| that is NOT monotone, arbitrary small integers
+    with a zero diagonal, a scaled square."""
+    rng = np.random.default_rng(5000 + seed)
+    kind = seed % 4
+    m = np.zeros((72, 72))
+    x, y = np.meshgrid(np.arange(72), np.arange(72), indexing="ij")
+    if kind == 0:
+        a, b = rng.choice([0.5, 1.0, 1.5, 2.0, 3.0], size=2)
+        m = np.where(y > x, a * (y - x), b * (x - y))
+    elif kind == 1:
+        f = np.concatenate([[0.0], rng.integers(1, 12, size=71) * 0.5])
+        m = f[np.abs(x - y)]
+    elif kind == 2:
+        m = rng.integers(1, 10, size=(72, 72)).astype(float)
+        m[np.arange(72), np.arange(72)] = 0.0
+    else:
+        m = 0.25 * (x - y) ** 2
+    return ("\n".join(",".join(f"{v:g}" for v in row) for row in m) + "\n").encode()
+
+
 def stats_fields(stdout):
     m = re.search(r"rate, ([\d.]+), distortion, ([\d.naninf-]+), time, [\d.]+, size, (\d+)", stdout)
     return m.groups() if m else None
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_input_against_the_reference_binary(tmp_path, seed):
     rows, flags, k = make_case(seed)
     n, c = rows.shape[0], rows.shape[1] - 1
     inp = str(tmp_path / "in.txt")
     open(inp, "wb").write(rows.tobytes())
+    if flags[3] == "file":
+        dfile = str(tmp_path / "dist.txt")
+        open(dfile, "wb").write(distortion_text(seed))
+        flags = flags[:2] + ["-D", dfile] + flags[4:]
     ref_q, ref_u, our_q, our_u = (str(tmp_path / x) for x in ("ref.q", "ref.u", "our.q", "our.u"))
     env = dict(os.environ, QVZ_WELL_SEED="debug")
     if os.path.exists(REF_FIXED):
@@ -90,6 +118,8 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
             pytest.skip(f"the reference fails here (rc {ref.returncode})")
         want_q, want_u, want_s = open(ref_q, "rb").read(), open(ref_u, "rb").read(), stats_fields(ref.stdout)
     else:
+        if flags[2] == "-D":
+            pytest.skip("-D FILE is checked against the reference binary only")
         mode = O.MODE_RATIO if flags[4] == "-f" else O.MODE_FIXED
         fresh_process_rand()
         e = O.encode(rows, k=k, mode=mode, ratio=float(flags[5]), dist=flags[3])
