@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 pytest.importorskip("torch")
 
 REF_FIXED = os.path.join(ROOT, "oracle", "_ref", "qvz_ref_fixedseed")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "qvz_ref")            # the reference as it is built (its decoder needs no seed)
 DROPIN = os.path.join(ROOT, "oracle", "_ref", "qvz_dropin")        # the reference's unmodified main.c on qvz_amd/libqvzcompat.so
 
 
@@ -137,6 +138,10 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
         assert drop.returncode == 0, drop.stdout[-1500:] + drop.stderr[-1500:]
         assert open(dq, "rb").read() == want_q and open(du, "rb").read() == want_u, f"drop-in differs ({n} x {c}, {' '.join(flags)})"
         assert stats_fields(drop.stdout) == tuple(want_s)
+    # the decode direction: `qvz -x` of the file the REFERENCE wrote is the reference's -u text
+    dec1 = str(tmp_path / "ref.dec")
+    subprocess.run([QVZ_BIN, "-x", ref_q if os.path.exists(ref_q) else our_q, dec1], env=env, check=True, capture_output=True, timeout=120)
+    assert open(dec1, "rb").read() == want_u, "qvz -x of the reference's .q differs from its -u text"
     # the same input as a shard set: its decode is the reference's -u text
     shards = 1 + seed % 5
     if n // 4 >= shards:
@@ -144,3 +149,14 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
         subprocess.run([QVZ_BIN] + flags + [inp, qset], env=dict(env, QVZ_SHARDS=str(shards)), check=True, capture_output=True, timeout=120)
         subprocess.run([QVZ_BIN, "-x", qset, dec], env=env, check=True, capture_output=True, timeout=120)
         assert open(dec, "rb").read() == want_u, f"the shard set ({shards} streams) does not decode to the reference's -u text"
+        # ... and as shard FILES, each a complete reference-format file: the REFERENCE's decoder reads them one by one
+        if os.path.exists(REF_BIN) and seed % 3 == 0:
+            prefix = str(tmp_path / "piece.q")
+            subprocess.run([QVZ_BIN] + flags + [inp, prefix], env=dict(env, QVZ_SHARDS=str(shards), QVZ_SHARD_FILES="1"), check=True,
+                           capture_output=True, timeout=120)
+            text = b""
+            for g in range(shards):
+                out = str(tmp_path / f"piece.{g}.dec")
+                subprocess.run([REF_BIN, "-x", f"{prefix}.{g:04d}", out], check=True, capture_output=True, timeout=120)
+                text += open(out, "rb").read()
+            assert text == want_u, "the reference's decoder reads something else out of the shard files"
