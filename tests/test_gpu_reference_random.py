@@ -29,6 +29,8 @@ def make_case(seed):
     kind = seed % 6
     n = int(rng.choice([37, 64, 250, 1001, 2500, 6000]))
     c = int(rng.choice([2, 3, 7, 16, 33, 60]))
+    if seed >= 36 and c > 33:
+        c = 33                                                   # (the reference takes a quarter of a minute for 60 columns under an arbitrary -D matrix)
     k = 1
     if kind == 0:                                                # QGEN-1: the bench's generator (classes of reads, position-dependent qualities)
         n = max(n, 1001)
