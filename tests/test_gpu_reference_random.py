@@ -134,16 +134,17 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
     assert open(our_q, "rb").read() == want_q, f".q differs ({n} x {c}, {' '.join(flags)})"
     assert stats_fields(ours.stdout) == tuple(want_s), (ours.stdout, want_s)
     # the drop-in boundary: the reference's own main.c, linked on the compat library, writes the same three things
-    if os.path.exists(DROPIN):
+    if os.path.exists(DROPIN) and seed % 2 == 0:                  # (every other case: a process start costs a third of a second)
         dq, du = str(tmp_path / "drop.q"), str(tmp_path / "drop.u")
         drop = subprocess.run([DROPIN, "-s", "-u", du] + flags + [inp, dq], env=env, capture_output=True, text=True, timeout=120)
         assert drop.returncode == 0, drop.stdout[-1500:] + drop.stderr[-1500:]
         assert open(dq, "rb").read() == want_q and open(du, "rb").read() == want_u, f"drop-in differs ({n} x {c}, {' '.join(flags)})"
         assert stats_fields(drop.stdout) == tuple(want_s)
     # the decode direction: `qvz -x` of the file the REFERENCE wrote is the reference's -u text
-    dec1 = str(tmp_path / "ref.dec")
-    subprocess.run([QVZ_BIN, "-x", ref_q if os.path.exists(ref_q) else our_q, dec1], env=env, check=True, capture_output=True, timeout=120)
-    assert open(dec1, "rb").read() == want_u, "qvz -x of the reference's .q differs from its -u text"
+    if seed % 2 == 1:
+        dec1 = str(tmp_path / "ref.dec")
+        subprocess.run([QVZ_BIN, "-x", ref_q if os.path.exists(ref_q) else our_q, dec1], env=env, check=True, capture_output=True, timeout=120)
+        assert open(dec1, "rb").read() == want_u, "qvz -x of the reference's .q differs from its -u text"
     # the same input as a shard set: its decode is the reference's -u text
     shards = 1 + seed % 5
     if n // 4 >= shards:
