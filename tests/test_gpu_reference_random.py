@@ -163,3 +163,32 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
                 subprocess.run([REF_BIN, "-x", f"{prefix}.{g:04d}", out], check=True, capture_output=True, timeout=120)
                 text += open(out, "rb").read()
             assert text == want_u, "the reference's decoder reads something else out of the shard files"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FIXED), reason="needs the reference binary (oracle/_ref travels with the repo)")
+def test_seventeen_million_reads_against_the_reference_binary(tmp_path_factory):
+    """A size at which the GPU path takes its large-input kernels (the column-walking PMF pass with packed labels from 16.4M
+    reads on, k-means over a matrix the caches do not hold, the chunked single-stream coder) - and the reference still answers in
+    ten seconds: 17M x 6, three clusters. Same `.q`, same `-u`, same `-s` line."""
+    import hashlib
+    import shutil
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (2 << 30) else None
+    d = str(tmp_path_factory.mktemp("mid")) if base is None else os.path.join(base, f"qvz_mid_{os.getpid()}")
+    os.makedirs(d, exist_ok=True)
+    try:
+        n, c = 17_000_000, 6
+        inp = os.path.join(d, "in.txt")
+        O.qgen1_rows(21, n, c).tofile(inp)
+        flags = ["-c", "3", "-d", "M", "-r", "1.00"]
+        ref = subprocess.run([REF_FIXED, "-s", "-u", os.path.join(d, "ref.u")] + flags + [inp, os.path.join(d, "ref.q")],
+                             capture_output=True, text=True, timeout=300)
+        assert ref.returncode == 0, ref.stdout[-1000:]
+        ours = subprocess.run([QVZ_BIN, "-s", "-u", os.path.join(d, "our.u")] + flags + [inp, os.path.join(d, "our.q")],
+                              env=dict(os.environ, QVZ_WELL_SEED="debug"), capture_output=True, text=True, timeout=300)
+        assert ours.returncode == 0, ours.stdout[-1500:] + ours.stderr[-1500:]
+        assert stats_fields(ours.stdout) == stats_fields(ref.stdout), (ours.stdout, ref.stdout)
+        assert open(os.path.join(d, "our.q"), "rb").read() == open(os.path.join(d, "ref.q"), "rb").read(), ".q differs"
+        md5 = lambda p: hashlib.md5(open(p, "rb").read()).hexdigest()      # noqa: E731
+        assert md5(os.path.join(d, "our.u")) == md5(os.path.join(d, "ref.u")), "-u differs"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
