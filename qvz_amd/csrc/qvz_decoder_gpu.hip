@@ -232,8 +232,8 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
                                                       uint32_t arena_words, const uint8_t *__restrict__ draws, uint64_t ld,
                                                       uint8_t *__restrict__ qv, uint8_t *__restrict__ labels,
                                                       int32_t *__restrict__ status, uint32_t lanes) {
-    extern __shared__ uint32_t stage[];                          // [C][64] dwords: 4 reads of a column per lane; then ctx2 (CTX_LDS)
-    uint2 *lctx = reinterpret_cast<uint2 *>(stage + (size_t)C * 64);
+    extern __shared__ uint32_t stage[];                          // [C + 1][lanes] dwords: 4 reads of a column per lane (+ a row nobody reads); then ctx2 (CTX_LDS)
+    uint2 *lctx = reinterpret_cast<uint2 *>(stage + ((size_t)C + 1) * lanes);
     if (CTX_LDS) {
         for (uint32_t i = threadIdx.x; i < K * C * A; i += 64) lctx[i] = ctx2[i];
         __syncthreads();
@@ -242,6 +242,9 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
     const uint32_t lane = threadIdx.x;
     const uint32_t g = blockIdx.x * lanes + lane;                 // `lanes` streams per wave (64, or 32 when that puts a workgroup on every CU)
     const bool live = lane < lanes && g < shards;
+    // where this lane's dword of column s lies in the staging area: s * st_stride + st_base; the lanes beyond `lanes` share the
+    // last row (whatever they put there, nobody reads)
+    const uint32_t st_stride = lane < lanes ? lanes : 0u, st_base = lane < lanes ? lane : C * lanes + (lane - lanes) % lanes;
     const uint64_t r0 = live ? first[g] : 0, nreads = live ? first[g + 1] - r0 : 0;
     uint64_t most = nreads;
     for (int o = 32; o > 0; o >>= 1) { const uint64_t v = __shfl_xor(most, o, 64); most = v > most ? v : most; }
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
             // one inside the symbol chain each of them was a cache miss of its own); a draw sits in the staging byte
             // that the decoded value of the same (read, column) overwrites
             for (uint32_t s = 0; s < C; ++s)
-                stage[s * 64 + lane] = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)s * ld + r0 + i);
+                stage[s * st_stride + st_base] = *reinterpret_cast<const uint32_t *>(draws + (uint64_t)s * ld + r0 + i);
         }
         const bool mine = i < nreads;                            // this lane has a read i; it decodes it unless the stream has failed (`bad`)
         const uint32_t bsel = (uint32_t)(i & 3);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
         // column 0's table (the previous value is 0 there)
         uint32_t *tA = nobody, *tB = nobody;
         {
-            const uint32_t o = table_of(cl, 0, 0, sb[lane * 4 + bsel] & 127);       // well.c:33-46
+            const uint32_t o = table_of(cl, 0, 0, sb[st_base * 4 + bsel] & 127);    // well.c:33-46
             bad = bad || (mine && o == NO_TABLE);
             if (mine && !bad) tA = ar + o;
         }
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
         // qv_compressor.c:222-225 -; here it does, and nobody looks at that state again.)
         auto column = [&](uint32_t s, DecHeader &hc, uint32_t *tc, DecHeader &hn, uint32_t *&tn) {
             // (the draw of the next column, before this column's value goes into the staging area: another byte, but the compiler cannot know)
-            const uint32_t draw_next = s + 1 < C ? sb[((s + 1) * 64 + lane) * 4 + bsel] & 127u : 0u;
+            const uint32_t draw_next = s + 1 < C ? sb[((s + 1) * st_stride + st_base) * 4 + bsel] & 127u : 0u;
 #ifdef QVZ_PROFILE
             const unsigned long long dp0 = DP_NOW();
 #endif
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
             uint32_t value, lo, fx;
             bool ok;
             const uint32_t x = ld_front(d, hc, tc, &value, &lo, &fx, &ok);
-            sb[(s * 64 + lane) * 4 + bsel] = (uint8_t)value;                         // the quantizer's output alphabet
+            sb[(s * st_stride + st_base) * 4 + bsel] = (uint8_t)value;                         // the quantizer's output alphabet
             bad = bad || (mine && !ok);
             // the next column's table is known now: its header is on its way while the interval is updated
             tn = nobody;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(64) void k_decode_shards(const uint8_t *__restrict_
             if (i0 < nreads) {
                 const uint32_t cnt = nreads - i0 < 4 ? (uint32_t)(nreads - i0) : 4u;
                 for (uint32_t s = 0; s < C; ++s) {
-                    const uint32_t w = stage[s * 64 + lane];
+                    const uint32_t w = stage[s * st_stride + st_base];
                     uint8_t *dst = qv + (uint64_t)s * ld + r0 + i0;                  // r0 and i0 are multiples of 4
                     if (cnt == 4) *reinterpret_cast<uint32_t *>(dst) = w;
                     else for (uint32_t b = 0; b < cnt; ++b) dst[b] = (uint8_t)(w >> (8 * b));
@@ -406,7 +409,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     if (!d_in || !h_sizes || !n || !columns || !clusters || !cbs || !shards || !d_draws || !d_qv || ld < n || (ld & 3) || (cap_per_shard & 3))
         return qvz_set_error(QVZ_E_ARG, "bad shard-decoder arguments");
     if (clusters > 1 && !d_labels) return qvz_set_error(QVZ_E_ARG, "a label buffer is required for clusters > 1");
-    if ((size_t)columns * 64 * 4 > 150 * 1024) return qvz_set_error(QVZ_E_ARG, "%u columns exceed the decoder's LDS staging (600 at most)", columns);
+    if (((size_t)columns + 1) * 32 * 4 > 150 * 1024) return qvz_set_error(QVZ_E_ARG, "%u columns exceed the decoder's LDS staging (1199 at most)", columns);
     for (uint32_t g = 0; g < shards; ++g)
         if (h_sizes[g] > cap_per_shard) return qvz_set_error(QVZ_E_ARG, "stream %u is longer than cap_per_shard", g);
     hipStream_t st = (hipStream_t)stream;
@@ -418,6 +421,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
             (shards + 31) / 32 <= (uint32_t)cus) dec_lanes = 32;
+        if (((size_t)columns + 1) * 64 * 4 > 150 * 1024) dec_lanes = 32;   // long reads: a staging row of 64 lanes would not fit the LDS
     }
     uint32_t *h_arena = nullptr, *h_off = nullptr, words = 0;
     if (qvz_model_build(clusters, columns, cbs, QVZ_MODEL_LIVE_ONLY | QVZ_MODEL_ALIGN16, &h_arena, &h_off, &words))
@@ -435,7 +439,7 @@ extern "C" int qvz_hip_decode_shards_bounds(const uint8_t *d_in, uint64_t cap_pe
     int rc = QVZ_OK;
     int32_t status = 0;
     uint32_t dwords = 0, dwords_stride = 0;
-    const size_t lds_stage = (size_t)columns * 64 * 4, lds_ctx = ctxn * sizeof(uint2);
+    const size_t lds_stage = ((size_t)columns + 1) * dec_lanes * 4, lds_ctx = ctxn * sizeof(uint2);
     const bool ctx_lds = lds_stage + lds_ctx <= 150 * 1024;
     const size_t lds = lds_stage + (ctx_lds ? lds_ctx : 0);
 #define TRY(expr)                                                                                                    \

@@ -29,13 +29,15 @@ def make_case(seed):
     kind = seed % 6
     n = int(rng.choice([37, 64, 250, 1001, 2500, 6000]))
     c = int(rng.choice([2, 3, 7, 16, 33, 60]))
-    if seed >= 36 and c > 33:
+    if 36 <= seed < 48 and c > 33:
         c = 33                                                   # (the reference takes a quarter of a minute for 60 columns under an arbitrary -D matrix)
     k = 1
+    if seed >= 48:                                               # long reads: more columns than 64 lanes' staging rows fit the decoder's LDS (600)
+        n, c, kind = 400, 640, 0
     if kind == 0:                                                # QGEN-1: the bench's generator (classes of reads, position-dependent qualities)
-        n = max(n, 1001)
+        n = max(n, 1001) if seed < 48 else n
         rows = O.qgen1_rows(seed, n, c)
-        k = int(rng.choice([1, 2, 3]))
+        k = int(rng.choice([1, 2, 3])) if seed < 48 else 1
     elif kind == 1:                                              # uniform over a window of the alphabet
         lo = int(rng.integers(0, 60))
         hi = int(rng.integers(lo + 1, 72))
@@ -61,12 +63,14 @@ def make_case(seed):
         rows = np.full((n, c + 1), 10, dtype=np.uint8)
         rows[:, :c] = 33 + rng.integers(0, 72, size=(n, c))
     dist = str(rng.choice(["M", "L", "A"]))
-    if seed >= 36:                                               # -D FILE: a matrix of the caller's (distortion.c:100-145), written beside the input
+    if 36 <= seed < 48:                                          # -D FILE: a matrix of the caller's (distortion.c:100-145), written beside the input
         dist = "file"
     if rng.integers(2):
         flags = ["-f", f"{rng.choice([0.0, 0.1, 0.33, 0.5, 0.75, 0.95, 1.0]):.2f}"]
     else:
         flags = ["-r", f"{rng.choice([0.0, 0.25, 0.5, 1.0, 1.7, 2.5, 4.0]):.2f}"]
+    if seed >= 48:                                               # (targets the reference reaches in seconds at this many columns)
+        dist, flags = "L", ["-f", "0.10"]
     return np.ascontiguousarray(rows), ["-c", str(k), "-d", dist] + flags, k
 
 
@@ -97,7 +101,7 @@ def stats_fields(stdout):
     return m.groups() if m else None
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(49))
 def test_random_input_against_the_reference_binary(tmp_path, seed):
     rows, flags, k = make_case(seed)
     n, c = rows.shape[0], rows.shape[1] - 1
@@ -192,3 +196,24 @@ def test_seventeen_million_reads_against_the_reference_binary(tmp_path_factory):
         assert md5(os.path.join(d, "our.u")) == md5(os.path.join(d, "ref.u")), "-u differs"
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_long_reads_as_a_shard_set(tmp_path):
+    """1001 columns - beyond what 64 staging rows per column hold of the decoder's LDS (600), so its waves take 32 streams -: the
+    shard set decodes to the `-u` text, and every shard's file decodes with the ORACLE's decoder to its part of it."""
+    from qvz_amd import host
+    n, c, shards = 320, 1001, 5
+    rows = O.qgen1_rows(77, n, c)
+    inp = str(tmp_path / "long.txt")
+    open(inp, "wb").write(rows.tobytes())
+    qset, u, dec, prefix = (str(tmp_path / x) for x in ("l.qset", "l.u", "l.dec", "piece"))
+    env = dict(os.environ, QVZ_WELL_SEED="debug", QVZ_SHARDS=str(shards))
+    flags = ["-c", "1", "-d", "L", "-f", "0.10"]
+    subprocess.run([QVZ_BIN, "-u", u] + flags + [inp, qset], env=env, check=True, capture_output=True, timeout=300)
+    subprocess.run([QVZ_BIN, "-x", qset, dec], env=env, check=True, capture_output=True, timeout=300)
+    text = open(u, "rb").read()
+    assert len(text) == n * (c + 1) and open(dec, "rb").read() == text
+    host.shardset_split(qset, prefix)
+    first = host.shard_bounds(n, shards)
+    for g in range(shards):
+        assert O.decode(open(f"{prefix}.{g:04d}", "rb").read()) == text[first[g] * (c + 1):first[g + 1] * (c + 1)], f"shard {g}"
