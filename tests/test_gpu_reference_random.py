@@ -32,12 +32,14 @@ def make_case(seed):
     if 36 <= seed < 48 and c > 33:
         c = 33                                                   # (the reference takes a quarter of a minute for 60 columns under an arbitrary -D matrix)
     k = 1
-    if seed >= 48:                                               # long reads: more columns than 64 lanes' staging rows fit the decoder's LDS (600)
+    if seed == 48:                                               # long reads: more columns than 64 lanes' staging rows fit the decoder's LDS (600)
         n, c, kind = 400, 640, 0
+    if seed >= 49:                                               # five and six clusters (label bytes instead of 2-bit packs in the PMF pass)
+        n, c, kind = (6000, 20, 0) if seed == 49 else (20000, 12, 0)
     if kind == 0:                                                # QGEN-1: the bench's generator (classes of reads, position-dependent qualities)
         n = max(n, 1001) if seed < 48 else n
         rows = O.qgen1_rows(seed, n, c)
-        k = int(rng.choice([1, 2, 3])) if seed < 48 else 1
+        k = int(rng.choice([1, 2, 3])) if seed < 48 else {48: 1, 49: 5, 50: 6}[seed]
     elif kind == 1:                                              # uniform over a window of the alphabet
         lo = int(rng.integers(0, 60))
         hi = int(rng.integers(lo + 1, 72))
@@ -69,8 +71,10 @@ def make_case(seed):
         flags = ["-f", f"{rng.choice([0.0, 0.1, 0.33, 0.5, 0.75, 0.95, 1.0]):.2f}"]
     else:
         flags = ["-r", f"{rng.choice([0.0, 0.25, 0.5, 1.0, 1.7, 2.5, 4.0]):.2f}"]
-    if seed >= 48:                                               # (targets the reference reaches in seconds at this many columns)
+    if seed == 48:                                               # (a target the reference reaches in seconds at this many columns)
         dist, flags = "L", ["-f", "0.10"]
+    if seed >= 49:
+        dist, flags = "M", ["-f", "0.50"]
     return np.ascontiguousarray(rows), ["-c", str(k), "-d", dist] + flags, k
 
 
@@ -101,7 +105,7 @@ def stats_fields(stdout):
     return m.groups() if m else None
 
 
-@pytest.mark.parametrize("seed", range(49))
+@pytest.mark.parametrize("seed", range(51))
 def test_random_input_against_the_reference_binary(tmp_path, seed):
     rows, flags, k = make_case(seed)
     n, c = rows.shape[0], rows.shape[1] - 1
