@@ -75,6 +75,8 @@ def make_case(seed):
         dist, flags = "L", ["-f", "0.10"]
     if seed >= 49:
         dist, flags = "M", ["-f", "0.50"]
+    if k > 1 and seed % 3 != 2:                                  # -T: the movement below which k-means stops (cluster.c:212-244; 4 by default)
+        flags = flags + ["-T", str((1, 16)[seed % 3])]
     return np.ascontiguousarray(rows), ["-c", str(k), "-d", dist] + flags, k
 
 
@@ -133,7 +135,7 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
             pytest.skip("-D FILE is checked against the reference binary only")
         mode = O.MODE_RATIO if flags[4] == "-f" else O.MODE_FIXED
         fresh_process_rand()
-        e = O.encode(rows, k=k, mode=mode, ratio=float(flags[5]), dist=flags[3])
+        e = O.encode(rows, k=k, mode=mode, ratio=float(flags[5]), dist=flags[3], threshold=float(flags[7]) if "-T" in flags else 4.0)
         want_q, want_u = e["q"], e["u"]
         want_s = (f"{e['rate']:.4f}", f"{e['distortion']:.4f}", str(e["size"]))
     ours = subprocess.run([QVZ_BIN, "-s", "-u", our_u] + flags + [inp, our_q], env=env, capture_output=True, text=True, timeout=120)
