@@ -162,6 +162,13 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
         subprocess.run([QVZ_BIN] + flags + [inp, qset], env=dict(env, QVZ_SHARDS=str(shards)), check=True, capture_output=True, timeout=120)
         subprocess.run([QVZ_BIN, "-x", qset, dec], env=env, check=True, capture_output=True, timeout=120)
         assert open(dec, "rb").read() == want_u, f"the shard set ({shards} streams) does not decode to the reference's -u text"
+        # ... and written by TWO parts of one process (the multi-device driver with this GPU listed twice: the k-means sums and the
+        # counters added up between the parts): the same shard set, byte for byte
+        if seed % 4 == 0 and shards >= 2:
+            q2 = str(tmp_path / "two.qset")
+            subprocess.run([QVZ_BIN] + flags + [inp, q2], env=dict(env, QVZ_SHARDS=str(shards), QVZ_DEVICES="0,0"), check=True,
+                           capture_output=True, timeout=120)
+            assert open(q2, "rb").read() == open(qset, "rb").read(), "two parts write another shard set than one"
         # ... and as shard FILES, each a complete reference-format file: the REFERENCE's decoder reads them one by one
         if os.path.exists(REF_BIN) and seed % 3 == 0:
             prefix = str(tmp_path / "piece.q")
