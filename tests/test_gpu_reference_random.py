@@ -143,6 +143,16 @@ def test_random_input_against_the_reference_binary(tmp_path, seed):
     assert open(our_u, "rb").read() == want_u, f"-u differs ({n} x {c}, {' '.join(flags)})"
     assert open(our_q, "rb").read() == want_q, f".q differs ({n} x {c}, {' '.join(flags)})"
     assert stats_fields(ours.stdout) == tuple(want_s), (ours.stdout, want_s)
+    # what -v prints (main.c, cluster.c, qv_compressor.c), line by line, the seconds aside
+    if seed % 5 == 0 and os.path.exists(REF_FIXED):
+        def talk(out, q_name):
+            out = out.replace(q_name, "OUT")
+            out = re.sub(r"took [\d.]+ seconds", "took T seconds", out)
+            out = re.sub(r"elapsed: [\d.]+ seconds", "elapsed: T seconds", out)
+            return re.sub(r"time, [\d.]+,", "time, T,", out).splitlines()
+        ref_v = subprocess.run([REF_FIXED, "-v", "-s"] + flags + [inp, ref_q], capture_output=True, text=True, timeout=120).stdout
+        our_v = subprocess.run([QVZ_BIN, "-v", "-s"] + flags + [inp, our_q], env=env, capture_output=True, text=True, timeout=120).stdout
+        assert talk(our_v, our_q) == talk(ref_v, ref_q)
     # the drop-in boundary: the reference's own main.c, linked on the compat library, writes the same three things
     if os.path.exists(DROPIN) and seed % 2 == 0:                  # (every other case: a process start costs a third of a second)
         dq, du = str(tmp_path / "drop.q"), str(tmp_path / "drop.u")
