@@ -34,12 +34,12 @@ def make_case(seed):
     k = 1
     if seed == 48:                                               # long reads: more columns than 64 lanes' staging rows fit the decoder's LDS (600)
         n, c, kind = 400, 640, 0
-    if seed >= 49:                                               # five and six clusters (label bytes instead of 2-bit packs in the PMF pass)
+    if 49 <= seed <= 50:                                         # five and six clusters (label bytes instead of 2-bit packs in the PMF pass)
         n, c, kind = (6000, 20, 0) if seed == 49 else (20000, 12, 0)
     if kind == 0:                                                # QGEN-1: the bench's generator (classes of reads, position-dependent qualities)
         n = max(n, 1001) if seed < 48 else n
         rows = O.qgen1_rows(seed, n, c)
-        k = int(rng.choice([1, 2, 3])) if seed < 48 else {48: 1, 49: 5, 50: 6}[seed]
+        k = int(rng.choice([1, 2, 3])) if seed < 48 else {49: 5, 50: 6}.get(seed, 1)
     elif kind == 1:                                              # uniform over a window of the alphabet
         lo = int(rng.integers(0, 60))
         hi = int(rng.integers(lo + 1, 72))
@@ -73,8 +73,13 @@ def make_case(seed):
         flags = ["-r", f"{rng.choice([0.0, 0.25, 0.5, 1.0, 1.7, 2.5, 4.0]):.2f}"]
     if seed == 48:                                               # (a target the reference reaches in seconds at this many columns)
         dist, flags = "L", ["-f", "0.10"]
-    if seed >= 49:
+    if 49 <= seed <= 50:
         dist, flags = "M", ["-f", "0.50"]
+    if seed >= 51:                                               # tiny inputs: one read, one column
+        n, c = ((1, 2), (1, 7), (2, 3), (3, 2), (5, 4), (4, 1), (9, 1))[seed - 51]
+        rows = np.full((n, c + 1), 10, dtype=np.uint8)
+        rows[:, :c] = 33 + rng.integers(0, 41, size=(n, c))
+        k, dist, flags = 1, "M", (["-f", "0.50"], ["-r", "1.00"])[seed % 2]
     if k > 1 and seed % 3 != 2:                                  # -T: the movement below which k-means stops (cluster.c:212-244; 4 by default)
         flags = flags + ["-T", str((1, 16)[seed % 3])]
     return np.ascontiguousarray(rows), ["-c", str(k), "-d", dist] + flags, k
@@ -107,7 +112,7 @@ def stats_fields(stdout):
     return m.groups() if m else None
 
 
-@pytest.mark.parametrize("seed", range(51))
+@pytest.mark.parametrize("seed", range(58))
 def test_random_input_against_the_reference_binary(tmp_path, seed):
     rows, flags, k = make_case(seed)
     n, c = rows.shape[0], rows.shape[1] - 1
