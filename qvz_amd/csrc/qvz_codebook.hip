@@ -70,46 +70,54 @@ __global__ __launch_bounds__(64) void k_cond_pmf(const CountT *__restrict__ cnt,
 
 // marg[0] = 1.0*P[0][0] + 0.0*0 ; marg[s][x] = sum_j (1.0*marg[s][x] + marg[s-1][j]*P[s][j][x]) in j order
 // (codebook.c:213-218, combine_pmfs pmf.c:200-202)
-__global__ __launch_bounds__(128) void k_marginals(const double *__restrict__ P, uint32_t C, double *__restrict__ marg) {
-    // Columns are a chain (marg[s] needs marg[s-1]) and a column is a chain of 72 multiply-adds per symbol: ~0.7 us of arithmetic.
-    // Loading P(X_s | X_{s-1}) inside that chain cost another 2.5 us per column (0.49 ms per codebook); the next column's 72 x 72
-    // tile is now requested into registers before the current column is summed out of LDS, and parked behind it.
+__global__ __launch_bounds__(256) void k_marginals(const double *__restrict__ P, uint32_t C, double *__restrict__ marg) {
+    // Columns are a chain (marg[s] needs marg[s-1]) and a column is a chain of 72 multiply-adds per symbol: ~0.5 us of arithmetic.
+    // What a column cost beyond that was the round trip of its 72 x 72 tile P(X_s | X_{s-1}): requested one column ahead into
+    // registers it still took 4.2 us per column (0.64 ms per codebook in round 5's kernel statistics) - __syncthreads() waits
+    // for every outstanding global load, so each column paid the whole round trip at its first barrier. Now the barriers order
+    // LDS only and TWO tiles are on their way (two register sets, even and odd columns) while a third is summed out of LDS.
+#define MG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     __shared__ double prev[A];
     __shared__ double tile[A * A];                               // P_s[j][x], the column being summed
-    constexpr uint32_t PER = (A * A + 127) / 128;                // tile elements per thread
+    constexpr uint32_t PER = (A * A + 255) / 256;                // tile elements per thread
     const uint32_t x = threadIdx.x;
     if (x < A) {
         const double m0 = 1.0 * P[x] + 0.0 * 0.0;
         prev[x] = m0;
         marg[x] = m0;
     }
-    double nxt[PER];
-    if (C > 1) {
+    double ra[PER], rb[PER];
+    auto request = [&](double *r, uint32_t s) {
 #pragma unroll
-        for (uint32_t u = 0; u < PER; ++u) { const uint32_t e = u * 128 + x; nxt[u] = e < A * A ? P[(uint64_t)A * A + e] : 0.0; }
+        for (uint32_t u = 0; u < PER; ++u) { const uint32_t e = u * 256 + x; r[u] = P[(uint64_t)s * A * A + (e < A * A ? e : 0u)]; }
+    };
+    auto park = [&](const double *r) {
 #pragma unroll
-        for (uint32_t u = 0; u < PER; ++u) { const uint32_t e = u * 128 + x; if (e < A * A) tile[e] = nxt[u]; }
-    }
-    __syncthreads();
-    for (uint32_t s = 1; s < C; ++s) {
-        if (s + 1 < C) {
-#pragma unroll
-            for (uint32_t u = 0; u < PER; ++u) { const uint32_t e = u * 128 + x; nxt[u] = e < A * A ? P[(uint64_t)(s + 1) * A * A + e] : 0.0; }
-        }
+        for (uint32_t u = 0; u < PER; ++u) { const uint32_t e = u * 256 + x; if (e < A * A) tile[e] = r[u]; }
+    };
+    // One column: tile s is in LDS, tile s + 1 in `r1` (requested two columns ago), tile s + 2 on its way in the other set.
+    auto column = [&](uint32_t s, double *r1) {
         double m = 0.0;
         if (x < A)
             for (int j = 0; j < A; ++j) m = 1.0 * m + prev[j] * tile[j * A + x];   // combine_pmfs, pmf.c:200-202: the same terms in the same order
-        __syncthreads();
+        MG_BARRIER();                                            // everybody has read prev and the tile
         if (x < A) {
             prev[x] = m;
             marg[(uint64_t)s * A + x] = m;
         }
-        if (s + 1 < C) {
-#pragma unroll
-            for (uint32_t u = 0; u < PER; ++u) { const uint32_t e = u * 128 + x; if (e < A * A) tile[e] = nxt[u]; }
-        }
-        __syncthreads();
+        if (s + 1 < C) park(r1);
+        if (s + 3 < C) request(r1, s + 3);
+        MG_BARRIER();
+    };
+    if (C > 1) { request(ra, 1); park(ra); }
+    if (C > 2) request(ra, 2);                                   // even tiles travel in ra, odd ones in rb
+    if (C > 3) request(rb, 3);
+    MG_BARRIER();
+    for (uint32_t s = 1; s < C; s += 2) {
+        column(s, ra);
+        if (s + 1 < C) column(s + 1, rb);
     }
+#undef MG_BARRIER
 }
 
 // what the Lloyd-Max window kernel is told per context (k_lm_window)
@@ -135,19 +143,20 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
                                                        const uint8_t *__restrict__ qprev,     // [144][72] tables of column s-1
                                                        const double *__restrict__ rprev,      // [72] ratios of column s-1
                                                        const double *__restrict__ ptemp,      // [72][72] (s >= 2)
-                                                       double *__restrict__ qpmf, uint32_t *__restrict__ stop,
-                                                       const uint8_t *__restrict__ nctx) {    // device-driven flow: contexts per column
+                                                       double *__restrict__ qpmf, uint32_t *__restrict__ stop) {
     __shared__ double pt[A], raw[A], sr[A];
     __shared__ uint8_t slo[A], shi[A];
     CB_PRIO();
     const uint32_t k = blockIdx.x, idx = threadIdx.x;
-    if (nctx) { nprev = nctx[s - 1]; nu = nctx[s]; }
+    // (ctx_sym, qprev and rprev are mapped HOST memory: a load is a PCIe round trip. The context symbol is asked for here, with the
+    // tables and ratios below - behind the barrier it was a second round trip in a row.)
+    const uint32_t sym_of_idx = idx < nu ? ctx_sym[idx] : 0u;
     if (k == 0 && idx < A) stop[idx] = 0xFFFFFFFFu;              // the design window that follows starts with no stop marks
     if (s == 1) {
         // compute_qpmf_quan_list (codebook.c:274-289): not renormalised
         if (idx < nu) {
             const double r0 = rprev[0];
-            const uint32_t sym = ctx_sym[idx];
+            const uint32_t sym = sym_of_idx;
             double v = 0.0;
             if (qprev[k] == sym) v += r0;
             if (qprev[A + k] == sym) v += (1 - r0);
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
     __syncthreads();
     // qpmf[k][idx] += p_q_xq * p_temp over j                                          (codebook.c:301-322)
     if (idx < nu) {
-        const uint32_t sym = ctx_sym[idx];
+        const uint32_t sym = sym_of_idx;
         double acc = 0.0;
         for (uint32_t j = 0; j < nprev; ++j) {
             double p_q_xq = 0.0;
@@ -193,17 +202,29 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
 __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, const double *__restrict__ marg, uint32_t s,
                                                   const double *__restrict__ qpmf, double *__restrict__ xpmf, double *__restrict__ xpmf_host,
                                                   LmIn *__restrict__ lin, int ratio_mode, double opt_ratio, int exact,
-                                                  LmIn *__restrict__ lin_host, const uint8_t *__restrict__ nctx) {
-    __shared__ double row[A], nrow[A], ent[A];
+                                                  LmIn *__restrict__ lin_host) {
+    __shared__ double row[A], nrow[A], ent[A], qcol[A], mcol[A];
     CB_PRIO();
     const uint32_t idx = blockIdx.x, k = threadIdx.x;
-    if (nctx && idx >= nctx[s]) return;                           // device-driven flow: the grid is sized for 72 contexts
     const double *Ps = P + (uint64_t)s * A * A;
     const double *m1 = marg + (uint64_t)(s - 1) * A;
+    // A thread per symbol k adds its 72 terms qpmf[x][idx] * P_s[x][k] * marg_{s-1}[x] in x order. Its 72 values of P_s are asked
+    // for AT ONCE (one memory round trip; gathered term by term, eight at a time, the sum waited nine round trips in a row - beside
+    // the WELL generator's stores most of the kernel's 19 us); the two operands every thread shares come through LDS. The workgroup
+    // stays small in registers-times-threads and LDS: it has to find room on a CU beside the generator's workgroups.
+    double pk[A];
+    const uint32_t kk = k < A ? k : 0u;
+#pragma unroll
+    for (int x = 0; x < A; ++x) pk[x] = Ps[x * A + kk];
+    if (k < A) {
+        qcol[k] = qpmf[k * A + idx];
+        mcol[k] = m1[k];
+    }
+    __syncthreads();
     if (k < A) {
         double acc = 0.0;
-#pragma unroll 8
-        for (int x = 0; x < A; ++x) acc += qpmf[x * A + idx] * Ps[x * A + k] * m1[x];
+#pragma unroll
+        for (int x = 0; x < A; ++x) acc += qcol[x] * pk[x] * mcol[x];
         row[k] = acc;
     }
     __syncthreads();
@@ -306,7 +327,7 @@ template <bool TOEP, bool MONO>
 __device__ bool lm_design(const double *__restrict__ p, const double *__restrict__ dl, uint32_t S, LmLds *L,
                           double *__restrict__ o, int b, const uint32_t *stop) {
     auto D = [&](uint32_t i, uint32_t r) -> double { return TOEP ? dl[i > r ? i - r : r - i] : dl[i * A + r]; };
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
     uint8_t *bounds = L->bounds, *recon = L->recon[b], *q = L->q[b];
     if (lane == 0) { bounds[0] = 0; bounds[S] = A; }                                  // :45-46
     for (uint32_t j = lane; j < S; j += 64) if (j >= 1) bounds[j] = (uint8_t)((j * A) / S);   // :47-49
@@ -591,12 +612,12 @@ __device__ bool lm_design(const double *__restrict__ p, const double *__restrict
 // get_entropy (pmf.c:141-155) of a design's output pmf, bit for bit: the 72 terms p * log2(p) by the lanes (glibc's log2
 // restated, one IEEE multiply), then ONE lane subtracts them in index order as the reference's loop does. `term` is LDS.
 __device__ double lm_entropy_exact(const double *o, double *term) {
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
     for (uint32_t v = lane; v < A; v += 64) {
         const double x = o[v];
         term[v] = x > 0.0 ? x * qvz_log2_glibc(x) : 0.0;         // e - 0.0 == e: a skipped term changes nothing
     }
-    __syncthreads();
+    LM_SYNC();                                                   // one wave: its LDS operations complete in order
     double e = 0.0;
     if (lane == 0)
         for (uint32_t v = 0; v < A; ++v) e -= term[v];
@@ -604,7 +625,7 @@ __device__ double lm_entropy_exact(const double *o, double *term) {
 }
 
 __device__ double lm_entropy_dev(const double *o) {   // steering value only (device log2, tree order)
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
     double t = 0.0;
     for (uint32_t v = lane; v < A; v += 64) {
         const double x = o[v];
@@ -968,7 +989,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
 
     if (wide) hipLaunchKernelGGL(k_cond_pmf<unsigned long long>, dim3(C * A), dim3(64), 0, st, (const unsigned long long *)d_cnt, W.P);
     else hipLaunchKernelGGL(k_cond_pmf<uint32_t>, dim3(C * A), dim3(64), 0, st, (const uint32_t *)d_cnt, W.P);
-    hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, W.P, C, W.marg);
+    hipLaunchKernelGGL(k_marginals, dim3(1), dim3(256), 0, st, W.P, C, W.marg);
     QVZ_HIP_CHECK(hipGetLastError());
 
     // One exchange with the host per column (two when a context's walk runs off the first design window). Everything that
@@ -1065,11 +1086,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             // column's context symbols straight from mapped host memory: a few hundred bytes per workgroup.
             hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu, (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A),
                                (const uint8_t *)(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
-                               W.ptemp, W.qpmf[pq ^ 1], W.stop, (const uint8_t *)nullptr);
+                               W.ptemp, W.qpmf[pq ^ 1], W.stop);
             // k_ctx_xpmf plans the first design window on the device (all-zero rows and zero targets are exact on both
             // sides; its log2-based target only steers which designs give up early), so the window follows at once
             hipLaunchKernelGGL(k_ctx_xpmf, dim3(nu), dim3(128), 0, st, W.P, W.marg, s, W.qpmf[pq ^ 1], W.xpmf, hx_d,
-                               W.lin, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio, exact ? 1 : 0, hplan_d, (const uint8_t *)nullptr);
+                               W.lin, mode == QVZ_MODE_RATIO ? 1 : 0, opt_ratio, exact ? 1 : 0, hplan_d);
             pq ^= 1;
             d_rows = W.xpmf;
             win0 = window0;
@@ -1292,7 +1313,7 @@ extern "C" int qvz_hip_marginals(const uint32_t *d_cnt, uint32_t C, double *h_ma
         rc = qvz_set_error(QVZ_E_NOMEM, "device alloc");
     } else {
         hipLaunchKernelGGL(k_cond_pmf<uint32_t>, dim3(C * A), dim3(64), 0, st, d_cnt, P);
-        hipLaunchKernelGGL(k_marginals, dim3(1), dim3(128), 0, st, P, C, marg);
+        hipLaunchKernelGGL(k_marginals, dim3(1), dim3(256), 0, st, P, C, marg);
         if (hipMemcpyAsync(h_marg, marg, (size_t)C * A * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             rc = qvz_set_error(QVZ_E_HIP, "marginals copy failed");
