@@ -277,6 +277,14 @@ struct LmDesign {
     uint8_t pad[6];
 };
 
+// What the host's walk over a window reads of every design - the entropy, the state count, whether it was computed - once more
+// in 16 bytes of a dense array: the walk then reads a window's summaries line after line (a dozen cache lines that the
+// prefetcher sees coming) instead of two lines out of every 736-byte LmDesign the device has just written to host memory.
+struct LmSum {
+    double hdev;
+    uint8_t S, valid, pad[6];
+};
+
 // Region index of two symbols under a partition: the number of interior bounds (t = 1 .. S-1) not above the symbol.
 // The bounds are read sixteen at a time (one LDS round trip) and compared from registers.
 template <bool BOTH = true>
@@ -645,7 +653,7 @@ struct LmRider {           // k_ctx_ptemp of the next column riding on a window 
 // bank conflicts). blockIdx.x runs fastest, so the small S of every context are dispatched first.
 template <bool TOEP, bool MONO>
 __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm, const double *__restrict__ distT,
-                                                  const LmIn *__restrict__ in, LmDesign *__restrict__ out,
+                                                  const LmIn *__restrict__ in, LmDesign *__restrict__ out, LmSum *__restrict__ sum,
                                                   uint32_t *__restrict__ stop, double guard, int exact, LmRider rider) {
     CB_PRIO();
     // Rows of the grid beyond the window (blockIdx.y >= rider.rows) carry k_ctx_ptemp of the NEXT column: it needs this
@@ -671,23 +679,25 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     const uint32_t ctx = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
     const LmIn I = in[ctx];
     LmDesign *O = out + (size_t)ctx * (rider.rows ? rider.rows : gridDim.y) + w;
+    LmSum *Q = sum + (size_t)ctx * (rider.rows ? rider.rows : gridDim.y) + w;
     const uint32_t S = (uint32_t)I.startS + w;
     // (`out` is mapped host memory: the results need no copy; the k_cb_flag launched behind this kernel tells the host.
     // Letting the last block raise the flag instead needs a system-scope fence in every block: measured, with the 72 x 72
     // block windows of -r 1.0 that cost 13 ms per codebook.)
     const unsigned long long t_begin = __builtin_readcyclecounter();
     const bool wanted = I.mode == 1 ? S <= A : (I.mode == 2 && w == 0);
-    if (!wanted || (I.mode == 1 && __atomic_load_n(stop + ctx, __ATOMIC_RELAXED) < S)) {
-        if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
-        return;
-    }
+    auto not_computed = [&]() {
+        if (lane == 0) {
+            O->S = (uint8_t)S; O->valid = 0;
+            LmSum q; q.hdev = 0.0; q.S = (uint8_t)S; q.valid = 0; for (int i = 0; i < 6; ++i) q.pad[i] = 0;
+            *Q = q;
+        }
+    };
+    if (!wanted || (I.mode == 1 && __atomic_load_n(stop + ctx, __ATOMIC_RELAXED) < S)) { not_computed(); return; }
     for (uint32_t e = lane; e < (TOEP ? A : A * A); e += 64) dl[e] = distT[e];   // TOEP: row 0 = d(0, r) = f(r)
     for (uint32_t e = lane; e < A; e += 64) p[e] = pm[(uint64_t)ctx * A + e];
     __syncthreads();
-    if (!lm_design<TOEP, MONO>(p, dl, S, L, o, 0, I.mode == 1 ? stop + ctx : nullptr)) {
-        if (lane == 0) { O->S = (uint8_t)S; O->valid = 0; }
-        return;
-    }
+    if (!lm_design<TOEP, MONO>(p, dl, S, L, o, 0, I.mode == 1 ? stop + ctx : nullptr)) { not_computed(); return; }
     // exact: hdev IS the libm entropy of o and every decision of the walk can be taken from it (no guard band);
     // L->mv (72 doubles of LDS) is free once the design is done
     const double H = exact ? lm_entropy_exact(o, L->mv) : lm_entropy_dev(o);
@@ -698,6 +708,10 @@ __global__ __launch_bounds__(64) void k_lm_window(const double *__restrict__ pm,
     }
     if (lane == 0) {
         O->S = (uint8_t)S; O->valid = 1; O->hdev = H;
+        {
+            LmSum q; q.hdev = H; q.S = (uint8_t)S; q.valid = 1; for (int i = 0; i < 6; ++i) q.pad[i] = 0;
+            *Q = q;
+        }
         O->pad[0] = (uint8_t)(L->iters > 255 ? 255 : L->iters);                       // diagnostics (QVZ_CB_DEBUG): iterations,
         const unsigned long long dt = (__builtin_readcyclecounter() - t_begin) >> 8;   // shader cycles / 256
         O->pad[1] = (uint8_t)(dt > 65535 ? 255 : dt >> 8);
@@ -760,6 +774,7 @@ struct CbWork {
     double *ptemp = nullptr;
     LmIn *lin = nullptr;
     LmDesign *hout = nullptr;                      // the design windows' results: mapped host memory the kernels write
+    LmSum *hsum = nullptr;                         // ... and their summaries (entropy, state count, computed or not), densely
     uint32_t *stop = nullptr;
     uint8_t *pin = nullptr;                        // pinned staging for everything else that crosses PCIe per column
     uint32_t *flag = nullptr;                      // mapped host word the device raises when a column's results are in host memory
@@ -770,6 +785,7 @@ struct CbWork {
         void *ptrs[] = {P, marg, qpmf[0], qpmf[1], xpmf, dist, zero_rows, ptemp, lin, stop};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (hout) (void)hipHostFree(hout);
+        if (hsum) (void)hipHostFree(hsum);
         if (pin) (void)hipHostFree(pin);
         if (flag) (void)hipHostFree(flag);
         *this = CbWork();
@@ -810,7 +826,8 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 
 static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static thread_local unsigned long long cb_stat[7];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns; [6] windows after a column's first
-static thread_local double cb_wait[4];   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
+static thread_local double cb_wait[6];   // [4], [5]: host time between a hand-over seen and the next column's first launch call, and in that column's launch calls
+   // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 // exact mode: |entropy - target| at or below this is re-decided by the host's libm (a one-bit miss of the device's log2 restatement
 // moves an entropy of at most ~6.2 bits by a few ulps of 8.9e-16; the band is a thousand times that and is met about once in 1e12 decisions)
 #define QVZ_EXACT_BAND 1e-12   /* QVZ_CB_LOG2=band=<x> overrides it (tests: a huge band makes the libm re-decide everything) */
@@ -962,7 +979,8 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
         QVZ_HIP_CHECK(hipMalloc(&W.dist, tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.zero_rows, tile * sizeof(double)));
         QVZ_HIP_CHECK(hipMalloc(&W.lin, A * sizeof(LmIn)));
-        QVZ_HIP_CHECK(hipHostMalloc(&W.hout, tile * sizeof(LmDesign), hipHostMallocMapped));
+        QVZ_HIP_CHECK(hipHostMalloc(&W.hout, 2 * tile * sizeof(LmDesign), hipHostMallocMapped));   // two halves, a column each in turn
+        QVZ_HIP_CHECK(hipHostMalloc(&W.hsum, 2 * tile * sizeof(LmSum), hipHostMallocMapped));
         QVZ_HIP_CHECK(hipMalloc(&W.stop, A * sizeof(uint32_t)));
         QVZ_HIP_CHECK(hipHostMalloc(&W.pin, tile * sizeof(double) + A * sizeof(LmIn) + 2 * (2 * tile + A * sizeof(double) + 4 * A) + A * sizeof(LmIn), hipHostMallocMapped));
         QVZ_HIP_CHECK(hipHostMalloc(&W.flag, 64, hipHostMallocMapped));
@@ -1001,12 +1019,16 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     uint8_t *hq2 = reinterpret_cast<uint8_t *>(hr2 + 2 * A);            // [2][2 * tile]
     uint8_t *hu2 = hq2 + 2 * 2 * tile;                                  // [2][4 * A]
     LmIn *hplan = reinterpret_cast<LmIn *>(hu2 + 2 * 4 * A);            // [A] exact mode: the device's plan of a column with its exact targets
-    LmDesign *hout = W.hout;
+    LmDesign *hout = W.hout;                                            // (the column loop below alternates between the area's two halves)
     uint8_t *pin_d = nullptr;                                           // the same areas as the device sees them
-    LmDesign *hout_d = nullptr;
+    LmDesign *hout_d = nullptr, *hout_d0 = nullptr;
+    LmSum *hsum_d = nullptr, *hsum_d0 = nullptr;
     uint32_t *flag_d = nullptr;
     QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&pin_d, W.pin, 0));
-    QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&hout_d, W.hout, 0));
+    QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&hout_d0, W.hout, 0));
+    hout_d = hout_d0;
+    QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&hsum_d0, W.hsum, 0));
+    hsum_d = hsum_d0;
     QVZ_HIP_CHECK(hipHostGetDevicePointer((void **)&flag_d, W.flag, 0));
     double *hx_d = reinterpret_cast<double *>(pin_d);
     LmIn *hin_d = reinterpret_cast<LmIn *>(hx_d + tile);
@@ -1042,9 +1064,9 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     };
     auto launch_window = [&](const double *d_rows, const LmIn *in, uint32_t nu, uint32_t win, LmRider rider = LmRider{nullptr, nullptr, nullptr, nullptr, 0, 0, 0}) -> uint32_t {
         const uint32_t extra = rider.rows ? (A * rider.nprev + 64 * nu - 1) / (64 * nu) : 0;     // rows of nu blocks x 64 threads for A * nprev sums
-        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, rider);
-        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, rider);
-        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, W.stop, guard, exact ? 1 : 0, rider);
+        if (mono) hipLaunchKernelGGL((k_lm_window<true, true>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, hsum_d, W.stop, guard, exact ? 1 : 0, rider);
+        else if (toep) hipLaunchKernelGGL((k_lm_window<true, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(true), st, d_rows, W.dist, in, hout_d, hsum_d, W.stop, guard, exact ? 1 : 0, rider);
+        else hipLaunchKernelGGL((k_lm_window<false, false>), dim3(nu, win + extra), dim3(64), LM_LDS_BYTES(false), st, d_rows, W.dist, in, hout_d, hsum_d, W.stop, guard, exact ? 1 : 0, rider);
         return flag_after();
     };
     LmDesign lo_d[A], hi_d[A];                     // chosen pair per context of the current column
@@ -1062,11 +1084,41 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
     for (int S = 1; S <= A; ++S) { memcpy(Z[S].q, hout[S - 1].q, A); memcpy(Z[S].recon, hout[S - 1].recon, A); }
     uint32_t window0 = 16;                         // first window of a column: the previous column's largest S + 3
 
-    uint32_t nprev = 0;
+    // What the host does between a column's hand-over and the next column's first launch is on the chain of 150 dependent
+    // columns (it was ~21 us of a column's ~116: struct copies of the chosen designs out of the results area, the codebook's
+    // bookkeeping, 86 list merges, a 10 KB table copy). So only what the next launch needs is done first - the walk over the
+    // window's entropies, the chosen tables and ratios into the mapped staging slot, the next column's context symbols - and
+    // the column's entries in the codebook are written (finish_column) once the next column's kernels are on their way. The
+    // results area has two halves in turn, so that a column's chosen designs stay where the kernels left them until then.
+    struct Pick { const uint8_t *q, *recon; uint32_t S; };
+    Pick pick[2 * A];                              // the chosen quantizer pair of every context of the column last decided
+    double ratio_s[A];
+    bool zero[A];
+    uint32_t nu_fin = 0;
+    auto finish_column = [&](uint32_t s) {          // store_cond_quantizers_indexed (codebook.c:152-157) and the context list of column s
+        const uint8_t *uni = hu2 + (size_t)(s & 1) * 4 * A;
+        cb->nctx[s] = (uint8_t)nu_fin;
+        memcpy(cb->ctx_sym + (size_t)s * A, uni, nu_fin);
+        for (uint32_t i = 0; i < nu_fin; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
+        for (uint32_t j = 0; j < nu_fin; ++j) {
+            store_design(cb, s, 2 * j, pick[2 * j].q, pick[2 * j].recon, pick[2 * j].S);
+            store_design(cb, s, 2 * j + 1, pick[2 * j + 1].q, pick[2 * j + 1].recon, pick[2 * j + 1].S);
+            cb->ratio[(size_t)s * A + j] = ratio_s[j];
+            cb->qratio[(size_t)s * A + j] = (uint8_t)(ratio_s[j] * 128.);
+            cb->live[(size_t)s * A + j] = zero[j] ? 0 : 1;
+        }
+    };
+    uint32_t nprev = 0, nu_next = 1;
+    double t_prev_seen = cb_now();
     int pq = 0;   // index of the qpmf buffer holding the previous column
     for (uint32_t s = 0; s < C; ++s) {
         uint32_t nu, win0 = 0, seq0;                                                // win0: width of a first window already run (s >= 1)
+        double t_launch = cb_now();
         uint8_t *uni = hu2 + (size_t)(s & 1) * 4 * A;
+        LmDesign *const hout = W.hout + (size_t)(s & 1) * tile;                     // this column's half of the results area
+        hout_d = hout_d0 + (size_t)(s & 1) * tile;
+        const LmSum *const hsum = W.hsum + (size_t)(s & 1) * tile;
+        hsum_d = hsum_d0 + (size_t)(s & 1) * tile;
         const double *d_rows;
         if (s == 0) {                                                               // codebook.c:392-411
             nu = 1;
@@ -1075,15 +1127,12 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             hipLaunchKernelGGL(k_cb_copy_f64, dim3(1), dim3(256), 0, st, (const double *)W.P, hx_d, (uint32_t)A);
             seq0 = flag_after();
         } else {                                                                    // codebook.c:419-438
-            const size_t b0 = ((size_t)(s - 1) * 2 * A) * A;
-            nu = cb->nstates[(size_t)(s - 1) * 2 * A];
-            memcpy(uni, cb->recon + b0, nu);
-            for (uint32_t j = 1; j < 2 * nprev; ++j)
-                nu = merge_lists(uni, nu, cb->recon + b0 + (size_t)j * A, cb->nstates[(size_t)(s - 1) * 2 * A + j], uni);
-            if (nu > A) return qvz_set_error(QVZ_E_DATA, "column %u: %u contexts exceed the alphabet", s, nu);
+            nu = nu_next;                                                           // (the context symbols are in `uni` already)
             // (k_ctx_ptemp of this column ran behind the previous column's window, while the host was busy: it needs nothing
             // from the host.) The propagation reads the previous column's tables and ratios (slot (s - 1) & 1) and this
             // column's context symbols straight from mapped host memory: a few hundred bytes per workgroup.
+            t_launch = cb_now();
+            if (cb_debug) cb_wait[4] += t_launch - t_prev_seen;
             hipLaunchKernelGGL(k_ctx_propagate, dim3(A), dim3(128), 0, st, s, nprev, nu, (const uint8_t *)(hu2_d + (size_t)(s & 1) * 4 * A),
                                (const uint8_t *)(hq2_d + (size_t)((s - 1) & 1) * 2 * tile), (const double *)(hr2_d + (size_t)((s - 1) & 1) * A),
                                W.ptemp, W.qpmf[pq ^ 1], W.stop);
@@ -1099,7 +1148,10 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                              : launch_window(d_rows, W.lin, nu, win0);
         }
         QVZ_HIP_CHECK(hipGetLastError());
+        if (cb_debug) cb_wait[5] += cb_now() - t_launch;
+        if (s > 0) finish_column(s - 1);                                            // while this column's kernels run
         { const int rc_ = await(seq0, 0); if (rc_) return rc_; }
+        const double t_seen = cb_now();
         if (cb_debug && win0) {                                                     // the first window's designs: how long, how many iterations
             uint32_t max_it = 0, max_cyc = 0, nvalid = 0, sum_it = 0, at_s = 0;
             for (uint32_t e = 0; e < nu * win0; ++e)
@@ -1111,12 +1163,8 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                 }
             cb_stat[0] += nvalid; cb_stat[1] += sum_it; cb_stat[2] += max_it; cb_stat[3] += max_cyc; cb_stat[4] += nu * win0; cb_stat[5] += at_s;
         }
-        cb->nctx[s] = (uint8_t)nu;
-        memcpy(cb->ctx_sym + (size_t)s * A, uni, nu);
-        for (uint32_t i = 0; i < nu; ++i) cb->ctx_idx[(size_t)s * A + uni[i]] = (uint8_t)i;
 
         // targets (libm) and the per-context plan
-        bool zero[A];
         double target[A];
         bool any_gpu = false;
         memset(hin, 0, A * sizeof(LmIn));
@@ -1142,6 +1190,8 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             }
         }
         cb_wait[2] += cb_now() - t_tg;
+        const LmDesign *lo_p[A], *hi_p[A];                                          // chosen pair per context: in the results area, or a copy (lo_d / hi_d)
+        bool fresh[A];                                                              // chosen by the window just replayed: still in the results area
         uint32_t win = window0, smax = 1, round = 0;
         while (any_gpu) {
             if (round == 0 && win0) {
@@ -1159,9 +1209,11 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             any_gpu = false;
             for (uint32_t j = 0; j < nu; ++j) {
                 const LmDesign *d = hout + (size_t)j * win;
+                const LmSum *q = hsum + (size_t)j * win;                            // the same designs' summaries: what the walk reads
+                fresh[j] = false;
                 if (hin[j].mode == 2) {                                             // target 0: one state, lo == hi
-                    if (!d[0].valid) return qvz_set_error(QVZ_E_HIP, "column %u context %u: design missing", s, j);
-                    lo_d[j] = d[0]; hi_d[j] = d[0];
+                    if (!q[0].valid) return qvz_set_error(QVZ_E_HIP, "column %u context %u: design missing", s, j);
+                    lo_p[j] = &d[0]; hi_p[j] = &d[0]; fresh[j] = true;
                     hin[j].mode = 0;
                     continue;
                 }
@@ -1172,9 +1224,9 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                 bool done = false;
                 uint32_t w = 1;
                 for (; w < win && (uint32_t)hin[j].startS + w <= A; ++w) {
-                    if (!d[w].valid || !d[w - 1].valid)
+                    if (!q[w].valid || !q[w - 1].valid)
                         return qvz_set_error(QVZ_E_HIP, "column %u context %u: design %u missing", s, j, hin[j].startS + w);
-                    const double diff = d[w].hdev - target[j];
+                    const double diff = q[w].hdev - target[j];
                     bool below;
                     if (exact && fabs(diff) <= guard) {
                         // The run-time check of the device's log2 is a sample: it catches another libm, it cannot prove equality
@@ -1184,72 +1236,103 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                         g_exact_rechecked += 1;
                         const double t_libm = mode == QVZ_MODE_RATIO && s > 0 ? entropy_libm(hx + (size_t)j * A) * opt_ratio : target[j];
                         const double h_libm = entropy_libm(d[w].o);
-                        if (memcmp(&t_libm, &target[j], sizeof(double)) != 0 || memcmp(&h_libm, &d[w].hdev, sizeof(double)) != 0) g_exact_mismatch += 1;
+                        if (memcmp(&t_libm, &target[j], sizeof(double)) != 0 || memcmp(&h_libm, &q[w].hdev, sizeof(double)) != 0) g_exact_mismatch += 1;
                         below = h_libm < t_libm;
                     }
-                    else if (exact) below = d[w].hdev < target[j];                  // hdev is get_entropy(d[w].o): codebook.c:249-258 as it stands
+                    else if (exact) below = q[w].hdev < target[j];                  // hdev is get_entropy(d[w].o): codebook.c:249-258 as it stands
                     else if (fabs(diff) <= guard) { g_deferred += 1; below = entropy_libm(d[w].o) < target[j]; }
                     else below = diff < 0.0;
-                    if (!below || d[w].S >= A) { done = true; break; }
+                    if (!below || q[w].S >= A) { done = true; break; }
                 }
                 if (done) {
-                    lo_d[j] = d[w - 1]; hi_d[j] = d[w];
-                    if (d[w].S > smax) smax = d[w].S;
+                    lo_p[j] = &d[w - 1]; hi_p[j] = &d[w]; fresh[j] = true;
+                    if (q[w].S > smax) smax = q[w].S;
                 } else {                                                            // keep walking from the last design
                     hin[j].mode = 1;
                     hin[j].startS = (uint8_t)(hin[j].startS + w - 1);
                     any_gpu = true;
                 }
             }
-            if (any_gpu) win = win * 2 > A ? A : win * 2;
+            if (any_gpu) {
+                win = win * 2 > A ? A : win * 2;
+                for (uint32_t j = 0; j < nu; ++j)                                   // the next window overwrites the results area: what this one decided is copied out
+                    if (fresh[j]) { lo_d[j] = *lo_p[j]; hi_d[j] = *hi_p[j]; lo_p[j] = &lo_d[j]; hi_p[j] = &hi_d[j]; }
+            }
         }
         {
             const uint32_t margin = 3u;
             window0 = smax + margin < 8 ? 8 : (smax + margin > A ? A : smax + margin);
         }
 
-        // ratios from libm entropies, store (optimize_for_entropy :263-268, store_cond_quantizers_indexed :152-157)
+        // ratios from the entropies (optimize_for_entropy :263-268), the chosen pairs
         const double t_rt = cb_now();
         for (uint32_t j = 0; j < nu; ++j) {
             double ratio;
             if (zero[j]) {
                 // every design of a zero pmf has entropy 0: replay the search loop on the host
                 if (target[j] == 0.0) {
-                    store_design(cb, s, 2 * j, Z[1].q, Z[1].recon, 1);
-                    store_design(cb, s, 2 * j + 1, Z[1].q, Z[1].recon, 1);
+                    pick[2 * j] = Pick{Z[1].q, Z[1].recon, 1};
+                    pick[2 * j + 1] = Pick{Z[1].q, Z[1].recon, 1};
                     ratio = 1.0;
                 } else {
                     uint32_t states = 1;
                     do { states += 1; } while (0.0 < target[j] && states < A);
-                    store_design(cb, s, 2 * j, Z[states - 1].q, Z[states - 1].recon, states - 1);
-                    store_design(cb, s, 2 * j + 1, Z[states].q, Z[states].recon, states);
+                    pick[2 * j] = Pick{Z[states - 1].q, Z[states - 1].recon, states - 1};
+                    pick[2 * j + 1] = Pick{Z[states].q, Z[states].recon, states};
                     if (0.0 < target[j]) ratio = 0.0;
                     else ratio = 1.0;                                               // lo_entropy (0) >= target
                 }
             } else {
-                store_design(cb, s, 2 * j, lo_d[j].q, lo_d[j].recon, lo_d[j].S);
-                store_design(cb, s, 2 * j + 1, hi_d[j].q, hi_d[j].recon, hi_d[j].S);
+                pick[2 * j] = Pick{lo_p[j]->q, lo_p[j]->recon, lo_p[j]->S};
+                pick[2 * j + 1] = Pick{hi_p[j]->q, hi_p[j]->recon, hi_p[j]->S};
                 if (target[j] == 0.0) {
                     ratio = 1.0;
                 } else {
-                    const double lo_entropy = exact ? lo_d[j].hdev : entropy_libm(lo_d[j].o), hi_entropy = exact ? hi_d[j].hdev : entropy_libm(hi_d[j].o);
+                    const double lo_entropy = exact ? lo_p[j]->hdev : entropy_libm(lo_p[j]->o), hi_entropy = exact ? hi_p[j]->hdev : entropy_libm(hi_p[j]->o);
                     if (hi_entropy < target[j]) ratio = 0.0;
                     else if (lo_entropy >= target[j] || hi_entropy == lo_entropy) ratio = 1.0;
                     else ratio = (target[j] - hi_entropy) / (lo_entropy - hi_entropy);
                 }
             }
-            cb->ratio[(size_t)s * A + j] = ratio;
-            cb->qratio[(size_t)s * A + j] = (uint8_t)(ratio * 128.);
-            cb->live[(size_t)s * A + j] = zero[j] ? 0 : 1;
+            ratio_s[j] = ratio;
+        }
+        nu_fin = nu;
+        // hand this column's tables and ratios to the next column's propagation, and make that column's context symbols:
+        // the union of the chosen quantizers' output alphabets (alphabet_union over all of them, codebook.c:419-438)
+        uint8_t *hq = hq2 + (size_t)(s & 1) * 2 * tile;   // slot s & 1: its last reader (the propagation of column s - 1) finished before that column's hand-over
+        double *hr = hr2 + (size_t)(s & 1) * A;
+        for (uint32_t t = 0; t < 2 * nu; ++t) memcpy(hq + (size_t)t * A, pick[t].q, A);
+        for (uint32_t j = 0; j < A; ++j) hr[j] = j < nu ? ratio_s[j] : 0.0;
+        if (s + 1 < C) {
+            uint8_t *nxt = hu2 + (size_t)((s + 1) & 1) * 4 * A;
+            // Merging sorted lists without duplicates one after the other (merge_lists, pmf.c:312-357) gives the sorted set of
+            // everything in them: a mark per symbol. A list that is not strictly increasing (bounds an earlier walk left in
+            // disorder can produce one) takes the merges themselves.
+            uint8_t mark[A];
+            memset(mark, 0, A);
+            bool sorted = true;
+            for (uint32_t t = 0; t < 2 * nu && sorted; ++t)
+                for (uint32_t i = 0; i < pick[t].S; ++i) {
+                    const uint8_t r = pick[t].recon[i];
+                    if (r >= A || (i && r <= pick[t].recon[i - 1])) { sorted = false; break; }
+                    mark[r] = 1;
+                }
+            uint32_t nn = 0;
+            if (sorted) {
+                for (uint32_t v = 0; v < A; ++v) if (mark[v]) nxt[nn++] = (uint8_t)v;
+            } else {
+                nn = pick[0].S;
+                memcpy(nxt, pick[0].recon, nn);
+                for (uint32_t t = 1; t < 2 * nu; ++t) nn = merge_lists(nxt, nn, pick[t].recon, pick[t].S, nxt);
+            }
+            if (nn > A) return qvz_set_error(QVZ_E_DATA, "column %u: %u contexts exceed the alphabet", s + 1, nn);
+            nu_next = nn;
         }
         cb_wait[3] += cb_now() - t_rt;
-        // hand this column's tables and ratios to the next column's propagation
-        uint8_t *hq = hq2 + (size_t)(s & 1) * 2 * tile;   // slot s & 1: its last reader (the stage-in of column s - 1) finished before that column's hand-over
-        double *hr = hr2 + (size_t)(s & 1) * A;
-        memcpy(hq, cb->q + (size_t)s * 2 * tile, 2 * tile);
-        for (uint32_t j = 0; j < A; ++j) hr[j] = j < nu ? cb->ratio[(size_t)s * A + j] : 0.0;
-        nprev = nu;                                                              // (k_cb_stage_in of the next column reads hq / hr)
+        nprev = nu;
+        t_prev_seen = t_seen;
     }
+    finish_column(C - 1);
     return QVZ_OK;
 }
 
@@ -1275,7 +1358,7 @@ static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const dou
     memset(out->ctx_idx, QVZ_NOT_FOUND, (size_t)C * A);
     CbWork *W = cbw_acquire();
     g_cb_active.fetch_add(1);
-    cb_wait[0] = cb_wait[1] = cb_wait[2] = cb_wait[3] = 0.0;
+    cb_wait[0] = cb_wait[1] = cb_wait[2] = cb_wait[3] = cb_wait[4] = cb_wait[5] = 0.0;
     for (auto &v : cb_stat) v = 0;
     const double t_gen = cb_now();
     const int rc = generate(d_cnt, wide, C, h_dist, mode, ratio, guard, out, (hipStream_t)stream, *W);
@@ -1283,8 +1366,8 @@ static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const dou
     g_cb_active.fetch_sub(1);
     cbw_give_back(W);
     if (getenv("QVZ_CB_DEBUG"))                                  // development knob
-        fprintf(stderr, "qvz_hip_generate_codebook: %.1f ms, of which waiting for the context propagation %.1f ms, for the design windows %.1f ms; host: targets %.1f ms, ratios and storing %.1f ms\n",
-                (cb_now() - t_gen) * 1e3, cb_wait[0] * 1e3, cb_wait[1] * 1e3, cb_wait[2] * 1e3, cb_wait[3] * 1e3);
+        fprintf(stderr, "qvz_hip_generate_codebook: %.1f ms, of which waiting for the context propagation %.1f ms, for the design windows %.1f ms; host: targets %.1f ms, ratios and storing %.1f ms, hand-over seen to next launch call %.2f ms, launch calls %.2f ms\n",
+                (cb_now() - t_gen) * 1e3, cb_wait[0] * 1e3, cb_wait[1] * 1e3, cb_wait[2] * 1e3, cb_wait[3] * 1e3, cb_wait[4] * 1e3, cb_wait[5] * 1e3);
 #ifdef QVZ_PROFILE
     {
         unsigned long long z[8] = {0};
