@@ -147,6 +147,29 @@ __device__ __forceinline__ void unpack_records4(const uint4 &a, const uint4 &b, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = make_double2(cd[i] * rn[i], qd[i] * rn[i]);
 }
+// two records (one 16-byte piece): the third loader's share of a block
+template <int NEWTON>
+__device__ __forceinline__ void unpack_records2(const uint4 &a, Record *out) {
+    const uint32_t lo[2] = {a.x, a.z}, hi[2] = {a.y, a.w};
+    double nd[2], rn[2], e[2], cd[2], qd[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) nd[i] = (double)(hi[i] & 0xFFFFFC00u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rn[i] = __builtin_amdgcn_rcp(nd[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cd[i] = (double)(lo[i] & 0x1FFFFFu);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) qd[i] = (double)(__builtin_amdgcn_alignbit(hi[i], lo[i], 21) & 0x1FFFFFu);
+#pragma unroll
+    for (int k = 0; k < NEWTON; ++k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) e[i] = __builtin_fma(-nd[i], rn[i], 1.0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rn[i] = __builtin_fma(e[i], rn[i], rn[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) out[i] = make_double2(cd[i] * rn[i], qd[i] * rn[i]);
+}
 // worst |1 - n 2^10 rn| over n = 1 .. nmax for v_rcp_f64 + NEWTON steps (the residual is exact in an fma): the relative error of rn
 template <int NEWTON>
 __global__ __launch_bounds__(256) void k_rcp_accuracy(unsigned long long *worst, uint32_t nmax) {
@@ -928,9 +951,6 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
 // packed records, 16 (58 KB: half as many barriers; a coder workgroup then leaves room for two model workgroups, which is what the
 // LDS padding of the 8-symbol kernel arranges on purpose)
 #define CR_B NB
-#ifndef QVZ_LOADER_STAGES
-#define QVZ_LOADER_STAGES 3
-#endif
 #define CR_RARE 0x80000000u   // ebits entry of a symbol with more than 16 bits: CR_RARE | pending run (the word itself is still in `words`)
 // REC8 (round 4): the records come packed (PRec, rec8_index) and a FIFTH wave joins: waves 0 and 4 - which a round-robin
 // placement of the workgroup's waves puts on one SIMD - are two loaders that each take half of every block (symbols 0-3 /
@@ -938,7 +958,7 @@ __global__ __launch_bounds__(64) void k_coder_spin_us(uint32_t us) {   // see th
 // in the ring; waves 1, 2, 3 are interval, bits, bytes as before. The loaders are throughput work (eight independent
 // records per block and lane); the three chain waves keep a SIMD each.
 template <int NB, int NEWTON>
-__global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
+__global__ __launch_bounds__(384) void k_code_records(const Record *__restrict__ rec, uint32_t Cx, const uint64_t *__restrict__ first,
                                                       uint32_t shards, uint64_t seg_lo, uint32_t seg_reads, int is_first, int is_last,
                                                       CoderState *__restrict__ cs, uint8_t *__restrict__ out, uint64_t cap,
                                                       uint64_t *__restrict__ sizes, int32_t *__restrict__ status, int high_prio) {
@@ -950,8 +970,11 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
     __shared__ uint32_t final_l[64], final_s3[64];
     __shared__ uint4 oring[64 * 5];                              // the bytes wave's output ring: 16 words per lane, 80-byte stride
     const uint32_t hw_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // role: 0 interval, 1 bits, 2 bytes, 3 loader (REC8: of symbols 0-3), 4 (REC8 only) loader of symbols 4-7
-    const uint32_t wave = hw_wave == 0 ? 3u : hw_wave == 4 ? 4u : hw_wave - 1;
+    // role: 0 interval, 1 bits, 2 bytes, 3 loader of symbols 0-3 of every sub-block, 4 loader of symbols 4-7, 5 the third loader.
+    // Six waves on four SIMDs: the placement goes round (hardware waves 0 and 4 share a SIMD, 1 and 5 another), so the two big
+    // loaders are waves 0 and 4 as before, the bytes wave - the lightest of the chain's three - is wave 1 and gets the third
+    // loader (wave 5) for company, and bits and interval keep a SIMD each (waves 2 and 3).
+    const uint32_t wave = hw_wave == 0 ? 3u : hw_wave == 4 ? 4u : hw_wave == 5 ? 5u : hw_wave == 1 ? 2u : hw_wave == 2 ? 1u : 0u;
     const uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < shards;
     const uint32_t Cp = (Cx + 7) & ~7u;                          // records per read (rec_index)
@@ -987,6 +1010,7 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
                                                                     atomicAdd(&g_cr_prof[9 + wave], cr_drain); \
                                                                     if (wave == 0) atomicAdd(&g_cr_prof[8], (unsigned long long)nblk); } \
                          if (lane == 0 && (blockIdx.x & 15) == 3 && wave == 4) { atomicAdd(&g_cr_prof[13], cr_busy); atomicAdd(&g_cr_prof[14], cr_wait); } \
+                         if (lane == 0 && (blockIdx.x & 15) == 3 && wave == 5) { atomicAdd(&g_cr_prof[15], cr_busy); } \
                          if (lane == 0 && (blockIdx.x & 15) == 3) { uint32_t hwid_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_)); g_cr_simd[hw_wave] = (hwid_ >> 4) & 3; } } while (0)
 #else
 #define CR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -1000,6 +1024,69 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
     // 110 ms) and beside the model kernel (223 against 139): a hand-over costs a write's and a read's LDS latency plus the
     // poll's sleep where the barrier costs tens of cycles, and the polling waves take LDS slots from the one that works.)
 
+    // The two loaders' SIMD is the busiest of the workgroup (the second loader was busy 2175 of a block's 2327 cycles, the interval
+    // wave 1823: profiles/r05_coder_cycles.txt), and what they do is wave-wide instructions: a block is eight wave-loads of 64
+    // sixteen-byte pieces, four per loader. The third loader takes ONE of the second loader's four - the piece of streams
+    // 32 .. 63 in the second half of a block's second sub-block - on the bytes wave's SIMD.
+    if (wave == 5) {
+        // ------------------------------------ the third loader ------------------------------------
+        static_assert(NB == 16, "the third loader's share is the odd sub-block of a 16-symbol block");
+        const uint32_t sB = 32 + (lane >> 1), hp = lane & 1;
+        const uint64_t nunit = (uint64_t)seg_reads * Cp / 16;
+        const uint64_t nblk8 = (uint64_t)seg_reads * Cp / 8;
+        const uint4 *p0 = reinterpret_cast<const uint4 *>(reinterpret_cast<const PRec *>(rec) + ((uint64_t)blockIdx.x * nunit * 64) * 16);
+        const uint4 *pB = p0 + sB * 8 + hp;
+        const uint64_t TB = __shfl(T, (int)sB, 64);
+        const uint64_t nfull = Tmin / 8;
+        const uint32_t per_row = Cp >> 3;                        // sub-blocks per read
+        uint64_t l_blk = 1;                                      // the sub-block the next load asks for: 1, 3, 5, ...
+        uint32_t l_row = 0, l_m = 1;
+        while (l_m >= per_row) { l_m -= per_row; ++l_row; }
+        if (l_blk >= nblk8) { l_blk = 0; l_row = 0; l_m = 0; }   // (an area of one sub-block: its odd sub-blocks are padding, any address inside it will do)
+        auto load1 = [&]() -> uint4 {
+            const uint64_t at = (((uint64_t)(l_row >> 2) * (Cp >> 2) + 2 * l_m + 1) * 64 * 8) + (l_row & 3) * 2;
+            const uint4 v = pB[at];
+            if (l_blk + 2 < nblk8) {                             // (past the area's last odd sub-block the same one is loaded again)
+                l_blk += 2;
+                l_m += 2;
+                while (l_m >= per_row) { l_m -= per_row; ++l_row; }
+            }
+            return v;
+        };
+        auto park1 = [&](uint64_t t, const uint4 &d) {           // block t's piece -> slot t & 1, then the block's barrier
+            const uint64_t sb = 2 * t + 1;
+            const uint32_t slot = (uint32_t)(t & 1), sym = 12 + 2 * hp, tw = hp << 3;
+            Record r2[2];
+            unpack_records2<NEWTON>(d, r2);
+            if (sb < nfull) {
+                ring[slot][sym][sB ^ tw] = r2[0];
+                ring[slot][sym + 1][sB ^ tw] = r2[1];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint64_t ts = sb * 8 + 4 + 2 * hp + i;
+                    ring[slot][sym + i][sB ^ tw] = make_double2(ts >= TB ? 0.0 : r2[i].x, ts >= TB ? 0.0 : r2[i].y);
+                }
+            }
+            CR_BARRIER();
+        };
+        uint4 q0 = load1(), q1 = load1(), q2 = load1(), q3 = load1();   // four blocks' pieces on their way
+        for (uint64_t t = 0; t < nblk; t += 4) {
+            park1(t, q0); q0 = load1();
+            if (t + 1 >= nblk) break;
+            park1(t + 1, q1); q1 = load1();
+            if (t + 2 >= nblk) break;
+            park1(t + 2, q2); q2 = load1();
+            if (t + 3 >= nblk) break;
+            park1(t + 3, q3); q3 = load1();
+        }
+        CR_BARRIER();                                            // barriers nblk .. nblk + 2: the other waves run behind
+        CR_BARRIER();
+        CR_BARRIER();
+        if (is_last) CR_BARRIER();
+        CR_REPORT();
+        return;
+    }
     if (wave >= 3) {
         // ------------------------------------ the two loaders of packed records ------------------------------------
         constexpr int SUB = NB / 8;                              // sub-blocks of 8 symbols per block
@@ -1019,8 +1106,8 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
         const uint64_t nfull = Tmin / 8;                         // sub-blocks that are whole in every lane: no padding test
         const uint64_t nsub = nblk * SUB;                        // sub-blocks to park (those past the last symbol as no-op records)
         // sub-block sb of a lane = columns 8m .. 8m+7 of read `row` (sb = row * Cp/8 + m): this wave's four are the quarter
-        // [row & 3] of unit (row / 4, 2m + half): 32 bytes. A register stage holds LD_B sub-blocks' pieces; three stages in
-        // rotation keep two of them in flight. Past the last sub-block of the area the last one is loaded again (unconditional
+        // [row & 3] of unit (row / 4, 2m + half): 32 bytes. A register stage holds LD_B sub-blocks' pieces; five stages in
+        // rotation keep four of them in flight. Past the last sub-block of the area the last one is loaded again (unconditional
         // loads keep vmcnt countable).
         constexpr int LD_B = 2;
         uint64_t l_blk = 0;
@@ -1030,7 +1117,10 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
             for (int k = 0; k < LD_B; ++k) {
                 const uint64_t at = (((uint64_t)(l_row >> 2) * (Cp >> 2) + 2 * l_m + half) * 64 * 8) + (l_row & 3) * 2;   // in uint4: a unit is 8, the 64 streams' units lie side by side
                 d[k * 2] = pA[at];
-                d[k * 2 + 1] = pB[at];
+                // (a block's last piece of streams 32 .. 63 is the third loader's: the second loader asks for one line in all its
+                // lanes instead - a load all the same, so that the loads in flight stay countable, but one line of work for the memory path)
+                const uint4 *const srcB = (half == 1 && k == LD_B - 1) ? p0 : pB + at;
+                d[k * 2 + 1] = *srcB;
                 if (l_blk + 1 < nblk8) {
                     ++l_blk;
                     if (++l_m == (Cp >> 3)) { l_m = 0; ++l_row; }
@@ -1039,9 +1129,25 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
         };
         auto park = [&](uint64_t sb, const uint4 *d) {           // this wave's half of sub-block sb -> slot (block & 1); the block's barrier behind its last sub-block
             const uint32_t slot = (uint32_t)((sb / SUB) & 1), at = (uint32_t)(sb % SUB) * 8 + half * 4;
+            const uint32_t sym = at + 2 * hp, tw = hp << 3;      // (at is a multiple of 4: bit 1 of the symbol number is hp)
+            if (half == 1 && sb % SUB == SUB - 1) {              // the second loader's short piece: stream sA only
+                Record r2[2];
+                unpack_records2<NEWTON>(d[0], r2);
+                if (sb < nfull) {
+                    ring[slot][sym][sA ^ tw] = r2[0];
+                    ring[slot][sym + 1][sA ^ tw] = r2[1];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const uint64_t t = sb * 8 + half * 4 + 2 * hp + i;
+                        ring[slot][sym + i][sA ^ tw] = make_double2(t >= TA ? 0.0 : r2[i].x, t >= TA ? 0.0 : r2[i].y);
+                    }
+                }
+                CR_BARRIER();
+                return;
+            }
             Record r4[4];                                        // records 2 hp, 2 hp + 1 of the piece of stream sA, then of stream sB
             unpack_records4<NEWTON>(d[0], d[1], r4);
-            const uint32_t sym = at + 2 * hp, tw = hp << 3;      // (at is a multiple of 4: bit 1 of the symbol number is hp)
             if (sb < nfull) {
                 ring[slot][sym][sA ^ tw] = r4[0];
                 ring[slot][sym + 1][sA ^ tw] = r4[1];
@@ -1066,7 +1172,8 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
             }
             return (stg + 1) * LD_B < nsub;
         };
-#if QVZ_LOADER_STAGES == 5
+        // five register stages in rotation: four (eight sub-blocks = four blocks) on their way while one is unpacked; with three
+        // stages the coder kernels took 105.5-106.2 ms against 104.7 on the same box (round 5)
         uint4 s0[LD_B * 2], s1[LD_B * 2], s2[LD_B * 2], s3[LD_B * 2], s4[LD_B * 2];
         load_stage(s0); load_stage(s1); load_stage(s2); load_stage(s3);
         for (uint64_t t = 0; t * LD_B < nsub; t += 5) {
@@ -1081,19 +1188,6 @@ __global__ __launch_bounds__(320) void k_code_records(const Record *__restrict__
             load_stage(s3);
             if (!park_stage(t + 4, s4)) break;
         }
-#else
-        uint4 s0[LD_B * 2], s1[LD_B * 2], s2[LD_B * 2];
-        load_stage(s0);
-        load_stage(s1);
-        for (uint64_t t = 0; t * LD_B < nsub; t += 3) {
-            load_stage(s2);
-            if (!park_stage(t, s0)) break;
-            load_stage(s0);
-            if (!park_stage(t + 1, s1)) break;
-            load_stage(s1);
-            if (!park_stage(t + 2, s2)) break;
-        }
-#endif
         CR_BARRIER();                                            // barriers nblk .. nblk + 2: the other waves run behind
         CR_BARRIER();
         CR_BARRIER();
@@ -1954,8 +2048,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         if (overlap) TRY(hipStreamWaitEvent(s_coder, e[1], 0));
         TRY(hipEventRecord(e[2], s_coder));
 #define CR_ARGS (const Record *)buf, Cx, d_first, shards, seg_lo, seg_len, is_first, is_last, d_cs, d_out, cap_per_shard, d_sizes, d_status, coder_prio
-        if (one_step) hipLaunchKernelGGL((k_code_records<16, 1>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
-        else hipLaunchKernelGGL((k_code_records<16, 2>), dim3((shards + 63) / 64), dim3(320), cr_pad, s_coder, CR_ARGS);
+        if (one_step) hipLaunchKernelGGL((k_code_records<16, 1>), dim3((shards + 63) / 64), dim3(384), cr_pad, s_coder, CR_ARGS);
+        else hipLaunchKernelGGL((k_code_records<16, 2>), dim3((shards + 63) / 64), dim3(384), cr_pad, s_coder, CR_ARGS);
 #undef CR_ARGS
         TRY(hipEventRecord(e[3], s_coder));
     }
@@ -2025,8 +2119,8 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
         {
             uint32_t simd[8] = {0};
             (void)hipMemcpyFromSymbol(simd, HIP_SYMBOL(g_cr_simd), sizeof(simd));
-            fprintf(stderr, "  second loader %.0f/%.0f; SIMD of the workgroup's waves 0..4 (loader, interval, bits, bytes, loader): %u %u %u %u %u\n", cr[13] / nb, cr[14] / nb,
-                    simd[0], simd[1], simd[2], simd[3], simd[4]);
+            fprintf(stderr, "  second loader %.0f/%.0f, third loader busy %.0f; SIMD of the workgroup's waves 0..5 (loader, bytes, bits, interval, second loader, third loader): %u %u %u %u %u %u\n", cr[13] / nb, cr[14] / nb, cr[15] / nb,
+                    simd[0], simd[1], simd[2], simd[3], simd[4], simd[5]);
         }
         fprintf(stderr, "k_model_ranks cycles per wave and chunk: lookup %.0f  ranks %.0f  update+record %.0f  barrier1 %.0f  park+barrier2 %.0f  drain %.0f  (%.3g wave-chunks)\n",
                 z[0] / ch, z[1] / ch, z[2] / ch, z[3] / ch, z[4] / ch, z[5] / ch, ch);

@@ -7,7 +7,7 @@ one() { # dir label env...
   ( cd $dir && env "$@" timeout -k 10 300 python3 bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-extras 2>> $out/err.txt ) | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); p=d['step_phase_ms']
-print('$label', d['ms_per_step'], 'codebook', p['codebook'], 'coder', p['coder'][:3])"
+print('$label', d['ms_per_step'], 'codebook', p['codebook'][:3], 'coder', p['coder'][:3], 'model', p['coder_model_kernels'][:2], 'interval', p['coder_interval_kernels'][:2])"
 }
 for r in $(seq $rounds); do
   one $root/ab_base base A=1
