@@ -175,7 +175,8 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
     if (idx < nu) {
         const uint32_t sym = sym_of_idx;
         double acc = 0.0;
-        for (uint32_t j = 0; j < nprev; ++j) {
+#pragma unroll 8
+        for (uint32_t j = 0; j < nprev; ++j) {                   // (eight terms' operands asked of LDS at a time; added in j order)
             double p_q_xq = 0.0;
             const double rj = sr[j];
             if (slo[j] == sym) p_q_xq += rj;                     // q_lo->ratio
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(128) void k_ctx_propagate(uint32_t s, uint32_t npre
     // renormalize_pmf of the row (pmf.c:235-254): sequential total, true division when total > 0
     if (idx < nu) {
         double total = 0;
+#pragma unroll 8
         for (uint32_t i = 0; i < nu; ++i) total += raw[i];
         const double v = raw[idx];
         qpmf[k * A + idx] = total > 0 ? v / total : v;
