@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_marginals(const double *__restrict__ P,
 }
 
 // what the Lloyd-Max window kernel is told per context (k_lm_window)
+#define LM_JUMP_BAND 1e-9   // how far below its target a row's entropy must lie for its walk to be known in advance (k_ctx_xpmf)
 struct LmIn {
     double target;
     uint8_t mode;      // 0 skip, 1 window [startS, startS + W), 2 the single design startS
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(128) void k_ctx_xpmf(const double *__restrict__ P, 
         LmIn I;
         I.target = target0 ? 0.0 : ratio_mode ? h * opt_ratio : opt_ratio;
         I.mode = zero ? 0 : target0 ? 2 : 1;
-        I.startS = 1;
+        // A row whose own entropy is below the target: no quantizer's output has more (the output is a function of the symbol,
+        // H(Q(X)) <= H(X); the sums differ by rounding, ~1e-14), so every step of the walk (codebook.c:256) says "below" and it
+        // ends at the alphabet's size with the designs A - 1 and A - the only two of the row's A that are made.
+        I.startS = I.mode == 1 && h < I.target - LM_JUMP_BAND ? A - 1 : 1;
         for (int i = 0; i < 6; ++i) I.pad[i] = 0;
         lin[idx] = I;
         if (exact && lin_host) lin_host[idx] = I;                  // mapped host memory: the host's copy of the plan and the exact target
@@ -827,7 +831,7 @@ static void store_design(qvz_codebook_t *cb, uint32_t s, uint32_t qi, const uint
 }
 
 static double cb_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-static thread_local unsigned long long cb_stat[7];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns; [6] windows after a column's first
+static thread_local unsigned long long cb_stat[8];   // QVZ_CB_DEBUG: designs run, their iterations, per-column maxima summed over columns; [6] windows after a column's first; [7] walks known in advance
 static thread_local double cb_wait[6];   // [4], [5]: host time between a hand-over seen and the next column's first launch call, and in that column's launch calls
    // seconds spent waiting for the context propagation / the design windows (QVZ_CB_DEBUG)
 // exact mode: |entropy - target| at or below this is re-decided by the host's libm (a one-bit miss of the device's log2 restatement
@@ -1183,15 +1187,18 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             const double *pj = hx + (size_t)j * A;
             zero[j] = true;
             for (int i = 0; i < A; ++i) if (pj[i] != 0.0) { zero[j] = false; break; }
-            target[j] = mode == QVZ_MODE_RATIO ? entropy_libm(pj) * opt_ratio : opt_ratio;   // codebook.c:444-447
+            const double hrow = zero[j] ? 0.0 : entropy_libm(pj);
+            target[j] = mode == QVZ_MODE_RATIO ? hrow * opt_ratio : opt_ratio;     // codebook.c:444-447
             if (!zero[j]) {
                 hin[j].target = target[j];
                 hin[j].mode = target[j] == 0.0 ? 2 : 1;                            // :236-242 vs the search
-                hin[j].startS = 1;
+                hin[j].startS = hin[j].mode == 1 && hrow < target[j] - LM_JUMP_BAND ? A - 1 : 1;   // as k_ctx_xpmf plans it
                 any_gpu = true;
             }
         }
         cb_wait[2] += cb_now() - t_tg;
+        bool jumped[A];                                                             // the plan starts at A - 1: the row's entropy is below its target
+        for (uint32_t j = 0; j < nu; ++j) { jumped[j] = hin[j].mode == 1 && hin[j].startS == A - 1; cb_stat[7] += jumped[j] ? 1 : 0; }
         const LmDesign *lo_p[A], *hi_p[A];                                          // chosen pair per context: in the results area, or a copy (lo_d / hi_d)
         bool fresh[A];                                                              // chosen by the window just replayed: still in the results area
         uint32_t win = window0, smax = 1, round = 0;
@@ -1248,7 +1255,7 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
                 }
                 if (done) {
                     lo_p[j] = &d[w - 1]; hi_p[j] = &d[w]; fresh[j] = true;
-                    if (q[w].S > smax) smax = q[w].S;
+                    if (q[w].S > smax && !jumped[j]) smax = q[w].S;                // (a walk known in advance needs two designs, not a window up to A)
                 } else {                                                            // keep walking from the last design
                     hin[j].mode = 1;
                     hin[j].startS = (uint8_t)(hin[j].startS + w - 1);
@@ -1262,6 +1269,8 @@ static int generate(const void *d_cnt, bool wide, uint32_t C, const double *h_di
             }
         }
         {
+            // (a wider margin, or the largest of the last few columns instead of the last one's, saves some of the second windows
+            // that -r targets need in a third of the columns and costs as much in wider first windows: HISTORY.md, round 5)
             const uint32_t margin = 3u;
             window0 = smax + margin < 8 ? 8 : (smax + margin > A ? A : smax + margin);
         }
@@ -1382,7 +1391,7 @@ static int generate_codebook(const void *d_cnt, bool wide, uint32_t C, const dou
     if (getenv("QVZ_CB_DEBUG") && C > 1)
         fprintf(stderr, "  first windows: %llu blocks, %llu designs completed, %.1f iterations on average; per column the longest design: %.1f iterations at most, %.0f shader cycles (S = %.1f on average)\n",
                 cb_stat[4], cb_stat[0], cb_stat[0] ? (double)cb_stat[1] / cb_stat[0] : 0.0, (double)cb_stat[2] / (C - 1), (double)cb_stat[3] / (C - 1), (double)cb_stat[5] / (C - 1));
-    if (getenv("QVZ_CB_DEBUG")) fprintf(stderr, "  windows after a column's first: %llu over %u columns\n", cb_stat[6], C);
+    if (getenv("QVZ_CB_DEBUG")) fprintf(stderr, "  windows after a column's first: %llu over %u columns; walks known in advance (row entropy below the target): %llu contexts\n", cb_stat[6], C, cb_stat[7]);
     return rc;
 }
 

@@ -110,6 +110,29 @@ def test_device_entropies_decide_like_the_hosts_libm(K, name, monkeypatch):
         assert_same_codebook(c_, a)
 
 
+@pytest.mark.parametrize("name,how", [("r35_high_rate", ""), ("r35_high_rate", "host"), ("cfg1_c3_r10_M", ""), ("cfg1_c3_r10_M", "host")])
+def test_walks_known_in_advance_give_the_oracles_codebook(K, name, how, monkeypatch, capfd):
+    """A row whose own entropy lies below its target (a -r rate no quantizer of that context can reach): every step of the
+    reference's walk (codebook.c:244-258) says "below" and it ends at the alphabet's size; the GPU path makes the designs A - 1
+    and A only. The oracle walks all 72 state counts as the reference does: same bytes, with the device's entropies and with
+    the host's libm, and the short cut must actually have been taken on these inputs."""
+    import re
+    monkeypatch.setenv("QVZ_CB_DEBUG", "1")
+    if how:
+        monkeypatch.setenv("QVZ_CB_LOG2", how)
+    rows, opts, cnt, d, refs = oracle_codebooks(name)
+    taken = 0
+    for j in range(opts["k"]):
+        capfd.readouterr()
+        cb, _ = K.generate_codebook(torch.from_numpy(cnt[j].view(np.int32)).cuda(), d, opts["mode"], opts["ratio"])
+        err = capfd.readouterr().err
+        assert_same_codebook(cb, refs[j])
+        m = re.search(r"walks known in advance \(row entropy below the target\): (\d+) contexts", err)
+        assert m, err[-400:]
+        taken += int(m.group(1))
+    assert taken > 0
+
+
 def test_device_tables_match_python_builder(K):
     from test_gpu_kernels import tables_from_codebooks
     rows, opts, cnt, d, refs = oracle_codebooks("t2k_c3_f05_M")
