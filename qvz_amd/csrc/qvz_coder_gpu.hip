@@ -1904,6 +1904,9 @@ static int encode_planes_impl(bool dry, const uint8_t *d_qi, const uint8_t *d_st
     if (getenv("QVZ_CODER_DEBUG"))
         fprintf(stderr, "qvz_hip_encode_planes: %u streams, longest %llu reads, %llu reads/segment, overlap %d, model waves %u, LDS %zu B, slice_cap %u words, total table words %zu\n",
                 shards, (unsigned long long)longest, (unsigned long long)seg_reads, (int)overlap, rk_waves, rk_lds, slice_cap, h_slices.size());
+    if (getenv("QVZ_CODER_DEBUG"))
+        for (size_t ci = 0; ci < rk_classes.size(); ++ci)
+            fprintf(stderr, "  model launch %zu: %u column groups, LDS %zu B, largest slice %u words\n", ci, rk_classes[ci].count, rk_classes[ci].lds, rk_classes[ci].cap);
     TRY(area.get((void **)&d_first, (shards + 1) * sizeof(uint64_t)));
     TRY(area.get((void **)&d_sizes, shards * sizeof(uint64_t)));
     TRY(area.get((void **)&d_status, sizeof(int32_t)));
