@@ -133,6 +133,27 @@ def test_walks_known_in_advance_give_the_oracles_codebook(K, name, how, monkeypa
     assert taken > 0
 
 
+@pytest.mark.parametrize("mode,target", [("ratio", 1.25), ("fixed", 5.5), ("fixed", 0.999999999)])
+def test_targets_no_row_can_reach(K, mode, target, monkeypatch, capfd):
+    """-f above 1 (every row's target lies above its own entropy), a -r rate beyond log2 of the alphabet in use, and a rate a
+    hair below 1 bit: the oracle walks state count by state count as the reference does (codebook.c:244-258), the GPU path
+    skips the walks it can prove; same codebook bytes."""
+    import re
+    monkeypatch.setenv("QVZ_CB_DEBUG", "1")
+    full = G.case_rows("t2k_r10_M")
+    rows = np.ascontiguousarray(np.concatenate([full[:, :12], full[:, -1:]], axis=1))   # twelve columns of the fixture's reads (+ the newline)
+    cnt = O.stats(rows, np.zeros(rows.shape[0], np.uint8), 1)
+    d = O.distortion("M")
+    m = O.MODE_RATIO if mode == "ratio" else O.MODE_FIXED
+    ref = O.generate_codebook(cnt[0], d, m, target)
+    capfd.readouterr()
+    cb, _ = K.generate_codebook(torch.from_numpy(cnt[0].view(np.int32)).cuda(), d, m, target)
+    err = capfd.readouterr().err
+    assert_same_codebook(cb, ref)
+    taken = int(re.search(r"walks known in advance \(row entropy below the target\): (\d+) contexts", err).group(1))
+    assert taken > 0 or target < 1.0
+
+
 def test_device_tables_match_python_builder(K):
     from test_gpu_kernels import tables_from_codebooks
     rows, opts, cnt, d, refs = oracle_codebooks("t2k_c3_f05_M")
