@@ -112,7 +112,14 @@ def stats_fields(stdout):
     return m.groups() if m else None
 
 
-@pytest.mark.parametrize("seed", range(58))
+# All 58 seeds with QVZ_TEST_ALL_SEEDS=1 (2.5 minutes; run at the end of round 5: all pass); by default the 26 that keep every kind
+# of case in the suite - every third of the general ones (those also write shard FILES for the reference's decoder; -v, the drop-in
+# binary, the two-part shard set and the decode direction take turns among them), one -D matrix of each kind, the long reads, five
+# and six clusters, the tiny inputs - so that the whole -m gpu suite stays near five minutes on a fresh box.
+SEEDS = list(range(58)) if os.environ.get("QVZ_TEST_ALL_SEEDS") else list(range(0, 36, 3)) + [36, 37, 38, 39] + list(range(48, 58))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_input_against_the_reference_binary(tmp_path, seed):
     rows, flags, k = make_case(seed)
     n, c = rows.shape[0], rows.shape[1] - 1
