@@ -1922,12 +1922,18 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     __syncthreads();
     // the symbols and draws of column s+1 are requested while column s is quantized: the workgroup moves in step
     // (one barrier per column), so an HBM latency left exposed here would be paid 150 times by every wave
-    const uint64_t io = active ? i0 : 0;
+    // Addresses: a base that is the same in every lane - the plane's column plus the workgroup's first read, scalar registers and
+    // scalar adds per column - and this thread's few KB into the workgroup's reads as a 32-bit offset, instead of a 64-bit vector
+    // add per access and column (14 of the loop's 190 vector instructions per eight symbols). Idle threads read the workgroup's
+    // first reads (a workgroup exists because its first read does).
+    const uint64_t wg0 = (uint64_t)blockIdx.x * T * R;           // first read of this workgroup
+    const uint32_t toff = active ? threadIdx.x * R : 0u;
+    const uint8_t *const Dw = D + wg0, *const drw = draws + wg0;
     uint32_t x4n[RW], d4n[RW];
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
-        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + io + 4 * w));
-        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + io + 4 * w));      // 7-bit draws, same layout
+        x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(Dw + toff + 4 * w));
+        d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(drw + toff + 4 * w));      // 7-bit draws, same layout
     }
     for (uint32_t s = 0; s < C; ++s) {
         const uint16_t *cur = reinterpret_cast<const uint16_t *>(tbuf + (NBUF == 2 ? (s & 1) * per_col4 : 0u));
@@ -1936,10 +1942,14 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
         for (int w = 0; w < RW; ++w) { x4[w] = x4n[w] & xmask[w]; d4[w] = d4n[w]; qv4[w] = qi4[w] = st4[w] = 0; }
         if (s + 1 < C) {
             fetch(s + 1);
+            // (held in scalar registers by the constraint: left alone the compiler turns every access into a 64-bit vector
+            // induction variable of its own)
+            const uint8_t *dcol = Dw + (uint64_t)(s + 1) * ld, *rcol = drw + (uint64_t)(s + 1) * ldd;
+            asm volatile("" : "+s"(dcol), "+s"(rcol));
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
-                x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(D + (uint64_t)(s + 1) * ld + io + 4 * w));
-                d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(draws + (uint64_t)(s + 1) * ldd + io + 4 * w));
+                x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(dcol + toff + 4 * w));
+                d4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(rcol + toff + 4 * w));
             }
         }
 #pragma unroll
@@ -1964,11 +1974,13 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
             st4[r >> 2] |= (qsv >> 8) << (8 * (r & 3));
         }
         if (active) {
+            uint8_t *qv_col = qv_out + wg0 + (uint64_t)s * ldo, *qi_col = qi_out + wg0 + (uint64_t)s * ldo, *st_col = st_out + wg0 + (uint64_t)s * ldo;
+            asm volatile("" : "+s"(qv_col), "+s"(qi_col), "+s"(st_col));
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
-                if (qv_out) *reinterpret_cast<uint32_t *>(qv_out + (uint64_t)s * ldo + i0 + 4 * w) = qv4[w];
-                if (qi_out) *reinterpret_cast<uint32_t *>(qi_out + (uint64_t)s * ldo + i0 + 4 * w) = qi4[w];
-                if (st_out) *reinterpret_cast<uint32_t *>(st_out + (uint64_t)s * ldo + i0 + 4 * w) = st4[w];
+                if (qv_out) *reinterpret_cast<uint32_t *>(qv_col + toff + 4 * w) = qv4[w];
+                if (qi_out) *reinterpret_cast<uint32_t *>(qi_col + toff + 4 * w) = qi4[w];
+                if (st_out) *reinterpret_cast<uint32_t *>(st_col + toff + 4 * w) = st4[w];
             }
         }
         if (s + 1 < C) {
