@@ -1944,8 +1944,11 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
             fetch(s + 1);
             // (held in scalar registers by the constraint: left alone the compiler turns every access into a 64-bit vector
             // induction variable of its own)
-            const uint8_t *dcol = Dw + (uint64_t)(s + 1) * ld, *rcol = drw + (uint64_t)(s + 1) * ldd;
-            asm volatile("" : "+s"(dcol), "+s"(rcol));
+            // (the OFFSETS pass through the constraint, not the pointers: a pointer out of an asm statement has lost its address
+            // space and is loaded from with flat instructions, which count on the LDS counter as well)
+            uint64_t doff = wg0 + (uint64_t)(s + 1) * ld, roff = wg0 + (uint64_t)(s + 1) * ldd;
+            asm volatile("" : "+s"(doff), "+s"(roff));
+            const uint8_t *dcol = D + doff, *rcol = draws + roff;
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
                 x4n[w] = QZ_LD(reinterpret_cast<const uint32_t *>(dcol + toff + 4 * w));
@@ -1974,13 +1977,24 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
             st4[r >> 2] |= (qsv >> 8) << (8 * (r & 3));
         }
         if (active) {
-            uint8_t *qv_col = qv_out + wg0 + (uint64_t)s * ldo, *qi_col = qi_out + wg0 + (uint64_t)s * ldo, *st_col = st_out + wg0 + (uint64_t)s * ldo;
-            asm volatile("" : "+s"(qv_col), "+s"(qi_col), "+s"(st_col));
+            uint64_t ooff = wg0 + (uint64_t)s * ldo;
+            asm volatile("" : "+s"(ooff));
+            uint8_t *qv_col = qv_out + ooff, *qi_col = qi_out + ooff, *st_col = st_out + ooff;
+            if (RW == 2) {                                       // a thread's eight reads of a column: one 8-byte store per plane
+                // (a caller's plane may begin at any multiple of four reads: the type promises dword alignment only)
+                typedef uint32_t qz_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+                qz_u32x2 a, b, c2;
+                a.x = qv4[0]; a.y = qv4[RW - 1]; b.x = qi4[0]; b.y = qi4[RW - 1]; c2.x = st4[0]; c2.y = st4[RW - 1];
+                if (qv_out) *reinterpret_cast<qz_u32x2 *>(qv_col + toff) = a;
+                if (qi_out) *reinterpret_cast<qz_u32x2 *>(qi_col + toff) = b;
+                if (st_out) *reinterpret_cast<qz_u32x2 *>(st_col + toff) = c2;
+            } else {
 #pragma unroll
-            for (int w = 0; w < RW; ++w) {
-                if (qv_out) *reinterpret_cast<uint32_t *>(qv_col + toff + 4 * w) = qv4[w];
-                if (qi_out) *reinterpret_cast<uint32_t *>(qi_col + toff + 4 * w) = qi4[w];
-                if (st_out) *reinterpret_cast<uint32_t *>(st_col + toff + 4 * w) = st4[w];
+                for (int w = 0; w < RW; ++w) {
+                    if (qv_out) *reinterpret_cast<uint32_t *>(qv_col + toff + 4 * w) = qv4[w];
+                    if (qi_out) *reinterpret_cast<uint32_t *>(qi_col + toff + 4 * w) = qi4[w];
+                    if (st_out) *reinterpret_cast<uint32_t *>(st_col + toff + 4 * w) = st4[w];
+                }
             }
         }
         if (s + 1 < C) {
