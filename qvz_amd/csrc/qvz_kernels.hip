@@ -1748,7 +1748,20 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
 // launched and the one that is not meant returns at once.
 #define QZ_ROUTE_LDS 1
 #define QZ_ROUTE_GENERAL 2
-__global__ __launch_bounds__(256) void k_quantize_route(const double *__restrict__ dist, int32_t *__restrict__ route, int lds_possible) {
+// route[1 + l * C + s] (k_quantize_lds reads it as route[2 + ...]): the quantizers column s of cluster l defines - two per context,
+// the contexts of a column are numbered from 0 (`ct`: context index | ratio << 8, QVZ_NOT_FOUND where the previous value is no
+// context) - so that a workgroup copies those rows of the column's 144 and no others (a -f codebook has a few dozen).
+__global__ __launch_bounds__(256) void k_quantize_route(const double *__restrict__ dist, int32_t *__restrict__ route, int lds_possible,
+                                                        const uint16_t *__restrict__ ct, uint32_t K, uint32_t C) {
+    if (lds_possible)
+        for (uint32_t e = threadIdx.x; e < K * C; e += 256) {
+            uint32_t nctx = 0;
+            for (uint32_t p = 0; p < QVZ_A; ++p) {
+                const uint32_t v = ct[(uint64_t)e * QVZ_CT_STRIDE + p] & 0xFFu;
+                if (v != QVZ_NOT_FOUND && v + 1 > nctx) nctx = v + 1;
+            }
+            route[1 + e] = (int32_t)(2 * (nctx > QVZ_A ? QVZ_A : nctx));
+        }
     __shared__ int general;
     if (threadIdx.x == 0) general = lds_possible ? 0 : 1;
     __syncthreads();
@@ -1892,12 +1905,31 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
     // VALU-bound: SQ counters in profiles/r03_sq_counters_cfg2.txt).
     typedef uint32_t qz_u32x4 __attribute__((ext_vector_type(4)));
     qz_u32x4 stg[NQ];
+    // Of a column's 144 quantizers only those of its contexts are ever looked at (two per context: k_quantize_route counted them):
+    // a wave whose part of the tables lies wholly behind them asks for nothing and parks nothing - whole waves, by a scalar branch,
+    // so that the loads stay unconditional for the lanes (with a -f codebook's few dozen contexts that is half of a workgroup's
+    // copy and more: 10 bytes of L2 traffic per symbol, three loads and three LDS stores per thread and column before).
+    // (The 1024-thread instantiation of three clusters copies everything: it has no registers left for this - four spilled -, and
+    // with the -r targets it is measured on every context of every column exists: 22.3 -> 24.6 ms with the test in it.)
+    constexpr bool PARTIAL = NBUF == 2;
+    uint32_t loaded = PARTIAL ? 0u : ~0u;                       // bit q: this wave holds a piece of the column in stg[q] (wave-uniform)
     auto fetch = [&](uint32_t s) {
+        uint32_t rows[3] = {~0u, ~0u, ~0u};                     // uint4 of a cluster's tables that are in use: ct, pad, the quantizers' rows
+        if (PARTIAL) {
+#pragma unroll
+            for (uint32_t l = 0; l < 3; ++l) rows[l] = l < K ? 10u + 9u * (uint32_t)route[2 + l * C + s] : 0u;
+            loaded = 0;
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint32_t i = threadIdx.x + q * T;
             const uint32_t ii = i < per_col4 ? i : 0u;          // threads past the column's tables load entry 0 and park nothing
             const uint32_t l = ii / QZ_CLUSTER4, j = ii % QZ_CLUSTER4;
+            if (PARTIAL) {
+                const bool need = i < per_col4 && j < (l == 0 ? rows[0] : l == 1 ? rows[1] : rows[2]);
+                if (__ballot(need) == 0) continue;              // (the same in every lane of the wave)
+                loaded |= 1u << q;
+            }
             const uint64_t cs = (uint64_t)l * C + s;
             const uint4 *pct = reinterpret_cast<const uint4 *>(ct + cs * QVZ_CT_STRIDE);
             const uint4 *pqs = reinterpret_cast<const uint4 *>(qs + cs * QVZ_QS_STRIDE);
@@ -1914,6 +1946,7 @@ __global__ __launch_bounds__(T) void k_quantize_lds(const uint8_t *__restrict__ 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint32_t i = threadIdx.x + q * T;
+            if (PARTIAL && !((loaded >> q) & 1u)) continue;     // (wave-uniform)
             if (i < per_col4) dst[i] = make_uint4(stg[q].x, stg[q].y, stg[q].z, stg[q].w);
         }
     };
@@ -2043,7 +2076,7 @@ static int quantize_launch(const QvzQuantArgs &a, int32_t *d_route, hipStream_t 
     const char *force = getenv("QVZ_QUANTIZE_KERNEL");           // test hook: "global" keeps the tables in L1/L2 (the kernel of more than three clusters)
     const bool lds_possible = k <= 3 && !(force && strcmp(force, "global") == 0);
     // [0] mirrors nothing (the kernels write the caller's d_status); [1] = route of this call
-    hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, stream, a.d_dist, d_route + 1, lds_possible ? 1 : 0);
+    hipLaunchKernelGGL(k_quantize_route, dim3(1), dim3(256), 0, stream, a.d_dist, d_route + 1, lds_possible ? 1 : 0, a.d_ct, a.k, a.c);
     QVZ_HIP_CHECK(hipGetLastError());
     if (lds_possible) {
         // dwords (4 reads each) per thread: 8 reads = 8 independent chains (22.6 -> 20.4 ms at 100M x 150 with one cluster)
@@ -2085,7 +2118,7 @@ extern "C" int qvz_hip_quantize(const uint8_t *d_sym, const uint8_t *d_labels, u
     // the route word lives behind the caller's status word in this device's scratch pair (stream-ordered like the rest of it)
     ScratchLock lk((hipStream_t)stream);
     if (lk.rc) return lk.rc;
-    if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, 2 * sizeof(int32_t)));
+    if (!lk.d->d_route) QVZ_HIP_CHECK(hipMalloc(&lk.d->d_route, (2 + 3 * 1024) * sizeof(int32_t)));   // route word + the quantizer counts of up to 3 x 1022 columns
     return quantize_launch(a, lk.d->d_route, (hipStream_t)stream);
 }
 
