@@ -1753,15 +1753,17 @@ extern "C" int qvz_hip_well_draws(const uint32_t *h_state, uint64_t first_read, 
 // context) - so that a workgroup copies those rows of the column's 144 and no others (a -f codebook has a few dozen).
 __global__ __launch_bounds__(256) void k_quantize_route(const double *__restrict__ dist, int32_t *__restrict__ route, int lds_possible,
                                                         const uint16_t *__restrict__ ct, uint32_t K, uint32_t C) {
-    if (lds_possible)
-        for (uint32_t e = threadIdx.x; e < K * C; e += 256) {
-            uint32_t nctx = 0;
-            for (uint32_t p = 0; p < QVZ_A; ++p) {
-                const uint32_t v = ct[(uint64_t)e * QVZ_CT_STRIDE + p] & 0xFFu;
-                if (v != QVZ_NOT_FOUND && v + 1 > nctx) nctx = v + 1;
-            }
-            route[1 + e] = (int32_t)(2 * (nctx > QVZ_A ? QVZ_A : nctx));
+    __shared__ uint32_t nctx[3 * 1024];                         // (the LDS kernel serves three clusters at most, a read 1022 columns)
+    if (lds_possible && K * C <= 3 * 1024) {
+        for (uint32_t e = threadIdx.x; e < K * C; e += 256) nctx[e] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < K * C * QVZ_CT_STRIDE; i += 256) {     // consecutive threads, consecutive entries
+            const uint32_t v = ct[i] & 0xFFu;
+            if (v != QVZ_NOT_FOUND) atomicMax(&nctx[i / QVZ_CT_STRIDE], v + 1);
         }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < K * C; e += 256) route[1 + e] = (int32_t)(2 * (nctx[e] > QVZ_A ? QVZ_A : nctx[e]));
+    }
     __shared__ int general;
     if (threadIdx.x == 0) general = lds_possible ? 0 : 1;
     __syncthreads();
